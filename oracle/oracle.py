@@ -1,0 +1,637 @@
+"""TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
+
+Python front-end of the CPU oracle (``oracle/boxtree_oracle.c``): a restatement
+of inducer/boxtree's ``TreeBuilder.__call__`` (boxtree/tree_build.py:145-1878)
+and ``FMMTraversalBuilder.__call__`` (boxtree/traversal.py:1969-2345).
+
+PARITY UNPINNED: the reference cannot be imported here (pyopencl, arraycontext,
+pytools, mako are absent, no OpenCL device) and its tests hold no golden
+vectors; this restatement is validated against the invariants the reference's
+tests assert (tests/test_oracle_invariants.py).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.  The host-side numpy arithmetic (root box, argument
+checks) below mirrors tree_build.py:223-510 line by line and is deliberately NOT
+shared with the product package.
+"""
+
+from __future__ import annotations
+
+import ctypes as ct
+import os
+import subprocess
+from types import SimpleNamespace
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MAXDIM = 3
+AXIS_NAMES = ("x", "y", "z")
+ROOT_EXTENT_STRETCH_FACTOR = 1e-4      # tree_build.py:101
+
+
+class MaxLevelsExceeded(RuntimeError):   # tree_build.py:79
+    pass
+
+
+def build_lib(force=False):
+    """Compile liboracle.so with gcc (a few seconds)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in (
+        "boxtree_oracle.c", "boxtree_oracle_impl.h", "boxtree_oracle_trav_impl.h")]
+    if (force or not os.path.exists(so)
+            or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so", "-B"])
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ct.CDLL(build_lib())
+        _LIB.orc_free.argtypes = [ct.c_void_p]
+        _LIB.orc_free.restype = None
+    return _LIB
+
+
+def _ctype(dtype):
+    return ct.c_double if np.dtype(dtype) == np.float64 else ct.c_float
+
+
+def _sfx(dtype):
+    return "_f64" if np.dtype(dtype) == np.float64 else "_f32"
+
+
+def _make_structs(cf):
+    P = ct.POINTER
+
+    class TreeIn(ct.Structure):
+        _fields_ = [
+            ("dims", ct.c_int32), ("sources_are_targets", ct.c_int32),
+            ("nsrcntgts", ct.c_int64), ("nsources", ct.c_int64),
+            ("srcntgts", P(cf) * MAXDIM), ("srcntgt_radii", P(cf)),
+            ("sources_have_extent", ct.c_int32), ("targets_have_extent", ct.c_int32),
+            ("refine_weights", P(ct.c_int32)), ("max_leaf_refine_weight", ct.c_int32),
+            ("bbox_min", cf * MAXDIM), ("bbox_max", cf * MAXDIM),
+            ("root_extent", cf), ("stick_out_factor", cf),
+            ("extent_norm", ct.c_int32), ("kind", ct.c_int32),
+            ("skip_prune", ct.c_int32), ("nlevels_max", ct.c_int32),
+        ]
+
+    class TreeOut(ct.Structure):
+        _fields_ = [
+            ("status", ct.c_int32), ("nlevels", ct.c_int32),
+            ("nboxes", ct.c_int64), ("aligned_nboxes", ct.c_int64),
+            ("level_start_box_nrs", P(ct.c_int32)),
+            ("user_source_ids", P(ct.c_int32)), ("sorted_target_ids", P(ct.c_int32)),
+            ("sources", P(cf) * MAXDIM), ("targets", P(cf) * MAXDIM),
+            ("source_radii", P(cf)), ("target_radii", P(cf)),
+            ("box_source_starts", P(ct.c_int32)),
+            ("box_source_counts_nonchild", P(ct.c_int32)),
+            ("box_source_counts_cumul", P(ct.c_int32)),
+            ("box_target_starts", P(ct.c_int32)),
+            ("box_target_counts_nonchild", P(ct.c_int32)),
+            ("box_target_counts_cumul", P(ct.c_int32)),
+            ("box_parent_ids", P(ct.c_int32)), ("box_child_ids", P(ct.c_int32)),
+            ("box_centers", P(cf)), ("box_levels", P(ct.c_uint8)),
+            ("box_flags", P(ct.c_uint8)),
+            ("box_source_bounding_box_min", P(cf)), ("box_source_bounding_box_max", P(cf)),
+            ("box_target_bounding_box_min", P(cf)), ("box_target_bounding_box_max", P(cf)),
+        ]
+
+    class BuiltListC(ct.Structure):
+        _fields_ = [
+            ("n_objects", ct.c_int64), ("count", ct.c_int64),
+            ("starts", P(ct.c_int32)), ("lists", P(ct.c_int32)),
+            ("num_nonempty_lists", ct.c_int64),
+            ("nonempty_indices", P(ct.c_int32)), ("compressed_indices", P(ct.c_int32)),
+        ]
+
+    class TravIn(ct.Structure):
+        _fields_ = [
+            ("dims", ct.c_int32), ("nlevels", ct.c_int32),
+            ("nboxes", ct.c_int64), ("aligned_nboxes", ct.c_int64),
+            ("root_extent", cf),
+            ("box_centers", P(cf)), ("box_levels", P(ct.c_uint8)),
+            ("box_child_ids", P(ct.c_int32)), ("box_flags", P(ct.c_uint8)),
+            ("box_parent_ids", P(ct.c_int32)), ("level_start_box_nrs", P(ct.c_int32)),
+            ("sources_are_targets", ct.c_int32),
+            ("sources_have_extent", ct.c_int32), ("targets_have_extent", ct.c_int32),
+            ("stick_out_factor", cf),
+            ("box_target_bounding_box_min", P(cf)), ("box_target_bounding_box_max", P(cf)),
+            ("box_source_counts_cumul", P(ct.c_int32)),
+            ("well_sep_is_n_away", ct.c_int32), ("from_sep_smaller_crit", ct.c_int32),
+            ("from_sep_smaller_min_nsources_cumul", ct.c_int32),
+            ("source_boxes_mask", P(ct.c_int8)), ("source_parent_boxes_mask", P(ct.c_int8)),
+        ]
+
+    class TravOut(ct.Structure):
+        _fields_ = [
+            ("status", ct.c_int32),
+            ("nsource_boxes", ct.c_int64), ("ntarget_boxes", ct.c_int64),
+            ("nsource_parent_boxes", ct.c_int64),
+            ("ntarget_or_target_parent_boxes", ct.c_int64),
+            ("source_boxes", P(ct.c_int32)), ("target_boxes", P(ct.c_int32)),
+            ("source_parent_boxes", P(ct.c_int32)),
+            ("target_or_target_parent_boxes", P(ct.c_int32)),
+            ("level_start_source_box_nrs", P(ct.c_int32)),
+            ("level_start_target_box_nrs", P(ct.c_int32)),
+            ("level_start_source_parent_box_nrs", P(ct.c_int32)),
+            ("level_start_target_or_target_parent_box_nrs", P(ct.c_int32)),
+            ("same_level_non_well_sep_boxes", BuiltListC),
+            ("neighbor_source_boxes", BuiltListC),
+            ("from_sep_siblings", BuiltListC),
+            ("from_sep_smaller_by_level", P(BuiltListC)),
+            ("from_sep_close_smaller", BuiltListC),
+            ("from_sep_bigger", BuiltListC),
+            ("from_sep_close_bigger", BuiltListC),
+        ]
+
+    return SimpleNamespace(TreeIn=TreeIn, TreeOut=TreeOut, BuiltListC=BuiltListC,
+                           TravIn=TravIn, TravOut=TravOut)
+
+
+_STRUCTS = {}
+
+
+def _structs(dtype):
+    key = np.dtype(dtype).str
+    if key not in _STRUCTS:
+        _STRUCTS[key] = _make_structs(_ctype(dtype))
+    return _STRUCTS[key]
+
+
+def _take(ptr, n, dtype, free=True):
+    """Copy n elements out of a malloc'd C array and free it."""
+    n = int(n)
+    if not ptr:
+        return None
+    if n == 0:
+        arr = np.zeros(0, dtype)
+    else:
+        arr = np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+    if free:
+        _lib().orc_free(ct.cast(ptr, ct.c_void_p))
+    return arr
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(ct.POINTER(ctype))
+
+
+# {{{ bounding box
+
+def bounding_box(particles, radii=None):
+    """boxtree/bounding_box.py:163-174 -> (mins, maxs) arrays of coord dtype."""
+    dims = len(particles)
+    dtype = particles[0].dtype
+    cf = _ctype(dtype)
+    particles = [np.ascontiguousarray(p) for p in particles]
+    n = len(particles[0])
+    arr = (ct.POINTER(cf) * dims)(*[_ptr(p, cf) for p in particles])
+    mn = np.empty(dims, dtype)
+    mx = np.empty(dims, dtype)
+    fn = getattr(_lib(), "orc_bbox" + _sfx(dtype))
+    fn.restype = None
+    r = None if radii is None else _ptr(np.ascontiguousarray(radii), cf)
+    fn(ct.c_int(dims), ct.c_int64(n), arr, r, _ptr(mn, cf), _ptr(mx, cf))
+    return mn, mx
+
+# }}}
+
+
+# {{{ tree build
+
+_KINDS = {"adaptive": 0, "non-adaptive": 2}
+_NORMS = {None: 0, "linf": 1, "l2": 2}
+
+
+def build_tree(particles, kind="adaptive", max_particles_in_box=None,
+               targets=None, source_radii=None, target_radii=None,
+               stick_out_factor=None, refine_weights=None,
+               max_leaf_refine_weight=None, extent_norm=None, bbox=None,
+               **kwargs):
+    """Restatement of TreeBuilder.__call__ (tree_build.py:145-1878).
+
+    Returns a namespace with the attribute names of :class:`boxtree.Tree`
+    (tree.py:298-686), all numpy.
+    """
+    # {{{ input processing: tree_build.py:223-295
+    if kind not in ["adaptive", "adaptive-level-restricted", "non-adaptive"]:
+        raise ValueError(f"unknown tree kind: '{kind}'")
+    if kind == "adaptive-level-restricted":
+        raise NotImplementedError("oracle: level-restricted trees not restated")
+
+    dimensions = len(particles)
+    axis_names = AXIS_NAMES[:dimensions]
+    sources_are_targets = targets is None
+    sources_have_extent = source_radii is not None
+    targets_have_extent = target_radii is not None
+
+    if extent_norm is None:
+        extent_norm = "linf"
+    if extent_norm not in ["linf", "l2"]:
+        raise ValueError(f"unexpected value of 'extent_norm': {extent_norm}")
+    srcntgts_extent_norm = extent_norm
+    srcntgts_have_extent = sources_have_extent or targets_have_extent
+    if not srcntgts_have_extent:
+        srcntgts_extent_norm = None
+    if srcntgts_extent_norm and targets is None:
+        raise ValueError("must specify targets when specifying any kind of radii")
+
+    particles = [np.ascontiguousarray(p) for p in particles]
+    coord_dtype = particles[0].dtype
+    assert all(p.dtype == coord_dtype for p in particles)
+    if targets is None:
+        nsrcntgts = nsources = len(particles[0])
+        ntargets = nsources
+    else:
+        targets = [np.ascontiguousarray(t) for t in targets]
+        nsources = len(particles[0])
+        ntargets = len(targets[0])
+        nsrcntgts = nsources + ntargets
+
+    if source_radii is not None:
+        if source_radii.shape != (nsources,):
+            raise ValueError("'source_radii' has an invalid shape")
+        if source_radii.dtype != coord_dtype:
+            raise TypeError("dtypes of 'particles' and 'source_radii' must agree")
+    if target_radii is not None:
+        if target_radii.shape != (ntargets,):
+            raise ValueError("'target_radii' has an invalid shape")
+        if target_radii.dtype != coord_dtype:
+            raise TypeError("dtypes of 'particles' and 'target_radii' must agree")
+
+    if sources_have_extent or targets_have_extent:
+        if stick_out_factor is None:
+            raise ValueError("if sources or targets have extent, "
+                             "'stick_out_factor' must be explicitly specified")
+    else:
+        stick_out_factor = 0
+    # }}}
+
+    # {{{ combine sources and targets: tree_build.py:328-388
+    if targets is None:
+        srcntgts = particles
+        srcntgt_radii = None
+    else:
+        if targets[0].dtype != coord_dtype:
+            raise TypeError("sources and targets coordinates must have same dtype")
+
+        def combine(a1, a2):
+            result = np.zeros(nsrcntgts, coord_dtype)
+            if a1 is not None:
+                result[:len(a1)] = a1
+            if a2 is not None:
+                result[nsources:] = a2
+            return result
+
+        srcntgts = [combine(s, t) for s, t in zip(particles, targets)]
+        srcntgt_radii = (combine(source_radii, target_radii)
+                         if srcntgts_have_extent else None)
+    # }}}
+
+    # {{{ refine weights: tree_build.py:405-454
+    specified_mpb = max_particles_in_box is not None
+    specified_rw = refine_weights is not None and max_leaf_refine_weight is not None
+    if specified_mpb and specified_rw:
+        raise ValueError("may only specify one of 'max_particles_in_box' and "
+                         "'refine_weights'/'max_leaf_refine_weight")
+    elif not specified_mpb and not specified_rw:
+        raise ValueError("must specify either 'max_particles_in_box' or "
+                         "'refine_weights'/'max_leaf_refine_weight'")
+    elif specified_mpb:
+        refine_weights = np.ones(nsrcntgts, np.int32)
+        max_leaf_refine_weight = max_particles_in_box
+    else:
+        if refine_weights.dtype != np.int32:
+            raise TypeError("'refine_weights' must have dtype 'int32'")
+    if max_leaf_refine_weight <= 0:
+        raise ValueError("'max_leaf_refine_weight' must be positive")
+    if nsrcntgts and max_leaf_refine_weight < np.max(refine_weights):
+        raise ValueError(
+            "entries of 'refine_weights' cannot exceed 'max_leaf_refine_weight'")
+    if nsrcntgts and np.min(refine_weights) < 0:
+        raise ValueError("all entries of 'refine_weights' must be nonnegative")
+    refine_weights = np.ascontiguousarray(refine_weights)
+    # }}}
+
+    # {{{ bounding box: tree_build.py:456-510
+    auto_min, auto_max = bounding_box(srcntgts, srcntgt_radii)
+    if bbox is None:
+        root_extent = max(
+            auto_max[i] - auto_min[i] for i in range(dimensions)
+        ) * (1 + ROOT_EXTENT_STRETCH_FACTOR)
+        bbox_min = np.empty(dimensions, coord_dtype)
+        for i in range(dimensions):
+            bbox_min[i] = auto_min[i]
+        bbox_max = bbox_min + root_extent
+        # the bbox struct stores coord_dtype values (:475-476)
+        bbox_struct_min = bbox_min.copy()
+        bbox_struct_max = bbox_max.astype(coord_dtype)
+    else:
+        bbox = np.asarray(bbox)
+        assert len(bbox) == dimensions
+        bbox_min = np.empty(dimensions, coord_dtype)
+        bbox_max = np.empty(dimensions, coord_dtype)
+        for i in range(dimensions):
+            bbox_min[i] = bbox[i][0]
+            bbox_max[i] = bbox[i][1]
+            assert bbox_min[i] < bbox_max[i]
+            assert bbox_min[i] <= auto_min[i]
+            assert bbox_max[i] >= auto_max[i]
+        bbox_exts = bbox_max - bbox_min
+        for ext in bbox_exts:
+            assert abs(ext - bbox_exts[0]) < 1e-15
+        root_extent = bbox_exts[0]
+        bbox_struct_min = bbox_min.copy()
+        bbox_struct_max = bbox_max.copy()
+    # }}}
+
+    S = _structs(coord_dtype)
+    cf = _ctype(coord_dtype)
+    tin = S.TreeIn()
+    tin.dims = dimensions
+    tin.sources_are_targets = int(sources_are_targets)
+    tin.nsrcntgts = nsrcntgts
+    tin.nsources = nsources
+    for i in range(dimensions):
+        tin.srcntgts[i] = _ptr(srcntgts[i], cf)
+    if srcntgt_radii is not None:
+        tin.srcntgt_radii = _ptr(srcntgt_radii, cf)
+    tin.sources_have_extent = int(sources_have_extent)
+    tin.targets_have_extent = int(targets_have_extent)
+    tin.refine_weights = _ptr(refine_weights, ct.c_int32)
+    tin.max_leaf_refine_weight = int(max_leaf_refine_weight)
+    for i in range(dimensions):
+        tin.bbox_min[i] = bbox_struct_min[i]
+        tin.bbox_max[i] = bbox_struct_max[i]
+    tin.root_extent = float(coord_dtype.type(root_extent))
+    tin.stick_out_factor = float(coord_dtype.type(stick_out_factor))
+    tin.extent_norm = _NORMS[srcntgts_extent_norm]
+    tin.kind = _KINDS[kind]
+    tin.skip_prune = int(bool(kwargs.get("skip_prune")))
+    tin.nlevels_max = 2 * (np.finfo(coord_dtype).nmant + 1)   # :622
+
+    tout = S.TreeOut()
+    fn = getattr(_lib(), "orc_tree_build" + _sfx(coord_dtype))
+    fn.restype = ct.c_int
+    status = fn(ct.byref(tin), ct.byref(tout))
+    if status == 1:
+        raise MaxLevelsExceeded("Level count exceeded number of significant "
+                                "bits in coordinate dtype.")
+    if status != 0:
+        raise RuntimeError(f"oracle tree build failed with status {status}")
+
+    nboxes = int(tout.nboxes)
+    aligned = int(tout.aligned_nboxes)
+    nlevels = int(tout.nlevels)
+    C = 2 ** dimensions
+    i32 = np.int32
+
+    t = SimpleNamespace()
+    t.sources_are_targets = sources_are_targets
+    t.sources_have_extent = sources_have_extent
+    t.targets_have_extent = targets_have_extent
+    t.particle_id_dtype = np.dtype(np.int32)
+    t.box_id_dtype = np.dtype(np.int32)
+    t.coord_dtype = coord_dtype
+    t.box_level_dtype = np.dtype(np.uint8)
+    t.bounding_box = (bbox_min, bbox_max)
+    t.root_extent = root_extent
+    t.stick_out_factor = stick_out_factor
+    t.extent_norm = srcntgts_extent_norm
+    t.level_start_box_nrs = _take(tout.level_start_box_nrs, nlevels + 1, i32)
+    t.user_source_ids = _take(tout.user_source_ids, nsources, i32)
+    t.sorted_target_ids = _take(tout.sorted_target_ids, ntargets, i32)
+    t.sources = [_take(tout.sources[d], nsources, coord_dtype, free=True)
+                 for d in range(dimensions)]
+    if sources_are_targets:
+        t.targets = t.sources
+    else:
+        t.targets = [_take(tout.targets[d], ntargets, coord_dtype)
+                     for d in range(dimensions)]
+    t.source_radii = _take(tout.source_radii, nsources, coord_dtype)
+    t.target_radii = _take(tout.target_radii, ntargets, coord_dtype)
+    if not sources_have_extent:
+        t.source_radii = None
+    if not targets_have_extent:
+        t.target_radii = None
+    t.box_source_starts = _take(tout.box_source_starts, nboxes, i32)
+    t.box_source_counts_nonchild = _take(tout.box_source_counts_nonchild, nboxes, i32)
+    t.box_source_counts_cumul = _take(tout.box_source_counts_cumul, nboxes, i32)
+    if sources_are_targets:
+        t.box_target_starts = t.box_source_starts
+        t.box_target_counts_nonchild = t.box_source_counts_nonchild
+        t.box_target_counts_cumul = t.box_source_counts_cumul
+    else:
+        t.box_target_starts = _take(tout.box_target_starts, nboxes, i32)
+        t.box_target_counts_nonchild = _take(tout.box_target_counts_nonchild, nboxes, i32)
+        t.box_target_counts_cumul = _take(tout.box_target_counts_cumul, nboxes, i32)
+    t.box_parent_ids = _take(tout.box_parent_ids, nboxes, i32)
+    t.box_child_ids = _take(tout.box_child_ids, C * aligned, i32).reshape(C, aligned)
+    t.box_centers = _take(tout.box_centers, dimensions * aligned,
+                          coord_dtype).reshape(dimensions, aligned)
+    t.box_levels = _take(tout.box_levels, nboxes, np.uint8)
+    t.box_flags = _take(tout.box_flags, nboxes, np.uint8)
+    t.box_source_bounding_box_min = _take(
+        tout.box_source_bounding_box_min, dimensions * aligned,
+        coord_dtype).reshape(dimensions, aligned)
+    t.box_source_bounding_box_max = _take(
+        tout.box_source_bounding_box_max, dimensions * aligned,
+        coord_dtype).reshape(dimensions, aligned)
+    if sources_are_targets:
+        t.box_target_bounding_box_min = t.box_source_bounding_box_min
+        t.box_target_bounding_box_max = t.box_source_bounding_box_max
+    else:
+        t.box_target_bounding_box_min = _take(
+            tout.box_target_bounding_box_min, dimensions * aligned,
+            coord_dtype).reshape(dimensions, aligned)
+        t.box_target_bounding_box_max = _take(
+            tout.box_target_bounding_box_max, dimensions * aligned,
+            coord_dtype).reshape(dimensions, aligned)
+    t._is_pruned = not kwargs.get("skip_prune")
+
+    t.dimensions = dimensions
+    t.nboxes = nboxes
+    t.aligned_nboxes = aligned
+    t.nlevels = nlevels
+    t.nsources = nsources
+    t.ntargets = ntargets
+    return t
+
+# }}}
+
+
+# {{{ traversal
+
+_CRITS = {"static_linf": 0, "precise_linf": 1, "static_l2": 2}
+
+
+def _built_list(bl, free=True):
+    n_objects = int(bl.n_objects)
+    count = int(bl.count)
+    nne = int(bl.num_nonempty_lists)
+    r = SimpleNamespace()
+    r.count = count
+    r.lists = _take(bl.lists, count, np.int32, free)
+    if nne < 0:
+        r.starts = _take(bl.starts, n_objects + 1, np.int32, free)
+        r.num_nonempty_lists = None
+        r.nonempty_indices = None
+        r.compressed_indices = None
+    else:
+        r.starts = _take(bl.starts, nne + 1, np.int32, free)
+        r.num_nonempty_lists = nne
+        r.nonempty_indices = _take(bl.nonempty_indices, nne, np.int32, free)
+        r.compressed_indices = _take(bl.compressed_indices, n_objects + 1,
+                                     np.int32, free)
+    return r
+
+
+def build_traversal(tree, well_sep_is_n_away=1, from_sep_smaller_crit=None,
+                    _from_sep_smaller_min_nsources_cumul=None,
+                    source_boxes_mask=None, source_parent_boxes_mask=None):
+    """Restatement of FMMTraversalBuilder.__call__ (traversal.py:1969-2345)."""
+    if _from_sep_smaller_min_nsources_cumul is None:
+        _from_sep_smaller_min_nsources_cumul = 0          # :1995-1997
+    if not tree._is_pruned:
+        raise ValueError("tree must be pruned for traversal generation")
+    if tree.sources_have_extent:
+        raise NotImplementedError("trees with source extent are not supported "
+                                  "for traversal generation")
+    # :1776-1805
+    if from_sep_smaller_crit is None:
+        from_sep_smaller_crit = "precise_linf"
+    extent_norm = tree.extent_norm
+    if extent_norm == "l2" and from_sep_smaller_crit == "static_linf":
+        raise ValueError("the static l^inf from-sep-smaller criterion "
+                         "cannot be used with the l^2 extent norm")
+    if extent_norm not in ("linf", "l2", None):
+        raise ValueError(f"unexpected value of 'extent_norm': {extent_norm}")
+    if from_sep_smaller_crit not in _CRITS:
+        raise ValueError("unexpected value of 'from_sep_smaller_crit': "
+                         f"{from_sep_smaller_crit}")
+
+    coord_dtype = np.dtype(tree.coord_dtype)
+    S = _structs(coord_dtype)
+    cf = _ctype(coord_dtype)
+    dims = tree.dimensions
+    nlevels = int(tree.nlevels)
+
+    keep = []
+
+    def c(arr, dtype):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        keep.append(a)
+        return a
+
+    tin = S.TravIn()
+    tin.dims = dims
+    tin.nlevels = nlevels
+    tin.nboxes = tree.nboxes
+    tin.aligned_nboxes = tree.aligned_nboxes
+    tin.root_extent = float(coord_dtype.type(tree.root_extent))
+    tin.box_centers = _ptr(c(tree.box_centers, coord_dtype), cf)
+    tin.box_levels = _ptr(c(tree.box_levels, np.uint8), ct.c_uint8)
+    tin.box_child_ids = _ptr(c(tree.box_child_ids, np.int32), ct.c_int32)
+    tin.box_flags = _ptr(c(tree.box_flags, np.uint8), ct.c_uint8)
+    tin.box_parent_ids = _ptr(c(tree.box_parent_ids, np.int32), ct.c_int32)
+    tin.level_start_box_nrs = _ptr(c(tree.level_start_box_nrs, np.int32), ct.c_int32)
+    tin.sources_are_targets = int(getattr(tree, "sources_are_targets", True))
+    tin.sources_have_extent = int(tree.sources_have_extent)
+    tin.targets_have_extent = int(tree.targets_have_extent)
+    tin.stick_out_factor = float(coord_dtype.type(tree.stick_out_factor))
+    if tree.targets_have_extent:
+        tin.box_target_bounding_box_min = _ptr(
+            c(tree.box_target_bounding_box_min, coord_dtype), cf)
+        tin.box_target_bounding_box_max = _ptr(
+            c(tree.box_target_bounding_box_max, coord_dtype), cf)
+        tin.box_source_counts_cumul = _ptr(
+            c(tree.box_source_counts_cumul, np.int32), ct.c_int32)
+    tin.well_sep_is_n_away = int(well_sep_is_n_away)
+    tin.from_sep_smaller_crit = _CRITS[from_sep_smaller_crit]
+    tin.from_sep_smaller_min_nsources_cumul = int(_from_sep_smaller_min_nsources_cumul)
+    if source_boxes_mask is not None:
+        tin.source_boxes_mask = _ptr(c(source_boxes_mask, np.int8), ct.c_int8)
+    if source_parent_boxes_mask is not None:
+        tin.source_parent_boxes_mask = _ptr(
+            c(source_parent_boxes_mask, np.int8), ct.c_int8)
+
+    tout = S.TravOut()
+    fn = getattr(_lib(), "orc_trav_build" + _sfx(coord_dtype))
+    fn.restype = ct.c_int
+    status = fn(ct.byref(tin), ct.byref(tout))
+    if status != 0:
+        raise RuntimeError(f"oracle traversal failed with status {status}")
+
+    i32 = np.int32
+    r = SimpleNamespace()
+    r.tree = tree
+    r.well_sep_is_n_away = well_sep_is_n_away
+    sat = bool(tin.sources_are_targets)
+    r.source_boxes = _take(tout.source_boxes, tout.nsource_boxes, i32)
+    if sat:
+        r.target_boxes = r.source_boxes
+    else:
+        r.target_boxes = _take(tout.target_boxes, tout.ntarget_boxes, i32)
+    r.source_parent_boxes = _take(tout.source_parent_boxes,
+                                  tout.nsource_parent_boxes, i32)
+    r.target_or_target_parent_boxes = _take(
+        tout.target_or_target_parent_boxes,
+        tout.ntarget_or_target_parent_boxes, i32)
+    for name in ("level_start_source_box_nrs", "level_start_target_box_nrs",
+                 "level_start_source_parent_box_nrs",
+                 "level_start_target_or_target_parent_box_nrs"):
+        setattr(r, name, _take(getattr(tout, name), nlevels + 1, i32))
+
+    slnws = _built_list(tout.same_level_non_well_sep_boxes)
+    r.same_level_non_well_sep_boxes_starts = slnws.starts
+    r.same_level_non_well_sep_boxes_lists = slnws.lists
+    l1 = _built_list(tout.neighbor_source_boxes)
+    r.neighbor_source_boxes_starts = l1.starts
+    r.neighbor_source_boxes_lists = l1.lists
+    l2 = _built_list(tout.from_sep_siblings)
+    r.from_sep_siblings_starts = l2.starts
+    r.from_sep_siblings_lists = l2.lists
+
+    r.from_sep_smaller_by_level = []
+    r.target_boxes_sep_smaller_by_source_level = []
+    for ilev in range(nlevels):
+        bl = _built_list(tout.from_sep_smaller_by_level[ilev])
+        r.from_sep_smaller_by_level.append(bl)
+        r.target_boxes_sep_smaller_by_source_level.append(
+            r.target_boxes[bl.nonempty_indices])         # :2211-2212
+    _lib().orc_free(ct.cast(tout.from_sep_smaller_by_level, ct.c_void_p))
+
+    with_extent = tree.sources_have_extent or tree.targets_have_extent
+    if with_extent:
+        cs = _built_list(tout.from_sep_close_smaller)
+        r.from_sep_close_smaller_starts = cs.starts
+        r.from_sep_close_smaller_lists = cs.lists
+    else:
+        r.from_sep_close_smaller_starts = None
+        r.from_sep_close_smaller_lists = None
+
+    l4 = _built_list(tout.from_sep_bigger)
+    r.from_sep_bigger_starts = l4.starts
+    r.from_sep_bigger_lists = l4.lists
+    if with_extent:
+        cb = _built_list(tout.from_sep_close_bigger)
+        r.from_sep_close_bigger_starts = cb.starts
+        r.from_sep_close_bigger_lists = cb.lists
+    else:
+        r.from_sep_close_bigger_starts = None
+        r.from_sep_close_bigger_lists = None
+
+    r.nboxes = tree.nboxes
+    r.nlevels = nlevels
+    r.ntarget_boxes = len(r.target_boxes)
+    r.ntarget_or_target_parent_boxes = len(r.target_or_target_parent_boxes)
+    return r
+
+# }}}
+
+# vim: foldmethod=marker
