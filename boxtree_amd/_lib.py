@@ -1,0 +1,193 @@
+"""ctypes binding of ``libboxtree_hip.so`` (C ABI in ``include/boxtree_hip.h``).
+
+The product path has no CPU fallback: if the HIP library is missing or does not
+load, importing a builder raises immediately.
+"""
+
+from __future__ import annotations
+
+import ctypes as ct
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libboxtree_hip.so")
+
+BT_MAX_DIMS = 3
+BT_MAX_LEVELS = 64
+BT_NUM_STAGES = 24
+
+BT_OK, BT_ERR_INVALID, BT_ERR_MAX_LEVELS, BT_ERR_ALLOC, BT_ERR_HIP, \
+    BT_ERR_INTERNAL, BT_ERR_UNSUPPORTED = range(7)
+
+BT_F32, BT_F64 = 0, 1
+NORMS = {None: 0, "linf": 1, "l2": 2}
+KINDS = {"adaptive": 0, "adaptive-level-restricted": 1, "non-adaptive": 2}
+CRITS = {"static_linf": 0, "precise_linf": 1, "static_l2": 2}
+
+vp = ct.c_void_p
+i32p = ct.c_void_p     # device pointers are passed as plain addresses
+P3 = vp * BT_MAX_DIMS
+PL = vp * BT_MAX_LEVELS
+
+
+class SortStats(ct.Structure):
+    _fields_ = [("passes", ct.c_int32), ("pass_ms_avg", ct.c_float),
+                ("hist_ms", ct.c_float), ("total_ms", ct.c_float)]
+
+
+class TreeParams(ct.Structure):
+    _fields_ = [
+        ("dims", ct.c_int32), ("coord_kind", ct.c_int32),
+        ("nsources", ct.c_int64), ("ntargets", ct.c_int64),
+        ("sources", P3), ("targets", P3),
+        ("source_radii", vp), ("target_radii", vp),
+        ("refine_weights", vp),
+        ("max_leaf_refine_weight", ct.c_int32),
+        ("kind", ct.c_int32), ("extent_norm", ct.c_int32), ("skip_prune", ct.c_int32),
+        ("stick_out_factor", ct.c_double),
+        ("bbox_min", ct.c_double * BT_MAX_DIMS), ("bbox_max", ct.c_double * BT_MAX_DIMS),
+        ("root_extent", ct.c_double),
+    ]
+
+
+class TreeSizes(ct.Structure):
+    _fields_ = [
+        ("nboxes", ct.c_int64), ("aligned_nboxes", ct.c_int64),
+        ("nlevels", ct.c_int32), ("key_levels", ct.c_int32),
+        ("level_start_box_nrs", ct.c_int32 * (BT_MAX_LEVELS + 1)),
+    ]
+
+
+class TreeArrays(ct.Structure):
+    _fields_ = [
+        ("user_source_ids", vp), ("sorted_target_ids", vp),
+        ("sources", P3), ("targets", P3),
+        ("source_radii", vp), ("target_radii", vp),
+        ("box_source_starts", vp), ("box_source_counts_nonchild", vp),
+        ("box_source_counts_cumul", vp),
+        ("box_target_starts", vp), ("box_target_counts_nonchild", vp),
+        ("box_target_counts_cumul", vp),
+        ("box_parent_ids", vp), ("box_child_ids", vp), ("box_centers", vp),
+        ("box_levels", vp), ("box_flags", vp),
+        ("box_source_bounding_box_min", vp), ("box_source_bounding_box_max", vp),
+        ("box_target_bounding_box_min", vp), ("box_target_bounding_box_max", vp),
+    ]
+
+
+class StageTimes(ct.Structure):
+    _fields_ = [("ms", ct.c_float * BT_NUM_STAGES),
+                ("name", ct.c_char_p * BT_NUM_STAGES),
+                ("n", ct.c_int32)]
+
+
+class TravParams(ct.Structure):
+    _fields_ = [
+        ("dims", ct.c_int32), ("coord_kind", ct.c_int32), ("nlevels", ct.c_int32),
+        ("nboxes", ct.c_int64), ("aligned_nboxes", ct.c_int64),
+        ("root_extent", ct.c_double), ("stick_out_factor", ct.c_double),
+        ("box_centers", vp), ("box_levels", vp), ("box_child_ids", vp),
+        ("box_flags", vp), ("box_parent_ids", vp),
+        ("box_target_bounding_box_min", vp), ("box_target_bounding_box_max", vp),
+        ("box_source_counts_cumul", vp),
+        ("level_start_box_nrs", ct.POINTER(ct.c_int32)),      # host
+        ("sources_are_targets", ct.c_int32),
+        ("sources_have_extent", ct.c_int32), ("targets_have_extent", ct.c_int32),
+        ("well_sep_is_n_away", ct.c_int32),
+        ("from_sep_smaller_crit", ct.c_int32),
+        ("from_sep_smaller_min_nsources_cumul", ct.c_int32),
+        ("source_boxes_mask", vp), ("source_parent_boxes_mask", vp),
+    ]
+
+
+class TravSizes(ct.Structure):
+    _fields_ = [
+        ("nsource_boxes", ct.c_int64), ("ntarget_boxes", ct.c_int64),
+        ("nsource_parent_boxes", ct.c_int64),
+        ("ntarget_or_target_parent_boxes", ct.c_int64),
+        ("n_same_level_non_well_sep", ct.c_int64),
+        ("n_neighbor_source", ct.c_int64),
+        ("n_from_sep_siblings", ct.c_int64),
+        ("n_from_sep_bigger", ct.c_int64),
+        ("n_from_sep_close_smaller", ct.c_int64),
+        ("n_from_sep_close_bigger", ct.c_int64),
+        ("n_from_sep_smaller", ct.c_int64 * BT_MAX_LEVELS),
+        ("n_from_sep_smaller_nonempty", ct.c_int64 * BT_MAX_LEVELS),
+    ]
+
+
+class TravArrays(ct.Structure):
+    _fields_ = [
+        ("source_boxes", vp), ("target_boxes", vp), ("source_parent_boxes", vp),
+        ("target_or_target_parent_boxes", vp),
+        ("level_start_source_box_nrs", vp), ("level_start_target_box_nrs", vp),
+        ("level_start_source_parent_box_nrs", vp),
+        ("level_start_target_or_target_parent_box_nrs", vp),
+        ("same_level_non_well_sep_boxes_starts", vp),
+        ("same_level_non_well_sep_boxes_lists", vp),
+        ("neighbor_source_boxes_starts", vp), ("neighbor_source_boxes_lists", vp),
+        ("from_sep_siblings_starts", vp), ("from_sep_siblings_lists", vp),
+        ("from_sep_bigger_starts", vp), ("from_sep_bigger_lists", vp),
+        ("from_sep_close_smaller_starts", vp), ("from_sep_close_smaller_lists", vp),
+        ("from_sep_close_bigger_starts", vp), ("from_sep_close_bigger_lists", vp),
+        ("from_sep_smaller_starts", PL), ("from_sep_smaller_lists", PL),
+        ("from_sep_smaller_nonempty_indices", PL),
+        ("from_sep_smaller_compressed_indices", PL),
+        ("target_boxes_sep_smaller", PL),
+    ]
+
+
+# every symbol include/boxtree_hip.h declares
+EXPORTED_SYMBOLS = [
+    "bt_abi_version", "bt_create", "bt_destroy", "bt_trim", "bt_last_error_string",
+    "bt_bbox", "bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32", "bt_get_sort_stats",
+    "bt_tree_build", "bt_tree_export", "bt_get_stage_times",
+    "bt_traversal_build", "bt_traversal_export",
+]
+
+_lib = None
+
+
+class BoxtreeHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libboxtree_hip error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def load():
+    """Load the HIP library; fail loudly if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C boxtree_amd/csrc`). boxtree_amd has no CPU fallback.")
+    lib = ct.CDLL(LIB_PATH)
+    lib.bt_abi_version.restype = ct.c_int
+    lib.bt_last_error_string.restype = ct.c_char_p
+    lib.bt_create.argtypes = [ct.c_int, vp, ct.POINTER(vp)]
+    lib.bt_destroy.argtypes = [vp]
+    lib.bt_destroy.restype = None
+    lib.bt_trim.argtypes = [vp]
+    lib.bt_bbox.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), vp, ct.c_int64,
+                            ct.POINTER(ct.c_double), ct.POINTER(ct.c_double)]
+    for name in ("bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32"):
+        getattr(lib, name).argtypes = [vp, vp, vp, vp, vp, ct.c_int64, ct.c_int, ct.c_int]
+    lib.bt_get_sort_stats.argtypes = [vp, ct.POINTER(SortStats)]
+    lib.bt_tree_build.argtypes = [vp, ct.POINTER(TreeParams), ct.POINTER(TreeSizes)]
+    lib.bt_tree_export.argtypes = [vp, ct.POINTER(TreeArrays)]
+    lib.bt_get_stage_times.argtypes = [vp, ct.POINTER(StageTimes)]
+    lib.bt_traversal_build.argtypes = [vp, ct.POINTER(TravParams), ct.POINTER(TravSizes)]
+    lib.bt_traversal_export.argtypes = [vp, ct.POINTER(TravArrays)]
+    if lib.bt_abi_version() != 1:
+        raise RuntimeError("libboxtree_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != BT_OK:
+        msg = load().bt_last_error_string().decode("utf-8", "replace")
+        raise BoxtreeHipError(code, msg)

@@ -1,0 +1,135 @@
+"""Minimal stand-in for the reference's array context (boxtree/array_context.py:63-132).
+
+The reference threads a PyOpenCL array context through every call; here the
+"context" owns a HIP device, a stream and the library handle.  Device arrays
+are ``torch`` tensors on that device -- torch is used for device memory and
+stream plumbing only.
+"""
+
+from __future__ import annotations
+
+import ctypes as ct
+import dataclasses
+
+import numpy as np
+
+from boxtree_amd import _lib
+
+
+class HIPArrayContext:
+    """Owns one ``bt_context`` (one HIP device + stream).
+
+    Counterpart of ``PyOpenCLArrayContext``: ``from_numpy``/``to_numpy`` move
+    arrays and whole containers (``Tree``, ``FMMTraversalInfo``), ``freeze`` /
+    ``thaw`` are identities (outputs are immutable by convention).
+    """
+
+    def __init__(self, device=None):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "boxtree_amd needs a HIP device (torch.cuda.is_available() is False); "
+                "there is no CPU fallback")
+        self.torch = torch
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device_index = int(device)
+        self.device = torch.device("cuda", self.device_index)
+        self.lib = _lib.load()
+        self.stream = torch.cuda.Stream(self.device)
+        handle = ct.c_void_p()
+        _lib.check(self.lib.bt_create(self.device_index,
+                                      ct.c_void_p(self.stream.cuda_stream),
+                                      ct.byref(handle)))
+        self.handle = handle
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.bt_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # -- stream ordering -------------------------------------------------------
+    def sync_in(self):
+        """Make the library stream wait for work queued on torch's current stream."""
+        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+
+    # -- array movement ----------------------------------------------------------
+    def from_numpy(self, ary):
+        torch = self.torch
+        if isinstance(ary, np.ndarray) and ary.dtype.char == "O":
+            out = np.empty(ary.shape, dtype=object)
+            for i, a in np.ndenumerate(ary):
+                out[i] = self.from_numpy(a)
+            return out
+        if isinstance(ary, torch.Tensor):
+            return ary.to(self.device)
+        return torch.from_numpy(np.ascontiguousarray(ary)).to(self.device)
+
+    def to_numpy(self, obj):
+        torch = self.torch
+        if obj is None or isinstance(obj, (int, float, str, bool, np.generic, np.dtype)):
+            return obj
+        if isinstance(obj, torch.Tensor):
+            return obj.detach().cpu().numpy()
+        if isinstance(obj, np.ndarray):
+            if obj.dtype.char == "O":
+                out = np.empty(obj.shape, dtype=object)
+                for i, a in np.ndenumerate(obj):
+                    out[i] = self.to_numpy(a)
+                return out
+            return obj
+        if isinstance(obj, (list, tuple)):
+            return type(obj)(self.to_numpy(o) for o in obj)
+        if dataclasses.is_dataclass(obj):
+            return obj._map_arrays(self.to_numpy)
+        return obj
+
+    def freeze(self, obj):
+        return obj
+
+    def thaw(self, obj):
+        return obj
+
+    def zeros(self, shape, dtype):
+        return self.torch.zeros(shape, dtype=_torch_dtype(self.torch, dtype), device=self.device)
+
+    def empty(self, shape, dtype):
+        return self.torch.empty(shape, dtype=_torch_dtype(self.torch, dtype), device=self.device)
+
+
+def _torch_dtype(torch, dtype):
+    dtype = np.dtype(dtype)
+    return {
+        np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+        np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64,
+        np.dtype(np.uint8): torch.uint8, np.dtype(np.int8): torch.int8,
+        np.dtype(np.uint32): torch.int32, np.dtype(np.uint64): torch.int64,
+    }[dtype]
+
+
+def np_dtype_of(t):
+    """numpy dtype of a torch tensor / numpy array."""
+    if isinstance(t, np.ndarray):
+        return t.dtype
+    import torch
+    return {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64),
+            torch.int32: np.dtype(np.int32), torch.int64: np.dtype(np.int64),
+            torch.uint8: np.dtype(np.uint8), torch.int8: np.dtype(np.int8)}[t.dtype]
+
+
+def ptr(t):
+    """Device address of a tensor as a ctypes void pointer (NULL for None)."""
+    if t is None:
+        return ct.c_void_p(None)
+    assert t.is_contiguous()
+    return ct.c_void_p(t.data_ptr())
+
+
+def make_obj_array(arrays):
+    out = np.empty(len(arrays), dtype=object)
+    for i, a in enumerate(arrays):
+        out[i] = a
+    return out

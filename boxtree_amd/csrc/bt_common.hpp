@@ -1,0 +1,128 @@
+// boxtree_amd -- MI355X (gfx950) native tree build + FMM traversal.
+// Common host-side plumbing: error handling, the context, a caching device
+// allocator.  Wave size is 64 everywhere (CDNA4).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/boxtree_hip.h"
+
+namespace bt {
+
+constexpr int WAVE = 64;
+
+void set_error(const char *fmt, ...);
+
+#define BT_HIP_CHECK(expr)                                                        \
+    do {                                                                          \
+        hipError_t e_ = (expr);                                                   \
+        if (e_ != hipSuccess) {                                                   \
+            ::bt::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,         \
+                            hipGetErrorString(e_));                               \
+            return BT_ERR_HIP;                                                    \
+        }                                                                         \
+    } while (0)
+
+#define BT_CHECK(expr)                                                            \
+    do {                                                                          \
+        int s_ = (expr);                                                          \
+        if (s_ != BT_OK) return s_;                                               \
+    } while (0)
+
+inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Device error flags polled by the host at its sync points.
+struct DeviceStatus {
+    int lookback_timeout;   // onesweep look-back spin bound hit
+    int max_levels;         // a box at the deepest representable level must split
+    int internal;           // assertion-like failures
+    int pad;
+};
+
+// Caching device allocator: blocks are kept until bt_destroy / trim.  All
+// allocations are 256-byte aligned (hipMalloc guarantees it).
+class Pool {
+public:
+    ~Pool() { release_all(); }
+    int alloc(void **out, size_t bytes);
+    void free(void *p);
+    void release_all();
+    size_t bytes_reserved() const { return reserved_; }
+
+private:
+    struct Block { void *ptr; size_t size; bool used; };
+    std::vector<Block> blocks_;
+    size_t reserved_ = 0;
+};
+
+// RAII handle on a pool allocation.
+template <class T>
+class Buf {
+public:
+    Buf() = default;
+    Buf(const Buf &) = delete;
+    Buf &operator=(const Buf &) = delete;
+    Buf(Buf &&o) noexcept { *this = std::move(o); }
+    Buf &operator=(Buf &&o) noexcept {
+        if (this != &o) {
+            reset();
+            pool_ = o.pool_; p_ = o.p_; n_ = o.n_;
+            o.p_ = nullptr; o.n_ = 0; o.pool_ = nullptr;
+        }
+        return *this;
+    }
+    ~Buf() { reset(); }
+    int alloc(Pool &pool, int64_t n) {
+        reset();
+        pool_ = &pool;
+        n_ = n;
+        void *p = nullptr;
+        int s = pool.alloc(&p, (size_t) (n > 0 ? n : 1) * sizeof(T));
+        p_ = (T *) p;
+        return s;
+    }
+    void reset() {
+        if (p_ && pool_) pool_->free(p_);
+        p_ = nullptr; n_ = 0;
+    }
+    T *get() const { return p_; }
+    int64_t size() const { return n_; }
+    void swap(Buf &o) { std::swap(pool_, o.pool_); std::swap(p_, o.p_); std::swap(n_, o.n_); }
+
+private:
+    Pool *pool_ = nullptr;
+    T *p_ = nullptr;
+    int64_t n_ = 0;
+};
+
+}  // namespace bt
+
+struct TreeState;   // bt_tree.hip
+struct TravState;   // bt_trav.hip
+
+struct bt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int num_cus = 256;
+    bt::Pool pool;
+    bt::DeviceStatus *d_status = nullptr;     // device
+    bt::DeviceStatus *h_status = nullptr;     // pinned host mirror
+    TreeState *tree = nullptr;
+    TravState *trav = nullptr;
+    // timing of the last bt_radix_sort call (HIP events on ctx->stream)
+    float last_sort_pass_ms = 0.f;
+    int last_sort_passes = 0;
+    float stage_ms[32] = {0};
+};
+
+namespace bt {
+int check_status(bt_context *ctx);   // sync + read device status flags
+int reset_status(bt_context *ctx);
+}  // namespace bt

@@ -1,0 +1,170 @@
+// Context, error strings, caching device allocator.
+#include "bt_common.hpp"
+
+#include <cstdarg>
+
+namespace bt {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int Pool::alloc(void **out, size_t bytes)
+{
+    bytes = (bytes + 255) & ~(size_t) 255;
+    // best fit among free blocks
+    int best = -1;
+    for (int i = 0; i < (int) blocks_.size(); ++i) {
+        const Block &b = blocks_[i];
+        if (!b.used && b.size >= bytes && (best < 0 || b.size < blocks_[best].size))
+            best = i;
+    }
+    // accept a cached block only if it wastes < 2x
+    if (best >= 0 && blocks_[best].size <= 2 * bytes + (1 << 20)) {
+        blocks_[best].used = true;
+        *out = blocks_[best].ptr;
+        return BT_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+        // drop the cache and retry once
+        (void) hipGetLastError();
+        std::vector<Block> keep;
+        for (auto &b : blocks_) {
+            if (b.used) keep.push_back(b);
+            else { (void) hipFree(b.ptr); reserved_ -= b.size; }
+        }
+        blocks_.swap(keep);
+        e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+            *out = nullptr;
+            return BT_ERR_ALLOC;
+        }
+    }
+    blocks_.push_back({p, bytes, true});
+    reserved_ += bytes;
+    *out = p;
+    return BT_OK;
+}
+
+void Pool::free(void *p)
+{
+    for (auto &b : blocks_)
+        if (b.ptr == p) { b.used = false; return; }
+}
+
+void Pool::release_all()
+{
+    for (auto &b : blocks_) (void) hipFree(b.ptr);
+    blocks_.clear();
+    reserved_ = 0;
+}
+
+int reset_status(bt_context *ctx)
+{
+    BT_HIP_CHECK(hipMemsetAsync(ctx->d_status, 0, sizeof(DeviceStatus), ctx->stream));
+    return BT_OK;
+}
+
+int check_status(bt_context *ctx)
+{
+    BT_HIP_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(DeviceStatus),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->h_status->lookback_timeout) {
+        set_error("radix sort: decoupled look-back spin bound exceeded");
+        return BT_ERR_INTERNAL;
+    }
+    if (ctx->h_status->internal) {
+        set_error("device-side consistency check failed (code %d)", ctx->h_status->internal);
+        return BT_ERR_INTERNAL;
+    }
+    if (ctx->h_status->max_levels) {
+        set_error("Level count exceeded the depth addressable by the 64-bit Morton key "
+                  "(a large number of particles is indistinguishable at that depth).");
+        return BT_ERR_MAX_LEVELS;
+    }
+    return BT_OK;
+}
+
+}  // namespace bt
+
+void bt_free_tree_state(bt_context *ctx);   // bt_tree.hip
+void bt_free_trav_state(bt_context *ctx);   // bt_trav.hip
+
+extern "C" {
+
+int bt_abi_version(void) { return BT_ABI_VERSION; }
+
+const char *bt_last_error_string(void) { return bt::g_last_error.c_str(); }
+
+int bt_create(int device, void *hip_stream, bt_context **out)
+{
+    if (!out) { bt::set_error("bt_create: out is NULL"); return BT_ERR_INVALID; }
+    *out = nullptr;
+    int ndev = 0;
+    BT_HIP_CHECK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        bt::set_error("bt_create: device %d out of range (have %d)", device, ndev);
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(device));
+    bt_context *ctx = new bt_context();
+    ctx->device = device;
+    if (hip_stream) {
+        ctx->stream = (hipStream_t) hip_stream;
+    } else {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ctx; BT_HIP_CHECK(e); }
+        ctx->own_stream = true;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+        ctx->num_cus = prop.multiProcessorCount;
+    hipError_t e = hipMalloc((void **) &ctx->d_status, sizeof(bt::DeviceStatus));
+    if (e == hipSuccess)
+        e = hipHostMalloc((void **) &ctx->h_status, sizeof(bt::DeviceStatus), hipHostMallocDefault);
+    if (e != hipSuccess) { bt_destroy(ctx); BT_HIP_CHECK(e); }
+    memset(ctx->h_status, 0, sizeof(bt::DeviceStatus));
+    int s = bt::reset_status(ctx);
+    if (s != BT_OK) { bt_destroy(ctx); return s; }
+    *out = ctx;
+    return BT_OK;
+}
+
+void bt_destroy(bt_context *ctx)
+{
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+    bt_free_tree_state(ctx);
+    bt_free_trav_state(ctx);
+    ctx->pool.release_all();
+    if (ctx->d_status) (void) hipFree(ctx->d_status);
+    if (ctx->h_status) (void) hipHostFree(ctx->h_status);
+    if (ctx->own_stream && ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int bt_trim(bt_context *ctx)
+{
+    if (!ctx) return BT_ERR_INVALID;
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    bt_free_tree_state(ctx);
+    bt_free_trav_state(ctx);
+    ctx->pool.release_all();
+    return BT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,378 @@
+// Onesweep-style LSD radix sort for gfx950 (wave64).
+//
+// One up-front kernel histograms every digit of every key (keys read once).
+// Each digit pass is then ONE kernel: a workgroup takes the next tile (ticket
+// from an atomic counter, so all predecessor tiles are resident or done),
+// ranks its keys with wave-wide ballot matching (no per-thread counters),
+// obtains the global offset of each of its 256 digit bins by decoupled
+// look-back over the preceding tiles' published bin counts, reorders the tile
+// through LDS so that equal digits are contiguous, and writes coalesced runs.
+// Algorithmic traffic per pass: (sizeof(key)+4) bytes read + written per pair.
+//
+// Cross-workgroup hand-off is a single relaxed agent-scope 64-bit word per
+// (tile, digit): {generation|flag, count}.  The data IS the flag (one aligned
+// 8-byte sc1 store), so no fence is needed and placement on XCDs is irrelevant.
+#include "bt_sort.hpp"
+#include "bt_prims.hpp"
+
+namespace bt {
+
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+constexpr uint32_t LB_AGG = 1, LB_PREFIX = 2;
+constexpr uint32_t LOOKBACK_SPIN_LIMIT = 1u << 22;
+
+template <class KeyT> struct SortTraits;
+template <> struct SortTraits<uint64_t> { static constexpr int THREADS = 512, ITEMS = 16; };
+template <> struct SortTraits<uint32_t> { static constexpr int THREADS = 512, ITEMS = 16; };
+
+__device__ __forceinline__ uint64_t lb_pack(uint32_t gen, uint32_t flag, uint32_t v)
+{
+    return ((uint64_t) ((gen << 2) | flag) << 32) | v;
+}
+
+__device__ __forceinline__ void lb_store(uint64_t *p, uint64_t v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint64_t lb_load(const uint64_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- up-front histogram of all digits -------------------------------------
+
+template <class KeyT, int MAXP>
+__global__ __launch_bounds__(256) void sort_hist_kernel(const KeyT *keys, uint32_t n,
+        int begin_bit, int npasses, uint32_t *ghist /* [npasses][RADIX] */)
+{
+    __shared__ uint32_t s_h[MAXP * RADIX];
+    for (int i = threadIdx.x; i < npasses * RADIX; i += 256) s_h[i] = 0;
+    __syncthreads();
+    const uint32_t stride = gridDim.x * 256;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        KeyT k = keys[i] >> begin_bit;
+#pragma unroll
+        for (int p = 0; p < MAXP; ++p) {
+            if (p < npasses) {
+                atomicAdd(&s_h[p * RADIX + (uint32_t) (k & 0xFF)], 1u);
+                k >>= RADIX_BITS;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < npasses * RADIX; i += 256) {
+        uint32_t c = s_h[i];
+        if (c) atomicAdd(&ghist[i], c);
+    }
+}
+
+// exclusive scan of each pass's 256 bins (in place)
+__global__ __launch_bounds__(RADIX) void sort_hist_scan_kernel(uint32_t *ghist)
+{
+    __shared__ uint32_t s_tmp[RADIX / 64 + 1];
+    uint32_t *h = ghist + blockIdx.x * RADIX;
+    uint32_t v = h[threadIdx.x];
+    uint32_t ex = block_exclusive_scan<uint32_t, RADIX>(v, s_tmp, (uint32_t *) nullptr);
+    h[threadIdx.x] = ex;
+}
+
+// ---- one digit pass ---------------------------------------------------------
+
+template <class KeyT, int THREADS, int ITEMS, bool IDENTITY_VALS>
+__global__ __launch_bounds__(THREADS, THREADS / 128) void onesweep_kernel(
+        const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+        KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
+        uint32_t n, int shift, const uint32_t *__restrict__ digit_start,
+        uint64_t *lookback, uint32_t *tile_counter, uint32_t gen, DeviceStatus *status)
+{
+    constexpr int NW = THREADS / 64;
+    constexpr int TILE = THREADS * ITEMS;
+    constexpr int WAVE_ITEMS = 64 * ITEMS;
+
+    __shared__ uint32_t s_hist[NW * RADIX];
+    __shared__ uint32_t s_digit_base[RADIX];
+    __shared__ uint32_t s_global_base[RADIX];
+    __shared__ uint32_t s_tmp[RADIX / 64 + 1];
+    __shared__ uint32_t s_tile;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[TILE * sizeof(KeyT)];
+    KeyT *s_keys = reinterpret_cast<KeyT *>(s_raw);
+    uint32_t *s_vals = reinterpret_cast<uint32_t *>(s_raw);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    if (tid == 0) s_tile = atomicAdd(tile_counter, 1u);
+    for (int i = tid; i < NW * RADIX; i += THREADS) s_hist[i] = 0;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t base = tile * (uint32_t) TILE;
+    const uint32_t valid = min((uint32_t) TILE, n - base);
+
+    // ---- load (wave-striped: item j of lane l = wave chunk + j*64 + l) ----
+    KeyT key[ITEMS];
+    uint32_t val[ITEMS];
+    const uint32_t wbase = base + wave * WAVE_ITEMS + lane;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        uint32_t i = wbase + j * 64;
+        key[j] = (i < n) ? keys_in[i] : ~(KeyT) 0;
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        uint32_t i = wbase + j * 64;
+        if (IDENTITY_VALS) val[j] = i;
+        else val[j] = (i < n) ? vals_in[i] : 0u;
+    }
+
+    // ---- rank within the wave by ballot matching ---------------------------
+    uint32_t rank[ITEMS];
+    uint32_t *wh = s_hist + wave * RADIX;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t d = (uint32_t) (key[j] >> shift) & (RADIX - 1);
+        uint64_t mask = ~0ull;
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+            const bool bit = (d >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            mask &= bit ? bal : ~bal;
+        }
+        const uint32_t below = (uint32_t) mask_popc_lt(mask);
+        const uint32_t cnt = (uint32_t) __popcll(mask);
+        const uint32_t old = wh[d];
+        if (below == 0) wh[d] = old + cnt;
+        rank[j] = old + below;
+    }
+    __syncthreads();
+
+    // ---- per-digit totals, wave offsets, look-back --------------------------
+    uint32_t tot = 0;
+    if (tid < RADIX) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            uint32_t c = s_hist[w * RADIX + tid];
+            s_hist[w * RADIX + tid] = tot;
+            tot += c;
+        }
+    }
+    uint32_t count = tot;
+    if (tid == RADIX - 1) count -= ((uint32_t) TILE - valid);   // padding keys
+    uint64_t *lb = lookback + (uint64_t) tile * RADIX + tid;
+    if (tid < RADIX)
+        lb_store(lb, lb_pack(gen, tile == 0 ? LB_PREFIX : LB_AGG, count));
+
+    // exclusive scan of the tile's digit counts (threads >= RADIX contribute 0)
+    uint32_t dbase;
+    {
+        uint32_t incl = wave_inclusive_scan(tot);
+        if (lane == 63 && wave < RADIX / 64) s_tmp[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+#pragma unroll
+        for (int i = 0; i < RADIX / 64; ++i)
+            if (i < wave) woff += s_tmp[i];
+        dbase = woff + incl - tot;
+    }
+
+    if (tid < RADIX) {
+        uint32_t excl = 0;
+        if (tile > 0) {
+            int64_t t = (int64_t) tile - 1;
+            uint32_t spins = 0;
+            const uint32_t want_p = (gen << 2) | LB_PREFIX;
+            const uint32_t want_a = (gen << 2) | LB_AGG;
+            while (true) {
+                const uint64_t w = lb_load(lookback + (uint64_t) t * RADIX + tid);
+                const uint32_t hi = (uint32_t) (w >> 32);
+                if (hi == want_p) { excl += (uint32_t) w; break; }
+                if (hi == want_a) { excl += (uint32_t) w; --t; continue; }
+                if (++spins > LOOKBACK_SPIN_LIMIT) {
+                    atomicExch(&status->lookback_timeout, 1);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            lb_store(lb, lb_pack(gen, LB_PREFIX, excl + count));
+        }
+        s_digit_base[tid] = dbase;
+        s_global_base[tid] = digit_start[tid] + excl - dbase;
+    }
+    __syncthreads();
+
+    // ---- reorder the tile through LDS, write coalesced runs -----------------
+    uint32_t pos[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t d = (uint32_t) (key[j] >> shift) & (RADIX - 1);
+        pos[j] = s_digit_base[d] + wh[d] + rank[j];
+        s_keys[pos[j]] = key[j];
+    }
+    __syncthreads();
+
+    uint32_t gpos[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const uint32_t p = k * THREADS + tid;
+        const KeyT kk = s_keys[p];
+        const uint32_t d = (uint32_t) (kk >> shift) & (RADIX - 1);
+        gpos[k] = s_global_base[d] + p;
+        if (p < valid) keys_out[gpos[k]] = kk;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) s_vals[pos[j]] = val[j];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; ++k) {
+        const uint32_t p = k * THREADS + tid;
+        if (p < valid) vals_out[gpos[k]] = s_vals[p];
+    }
+}
+
+template <class KeyT>
+int radix_sort_pairs(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t *vb,
+                     int64_t n, int begin_bit, int end_bit, bool identity_vals, bool *in_b)
+{
+    using Tr = SortTraits<KeyT>;
+    constexpr int TILE = Tr::THREADS * Tr::ITEMS;
+    constexpr int MAXP = (int) sizeof(KeyT);   // at most one pass per key byte
+
+    *in_b = false;
+    ctx->last_sort_passes = 0;
+    ctx->last_sort_pass_ms = 0.f;
+    if (n >= ((int64_t) 1 << 31)) {
+        set_error("radix sort: n=%lld exceeds the 2^31-1 limit of 32-bit ids", (long long) n);
+        return BT_ERR_INVALID;
+    }
+    if (begin_bit < 0 || end_bit > (int) sizeof(KeyT) * 8 || begin_bit > end_bit) {
+        set_error("radix sort: bad bit range [%d, %d)", begin_bit, end_bit);
+        return BT_ERR_INVALID;
+    }
+    const int npasses = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
+    if (n == 0) return BT_OK;
+    if (npasses == 0) {
+        if (identity_vals) {
+            set_error("radix sort: identity values need at least one pass");
+            return BT_ERR_INVALID;
+        }
+        return BT_OK;
+    }
+
+    const uint32_t ntiles = (uint32_t) div_up(n, TILE);
+    Buf<uint32_t> hist;      // [npasses][RADIX] then tile counters [npasses]
+    Buf<uint64_t> lookback;  // [ntiles][RADIX]
+    BT_CHECK(hist.alloc(ctx->pool, (int64_t) npasses * RADIX + MAXP));
+    BT_CHECK(lookback.alloc(ctx->pool, (int64_t) ntiles * RADIX));
+    uint32_t *tile_counters = hist.get() + (int64_t) npasses * RADIX;
+
+    hipEvent_t ev[3];
+    for (auto &e : ev) BT_HIP_CHECK(hipEventCreate(&e));
+
+    BT_HIP_CHECK(hipMemsetAsync(hist.get(), 0, ((size_t) npasses * RADIX + MAXP) * 4, ctx->stream));
+    BT_HIP_CHECK(hipMemsetAsync(lookback.get(), 0, (size_t) ntiles * RADIX * 8, ctx->stream));
+
+    BT_HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
+    {
+        int64_t blocks = div_up(n, 256 * 16);
+        int64_t cap = (int64_t) ctx->num_cus * 8;
+        if (blocks > cap) blocks = cap;
+        sort_hist_kernel<KeyT, MAXP><<<(unsigned) blocks, 256, 0, ctx->stream>>>(
+            ka, (uint32_t) n, begin_bit, npasses, hist.get());
+        sort_hist_scan_kernel<<<npasses, RADIX, 0, ctx->stream>>>(hist.get());
+    }
+    BT_HIP_CHECK(hipEventRecord(ev[1], ctx->stream));
+
+    KeyT *kin = ka, *kout = kb;
+    uint32_t *vin = va, *vout = vb;
+    for (int p = 0; p < npasses; ++p) {
+        const int shift = begin_bit + p * RADIX_BITS;
+        if (p == 0 && identity_vals) {
+            onesweep_kernel<KeyT, Tr::THREADS, Tr::ITEMS, true>
+                <<<ntiles, Tr::THREADS, 0, ctx->stream>>>(
+                    kin, vin, kout, vout, (uint32_t) n, shift, hist.get() + p * RADIX,
+                    lookback.get(), tile_counters + p, (uint32_t) (p + 1), ctx->d_status);
+        } else {
+            onesweep_kernel<KeyT, Tr::THREADS, Tr::ITEMS, false>
+                <<<ntiles, Tr::THREADS, 0, ctx->stream>>>(
+                    kin, vin, kout, vout, (uint32_t) n, shift, hist.get() + p * RADIX,
+                    lookback.get(), tile_counters + p, (uint32_t) (p + 1), ctx->d_status);
+        }
+        KeyT *tk = kin; kin = kout; kout = tk;
+        uint32_t *tv = vin; vin = vout; vout = tv;
+    }
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipEventRecord(ev[2], ctx->stream));
+    BT_HIP_CHECK(hipEventSynchronize(ev[2]));
+    float hist_ms = 0.f, pass_ms = 0.f;
+    BT_HIP_CHECK(hipEventElapsedTime(&hist_ms, ev[0], ev[1]));
+    BT_HIP_CHECK(hipEventElapsedTime(&pass_ms, ev[1], ev[2]));
+    for (auto &e : ev) (void) hipEventDestroy(e);
+    ctx->last_sort_passes = npasses;
+    ctx->last_sort_pass_ms = pass_ms / npasses;
+    ctx->stage_ms[30] = hist_ms;
+    ctx->stage_ms[31] = hist_ms + pass_ms;
+    *in_b = (npasses & 1) != 0;
+    return BT_OK;
+}
+
+template int radix_sort_pairs<uint64_t>(bt_context *, uint64_t *, uint32_t *, uint64_t *,
+                                        uint32_t *, int64_t, int, int, bool, bool *);
+template int radix_sort_pairs<uint32_t>(bt_context *, uint32_t *, uint32_t *, uint32_t *,
+                                        uint32_t *, int64_t, int, int, bool, bool *);
+
+}  // namespace bt
+
+// ---- C API -------------------------------------------------------------------
+
+template <class KeyT>
+static int sort_api(bt_context *ctx, KeyT *keys_in, uint32_t *vals_in, KeyT *keys_out,
+                    uint32_t *vals_out, int64_t n, int begin_bit, int end_bit)
+{
+    if (!ctx || !keys_in || !vals_in || !keys_out || !vals_out || n < 0) {
+        bt::set_error("bt_radix_sort: NULL argument or negative n");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    BT_CHECK(bt::reset_status(ctx));
+    bool in_b = false;
+    BT_CHECK(bt::radix_sort_pairs<KeyT>(ctx, keys_in, vals_in, keys_out, vals_out, n,
+                                        begin_bit, end_bit, false, &in_b));
+    if (!in_b && n > 0) {
+        BT_HIP_CHECK(hipMemcpyAsync(keys_out, keys_in, (size_t) n * sizeof(KeyT),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+        BT_HIP_CHECK(hipMemcpyAsync(vals_out, vals_in, (size_t) n * 4,
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    return bt::check_status(ctx);
+}
+
+extern "C" {
+
+int bt_radix_sort_u64_u32(bt_context *ctx, uint64_t *keys_in, uint32_t *vals_in,
+                          uint64_t *keys_out, uint32_t *vals_out, int64_t n,
+                          int begin_bit, int end_bit)
+{
+    return sort_api<uint64_t>(ctx, keys_in, vals_in, keys_out, vals_out, n, begin_bit, end_bit);
+}
+
+int bt_radix_sort_u32_u32(bt_context *ctx, uint32_t *keys_in, uint32_t *vals_in,
+                          uint32_t *keys_out, uint32_t *vals_out, int64_t n,
+                          int begin_bit, int end_bit)
+{
+    return sort_api<uint32_t>(ctx, keys_in, vals_in, keys_out, vals_out, n, begin_bit, end_bit);
+}
+
+int bt_get_sort_stats(bt_context *ctx, bt_sort_stats *out)
+{
+    if (!ctx || !out) return BT_ERR_INVALID;
+    out->passes = ctx->last_sort_passes;
+    out->pass_ms_avg = ctx->last_sort_pass_ms;
+    out->hist_ms = ctx->stage_ms[30];
+    out->total_ms = ctx->stage_ms[31];
+    return BT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,958 @@
+// FMM interaction-list generation for gfx950 (boxtree/traversal.py:1969-2345).
+//
+// Every list is produced count -> exclusive scan -> fill, like pyopencl's
+// ListOfListsBuilder, by kernels that evaluate the reference's box predicates
+// (traversal.py:255-320, 933-972) with identical floating-point expressions
+// (-ffp-contract=off).  List 3 ("from_sep_smaller") is generated for all source
+// levels in ONE walk per target box and bucketed by level afterwards, instead
+// of nlevels relaunches (traversal.py:2203-2216).
+#include "bt_common.hpp"
+#include "bt_prims.hpp"
+
+#include <algorithm>
+#include <vector>
+
+using namespace bt;
+
+namespace {
+
+constexpr int MAX_WALK = 40;      // walk stack depth (tree levels <= 32)
+
+template <class T> struct Eps;
+template <> struct Eps<float> { static constexpr float v = 1.1920928955078125e-07f; };
+template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
+
+template <class T, int D>
+struct TravArgs {
+    const T *centers;             // [D][aligned]
+    const uint8_t *levels;
+    const int32_t *child;         // [C][aligned]
+    const uint8_t *flags;
+    const int32_t *parent;
+    const T *tgt_bbox_min, *tgt_bbox_max;
+    const int32_t *src_counts_cumul;
+    int64_t aligned;
+    int32_t nboxes;
+    T root_extent;
+    T stick_out_factor;
+    int nway;
+    int crit;
+    int32_t min_nsources_cumul;
+    int targets_have_extent;
+    int close_lists_exist;
+    // lists built earlier
+    const int32_t *target_boxes; int32_t ntarget_boxes;
+    const int32_t *ttp_boxes; int32_t nttp;
+    const int32_t *coll_starts, *coll_lists;
+};
+
+template <class T>
+__device__ __forceinline__ T level_to_rad(T root_extent, int level)
+{
+    return (root_extent * 1 / (T) (1ull << (level + 1)));      // traversal.py:234-235
+}
+
+template <class T, int D>
+__device__ __forceinline__ void load_center(const TravArgs<T, D> &a, int32_t box, T *c)
+{
+#pragma unroll
+    for (int i = 0; i < D; ++i) c[i] = a.centers[a.aligned * i + box];
+}
+
+// traversal.py:279-305
+template <class T, int D>
+__device__ __forceinline__ bool adj_nbhd(T root_extent, const T *tc, int tl, T nbhd,
+                                         const T *sc, int sl)
+{
+    const T target_rad = level_to_rad(root_extent, tl);
+    const T source_rad = level_to_rad(root_extent, sl);
+    const T rad_sum = ((2 * (nbhd - 1) + 1) * target_rad + source_rad);
+    const T slack = rad_sum + ((target_rad < source_rad) ? target_rad : source_rad);
+    T l_inf = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        T d = tc[i] - sc[i];
+        d = (d < 0) ? -d : d;
+        l_inf = (d > l_inf) ? d : l_inf;
+    }
+    return l_inf <= slack;
+}
+
+template <class T, int D>
+__device__ __forceinline__ bool adj(T root_extent, const T *tc, int tl, const T *sc, int sl)
+{
+    return adj_nbhd<T, D>(root_extent, tc, tl, (T) 1, sc, sl);
+}
+
+// walk state: traversal.py:98-160
+struct Walk {
+    int32_t box_stack[MAX_WALK];
+    int8_t mnr_stack[MAX_WALK];
+    int size;
+    int32_t parent;
+    int mnr;
+    bool go;
+    __device__ __forceinline__ void init(int32_t start) { size = 0; parent = start; mnr = 0; go = true; }
+    template <int C>
+    __device__ __forceinline__ void advance()
+    {
+        while (true) {
+            ++mnr;
+            if (mnr < C) break;
+            go = size > 0;
+            if (go) { --size; parent = box_stack[size]; mnr = mnr_stack[size]; }
+            else break;
+        }
+    }
+    __device__ __forceinline__ void push(int32_t nb)
+    {
+        box_stack[size] = parent; mnr_stack[size] = (int8_t) mnr;
+        if (size < MAX_WALK - 1) ++size;
+        parent = nb; mnr = 0;
+    }
+};
+
+// ---- emitters ---------------------------------------------------------------
+
+struct CountEmit {
+    int32_t n = 0;
+    __device__ __forceinline__ void operator()(int32_t) { ++n; }
+};
+struct WriteEmit {
+    int32_t *p;
+    __device__ __forceinline__ void operator()(int32_t b) { *p++ = b; }
+};
+
+// ---- T3 colleagues: traversal.py:398-464 ---------------------------------------
+
+template <class T, int D, class E>
+__device__ __forceinline__ void gen_colleagues(const TravArgs<T, D> &a, int32_t box_id, E &emit)
+{
+    constexpr int C = 1 << D;
+    if (box_id == 0) return;
+    T center[D];
+    load_center(a, box_id, center);
+    const int level = a.levels[box_id];
+    Walk w;
+    w.init(0);
+    while (w.go) {
+        const int32_t wb = a.child[(int64_t) w.mnr * a.aligned + w.parent];
+        if (wb) {
+            T wc[D];
+            load_center(a, wb, wc);
+            const bool a_or_o = adj_nbhd<T, D>(a.root_extent, center, level, (T) a.nway, wc,
+                                               a.levels[wb]);
+            if (a_or_o) {
+                if (w.size + 1 == level && wb != box_id) {
+                    emit(wb);
+                } else {
+                    w.push(wb);
+                    continue;
+                }
+            }
+        }
+        w.template advance<C>();
+    }
+}
+
+// ---- T4 list 1: traversal.py:470-550 ---------------------------------------------
+
+template <class T, int D, class E>
+__device__ __forceinline__ void gen_list1(const TravArgs<T, D> &a, int32_t tbn, E &emit)
+{
+    constexpr int C = 1 << D;
+    const int32_t box_id = a.target_boxes[tbn];
+    T center[D];
+    load_center(a, box_id, center);
+    const int level = a.levels[box_id];
+    if (a.flags[0] & BT_BOX_IS_SOURCE_BOX) emit(0);
+    Walk w;
+    w.init(0);
+    while (w.go) {
+        const int32_t wb = a.child[(int64_t) w.mnr * a.aligned + w.parent];
+        if (wb) {
+            T wc[D];
+            load_center(a, wb, wc);
+            if (adj<T, D>(a.root_extent, center, level, wc, a.levels[wb])) {
+                const uint8_t fl = a.flags[wb];
+                if (fl & BT_BOX_IS_SOURCE_BOX) emit(wb);
+                if (fl & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
+                    w.push(wb);
+                    continue;
+                }
+            }
+        }
+        w.template advance<C>();
+    }
+}
+
+// ---- T5 list 2: traversal.py:556-601 ----------------------------------------------
+
+template <class T, int D, class E>
+__device__ __forceinline__ void gen_list2(const TravArgs<T, D> &a, int32_t it, E &emit)
+{
+    constexpr int C = 1 << D;
+    const int32_t box_id = a.ttp_boxes[it];
+    T center[D];
+    load_center(a, box_id, center);
+    const int level = a.levels[box_id];
+    const int32_t parent = a.parent[box_id];
+    if (parent == box_id) return;
+    const int32_t ps = a.coll_starts[parent], pe = a.coll_starts[parent + 1];
+    for (int32_t i = ps; i < pe; ++i) {
+        const int32_t pnf = a.coll_lists[i];
+        for (int m = 0; m < C; ++m) {
+            const int32_t sib = a.child[(int64_t) m * a.aligned + pnf];
+            if (sib == 0) continue;
+            T sc[D];
+            load_center(a, sib, sc);
+            const bool sep = !adj_nbhd<T, D>(a.root_extent, center, level, (T) a.nway, sc,
+                                             a.levels[sib]);
+            if (sep) emit(sib);
+        }
+    }
+}
+
+// ---- T6 list 3 (+ close): traversal.py:607-875, all source levels in one walk ------
+
+template <class T, int D, class EM, class EC>
+__device__ __forceinline__ void gen_list3(const TravArgs<T, D> &a, int32_t tbn, EM &emit_main,
+                                          EC &emit_close)
+{
+    constexpr int C = 1 << D;
+    const int32_t tgt = a.target_boxes[tbn];
+    T tc[D];
+    load_center(a, tgt, tc);
+    const int tl = a.levels[tgt];
+
+    T stickout_rad = 0;
+    T ext_center[D], radii_vec[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { ext_center[i] = 0; radii_vec[i] = 0; }
+    if (a.targets_have_extent) {
+        if (a.crit == BT_CRIT_STATIC_LINF || a.crit == BT_CRIT_STATIC_L2) {
+            stickout_rad = (1 + a.stick_out_factor) * level_to_rad(a.root_extent, tl);
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {          // load_true_box_extent, :177-198
+                const T mn = a.tgt_bbox_min[i * a.aligned + tgt];
+                const T mx = a.tgt_bbox_max[i * a.aligned + tgt];
+                ext_center[i] = ((T) 0.5) * (mn + mx);
+                radii_vec[i] = ((T) 0.5) * (mx - mn);
+            }
+        }
+    }
+
+    const int32_t s0 = a.coll_starts[tgt], s1 = a.coll_starts[tgt + 1];
+    for (int32_t i = s0; i < s1; ++i) {
+        const int32_t nws = a.coll_lists[i];
+        if (nws == tgt) continue;
+        Walk w;
+        w.init(nws);
+        while (w.go) {
+            const int32_t wb = a.child[(int64_t) w.mnr * a.aligned + w.parent];
+            const uint8_t fl = a.flags[wb];
+            if (wb && (fl & (BT_BOX_IS_SOURCE_BOX | BT_BOX_HAS_SOURCE_CHILD_BOXES))) {
+                T wc[D];
+                load_center(a, wb, wc);
+                const int wl = a.levels[wb];
+                const bool in_list_1 = adj<T, D>(a.root_extent, tc, tl, wc, wl);
+                if (in_list_1) {
+                    if (fl & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
+                        w.push(wb);
+                        continue;
+                    }
+                } else {
+                    bool meets;
+                    if (!a.targets_have_extent) {
+                        meets = true;
+                    } else if (a.crit == BT_CRIT_STATIC_LINF) {
+                        const T source_rad = level_to_rad(a.root_extent, wl);
+                        T l_inf = 0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            T d = tc[k] - wc[k];
+                            d = (d < 0) ? -d : d;
+                            const T v = d - stickout_rad - source_rad;
+                            l_inf = (v > l_inf) ? v : l_inf;
+                        }
+                        meets = l_inf >= (2 - 8 * Eps<T>::v) * source_rad;
+                    } else if (a.crit == BT_CRIT_PRECISE_LINF) {
+                        const T source_rad = level_to_rad(a.root_extent, wl);
+                        T l_inf = 0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            T d = ext_center[k] - wc[k];
+                            d = (d < 0) ? -d : d;
+                            const T v = d - radii_vec[k] - source_rad;
+                            l_inf = (v > l_inf) ? v : l_inf;
+                        }
+                        meets = l_inf >= (2 - 8 * Eps<T>::v) * source_rad;
+                    } else {
+                        const T source_rad = level_to_rad(a.root_extent, wl);
+                        T l2sq = 0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) {
+                            const T d = tc[k] - wc[k];
+                            l2sq = l2sq + d * d;
+                        }
+                        const T rhs = sqrt(l2sq) - sqrt((T) D) * stickout_rad - source_rad;
+                        meets = ((2 - 8 * Eps<T>::v) * source_rad <= rhs);
+                    }
+                    const bool force_close = a.close_lists_exist
+                        && (a.src_counts_cumul[wb] < a.min_nsources_cumul);
+                    if (meets && !force_close) {
+                        emit_main(wl, wb);
+                    } else if (a.close_lists_exist) {
+                        if (fl & BT_BOX_IS_SOURCE_BOX) emit_close(wb);
+                        if (fl & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
+                            w.push(wb);
+                            continue;
+                        }
+                    }
+                }
+            }
+            w.template advance<C>();
+        }
+    }
+}
+
+// ---- T7 list 4 (+ close): traversal.py:931-1146 ---------------------------------------
+
+template <class T, int D>
+__device__ __forceinline__ bool meets_sep_bigger(T root_extent, const T *tc, int tl, const T *sc,
+                                                 int sl, T stick_out_factor)
+{
+    const T target_rad = level_to_rad(root_extent, tl);
+    const T source_rad = level_to_rad(root_extent, sl);
+    const T max_allowed = (3 * (1 + stick_out_factor) * target_rad + source_rad);
+    T l_inf = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        T d = tc[i] - sc[i];
+        d = (d < 0) ? -d : d;
+        l_inf = (d > l_inf) ? d : l_inf;
+    }
+    return l_inf >= max_allowed * (1 - 8 * Eps<T>::v);
+}
+
+template <class T, int D, class EM, class EC>
+__device__ __forceinline__ void gen_list4(const TravArgs<T, D> &a, int32_t it, EM &emit_main,
+                                          EC &emit_close)
+{
+    const int32_t tgt = a.ttp_boxes[it];
+    T tc[D];
+    load_center(a, tgt, tc);
+    const int tl = a.levels[tgt];
+    if (tl == 0) return;
+    const int32_t tparent = a.parent[tgt];
+    const int pl = tl - 1;
+    T pc[D];
+    load_center(a, tparent, pc);
+    const uint8_t tflags = a.flags[tgt];
+    int wl; int32_t cur;
+    if (a.nway == 1) { wl = tl - 1; cur = tparent; }
+    else { wl = tl; cur = tgt; }
+    for (; wl != 0; --wl, cur = a.parent[cur]) {
+        const int32_t s0 = a.coll_starts[cur], s1 = a.coll_starts[cur + 1];
+        for (int32_t i = s0; i < s1; ++i) {
+            const int32_t sb = a.coll_lists[i];
+            if (!(a.flags[sb] & BT_BOX_IS_SOURCE_BOX)) continue;
+            T sc[D];
+            load_center(a, sb, sc);
+            if (adj<T, D>(a.root_extent, tc, tl, sc, wl)) continue;
+            if (a.close_lists_exist) {
+                if (!meets_sep_bigger<T, D>(a.root_extent, tc, tl, sc, wl, a.stick_out_factor)) {
+                    if (tflags & BT_BOX_IS_TARGET_BOX) emit_close(sb);
+                    continue;
+                }
+            }
+            const bool in_parent_list_1 = adj<T, D>(a.root_extent, pc, pl, sc, wl);
+            bool would = !in_parent_list_1;
+            if (a.nway > 1) would = would && (wl < tl);
+            if (would) {
+                if (a.close_lists_exist) {
+                    if (!meets_sep_bigger<T, D>(a.root_extent, pc, pl, sc, wl, a.stick_out_factor))
+                        emit_main(sb);
+                }
+            } else {
+                emit_main(sb);
+            }
+        }
+    }
+}
+
+// ---- kernels --------------------------------------------------------------------------
+
+enum { GEN_COLL = 0, GEN_L1 = 1, GEN_L2 = 2 };
+
+template <class T, int D, int WHICH, bool FILL>
+__global__ __launch_bounds__(256) void list_kernel(TravArgs<T, D> a, int32_t n,
+        int32_t *counts_or_starts, int32_t *lists)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (!FILL) {
+        CountEmit e;
+        if (WHICH == GEN_COLL) gen_colleagues<T, D>(a, i, e);
+        else if (WHICH == GEN_L1) gen_list1<T, D>(a, i, e);
+        else gen_list2<T, D>(a, i, e);
+        counts_or_starts[i] = e.n;
+    } else {
+        WriteEmit e{lists + counts_or_starts[i]};
+        if (WHICH == GEN_COLL) gen_colleagues<T, D>(a, i, e);
+        else if (WHICH == GEN_L1) gen_list1<T, D>(a, i, e);
+        else gen_list2<T, D>(a, i, e);
+    }
+}
+
+constexpr int L3_MAXLEV = 40;
+
+struct L3CountMain {
+    int32_t c[L3_MAXLEV];
+    __device__ __forceinline__ void operator()(int lev, int32_t) { ++c[lev]; }
+};
+struct L3WriteMain {
+    int32_t *lists;
+    int32_t cur[L3_MAXLEV];
+    __device__ __forceinline__ void operator()(int lev, int32_t b) { lists[cur[lev]++] = b; }
+};
+
+// counts layout: [nlevels][ntb] (level-major) for the main list, [ntb] for close
+template <class T, int D, bool FILL>
+__global__ __launch_bounds__(256) void list3_kernel(TravArgs<T, D> a, int32_t ntb, int nlevels,
+        int32_t *main_cs, int32_t *main_lists, int32_t *close_cs, int32_t *close_lists)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ntb) return;
+    if (!FILL) {
+        L3CountMain em;
+        for (int l = 0; l < nlevels; ++l) em.c[l] = 0;
+        CountEmit ec;
+        gen_list3<T, D>(a, i, em, ec);
+        for (int l = 0; l < nlevels; ++l) main_cs[(int64_t) l * ntb + i] = em.c[l];
+        if (close_cs) close_cs[i] = ec.n;
+    } else {
+        L3WriteMain em;
+        em.lists = main_lists;
+        for (int l = 0; l < nlevels; ++l) em.cur[l] = main_cs[(int64_t) l * ntb + i];
+        WriteEmit ec{close_lists ? close_lists + close_cs[i] : nullptr};
+        CountEmit dummy;
+        if (close_lists) gen_list3<T, D>(a, i, em, ec);
+        else gen_list3<T, D>(a, i, em, dummy);
+    }
+}
+
+template <class T, int D, bool FILL>
+__global__ __launch_bounds__(256) void list4_kernel(TravArgs<T, D> a, int32_t n,
+        int32_t *main_cs, int32_t *main_lists, int32_t *close_cs, int32_t *close_lists)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (!FILL) {
+        CountEmit em, ec;
+        gen_list4<T, D>(a, i, em, ec);
+        main_cs[i] = em.n;
+        if (close_cs) close_cs[i] = ec.n;
+    } else {
+        WriteEmit em{main_lists + main_cs[i]};
+        WriteEmit ec{close_lists ? close_lists + close_cs[i] : nullptr};
+        CountEmit dummy;
+        if (close_lists) gen_list4<T, D>(a, i, em, ec);
+        else gen_list4<T, D>(a, i, em, dummy);
+    }
+}
+
+struct ScanI32 {
+    const int32_t *p;
+    __device__ int32_t operator()(int64_t i) const { return p[i]; }
+};
+
+// ---- box lists by flag (T1, traversal.py:326-355) ---------------------------------------
+
+struct FlagPred {
+    const uint8_t *flags;
+    const int8_t *mask;     // optional
+    uint8_t bits;
+    __device__ int32_t operator()(int64_t i) const
+    {
+        return ((flags[i] & bits) && (!mask || mask[i])) ? 1 : 0;
+    }
+};
+
+__global__ __launch_bounds__(256) void compact_kernel(FlagPred pr, int32_t n, const int32_t *pos,
+                                                      int32_t *out)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (pr(i)) out[pos[i]] = i;
+}
+
+// level starts in a box list: traversal.py:361-392 + 2093-2096 (== lower_bound of the
+// level's first box id in the ascending list)
+__global__ void level_starts_kernel(const int32_t *list, int32_t n, const int32_t *level_start_box_nrs,
+                                    int nlevels, int32_t *out)
+{
+    const int l = threadIdx.x;
+    if (l > nlevels) return;
+    if (l == nlevels) { out[l] = n; return; }
+    const int32_t v = level_start_box_nrs[l];
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (list[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    out[l] = lo;
+}
+
+// ---- list 3 per-level post-processing (BuiltList with eliminate_empty) --------------------
+
+struct NonEmptyPred {
+    const int32_t *starts;    // [ntb+1] slice of the level (global offsets)
+    __device__ int32_t operator()(int64_t i) const { return starts[i + 1] > starts[i] ? 1 : 0; }
+};
+
+__global__ __launch_bounds__(256) void l3_compress_kernel(int32_t ntb, const int32_t *lev_starts,
+        int32_t lev_base, const int32_t *cidx /* [ntb+1] exclusive scan of nonempty */,
+        const int32_t *target_boxes, int32_t *o_starts, int32_t *o_nonempty,
+        int32_t *o_cidx, int32_t *o_tboxes, int32_t lev_total)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i > ntb) return;
+    if (o_cidx) o_cidx[i] = cidx[i];
+    if (i == ntb) {
+        o_starts[cidx[ntb]] = lev_total;
+        return;
+    }
+    if (lev_starts[i + 1] > lev_starts[i]) {
+        const int32_t k = cidx[i];
+        o_starts[k] = lev_starts[i] - lev_base;
+        o_nonempty[k] = i;
+        o_tboxes[k] = target_boxes[i];
+    }
+}
+
+// ---- close-bigger re-indexing (_ListMerger, traversal.py:1259-1344) --------------------------
+
+__global__ __launch_bounds__(256) void reverse_index_kernel(const int32_t *list, int32_t n, int32_t *out)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[list[i]] = i;
+}
+
+struct MergeCount {
+    const int32_t *target_boxes, *ttp_from_all, *raw_starts;
+    __device__ int32_t operator()(int64_t i) const
+    {
+        const int32_t ib = ttp_from_all[target_boxes[i]];
+        return raw_starts[ib + 1] - raw_starts[ib];
+    }
+};
+
+__global__ __launch_bounds__(256) void merge_copy_kernel(int32_t n, MergeCount mc,
+        const int32_t *raw_lists, const int32_t *new_starts, int32_t *new_lists)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t ib = mc.ttp_from_all[mc.target_boxes[i]];
+    const int32_t s = mc.raw_starts[ib], e = mc.raw_starts[ib + 1];
+    int32_t o = new_starts[i];
+    for (int32_t j = s; j < e; ++j) new_lists[o++] = raw_lists[j];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+
+struct CsrList {
+    Buf<int32_t> starts, lists;
+    int64_t n = 0, total = 0;
+};
+
+struct TravState {
+    bt_trav_params p{};
+    int nlevels = 0;
+    bool with_extent = false;
+    Buf<int32_t> source_boxes, target_boxes_buf, source_parent_boxes, ttp_boxes;
+    int64_t nsb = 0, ntb = 0, nspb = 0, nttp = 0;
+    const int32_t *target_boxes = nullptr;
+    Buf<int32_t> lev_starts;           // [4][nlevels+1]
+    Buf<int32_t> d_level_start_box_nrs;
+    CsrList coll, l1, l2, l4, close_smaller, close_bigger;
+    // list 3: flat level-major
+    Buf<int32_t> l3_starts;            // [nlevels*ntb + 1]
+    Buf<int32_t> l3_lists;
+    Buf<int32_t> l3_cidx;              // [nlevels][ntb+1]
+    std::vector<int64_t> l3_level_base, l3_level_count, l3_nonempty;
+    bool built = false;
+};
+
+void bt_free_trav_state(bt_context *ctx)
+{
+    if (ctx->trav) { delete ctx->trav; ctx->trav = nullptr; }
+}
+
+namespace {
+
+inline unsigned nblk(int64_t n) { return (unsigned) std::max<int64_t>(1, div_up(n, 256)); }
+
+int read_i32(bt_context *ctx, const int32_t *d, int32_t *h)
+{
+    BT_HIP_CHECK(hipMemcpyAsync(h, d, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+// counts (in `cs`, n entries) -> exclusive starts in place (n+1 entries) + total on host
+int counts_to_starts(bt_context *ctx, Buf<int32_t> &cs, int64_t n, int64_t *total)
+{
+    Buf<int32_t> tmp;
+    BT_CHECK(tmp.alloc(ctx->pool, n + 1));
+    ScanI32 f{cs.get()};
+    BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, f, n, tmp.get(), (int32_t *) nullptr, true)));
+    cs.swap(tmp);
+    int32_t t = 0;
+    BT_CHECK(read_i32(ctx, cs.get() + n, &t));
+    if (t < 0) {
+        set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference)");
+        return BT_ERR_UNSUPPORTED;
+    }
+    *total = t;
+    return BT_OK;
+}
+
+int compact_boxes(bt_context *ctx, const bt_trav_params &p, uint8_t bits, const int8_t *mask,
+                  Buf<int32_t> &out, int64_t *n_out)
+{
+    const int64_t B = p.nboxes;
+    FlagPred pr{p.box_flags, mask, bits};
+    Buf<int32_t> pos;
+    BT_CHECK(pos.alloc(ctx->pool, B + 1));
+    BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, pr, B, pos.get(), (int32_t *) nullptr, true)));
+    int32_t t = 0;
+    BT_CHECK(read_i32(ctx, pos.get() + B, &t));
+    BT_CHECK(out.alloc(ctx->pool, t));
+    compact_kernel<<<nblk(B), 256, 0, ctx->stream>>>(pr, (int32_t) B, pos.get(), out.get());
+    *n_out = t;
+    return BT_OK;
+}
+
+template <class T, int D>
+int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
+{
+    const bt_trav_params &p = st->p;
+    const int64_t B = p.nboxes;
+    const int nlevels = p.nlevels;
+    const bool sat = p.sources_are_targets;
+    st->with_extent = p.sources_have_extent || p.targets_have_extent;
+
+    // T1
+    BT_CHECK(compact_boxes(ctx, p, BT_BOX_IS_SOURCE_BOX, p.source_boxes_mask, st->source_boxes, &st->nsb));
+    BT_CHECK(compact_boxes(ctx, p, BT_BOX_HAS_SOURCE_CHILD_BOXES, p.source_parent_boxes_mask,
+                           st->source_parent_boxes, &st->nspb));
+    BT_CHECK(compact_boxes(ctx, p, BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX, nullptr,
+                           st->ttp_boxes, &st->nttp));
+    if (sat) {
+        st->target_boxes = st->source_boxes.get();
+        st->ntb = st->nsb;
+    } else {
+        BT_CHECK(compact_boxes(ctx, p, BT_BOX_IS_TARGET_BOX, nullptr, st->target_boxes_buf, &st->ntb));
+        st->target_boxes = st->target_boxes_buf.get();
+    }
+
+    // T2
+    BT_CHECK(st->d_level_start_box_nrs.alloc(ctx->pool, nlevels + 1));
+    BT_HIP_CHECK(hipMemcpyAsync(st->d_level_start_box_nrs.get(), p.level_start_box_nrs,
+                                (size_t) (nlevels + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    BT_CHECK(st->lev_starts.alloc(ctx->pool, 4 * (nlevels + 1)));
+    {
+        const int32_t *lists[4] = {st->source_boxes.get(), st->target_boxes,
+                                   st->source_parent_boxes.get(), st->ttp_boxes.get()};
+        const int64_t ns[4] = {st->nsb, st->ntb, st->nspb, st->nttp};
+        for (int k = 0; k < 4; ++k)
+            level_starts_kernel<<<1, 64, 0, ctx->stream>>>(lists[k], (int32_t) ns[k],
+                    st->d_level_start_box_nrs.get(), nlevels,
+                    st->lev_starts.get() + k * (nlevels + 1));
+    }
+
+    TravArgs<T, D> a{};
+    a.centers = (const T *) p.box_centers;
+    a.levels = p.box_levels;
+    a.child = p.box_child_ids;
+    a.flags = p.box_flags;
+    a.parent = p.box_parent_ids;
+    a.tgt_bbox_min = (const T *) p.box_target_bounding_box_min;
+    a.tgt_bbox_max = (const T *) p.box_target_bounding_box_max;
+    a.src_counts_cumul = p.box_source_counts_cumul;
+    a.aligned = p.aligned_nboxes;
+    a.nboxes = (int32_t) B;
+    a.root_extent = (T) p.root_extent;
+    a.stick_out_factor = (T) p.stick_out_factor;
+    a.nway = p.well_sep_is_n_away;
+    a.crit = p.from_sep_smaller_crit;
+    a.min_nsources_cumul = p.from_sep_smaller_min_nsources_cumul;
+    a.targets_have_extent = p.targets_have_extent;
+    a.close_lists_exist = st->with_extent;
+    a.target_boxes = st->target_boxes; a.ntarget_boxes = (int32_t) st->ntb;
+    a.ttp_boxes = st->ttp_boxes.get(); a.nttp = (int32_t) st->nttp;
+
+    // T3 colleagues
+    {
+        CsrList &c = st->coll;
+        c.n = B;
+        BT_CHECK(c.starts.alloc(ctx->pool, B + 1));
+        list_kernel<T, D, GEN_COLL, false><<<nblk(B), 256, 0, ctx->stream>>>(a, (int32_t) B, c.starts.get(), nullptr);
+        BT_CHECK(counts_to_starts(ctx, c.starts, B, &c.total));
+        BT_CHECK(c.lists.alloc(ctx->pool, c.total));
+        list_kernel<T, D, GEN_COLL, true><<<nblk(B), 256, 0, ctx->stream>>>(a, (int32_t) B, c.starts.get(), c.lists.get());
+    }
+    a.coll_starts = st->coll.starts.get();
+    a.coll_lists = st->coll.lists.get();
+
+    // T4 list 1
+    {
+        CsrList &c = st->l1;
+        c.n = st->ntb;
+        BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
+        list_kernel<T, D, GEN_L1, false><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), nullptr);
+        BT_CHECK(counts_to_starts(ctx, c.starts, c.n, &c.total));
+        BT_CHECK(c.lists.alloc(ctx->pool, c.total));
+        list_kernel<T, D, GEN_L1, true><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), c.lists.get());
+    }
+    // T5 list 2
+    {
+        CsrList &c = st->l2;
+        c.n = st->nttp;
+        BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
+        list_kernel<T, D, GEN_L2, false><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), nullptr);
+        BT_CHECK(counts_to_starts(ctx, c.starts, c.n, &c.total));
+        BT_CHECK(c.lists.alloc(ctx->pool, c.total));
+        list_kernel<T, D, GEN_L2, true><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), c.lists.get());
+    }
+
+    // T6 list 3: one walk for all source levels
+    {
+        const int64_t ntb = st->ntb;
+        const int64_t nflat = (int64_t) nlevels * ntb;
+        if (nflat >= ((int64_t) 1 << 31)) {
+            set_error("list 3 bookkeeping exceeds int32 range");
+            return BT_ERR_UNSUPPORTED;
+        }
+        BT_CHECK(st->l3_starts.alloc(ctx->pool, nflat + 1));
+        CsrList &cs = st->close_smaller;
+        cs.n = ntb;
+        if (st->with_extent) BT_CHECK(cs.starts.alloc(ctx->pool, ntb + 1));
+        list3_kernel<T, D, false><<<nblk(ntb), 256, 0, ctx->stream>>>(
+            a, (int32_t) ntb, nlevels, st->l3_starts.get(), nullptr,
+            st->with_extent ? cs.starts.get() : nullptr, nullptr);
+        int64_t total = 0;
+        BT_CHECK(counts_to_starts(ctx, st->l3_starts, nflat, &total));
+        BT_CHECK(st->l3_lists.alloc(ctx->pool, total));
+        if (st->with_extent) {
+            BT_CHECK(counts_to_starts(ctx, cs.starts, ntb, &cs.total));
+            BT_CHECK(cs.lists.alloc(ctx->pool, cs.total));
+        }
+        list3_kernel<T, D, true><<<nblk(ntb), 256, 0, ctx->stream>>>(
+            a, (int32_t) ntb, nlevels, st->l3_starts.get(), st->l3_lists.get(),
+            st->with_extent ? cs.starts.get() : nullptr,
+            st->with_extent ? cs.lists.get() : nullptr);
+
+        // per-level bases + nonempty counts
+        std::vector<int32_t> h_base((size_t) nlevels + 1);
+        for (int l = 0; l <= nlevels; ++l)
+            BT_HIP_CHECK(hipMemcpyAsync(&h_base[l], st->l3_starts.get() + (int64_t) l * ntb, 4,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        st->l3_level_base.assign((size_t) nlevels, 0);
+        st->l3_level_count.assign((size_t) nlevels, 0);
+        st->l3_nonempty.assign((size_t) nlevels, 0);
+        BT_CHECK(st->l3_cidx.alloc(ctx->pool, (int64_t) nlevels * (ntb + 1)));
+        for (int l = 0; l < nlevels; ++l) {
+            st->l3_level_base[l] = h_base[l];
+            st->l3_level_count[l] = h_base[l + 1] - h_base[l];
+            NonEmptyPred ne{st->l3_starts.get() + (int64_t) l * ntb};
+            int32_t *cidx = st->l3_cidx.get() + (int64_t) l * (ntb + 1);
+            BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, ne, ntb, cidx, (int32_t *) nullptr, true)));
+        }
+        std::vector<int32_t> h_ne((size_t) nlevels);
+        for (int l = 0; l < nlevels; ++l)
+            BT_HIP_CHECK(hipMemcpyAsync(&h_ne[l], st->l3_cidx.get() + (int64_t) l * (ntb + 1) + ntb, 4,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int l = 0; l < nlevels; ++l) st->l3_nonempty[l] = h_ne[l];
+    }
+
+    // T7 list 4 (+ close, re-indexed to target boxes)
+    {
+        CsrList &c = st->l4;
+        c.n = st->nttp;
+        BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
+        CsrList raw;
+        raw.n = st->nttp;
+        if (st->with_extent) BT_CHECK(raw.starts.alloc(ctx->pool, raw.n + 1));
+        list4_kernel<T, D, false><<<nblk(c.n), 256, 0, ctx->stream>>>(
+            a, (int32_t) c.n, c.starts.get(), nullptr,
+            st->with_extent ? raw.starts.get() : nullptr, nullptr);
+        BT_CHECK(counts_to_starts(ctx, c.starts, c.n, &c.total));
+        BT_CHECK(c.lists.alloc(ctx->pool, c.total));
+        if (st->with_extent) {
+            BT_CHECK(counts_to_starts(ctx, raw.starts, raw.n, &raw.total));
+            BT_CHECK(raw.lists.alloc(ctx->pool, raw.total));
+        }
+        list4_kernel<T, D, true><<<nblk(c.n), 256, 0, ctx->stream>>>(
+            a, (int32_t) c.n, c.starts.get(), c.lists.get(),
+            st->with_extent ? raw.starts.get() : nullptr,
+            st->with_extent ? raw.lists.get() : nullptr);
+        if (st->with_extent) {
+            Buf<int32_t> ttp_from_all;
+            BT_CHECK(ttp_from_all.alloc(ctx->pool, B));
+            BT_HIP_CHECK(hipMemsetAsync(ttp_from_all.get(), 0, (size_t) B * 4, ctx->stream));
+            reverse_index_kernel<<<nblk(st->nttp), 256, 0, ctx->stream>>>(
+                st->ttp_boxes.get(), (int32_t) st->nttp, ttp_from_all.get());
+            CsrList &cb = st->close_bigger;
+            cb.n = st->ntb;
+            BT_CHECK(cb.starts.alloc(ctx->pool, cb.n + 1));
+            MergeCount mc{st->target_boxes, ttp_from_all.get(), raw.starts.get()};
+            BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, mc, cb.n, cb.starts.get(),
+                                                              (int32_t *) nullptr, true)));
+            int32_t t = 0;
+            BT_CHECK(read_i32(ctx, cb.starts.get() + cb.n, &t));
+            cb.total = t;
+            BT_CHECK(cb.lists.alloc(ctx->pool, cb.total));
+            merge_copy_kernel<<<nblk(cb.n), 256, 0, ctx->stream>>>(
+                (int32_t) cb.n, mc, raw.lists.get(), cb.starts.get(), cb.lists.get());
+            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+
+    out->nsource_boxes = st->nsb; out->ntarget_boxes = st->ntb;
+    out->nsource_parent_boxes = st->nspb;
+    out->ntarget_or_target_parent_boxes = st->nttp;
+    out->n_same_level_non_well_sep = st->coll.total;
+    out->n_neighbor_source = st->l1.total;
+    out->n_from_sep_siblings = st->l2.total;
+    out->n_from_sep_bigger = st->l4.total;
+    out->n_from_sep_close_smaller = st->with_extent ? st->close_smaller.total : -1;
+    out->n_from_sep_close_bigger = st->with_extent ? st->close_bigger.total : -1;
+    for (int l = 0; l < nlevels; ++l) {
+        out->n_from_sep_smaller[l] = st->l3_level_count[l];
+        out->n_from_sep_smaller_nonempty[l] = st->l3_nonempty[l];
+    }
+    st->built = true;
+    return BT_OK;
+}
+
+int copy_i32(bt_context *ctx, int32_t *dst, const int32_t *src, int64_t n)
+{
+    if (n > 0 && dst)
+        BT_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t) n * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return BT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bt_traversal_build(bt_context *ctx, const bt_trav_params *p, bt_trav_sizes *out)
+{
+    if (!ctx || !p || !out) { set_error("bt_traversal_build: NULL argument"); return BT_ERR_INVALID; }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    memset(out, 0, sizeof(*out));
+    if (p->dims < 1 || p->dims > BT_MAX_DIMS || (p->coord_kind != BT_F32 && p->coord_kind != BT_F64)) {
+        set_error("bt_traversal_build: bad dims/coord_kind");
+        return BT_ERR_INVALID;
+    }
+    if (p->sources_have_extent) {
+        set_error("trees with source extent are not supported for traversal generation");
+        return BT_ERR_UNSUPPORTED;                       // traversal.py:2002-2006
+    }
+    if (p->nlevels < 1 || p->nlevels > 32 || p->nboxes < 1 || !p->level_start_box_nrs) {
+        set_error("bt_traversal_build: bad nlevels/nboxes");
+        return BT_ERR_INVALID;
+    }
+    if (p->well_sep_is_n_away < 1) {
+        set_error("well_sep_is_n_away must be >= 1");
+        return BT_ERR_INVALID;
+    }
+    if (!p->box_centers || !p->box_levels || !p->box_child_ids || !p->box_flags || !p->box_parent_ids) {
+        set_error("bt_traversal_build: NULL tree array");
+        return BT_ERR_INVALID;
+    }
+    if (p->targets_have_extent && (!p->box_target_bounding_box_min || !p->box_target_bounding_box_max
+                                   || !p->box_source_counts_cumul)) {
+        set_error("bt_traversal_build: target-extent trees need the target bounding boxes "
+                  "and box_source_counts_cumul");
+        return BT_ERR_INVALID;
+    }
+    bt_free_trav_state(ctx);
+    TravState *st = new TravState();
+    ctx->trav = st;
+    st->p = *p;
+    st->nlevels = p->nlevels;
+    int s = BT_ERR_INVALID;
+    const bool f64 = p->coord_kind == BT_F64;
+    switch (p->dims) {
+    case 1: s = f64 ? trav_build_impl<double, 1>(ctx, st, out) : trav_build_impl<float, 1>(ctx, st, out); break;
+    case 2: s = f64 ? trav_build_impl<double, 2>(ctx, st, out) : trav_build_impl<float, 2>(ctx, st, out); break;
+    case 3: s = f64 ? trav_build_impl<double, 3>(ctx, st, out) : trav_build_impl<float, 3>(ctx, st, out); break;
+    }
+    if (s != BT_OK) { (void) hipStreamSynchronize(ctx->stream); bt_free_trav_state(ctx); }
+    return s;
+}
+
+int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
+{
+    if (!ctx || !o) { set_error("bt_traversal_export: NULL argument"); return BT_ERR_INVALID; }
+    TravState *st = ctx->trav;
+    if (!st || !st->built) {
+        set_error("bt_traversal_export: no traversal has been built on this context");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    const int nl = st->nlevels;
+    BT_CHECK(copy_i32(ctx, o->source_boxes, st->source_boxes.get(), st->nsb));
+    if (!st->p.sources_are_targets)
+        BT_CHECK(copy_i32(ctx, o->target_boxes, st->target_boxes, st->ntb));
+    BT_CHECK(copy_i32(ctx, o->source_parent_boxes, st->source_parent_boxes.get(), st->nspb));
+    BT_CHECK(copy_i32(ctx, o->target_or_target_parent_boxes, st->ttp_boxes.get(), st->nttp));
+    BT_CHECK(copy_i32(ctx, o->level_start_source_box_nrs, st->lev_starts.get() + 0 * (nl + 1), nl + 1));
+    BT_CHECK(copy_i32(ctx, o->level_start_target_box_nrs, st->lev_starts.get() + 1 * (nl + 1), nl + 1));
+    BT_CHECK(copy_i32(ctx, o->level_start_source_parent_box_nrs, st->lev_starts.get() + 2 * (nl + 1), nl + 1));
+    BT_CHECK(copy_i32(ctx, o->level_start_target_or_target_parent_box_nrs,
+                      st->lev_starts.get() + 3 * (nl + 1), nl + 1));
+    auto put = [&](const CsrList &c, int32_t *starts, int32_t *lists) -> int {
+        BT_CHECK(copy_i32(ctx, starts, c.starts.get(), c.n + 1));
+        BT_CHECK(copy_i32(ctx, lists, c.lists.get(), c.total));
+        return BT_OK;
+    };
+    BT_CHECK(put(st->coll, o->same_level_non_well_sep_boxes_starts, o->same_level_non_well_sep_boxes_lists));
+    BT_CHECK(put(st->l1, o->neighbor_source_boxes_starts, o->neighbor_source_boxes_lists));
+    BT_CHECK(put(st->l2, o->from_sep_siblings_starts, o->from_sep_siblings_lists));
+    BT_CHECK(put(st->l4, o->from_sep_bigger_starts, o->from_sep_bigger_lists));
+    if (st->with_extent) {
+        BT_CHECK(put(st->close_smaller, o->from_sep_close_smaller_starts, o->from_sep_close_smaller_lists));
+        BT_CHECK(put(st->close_bigger, o->from_sep_close_bigger_starts, o->from_sep_close_bigger_lists));
+    }
+    const int64_t ntb = st->ntb;
+    for (int l = 0; l < nl; ++l) {
+        if (!o->from_sep_smaller_starts[l]) {
+            set_error("bt_traversal_export: NULL list-3 output for level %d", l);
+            return BT_ERR_INVALID;
+        }
+        BT_CHECK(copy_i32(ctx, o->from_sep_smaller_lists[l],
+                          st->l3_lists.get() + st->l3_level_base[l], st->l3_level_count[l]));
+        l3_compress_kernel<<<nblk(ntb + 1), 256, 0, ctx->stream>>>(
+            (int32_t) ntb, st->l3_starts.get() + (int64_t) l * ntb, (int32_t) st->l3_level_base[l],
+            st->l3_cidx.get() + (int64_t) l * (ntb + 1), st->target_boxes,
+            o->from_sep_smaller_starts[l], o->from_sep_smaller_nonempty_indices[l],
+            o->from_sep_smaller_compressed_indices[l], o->target_boxes_sep_smaller[l],
+            (int32_t) st->l3_level_count[l]);
+    }
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1140 @@
+// Tree build for gfx950: bounding box, Morton keys, sort-first box construction,
+// within-box order fix-up, source/target split, coordinate gather, flags and
+// box extents.  Produces arrays bit-identical to the reference's level loop
+// (boxtree/tree_build.py:145-1878, boxtree/tree_build_kernels.py) -- see
+// DESIGN.md for the equivalence argument.
+//
+// Sort-first formulation.  Per particle one 64-bit composite key
+//     K = (Kt << CAPBITS) | cap
+// Kt  = Morton path of the particle (d bits per level, level 1 most significant,
+//       x most significant inside a digit: tbk:441-445), truncated (zeroed)
+//       below level `cap`,
+// cap = deepest level the particle may descend to: one less than the first
+//       level whose box it sticks out of (tbk:388-428); = L without extents.
+// A stable LSD radix sort by K starting from user order places every box's
+// particles contiguously, a box's own ("non-child") particles before its
+// children (tbk:163), children in Morton order.  Boxes are then carved out of
+// the sorted key array level by level with binary searches (work ~ #boxes, not
+// #particles x #levels as in the reference).
+#include "bt_common.hpp"
+#include "bt_prims.hpp"
+#include "bt_sort.hpp"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+
+using namespace bt;
+
+namespace {
+
+constexpr int CAPBITS_EXT = 5;
+
+template <class T> struct CoordTraits;
+template <> struct CoordTraits<float> { static constexpr float maxval = 3.402823466e+38f; };
+template <> struct CoordTraits<double> { static constexpr double maxval = 1.7976931348623158e+308; };
+
+// ---------------------------------------------------------------------------
+// bounding box (bounding_box.py:54-122)
+// ---------------------------------------------------------------------------
+
+constexpr int BBOX_THREADS = 256;
+
+template <class T>
+__global__ __launch_bounds__(BBOX_THREADS) void bbox_kernel(const T *__restrict__ x,
+        const T *__restrict__ radii, int64_t n, T *partial /* [2*gridDim.x] */)
+{
+    __shared__ T s_mn[BBOX_THREADS / 64], s_mx[BBOX_THREADS / 64];
+    T mn = CoordTraits<T>::maxval, mx = -CoordTraits<T>::maxval;
+    const int64_t stride = (int64_t) gridDim.x * BBOX_THREADS;
+    for (int64_t i = (int64_t) blockIdx.x * BBOX_THREADS + threadIdx.x; i < n; i += stride) {
+        const T r = radii ? radii[i] : (T) 0;
+        const T c = x[i];
+        const T lo = c - r, hi = c + r;
+        mn = (lo < mn) ? lo : mn;
+        mx = (hi > mx) ? hi : mx;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const T omn = __shfl_xor(mn, off, 64), omx = __shfl_xor(mx, off, 64);
+        mn = (omn < mn) ? omn : mn;
+        mx = (omx > mx) ? omx : mx;
+    }
+    if (lane_id() == 0) { s_mn[threadIdx.x >> 6] = mn; s_mx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BBOX_THREADS / 64; ++w) {
+            mn = (s_mn[w] < mn) ? s_mn[w] : mn;
+            mx = (s_mx[w] > mx) ? s_mx[w] : mx;
+        }
+        partial[2 * blockIdx.x] = mn;
+        partial[2 * blockIdx.x + 1] = mx;
+    }
+}
+
+template <class T>
+int bbox_impl(bt_context *ctx, int dims, const void *const *coords, const void *radii,
+              int64_t n, double *out_min, double *out_max)
+{
+    for (int d = 0; d < dims; ++d) {
+        out_min[d] = (double) CoordTraits<T>::maxval;
+        out_max[d] = -(double) CoordTraits<T>::maxval;
+    }
+    if (n == 0) return BT_OK;
+    int64_t blocks = std::min<int64_t>(div_up(n, BBOX_THREADS * 8), (int64_t) ctx->num_cus * 8);
+    Buf<T> partial;
+    BT_CHECK(partial.alloc(ctx->pool, 2 * blocks * dims));
+    for (int d = 0; d < dims; ++d)
+        bbox_kernel<T><<<(unsigned) blocks, BBOX_THREADS, 0, ctx->stream>>>(
+            (const T *) coords[d], (const T *) radii, n, partial.get() + 2 * blocks * d);
+    BT_HIP_CHECK(hipGetLastError());
+    std::vector<T> h((size_t) (2 * blocks * dims));
+    BT_HIP_CHECK(hipMemcpyAsync(h.data(), partial.get(), h.size() * sizeof(T),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int d = 0; d < dims; ++d) {
+        T mn = CoordTraits<T>::maxval, mx = -CoordTraits<T>::maxval;
+        for (int64_t b = 0; b < blocks; ++b) {
+            T a = h[(size_t) (2 * blocks * d + 2 * b)], c = h[(size_t) (2 * blocks * d + 2 * b + 1)];
+            mn = (a < mn) ? a : mn;
+            mx = (c > mx) ? c : mx;
+        }
+        out_min[d] = (double) mn;
+        out_max[d] = (double) mx;
+    }
+    return BT_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Morton keys (tbk:308-470)
+// ---------------------------------------------------------------------------
+
+template <int D> __device__ __forceinline__ uint64_t spread_bits(uint32_t v);
+template <> __device__ __forceinline__ uint64_t spread_bits<1>(uint32_t v) { return v; }
+template <> __device__ __forceinline__ uint64_t spread_bits<2>(uint32_t v)
+{
+    uint64_t x = v;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+template <> __device__ __forceinline__ uint64_t spread_bits<3>(uint32_t v)
+{
+    uint64_t x = v & 0x1fffffu;
+    x = (x | (x << 32)) & 0x1f00000000ffffull;
+    x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+    x = (x | (x << 8)) & 0x100f00f00f00f00full;
+    x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+    x = (x | (x << 2)) & 0x1249249249249249ull;
+    return x;
+}
+
+template <class T, int D>
+struct KeygenArgs {
+    const T *src[D];
+    const T *tgt[D];
+    const T *src_radii;
+    const T *tgt_radii;
+    int64_t nsources, n;
+    T bbox_min[D], bbox_max[D];
+    T stick_out_factor;
+    int L;          // levels in the key
+    int norm;       // BT_NORM_*
+};
+
+template <class T, int D, bool EXT>
+__global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_t *__restrict__ keys)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const bool is_src = i < a.nsources;
+    const int64_t j = is_src ? i : i - a.nsources;
+
+    T x[D], gmin[D], gext[D];
+    uint32_t v[D];
+    const int L = a.L;
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        x[ax] = is_src ? a.src[ax][j] : a.tgt[ax][j];
+        gmin[ax] = a.bbox_min[ax];                              // tbk:358
+        gext[ax] = a.bbox_max[ax] - gmin[ax];                   // tbk:359
+        // tbk:374-376 evaluated at the deepest level; scaling by 2^k is exact,
+        // so (v >> (L-l)) is the reference's level-l value.
+        v[ax] = (uint32_t) (((x[ax] - gmin[ax]) / gext[ax]) * (T) (1u << L));
+    }
+
+    int cap = L;
+    if (EXT) {
+        T radius = (T) 0;
+        if (is_src) { if (a.src_radii) radius = a.src_radii[j]; }
+        else        { if (a.tgt_radii) radius = a.tgt_radii[j]; }
+        const T one_half = ((T) 1) / 2;
+        const T brf = (T) ((1. + (double) a.stick_out_factor) * (double) one_half);   // tbk:342-346
+        for (int l = 1; l <= L; ++l) {
+            const T size_factor = ((T) 1) / ((T) (1u << l));    // tbk:328-329
+            bool stop = false;
+            T center[D];
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) {
+                const uint32_t bits = v[ax] >> (L - l);
+                center[ax] = gmin[ax] + gext[ax] * ((T) bits + one_half) * size_factor;  // tbk:380-384
+            }
+            if (a.norm == BT_NORM_LINF) {
+#pragma unroll
+                for (int ax = 0; ax < D; ++ax) {
+                    const T sor = brf * gext[ax] * size_factor;                // tbk:390-393
+                    stop = stop || (x[ax] + radius >= center[ax] + sor);       // tbk:396-399
+                    stop = stop || (x[ax] - radius < center[ax] - sor);        // tbk:400-403
+                }
+            } else {
+                const T sor = brf * gext[0] * size_factor;                     // tbk:408-411
+                T sumsq = (T) 0;
+#pragma unroll
+                for (int ax = 0; ax < D; ++ax) {
+                    const T t = (x[ax] - center[ax]) * (x[ax] - center[ax]);
+                    sumsq = (ax == 0) ? t : sumsq + t;
+                }
+                const T dist = sqrt(sumsq) + radius;                           // tbk:413-419
+                stop = stop || (dist * dist >= D * sor * sor);                 // tbk:422-428
+            }
+            if (stop) { cap = l - 1; break; }
+        }
+    }
+
+    uint64_t kt = 0;
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        const uint32_t m = (L >= 32) ? v[ax] : (v[ax] & ((1u << L) - 1u));
+        kt |= spread_bits<D>(m) << (D - 1 - ax);                              // tbk:441-445
+    }
+    if (EXT) {
+        const int drop = D * (L - cap);
+        if (drop > 0) kt = (drop >= 64) ? 0 : (kt >> drop) << drop;
+        keys[i] = (kt << CAPBITS_EXT) | (uint64_t) cap;
+    } else {
+        keys[i] = kt;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// box construction from the sorted keys
+// ---------------------------------------------------------------------------
+
+__device__ __forceinline__ int lower_bound_key(const uint64_t *k, int lo, int hi, uint64_t v)
+{
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (k[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ int upper_bound_key(const uint64_t *k, int lo, int hi, uint64_t v)
+{
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if (k[mid] <= v) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+struct LevelFlags {
+    int32_t total_new;      // written by the scan
+    int32_t have_oversize;  // tbk:600-610
+};
+
+struct BuildArgs {
+    const uint64_t *keys;
+    const int64_t *wprefix;     // [N+1] or null (unit weights)
+    int32_t *box_start, *box_count, *box_parent, *box_nonchild, *box_child;
+    uint8_t *box_level, *box_haschild;
+    int32_t *bounds;            // [nprev][C+1]
+    int32_t *nnew;              // [nprev]
+    const int32_t *offsets;     // [nprev] exclusive scan of nnew
+    LevelFlags *flags;
+    DeviceStatus *status;
+    int32_t max_weight;
+    int level;                  // level being built
+    int L, capbits;
+    int b0, nprev;              // boxes of level-1: [b0, b0+nprev)
+    int new_level_start;
+    int adaptive;
+};
+
+__device__ __forceinline__ int32_t range_weight(const BuildArgs &a, int lo, int hi)
+{
+    if (!a.wprefix) return hi - lo;
+    const int64_t w = a.wprefix[hi] - a.wprefix[lo];
+    return (w > (int64_t) INT_MAX) ? INT_MAX : (int32_t) w;     // my_add_sat, tbk:270-274
+}
+
+// one thread per (box of level-1, child morton number)
+template <int D, bool EXT>
+__global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
+{
+    constexpr int C = 1 << D;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int bl = t / C, m = t % C;
+    const bool active = bl < a.nprev;
+    const int b = a.b0 + (active ? bl : 0);
+    const int l = a.level;
+
+    int lo = 0, e = 0, s = 0;
+    if (active) {
+        s = a.box_start[b];
+        e = s + a.box_count[b];
+        if (l - 1 < a.L && e > s) {
+            const int pshift = a.capbits + D * (a.L - (l - 1));
+            const uint64_t prefix = (pshift >= 64) ? 0 : (a.keys[s] >> pshift);
+            const int cshift = a.capbits + D * (a.L - l);
+            if (m == 0) {
+                if (EXT) {
+                    // own (stuck) particles: Kt == prefix000.., cap == l-1
+                    const uint64_t stuck = ((prefix << D) << cshift) | (uint64_t) (l - 1);
+                    lo = upper_bound_key(a.keys, s, e, stuck);
+                } else {
+                    lo = s;
+                }
+            } else {
+                const uint64_t ck = ((prefix << D) | (uint64_t) m) << cshift;
+                lo = lower_bound_key(a.keys, s, e, ck);
+            }
+        } else {
+            lo = (m == 0) ? s : e;
+        }
+    }
+    // children boundaries across the C lanes of the group
+    int hi = __shfl_down(lo, 1, C);
+    if (m == C - 1) hi = e;
+    const int first = __shfl(lo, 0, C);     // start of the child-bound range
+    if (!active) return;
+
+    const int32_t W = range_weight(a, first, e);                 // tbk:569-573
+    bool split;
+    if (a.adaptive) split = W > a.max_weight;                    // tbk:577-591
+    else split = true;
+    if (l - 1 >= a.L) {
+        if (split && e > s && (a.adaptive || W > a.max_weight)) {
+            if (m == 0) atomicExch(&a.status->max_levels, 1);
+        }
+        split = false;
+    }
+    if (e == s) split = false;   // (pruned trees have no empty boxes)
+
+    const int cnt = hi - lo;
+    const bool nonempty = split && cnt > 0;
+    const uint64_t bal = __ballot(nonempty);
+    const int gshift = (threadIdx.x & 63) / C * C;
+    const uint32_t gmask = (uint32_t) ((bal >> gshift) & ((1ull << C) - 1));
+    if (split && range_weight(a, lo, hi) > a.max_weight)         // tbk:600-610
+        atomicExch(&a.flags->have_oversize, 1);
+
+    a.bounds[(int64_t) bl * (C + 1) + m] = lo;
+    if (m == 0) {
+        a.bounds[(int64_t) bl * (C + 1) + C] = e;
+        a.nnew[bl] = split ? __popc(gmask) : 0;
+        a.box_haschild[b] = split ? 1 : 0;
+        a.box_nonchild[b] = split ? (first - s) : 0;
+    }
+}
+
+template <class T, int D>
+__global__ __launch_bounds__(256) void write_children_kernel(BuildArgs a, T *centers /* [cap][D] */,
+                                                            T root_extent)
+{
+    constexpr int C = 1 << D;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int bl = t / C, m = t % C;
+    const bool active = bl < a.nprev;
+    const int b = a.b0 + (active ? bl : 0);
+    const bool split = active && a.box_haschild[b];
+    int lo = 0, hi = 0;
+    if (split) {
+        lo = a.bounds[(int64_t) bl * (C + 1) + m];
+        hi = a.bounds[(int64_t) bl * (C + 1) + m + 1];
+    }
+    const bool nonempty = split && hi > lo;
+    const uint64_t bal = __ballot(nonempty);
+    if (!active) return;
+    const int gshift = (threadIdx.x & 63) / C * C;
+    const uint32_t gmask = (uint32_t) ((bal >> gshift) & ((1ull << C) - 1));
+    const int rank = __popc(gmask & ((1u << m) - 1u));
+
+    int32_t child_id = 0;
+    if (nonempty) {
+        child_id = a.new_level_start + a.offsets[bl] + rank;     // tbk:667 (after pruning)
+        a.box_start[child_id] = lo;
+        a.box_count[child_id] = hi - lo;
+        a.box_parent[child_id] = b;
+        a.box_level[child_id] = (uint8_t) a.level;
+        a.box_haschild[child_id] = 0;
+        a.box_nonchild[child_id] = 0;
+        // tbk:698-705: centre = parent centre +/- root_extent / 2^(1+level)
+        const T radius = (root_extent * 1 / (T) (1ull << (1 + a.level)));
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) {
+            const bool has_bit = (m >> (D - 1 - ax)) & 1;
+            const T pc = centers[(int64_t) b * D + ax];
+            centers[(int64_t) child_id * D + ax] = has_bit ? pc + radius : pc - radius;
+        }
+#pragma unroll
+        for (int mm = 0; mm < C; ++mm) a.box_child[(int64_t) child_id * C + mm] = 0;
+    }
+    a.box_child[(int64_t) b * C + m] = child_id;
+}
+
+struct ScanNnew {
+    const int32_t *nnew;
+    __device__ int32_t operator()(int64_t i) const { return nnew[i]; }
+};
+
+struct GatherWeight {
+    const int32_t *w;
+    const uint32_t *ids;
+    __device__ int64_t operator()(int64_t i) const { return (int64_t) w[ids[i]]; }
+};
+
+// ---------------------------------------------------------------------------
+// within-box order fix-up: key = start of the owning segment, scattered to
+// user order; a stable sort of (key, 0..N-1) then yields the reference's
+// "ascending user id inside every box" order (tbk:776-790 is stable).
+// ---------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void segment_key_kernel(int nboxes, const int32_t *box_start,
+        const int32_t *box_count, const int32_t *box_nonchild, const uint8_t *box_haschild,
+        const uint32_t *ids, uint32_t *fix_key /* [N], user order */)
+{
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 4;   // 16 lanes per box
+    const int l16 = threadIdx.x & 15;
+    if (g >= nboxes) return;
+    const int s = box_start[g];
+    const int n = box_haschild[g] ? box_nonchild[g] : box_count[g];
+    for (int p = s + l16; p < s + n; p += 16) fix_key[ids[p]] = (uint32_t) s;
+}
+
+// ---------------------------------------------------------------------------
+// sources / targets (tbk:1013-1164, 1770-1782; tools.py:81-109)
+// ---------------------------------------------------------------------------
+
+struct IsSource {
+    const uint32_t *ids;
+    uint32_t nsources;
+    __device__ int32_t operator()(int64_t i) const { return ids[i] < nsources ? 1 : 0; }
+};
+
+__global__ __launch_bounds__(256) void split_ids_kernel(int64_t n, const uint32_t *ids,
+        const int32_t *src_prefix, uint32_t nsources, int32_t *user_source_ids,
+        int32_t *srcntgt_target_ids, int32_t *sorted_target_ids)
+{
+    const int64_t p = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t id = ids[p];
+    const int32_t source_nr = src_prefix[p];
+    if (id < nsources) {
+        user_source_ids[source_nr] = (int32_t) id;
+    } else {
+        const int32_t target_nr = (int32_t) p - source_nr;
+        srcntgt_target_ids[target_nr] = (int32_t) id;
+        sorted_target_ids[id - nsources] = target_nr;
+    }
+}
+
+__global__ __launch_bounds__(256) void same_ids_kernel(int64_t n, const uint32_t *ids,
+        int32_t *user_source_ids, int32_t *sorted_target_ids)
+{
+    const int64_t p = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t id = ids[p];
+    user_source_ids[p] = (int32_t) id;
+    sorted_target_ids[id] = (int32_t) p;       // reverse_index_array, tools.py:81-109
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void gather_kernel(int64_t n, const int32_t *from_ids,
+        int32_t id_offset, const T *__restrict__ in, T *__restrict__ out)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = in[from_ids[i] - id_offset];      // tbk:1170-1186
+}
+
+// ---------------------------------------------------------------------------
+// per-box outputs: counts, flags (tbk:1192-1305), repack (tree_build.py:1636-1664)
+// ---------------------------------------------------------------------------
+
+struct BoxInfoArgs {
+    int nboxes;
+    int64_t aligned;
+    int C, D;
+    int sat, have_extent;
+    const int32_t *box_start, *box_count, *box_parent, *box_nonchild, *box_child;
+    const uint8_t *box_level, *box_haschild;
+    const int32_t *src_prefix;     // [N+1] or null when sat
+    int32_t *o_src_starts, *o_src_nonchild, *o_src_cumul;
+    int32_t *o_tgt_starts, *o_tgt_nonchild, *o_tgt_cumul;
+    int32_t *o_parent, *o_child;
+    uint8_t *o_levels, *o_flags;
+};
+
+__global__ __launch_bounds__(256) void box_info_kernel(BoxInfoArgs a)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= a.nboxes) return;
+    const int s = a.box_start[b], cnt = a.box_count[b];
+    const int haschild = a.box_haschild[b];
+    const int n0 = a.box_nonchild[b];      // own particles of a split box (0 w/o extents)
+    int32_t src_start, src_cumul, tgt_start, tgt_cumul, src_nc, tgt_nc;
+    if (a.sat) {
+        src_start = tgt_start = s;
+        src_cumul = tgt_cumul = cnt;
+        src_nc = tgt_nc = haschild ? n0 : cnt;
+    } else {
+        const int32_t S0 = a.src_prefix[s], S1 = a.src_prefix[s + cnt];
+        src_start = S0; tgt_start = s - S0;
+        src_cumul = S1 - S0; tgt_cumul = cnt - src_cumul;
+        if (haschild) {
+            const int32_t Sn = a.src_prefix[s + n0];
+            src_nc = Sn - S0; tgt_nc = n0 - src_nc;
+        } else {
+            src_nc = src_cumul; tgt_nc = tgt_cumul;
+        }
+    }
+    uint8_t flags = 0;
+    if (haschild) {
+        flags |= BT_BOX_HAS_SOURCE_CHILD_BOXES | BT_BOX_HAS_TARGET_CHILD_BOXES;   // tbk:1252-1256
+        if (src_nc) flags |= BT_BOX_IS_SOURCE_BOX;
+        if (tgt_nc) flags |= BT_BOX_IS_TARGET_BOX;
+    } else {
+        if (src_cumul) flags |= BT_BOX_IS_SOURCE_BOX;
+        if (tgt_cumul) flags |= BT_BOX_IS_TARGET_BOX;
+    }
+    a.o_src_starts[b] = src_start; a.o_src_cumul[b] = src_cumul; a.o_src_nonchild[b] = src_nc;
+    if (!a.sat) {
+        a.o_tgt_starts[b] = tgt_start; a.o_tgt_cumul[b] = tgt_cumul; a.o_tgt_nonchild[b] = tgt_nc;
+    }
+    a.o_parent[b] = a.box_parent[b];
+    a.o_levels[b] = a.box_level[b];
+    a.o_flags[b] = flags;
+    for (int m = 0; m < a.C; ++m)
+        a.o_child[(int64_t) m * a.aligned + b] = a.box_child[(int64_t) b * a.C + m];
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void repack_centers_kernel(int nboxes, int64_t aligned, int D,
+        const T *centers, T *o_centers)
+{
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nboxes) return;
+    for (int ax = 0; ax < D; ++ax) o_centers[(int64_t) ax * aligned + b] = centers[(int64_t) b * D + ax];
+}
+
+// box extents: tbk:1311-1399, one 16-lane group per box of one level
+template <class T, int D>
+struct ExtentArgs {
+    int b0, nb;
+    int64_t aligned;
+    const int32_t *starts, *counts_nonchild, *child /* [C][aligned] */;
+    const T *centers /* [D][aligned] */;
+    const T *part[D];
+    const T *radii;          // null if disabled
+    T *bmin, *bmax;          // [D][aligned]
+};
+
+template <class T, int D>
+__global__ __launch_bounds__(256) void box_extent_kernel(ExtentArgs<T, D> a)
+{
+    constexpr int C = 1 << D;
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int l16 = threadIdx.x & 15;
+    const bool active = g < a.nb;
+    const int b = a.b0 + (active ? g : 0);
+    T mn[D], mx[D];
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) mn[ax] = mx[ax] = a.centers[(int64_t) ax * a.aligned + b];
+    if (active) {
+        const int s = a.starts[b], e = s + a.counts_nonchild[b];
+        for (int p = s + l16; p < e; p += 16) {
+            const T r = a.radii ? a.radii[p] : (T) 0;
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) {
+                const T c = a.part[ax][p];
+                const T lo = c - r, hi = c + r;
+                mn[ax] = (lo < mn[ax]) ? lo : mn[ax];
+                mx[ax] = (hi > mx[ax]) ? hi : mx[ax];
+            }
+        }
+        if (l16 < C) {
+            const int32_t ch = a.child[(int64_t) l16 * a.aligned + b];
+            if (ch != 0) {
+#pragma unroll
+                for (int ax = 0; ax < D; ++ax) {
+                    const T lo = a.bmin[(int64_t) ax * a.aligned + ch];
+                    const T hi = a.bmax[(int64_t) ax * a.aligned + ch];
+                    mn[ax] = (lo < mn[ax]) ? lo : mn[ax];
+                    mx[ax] = (hi > mx[ax]) ? hi : mx[ax];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) {
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) {
+            const T omn = __shfl_xor(mn[ax], off, 16), omx = __shfl_xor(mx[ax], off, 16);
+            mn[ax] = (omn < mn[ax]) ? omn : mn[ax];
+            mx[ax] = (omx > mx[ax]) ? omx : mx[ax];
+        }
+    }
+    if (active && l16 == 0) {
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) {
+            a.bmin[(int64_t) ax * a.aligned + b] = mn[ax];
+            a.bmax[(int64_t) ax * a.aligned + b] = mx[ax];
+        }
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+
+struct TreeState {
+    bt_tree_params p{};
+    int D = 0, C = 0, L = 0, capbits = 0;
+    bool f64 = true, sat = true, have_extent = false;
+    int64_t N = 0, nsources = 0, ntargets = 0;
+    int64_t nboxes = 0, cap = 0;
+    std::vector<int32_t> level_start;
+
+    Buf<uint64_t> keys_a, keys_b;
+    Buf<uint32_t> ids_a, ids_b;
+    uint32_t *ids = nullptr;           // final tree order -> user srcntgt id
+    Buf<int64_t> wprefix;
+    Buf<int32_t> src_prefix;           // [N+1] (separate targets only)
+    Buf<int32_t> srcntgt_target_ids;   // [ntargets]
+
+    Buf<int32_t> box_start, box_count, box_parent, box_nonchild, box_child;
+    Buf<uint8_t> box_level, box_haschild;
+    Buf<unsigned char> centers;        // [cap][D] of coord type
+
+    std::vector<std::pair<const char *, hipEvent_t>> events;
+    bool built = false;
+};
+
+void bt_free_tree_state(bt_context *ctx)
+{
+    if (ctx->tree) {
+        for (auto &e : ctx->tree->events) (void) hipEventDestroy(e.second);
+        delete ctx->tree;
+        ctx->tree = nullptr;
+    }
+}
+
+namespace {
+
+int mark(bt_context *ctx, TreeState *st, const char *name)
+{
+    hipEvent_t e;
+    BT_HIP_CHECK(hipEventCreate(&e));
+    BT_HIP_CHECK(hipEventRecord(e, ctx->stream));
+    st->events.push_back({name, e});
+    return BT_OK;
+}
+
+template <class U>
+int grow(bt_context *ctx, Buf<U> &buf, int64_t old_n, int64_t new_n, bool zero)
+{
+    Buf<U> nb;
+    BT_CHECK(nb.alloc(ctx->pool, new_n));
+    if (zero) BT_HIP_CHECK(hipMemsetAsync(nb.get(), 0, (size_t) new_n * sizeof(U), ctx->stream));
+    if (old_n > 0 && buf.get())
+        BT_HIP_CHECK(hipMemcpyAsync(nb.get(), buf.get(), (size_t) old_n * sizeof(U),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    buf.swap(nb);
+    return BT_OK;
+}
+
+int ensure_box_capacity(bt_context *ctx, TreeState *st, int64_t need, size_t coord_size)
+{
+    if (need <= st->cap) return BT_OK;
+    int64_t nc = std::max<int64_t>(st->cap * 2, 1024);
+    while (nc < need) nc *= 2;
+    const int64_t old = st->nboxes;
+    BT_CHECK(grow(ctx, st->box_start, old, nc, false));
+    BT_CHECK(grow(ctx, st->box_count, old, nc, false));
+    BT_CHECK(grow(ctx, st->box_parent, old, nc, false));
+    BT_CHECK(grow(ctx, st->box_nonchild, old, nc, true));
+    BT_CHECK(grow(ctx, st->box_child, old * st->C, nc * st->C, true));
+    BT_CHECK(grow(ctx, st->box_level, old, nc, false));
+    BT_CHECK(grow(ctx, st->box_haschild, old, nc, true));
+    BT_CHECK(grow(ctx, st->centers, old * st->D * (int64_t) coord_size,
+                  nc * st->D * (int64_t) coord_size, false));
+    st->cap = nc;
+    return BT_OK;
+}
+
+template <class T, int D>
+int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
+{
+    constexpr int C = 1 << D;
+    const bt_tree_params &p = st->p;
+    const int64_t N = st->N;
+    const bool EXT = st->have_extent;
+
+    BT_CHECK(mark(ctx, st, "start"));
+
+    // ---- keys ----------------------------------------------------------------
+    BT_CHECK(st->keys_a.alloc(ctx->pool, N));
+    BT_CHECK(st->keys_b.alloc(ctx->pool, N));
+    BT_CHECK(st->ids_a.alloc(ctx->pool, N));
+    BT_CHECK(st->ids_b.alloc(ctx->pool, N));
+    if (N > 0) {
+        KeygenArgs<T, D> ka;
+        for (int ax = 0; ax < D; ++ax) {
+            ka.src[ax] = (const T *) p.sources[ax];
+            ka.tgt[ax] = (const T *) p.targets[ax];
+            ka.bbox_min[ax] = (T) p.bbox_min[ax];
+            ka.bbox_max[ax] = (T) p.bbox_max[ax];
+        }
+        ka.src_radii = (const T *) p.source_radii;
+        ka.tgt_radii = (const T *) p.target_radii;
+        ka.nsources = st->nsources;
+        ka.n = N;
+        ka.stick_out_factor = (T) p.stick_out_factor;
+        ka.L = st->L;
+        ka.norm = p.extent_norm;
+        const unsigned blocks = (unsigned) div_up(N, 256);
+        if (EXT) keygen_kernel<T, D, true><<<blocks, 256, 0, ctx->stream>>>(ka, st->keys_a.get());
+        else keygen_kernel<T, D, false><<<blocks, 256, 0, ctx->stream>>>(ka, st->keys_a.get());
+        BT_HIP_CHECK(hipGetLastError());
+    }
+    BT_CHECK(mark(ctx, st, "keygen"));
+
+    // ---- sort ----------------------------------------------------------------
+    const uint64_t *keys = st->keys_a.get();
+    uint32_t *ids = st->ids_a.get();
+    uint32_t *ids_other = st->ids_b.get();
+    if (N > 0) {
+        bool in_b = false;
+        const int keybits = D * st->L + st->capbits;
+        BT_CHECK(radix_sort_pairs<uint64_t>(ctx, st->keys_a.get(), st->ids_a.get(),
+                                            st->keys_b.get(), st->ids_b.get(), N, 0, keybits,
+                                            true, &in_b));
+        if (in_b) { keys = st->keys_b.get(); ids = st->ids_b.get(); ids_other = st->ids_a.get(); }
+    }
+    BT_CHECK(mark(ctx, st, "sort"));
+
+    // ---- refine-weight prefix sums (only with explicit weights) ---------------
+    if (p.refine_weights && N > 0) {
+        BT_CHECK(st->wprefix.alloc(ctx->pool, N + 1));
+        GatherWeight gw{p.refine_weights, ids};
+        BT_CHECK((device_exclusive_scan<int64_t, int64_t>(ctx, gw, N, st->wprefix.get(),
+                                                          (int64_t *) nullptr, true)));
+    }
+
+    // ---- boxes, level by level -------------------------------------------------
+    st->nboxes = 0;
+    st->cap = 0;
+    BT_CHECK(ensure_box_capacity(ctx, st, 1024, sizeof(T)));
+    {
+        // root box: tree_build.py:585-618
+        int32_t zero = 0, n32 = (int32_t) N;
+        T center[D];
+        for (int ax = 0; ax < D; ++ax) {
+            const T mn = (T) p.bbox_min[ax], mx = (T) p.bbox_max[ax];
+            center[ax] = mn + (mx - mn) / 2;
+        }
+        BT_HIP_CHECK(hipMemcpyAsync(st->box_start.get(), &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+        BT_HIP_CHECK(hipMemcpyAsync(st->box_count.get(), &n32, 4, hipMemcpyHostToDevice, ctx->stream));
+        BT_HIP_CHECK(hipMemcpyAsync(st->box_parent.get(), &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+        BT_HIP_CHECK(hipMemsetAsync(st->box_level.get(), 0, 1, ctx->stream));
+        BT_HIP_CHECK(hipMemcpyAsync(st->centers.get(), center, sizeof(T) * D, hipMemcpyHostToDevice,
+                                    ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // host temporaries go out of scope
+    }
+    st->nboxes = 1;
+    st->level_start = {0, 1};
+
+    Buf<LevelFlags> d_flags;
+    BT_CHECK(d_flags.alloc(ctx->pool, 1));
+    LevelFlags *h_flags = nullptr;
+    BT_HIP_CHECK(hipHostMalloc((void **) &h_flags, sizeof(LevelFlags), hipHostMallocDefault));
+    struct HostFree { LevelFlags *p; ~HostFree() { (void) hipHostFree(p); } } host_free{h_flags};
+
+    int level = 1;
+    while (N > 0) {
+        const int b0 = st->level_start[level - 1];
+        const int nprev = st->level_start[level] - b0;
+        Buf<int32_t> bounds, nnew, offsets;
+        BT_CHECK(bounds.alloc(ctx->pool, (int64_t) nprev * (C + 1)));
+        BT_CHECK(nnew.alloc(ctx->pool, nprev));
+        BT_CHECK(offsets.alloc(ctx->pool, nprev));
+        BT_HIP_CHECK(hipMemsetAsync(d_flags.get(), 0, sizeof(LevelFlags), ctx->stream));
+
+        BuildArgs a{};
+        a.keys = keys;
+        a.wprefix = st->wprefix.get();
+        a.box_start = st->box_start.get(); a.box_count = st->box_count.get();
+        a.box_parent = st->box_parent.get(); a.box_nonchild = st->box_nonchild.get();
+        a.box_child = st->box_child.get();
+        a.box_level = st->box_level.get(); a.box_haschild = st->box_haschild.get();
+        a.bounds = bounds.get(); a.nnew = nnew.get(); a.offsets = offsets.get();
+        a.flags = d_flags.get(); a.status = ctx->d_status;
+        a.max_weight = p.max_leaf_refine_weight;
+        a.level = level; a.L = st->L; a.capbits = st->capbits;
+        a.b0 = b0; a.nprev = nprev;
+        a.adaptive = p.kind != BT_KIND_NON_ADAPTIVE;
+
+        const unsigned blocks = (unsigned) div_up((int64_t) nprev * C, 256);
+        if (EXT) count_children_kernel<D, true><<<blocks, 256, 0, ctx->stream>>>(a);
+        else count_children_kernel<D, false><<<blocks, 256, 0, ctx->stream>>>(a);
+        ScanNnew sn{nnew.get()};
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, sn, nprev, offsets.get(),
+                                                          &d_flags.get()->total_new)));
+        BT_HIP_CHECK(hipMemcpyAsync(h_flags, d_flags.get(), sizeof(LevelFlags),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const int total_new = h_flags->total_new;
+        if (total_new == 0) break;                 // tree_build.py:1016-1025 / no split
+
+        const int64_t new_start = st->level_start[level];
+        BT_CHECK(ensure_box_capacity(ctx, st, new_start + total_new, sizeof(T)));
+        // pointers may have moved
+        a.box_start = st->box_start.get(); a.box_count = st->box_count.get();
+        a.box_parent = st->box_parent.get(); a.box_nonchild = st->box_nonchild.get();
+        a.box_child = st->box_child.get();
+        a.box_level = st->box_level.get(); a.box_haschild = st->box_haschild.get();
+        a.new_level_start = (int) new_start;
+        write_children_kernel<T, D><<<blocks, 256, 0, ctx->stream>>>(
+            a, (T *) st->centers.get(), (T) p.root_extent);
+        BT_HIP_CHECK(hipGetLastError());
+        st->nboxes = new_start + total_new;
+        st->level_start.push_back((int32_t) st->nboxes);
+        if (!h_flags->have_oversize) break;        // tree_build.py:1228-1230
+        level += 1;
+        if (level > st->L + 1) break;              // defensive; max_levels flag is set on device
+    }
+    BT_CHECK(check_status(ctx));
+    BT_CHECK(mark(ctx, st, "boxes"));
+
+    // ---- within-box order fix-up ----------------------------------------------
+    st->ids = ids;
+    if (N > 1) {
+        Buf<uint32_t> fk_a, fk_b;
+        BT_CHECK(fk_a.alloc(ctx->pool, N));
+        BT_CHECK(fk_b.alloc(ctx->pool, N));
+        segment_key_kernel<<<(unsigned) div_up(st->nboxes * 16, 256), 256, 0, ctx->stream>>>(
+            (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_nonchild.get(),
+            st->box_haschild.get(), ids, fk_a.get());
+        int bits = 1;
+        while (((int64_t) 1 << bits) < N) ++bits;
+        bool in_b = false;
+        // values: reuse the two id buffers; `ids` is consumed by segment_key_kernel
+        // (stream order) before the sort overwrites it.
+        uint32_t *va = ids_other, *vb = ids;
+        BT_CHECK(radix_sort_pairs<uint32_t>(ctx, fk_a.get(), va, fk_b.get(), vb, N, 0, bits,
+                                            true, &in_b));
+        st->ids = in_b ? vb : va;
+        BT_CHECK(check_status(ctx));
+    }
+    BT_CHECK(mark(ctx, st, "fixup"));
+
+    // keys are no longer needed
+    st->keys_a.reset();
+    st->keys_b.reset();
+    st->wprefix.reset();
+
+    // ---- source prefix (separate targets) ---------------------------------------
+    if (!st->sat) {
+        BT_CHECK(st->src_prefix.alloc(ctx->pool, N + 1));
+        IsSource is{st->ids, (uint32_t) st->nsources};
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, is, N, st->src_prefix.get(),
+                                                          (int32_t *) nullptr, true)));
+    }
+    BT_CHECK(mark(ctx, st, "srcscan"));
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+
+    out->nboxes = st->nboxes;
+    out->aligned_nboxes = div_up(st->nboxes, 32) * 32;
+    out->nlevels = (int32_t) st->level_start.size() - 1;
+    out->key_levels = st->L;
+    for (size_t i = 0; i < st->level_start.size() && i <= BT_MAX_LEVELS; ++i)
+        out->level_start_box_nrs[i] = st->level_start[i];
+    st->built = true;
+    return BT_OK;
+}
+
+template <class T, int D>
+int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
+{
+    constexpr int C = 1 << D;
+    const bt_tree_params &p = st->p;
+    const int64_t N = st->N, B = st->nboxes;
+    const int64_t aligned = div_up(B, 32) * 32;
+    const bool sat = st->sat;
+    auto blocks = [](int64_t n) { return (unsigned) std::max<int64_t>(1, div_up(n, 256)); };
+
+    // ---- ids -------------------------------------------------------------------
+    if (N > 0) {
+        if (sat) {
+            same_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(N, st->ids, o->user_source_ids,
+                                                              o->sorted_target_ids);
+        } else {
+            BT_CHECK(st->srcntgt_target_ids.alloc(ctx->pool, st->ntargets));
+            split_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(
+                N, st->ids, st->src_prefix.get(), (uint32_t) st->nsources, o->user_source_ids,
+                st->srcntgt_target_ids.get(), o->sorted_target_ids);
+        }
+    }
+    BT_CHECK(mark(ctx, st, "ids"));
+
+    // ---- coordinates and radii (tbk:1170-1186, tree_build.py:1569-1622) ----------
+    for (int ax = 0; ax < D; ++ax) {
+        if (st->nsources > 0)
+            gather_kernel<T><<<blocks(st->nsources), 256, 0, ctx->stream>>>(
+                st->nsources, o->user_source_ids, 0, (const T *) p.sources[ax], (T *) o->sources[ax]);
+        if (!sat && st->ntargets > 0)
+            gather_kernel<T><<<blocks(st->ntargets), 256, 0, ctx->stream>>>(
+                st->ntargets, st->srcntgt_target_ids.get(), (int32_t) st->nsources,
+                (const T *) p.targets[ax], (T *) o->targets[ax]);
+    }
+    if (p.source_radii && o->source_radii && st->nsources > 0)
+        gather_kernel<T><<<blocks(st->nsources), 256, 0, ctx->stream>>>(
+            st->nsources, o->user_source_ids, 0, (const T *) p.source_radii, (T *) o->source_radii);
+    if (p.target_radii && o->target_radii && st->ntargets > 0)
+        gather_kernel<T><<<blocks(st->ntargets), 256, 0, ctx->stream>>>(
+            st->ntargets, st->srcntgt_target_ids.get(), (int32_t) st->nsources,
+            (const T *) p.target_radii, (T *) o->target_radii);
+    BT_CHECK(mark(ctx, st, "gather"));
+
+    // ---- per-box arrays -----------------------------------------------------------
+    BT_HIP_CHECK(hipMemsetAsync(o->box_child_ids, 0, (size_t) (C * aligned) * 4, ctx->stream));
+    BT_HIP_CHECK(hipMemsetAsync(o->box_centers, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
+    {
+        BoxInfoArgs a{};
+        a.nboxes = (int) B; a.aligned = aligned; a.C = C; a.D = D;
+        a.sat = sat; a.have_extent = st->have_extent;
+        a.box_start = st->box_start.get(); a.box_count = st->box_count.get();
+        a.box_parent = st->box_parent.get(); a.box_nonchild = st->box_nonchild.get();
+        a.box_child = st->box_child.get(); a.box_level = st->box_level.get();
+        a.box_haschild = st->box_haschild.get();
+        a.src_prefix = st->src_prefix.get();
+        a.o_src_starts = o->box_source_starts; a.o_src_nonchild = o->box_source_counts_nonchild;
+        a.o_src_cumul = o->box_source_counts_cumul;
+        a.o_tgt_starts = o->box_target_starts; a.o_tgt_nonchild = o->box_target_counts_nonchild;
+        a.o_tgt_cumul = o->box_target_counts_cumul;
+        a.o_parent = o->box_parent_ids; a.o_child = o->box_child_ids;
+        a.o_levels = o->box_levels; a.o_flags = o->box_flags;
+        box_info_kernel<<<blocks(B), 256, 0, ctx->stream>>>(a);
+        repack_centers_kernel<T><<<blocks(B), 256, 0, ctx->stream>>>(
+            (int) B, aligned, D, (const T *) st->centers.get(), (T *) o->box_centers);
+    }
+    BT_CHECK(mark(ctx, st, "boxinfo"));
+
+    // ---- box extents, bottom-up (tree_build.py:1730-1806) ----------------------------
+    const int nlevels = (int) st->level_start.size() - 1;
+    for (int round = 0; round < 2; ++round) {
+        if (round == 1 && sat) continue;
+        T *bmin = (T *) (round == 0 ? o->box_source_bounding_box_min : o->box_target_bounding_box_min);
+        T *bmax = (T *) (round == 0 ? o->box_source_bounding_box_max : o->box_target_bounding_box_max);
+        BT_HIP_CHECK(hipMemsetAsync(bmin, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
+        BT_HIP_CHECK(hipMemsetAsync(bmax, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
+        for (int lev = nlevels - 1; lev >= 0; --lev) {
+            ExtentArgs<T, D> a;
+            a.b0 = st->level_start[lev];
+            a.nb = st->level_start[lev + 1] - a.b0;
+            a.aligned = aligned;
+            a.starts = round == 0 ? o->box_source_starts : o->box_target_starts;
+            a.counts_nonchild = round == 0 ? o->box_source_counts_nonchild
+                                           : o->box_target_counts_nonchild;
+            a.child = o->box_child_ids;
+            a.centers = (const T *) o->box_centers;
+            for (int ax = 0; ax < D; ++ax)
+                a.part[ax] = (const T *) (round == 0 ? o->sources[ax] : o->targets[ax]);
+            a.radii = (const T *) (round == 0 ? (p.source_radii ? o->source_radii : nullptr)
+                                              : (p.target_radii ? o->target_radii : nullptr));
+            a.bmin = bmin; a.bmax = bmax;
+            box_extent_kernel<T, D><<<blocks((int64_t) a.nb * 16), 256, 0, ctx->stream>>>(a);
+        }
+    }
+    BT_HIP_CHECK(hipGetLastError());
+    BT_CHECK(mark(ctx, st, "extents"));
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+template <class T>
+int dispatch_dims_build(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
+{
+    switch (st->D) {
+    case 1: return tree_build_impl<T, 1>(ctx, st, out);
+    case 2: return tree_build_impl<T, 2>(ctx, st, out);
+    case 3: return tree_build_impl<T, 3>(ctx, st, out);
+    }
+    return BT_ERR_INVALID;
+}
+
+template <class T>
+int dispatch_dims_export(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
+{
+    switch (st->D) {
+    case 1: return tree_export_impl<T, 1>(ctx, st, o);
+    case 2: return tree_export_impl<T, 2>(ctx, st, o);
+    case 3: return tree_export_impl<T, 3>(ctx, st, o);
+    }
+    return BT_ERR_INVALID;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bt_bbox(bt_context *ctx, int dims, int coord_kind, const void *const *coords,
+            const void *radii, int64_t n, double *out_min, double *out_max)
+{
+    if (!ctx || !coords || !out_min || !out_max || dims < 1 || dims > BT_MAX_DIMS || n < 0) {
+        set_error("bt_bbox: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (coord_kind == BT_F64) return bbox_impl<double>(ctx, dims, coords, radii, n, out_min, out_max);
+    if (coord_kind == BT_F32) return bbox_impl<float>(ctx, dims, coords, radii, n, out_min, out_max);
+    set_error("bt_bbox: unknown coord_kind %d", coord_kind);
+    return BT_ERR_INVALID;
+}
+
+int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
+{
+    if (!ctx || !p || !out) { set_error("bt_tree_build: NULL argument"); return BT_ERR_INVALID; }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    memset(out, 0, sizeof(*out));
+    if (p->dims < 1 || p->dims > BT_MAX_DIMS) {
+        set_error("bt_tree_build: dims must be 1..3 (got %d)", p->dims);
+        return BT_ERR_INVALID;
+    }
+    if (p->coord_kind != BT_F32 && p->coord_kind != BT_F64) {
+        set_error("bt_tree_build: unknown coord_kind %d", p->coord_kind);
+        return BT_ERR_INVALID;
+    }
+    if (p->kind == BT_KIND_ADAPTIVE_LEVEL_RESTRICTED) {
+        set_error("kind='adaptive-level-restricted' is not implemented yet");
+        return BT_ERR_UNSUPPORTED;
+    }
+    if (p->kind != BT_KIND_ADAPTIVE && p->kind != BT_KIND_NON_ADAPTIVE) {
+        set_error("unknown tree kind %d", p->kind);
+        return BT_ERR_INVALID;
+    }
+    if (p->skip_prune) {
+        set_error("skip_prune (unpruned trees) is not implemented");
+        return BT_ERR_UNSUPPORTED;
+    }
+    if (p->max_leaf_refine_weight <= 0) {
+        set_error("'max_leaf_refine_weight' must be positive");
+        return BT_ERR_INVALID;
+    }
+    const bool sat = p->ntargets < 0;
+    const bool have_extent = p->source_radii || p->target_radii;
+    if (have_extent && sat) {
+        set_error("must specify targets when specifying any kind of radii");
+        return BT_ERR_INVALID;
+    }
+    if (have_extent && p->extent_norm != BT_NORM_LINF && p->extent_norm != BT_NORM_L2) {
+        set_error("bad extent_norm %d", p->extent_norm);
+        return BT_ERR_INVALID;
+    }
+    const int64_t N = p->nsources + (sat ? 0 : p->ntargets);
+    if (p->nsources < 0 || N >= ((int64_t) 1 << 31)) {
+        set_error("particle count %lld outside [0, 2^31)", (long long) N);
+        return BT_ERR_INVALID;
+    }
+    for (int ax = 0; ax < p->dims; ++ax) {
+        if ((p->nsources > 0 && !p->sources[ax]) || (!sat && p->ntargets > 0 && !p->targets[ax])) {
+            set_error("bt_tree_build: NULL coordinate array");
+            return BT_ERR_INVALID;
+        }
+        if (!(p->bbox_max[ax] > p->bbox_min[ax]) && N > 0) {
+            set_error("bt_tree_build: empty bounding box on axis %d", ax);
+            return BT_ERR_INVALID;
+        }
+    }
+
+    bt_free_tree_state(ctx);
+    TreeState *st = new TreeState();
+    ctx->tree = st;
+    st->p = *p;
+    st->D = p->dims; st->C = 1 << p->dims;
+    st->f64 = p->coord_kind == BT_F64;
+    st->sat = sat; st->have_extent = have_extent;
+    st->nsources = p->nsources; st->ntargets = sat ? p->nsources : p->ntargets;
+    st->N = N;
+    st->capbits = have_extent ? CAPBITS_EXT : 0;
+    // levels addressable by the 64-bit key (per-axis value must fit 31 bits)
+    st->L = std::min(31, (63 - st->capbits) / st->D);
+
+    BT_CHECK(reset_status(ctx));
+    int s = st->f64 ? dispatch_dims_build<double>(ctx, st, out)
+                    : dispatch_dims_build<float>(ctx, st, out);
+    if (s != BT_OK) { (void) hipStreamSynchronize(ctx->stream); bt_free_tree_state(ctx); }
+    return s;
+}
+
+int bt_tree_export(bt_context *ctx, const bt_tree_arrays *o)
+{
+    if (!ctx || !o) { set_error("bt_tree_export: NULL argument"); return BT_ERR_INVALID; }
+    TreeState *st = ctx->tree;
+    if (!st || !st->built) {
+        set_error("bt_tree_export: no tree has been built on this context");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    const bool need_tgt = !st->sat;
+    if (!o->user_source_ids || !o->sorted_target_ids || !o->box_source_starts
+            || !o->box_source_counts_nonchild || !o->box_source_counts_cumul
+            || !o->box_parent_ids || !o->box_child_ids || !o->box_centers || !o->box_levels
+            || !o->box_flags || !o->box_source_bounding_box_min || !o->box_source_bounding_box_max
+            || (need_tgt && (!o->box_target_starts || !o->box_target_counts_nonchild
+                             || !o->box_target_counts_cumul || !o->box_target_bounding_box_min
+                             || !o->box_target_bounding_box_max))) {
+        set_error("bt_tree_export: NULL output array");
+        return BT_ERR_INVALID;
+    }
+    for (int ax = 0; ax < st->D; ++ax)
+        if ((st->nsources > 0 && !o->sources[ax]) || (need_tgt && st->ntargets > 0 && !o->targets[ax])) {
+            set_error("bt_tree_export: NULL coordinate output");
+            return BT_ERR_INVALID;
+        }
+    int s = st->f64 ? dispatch_dims_export<double>(ctx, st, o)
+                    : dispatch_dims_export<float>(ctx, st, o);
+    return s;
+}
+
+static const char *g_stage_names[BT_NUM_STAGES];
+
+int bt_get_stage_times(bt_context *ctx, bt_stage_times *out)
+{
+    if (!ctx || !out) return BT_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    TreeState *st = ctx->tree;
+    if (!st) return BT_OK;
+    int n = 0;
+    for (size_t i = 1; i < st->events.size() && n < BT_NUM_STAGES; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, st->events[i - 1].second, st->events[i].second) != hipSuccess) {
+            (void) hipGetLastError();
+            ms = -1.f;
+        }
+        g_stage_names[n] = st->events[i].first;
+        out->ms[n] = ms;
+        out->name[n] = g_stage_names[n];
+        ++n;
+    }
+    out->n = n;
+    return BT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,340 @@
+"""``FMMTraversalBuilder`` / ``FMMTraversalInfo``: the reference's call surface
+(boxtree/traversal.py:1353-2345) in front of the gfx950 list-building kernels.
+"""
+
+from __future__ import annotations
+
+import ctypes as ct
+import dataclasses
+import logging
+from dataclasses import dataclass
+from typing import Any
+
+import numpy as np
+
+from boxtree_amd import _lib
+from boxtree_amd.array_context import HIPArrayContext, make_obj_array, np_dtype_of, ptr
+from boxtree_amd.tools import DoneEvent
+from boxtree_amd.tree import _Container
+
+logger = logging.getLogger(__name__)
+
+
+@dataclass(frozen=True)
+class BuiltList(_Container):
+    """CSR list with optional empty-list elimination; fields as produced by
+    ``pyopencl.algorithm.ListOfListsBuilder`` (boxtree/array_context.py:222-238)."""
+    count: Any
+    starts: Any
+    lists: Any
+    num_nonempty_lists: Any = None
+    nonempty_indices: Any = None
+    compressed_indices: Any = None
+
+
+@dataclass(frozen=True)
+class FMMTraversalInfo(_Container):
+    """Interaction lists; field-for-field boxtree/traversal.py:1595-1630."""
+    tree: Any
+    well_sep_is_n_away: int
+
+    source_boxes: Any
+    target_boxes: Any
+    level_start_source_box_nrs: Any
+    level_start_target_box_nrs: Any
+    source_parent_boxes: Any
+    level_start_source_parent_box_nrs: Any
+    target_or_target_parent_boxes: Any
+    level_start_target_or_target_parent_box_nrs: Any
+
+    same_level_non_well_sep_boxes_starts: Any
+    same_level_non_well_sep_boxes_lists: Any
+
+    neighbor_source_boxes_starts: Any
+    neighbor_source_boxes_lists: Any
+
+    from_sep_siblings_starts: Any
+    from_sep_siblings_lists: Any
+
+    from_sep_smaller_by_level: Any
+    target_boxes_sep_smaller_by_source_level: Any
+    from_sep_close_smaller_starts: Any
+    from_sep_close_smaller_lists: Any
+
+    from_sep_bigger_starts: Any
+    from_sep_bigger_lists: Any
+    from_sep_close_bigger_starts: Any
+    from_sep_close_bigger_lists: Any
+
+    @property
+    def nboxes(self):
+        return self.tree.nboxes
+
+    @property
+    def nlevels(self):
+        return self.tree.nlevels
+
+    @property
+    def ntarget_boxes(self):
+        return len(self.target_boxes)
+
+    @property
+    def ntarget_or_target_parent_boxes(self):
+        return len(self.target_or_target_parent_boxes)
+
+    def merge_close_lists(self, actx, debug=False):
+        """Merge the "close" lists into list 1 (traversal.py:1650-1693).
+
+        Host-side (numpy) for now: this is a consumer-side convenience, not
+        part of the list-building hot path."""
+        import torch
+
+        def host(a):
+            return a.cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+        starts = [host(s) for s in (self.neighbor_source_boxes_starts,
+                                    self.from_sep_close_smaller_starts,
+                                    self.from_sep_close_bigger_starts)]
+        lists = [host(s) for s in (self.neighbor_source_boxes_lists,
+                                   self.from_sep_close_smaller_lists,
+                                   self.from_sep_close_bigger_lists)]
+        n = len(starts[0]) - 1
+        counts = sum(np.diff(s) for s in starts)
+        new_starts = np.zeros(n + 1, np.int32)
+        np.cumsum(counts, out=new_starts[1:])
+        new_lists = np.empty(int(new_starts[-1]), np.int32)
+        cur = new_starts[:-1].astype(np.int64).copy()
+        for s, lst in zip(starts, lists):
+            cnt = np.diff(s)
+            owner = np.repeat(np.arange(n), cnt)
+            within = np.arange(len(lst)) - np.repeat(s[:-1], cnt)
+            new_lists[cur[owner] + within] = lst
+            cur += cnt
+        conv = actx.from_numpy if isinstance(self.neighbor_source_boxes_starts,
+                                             torch.Tensor) else (lambda x: x)
+        return dataclasses.replace(
+            self,
+            neighbor_source_boxes_starts=conv(new_starts),
+            neighbor_source_boxes_lists=conv(new_lists),
+            from_sep_close_smaller_starts=None,
+            from_sep_close_smaller_lists=None,
+            from_sep_close_bigger_starts=None,
+            from_sep_close_bigger_lists=None)
+
+    def get_box_list(self, what, index):
+        starts = getattr(self, f"{what}_starts")
+        lists = getattr(self, f"{what}_lists")
+        start, stop = starts[index:index + 2]
+        return lists[start:stop]
+
+
+class FMMTraversalBuilder:
+    def __init__(self, array_context, *, well_sep_is_n_away=1,
+                 from_sep_smaller_crit=None):
+        """
+        :arg well_sep_is_n_away: an integer 1 or greater (traversal.py:1731-1745).
+        """
+        assert isinstance(array_context, HIPArrayContext)
+        self._setup_actx = array_context
+        self.well_sep_is_n_away = well_sep_is_n_away
+        self.from_sep_smaller_crit = from_sep_smaller_crit
+
+    def __call__(self, actx, tree, wait_for=None, debug=False,
+                 _from_sep_smaller_min_nsources_cumul=None,
+                 source_boxes_mask=None, source_parent_boxes_mask=None):
+        """Same arguments, return value ``(trav, event)`` and exceptions as
+        ``FMMTraversalBuilder.__call__`` (traversal.py:1969-1990)."""
+        assert isinstance(actx, HIPArrayContext)
+
+        from_sep_smaller_min_nsources_cumul = _from_sep_smaller_min_nsources_cumul
+        if from_sep_smaller_min_nsources_cumul is None:
+            from_sep_smaller_min_nsources_cumul = 0     # traversal.py:1995-1997
+
+        if not tree._is_pruned:
+            raise ValueError("tree must be pruned for traversal generation")
+        if tree.sources_have_extent:
+            raise NotImplementedError(
+                "trees with source extent are not supported for "
+                "traversal generation")
+
+        # traversal.py:1776-1805
+        from_sep_smaller_crit = self.from_sep_smaller_crit
+        if from_sep_smaller_crit is None:
+            from_sep_smaller_crit = "precise_linf"
+        extent_norm = tree.extent_norm
+        if extent_norm == "linf":
+            pass
+        elif extent_norm == "l2":
+            if from_sep_smaller_crit == "static_linf":
+                raise ValueError(
+                    "the static l^inf from-sep-smaller criterion "
+                    "cannot be used with the l^2 extent norm")
+        elif extent_norm is None:
+            assert not (tree.sources_have_extent or tree.targets_have_extent)
+        else:
+            raise ValueError(f"unexpected value of 'extent_norm': {extent_norm}")
+        if from_sep_smaller_crit not in ["static_linf", "precise_linf", "static_l2"]:
+            raise ValueError(
+                "unexpected value of 'from_sep_smaller_crit': "
+                f"{from_sep_smaller_crit}")
+
+        def dev(a):
+            if a is None:
+                return None
+            t = actx.from_numpy(a) if isinstance(a, np.ndarray) else a
+            return t.contiguous()
+
+        nlevels = int(tree.nlevels)
+        sources_are_targets = getattr(tree, "sources_are_targets", True)
+        coord_dtype = np.dtype(tree.coord_dtype)
+        dims = int(tree.dimensions)
+        nboxes = int(tree.nboxes)
+
+        box_centers = dev(tree.box_centers)
+        box_levels = dev(tree.box_levels)
+        box_child_ids = dev(tree.box_child_ids)
+        box_flags = dev(tree.box_flags)
+        box_parent_ids = dev(tree.box_parent_ids)
+        assert np_dtype_of(box_centers) == coord_dtype
+        level_start_box_nrs = tree.level_start_box_nrs
+        if level_start_box_nrs is None:
+            raise NotImplementedError("trees without level_start_box_nrs")
+        lsb = np.ascontiguousarray(actx.to_numpy(level_start_box_nrs), dtype=np.int32)
+
+        tp = _lib.TravParams()
+        tp.dims = dims
+        tp.coord_kind = _lib.BT_F64 if coord_dtype == np.float64 else _lib.BT_F32
+        tp.nlevels = nlevels
+        tp.nboxes = nboxes
+        tp.aligned_nboxes = int(tree.aligned_nboxes)
+        tp.root_extent = float(coord_dtype.type(tree.root_extent))
+        tp.stick_out_factor = float(coord_dtype.type(tree.stick_out_factor))
+        tp.box_centers = ptr(box_centers)
+        tp.box_levels = ptr(box_levels)
+        tp.box_child_ids = ptr(box_child_ids)
+        tp.box_flags = ptr(box_flags)
+        tp.box_parent_ids = ptr(box_parent_ids)
+        keep = []
+        if tree.targets_have_extent:
+            for name in ("box_target_bounding_box_min", "box_target_bounding_box_max",
+                         "box_source_counts_cumul"):
+                t = dev(getattr(tree, name))
+                keep.append(t)
+                setattr(tp, name, ptr(t))
+        tp.level_start_box_nrs = lsb.ctypes.data_as(ct.POINTER(ct.c_int32))
+        tp.sources_are_targets = int(bool(sources_are_targets))
+        tp.sources_have_extent = int(bool(tree.sources_have_extent))
+        tp.targets_have_extent = int(bool(tree.targets_have_extent))
+        tp.well_sep_is_n_away = int(self.well_sep_is_n_away)
+        tp.from_sep_smaller_crit = _lib.CRITS[from_sep_smaller_crit]
+        tp.from_sep_smaller_min_nsources_cumul = int(from_sep_smaller_min_nsources_cumul)
+        sbm = dev(source_boxes_mask)
+        spbm = dev(source_parent_boxes_mask)
+        tp.source_boxes_mask = ptr(sbm)
+        tp.source_parent_boxes_mask = ptr(spbm)
+
+        lib = actx.lib
+        sizes = _lib.TravSizes()
+        actx.sync_in()
+        code = lib.bt_traversal_build(actx.handle, ct.byref(tp), ct.byref(sizes))
+        if code == _lib.BT_ERR_UNSUPPORTED:
+            raise NotImplementedError(lib.bt_last_error_string().decode())
+        if code == _lib.BT_ERR_INVALID:
+            raise ValueError(lib.bt_last_error_string().decode())
+        _lib.check(code)
+
+        e = actx.empty
+        i32 = np.int32
+        out = _lib.TravArrays()
+        ntb = int(sizes.ntarget_boxes)
+        nttp = int(sizes.ntarget_or_target_parent_boxes)
+        with_extent = tree.sources_have_extent or tree.targets_have_extent
+
+        source_boxes = e(int(sizes.nsource_boxes), i32)
+        source_parent_boxes = e(int(sizes.nsource_parent_boxes), i32)
+        target_or_target_parent_boxes = e(nttp, i32)
+        target_boxes = source_boxes if sources_are_targets else e(ntb, i32)
+        out.source_boxes = ptr(source_boxes)
+        out.target_boxes = ptr(target_boxes)
+        out.source_parent_boxes = ptr(source_parent_boxes)
+        out.target_or_target_parent_boxes = ptr(target_or_target_parent_boxes)
+
+        lev = {}
+        for name in ("level_start_source_box_nrs", "level_start_target_box_nrs",
+                     "level_start_source_parent_box_nrs",
+                     "level_start_target_or_target_parent_box_nrs"):
+            lev[name] = e(nlevels + 1, i32)
+            setattr(out, name, ptr(lev[name]))
+
+        def csr(prefix, n, total):
+            starts = e(n + 1, i32)
+            lists = e(int(total), i32)
+            setattr(out, prefix + "_starts", ptr(starts))
+            setattr(out, prefix + "_lists", ptr(lists))
+            return starts, lists
+
+        slnws = csr("same_level_non_well_sep_boxes", nboxes, sizes.n_same_level_non_well_sep)
+        l1 = csr("neighbor_source_boxes", ntb, sizes.n_neighbor_source)
+        l2 = csr("from_sep_siblings", nttp, sizes.n_from_sep_siblings)
+        l4 = csr("from_sep_bigger", nttp, sizes.n_from_sep_bigger)
+        if with_extent:
+            cs = csr("from_sep_close_smaller", ntb, sizes.n_from_sep_close_smaller)
+            cb = csr("from_sep_close_bigger", ntb, sizes.n_from_sep_close_bigger)
+        else:
+            cs = cb = (None, None)
+
+        l3 = []
+        for ilev in range(nlevels):
+            nne = int(sizes.n_from_sep_smaller_nonempty[ilev])
+            cnt = int(sizes.n_from_sep_smaller[ilev])
+            arrs = dict(starts=e(nne + 1, i32), lists=e(cnt, i32),
+                        nonempty_indices=e(nne, i32),
+                        compressed_indices=e(ntb + 1, i32), tboxes=e(nne, i32))
+            out.from_sep_smaller_starts[ilev] = ptr(arrs["starts"]).value
+            out.from_sep_smaller_lists[ilev] = ptr(arrs["lists"]).value
+            out.from_sep_smaller_nonempty_indices[ilev] = ptr(arrs["nonempty_indices"]).value
+            out.from_sep_smaller_compressed_indices[ilev] = ptr(arrs["compressed_indices"]).value
+            out.target_boxes_sep_smaller[ilev] = ptr(arrs["tboxes"]).value
+            l3.append((nne, cnt, arrs))
+
+        _lib.check(lib.bt_traversal_export(actx.handle, ct.byref(out)))
+
+        from_sep_smaller_by_level = make_obj_array([
+            BuiltList(count=cnt, starts=a["starts"], lists=a["lists"],
+                      num_nonempty_lists=nne, nonempty_indices=a["nonempty_indices"],
+                      compressed_indices=a["compressed_indices"])
+            for nne, cnt, a in l3])
+        target_boxes_sep_smaller_by_source_level = make_obj_array(
+            [a["tboxes"] for _, _, a in l3])
+
+        info = FMMTraversalInfo(
+            tree=tree,
+            well_sep_is_n_away=self.well_sep_is_n_away,
+            source_boxes=source_boxes,
+            target_boxes=target_boxes,
+            level_start_source_box_nrs=lev["level_start_source_box_nrs"],
+            level_start_target_box_nrs=lev["level_start_target_box_nrs"],
+            source_parent_boxes=source_parent_boxes,
+            level_start_source_parent_box_nrs=lev["level_start_source_parent_box_nrs"],
+            target_or_target_parent_boxes=target_or_target_parent_boxes,
+            level_start_target_or_target_parent_box_nrs=lev[
+                "level_start_target_or_target_parent_box_nrs"],
+            same_level_non_well_sep_boxes_starts=slnws[0],
+            same_level_non_well_sep_boxes_lists=slnws[1],
+            neighbor_source_boxes_starts=l1[0],
+            neighbor_source_boxes_lists=l1[1],
+            from_sep_siblings_starts=l2[0],
+            from_sep_siblings_lists=l2[1],
+            from_sep_smaller_by_level=from_sep_smaller_by_level,
+            target_boxes_sep_smaller_by_source_level=(
+                target_boxes_sep_smaller_by_source_level),
+            from_sep_close_smaller_starts=cs[0],
+            from_sep_close_smaller_lists=cs[1],
+            from_sep_bigger_starts=l4[0],
+            from_sep_bigger_lists=l4[1],
+            from_sep_close_bigger_starts=cb[0],
+            from_sep_close_bigger_lists=cb[1],
+        )
+        return actx.freeze(info), DoneEvent()
+
+# vim: fdm=marker

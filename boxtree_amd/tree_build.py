@@ -1,0 +1,419 @@
+"""``TreeBuilder``: the reference's call surface (boxtree/tree_build.py:93-1878)
+in front of the gfx950 kernels in ``libboxtree_hip.so``.
+
+Host code here does what the reference does on the host: argument checking
+(tree_build.py:223-295, 405-454), the root box (:456-510) in numpy so that every
+rounding matches, and container assembly (:1828-1876).  Everything the reference
+enqueues on its command queue happens inside ``bt_tree_build``/``bt_tree_export``.
+"""
+
+from __future__ import annotations
+
+import ctypes as ct
+import logging
+from typing import Any
+
+import numpy as np
+
+from boxtree_amd import _lib
+from boxtree_amd.array_context import (
+    HIPArrayContext, make_obj_array, np_dtype_of, ptr)
+from boxtree_amd.bounding_box import AXIS_NAMES, BoundingBoxFinder
+from boxtree_amd.tools import DoneEvent
+from boxtree_amd.tree import Tree
+
+logger = logging.getLogger(__name__)
+
+
+class MaxLevelsExceeded(RuntimeError):   # tree_build.py:79
+    pass
+
+
+class TreeBuilder:
+    """
+    .. automethod:: __init__
+    .. automethod:: __call__
+    """
+
+    morton_nr_dtype = np.dtype(np.int8)
+    box_level_dtype = np.dtype(np.uint8)
+    ROOT_EXTENT_STRETCH_FACTOR = 1e-4        # tree_build.py:101
+
+    def __init__(self, array_context: HIPArrayContext) -> None:
+        assert isinstance(array_context, HIPArrayContext)
+        self._setup_actx = array_context
+        self.bbox_finder = BoundingBoxFinder(array_context)
+        self.last_stage_times: dict[str, float] = {}
+
+    def __call__(self, actx, particles, kind="adaptive",
+                 max_particles_in_box=None, allocator=None, debug=False,
+                 targets=None, source_radii=None, target_radii=None,
+                 stick_out_factor=None, refine_weights=None,
+                 max_leaf_refine_weight=None, wait_for=None,
+                 extent_norm=None, bbox=None, **kwargs: Any):
+        """Same arguments, return value ``(tree, event)`` and exceptions as
+        ``boxtree.TreeBuilder.__call__`` (tree_build.py:145-215).  *particles*,
+        *targets*, radii and *refine_weights* are device arrays (torch tensors
+        on the context's device) or numpy arrays (copied to the device)."""
+        assert isinstance(actx, HIPArrayContext)
+
+        if allocator is not None:
+            from warnings import warn
+            warn("Passing in 'allocator' is deprecated. The allocator of the "
+                 "array context 'actx' is used throughout.",
+                 DeprecationWarning, stacklevel=2)
+
+        # {{{ input processing (tree_build.py:223-295)
+
+        if kind not in ["adaptive", "adaptive-level-restricted", "non-adaptive"]:
+            raise ValueError(f"unknown tree kind: '{kind}'")
+
+        dimensions = len(particles)
+        axis_names = AXIS_NAMES[:dimensions]
+
+        sources_are_targets = targets is None
+        sources_have_extent = source_radii is not None
+        targets_have_extent = target_radii is not None
+
+        if extent_norm is None:
+            extent_norm = "linf"
+        if extent_norm not in ["linf", "l2"]:
+            raise ValueError(f"unexpected value of 'extent_norm': {extent_norm}")
+
+        srcntgts_extent_norm = extent_norm
+        srcntgts_have_extent = sources_have_extent or targets_have_extent
+        if not srcntgts_have_extent:
+            srcntgts_extent_norm = None
+        del extent_norm
+
+        if srcntgts_extent_norm and targets is None:
+            raise ValueError("must specify targets when specifying any kind of radii")
+
+        def dev(a):
+            if a is None:
+                return None
+            t = actx.from_numpy(a) if isinstance(a, np.ndarray) else a
+            return t.contiguous()
+
+        particles = [dev(p) for p in particles]
+        coord_dtypes = {np_dtype_of(p) for p in particles}
+        if len(coord_dtypes) != 1:
+            raise ValueError("coordinate arrays must share one dtype")
+        coord_dtype, = coord_dtypes
+        if coord_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+            raise TypeError(f"unsupported coordinate dtype {coord_dtype}")
+        particle_id_dtype = np.dtype(np.int32)
+        box_id_dtype = np.dtype(np.int32)
+
+        if len({len(p) for p in particles}) != 1:
+            raise ValueError("coordinate arrays must have equal length")
+        nsources = len(particles[0])
+        if targets is None:
+            nsrcntgts = nsources
+            ntargets = nsources
+        else:
+            targets = [dev(t) for t in targets]
+            if len({len(t) for t in targets}) != 1:
+                raise ValueError("target coordinate arrays must have equal length")
+            ntargets = len(targets[0])
+            nsrcntgts = nsources + ntargets
+
+        source_radii = dev(source_radii)
+        target_radii = dev(target_radii)
+        if source_radii is not None:
+            if tuple(source_radii.shape) != (nsources,):
+                raise ValueError("'source_radii' has an invalid shape: "
+                                 f"{tuple(source_radii.shape)} (expected ({nsources},))")
+            if np_dtype_of(source_radii) != coord_dtype:
+                raise TypeError(
+                    "dtypes of coordinate array 'particles' and 'source_radii' "
+                    f"must agree: got {coord_dtype} and {np_dtype_of(source_radii)}")
+        if target_radii is not None:
+            if tuple(target_radii.shape) != (ntargets,):
+                raise ValueError("'target_radii' has an invalid shape: "
+                                 f"{tuple(target_radii.shape)} (expected ({ntargets},))")
+            if np_dtype_of(target_radii) != coord_dtype:
+                raise TypeError(
+                    "dtypes of coordinate array 'particles' and 'target_radii' "
+                    f"must agree: got {coord_dtype} and {np_dtype_of(target_radii)}")
+
+        if sources_have_extent or targets_have_extent:
+            if stick_out_factor is None:
+                raise ValueError("if sources or targets have extent, "
+                                 "'stick_out_factor' must be explicitly specified")
+        else:
+            stick_out_factor = 0
+
+        if targets is not None:
+            target_coord_dtypes = {np_dtype_of(t) for t in targets}
+            if target_coord_dtypes != {coord_dtype}:
+                raise TypeError(
+                    "sources and targets coordinates must have same dtype: "
+                    f"got {coord_dtype} and {target_coord_dtypes}")
+
+        # }}}
+
+        # {{{ refine weights (tree_build.py:405-454)
+
+        specified_max_particles_in_box = max_particles_in_box is not None
+        specified_refine_weights = (
+            refine_weights is not None and max_leaf_refine_weight is not None)
+
+        if specified_max_particles_in_box and specified_refine_weights:
+            raise ValueError("may only specify one of 'max_particles_in_box' and "
+                             "'refine_weights'/'max_leaf_refine_weight")
+        elif not specified_max_particles_in_box and not specified_refine_weights:
+            raise ValueError("must specify either 'max_particles_in_box' or "
+                             "'refine_weights'/'max_leaf_refine_weight'")
+        elif specified_max_particles_in_box:
+            refine_weights = None          # unit weights are implicit on the device
+            max_leaf_refine_weight = max_particles_in_box
+        else:
+            refine_weights = dev(refine_weights)
+            if np_dtype_of(refine_weights) != np.int32:
+                raise TypeError("'refine_weights' must have dtype 'int32' "
+                                f"(got {np_dtype_of(refine_weights)})")
+            if tuple(refine_weights.shape) != (nsrcntgts,):
+                raise ValueError("'refine_weights' has an invalid shape")
+
+        if max_leaf_refine_weight <= 0:
+            raise ValueError(
+                f"'max_leaf_refine_weight' must be positive: {max_leaf_refine_weight}")
+        if refine_weights is not None and nsrcntgts:
+            if max_leaf_refine_weight < int(refine_weights.max()):
+                raise ValueError(
+                    "entries of 'refine_weights' cannot exceed 'max_leaf_refine_weight'")
+            if int(refine_weights.min()) < 0:
+                raise ValueError("all entries of 'refine_weights' must be nonnegative")
+        elif max_leaf_refine_weight < 1:
+            raise ValueError(
+                "entries of 'refine_weights' cannot exceed 'max_leaf_refine_weight'")
+
+        # }}}
+
+        # {{{ find and process bounding box (tree_build.py:456-510)
+
+        bbox_auto, _ = self.bbox_finder(actx, particles, source_radii)
+        if targets is not None:
+            bbox_t, _ = self.bbox_finder(actx, targets, target_radii)
+            for ax in axis_names:
+                bbox_auto[f"min_{ax}"] = min(bbox_auto[f"min_{ax}"], bbox_t[f"min_{ax}"])
+                bbox_auto[f"max_{ax}"] = max(bbox_auto[f"max_{ax}"], bbox_t[f"max_{ax}"])
+
+        if bbox is None:
+            bbox = bbox_auto.copy()
+            root_extent = max(
+                bbox[f"max_{ax}"] - bbox[f"min_{ax}"]
+                for ax in axis_names) * (1 + TreeBuilder.ROOT_EXTENT_STRETCH_FACTOR)
+
+            # make bbox square and slightly larger at the top, to ensure scaled
+            # coordinates are always < 1
+            bbox_min = np.empty(dimensions, coord_dtype)
+            for i, ax in enumerate(axis_names):
+                bbox_min[i] = bbox[f"min_{ax}"]
+
+            bbox_max = bbox_min + root_extent
+            for i, ax in enumerate(axis_names):
+                bbox[f"max_{ax}"] = bbox_max[i]
+        else:
+            if isinstance(bbox, np.ndarray):
+                if len(bbox) == dimensions:
+                    bbox_bak = bbox.copy()
+                    bbox = np.empty((), bbox_auto.dtype)
+                    for i, ax in enumerate(axis_names):
+                        bbox[f"min_{ax}"] = bbox_bak[i][0]
+                        bbox[f"max_{ax}"] = bbox_bak[i][1]
+                else:
+                    assert bbox.size == 1
+                    bbox = bbox.reshape(())
+            else:
+                raise NotImplementedError(
+                    f"unsupported bounding box type: {type(bbox)}")
+
+            bbox_min = np.empty(dimensions, coord_dtype)
+            bbox_max = np.empty(dimensions, coord_dtype)
+            for i, ax in enumerate(axis_names):
+                bbox_min[i] = bbox[f"min_{ax}"]
+                bbox_max[i] = bbox[f"max_{ax}"]
+                assert bbox_min[i] < bbox_max[i]
+                assert bbox_min[i] <= bbox_auto[f"min_{ax}"]
+                assert bbox_max[i] >= bbox_auto[f"max_{ax}"]
+
+            bbox_exts = bbox_max - bbox_min
+            for ext in bbox_exts:
+                assert abs(ext - bbox_exts[0]) < 1e-15
+            root_extent = bbox_exts[0]
+
+        # }}}
+
+        # {{{ device build
+
+        lib = actx.lib
+        tp = _lib.TreeParams()
+        tp.dims = dimensions
+        tp.coord_kind = _lib.BT_F64 if coord_dtype == np.float64 else _lib.BT_F32
+        tp.nsources = nsources
+        tp.ntargets = -1 if sources_are_targets else ntargets
+        for i in range(dimensions):
+            tp.sources[i] = ptr(particles[i]).value
+            if targets is not None:
+                tp.targets[i] = ptr(targets[i]).value
+        tp.source_radii = ptr(source_radii)
+        tp.target_radii = ptr(target_radii)
+        tp.refine_weights = ptr(refine_weights)
+        tp.max_leaf_refine_weight = int(max_leaf_refine_weight)
+        tp.kind = _lib.KINDS[kind]
+        tp.extent_norm = _lib.NORMS[srcntgts_extent_norm]
+        tp.skip_prune = int(bool(kwargs.get("skip_prune")))
+        tp.stick_out_factor = float(coord_dtype.type(stick_out_factor))
+        for i, ax in enumerate(axis_names):
+            tp.bbox_min[i] = float(bbox[f"min_{ax}"])
+            tp.bbox_max[i] = float(bbox[f"max_{ax}"])
+        tp.root_extent = float(coord_dtype.type(root_extent))
+
+        sizes = _lib.TreeSizes()
+        actx.sync_in()
+        code = lib.bt_tree_build(actx.handle, ct.byref(tp), ct.byref(sizes))
+        if code == _lib.BT_ERR_MAX_LEVELS:
+            raise MaxLevelsExceeded(
+                "Level count exceeded number of significant "
+                "bits in coordinate dtype. That means that a large number "
+                "of particles was indistinguishable up to floating point "
+                "precision (because they ended up in the same box). "
+                f"[{lib.bt_last_error_string().decode()}]")
+        if code == _lib.BT_ERR_UNSUPPORTED:
+            raise NotImplementedError(lib.bt_last_error_string().decode())
+        if code == _lib.BT_ERR_INVALID:
+            raise ValueError(lib.bt_last_error_string().decode())
+        _lib.check(code)
+
+        nboxes = int(sizes.nboxes)
+        aligned_nboxes = int(sizes.aligned_nboxes)
+        nlevels = int(sizes.nlevels)
+        level_start_box_nrs = np.array(
+            sizes.level_start_box_nrs[:nlevels + 1], dtype=box_id_dtype)
+        logger.debug("tree: %d levels, %d boxes, %d particles", nlevels, nboxes, nsrcntgts)
+
+        e = actx.empty
+        C = 2**dimensions
+        i32 = np.int32
+
+        out = _lib.TreeArrays()
+        user_source_ids = e(nsources, i32)
+        sorted_target_ids = e(ntargets, i32)
+        sources = [e(nsources, coord_dtype) for _ in range(dimensions)]
+        box_source_starts = e(nboxes, i32)
+        box_source_counts_nonchild = e(nboxes, i32)
+        box_source_counts_cumul = e(nboxes, i32)
+        box_parent_ids = e(nboxes, i32)
+        box_child_ids = e((C, aligned_nboxes), i32)
+        box_centers = e((dimensions, aligned_nboxes), coord_dtype)
+        box_levels = e(nboxes, np.uint8)
+        box_flags = e(nboxes, np.uint8)
+        box_source_bounding_box_min = e((dimensions, aligned_nboxes), coord_dtype)
+        box_source_bounding_box_max = e((dimensions, aligned_nboxes), coord_dtype)
+
+        out.user_source_ids = ptr(user_source_ids)
+        out.sorted_target_ids = ptr(sorted_target_ids)
+        for i in range(dimensions):
+            out.sources[i] = ptr(sources[i]).value
+        out.box_source_starts = ptr(box_source_starts)
+        out.box_source_counts_nonchild = ptr(box_source_counts_nonchild)
+        out.box_source_counts_cumul = ptr(box_source_counts_cumul)
+        out.box_parent_ids = ptr(box_parent_ids)
+        out.box_child_ids = ptr(box_child_ids)
+        out.box_centers = ptr(box_centers)
+        out.box_levels = ptr(box_levels)
+        out.box_flags = ptr(box_flags)
+        out.box_source_bounding_box_min = ptr(box_source_bounding_box_min)
+        out.box_source_bounding_box_max = ptr(box_source_bounding_box_max)
+
+        if sources_are_targets:
+            # tree_build.py:1469-1474, 1572, 1739-1741: shared objects
+            tgt_arrays = sources
+            box_target_starts = box_source_starts
+            box_target_counts_nonchild = box_source_counts_nonchild
+            box_target_counts_cumul = box_source_counts_cumul
+            box_target_bounding_box_min = box_source_bounding_box_min
+            box_target_bounding_box_max = box_source_bounding_box_max
+            sorted_source_radii = sorted_target_radii = None
+        else:
+            tgt_arrays = [e(ntargets, coord_dtype) for _ in range(dimensions)]
+            box_target_starts = e(nboxes, i32)
+            box_target_counts_nonchild = e(nboxes, i32)
+            box_target_counts_cumul = e(nboxes, i32)
+            box_target_bounding_box_min = e((dimensions, aligned_nboxes), coord_dtype)
+            box_target_bounding_box_max = e((dimensions, aligned_nboxes), coord_dtype)
+            sorted_source_radii = e(nsources, coord_dtype) if sources_have_extent else None
+            sorted_target_radii = e(ntargets, coord_dtype) if targets_have_extent else None
+            for i in range(dimensions):
+                out.targets[i] = ptr(tgt_arrays[i]).value
+            out.source_radii = ptr(sorted_source_radii)
+            out.target_radii = ptr(sorted_target_radii)
+            out.box_target_starts = ptr(box_target_starts)
+            out.box_target_counts_nonchild = ptr(box_target_counts_nonchild)
+            out.box_target_counts_cumul = ptr(box_target_counts_cumul)
+            out.box_target_bounding_box_min = ptr(box_target_bounding_box_min)
+            out.box_target_bounding_box_max = ptr(box_target_bounding_box_max)
+
+        _lib.check(lib.bt_tree_export(actx.handle, ct.byref(out)))
+
+        st = _lib.StageTimes()
+        lib.bt_get_stage_times(actx.handle, ct.byref(st))
+        self.last_stage_times = {
+            st.name[i].decode(): float(st.ms[i]) for i in range(st.n)}
+
+        # }}}
+
+        sources_obj = make_obj_array(sources)
+        targets_obj = sources_obj if sources_are_targets else make_obj_array(tgt_arrays)
+
+        tree = Tree(
+            sources_are_targets=sources_are_targets,
+            sources_have_extent=sources_have_extent,
+            targets_have_extent=targets_have_extent,
+
+            particle_id_dtype=particle_id_dtype,
+            box_id_dtype=box_id_dtype,
+            coord_dtype=coord_dtype,
+            box_level_dtype=self.box_level_dtype,
+
+            bounding_box=(bbox_min, bbox_max),
+            root_extent=root_extent,
+            stick_out_factor=stick_out_factor,
+            extent_norm=srcntgts_extent_norm,
+
+            level_start_box_nrs=actx.from_numpy(level_start_box_nrs),
+
+            sources=sources_obj,
+            targets=targets_obj,
+            source_radii=sorted_source_radii,
+            target_radii=sorted_target_radii,
+
+            box_source_starts=box_source_starts,
+            box_source_counts_nonchild=box_source_counts_nonchild,
+            box_source_counts_cumul=box_source_counts_cumul,
+            box_target_starts=box_target_starts,
+            box_target_counts_nonchild=box_target_counts_nonchild,
+            box_target_counts_cumul=box_target_counts_cumul,
+
+            box_parent_ids=box_parent_ids,
+            box_child_ids=box_child_ids,
+            box_centers=box_centers,
+            box_levels=box_levels,
+            box_flags=box_flags,
+
+            user_source_ids=user_source_ids,
+            sorted_target_ids=sorted_target_ids,
+
+            box_source_bounding_box_min=box_source_bounding_box_min,
+            box_source_bounding_box_max=box_source_bounding_box_max,
+            box_target_bounding_box_min=box_target_bounding_box_min,
+            box_target_bounding_box_max=box_target_bounding_box_max,
+
+            _is_pruned=True,
+        )
+
+        return actx.freeze(tree), DoneEvent()
+
+# vim: foldmethod=marker

@@ -1,0 +1,242 @@
+/*
+ * boxtree_hip.h -- C ABI of libboxtree_hip.so (MI355X / gfx950 native).
+ *
+ * Drop-in boundary for the one data-parallel hot path of inducer/boxtree:
+ * particle tree build (TreeBuilder -> Tree) and FMM interaction-list
+ * generation (FMMTraversalBuilder -> FMMTraversalInfo).  The reference has no
+ * FFI layer of its own: what these entry points replace is the body of
+ *
+ *   boxtree/bounding_box.py:163   BoundingBoxFinder.__call__        -> bt_bbox
+ *   boxtree/tree_build.py:145     TreeBuilder.__call__              -> bt_tree_build
+ *                                                                     + bt_tree_export
+ *   boxtree/traversal.py:1969     FMMTraversalBuilder.__call__      -> bt_traversal_build
+ *                                                                     + bt_traversal_export
+ *
+ * i.e. everything those methods enqueue on a pyopencl CommandQueue.  The
+ * Python layer in boxtree_amd/ (same class names, kwargs and exceptions as the
+ * reference) binds them with ctypes; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.
+ *   - every "device pointer" is a HIP device pointer valid on the context's
+ *     device; arrays are dense, little-endian, int32 ids, uint8 levels/flags.
+ *   - all calls return BT_OK (0) or a BT_ERR_* code; bt_last_error_string()
+ *     gives a human-readable message for the calling thread.
+ *   - calls are host-synchronous with respect to the context's stream at
+ *     return.  A context must not be used from two threads at once.
+ *   - two-phase protocol: *_build computes the structure into library-owned
+ *     buffers and reports sizes; the caller allocates outputs (e.g. torch
+ *     tensors) and *_export writes them.  Inputs passed to *_build must stay
+ *     valid until *_export returns.
+ */
+#ifndef BOXTREE_HIP_H
+#define BOXTREE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BT_ABI_VERSION 1
+#define BT_MAX_DIMS 3
+#define BT_MAX_LEVELS 64       /* capacity of per-level arrays in the structs */
+
+enum {
+    BT_OK = 0,
+    BT_ERR_INVALID = 1,        /* bad argument (ValueError/TypeError upstream)   */
+    BT_ERR_MAX_LEVELS = 2,     /* boxtree.tree_build.MaxLevelsExceeded            */
+    BT_ERR_ALLOC = 3,
+    BT_ERR_HIP = 4,
+    BT_ERR_INTERNAL = 5,
+    BT_ERR_UNSUPPORTED = 6     /* NotImplementedError upstream                    */
+};
+
+enum { BT_F32 = 0, BT_F64 = 1 };
+enum { BT_NORM_NONE = 0, BT_NORM_LINF = 1, BT_NORM_L2 = 2 };      /* tree_build.py:88 */
+enum { BT_KIND_ADAPTIVE = 0, BT_KIND_ADAPTIVE_LEVEL_RESTRICTED = 1,
+       BT_KIND_NON_ADAPTIVE = 2 };                                /* tree_build.py:83-86 */
+enum { BT_CRIT_STATIC_LINF = 0, BT_CRIT_PRECISE_LINF = 1,
+       BT_CRIT_STATIC_L2 = 2 };                                   /* traversal.py:92 */
+
+/* box flags, boxtree/tree.py:109-145 */
+enum {
+    BT_BOX_IS_SOURCE_BOX = 1, BT_BOX_IS_TARGET_BOX = 2,
+    BT_BOX_HAS_SOURCE_CHILD_BOXES = 4, BT_BOX_HAS_TARGET_CHILD_BOXES = 8
+};
+
+typedef struct bt_context bt_context;
+
+/* ---- context ----------------------------------------------------------- */
+
+int bt_abi_version(void);
+
+/* hip_stream: a hipStream_t to run on, or NULL for a library-owned stream. */
+int bt_create(int device, void *hip_stream, bt_context **out);
+void bt_destroy(bt_context *ctx);
+/* release cached device workspace (kept between calls otherwise) */
+int bt_trim(bt_context *ctx);
+const char *bt_last_error_string(void);
+
+/* ---- bounding box (bounding_box.py:54-122, 163-174) --------------------- */
+
+/* min/max over i of coords[d][i] -/+ radii[i]; results are exact, returned as
+ * doubles.  radii may be NULL.  n == 0 gives (+MAX, -MAX) like bbox_neutral(). */
+int bt_bbox(bt_context *ctx, int dims, int coord_kind,
+            const void *const *coords, const void *radii, int64_t n,
+            double *out_min, double *out_max);
+
+/* ---- 64-bit-key radix sort (exposed for the roofline benchmark) ---------- */
+
+/* Stable LSD radix sort of (key, value) pairs on bits [begin_bit, end_bit).
+ * keys_in/vals_in are clobbered (ping-pong); the result is in keys_out/vals_out.
+ * One digit pass moves 24*n algorithmic bytes (12 read + 12 written per pair). */
+int bt_radix_sort_u64_u32(bt_context *ctx, uint64_t *keys_in, uint32_t *vals_in,
+                          uint64_t *keys_out, uint32_t *vals_out, int64_t n,
+                          int begin_bit, int end_bit);
+int bt_radix_sort_u32_u32(bt_context *ctx, uint32_t *keys_in, uint32_t *vals_in,
+                          uint32_t *keys_out, uint32_t *vals_out, int64_t n,
+                          int begin_bit, int end_bit);
+
+typedef struct {
+    int32_t passes;            /* digit passes of the last bt_radix_sort_* call  */
+    float pass_ms_avg;         /* HIP-event time of the onesweep kernel / passes */
+    float hist_ms;             /* up-front histogram kernel                      */
+    float total_ms;
+} bt_sort_stats;
+int bt_get_sort_stats(bt_context *ctx, bt_sort_stats *out);
+
+/* ---- tree build (tree_build.py:145-1878) -------------------------------- */
+
+typedef struct {
+    int32_t dims;              /* 2 or 3 (1 accepted) */
+    int32_t coord_kind;        /* BT_F32 / BT_F64 */
+    int64_t nsources;
+    int64_t ntargets;          /* -1: sources are also the targets (targets=None) */
+    const void *sources[BT_MAX_DIMS];     /* device, [nsources] each */
+    const void *targets[BT_MAX_DIMS];     /* device, [ntargets] each, or NULL */
+    const void *source_radii;  /* device [nsources] or NULL */
+    const void *target_radii;  /* device [ntargets] or NULL */
+    const int32_t *refine_weights;  /* device [nsources(+ntargets)] or NULL = all 1 */
+    int32_t max_leaf_refine_weight; /* = max_particles_in_box when weights NULL   */
+    int32_t kind;              /* BT_KIND_* */
+    int32_t extent_norm;       /* BT_NORM_* (NONE when no radii)                  */
+    int32_t skip_prune;        /* debugging kwarg of the reference (unsupported)  */
+    double stick_out_factor;
+    /* root box exactly as computed on the host by tree_build.py:456-510
+     * (values representable in the coordinate type):                       */
+    double bbox_min[BT_MAX_DIMS];
+    double bbox_max[BT_MAX_DIMS];
+    double root_extent;
+} bt_tree_params;
+
+typedef struct {
+    int64_t nboxes;
+    int64_t aligned_nboxes;    /* ceil(nboxes/32)*32, tree_build.py:1641 */
+    int32_t nlevels;
+    int32_t key_levels;        /* deepest level the 64-bit key can address */
+    int32_t level_start_box_nrs[BT_MAX_LEVELS + 1];   /* [nlevels+1] valid */
+} bt_tree_sizes;
+
+int bt_tree_build(bt_context *ctx, const bt_tree_params *params, bt_tree_sizes *out);
+
+/* Output arrays, caller-allocated device memory; names/layouts are those of
+ * boxtree.Tree (tree.py:298-590).  When sources are targets the target_*
+ * pointers may be NULL (the reference shares the arrays). */
+typedef struct {
+    int32_t *user_source_ids;              /* [nsources] */
+    int32_t *sorted_target_ids;            /* [ntargets] */
+    void *sources[BT_MAX_DIMS];            /* [nsources] tree order */
+    void *targets[BT_MAX_DIMS];            /* [ntargets] or NULL */
+    void *source_radii;                    /* or NULL */
+    void *target_radii;                    /* or NULL */
+    int32_t *box_source_starts, *box_source_counts_nonchild, *box_source_counts_cumul;
+    int32_t *box_target_starts, *box_target_counts_nonchild, *box_target_counts_cumul;
+    int32_t *box_parent_ids;               /* [nboxes] */
+    int32_t *box_child_ids;                /* [2^d, aligned_nboxes] */
+    void *box_centers;                     /* [d, aligned_nboxes] */
+    uint8_t *box_levels;                   /* [nboxes] */
+    uint8_t *box_flags;                    /* [nboxes] */
+    void *box_source_bounding_box_min, *box_source_bounding_box_max;  /* [d, aligned] */
+    void *box_target_bounding_box_min, *box_target_bounding_box_max;  /* or NULL */
+} bt_tree_arrays;
+
+int bt_tree_export(bt_context *ctx, const bt_tree_arrays *out);
+
+/* per-stage milliseconds of the last tree build / traversal (HIP events) */
+#define BT_NUM_STAGES 24
+typedef struct {
+    float ms[BT_NUM_STAGES];
+    const char *name[BT_NUM_STAGES];
+    int32_t n;
+} bt_stage_times;
+int bt_get_stage_times(bt_context *ctx, bt_stage_times *out);
+
+/* ---- traversal (traversal.py:1969-2345) --------------------------------- */
+
+typedef struct {
+    int32_t dims, coord_kind;
+    int32_t nlevels;
+    int64_t nboxes, aligned_nboxes;
+    double root_extent;
+    double stick_out_factor;
+    /* device arrays in boxtree.Tree layout */
+    const void *box_centers;               /* [d, aligned] */
+    const uint8_t *box_levels;
+    const int32_t *box_child_ids;          /* [2^d, aligned] */
+    const uint8_t *box_flags;
+    const int32_t *box_parent_ids;
+    const void *box_target_bounding_box_min, *box_target_bounding_box_max;
+    const int32_t *box_source_counts_cumul;
+    const int32_t *level_start_box_nrs;    /* HOST pointer, [nlevels+1] */
+    int32_t sources_are_targets;
+    int32_t sources_have_extent, targets_have_extent;
+    int32_t well_sep_is_n_away;
+    int32_t from_sep_smaller_crit;         /* BT_CRIT_* */
+    int32_t from_sep_smaller_min_nsources_cumul;
+    const int8_t *source_boxes_mask;           /* device or NULL */
+    const int8_t *source_parent_boxes_mask;    /* device or NULL */
+} bt_trav_params;
+
+typedef struct {
+    int64_t nsource_boxes, ntarget_boxes, nsource_parent_boxes,
+            ntarget_or_target_parent_boxes;
+    int64_t n_same_level_non_well_sep;     /* total list entries */
+    int64_t n_neighbor_source;
+    int64_t n_from_sep_siblings;
+    int64_t n_from_sep_bigger;
+    int64_t n_from_sep_close_smaller;      /* -1 when the list does not exist */
+    int64_t n_from_sep_close_bigger;       /* -1 when the list does not exist */
+    int64_t n_from_sep_smaller[BT_MAX_LEVELS];          /* entries per source level */
+    int64_t n_from_sep_smaller_nonempty[BT_MAX_LEVELS]; /* num_nonempty_lists      */
+} bt_trav_sizes;
+
+int bt_traversal_build(bt_context *ctx, const bt_trav_params *params, bt_trav_sizes *out);
+
+typedef struct {
+    int32_t *source_boxes, *target_boxes, *source_parent_boxes,
+            *target_or_target_parent_boxes;
+    int32_t *level_start_source_box_nrs, *level_start_target_box_nrs,
+            *level_start_source_parent_box_nrs,
+            *level_start_target_or_target_parent_box_nrs;      /* [nlevels+1] */
+    int32_t *same_level_non_well_sep_boxes_starts, *same_level_non_well_sep_boxes_lists;
+    int32_t *neighbor_source_boxes_starts, *neighbor_source_boxes_lists;
+    int32_t *from_sep_siblings_starts, *from_sep_siblings_lists;
+    int32_t *from_sep_bigger_starts, *from_sep_bigger_lists;
+    int32_t *from_sep_close_smaller_starts, *from_sep_close_smaller_lists;
+    int32_t *from_sep_close_bigger_starts, *from_sep_close_bigger_lists;
+    /* per source level (BuiltList with eliminate_empty_output_lists) */
+    int32_t *from_sep_smaller_starts[BT_MAX_LEVELS];            /* [nonempty+1] */
+    int32_t *from_sep_smaller_lists[BT_MAX_LEVELS];
+    int32_t *from_sep_smaller_nonempty_indices[BT_MAX_LEVELS];  /* [nonempty]   */
+    int32_t *from_sep_smaller_compressed_indices[BT_MAX_LEVELS];/* [ntarget_boxes+1] */
+    int32_t *target_boxes_sep_smaller[BT_MAX_LEVELS];           /* [nonempty]   */
+} bt_trav_arrays;
+
+int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BOXTREE_HIP_H */

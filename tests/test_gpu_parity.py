@@ -1,0 +1,252 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
+the same seeded inputs -- every Tree / FMMTraversalInfo array must be identical
+-- plus the reference tests' invariants on the GPU output."""
+
+import ctypes as ct
+
+import numpy as np
+import pytest
+
+from compare import assert_same_traversal, assert_same_tree
+from invariants import check_traversal, check_tree, constant_one_potentials
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def actx():
+    from boxtree_amd import HIPArrayContext
+    return HIPArrayContext(0)
+
+
+def normal_particles(n, dims, dtype, seed=15):
+    rng = np.random.default_rng(seed)
+    return [rng.standard_normal(n, dtype=dtype) for _ in range(dims)]
+
+
+def build_both(actx, oracle, particles, targets=None, trav_kw=None, **kw):
+    from boxtree_amd import FMMTraversalBuilder, TreeBuilder
+    dev = lambda arrs: None if arrs is None else [actx.from_numpy(a) for a in arrs]  # noqa: E731
+    dkw = dict(kw)
+    for name in ("source_radii", "target_radii", "refine_weights"):
+        if dkw.get(name) is not None:
+            dkw[name] = actx.from_numpy(dkw[name])
+    tree, _ = TreeBuilder(actx)(actx, dev(particles), targets=dev(targets), **dkw)
+    otree = oracle.build_tree(particles, targets=targets, **kw)
+    htree = actx.to_numpy(tree)
+    assert_same_tree(htree, otree)
+    if trav_kw is None:
+        return htree, otree, None, None
+    tkw = dict(trav_kw)
+    call_kw = {}
+    if "_from_sep_smaller_min_nsources_cumul" in tkw:
+        call_kw["_from_sep_smaller_min_nsources_cumul"] = tkw.pop(
+            "_from_sep_smaller_min_nsources_cumul")
+    trav, _ = FMMTraversalBuilder(actx, **tkw)(actx, tree, **call_kw)
+    otrav = oracle.build_traversal(otree, **trav_kw)
+    htrav = actx.to_numpy(trav)
+    assert_same_traversal(htrav, otrav)
+    return htree, otree, htrav, otrav
+
+
+# ---- primitives ---------------------------------------------------------------
+
+@pytest.mark.parametrize("n", [0, 1, 63, 8192, 8193, 100003, 3 * 10**6])
+@pytest.mark.parametrize("bits", [(0, 64), (0, 63), (5, 29)])
+def test_radix_sort_u64(actx, n, bits):
+    import torch
+    rng = np.random.default_rng(n + bits[1])
+    keys = rng.integers(0, 2**63, size=n, dtype=np.int64).astype(np.uint64)
+    if n > 10:
+        keys[: n // 3] = keys[0]        # heavy duplicates: stability matters
+    vals = rng.integers(0, 2**31, size=n, dtype=np.int64).astype(np.uint32)
+    dk = torch.from_numpy(keys.view(np.int64)).cuda()
+    dv = torch.from_numpy(vals.view(np.int32)).cuda()
+    ok = torch.empty_like(dk)
+    ov = torch.empty_like(dv)
+    from boxtree_amd import _lib
+    torch.cuda.synchronize()
+    _lib.check(actx.lib.bt_radix_sort_u64_u32(
+        actx.handle, ct.c_void_p(dk.data_ptr()), ct.c_void_p(dv.data_ptr()),
+        ct.c_void_p(ok.data_ptr()), ct.c_void_p(ov.data_ptr()), n, bits[0], bits[1]))
+    mask = np.uint64(((1 << (bits[1] - bits[0])) - 1) << bits[0]) if bits[1] - bits[0] < 64 \
+        else np.uint64(2**64 - 1)
+    order = np.argsort(keys & mask, kind="stable")
+    assert np.array_equal(ok.cpu().numpy().view(np.uint64), keys[order])
+    assert np.array_equal(ov.cpu().numpy().view(np.uint32), vals[order])
+
+
+@pytest.mark.parametrize("n", [1, 777, 10**6])
+def test_radix_sort_u32(actx, n):
+    import torch
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 2**20, size=n, dtype=np.int64).astype(np.uint32)
+    vals = np.arange(n, dtype=np.uint32)
+    dk = torch.from_numpy(keys.view(np.int32)).cuda()
+    dv = torch.from_numpy(vals.view(np.int32)).cuda()
+    ok = torch.empty_like(dk)
+    ov = torch.empty_like(dv)
+    from boxtree_amd import _lib
+    torch.cuda.synchronize()
+    _lib.check(actx.lib.bt_radix_sort_u32_u32(
+        actx.handle, ct.c_void_p(dk.data_ptr()), ct.c_void_p(dv.data_ptr()),
+        ct.c_void_p(ok.data_ptr()), ct.c_void_p(ov.data_ptr()), n, 0, 20))
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ok.cpu().numpy().view(np.uint32), keys[order])
+    assert np.array_equal(ov.cpu().numpy().view(np.uint32), vals[order])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("dims", [2, 3])
+@pytest.mark.parametrize("n", [9, 4096, 10**5])
+def test_bounding_box(actx, dtype, dims, n):
+    # test/test_tree.py:50-79
+    from boxtree_amd import BoundingBoxFinder
+    p = normal_particles(n, dims, dtype)
+    bbox, _ = BoundingBoxFinder(actx)(actx, [actx.from_numpy(x) for x in p], None)
+    for i, ax in enumerate("xyz"[:dims]):
+        assert bbox[f"min_{ax}"] == np.min(p[i])
+        assert bbox[f"max_{ax}"] == np.max(p[i])
+
+
+# ---- trees -----------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("dims", [2, 3])
+@pytest.mark.parametrize("n,mpb", [(4, 30), (50, 30), (1000, 5), (10**5, 5), (10**5, 30)])
+def test_particle_tree(actx, oracle, dtype, dims, n, mpb):
+    p = normal_particles(n, dims, dtype)
+    htree, _, _, _ = build_both(actx, oracle, p, max_particles_in_box=mpb)
+    check_tree(htree, p, max_particles_in_box=mpb)
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_explicit_refine_weights(actx, oracle, dims):
+    n = 10**5
+    p = normal_particles(n, dims, np.float64)
+    rw = np.random.default_rng(10).integers(1, 10, (n,), dtype=np.int32)
+    htree, _, _, _ = build_both(actx, oracle, p, refine_weights=rw,
+                                max_leaf_refine_weight=100)
+    check_tree(htree, p, refine_weights=rw, max_leaf_refine_weight=100)
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_non_adaptive(actx, oracle, dims):
+    p = normal_particles(10**4, dims, np.float64)
+    build_both(actx, oracle, p, max_particles_in_box=30, kind="non-adaptive")
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+def test_source_target_tree(actx, oracle, dims):
+    s = normal_particles(2 * 10**5, dims, np.float64, seed=12)
+    t = normal_particles(3 * 10**5, dims, np.float64, seed=19)
+    htree, _, _, _ = build_both(actx, oracle, s, targets=t, max_particles_in_box=10)
+    check_tree(htree, s, targets=t, max_particles_in_box=10)
+
+
+@pytest.mark.parametrize("dims", [2, 3])
+@pytest.mark.parametrize("extent_norm", ["linf", "l2"])
+def test_extent_tree(actx, oracle, dims, extent_norm):
+    ns, nt = 100000, 200000
+    s = normal_particles(ns, dims, np.float64, seed=12)
+    t = normal_particles(nt, dims, np.float64, seed=19)
+    rw = np.zeros(ns + nt, np.int32)
+    rw[:ns] = 1
+    rng = np.random.default_rng(13)
+    sr = 2**rng.uniform(-10, 0, (ns,))
+    tr = 2**rng.uniform(-10, 0, (nt,))
+    htree, _, _, _ = build_both(
+        actx, oracle, s, targets=t, source_radii=sr, target_radii=tr,
+        extent_norm=extent_norm, refine_weights=rw, max_leaf_refine_weight=20,
+        stick_out_factor=0)
+    check_tree(htree, s, targets=t, source_radii=sr, target_radii=tr,
+               extent_norm=extent_norm)
+
+
+def test_user_bbox(actx, oracle):
+    p = [np.random.default_rng(3).random(20000) for _ in range(3)]
+    bbox = np.array([[-0.5, 1.5]] * 3)
+    build_both(actx, oracle, p, max_particles_in_box=20, bbox=bbox,
+               trav_kw={})
+
+
+def test_max_levels_exceeded(actx):
+    from boxtree_amd import MaxLevelsExceeded, TreeBuilder
+    p = [np.zeros(100), np.zeros(100)]
+    p[0][:50] = 1
+    with pytest.raises(MaxLevelsExceeded):
+        TreeBuilder(actx)(actx, [actx.from_numpy(x) for x in p], max_particles_in_box=10)
+
+
+def test_argument_errors(actx):
+    from boxtree_amd import TreeBuilder
+    tb = TreeBuilder(actx)
+    p = [actx.from_numpy(np.zeros(10)) for _ in range(2)]
+    with pytest.raises(ValueError):
+        tb(actx, p, kind="bogus", max_particles_in_box=3)
+    with pytest.raises(ValueError):
+        tb(actx, p)
+    with pytest.raises(ValueError):
+        tb(actx, p, max_particles_in_box=3, refine_weights=actx.from_numpy(
+            np.ones(10, np.int32)), max_leaf_refine_weight=3)
+    with pytest.raises(ValueError):
+        tb(actx, p, max_particles_in_box=3, source_radii=actx.from_numpy(np.zeros(10)))
+    with pytest.raises(TypeError):
+        tb(actx, p, targets=p, max_particles_in_box=3, stick_out_factor=0,
+           target_radii=actx.from_numpy(np.zeros(10, np.float32)))
+
+
+# ---- traversals ---------------------------------------------------------------------
+
+@pytest.mark.parametrize("dims,sat", [(2, True), (2, False), (3, True), (3, False)])
+def test_tree_connectivity(actx, oracle, dims, sat):
+    s = normal_particles(10**5, dims, np.float64)
+    t = None if sat else normal_particles(2 * 10**5, dims, np.float64)
+    htree, _, htrav, _ = build_both(actx, oracle, s, targets=t,
+                                    max_particles_in_box=30, trav_kw={})
+    check_traversal(htree, htrav)
+
+
+@pytest.mark.parametrize("well_sep_is_n_away", [1, 2])
+@pytest.mark.parametrize("dims,ns,nt,ext,extent_norm,crit", [
+    (2, 10**5, None, "", "linf", "static_linf"),
+    (2, 5 * 10**4, 4 * 10**4, "", "linf", "static_linf"),
+    (2, 10**5, 4 * 10**4, "t", "linf", "static_linf"),
+    (3, 10**5, None, "", "linf", "static_linf"),
+    (3, 10**5, 4 * 10**4, "", "linf", "static_linf"),
+    (3, 10**5, 4 * 10**4, "t", "linf", "static_linf"),
+    (3, 10**5, 4 * 10**4, "t", "linf", "precise_linf"),
+    (3, 10**5, 4 * 10**4, "t", "l2", "precise_linf"),
+    (3, 10**5, 4 * 10**4, "t", "l2", "static_l2"),
+])
+def test_fmm_completeness(actx, oracle, dims, ns, nt, ext, extent_norm, crit,
+                          well_sep_is_n_away):
+    s = normal_particles(ns, dims, np.float64, seed=15)
+    t = None if nt is None else normal_particles(nt, dims, np.float64, seed=16)
+    rng = np.random.default_rng(12)
+    tr = 2**rng.uniform(-10, 0, (nt,)) if "t" in ext else None
+    htree, _, htrav, _ = build_both(
+        actx, oracle, s, targets=t, max_particles_in_box=30, target_radii=tr,
+        stick_out_factor=0.25, extent_norm=extent_norm,
+        trav_kw=dict(well_sep_is_n_away=well_sep_is_n_away, from_sep_smaller_crit=crit))
+    pot = constant_one_potentials(htree, htrav)
+    assert np.all(pot == ns)
+
+
+def test_from_sep_smaller_threshold(actx, oracle):
+    # test/test_fmm.py:617-665 (source-count thresholding of list 3)
+    s = normal_particles(5 * 10**4, 3, np.float64, seed=15)
+    t = normal_particles(10**4, 3, np.float64, seed=16)
+    tr = 2**np.random.default_rng(12).uniform(-10, 0, (10**4,))
+    build_both(actx, oracle, s, targets=t, max_particles_in_box=30, target_radii=tr,
+               stick_out_factor=0.25,
+               trav_kw=dict(_from_sep_smaller_min_nsources_cumul=15))
+
+
+def test_uniform_config_c2_small(actx, oracle):
+    # BASELINE.json configs[1] recipe (3D uniform, mpb=64) at a size the oracle
+    # finishes in seconds
+    rng = np.random.default_rng(15)
+    p = [rng.random(10**6) for _ in range(3)]
+    htree, _, htrav, _ = build_both(actx, oracle, p, max_particles_in_box=64, trav_kw={})
+    check_traversal(htree, htrav)
