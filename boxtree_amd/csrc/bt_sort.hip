@@ -331,10 +331,11 @@ template <class KeyT>
 static int sort_api(bt_context *ctx, KeyT *keys_in, uint32_t *vals_in, KeyT *keys_out,
                     uint32_t *vals_out, int64_t n, int begin_bit, int end_bit)
 {
-    if (!ctx || !keys_in || !vals_in || !keys_out || !vals_out || n < 0) {
+    if (!ctx || n < 0 || (n > 0 && (!keys_in || !vals_in || !keys_out || !vals_out))) {
         bt::set_error("bt_radix_sort: NULL argument or negative n");
         return BT_ERR_INVALID;
     }
+    if (n == 0) return BT_OK;
     BT_HIP_CHECK(hipSetDevice(ctx->device));
     BT_CHECK(bt::reset_status(ctx));
     bool in_b = false;
