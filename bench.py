@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: TreeBuilder + FMMTraversalBuilder on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c3] [--n N_POINTS]
+
+A "step" is one full pass of the hot path (tree build + traversal build) over
+one batch of synthetic particles already resident in HBM.  Rank 0 prints ONE
+JSON line (see DESIGN.md section "Measurement").
+
+Workloads (BASELINE.json configs):
+  c2  3D uniform, 10^7 sources=targets, max_particles_in_box=64
+  c3  3D sphere surface, 10^8 points, max_particles_in_box=64   (default: the
+      configuration the metric "3D 10^8 pts" is quoted on)
+  c4  3D 10^8 sources + 10^7 targets with target radii, stick_out_factor=0.25
+For --gpus N > 1 every rank holds its own chunk of the workload (weak scaling):
+global bounding box by RCCL all-reduce, particles exchanged all-to-all by
+top-level Morton cell, then every rank builds the subtrees it owns.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"])
+    ap.add_argument("--n", type=int, default=None, help="override particle count per GPU")
+    ap.add_argument("--cpu-sample", type=int, default=1_000_000,
+                    help="particles in the CPU-baseline sample (0 disables)")
+    ap.add_argument("--mpb", type=int, default=64)
+    return ap.parse_args()
+
+
+# {{{ synthetic data (on device)
+
+def make_workload(torch, device, workload, n, seed):
+    """Returns dict(particles=[x,y,z], targets=None|[...], target_radii=None|t, kw=...)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    f64 = torch.float64
+    if workload == "c2":
+        n = n or 10**7
+        pts = [torch.rand(n, generator=g, dtype=f64, device=device) for _ in range(3)]
+        return dict(name="3D uniform random, sources=targets", n=n, particles=pts,
+                    targets=None, kw={})
+    if workload == "c3":
+        n = n or 10**8
+        v = [torch.randn(n, generator=g, dtype=f64, device=device) for _ in range(3)]
+        nrm = torch.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
+        pts = [(c / nrm).contiguous() for c in v]
+        del v, nrm
+        return dict(name="3D sphere-surface points, sources=targets", n=n, particles=pts,
+                    targets=None, kw={})
+    if workload == "c4":
+        n = n or 10**8
+        nt = max(n // 10, 1)
+        src = [torch.rand(n, generator=g, dtype=f64, device=device) for _ in range(3)]
+        tgt = [torch.rand(nt, generator=g, dtype=f64, device=device) for _ in range(3)]
+        radii = (2.0 ** (-10.0 * torch.rand(nt, generator=g, dtype=f64, device=device))
+                 * 2.0 ** -7)
+        return dict(name="3D uniform sources + 10% targets with radii", n=n + nt,
+                    particles=src, targets=tgt,
+                    kw=dict(target_radii=radii, stick_out_factor=0.25))
+    raise ValueError(workload)
+
+
+def make_workload_numpy(workload, n, seed):
+    """Same recipes on the host for the CPU baseline sample."""
+    rng = np.random.default_rng(seed)
+    if workload == "c2":
+        return dict(particles=[rng.random(n) for _ in range(3)], targets=None, kw={})
+    if workload == "c3":
+        v = rng.standard_normal((3, n))
+        v /= np.sqrt((v * v).sum(axis=0))
+        return dict(particles=[np.ascontiguousarray(v[i]) for i in range(3)],
+                    targets=None, kw={})
+    if workload == "c4":
+        nt = max(n // 10, 1)
+        return dict(particles=[rng.random(n) for _ in range(3)],
+                    targets=[rng.random(nt) for _ in range(3)],
+                    kw=dict(target_radii=2.0 ** (-10.0 * rng.random(nt)) * 2.0 ** -7,
+                            stick_out_factor=0.25))
+    raise ValueError(workload)
+
+# }}}
+
+
+def cpu_baseline(workload, n_sample, mpb):
+    """The CPU oracle ("port" of the reference algorithm, 1 thread) timed on a
+    bounded sample of the same workload.  Reported, never the target."""
+    from oracle import oracle
+    oracle.build_lib()
+    w = make_workload_numpy(workload, n_sample, 15)
+    nn = len(w["particles"][0]) + (len(w["targets"][0]) if w["targets"] else 0)
+    t0 = time.perf_counter()
+    tree = oracle.build_tree(w["particles"], targets=w["targets"],
+                             max_particles_in_box=mpb, **w["kw"])
+    oracle.build_traversal(tree)
+    dt = time.perf_counter() - t0
+    return {
+        "value": nn / dt, "unit": "particles/s", "cores": 1, "kind": "port",
+        "sample": f"{workload} recipe at {nn} particles (tree build + traversal, "
+                  f"oracle/boxtree_oracle.c, {dt:.2f} s, {os.cpu_count()} host cores present)",
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
+    from boxtree_amd import _lib
+
+    actx = HIPArrayContext(local_rank)
+    tb = TreeBuilder(actx)
+    tg = FMMTraversalBuilder(actx)
+
+    w = make_workload(torch, device, args.workload, args.n, 15 + rank)
+    n_local = w["n"]
+    build_kw = dict(w["kw"])
+    particles, targets = w["particles"], w["targets"]
+
+    if distributed:
+        from boxtree_amd.distributed import exchange_particles
+        particles, targets, build_kw, xstats = exchange_particles(
+            actx, dist, particles, targets, build_kw)
+    torch.cuda.synchronize()
+
+    stage_acc: dict[str, float] = {}
+    sort_ms = []
+    info = {}
+
+    def step():
+        tree, _ = tb(actx, particles, targets=targets,
+                     max_particles_in_box=args.mpb, **build_kw)
+        st = _lib.SortStats()
+        actx.lib.bt_get_sort_stats(actx.handle, st)
+        trav, _ = tg(actx, tree)
+        times = dict(tb.last_stage_times)
+        stt = _lib.StageTimes()
+        actx.lib.bt_get_stage_times(actx.handle, stt)
+        for i in range(stt.n):
+            times[stt.name[i].decode()] = float(stt.ms[i])
+        info.update(nboxes=int(tree.nboxes), nlevels=int(tree.nlevels),
+                    n_list1=int(trav.neighbor_source_boxes_lists.shape[0]),
+                    n_list2=int(trav.from_sep_siblings_lists.shape[0]),
+                    n_colleagues=int(trav.same_level_non_well_sep_boxes_lists.shape[0]))
+        return st, times
+
+    for _ in range(args.warmup):
+        step()
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st, times = step()
+        sort_ms.append((st.pass_ms_avg, st.passes, st.n))
+        for k, v in times.items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        nn = torch.tensor([n_local], dtype=torch.int64, device=device)
+        dist.all_reduce(nn)
+        n_total = int(nn.item())
+    else:
+        n_total = n_local
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = n_total * args.steps / elapsed
+        pass_ms = float(np.mean([s[0] for s in sort_ms]))
+        n_sorted = sort_ms[-1][2]
+        achieved = 24.0 * n_sorted / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
+        out = {
+            "metric": "particles/sec tree build+traversal (3D); radix-sort HBM GB/s vs peak",
+            "value": value,
+            "unit": "particles/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64 coordinates, u64 Morton keys, int32 ids",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {w['name']}, {n_local} particles per GPU, "
+                            f"max_particles_in_box={args.mpb}, kind=adaptive",
+                "nboxes": info.get("nboxes"), "nlevels": info.get("nlevels"),
+                "list1_entries": info.get("n_list1"), "list2_entries": info.get("n_list2"),
+                "parallelism": f"{world} rank(s), one per GPU, shard by top-level Morton cell",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "onesweep_kernel<u64> (one 8-bit digit pass of the Morton-key sort)",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": 24.0 * n_sorted,
+                "avg_launch_ms": pass_ms,
+                "passes_per_sort": sort_ms[-1][1],
+            },
+            "stages_ms": {k: v / args.steps for k, v in stage_acc.items()},
+        }
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, args.mpb)
+        print(json.dumps(out))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

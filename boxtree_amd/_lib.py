@@ -31,7 +31,7 @@ PL = vp * BT_MAX_LEVELS
 
 
 class SortStats(ct.Structure):
-    _fields_ = [("passes", ct.c_int32), ("pass_ms_avg", ct.c_float),
+    _fields_ = [("n", ct.c_int64), ("passes", ct.c_int32), ("pass_ms_avg", ct.c_float),
                 ("hist_ms", ct.c_float), ("total_ms", ct.c_float)]
 
 

@@ -119,6 +119,11 @@ struct bt_context {
     // timing of the last bt_radix_sort call (HIP events on ctx->stream)
     float last_sort_pass_ms = 0.f;
     int last_sort_passes = 0;
+    int64_t last_sort_n = 0;
+    // same, for the last 64-bit-key sort (the tree build's main sort)
+    float last_sort64_pass_ms = 0.f;
+    int last_sort64_passes = 0;
+    int64_t last_sort64_n = 0;
     float stage_ms[32] = {0};
 };
 

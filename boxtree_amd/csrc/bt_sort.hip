@@ -312,6 +312,12 @@ int radix_sort_pairs(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t
     for (auto &e : ev) (void) hipEventDestroy(e);
     ctx->last_sort_passes = npasses;
     ctx->last_sort_pass_ms = pass_ms / npasses;
+    ctx->last_sort_n = n;
+    if (sizeof(KeyT) == 8) {
+        ctx->last_sort64_passes = npasses;
+        ctx->last_sort64_pass_ms = pass_ms / npasses;
+        ctx->last_sort64_n = n;
+    }
     ctx->stage_ms[30] = hist_ms;
     ctx->stage_ms[31] = hist_ms + pass_ms;
     *in_b = (npasses & 1) != 0;
@@ -369,8 +375,9 @@ int bt_radix_sort_u32_u32(bt_context *ctx, uint32_t *keys_in, uint32_t *vals_in,
 int bt_get_sort_stats(bt_context *ctx, bt_sort_stats *out)
 {
     if (!ctx || !out) return BT_ERR_INVALID;
-    out->passes = ctx->last_sort_passes;
-    out->pass_ms_avg = ctx->last_sort_pass_ms;
+    out->passes = ctx->last_sort64_passes;
+    out->pass_ms_avg = ctx->last_sort64_pass_ms;
+    out->n = ctx->last_sort64_n;
     out->hist_ms = ctx->stage_ms[30];
     out->total_ms = ctx->stage_ms[31];
     return BT_OK;

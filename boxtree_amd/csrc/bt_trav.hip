@@ -143,8 +143,11 @@ __device__ __forceinline__ void gen_colleagues(const TravArgs<T, D> &a, int32_t 
             const bool a_or_o = adj_nbhd<T, D>(a.root_extent, center, level, (T) a.nway, wc,
                                                a.levels[wb]);
             if (a_or_o) {
-                if (w.size + 1 == level && wb != box_id) {
-                    emit(wb);
+                // The reference (traversal.py:438-452) pushes box_id itself and then
+                // walks its whole subtree without ever emitting (nothing below
+                // `level` can be on `level`); stopping at `level` gives the same list.
+                if (w.size + 1 == level) {
+                    if (wb != box_id) emit(wb);
                 } else {
                     w.push(wb);
                     continue;
@@ -584,17 +587,48 @@ struct TravState {
     Buf<int32_t> l3_lists;
     Buf<int32_t> l3_cidx;              // [nlevels][ntb+1]
     std::vector<int64_t> l3_level_base, l3_level_count, l3_nonempty;
+    std::vector<std::pair<const char *, hipEvent_t>> events;
     bool built = false;
 };
 
 void bt_free_trav_state(bt_context *ctx)
 {
-    if (ctx->trav) { delete ctx->trav; ctx->trav = nullptr; }
+    if (ctx->trav) {
+        for (auto &e : ctx->trav->events) (void) hipEventDestroy(e.second);
+        delete ctx->trav;
+        ctx->trav = nullptr;
+    }
+}
+
+int bt_trav_stage_times(bt_context *ctx, bt_stage_times *out, int n)
+{
+    TravState *st = ctx->trav;
+    if (!st) return n;
+    for (size_t i = 1; i < st->events.size() && n < BT_NUM_STAGES; ++i) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, st->events[i - 1].second, st->events[i].second) != hipSuccess) {
+            (void) hipGetLastError();
+            ms = -1.f;
+        }
+        out->ms[n] = ms;
+        out->name[n] = st->events[i].first;
+        ++n;
+    }
+    return n;
 }
 
 namespace {
 
 inline unsigned nblk(int64_t n) { return (unsigned) std::max<int64_t>(1, div_up(n, 256)); }
+
+int tmark(bt_context *ctx, TravState *st, const char *name)
+{
+    hipEvent_t e;
+    BT_HIP_CHECK(hipEventCreate(&e));
+    BT_HIP_CHECK(hipEventRecord(e, ctx->stream));
+    st->events.push_back({name, e});
+    return BT_OK;
+}
 
 int read_i32(bt_context *ctx, const int32_t *d, int32_t *h)
 {
@@ -646,6 +680,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     const bool sat = p.sources_are_targets;
     st->with_extent = p.sources_have_extent || p.targets_have_extent;
 
+    BT_CHECK(tmark(ctx, st, "trav:start"));
     // T1
     BT_CHECK(compact_boxes(ctx, p, BT_BOX_IS_SOURCE_BOX, p.source_boxes_mask, st->source_boxes, &st->nsb));
     BT_CHECK(compact_boxes(ctx, p, BT_BOX_HAS_SOURCE_CHILD_BOXES, p.source_parent_boxes_mask,
@@ -696,6 +731,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     a.target_boxes = st->target_boxes; a.ntarget_boxes = (int32_t) st->ntb;
     a.ttp_boxes = st->ttp_boxes.get(); a.nttp = (int32_t) st->nttp;
 
+    BT_CHECK(tmark(ctx, st, "trav:boxlists"));
     // T3 colleagues
     {
         CsrList &c = st->coll;
@@ -709,6 +745,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     a.coll_starts = st->coll.starts.get();
     a.coll_lists = st->coll.lists.get();
 
+    BT_CHECK(tmark(ctx, st, "trav:colleagues"));
     // T4 list 1
     {
         CsrList &c = st->l1;
@@ -719,6 +756,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         BT_CHECK(c.lists.alloc(ctx->pool, c.total));
         list_kernel<T, D, GEN_L1, true><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), c.lists.get());
     }
+    BT_CHECK(tmark(ctx, st, "trav:list1"));
     // T5 list 2
     {
         CsrList &c = st->l2;
@@ -730,6 +768,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         list_kernel<T, D, GEN_L2, true><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), c.lists.get());
     }
 
+    BT_CHECK(tmark(ctx, st, "trav:list2"));
     // T6 list 3: one walk for all source levels
     {
         const int64_t ntb = st->ntb;
@@ -782,6 +821,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         for (int l = 0; l < nlevels; ++l) st->l3_nonempty[l] = h_ne[l];
     }
 
+    BT_CHECK(tmark(ctx, st, "trav:list3"));
     // T7 list 4 (+ close, re-indexed to target boxes)
     {
         CsrList &c = st->l4;
@@ -825,6 +865,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         }
     }
     BT_HIP_CHECK(hipGetLastError());
+    BT_CHECK(tmark(ctx, st, "trav:list4"));
     BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
 
     out->nsource_boxes = st->nsb; out->ntarget_boxes = st->ntb;
@@ -951,6 +992,7 @@ int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
             (int32_t) st->l3_level_count[l]);
     }
     BT_HIP_CHECK(hipGetLastError());
+    BT_CHECK(tmark(ctx, st, "trav:export"));
     BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return BT_OK;
 }

@@ -879,6 +879,7 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
     const bool sat = st->sat;
     auto blocks = [](int64_t n) { return (unsigned) std::max<int64_t>(1, div_up(n, 256)); };
 
+    BT_CHECK(mark(ctx, st, "(host gap)"));
     // ---- ids -------------------------------------------------------------------
     if (N > 0) {
         if (sat) {
@@ -991,6 +992,8 @@ int dispatch_dims_export(bt_context *ctx, TreeState *st, const bt_tree_arrays *o
 }
 
 }  // namespace
+
+int bt_trav_stage_times(bt_context *ctx, bt_stage_times *out, int n);   // bt_trav.hip
 
 extern "C" {
 
@@ -1113,27 +1116,26 @@ int bt_tree_export(bt_context *ctx, const bt_tree_arrays *o)
     return s;
 }
 
-static const char *g_stage_names[BT_NUM_STAGES];
-
 int bt_get_stage_times(bt_context *ctx, bt_stage_times *out)
 {
     if (!ctx || !out) return BT_ERR_INVALID;
     memset(out, 0, sizeof(*out));
     TreeState *st = ctx->tree;
-    if (!st) return BT_OK;
     int n = 0;
-    for (size_t i = 1; i < st->events.size() && n < BT_NUM_STAGES; ++i) {
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, st->events[i - 1].second, st->events[i].second) != hipSuccess) {
-            (void) hipGetLastError();
-            ms = -1.f;
+    if (st) {
+        for (size_t i = 1; i < st->events.size() && n < BT_NUM_STAGES; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, st->events[i - 1].second, st->events[i].second)
+                    != hipSuccess) {
+                (void) hipGetLastError();
+                ms = -1.f;
+            }
+            out->ms[n] = ms;
+            out->name[n] = st->events[i].first;
+            ++n;
         }
-        g_stage_names[n] = st->events[i].first;
-        out->ms[n] = ms;
-        out->name[n] = g_stage_names[n];
-        ++n;
     }
-    out->n = n;
+    out->n = bt_trav_stage_times(ctx, out, n);
     return BT_OK;
 }
 

@@ -100,8 +100,10 @@ int bt_radix_sort_u32_u32(bt_context *ctx, uint32_t *keys_in, uint32_t *vals_in,
                           int begin_bit, int end_bit);
 
 typedef struct {
-    int32_t passes;            /* digit passes of the last bt_radix_sort_* call  */
-    float pass_ms_avg;         /* HIP-event time of the onesweep kernel / passes */
+    int64_t n;                 /* pairs sorted                                    */
+    int32_t passes;            /* digit passes of the last 64-bit-key sort (the   */
+                               /* tree build's main sort or bt_radix_sort_u64_u32) */
+    float pass_ms_avg;         /* HIP-event time of the onesweep kernels / passes */
     float hist_ms;             /* up-front histogram kernel                      */
     float total_ms;
 } bt_sort_stats;
