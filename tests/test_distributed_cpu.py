@@ -1,0 +1,110 @@
+"""N>1 path on CPU: world_size-2 gloo run of the particle exchange that precedes
+the per-rank tree build (boxtree_amd/distributed.py).  No GPU needed."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, dims, with_targets, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from boxtree_amd.distributed import exchange_particles, morton_cells
+        rng = np.random.default_rng(15 + rank)
+        n = 20000 + 1000 * rank
+        pts = [torch.from_numpy(rng.standard_normal(n)) for _ in range(dims)]
+        tgts = None
+        kw = {}
+        if with_targets:
+            tgts = [torch.from_numpy(rng.random(5000)) for _ in range(dims)]
+            kw = {"target_radii": torch.from_numpy(2.0 ** rng.uniform(-10, 0, 5000) * 2.0 ** -7),
+                  "stick_out_factor": 0.25}
+        newp, newt, nkw, st = exchange_particles(None, dist, pts, tgts, kw, return_plan=True)
+        cells = morton_cells(newp, st["bbox_min"], st["bbox_max"], st["top_level"]).numpy()
+        res = dict(
+            rank=rank,
+            sent=np.stack([p.numpy() for p in pts]),
+            got=np.stack([p.numpy() for p in newp]),
+            owner=st["owner"], bbox=nkw["bbox"], cells=cells,
+            tsent=None if tgts is None else np.stack([t.numpy() for t in tgts]
+                                                     + [kw["target_radii"].numpy()]),
+            tgot=None if newt is None else np.stack([t.numpy() for t in newt]
+                                                    + [nkw["target_radii"].numpy()]),
+        )
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dims,with_targets", [(3, False), (2, True)])
+def test_exchange_world2(dims, with_targets):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, with_targets, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results.sort(key=lambda r: r["rank"])
+
+    # identical plan on all ranks
+    assert np.array_equal(results[0]["owner"], results[1]["owner"])
+    assert np.array_equal(results[0]["bbox"], results[1]["bbox"])
+    owner = results[0]["owner"]
+    assert np.all(np.diff(owner) >= 0)          # contiguous Morton ranges
+    assert set(owner.tolist()) <= {0, 1}
+
+    # nothing lost, nothing duplicated
+    def rows(a):
+        a = np.ascontiguousarray(a.T)
+        return a[np.lexsort(a.T[::-1])]
+    sent = np.concatenate([r["sent"] for r in results], axis=1)
+    got = np.concatenate([r["got"] for r in results], axis=1)
+    assert np.array_equal(rows(sent), rows(got))
+    if with_targets:
+        tsent = np.concatenate([r["tsent"] for r in results], axis=1)
+        tgot = np.concatenate([r["tgot"] for r in results], axis=1)
+        assert np.array_equal(rows(tsent), rows(tgot))
+
+    # every rank received exactly the particles of the cells it owns
+    for r in results:
+        assert np.all(owner[r["cells"]] == r["rank"])
+    # root box covers everything and is square
+    bbox = results[0]["bbox"]
+    assert np.all(bbox[:, 0] <= sent.min(axis=1)) and np.all(bbox[:, 1] > sent.max(axis=1))
+    ext = bbox[:, 1] - bbox[:, 0]
+    assert np.all(np.abs(ext - ext[0]) < 1e-15)
+    # balance: within 25% of even
+    sizes = [r["got"].shape[1] for r in results]
+    assert max(sizes) < 1.25 * sum(sizes) / world + 1
+
+
+def test_partition_cells_is_deterministic():
+    from boxtree_amd.distributed import partition_cells
+    hist = np.random.default_rng(0).integers(0, 1000, 4096)
+    o1 = partition_cells(hist, 8)
+    o2 = partition_cells(hist.copy(), 8)
+    assert np.array_equal(o1, o2)
+    assert np.all(np.diff(o1) >= 0) and o1.min() == 0 and o1.max() == 7
+    loads = np.bincount(o1, weights=hist, minlength=8)
+    assert loads.max() < 1.2 * hist.sum() / 8
