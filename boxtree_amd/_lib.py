@@ -96,6 +96,7 @@ class TravParams(ct.Structure):
         ("from_sep_smaller_crit", ct.c_int32),
         ("from_sep_smaller_min_nsources_cumul", ct.c_int32),
         ("source_boxes_mask", vp), ("source_parent_boxes_mask", vp),
+        ("force_generic", ct.c_int32),
     ]
 
 

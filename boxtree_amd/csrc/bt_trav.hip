@@ -40,6 +40,7 @@ struct TravArgs {
     int32_t min_nsources_cumul;
     int targets_have_extent;
     int close_lists_exist;
+    int fast;                     // structure verified by check_structure_kernel
     // lists built earlier
     const int32_t *target_boxes; int32_t ntarget_boxes;
     const int32_t *ttp_boxes; int32_t nttp;
@@ -250,6 +251,9 @@ __device__ __forceinline__ void gen_list3(const TravArgs<T, D> &a, int32_t tbn, 
     for (int32_t i = s0; i < s1; ++i) {
         const int32_t nws = a.coll_lists[i];
         if (nws == tgt) continue;
+        // nothing below a colleague without source children can be emitted
+        // (flag consistency is part of the verified structure)
+        if (a.fast && !(a.flags[nws] & BT_BOX_HAS_SOURCE_CHILD_BOXES)) continue;
         Walk w;
         w.init(nws);
         while (w.go) {
@@ -563,6 +567,8 @@ __global__ __launch_bounds__(256) void merge_copy_kernel(int32_t n, MergeCount m
     for (int32_t j = s; j < e; ++j) new_lists[o++] = raw_lists[j];
 }
 
+#include "bt_trav_fast.hpp"
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -587,6 +593,8 @@ struct TravState {
     Buf<int32_t> l3_lists;
     Buf<int32_t> l3_cidx;              // [nlevels][ntb+1]
     std::vector<int64_t> l3_level_base, l3_level_count, l3_nonempty;
+    Buf<int32_t> subtree_size, dfs_rank, box_of_rank;
+    bool fast = false;
     std::vector<std::pair<const char *, hipEvent_t>> events;
     bool built = false;
 };
@@ -671,6 +679,126 @@ int compact_boxes(bt_context *ctx, const bt_trav_params &p, uint8_t bits, const 
     return BT_OK;
 }
 
+template <class U>
+int grow_buf(bt_context *ctx, Buf<U> &buf, int64_t used, int64_t need)
+{
+    if (need <= buf.size()) return BT_OK;
+    int64_t nc = std::max<int64_t>(buf.size() * 2, 1024);
+    while (nc < need) nc *= 2;
+    Buf<U> nb;
+    BT_CHECK(nb.alloc(ctx->pool, nc));
+    if (used > 0)
+        BT_HIP_CHECK(hipMemcpyAsync(nb.get(), buf.get(), (size_t) used * sizeof(U),
+                                    hipMemcpyDeviceToDevice, ctx->stream));
+    buf.swap(nb);
+    return BT_OK;
+}
+
+// colleagues + list 2 (top-down from the parent's colleagues) and list 1 (from the
+// ancestors' colleagues), see bt_trav_fast.hpp
+template <class T, int D>
+int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
+{
+    constexpr int C = 1 << D;
+    const bt_trav_params &p = st->p;
+    const int64_t B = p.nboxes;
+    const int nlevels = p.nlevels;
+    const int32_t *ls = p.level_start_box_nrs;       // host
+
+    // depth-first preorder ranks
+    BT_CHECK(st->subtree_size.alloc(ctx->pool, B));
+    BT_CHECK(st->dfs_rank.alloc(ctx->pool, B));
+    BT_CHECK(st->box_of_rank.alloc(ctx->pool, B));
+    for (int lev = nlevels - 1; lev >= 0; --lev)
+        subtree_size_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
+            ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
+            st->subtree_size.get());
+    for (int lev = 0; lev < nlevels; ++lev)
+        dfs_rank_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
+            ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
+            st->subtree_size.get(), st->dfs_rank.get(), st->box_of_rank.get());
+    FastTree ft{st->dfs_rank.get(), st->box_of_rank.get()};
+
+    // colleagues + list 2, level by level
+    CsrList &coll = st->coll;
+    coll.n = B;
+    BT_CHECK(coll.starts.alloc(ctx->pool, B + 1));
+    Buf<int32_t> l2_by_box;
+    BT_CHECK(l2_by_box.alloc(ctx->pool, B + 1));
+    BT_HIP_CHECK(hipMemsetAsync(coll.starts.get(), 0, (size_t) (B + 1) * 4, ctx->stream));
+    BT_HIP_CHECK(hipMemsetAsync(l2_by_box.get(), 0, (size_t) (B + 1) * 4, ctx->stream));
+    Buf<int32_t> l2_lists;
+    BT_CHECK(grow_buf(ctx, coll.lists, 0, std::max<int64_t>(B * 10, 1024)));
+    BT_CHECK(grow_buf(ctx, l2_lists, 0, std::max<int64_t>(B * 40, 1024)));
+    int64_t coll_total = 0, l2_total = 0;
+    Buf<int32_t> totals_d;
+    BT_CHECK(totals_d.alloc(ctx->pool, 2));
+    for (int lev = 1; lev < nlevels; ++lev) {
+        const int32_t b0 = ls[lev], nb = ls[lev + 1] - ls[lev];
+        Buf<int32_t> ccnt, lcnt, crel, lrel;
+        BT_CHECK(ccnt.alloc(ctx->pool, nb));
+        BT_CHECK(lcnt.alloc(ctx->pool, nb));
+        BT_CHECK(crel.alloc(ctx->pool, nb + 1));
+        BT_CHECK(lrel.alloc(ctx->pool, nb + 1));
+        a.coll_starts = coll.starts.get();
+        a.coll_lists = coll.lists.get();
+        CollL2Out oc{ccnt.get(), lcnt.get(), nullptr, nullptr};
+        coll_l2_kernel<T, D, false><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(a, b0, nb, oc);
+        ScanI32 fc{ccnt.get()}, fl{lcnt.get()};
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, fc, nb, crel.get(), totals_d.get(), true)));
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, fl, nb, lrel.get(), totals_d.get() + 1, true)));
+        int32_t h_tot[2] = {0, 0};
+        BT_HIP_CHECK(hipMemcpyAsync(h_tot, totals_d.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (coll_total + h_tot[0] >= ((int64_t) 1 << 31) || l2_total + h_tot[1] >= ((int64_t) 1 << 31)) {
+            set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference)");
+            return BT_ERR_UNSUPPORTED;
+        }
+        BT_CHECK(grow_buf(ctx, coll.lists, coll_total, coll_total + h_tot[0]));
+        BT_CHECK(grow_buf(ctx, l2_lists, l2_total, l2_total + h_tot[1]));
+        add_base_kernel<<<nblk(nb + 1), 256, 0, ctx->stream>>>(nb + 1, crel.get(), (int32_t) coll_total,
+                                                              coll.starts.get() + b0);
+        add_base_kernel<<<nblk(nb + 1), 256, 0, ctx->stream>>>(nb + 1, lrel.get(), (int32_t) l2_total,
+                                                              l2_by_box.get() + b0);
+        a.coll_lists = coll.lists.get();
+        CollL2Out of{coll.starts.get(), l2_by_box.get(), coll.lists.get(), l2_lists.get()};
+        coll_l2_kernel<T, D, true><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(a, b0, nb, of);
+        coll_total += h_tot[0];
+        l2_total += h_tot[1];
+    }
+    coll.total = coll_total;
+    a.coll_starts = coll.starts.get();
+    a.coll_lists = coll.lists.get();
+    BT_CHECK(tmark(ctx, st, "trav:colleagues+list2"));
+
+    // list 2 is indexed by position in target_or_target_parent_boxes
+    {
+        CsrList &c = st->l2;
+        c.n = st->nttp;
+        c.total = l2_total;
+        BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
+        gather_starts_kernel<<<nblk(c.n + 1), 256, 0, ctx->stream>>>(
+            (int32_t) c.n, st->ttp_boxes.get(), l2_by_box.get(), (int32_t) l2_total, c.starts.get());
+        c.lists.swap(l2_lists);
+    }
+
+    // list 1
+    {
+        CsrList &c = st->l1;
+        c.n = st->ntb;
+        BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
+        list1_fast_kernel<T, D, false><<<nblk(c.n), 256, 0, ctx->stream>>>(
+            a, ft, (int32_t) c.n, c.starts.get(), nullptr);
+        BT_CHECK(counts_to_starts(ctx, c.starts, c.n, &c.total));
+        BT_CHECK(c.lists.alloc(ctx->pool, c.total));
+        list1_fast_kernel<T, D, true><<<nblk(c.n), 256, 0, ctx->stream>>>(
+            a, ft, (int32_t) c.n, c.starts.get(), c.lists.get());
+    }
+    BT_CHECK(tmark(ctx, st, "trav:list1"));
+    BT_HIP_CHECK(hipGetLastError());
+    return BT_OK;
+}
+
 template <class T, int D>
 int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
 {
@@ -732,42 +860,62 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     a.ttp_boxes = st->ttp_boxes.get(); a.nttp = (int32_t) st->nttp;
 
     BT_CHECK(tmark(ctx, st, "trav:boxlists"));
-    // T3 colleagues
-    {
-        CsrList &c = st->coll;
-        c.n = B;
-        BT_CHECK(c.starts.alloc(ctx->pool, B + 1));
-        list_kernel<T, D, GEN_COLL, false><<<nblk(B), 256, 0, ctx->stream>>>(a, (int32_t) B, c.starts.get(), nullptr);
-        BT_CHECK(counts_to_starts(ctx, c.starts, B, &c.total));
-        BT_CHECK(c.lists.alloc(ctx->pool, c.total));
-        list_kernel<T, D, GEN_COLL, true><<<nblk(B), 256, 0, ctx->stream>>>(a, (int32_t) B, c.starts.get(), c.lists.get());
-    }
-    a.coll_starts = st->coll.starts.get();
-    a.coll_lists = st->coll.lists.get();
 
-    BT_CHECK(tmark(ctx, st, "trav:colleagues"));
-    // T4 list 1
-    {
-        CsrList &c = st->l1;
-        c.n = st->ntb;
-        BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
-        list_kernel<T, D, GEN_L1, false><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), nullptr);
-        BT_CHECK(counts_to_starts(ctx, c.starts, c.n, &c.total));
-        BT_CHECK(c.lists.alloc(ctx->pool, c.total));
-        list_kernel<T, D, GEN_L1, true><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), c.lists.get());
+    // ---- which path? ---------------------------------------------------------------
+    st->fast = false;
+    if (!p.force_generic) {
+        Buf<int> bad;
+        BT_CHECK(bad.alloc(ctx->pool, 1));
+        BT_HIP_CHECK(hipMemsetAsync(bad.get(), 0, sizeof(int), ctx->stream));
+        check_structure_kernel<D><<<nblk(B), 256, 0, ctx->stream>>>(
+            (int32_t) B, p.aligned_nboxes, p.box_parent_ids, p.box_child_ids, p.box_levels,
+            p.box_flags, bad.get());
+        int32_t hb = 1;
+        BT_CHECK(read_i32(ctx, (const int32_t *) bad.get(), &hb));
+        st->fast = hb == 0;
     }
-    BT_CHECK(tmark(ctx, st, "trav:list1"));
-    // T5 list 2
-    {
-        CsrList &c = st->l2;
-        c.n = st->nttp;
-        BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
-        list_kernel<T, D, GEN_L2, false><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), nullptr);
-        BT_CHECK(counts_to_starts(ctx, c.starts, c.n, &c.total));
-        BT_CHECK(c.lists.alloc(ctx->pool, c.total));
-        list_kernel<T, D, GEN_L2, true><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), c.lists.get());
-    }
+    a.fast = st->fast ? 1 : 0;
 
+    if (st->fast) {
+        BT_CHECK((fast_lists<T, D>(ctx, st, a)));
+    } else {
+        // T3 colleagues
+        {
+            CsrList &c = st->coll;
+            c.n = B;
+            BT_CHECK(c.starts.alloc(ctx->pool, B + 1));
+            list_kernel<T, D, GEN_COLL, false><<<nblk(B), 256, 0, ctx->stream>>>(a, (int32_t) B, c.starts.get(), nullptr);
+            BT_CHECK(counts_to_starts(ctx, c.starts, B, &c.total));
+            BT_CHECK(c.lists.alloc(ctx->pool, c.total));
+            list_kernel<T, D, GEN_COLL, true><<<nblk(B), 256, 0, ctx->stream>>>(a, (int32_t) B, c.starts.get(), c.lists.get());
+        }
+        a.coll_starts = st->coll.starts.get();
+        a.coll_lists = st->coll.lists.get();
+
+        BT_CHECK(tmark(ctx, st, "trav:colleagues"));
+        // T4 list 1
+        {
+            CsrList &c = st->l1;
+            c.n = st->ntb;
+            BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
+            list_kernel<T, D, GEN_L1, false><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), nullptr);
+            BT_CHECK(counts_to_starts(ctx, c.starts, c.n, &c.total));
+            BT_CHECK(c.lists.alloc(ctx->pool, c.total));
+            list_kernel<T, D, GEN_L1, true><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), c.lists.get());
+        }
+        BT_CHECK(tmark(ctx, st, "trav:list1"));
+        // T5 list 2
+        {
+            CsrList &c = st->l2;
+            c.n = st->nttp;
+            BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
+            list_kernel<T, D, GEN_L2, false><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), nullptr);
+            BT_CHECK(counts_to_starts(ctx, c.starts, c.n, &c.total));
+            BT_CHECK(c.lists.alloc(ctx->pool, c.total));
+            list_kernel<T, D, GEN_L2, true><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), c.lists.get());
+        }
+
+    }
     BT_CHECK(tmark(ctx, st, "trav:list2"));
     // T6 list 3: one walk for all source levels
     {

@@ -1,0 +1,319 @@
+// Fast list generation for trees whose boxes are numbered level-major with
+// every level in depth-first (Morton) order -- which is what the tree builder
+// produces and what check_structure_kernel verifies for
+// any input tree.  Included by bt_trav.hip inside its anonymous namespace.
+//
+// Instead of walking from the root for every box (traversal.py:398-550), the
+// candidates of box b come from its PARENT's colleague list:
+//   children of (colleagues(parent) U {parent})  =  colleagues(b)  U  list2(b)
+// (traversal.py:556-601 already uses this for list 2).  The reference's float
+// predicates are evaluated unchanged on the candidates, so the lists are
+// identical whenever "child adjacent => parent adjacent" holds for the float
+// test -- rounding errors are ~1e-16*root_extent against a tolerance of one box
+// radius (traversal.py:257-276), and the parity tests compare both paths with
+// the walk-based oracle.
+//
+// Output order.  The walks emit in depth-first order.  Within one level that is
+// ascending box id here; across levels (list 1) entries are ordered by the
+// depth-first preorder rank of the box, computed once per tree.
+
+struct FastTree {
+    const int32_t *dfs_rank;      // [nboxes] preorder rank
+    const int32_t *box_of_rank;   // [nboxes]
+};
+
+// ---- structure check --------------------------------------------------------------
+
+template <int D>
+__device__ __forceinline__ int find_slot(const int32_t *child, int64_t aligned, int32_t parent,
+                                         int32_t b)
+{
+    constexpr int C = 1 << D;
+#pragma unroll
+    for (int m = 0; m < C; ++m)
+        if (child[(int64_t) m * aligned + parent] == b) return m;
+    return -1;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void check_structure_kernel(int32_t nboxes, int64_t aligned,
+        const int32_t *parent, const int32_t *child, const uint8_t *levels, const uint8_t *flags,
+        int *bad)
+{
+    constexpr int C = 1 << D;
+    const int32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nboxes) return;
+    bool ok = true;
+    for (int m = 0; m < C; ++m) {
+        const int32_t c = child[(int64_t) m * aligned + b];
+        if (c != 0) ok = ok && c > b && c < nboxes && parent[c] == b;
+    }
+    if (b == 0) {
+        ok = ok && levels[0] == 0;
+    } else {
+        const int32_t p = parent[b];
+        ok = ok && p >= 0 && p < b;
+        if (ok) {
+            ok = ok && levels[b] == levels[p] + 1;
+            const int slot = find_slot<D>(child, aligned, p, b);
+            ok = ok && slot >= 0;
+            const int32_t q = b - 1;
+            ok = ok && levels[q] <= levels[b];
+            if (ok && levels[q] == levels[b] && q > 0) {
+                const int32_t pq = parent[q];
+                if (pq >= 0 && pq < nboxes) {
+                    const int sq = find_slot<D>(child, aligned, pq, q);
+                    ok = ok && (pq < p || (pq == p && sq < slot));
+                } else ok = false;
+            }
+            // flag consistency: anything with sources below must be reachable
+            if (flags[b] & (BT_BOX_IS_SOURCE_BOX | BT_BOX_HAS_SOURCE_CHILD_BOXES))
+                ok = ok && (flags[p] & BT_BOX_HAS_SOURCE_CHILD_BOXES);
+        }
+    }
+    if (!ok) atomicExch(bad, 1);
+}
+
+// ---- depth-first preorder rank ---------------------------------------------------
+
+template <int D>
+__global__ __launch_bounds__(256) void subtree_size_kernel(int32_t b0, int32_t nb, int64_t aligned,
+        const int32_t *child, int32_t *size)
+{
+    constexpr int C = 1 << D;
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nb) return;
+    const int32_t b = b0 + i;
+    int32_t s = 1;
+#pragma unroll
+    for (int m = 0; m < C; ++m) {
+        const int32_t c = child[(int64_t) m * aligned + b];
+        if (c) s += size[c];
+    }
+    size[b] = s;
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void dfs_rank_kernel(int32_t b0, int32_t nb, int64_t aligned,
+        const int32_t *child, const int32_t *size, int32_t *rank, int32_t *box_of_rank)
+{
+    constexpr int C = 1 << D;
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nb) return;
+    const int32_t p = b0 + i;          // parent whose children get their ranks
+    if (p == 0) { rank[0] = 0; box_of_rank[0] = 0; }
+    int32_t run = ((p == 0) ? 0 : rank[p]) + 1;
+#pragma unroll
+    for (int m = 0; m < C; ++m) {
+        const int32_t c = child[(int64_t) m * aligned + p];
+        if (c) {
+            rank[c] = run;
+            box_of_rank[run] = c;
+            run += size[c];
+        }
+    }
+}
+
+// ---- colleagues + list 2, one level (top-down) ---------------------------------------
+
+struct CollL2Out {
+    int32_t *coll_cnt_or_starts;   // count: [nb] counts ; fill: global starts [nboxes+1]
+    int32_t *l2_cnt_or_starts;
+    int32_t *coll_lists;
+    int32_t *l2_lists;
+};
+
+template <class T, int D, bool FILL>
+__global__ __launch_bounds__(256) void coll_l2_kernel(TravArgs<T, D> a, int32_t b0, int32_t nb,
+                                                      CollL2Out o)
+{
+    constexpr int C = 1 << D;
+    const int32_t t = blockIdx.x * 256 + threadIdx.x;
+    const int32_t g = t / C;
+    const int m = t % C;
+    if (g >= nb) return;                 // whole groups drop out together
+    const int32_t b = b0 + g;
+    const int lane = threadIdx.x & 63;
+    const int gshift = lane / C * C;
+    const uint64_t lanes_below = (1ull << m) - 1ull;
+
+    T center[D];
+    load_center(a, b, center);
+    const int level = a.levels[b];
+    const int32_t p = a.parent[b];
+    const bool ttp = a.flags[b] & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX);
+    const int32_t ps = a.coll_starts[p];
+    const int32_t n = a.coll_starts[p + 1] - ps;
+    int ins = 0;                         // depth-first position of p among its colleagues
+    for (int i = 0; i < n; ++i) ins += (a.coll_lists[ps + i] < p) ? 1 : 0;
+
+    int32_t ccnt = 0, lcnt = 0;
+    int32_t ccur = 0, lcur = 0;
+    if (FILL) { ccur = o.coll_cnt_or_starts[b]; lcur = o.l2_cnt_or_starts[b]; }
+
+    for (int i = 0; i <= n; ++i) {
+        const int32_t c = (i < ins) ? a.coll_lists[ps + i]
+                        : (i == ins ? p : a.coll_lists[ps + i - 1]);
+        const int32_t ch = a.child[(int64_t) m * a.aligned + c];
+        bool is_coll = false, is_l2 = false;
+        if (ch != 0 && ch != b) {
+            T cc[D];
+            load_center(a, ch, cc);
+            const bool a_or_o = adj_nbhd<T, D>(a.root_extent, center, level, (T) a.nway, cc,
+                                               a.levels[ch]);
+            is_coll = a_or_o;                                   // traversal.py:429-442
+            is_l2 = !a_or_o && c != p && ttp;                   // traversal.py:588-597
+        }
+        if (FILL) {
+            const uint64_t bc = (__ballot(is_coll) >> gshift) & ((1ull << C) - 1);
+            const uint64_t bl = (__ballot(is_l2) >> gshift) & ((1ull << C) - 1);
+            if (is_coll) o.coll_lists[ccur + __popcll(bc & lanes_below)] = ch;
+            if (is_l2) o.l2_lists[lcur + __popcll(bl & lanes_below)] = ch;
+            ccur += __popcll(bc);
+            lcur += __popcll(bl);
+        } else {
+            ccnt += is_coll;
+            lcnt += is_l2;
+        }
+    }
+    if (!FILL) {
+#pragma unroll
+        for (int off = C / 2; off > 0; off >>= 1) {
+            ccnt += __shfl_xor(ccnt, off, C);
+            lcnt += __shfl_xor(lcnt, off, C);
+        }
+        if (m == 0) { o.coll_cnt_or_starts[g] = ccnt; o.l2_cnt_or_starts[g] = lcnt; }
+    }
+}
+
+__global__ __launch_bounds__(256) void add_base_kernel(int32_t n, const int32_t *rel, int32_t base,
+                                                       int32_t *dst)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = rel[i] + base;
+}
+
+__global__ __launch_bounds__(256) void gather_starts_kernel(int32_t n, const int32_t *boxes,
+        const int32_t *starts_by_box, int32_t total, int32_t *out)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = starts_by_box[boxes[i]];
+    if (i == n) out[n] = total;
+}
+
+// ---- list 1 from the ancestors' colleague lists ----------------------------------------
+
+__device__ __forceinline__ void sort_i32_inplace(int32_t *v, int n)
+{
+    if (n <= 48) {
+        for (int i = 1; i < n; ++i) {
+            const int32_t x = v[i];
+            int j = i - 1;
+            while (j >= 0 && v[j] > x) { v[j + 1] = v[j]; --j; }
+            v[j + 1] = x;
+        }
+        return;
+    }
+    // heapsort (in place, no recursion) for the rare long lists
+    for (int start = n / 2 - 1; start >= 0; --start) {
+        int root = start;
+        const int32_t x = v[root];
+        while (true) {
+            int ch = 2 * root + 1;
+            if (ch >= n) break;
+            if (ch + 1 < n && v[ch + 1] > v[ch]) ++ch;
+            if (v[ch] <= x) break;
+            v[root] = v[ch];
+            root = ch;
+        }
+        v[root] = x;
+    }
+    for (int end = n - 1; end > 0; --end) {
+        const int32_t x = v[end];
+        v[end] = v[0];
+        int root = 0;
+        while (true) {
+            int ch = 2 * root + 1;
+            if (ch >= end) break;
+            if (ch + 1 < end && v[ch + 1] > v[ch]) ++ch;
+            if (v[ch] <= x) break;
+            v[root] = v[ch];
+            root = ch;
+        }
+        v[root] = x;
+    }
+}
+
+template <class T, int D, bool FILL>
+__global__ __launch_bounds__(256) void list1_fast_kernel(TravArgs<T, D> a, FastTree ft, int32_t n,
+        int32_t *counts_or_starts, int32_t *lists)
+{
+    constexpr int C = 1 << D;
+    const int32_t tbn = blockIdx.x * 256 + threadIdx.x;
+    if (tbn >= n) return;
+    const int32_t b = a.target_boxes[tbn];
+    T center[D];
+    load_center(a, b, center);
+    const int level = a.levels[b];
+
+    int32_t cnt = 0;
+    int32_t *out = FILL ? lists + counts_or_starts[tbn] : nullptr;
+    auto emit = [&](int32_t u) {
+        if (FILL) out[cnt] = ft.dfs_rank[u];
+        ++cnt;
+    };
+
+    if (a.flags[0] & BT_BOX_IS_SOURCE_BOX) emit(0);              // traversal.py:489-495
+
+    // finer boxes: descend like traversal.py:501-547, but only inside box u
+    auto descend = [&](int32_t u) {
+        Walk w;
+        w.init(u);
+        while (w.go) {
+            const int32_t wb = a.child[(int64_t) w.mnr * a.aligned + w.parent];
+            if (wb) {
+                T wc[D];
+                load_center(a, wb, wc);
+                if (adj<T, D>(a.root_extent, center, level, wc, a.levels[wb])) {
+                    const uint8_t wf = a.flags[wb];
+                    if (wf & BT_BOX_IS_SOURCE_BOX) emit(wb);
+                    if (wf & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
+                        w.push(wb);
+                        continue;
+                    }
+                }
+            }
+            w.template advance<C>();
+        }
+    };
+
+    if (level == 0) {
+        // the root as a target box (only with target extents): everything below it
+        if (a.flags[0] & BT_BOX_HAS_SOURCE_CHILD_BOXES) descend(0);
+    }
+
+    // ancestors (and b): their colleagues hold every adjacent box of that level
+    int32_t anc = b;
+    for (int k = level; k >= 1; --k, anc = a.parent[anc]) {
+        const int32_t s0 = a.coll_starts[anc], s1 = a.coll_starts[anc + 1];
+        for (int32_t i = s0 - 1; i < s1; ++i) {
+            const int32_t u = (i < s0) ? anc : a.coll_lists[i];
+            const uint8_t fl = a.flags[u];
+            if (!(fl & (BT_BOX_IS_SOURCE_BOX | BT_BOX_HAS_SOURCE_CHILD_BOXES))) continue;
+            if (u != anc) {
+                T uc[D];
+                load_center(a, u, uc);
+                if (!adj<T, D>(a.root_extent, center, level, uc, k)) continue;
+            }
+            if (fl & BT_BOX_IS_SOURCE_BOX) emit(u);
+            if (k == level && (fl & BT_BOX_HAS_SOURCE_CHILD_BOXES)) descend(u);
+        }
+    }
+
+    if (!FILL) {
+        counts_or_starts[tbn] = cnt;
+    } else {
+        sort_i32_inplace(out, cnt);                 // depth-first preorder
+        for (int i = 0; i < cnt; ++i) out[i] = ft.box_of_rank[out[i]];
+    }
+}

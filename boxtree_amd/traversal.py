@@ -141,9 +141,14 @@ class FMMTraversalBuilder:
 
     def __call__(self, actx, tree, wait_for=None, debug=False,
                  _from_sep_smaller_min_nsources_cumul=None,
-                 source_boxes_mask=None, source_parent_boxes_mask=None):
+                 source_boxes_mask=None, source_parent_boxes_mask=None,
+                 _force_generic=None):
         """Same arguments, return value ``(trav, event)`` and exceptions as
-        ``FMMTraversalBuilder.__call__`` (traversal.py:1969-1990)."""
+        ``FMMTraversalBuilder.__call__`` (traversal.py:1969-1990).
+
+        ``_force_generic`` (or env ``BOXTREE_HIP_FORCE_GENERIC=1``) selects the
+        walk-from-root kernels even for trees whose numbering allows the faster
+        parent-colleague kernels; both produce identical lists."""
         assert isinstance(actx, HIPArrayContext)
 
         from_sep_smaller_min_nsources_cumul = _from_sep_smaller_min_nsources_cumul
@@ -232,6 +237,10 @@ class FMMTraversalBuilder:
         spbm = dev(source_parent_boxes_mask)
         tp.source_boxes_mask = ptr(sbm)
         tp.source_parent_boxes_mask = ptr(spbm)
+        if _force_generic is None:
+            import os
+            _force_generic = os.environ.get("BOXTREE_HIP_FORCE_GENERIC", "0") == "1"
+        tp.force_generic = int(bool(_force_generic))
 
         lib = actx.lib
         sizes = _lib.TravSizes()

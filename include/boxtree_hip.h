@@ -199,6 +199,9 @@ typedef struct {
     int32_t from_sep_smaller_min_nsources_cumul;
     const int8_t *source_boxes_mask;           /* device or NULL */
     const int8_t *source_parent_boxes_mask;    /* device or NULL */
+    int32_t force_generic;     /* 1: always use the walk-from-root kernels (any tree);
+                                  0: use the parent-colleague kernels when the box
+                                  numbering is verified level-major/depth-first      */
 } bt_trav_params;
 
 typedef struct {

@@ -42,10 +42,13 @@ def build_both(actx, oracle, particles, targets=None, trav_kw=None, **kw):
     if "_from_sep_smaller_min_nsources_cumul" in tkw:
         call_kw["_from_sep_smaller_min_nsources_cumul"] = tkw.pop(
             "_from_sep_smaller_min_nsources_cumul")
-    trav, _ = FMMTraversalBuilder(actx, **tkw)(actx, tree, **call_kw)
     otrav = oracle.build_traversal(otree, **trav_kw)
-    htrav = actx.to_numpy(trav)
-    assert_same_traversal(htrav, otrav)
+    # both device paths (parent-colleague kernels and walk-from-root kernels)
+    for force_generic in (True, False):
+        trav, _ = FMMTraversalBuilder(actx, **tkw)(actx, tree, _force_generic=force_generic,
+                                                   **call_kw)
+        htrav = actx.to_numpy(trav)
+        assert_same_traversal(htrav, otrav)
     return htree, otree, htrav, otrav
 
 
