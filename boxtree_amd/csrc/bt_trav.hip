@@ -22,12 +22,18 @@ template <class T> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.1920928955078125e-07f; };
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
 
+// Packed per-box record for the tree walks: one cache line holds everything an
+// adjacency test needs (the reference's SoA layout costs 5 lines per test).
+template <class T, int D>
+struct alignas(16) Node {
+    T c[D];
+    uint32_t lf;        // level | flags << 8
+};
+
 template <class T, int D>
 struct TravArgs {
-    const T *centers;             // [D][aligned]
-    const uint8_t *levels;
-    const int32_t *child;         // [C][aligned]
-    const uint8_t *flags;
+    const Node<T, D> *nodes;      // [nboxes]
+    const int32_t *child_t;       // [nboxes][C]  (children of a box contiguous)
     const int32_t *parent;
     const T *tgt_bbox_min, *tgt_bbox_max;
     const int32_t *src_counts_cumul;
@@ -47,6 +53,41 @@ struct TravArgs {
     const int32_t *coll_starts, *coll_lists;
 };
 
+template <class T, int D>
+__device__ __forceinline__ int box_level(const TravArgs<T, D> &a, int32_t box)
+{
+    return (int) (a.nodes[box].lf & 0xffu);
+}
+
+template <class T, int D>
+__device__ __forceinline__ uint8_t box_flags(const TravArgs<T, D> &a, int32_t box)
+{
+    return (uint8_t) (a.nodes[box].lf >> 8);
+}
+
+template <int D, class T>
+__device__ __forceinline__ int32_t child_of(const TravArgs<T, D> &a, int32_t box, int m)
+{
+    return a.child_t[(int64_t) box * (1 << D) + m];
+}
+
+template <class T, int D>
+__global__ __launch_bounds__(256) void pack_nodes_kernel(int32_t nboxes, int64_t aligned,
+        const T *centers, const uint8_t *levels, const uint8_t *flags, const int32_t *child,
+        Node<T, D> *nodes, int32_t *child_t)
+{
+    constexpr int C = 1 << D;
+    const int32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nboxes) return;
+    Node<T, D> n;
+#pragma unroll
+    for (int i = 0; i < D; ++i) n.c[i] = centers[aligned * i + b];
+    n.lf = (uint32_t) levels[b] | ((uint32_t) flags[b] << 8);
+    nodes[b] = n;
+#pragma unroll
+    for (int m = 0; m < C; ++m) child_t[(int64_t) b * C + m] = child[(int64_t) m * aligned + b];
+}
+
 template <class T>
 __device__ __forceinline__ T level_to_rad(T root_extent, int level)
 {
@@ -57,7 +98,7 @@ template <class T, int D>
 __device__ __forceinline__ void load_center(const TravArgs<T, D> &a, int32_t box, T *c)
 {
 #pragma unroll
-    for (int i = 0; i < D; ++i) c[i] = a.centers[a.aligned * i + box];
+    for (int i = 0; i < D; ++i) c[i] = a.nodes[box].c[i];
 }
 
 // traversal.py:279-305
@@ -133,16 +174,16 @@ __device__ __forceinline__ void gen_colleagues(const TravArgs<T, D> &a, int32_t 
     if (box_id == 0) return;
     T center[D];
     load_center(a, box_id, center);
-    const int level = a.levels[box_id];
+    const int level = box_level(a, box_id);
     Walk w;
     w.init(0);
     while (w.go) {
-        const int32_t wb = a.child[(int64_t) w.mnr * a.aligned + w.parent];
+        const int32_t wb = child_of<D>(a, w.parent, w.mnr);
         if (wb) {
             T wc[D];
             load_center(a, wb, wc);
             const bool a_or_o = adj_nbhd<T, D>(a.root_extent, center, level, (T) a.nway, wc,
-                                               a.levels[wb]);
+                                               box_level(a, wb));
             if (a_or_o) {
                 // The reference (traversal.py:438-452) pushes box_id itself and then
                 // walks its whole subtree without ever emitting (nothing below
@@ -168,17 +209,17 @@ __device__ __forceinline__ void gen_list1(const TravArgs<T, D> &a, int32_t tbn, 
     const int32_t box_id = a.target_boxes[tbn];
     T center[D];
     load_center(a, box_id, center);
-    const int level = a.levels[box_id];
-    if (a.flags[0] & BT_BOX_IS_SOURCE_BOX) emit(0);
+    const int level = box_level(a, box_id);
+    if (box_flags(a, 0) & BT_BOX_IS_SOURCE_BOX) emit(0);
     Walk w;
     w.init(0);
     while (w.go) {
-        const int32_t wb = a.child[(int64_t) w.mnr * a.aligned + w.parent];
+        const int32_t wb = child_of<D>(a, w.parent, w.mnr);
         if (wb) {
             T wc[D];
             load_center(a, wb, wc);
-            if (adj<T, D>(a.root_extent, center, level, wc, a.levels[wb])) {
-                const uint8_t fl = a.flags[wb];
+            if (adj<T, D>(a.root_extent, center, level, wc, box_level(a, wb))) {
+                const uint8_t fl = box_flags(a, wb);
                 if (fl & BT_BOX_IS_SOURCE_BOX) emit(wb);
                 if (fl & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
                     w.push(wb);
@@ -199,19 +240,19 @@ __device__ __forceinline__ void gen_list2(const TravArgs<T, D> &a, int32_t it, E
     const int32_t box_id = a.ttp_boxes[it];
     T center[D];
     load_center(a, box_id, center);
-    const int level = a.levels[box_id];
+    const int level = box_level(a, box_id);
     const int32_t parent = a.parent[box_id];
     if (parent == box_id) return;
     const int32_t ps = a.coll_starts[parent], pe = a.coll_starts[parent + 1];
     for (int32_t i = ps; i < pe; ++i) {
         const int32_t pnf = a.coll_lists[i];
         for (int m = 0; m < C; ++m) {
-            const int32_t sib = a.child[(int64_t) m * a.aligned + pnf];
+            const int32_t sib = child_of<D>(a, pnf, m);
             if (sib == 0) continue;
             T sc[D];
             load_center(a, sib, sc);
             const bool sep = !adj_nbhd<T, D>(a.root_extent, center, level, (T) a.nway, sc,
-                                             a.levels[sib]);
+                                             box_level(a, sib));
             if (sep) emit(sib);
         }
     }
@@ -219,15 +260,24 @@ __device__ __forceinline__ void gen_list2(const TravArgs<T, D> &a, int32_t it, E
 
 // ---- T6 list 3 (+ close): traversal.py:607-875, all source levels in one walk ------
 
-template <class T, int D, class EM, class EC>
+struct NoL1 {
+    static constexpr bool active = false;
+    __device__ __forceinline__ void operator()(int32_t) {}
+};
+
+// E1 (optional): receives the adjacent source boxes met on the way -- the part of
+// list 1 that lies at or below the colleagues' level (the walk of
+// traversal.py:501-547 restricted to the colleagues' subtrees visits exactly the
+// boxes this walk descends through).
+template <class T, int D, class EM, class EC, class E1>
 __device__ __forceinline__ void gen_list3(const TravArgs<T, D> &a, int32_t tbn, EM &emit_main,
-                                          EC &emit_close)
+                                          EC &emit_close, E1 &emit_l1)
 {
     constexpr int C = 1 << D;
     const int32_t tgt = a.target_boxes[tbn];
     T tc[D];
     load_center(a, tgt, tc);
-    const int tl = a.levels[tgt];
+    const int tl = box_level(a, tgt);
 
     T stickout_rad = 0;
     T ext_center[D], radii_vec[D];
@@ -251,20 +301,27 @@ __device__ __forceinline__ void gen_list3(const TravArgs<T, D> &a, int32_t tbn, 
     for (int32_t i = s0; i < s1; ++i) {
         const int32_t nws = a.coll_lists[i];
         if (nws == tgt) continue;
+        const uint8_t cfl = box_flags(a, nws);
+        if (E1::active && (cfl & BT_BOX_IS_SOURCE_BOX)) {
+            T cc[D];
+            load_center(a, nws, cc);
+            if (adj<T, D>(a.root_extent, tc, tl, cc, box_level(a, nws))) emit_l1(nws);
+        }
         // nothing below a colleague without source children can be emitted
         // (flag consistency is part of the verified structure)
-        if (a.fast && !(a.flags[nws] & BT_BOX_HAS_SOURCE_CHILD_BOXES)) continue;
+        if (a.fast && !(cfl & BT_BOX_HAS_SOURCE_CHILD_BOXES)) continue;
         Walk w;
         w.init(nws);
         while (w.go) {
-            const int32_t wb = a.child[(int64_t) w.mnr * a.aligned + w.parent];
-            const uint8_t fl = a.flags[wb];
+            const int32_t wb = child_of<D>(a, w.parent, w.mnr);
+            const uint8_t fl = box_flags(a, wb);
             if (wb && (fl & (BT_BOX_IS_SOURCE_BOX | BT_BOX_HAS_SOURCE_CHILD_BOXES))) {
                 T wc[D];
                 load_center(a, wb, wc);
-                const int wl = a.levels[wb];
+                const int wl = box_level(a, wb);
                 const bool in_list_1 = adj<T, D>(a.root_extent, tc, tl, wc, wl);
                 if (in_list_1) {
+                    if (E1::active && (fl & BT_BOX_IS_SOURCE_BOX)) emit_l1(wb);
                     if (fl & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
                         w.push(wb);
                         continue;
@@ -350,13 +407,13 @@ __device__ __forceinline__ void gen_list4(const TravArgs<T, D> &a, int32_t it, E
     const int32_t tgt = a.ttp_boxes[it];
     T tc[D];
     load_center(a, tgt, tc);
-    const int tl = a.levels[tgt];
+    const int tl = box_level(a, tgt);
     if (tl == 0) return;
     const int32_t tparent = a.parent[tgt];
     const int pl = tl - 1;
     T pc[D];
     load_center(a, tparent, pc);
-    const uint8_t tflags = a.flags[tgt];
+    const uint8_t tflags = box_flags(a, tgt);
     int wl; int32_t cur;
     if (a.nway == 1) { wl = tl - 1; cur = tparent; }
     else { wl = tl; cur = tgt; }
@@ -364,7 +421,7 @@ __device__ __forceinline__ void gen_list4(const TravArgs<T, D> &a, int32_t it, E
         const int32_t s0 = a.coll_starts[cur], s1 = a.coll_starts[cur + 1];
         for (int32_t i = s0; i < s1; ++i) {
             const int32_t sb = a.coll_lists[i];
-            if (!(a.flags[sb] & BT_BOX_IS_SOURCE_BOX)) continue;
+            if (!(box_flags(a, sb) & BT_BOX_IS_SOURCE_BOX)) continue;
             T sc[D];
             load_center(a, sb, sc);
             if (adj<T, D>(a.root_extent, tc, tl, sc, wl)) continue;
@@ -436,7 +493,8 @@ __global__ __launch_bounds__(256) void list3_kernel(TravArgs<T, D> a, int32_t nt
         L3CountMain em;
         for (int l = 0; l < nlevels; ++l) em.c[l] = 0;
         CountEmit ec;
-        gen_list3<T, D>(a, i, em, ec);
+        NoL1 no1;
+        gen_list3<T, D>(a, i, em, ec, no1);
         for (int l = 0; l < nlevels; ++l) main_cs[(int64_t) l * ntb + i] = em.c[l];
         if (close_cs) close_cs[i] = ec.n;
     } else {
@@ -445,8 +503,9 @@ __global__ __launch_bounds__(256) void list3_kernel(TravArgs<T, D> a, int32_t nt
         for (int l = 0; l < nlevels; ++l) em.cur[l] = main_cs[(int64_t) l * ntb + i];
         WriteEmit ec{close_lists ? close_lists + close_cs[i] : nullptr};
         CountEmit dummy;
-        if (close_lists) gen_list3<T, D>(a, i, em, ec);
-        else gen_list3<T, D>(a, i, em, dummy);
+        NoL1 no1;
+        if (close_lists) gen_list3<T, D>(a, i, em, ec, no1);
+        else gen_list3<T, D>(a, i, em, dummy, no1);
     }
 }
 
@@ -594,6 +653,8 @@ struct TravState {
     Buf<int32_t> l3_cidx;              // [nlevels][ntb+1]
     std::vector<int64_t> l3_level_base, l3_level_count, l3_nonempty;
     Buf<int32_t> subtree_size, dfs_rank, box_of_rank;
+    Buf<unsigned char> nodes;          // packed Node<T, D>[nboxes]
+    Buf<int32_t> child_t;              // [nboxes][C]
     bool fast = false;
     std::vector<std::pair<const char *, hipEvent_t>> events;
     bool built = false;
@@ -676,6 +737,39 @@ int compact_boxes(bt_context *ctx, const bt_trav_params &p, uint8_t bits, const 
     BT_CHECK(out.alloc(ctx->pool, t));
     compact_kernel<<<nblk(B), 256, 0, ctx->stream>>>(pr, (int32_t) B, pos.get(), out.get());
     *n_out = t;
+    return BT_OK;
+}
+
+// per-level bases and the compressed (non-empty) indexing of list 3
+int l3_postprocess(bt_context *ctx, TravState *st)
+{
+    const int nlevels = st->nlevels;
+    const int64_t ntb = st->ntb;
+    {
+        // per-level bases + nonempty counts
+        std::vector<int32_t> h_base((size_t) nlevels + 1);
+        for (int l = 0; l <= nlevels; ++l)
+            BT_HIP_CHECK(hipMemcpyAsync(&h_base[l], st->l3_starts.get() + (int64_t) l * ntb, 4,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        st->l3_level_base.assign((size_t) nlevels, 0);
+        st->l3_level_count.assign((size_t) nlevels, 0);
+        st->l3_nonempty.assign((size_t) nlevels, 0);
+        BT_CHECK(st->l3_cidx.alloc(ctx->pool, (int64_t) nlevels * (ntb + 1)));
+        for (int l = 0; l < nlevels; ++l) {
+            st->l3_level_base[l] = h_base[l];
+            st->l3_level_count[l] = h_base[l + 1] - h_base[l];
+            NonEmptyPred ne{st->l3_starts.get() + (int64_t) l * ntb};
+            int32_t *cidx = st->l3_cidx.get() + (int64_t) l * (ntb + 1);
+            BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, ne, ntb, cidx, (int32_t *) nullptr, true)));
+        }
+        std::vector<int32_t> h_ne((size_t) nlevels);
+        for (int l = 0; l < nlevels; ++l)
+            BT_HIP_CHECK(hipMemcpyAsync(&h_ne[l], st->l3_cidx.get() + (int64_t) l * (ntb + 1) + ntb, 4,
+                                        hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int l = 0; l < nlevels; ++l) st->l3_nonempty[l] = h_ne[l];
+    }
     return BT_OK;
 }
 
@@ -782,19 +876,54 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         c.lists.swap(l2_lists);
     }
 
-    // list 1
+    // source-box colleagues: what the ancestors contribute to list 1
+    Buf<int32_t> lcoll_starts, lcoll_lists;
     {
-        CsrList &c = st->l1;
-        c.n = st->ntb;
-        BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
-        list1_fast_kernel<T, D, false><<<nblk(c.n), 256, 0, ctx->stream>>>(
-            a, ft, (int32_t) c.n, c.starts.get(), nullptr);
-        BT_CHECK(counts_to_starts(ctx, c.starts, c.n, &c.total));
-        BT_CHECK(c.lists.alloc(ctx->pool, c.total));
-        list1_fast_kernel<T, D, true><<<nblk(c.n), 256, 0, ctx->stream>>>(
-            a, ft, (int32_t) c.n, c.starts.get(), c.lists.get());
+        BT_CHECK(lcoll_starts.alloc(ctx->pool, B + 1));
+        filter_source_colleagues_kernel<T, D, false><<<nblk(B), 256, 0, ctx->stream>>>(
+            a, (int32_t) B, lcoll_starts.get(), nullptr);
+        int64_t tot = 0;
+        BT_CHECK(counts_to_starts(ctx, lcoll_starts, B, &tot));
+        BT_CHECK(lcoll_lists.alloc(ctx->pool, tot));
+        filter_source_colleagues_kernel<T, D, true><<<nblk(B), 256, 0, ctx->stream>>>(
+            a, (int32_t) B, lcoll_starts.get(), lcoll_lists.get());
     }
-    BT_CHECK(tmark(ctx, st, "trav:list1"));
+
+    // lists 1 and 3 (+ close smaller) in one walk per target box
+    {
+        const int64_t ntb = st->ntb;
+        const int64_t nflat = (int64_t) nlevels * ntb;
+        if (nflat >= ((int64_t) 1 << 31)) {
+            set_error("list 3 bookkeeping exceeds int32 range");
+            return BT_ERR_UNSUPPORTED;
+        }
+        CsrList &c1 = st->l1;
+        c1.n = ntb;
+        BT_CHECK(c1.starts.alloc(ctx->pool, ntb + 1));
+        BT_CHECK(st->l3_starts.alloc(ctx->pool, nflat + 1));
+        CsrList &cs = st->close_smaller;
+        cs.n = ntb;
+        if (st->with_extent) BT_CHECK(cs.starts.alloc(ctx->pool, ntb + 1));
+        list13_kernel<T, D, false><<<nblk(ntb), 256, 0, ctx->stream>>>(
+            a, ft, lcoll_starts.get(), lcoll_lists.get(), (int32_t) ntb, nlevels,
+            c1.starts.get(), nullptr, st->l3_starts.get(), nullptr,
+            st->with_extent ? cs.starts.get() : nullptr, nullptr);
+        int64_t total3 = 0;
+        BT_CHECK(counts_to_starts(ctx, c1.starts, ntb, &c1.total));
+        BT_CHECK(counts_to_starts(ctx, st->l3_starts, nflat, &total3));
+        BT_CHECK(c1.lists.alloc(ctx->pool, c1.total));
+        BT_CHECK(st->l3_lists.alloc(ctx->pool, total3));
+        if (st->with_extent) {
+            BT_CHECK(counts_to_starts(ctx, cs.starts, ntb, &cs.total));
+            BT_CHECK(cs.lists.alloc(ctx->pool, cs.total));
+        }
+        list13_kernel<T, D, true><<<nblk(ntb), 256, 0, ctx->stream>>>(
+            a, ft, lcoll_starts.get(), lcoll_lists.get(), (int32_t) ntb, nlevels,
+            c1.starts.get(), c1.lists.get(), st->l3_starts.get(), st->l3_lists.get(),
+            st->with_extent ? cs.starts.get() : nullptr,
+            st->with_extent ? cs.lists.get() : nullptr);
+    }
+    BT_CHECK(tmark(ctx, st, "trav:list1+list3"));
     BT_HIP_CHECK(hipGetLastError());
     return BT_OK;
 }
@@ -838,11 +967,15 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
                     st->lev_starts.get() + k * (nlevels + 1));
     }
 
+    BT_CHECK(st->nodes.alloc(ctx->pool, B * (int64_t) sizeof(Node<T, D>)));
+    BT_CHECK(st->child_t.alloc(ctx->pool, B * (1 << D)));
+    pack_nodes_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
+        (int32_t) B, p.aligned_nboxes, (const T *) p.box_centers, p.box_levels, p.box_flags,
+        p.box_child_ids, (Node<T, D> *) st->nodes.get(), st->child_t.get());
+
     TravArgs<T, D> a{};
-    a.centers = (const T *) p.box_centers;
-    a.levels = p.box_levels;
-    a.child = p.box_child_ids;
-    a.flags = p.box_flags;
+    a.nodes = (const Node<T, D> *) st->nodes.get();
+    a.child_t = st->child_t.get();
     a.parent = p.box_parent_ids;
     a.tgt_bbox_min = (const T *) p.box_target_bounding_box_min;
     a.tgt_bbox_max = (const T *) p.box_target_bounding_box_max;
@@ -917,8 +1050,9 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
 
     }
     BT_CHECK(tmark(ctx, st, "trav:list2"));
-    // T6 list 3: one walk for all source levels
-    {
+    // T6 list 3: one walk for all source levels (done together with list 1 on the
+    // fast path)
+    if (!st->fast) {
         const int64_t ntb = st->ntb;
         const int64_t nflat = (int64_t) nlevels * ntb;
         if (nflat >= ((int64_t) 1 << 31)) {
@@ -944,31 +1078,8 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
             st->with_extent ? cs.starts.get() : nullptr,
             st->with_extent ? cs.lists.get() : nullptr);
 
-        // per-level bases + nonempty counts
-        std::vector<int32_t> h_base((size_t) nlevels + 1);
-        for (int l = 0; l <= nlevels; ++l)
-            BT_HIP_CHECK(hipMemcpyAsync(&h_base[l], st->l3_starts.get() + (int64_t) l * ntb, 4,
-                                        hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        st->l3_level_base.assign((size_t) nlevels, 0);
-        st->l3_level_count.assign((size_t) nlevels, 0);
-        st->l3_nonempty.assign((size_t) nlevels, 0);
-        BT_CHECK(st->l3_cidx.alloc(ctx->pool, (int64_t) nlevels * (ntb + 1)));
-        for (int l = 0; l < nlevels; ++l) {
-            st->l3_level_base[l] = h_base[l];
-            st->l3_level_count[l] = h_base[l + 1] - h_base[l];
-            NonEmptyPred ne{st->l3_starts.get() + (int64_t) l * ntb};
-            int32_t *cidx = st->l3_cidx.get() + (int64_t) l * (ntb + 1);
-            BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, ne, ntb, cidx, (int32_t *) nullptr, true)));
-        }
-        std::vector<int32_t> h_ne((size_t) nlevels);
-        for (int l = 0; l < nlevels; ++l)
-            BT_HIP_CHECK(hipMemcpyAsync(&h_ne[l], st->l3_cidx.get() + (int64_t) l * (ntb + 1) + ntb, 4,
-                                        hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        for (int l = 0; l < nlevels; ++l) st->l3_nonempty[l] = h_ne[l];
     }
-
+    BT_CHECK(l3_postprocess(ctx, st));
     BT_CHECK(tmark(ctx, st, "trav:list3"));
     // T7 list 4 (+ close, re-indexed to target boxes)
     {

@@ -139,9 +139,9 @@ __global__ __launch_bounds__(256) void coll_l2_kernel(TravArgs<T, D> a, int32_t 
 
     T center[D];
     load_center(a, b, center);
-    const int level = a.levels[b];
+    const int level = box_level(a, b);
     const int32_t p = a.parent[b];
-    const bool ttp = a.flags[b] & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX);
+    const bool ttp = box_flags(a, b) & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX);
     const int32_t ps = a.coll_starts[p];
     const int32_t n = a.coll_starts[p + 1] - ps;
     int ins = 0;                         // depth-first position of p among its colleagues
@@ -154,13 +154,13 @@ __global__ __launch_bounds__(256) void coll_l2_kernel(TravArgs<T, D> a, int32_t 
     for (int i = 0; i <= n; ++i) {
         const int32_t c = (i < ins) ? a.coll_lists[ps + i]
                         : (i == ins ? p : a.coll_lists[ps + i - 1]);
-        const int32_t ch = a.child[(int64_t) m * a.aligned + c];
+        const int32_t ch = child_of<D>(a, c, m);
         bool is_coll = false, is_l2 = false;
         if (ch != 0 && ch != b) {
             T cc[D];
             load_center(a, ch, cc);
             const bool a_or_o = adj_nbhd<T, D>(a.root_extent, center, level, (T) a.nway, cc,
-                                               a.levels[ch]);
+                                               box_level(a, ch));
             is_coll = a_or_o;                                   // traversal.py:429-442
             is_l2 = !a_or_o && c != p && ttp;                   // traversal.py:588-597
         }
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void list1_fast_kernel(TravArgs<T, D> a, FastT
     const int32_t b = a.target_boxes[tbn];
     T center[D];
     load_center(a, b, center);
-    const int level = a.levels[b];
+    const int level = box_level(a, b);
 
     int32_t cnt = 0;
     int32_t *out = FILL ? lists + counts_or_starts[tbn] : nullptr;
@@ -263,19 +263,19 @@ __global__ __launch_bounds__(256) void list1_fast_kernel(TravArgs<T, D> a, FastT
         ++cnt;
     };
 
-    if (a.flags[0] & BT_BOX_IS_SOURCE_BOX) emit(0);              // traversal.py:489-495
+    if (box_flags(a, 0) & BT_BOX_IS_SOURCE_BOX) emit(0);              // traversal.py:489-495
 
     // finer boxes: descend like traversal.py:501-547, but only inside box u
     auto descend = [&](int32_t u) {
         Walk w;
         w.init(u);
         while (w.go) {
-            const int32_t wb = a.child[(int64_t) w.mnr * a.aligned + w.parent];
+            const int32_t wb = child_of<D>(a, w.parent, w.mnr);
             if (wb) {
                 T wc[D];
                 load_center(a, wb, wc);
-                if (adj<T, D>(a.root_extent, center, level, wc, a.levels[wb])) {
-                    const uint8_t wf = a.flags[wb];
+                if (adj<T, D>(a.root_extent, center, level, wc, box_level(a, wb))) {
+                    const uint8_t wf = box_flags(a, wb);
                     if (wf & BT_BOX_IS_SOURCE_BOX) emit(wb);
                     if (wf & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
                         w.push(wb);
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void list1_fast_kernel(TravArgs<T, D> a, FastT
 
     if (level == 0) {
         // the root as a target box (only with target extents): everything below it
-        if (a.flags[0] & BT_BOX_HAS_SOURCE_CHILD_BOXES) descend(0);
+        if (box_flags(a, 0) & BT_BOX_HAS_SOURCE_CHILD_BOXES) descend(0);
     }
 
     // ancestors (and b): their colleagues hold every adjacent box of that level
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void list1_fast_kernel(TravArgs<T, D> a, FastT
         const int32_t s0 = a.coll_starts[anc], s1 = a.coll_starts[anc + 1];
         for (int32_t i = s0 - 1; i < s1; ++i) {
             const int32_t u = (i < s0) ? anc : a.coll_lists[i];
-            const uint8_t fl = a.flags[u];
+            const uint8_t fl = box_flags(a, u);
             if (!(fl & (BT_BOX_IS_SOURCE_BOX | BT_BOX_HAS_SOURCE_CHILD_BOXES))) continue;
             if (u != anc) {
                 T uc[D];
@@ -315,5 +315,123 @@ __global__ __launch_bounds__(256) void list1_fast_kernel(TravArgs<T, D> a, FastT
     } else {
         sort_i32_inplace(out, cnt);                 // depth-first preorder
         for (int i = 0; i < cnt; ++i) out[i] = ft.box_of_rank[out[i]];
+    }
+}
+
+
+// ---- source-box colleagues (filtered CSR) -------------------------------------------------
+
+template <class T, int D, bool FILL>
+__global__ __launch_bounds__(256) void filter_source_colleagues_kernel(TravArgs<T, D> a,
+        int32_t nboxes, int32_t *cnt_or_starts, int32_t *lists)
+{
+    const int32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= nboxes) return;
+    const int32_t s0 = a.coll_starts[b], s1 = a.coll_starts[b + 1];
+    int32_t n = 0;
+    int32_t *out = FILL ? lists + cnt_or_starts[b] : nullptr;
+    for (int32_t i = s0; i < s1; ++i) {
+        const int32_t u = a.coll_lists[i];
+        if (box_flags(a, u) & BT_BOX_IS_SOURCE_BOX) {
+            if (FILL) out[n] = u;
+            ++n;
+        }
+    }
+    if (!FILL) cnt_or_starts[b] = n;
+}
+
+// ---- lists 1 and 3 (+ close) in one walk per target box ----------------------------------
+
+struct L1Emit {
+    static constexpr bool active = true;
+    const int32_t *dfs_rank;
+    int32_t *out;       // null in the count pass
+    int32_t n;
+    __device__ __forceinline__ void operator()(int32_t u)
+    {
+        if (out) out[n] = dfs_rank[u];
+        ++n;
+    }
+};
+
+template <class T, int D, bool FILL>
+__global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree ft,
+        const int32_t *lcoll_starts, const int32_t *lcoll_lists, int32_t ntb, int nlevels,
+        int32_t *l1_cs, int32_t *l1_lists,
+        int32_t *l3_cs, int32_t *l3_lists, int32_t *close_cs, int32_t *close_lists)
+{
+    constexpr int C = 1 << D;
+    const int32_t tbn = blockIdx.x * 256 + threadIdx.x;
+    if (tbn >= ntb) return;
+    const int32_t b = a.target_boxes[tbn];
+    T center[D];
+    load_center(a, b, center);
+    const int level = box_level(a, b);
+
+    L1Emit e1{ft.dfs_rank, FILL ? l1_lists + l1_cs[tbn] : nullptr, 0};
+
+    if (box_flags(a, 0) & BT_BOX_IS_SOURCE_BOX) e1(0);           // traversal.py:489-495
+
+    // b itself, and (target boxes with children: extents only) its own subtree
+    if (level >= 1) {
+        const uint8_t fl = box_flags(a, b);
+        if (fl & BT_BOX_IS_SOURCE_BOX) e1(b);
+    }
+    if (box_flags(a, b) & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
+        Walk w;
+        w.init(b);
+        while (w.go) {
+            const int32_t wb = child_of<D>(a, w.parent, w.mnr);
+            if (wb) {
+                T wc[D];
+                load_center(a, wb, wc);
+                if (adj<T, D>(a.root_extent, center, level, wc, box_level(a, wb))) {
+                    const uint8_t wf = box_flags(a, wb);
+                    if (wf & BT_BOX_IS_SOURCE_BOX) e1(wb);
+                    if (wf & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
+                        w.push(wb);
+                        continue;
+                    }
+                }
+            }
+            w.template advance<C>();
+        }
+    }
+
+    // coarser levels: source-box colleagues of the ancestors, and the ancestors
+    if (level >= 2) {
+        int32_t anc = a.parent[b];
+        for (int k = level - 1; k >= 1; --k, anc = a.parent[anc]) {
+            if (box_flags(a, anc) & BT_BOX_IS_SOURCE_BOX) e1(anc);
+            const int32_t s0 = lcoll_starts[anc], s1 = lcoll_starts[anc + 1];
+            for (int32_t i = s0; i < s1; ++i) {
+                const int32_t u = lcoll_lists[i];
+                T uc[D];
+                load_center(a, u, uc);
+                if (adj<T, D>(a.root_extent, center, level, uc, k)) e1(u);
+            }
+        }
+    }
+
+    // colleagues and everything below them: list 3 walk, which also yields the
+    // list-1 boxes at the colleagues' level and finer
+    if (!FILL) {
+        L3CountMain em;
+        for (int l = 0; l < nlevels; ++l) em.c[l] = 0;
+        CountEmit ec;
+        gen_list3<T, D>(a, tbn, em, ec, e1);
+        for (int l = 0; l < nlevels; ++l) l3_cs[(int64_t) l * ntb + tbn] = em.c[l];
+        if (close_cs) close_cs[tbn] = ec.n;
+        l1_cs[tbn] = e1.n;
+    } else {
+        L3WriteMain em;
+        em.lists = l3_lists;
+        for (int l = 0; l < nlevels; ++l) em.cur[l] = l3_cs[(int64_t) l * ntb + tbn];
+        WriteEmit ec{close_lists ? close_lists + close_cs[tbn] : nullptr};
+        CountEmit dummy;
+        if (close_lists) gen_list3<T, D>(a, tbn, em, ec, e1);
+        else gen_list3<T, D>(a, tbn, em, dummy, e1);
+        sort_i32_inplace(e1.out, e1.n);                 // depth-first preorder
+        for (int i = 0; i < e1.n; ++i) e1.out[i] = ft.box_of_rank[e1.out[i]];
     }
 }
