@@ -146,7 +146,8 @@ struct KeygenArgs {
 };
 
 template <class T, int D, bool EXT>
-__global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_t *__restrict__ keys)
+__global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_t *__restrict__ keys,
+                                                     T *__restrict__ packed /* [n][D] */)
 {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
@@ -165,6 +166,10 @@ __global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_
         // so (v >> (L-l)) is the reference's level-l value.
         v[ax] = (uint32_t) (((x[ax] - gmin[ax]) / gext[ax]) * (T) (1u << L));
     }
+    // interleaved copy: the tree-order gather later needs ONE random access per
+    // particle instead of one per axis
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) packed[i * D + ax] = x[ax];
 
     int cap = L;
     if (EXT) {
@@ -421,6 +426,77 @@ __global__ __launch_bounds__(256) void segment_key_kernel(int nboxes, const int3
     for (int p = s + l16; p < s + n; p += 16) fix_key[ids[p]] = (uint32_t) s;
 }
 
+// Fast fix-up: a leaf's particles are a short contiguous run, so sort the ids of
+// every run in place -- one wave per box for runs <= 64 (bitonic network on
+// shuffles), one workgroup for runs <= SEG_BLOCK_MAX; anything longer (zero
+// refine weights, many stuck particles) falls back to the global sort above.
+constexpr int SEG_BLOCK_MAX = 4096;
+
+struct SegSortFlags {
+    int32_t n_large;      // runs in (64, SEG_BLOCK_MAX]
+    int32_t has_huge;     // some run > SEG_BLOCK_MAX
+};
+
+__global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, const int32_t *box_start,
+        const int32_t *box_count, const uint8_t *box_haschild, uint32_t *ids,
+        int32_t *large_list, SegSortFlags *flags)
+{
+    const int b = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (b >= nboxes) return;
+    // a split box's own particles share one key: the stable sort left them in id order
+    if (box_haschild[b]) return;
+    const int n = box_count[b];
+    if (n <= 1) return;
+    if (n > 64) {
+        if (lane == 0) {
+            if (n <= SEG_BLOCK_MAX) large_list[atomicAdd(&flags->n_large, 1)] = b;
+            else atomicExch(&flags->has_huge, 1);
+        }
+        return;
+    }
+    const int s = box_start[b];
+    uint32_t v = (lane < n) ? ids[s + lane] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const uint32_t o = __shfl_xor(v, j, 64);
+            const bool up = (lane & k) == 0;
+            const bool lower = (lane & j) == 0;
+            const uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
+            v = (lower == up) ? mn : mx;
+        }
+    }
+    if (lane < n) ids[s + lane] = v;
+}
+
+__global__ __launch_bounds__(256) void segment_sort_block_kernel(const int32_t *large_list,
+        const int32_t *box_start, const int32_t *box_count, uint32_t *ids)
+{
+    __shared__ uint32_t s_v[SEG_BLOCK_MAX];
+    const int b = large_list[blockIdx.x];
+    const int s = box_start[b], n = box_count[b];
+    int m = 128;
+    while (m < n) m <<= 1;
+    for (int i = threadIdx.x; i < m; i += 256) s_v[i] = (i < n) ? ids[s + i] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < m; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const uint32_t a = s_v[i], c = s_v[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > c) == up) { s_v[i] = c; s_v[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < n; i += 256) ids[s + i] = s_v[i];
+}
+
 // ---------------------------------------------------------------------------
 // sources / targets (tbk:1013-1164, 1770-1782; tools.py:81-109)
 // ---------------------------------------------------------------------------
@@ -459,6 +535,23 @@ __global__ __launch_bounds__(256) void same_ids_kernel(int64_t n, const uint32_t
     const uint32_t id = ids[p];
     user_source_ids[p] = (int32_t) id;
     sorted_target_ids[id] = (int32_t) p;       // reverse_index_array, tools.py:81-109
+}
+
+template <class T, int D>
+struct GatherOut { T *out[D]; };
+
+template <class T, int D>
+__global__ __launch_bounds__(256) void gather_packed_kernel(int64_t n, const int32_t *from_ids,
+        const T *__restrict__ packed, GatherOut<T, D> g)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t id = from_ids[i];            // srcntgt numbering
+    T c[D];
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) c[ax] = packed[id * D + ax];     // tbk:1170-1186
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) g.out[ax][i] = c[ax];
 }
 
 template <class T>
@@ -630,6 +723,7 @@ struct TreeState {
     Buf<int32_t> box_start, box_count, box_parent, box_nonchild, box_child;
     Buf<uint8_t> box_level, box_haschild;
     Buf<unsigned char> centers;        // [cap][D] of coord type
+    Buf<unsigned char> packed;         // [N][D] interleaved input coordinates (srcntgt order)
 
     std::vector<std::pair<const char *, hipEvent_t>> events;
     bool built = false;
@@ -718,8 +812,10 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         ka.L = st->L;
         ka.norm = p.extent_norm;
         const unsigned blocks = (unsigned) div_up(N, 256);
-        if (EXT) keygen_kernel<T, D, true><<<blocks, 256, 0, ctx->stream>>>(ka, st->keys_a.get());
-        else keygen_kernel<T, D, false><<<blocks, 256, 0, ctx->stream>>>(ka, st->keys_a.get());
+        BT_CHECK(st->packed.alloc(ctx->pool, N * D * (int64_t) sizeof(T)));
+        T *packed = (T *) st->packed.get();
+        if (EXT) keygen_kernel<T, D, true><<<blocks, 256, 0, ctx->stream>>>(ka, st->keys_a.get(), packed);
+        else keygen_kernel<T, D, false><<<blocks, 256, 0, ctx->stream>>>(ka, st->keys_a.get(), packed);
         BT_HIP_CHECK(hipGetLastError());
     }
     BT_CHECK(mark(ctx, st, "keygen"));
@@ -833,7 +929,27 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
 
     // ---- within-box order fix-up ----------------------------------------------
     st->ids = ids;
+    bool need_global_fixup = N > 1;
     if (N > 1) {
+        Buf<int32_t> large_list;
+        Buf<SegSortFlags> sflags;
+        BT_CHECK(large_list.alloc(ctx->pool, N / 64 + 1));
+        BT_CHECK(sflags.alloc(ctx->pool, 1));
+        BT_HIP_CHECK(hipMemsetAsync(sflags.get(), 0, sizeof(SegSortFlags), ctx->stream));
+        segment_sort_wave_kernel<<<(unsigned) div_up(st->nboxes * 64, 256), 256, 0, ctx->stream>>>(
+            (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_haschild.get(),
+            ids, large_list.get(), sflags.get());
+        SegSortFlags hf;
+        BT_HIP_CHECK(hipMemcpyAsync(&hf, sflags.get(), sizeof(hf), hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (!hf.has_huge) {
+            if (hf.n_large > 0)
+                segment_sort_block_kernel<<<hf.n_large, 256, 0, ctx->stream>>>(
+                    large_list.get(), st->box_start.get(), st->box_count.get(), ids);
+            need_global_fixup = false;
+        }
+    }
+    if (need_global_fixup) {
         Buf<uint32_t> fk_a, fk_b;
         BT_CHECK(fk_a.alloc(ctx->pool, N));
         BT_CHECK(fk_b.alloc(ctx->pool, N));
@@ -904,14 +1020,19 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
     BT_CHECK(mark(ctx, st, "ids"));
 
     // ---- coordinates and radii (tbk:1170-1186, tree_build.py:1569-1622) ----------
-    for (int ax = 0; ax < D; ++ax) {
+    {
+        const T *packed = (const T *) st->packed.get();
+        GatherOut<T, D> gs, gt;
+        for (int ax = 0; ax < D; ++ax) {
+            gs.out[ax] = (T *) o->sources[ax];
+            gt.out[ax] = sat ? nullptr : (T *) o->targets[ax];
+        }
         if (st->nsources > 0)
-            gather_kernel<T><<<blocks(st->nsources), 256, 0, ctx->stream>>>(
-                st->nsources, o->user_source_ids, 0, (const T *) p.sources[ax], (T *) o->sources[ax]);
+            gather_packed_kernel<T, D><<<blocks(st->nsources), 256, 0, ctx->stream>>>(
+                st->nsources, o->user_source_ids, packed, gs);
         if (!sat && st->ntargets > 0)
-            gather_kernel<T><<<blocks(st->ntargets), 256, 0, ctx->stream>>>(
-                st->ntargets, st->srcntgt_target_ids.get(), (int32_t) st->nsources,
-                (const T *) p.targets[ax], (T *) o->targets[ax]);
+            gather_packed_kernel<T, D><<<blocks(st->ntargets), 256, 0, ctx->stream>>>(
+                st->ntargets, st->srcntgt_target_ids.get(), packed, gt);
     }
     if (p.source_radii && o->source_radii && st->nsources > 0)
         gather_kernel<T><<<blocks(st->nsources), 256, 0, ctx->stream>>>(

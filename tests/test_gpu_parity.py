@@ -133,6 +133,17 @@ def test_explicit_refine_weights(actx, oracle, dims):
     check_tree(htree, p, refine_weights=rw, max_leaf_refine_weight=100)
 
 
+@pytest.mark.parametrize("n_heavy", [0, 300])
+def test_zero_weight_leaves(actx, oracle, n_heavy):
+    # leaves far larger than max_leaf_refine_weight (zero-weight particles): runs of
+    # >64 and >4096 ids exercise the workgroup sort and the global fix-up sort
+    n = 20000
+    p = normal_particles(n, 3, np.float64, seed=5)
+    rw = np.zeros(n, np.int32)
+    rw[np.random.default_rng(1).choice(n, n_heavy, replace=False)] = 1
+    build_both(actx, oracle, p, refine_weights=rw, max_leaf_refine_weight=2, trav_kw={})
+
+
 @pytest.mark.parametrize("dims", [2, 3])
 def test_non_adaptive(actx, oracle, dims):
     p = normal_particles(10**4, dims, np.float64)
