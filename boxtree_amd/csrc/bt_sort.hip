@@ -15,6 +15,9 @@
 #include "bt_sort.hpp"
 #include "bt_prims.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace bt {
 
 constexpr int RADIX_BITS = 8;
@@ -22,9 +25,38 @@ constexpr int RADIX = 1 << RADIX_BITS;
 constexpr uint32_t LB_AGG = 1, LB_PREFIX = 2;
 constexpr uint32_t LOOKBACK_SPIN_LIMIT = 1u << 22;
 
-template <class KeyT> struct SortTraits;
-template <> struct SortTraits<uint64_t> { static constexpr int THREADS = 512, ITEMS = 16; };
-template <> struct SortTraits<uint32_t> { static constexpr int THREADS = 512, ITEMS = 16; };
+// tile shapes (threads x keys per thread); index chosen by BT_SORT_CFG (tuning aid)
+// MINW = waves per SIMD the register allocator must leave room for
+struct Cfg0 { static constexpr int THREADS = 512, ITEMS = 16, MINW = 4; };
+struct Cfg1 { static constexpr int THREADS = 256, ITEMS = 16, MINW = 4; };
+struct Cfg2 { static constexpr int THREADS = 512, ITEMS = 12, MINW = 4; };
+struct Cfg3 { static constexpr int THREADS = 256, ITEMS = 24, MINW = 2; };
+struct Cfg4 { static constexpr int THREADS = 1024, ITEMS = 8, MINW = 4; };
+struct Cfg5 { static constexpr int THREADS = 512, ITEMS = 8, MINW = 6; };
+struct Cfg6 { static constexpr int THREADS = 512, ITEMS = 14, MINW = 4; };
+struct Cfg7 { static constexpr int THREADS = 512, ITEMS = 10, MINW = 6; };
+struct Cfg8 { static constexpr int THREADS = 768, ITEMS = 8, MINW = 6; };
+struct Cfg9 { static constexpr int THREADS = 384, ITEMS = 16, MINW = 3; };
+struct Cfg10 { static constexpr int THREADS = 512, ITEMS = 12, MINW = 2; };
+struct Cfg11 { static constexpr int THREADS = 256, ITEMS = 20, MINW = 2; };
+
+static int sort_dbg()
+{
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("BT_SORT_DBG"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+static int sort_cfg_index()
+{
+    static int idx = -1;
+    if (idx < 0) {
+        const char *e = getenv("BT_SORT_CFG");
+        idx = e ? atoi(e) : 0;
+        if (idx < 0 || idx > 11) idx = 0;
+    }
+    return idx;
+}
 
 __device__ __forceinline__ uint64_t lb_pack(uint32_t gen, uint32_t flag, uint32_t v)
 {
@@ -78,14 +110,51 @@ __global__ __launch_bounds__(RADIX) void sort_hist_scan_kernel(uint32_t *ghist)
     h[threadIdx.x] = ex;
 }
 
+// ---- look-back seeding --------------------------------------------------------
+// All workgroups of the first residency wave start together; without help tile j
+// would walk back over ~j/2 unfinished predecessors (hundreds of dependent
+// ~1 us polls, measured 0.25 ms of a 0.68 ms pass at 1e8 keys).  The digit
+// counts of the first `nseed` tiles are therefore computed up front (33 MB of
+// keys) and published as inclusive prefixes before the pass starts.
+
+template <class KeyT, int TILE>
+__global__ __launch_bounds__(256) void seed_hist_kernel(const KeyT *__restrict__ keys, uint32_t n,
+        int shift, uint32_t *tile_hist /* [nseed][RADIX] */)
+{
+    __shared__ uint32_t s_h[RADIX];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * (uint32_t) TILE;
+    for (uint32_t i = threadIdx.x; i < (uint32_t) TILE; i += 256) {
+        const uint32_t g = base + i;
+        if (g < n) atomicAdd(&s_h[(uint32_t) (keys[g] >> shift) & (RADIX - 1)], 1u);
+    }
+    __syncthreads();
+    tile_hist[blockIdx.x * RADIX + threadIdx.x] = s_h[threadIdx.x];
+}
+
+constexpr int MAX_SEED = 1024;
+
+// one workgroup per digit scans that digit's counts over the seeded tiles
+__global__ __launch_bounds__(MAX_SEED) void seed_scan_kernel(const uint32_t *tile_hist,
+        uint32_t nseed, uint64_t *lookback, uint32_t gen)
+{
+    __shared__ uint32_t s_tmp[MAX_SEED / 64 + 1];
+    const uint32_t d = blockIdx.x, t = threadIdx.x;
+    const uint32_t c = (t < nseed) ? tile_hist[t * RADIX + d] : 0u;
+    const uint32_t ex = block_exclusive_scan<uint32_t, MAX_SEED>(c, s_tmp, (uint32_t *) nullptr);
+    if (t < nseed) lookback[(uint64_t) t * RADIX + d] = lb_pack(gen, LB_PREFIX, ex + c);
+}
+
 // ---- one digit pass ---------------------------------------------------------
 
-template <class KeyT, int THREADS, int ITEMS, bool IDENTITY_VALS>
-__global__ __launch_bounds__(THREADS, THREADS / 128) void onesweep_kernel(
+template <class KeyT, int THREADS, int ITEMS, int MINW, bool IDENTITY_VALS>
+__global__ __launch_bounds__(THREADS, MINW) void onesweep_kernel(
         const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
         KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
         uint32_t n, int shift, const uint32_t *__restrict__ digit_start,
-        uint64_t *lookback, uint32_t *tile_counter, uint32_t gen, DeviceStatus *status)
+        uint64_t *lookback, uint32_t *tile_counter, uint32_t gen, DeviceStatus *status, int dbg,
+        uint32_t nseed)
 {
     constexpr int NW = THREADS / 64;
     constexpr int TILE = THREADS * ITEMS;
@@ -120,12 +189,8 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void onesweep_kernel(
         uint32_t i = wbase + j * 64;
         key[j] = (i < n) ? keys_in[i] : ~(KeyT) 0;
     }
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        uint32_t i = wbase + j * 64;
-        if (IDENTITY_VALS) val[j] = i;
-        else val[j] = (i < n) ? vals_in[i] : 0u;
-    }
+    // (values are loaded after the ranking phase: fewer live registers while
+    // ranking, and the loads overlap the look-back)
 
     // ---- rank within the wave by ballot matching ---------------------------
     uint32_t rank[ITEMS];
@@ -161,8 +226,15 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void onesweep_kernel(
     uint32_t count = tot;
     if (tid == RADIX - 1) count -= ((uint32_t) TILE - valid);   // padding keys
     uint64_t *lb = lookback + (uint64_t) tile * RADIX + tid;
-    if (tid < RADIX)
+    if (tid < RADIX && tile >= nseed)
         lb_store(lb, lb_pack(gen, tile == 0 ? LB_PREFIX : LB_AGG, count));
+
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        uint32_t i = wbase + j * 64;
+        if (IDENTITY_VALS) val[j] = i;
+        else val[j] = (i < n) ? vals_in[i] : 0u;
+    }
 
     // exclusive scan of the tile's digit counts (threads >= RADIX contribute 0)
     uint32_t dbase;
@@ -177,9 +249,26 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void onesweep_kernel(
         dbase = woff + incl - tot;
     }
 
+    // ---- reorder the tile through LDS (needs only tile-local offsets, so it runs
+    // while the predecessors make progress on their prefixes) ----------------------
+    if (tid < RADIX) s_digit_base[tid] = dbase;
+    __syncthreads();
+    uint32_t pos[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t d = (uint32_t) (key[j] >> shift) & (RADIX - 1);
+        pos[j] = s_digit_base[d] + wh[d] + rank[j];
+        s_keys[pos[j]] = key[j];
+    }
+
     if (tid < RADIX) {
         uint32_t excl = 0;
-        if (tile > 0) {
+        if (tile < nseed) {
+            // inclusive prefix was published before the pass started
+            excl = (uint32_t) lb_load(lb) - count;
+        } else if (tile > 0 && !(dbg & 2)) {
+            // serial walk back over the predecessors (issuing several polls at once
+            // was measured slower: the polls themselves are the scarce resource)
             int64_t t = (int64_t) tile - 1;
             uint32_t spins = 0;
             const uint32_t want_p = (gen << 2) | LB_PREFIX;
@@ -197,20 +286,11 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void onesweep_kernel(
             }
             lb_store(lb, lb_pack(gen, LB_PREFIX, excl + count));
         }
-        s_digit_base[tid] = dbase;
-        s_global_base[tid] = digit_start[tid] + excl - dbase;
+        s_global_base[tid] = (dbg & 1) ? base : digit_start[tid] + excl - dbase;
     }
     __syncthreads();
 
-    // ---- reorder the tile through LDS, write coalesced runs -----------------
-    uint32_t pos[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint32_t d = (uint32_t) (key[j] >> shift) & (RADIX - 1);
-        pos[j] = s_digit_base[d] + wh[d] + rank[j];
-        s_keys[pos[j]] = key[j];
-    }
-    __syncthreads();
+    // ---- write coalesced runs ----------------------------------------------------
 
     uint32_t gpos[ITEMS];
 #pragma unroll
@@ -232,11 +312,10 @@ __global__ __launch_bounds__(THREADS, THREADS / 128) void onesweep_kernel(
     }
 }
 
-template <class KeyT>
-int radix_sort_pairs(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t *vb,
-                     int64_t n, int begin_bit, int end_bit, bool identity_vals, bool *in_b)
+template <class KeyT, class Tr>
+int radix_sort_pairs_cfg(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t *vb,
+                         int64_t n, int begin_bit, int end_bit, bool identity_vals, bool *in_b)
 {
-    using Tr = SortTraits<KeyT>;
     constexpr int TILE = Tr::THREADS * Tr::ITEMS;
     constexpr int MAXP = (int) sizeof(KeyT);   // at most one pass per key byte
 
@@ -285,20 +364,31 @@ int radix_sort_pairs(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t
     }
     BT_HIP_CHECK(hipEventRecord(ev[1], ctx->stream));
 
+    // seeding measured neutral at 1e8 keys; off unless BT_SORT_DBG & 8
+    const uint32_t nseed = (sort_dbg() & 8) ? std::min<uint32_t>(ntiles, (uint32_t) MAX_SEED) : 0u;
+    Buf<uint32_t> tile_hist;
+    BT_CHECK(tile_hist.alloc(ctx->pool, (int64_t) nseed * RADIX));
+
     KeyT *kin = ka, *kout = kb;
     uint32_t *vin = va, *vout = vb;
     for (int p = 0; p < npasses; ++p) {
         const int shift = begin_bit + p * RADIX_BITS;
+        if (nseed > 0) {
+            seed_hist_kernel<KeyT, TILE><<<nseed, 256, 0, ctx->stream>>>(
+                kin, (uint32_t) n, shift, tile_hist.get());
+            seed_scan_kernel<<<RADIX, MAX_SEED, 0, ctx->stream>>>(tile_hist.get(), nseed, lookback.get(),
+                                                         (uint32_t) (p + 1));
+        }
         if (p == 0 && identity_vals) {
-            onesweep_kernel<KeyT, Tr::THREADS, Tr::ITEMS, true>
+            onesweep_kernel<KeyT, Tr::THREADS, Tr::ITEMS, Tr::MINW, true>
                 <<<ntiles, Tr::THREADS, 0, ctx->stream>>>(
                     kin, vin, kout, vout, (uint32_t) n, shift, hist.get() + p * RADIX,
-                    lookback.get(), tile_counters + p, (uint32_t) (p + 1), ctx->d_status);
+                    lookback.get(), tile_counters + p, (uint32_t) (p + 1), ctx->d_status, sort_dbg(), nseed);
         } else {
-            onesweep_kernel<KeyT, Tr::THREADS, Tr::ITEMS, false>
+            onesweep_kernel<KeyT, Tr::THREADS, Tr::ITEMS, Tr::MINW, false>
                 <<<ntiles, Tr::THREADS, 0, ctx->stream>>>(
                     kin, vin, kout, vout, (uint32_t) n, shift, hist.get() + p * RADIX,
-                    lookback.get(), tile_counters + p, (uint32_t) (p + 1), ctx->d_status);
+                    lookback.get(), tile_counters + p, (uint32_t) (p + 1), ctx->d_status, sort_dbg(), nseed);
         }
         KeyT *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
@@ -322,6 +412,26 @@ int radix_sort_pairs(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t
     ctx->stage_ms[31] = hist_ms + pass_ms;
     *in_b = (npasses & 1) != 0;
     return BT_OK;
+}
+
+template <class KeyT>
+int radix_sort_pairs(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t *vb,
+                     int64_t n, int begin_bit, int end_bit, bool identity_vals, bool *in_b)
+{
+    switch (sort_cfg_index()) {
+    case 1: return radix_sort_pairs_cfg<KeyT, Cfg1>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    case 2: return radix_sort_pairs_cfg<KeyT, Cfg2>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    case 3: return radix_sort_pairs_cfg<KeyT, Cfg3>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    case 4: return radix_sort_pairs_cfg<KeyT, Cfg4>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    case 5: return radix_sort_pairs_cfg<KeyT, Cfg5>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    case 6: return radix_sort_pairs_cfg<KeyT, Cfg6>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    case 7: return radix_sort_pairs_cfg<KeyT, Cfg7>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    case 8: return radix_sort_pairs_cfg<KeyT, Cfg8>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    case 9: return radix_sort_pairs_cfg<KeyT, Cfg9>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    case 10: return radix_sort_pairs_cfg<KeyT, Cfg10>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    case 11: return radix_sort_pairs_cfg<KeyT, Cfg11>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    default: return radix_sort_pairs_cfg<KeyT, Cfg0>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    }
 }
 
 template int radix_sort_pairs<uint64_t>(bt_context *, uint64_t *, uint32_t *, uint64_t *,
