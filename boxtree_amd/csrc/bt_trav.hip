@@ -652,7 +652,7 @@ struct TravState {
     Buf<int32_t> l3_lists;
     Buf<int32_t> l3_cidx;              // [nlevels][ntb+1]
     std::vector<int64_t> l3_level_base, l3_level_count, l3_nonempty;
-    Buf<int32_t> subtree_size, dfs_rank, box_of_rank;
+    Buf<int32_t> subtree_size, dfs_rank, box_of_rank, src_rank_prefix, src_by_rank;
     Buf<unsigned char> nodes;          // packed Node<T, D>[nboxes]
     Buf<int32_t> child_t;              // [nboxes][C]
     bool fast = false;
@@ -811,7 +811,18 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         dfs_rank_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
             ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
             st->subtree_size.get(), st->dfs_rank.get(), st->box_of_rank.get());
-    FastTree ft{st->dfs_rank.get(), st->box_of_rank.get()};
+    // source boxes in depth-first order (+ prefix counts over ranks)
+    BT_CHECK(st->src_rank_prefix.alloc(ctx->pool, B + 1));
+    {
+        SourceRankFlag<T, D> f{a.nodes, st->box_of_rank.get()};
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, f, B, st->src_rank_prefix.get(),
+                                                          (int32_t *) nullptr, true)));
+        BT_CHECK(st->src_by_rank.alloc(ctx->pool, st->nsb + 1));
+        compact_sources_by_rank_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
+            f, (int32_t) B, st->src_rank_prefix.get(), st->src_by_rank.get());
+    }
+    FastTree ft{st->dfs_rank.get(), st->box_of_rank.get(), st->subtree_size.get(),
+                st->src_rank_prefix.get(), st->src_by_rank.get()};
 
     // colleagues + list 2, level by level
     CsrList &coll = st->coll;
@@ -901,11 +912,17 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         c1.n = ntb;
         BT_CHECK(c1.starts.alloc(ctx->pool, ntb + 1));
         BT_CHECK(st->l3_starts.alloc(ctx->pool, nflat + 1));
+        // at most one block-copy job per target box that has children
+        Buf<int32_t> jobbuf;
+        BT_CHECK(jobbuf.alloc(ctx->pool, 3 * ntb + 1));
+        BlockJobs jobs{jobbuf.get(), jobbuf.get() + 1, jobbuf.get() + 1 + ntb,
+                       jobbuf.get() + 1 + 2 * ntb};
+        BT_HIP_CHECK(hipMemsetAsync(jobbuf.get(), 0, 4, ctx->stream));
         CsrList &cs = st->close_smaller;
         cs.n = ntb;
         if (st->with_extent) BT_CHECK(cs.starts.alloc(ctx->pool, ntb + 1));
         list13_kernel<T, D, false><<<nblk(ntb), 256, 0, ctx->stream>>>(
-            a, ft, lcoll_starts.get(), lcoll_lists.get(), (int32_t) ntb, nlevels,
+            a, ft, lcoll_starts.get(), lcoll_lists.get(), (int32_t) ntb, nlevels, jobs,
             c1.starts.get(), nullptr, st->l3_starts.get(), nullptr,
             st->with_extent ? cs.starts.get() : nullptr, nullptr);
         int64_t total3 = 0;
@@ -918,10 +935,15 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             BT_CHECK(cs.lists.alloc(ctx->pool, cs.total));
         }
         list13_kernel<T, D, true><<<nblk(ntb), 256, 0, ctx->stream>>>(
-            a, ft, lcoll_starts.get(), lcoll_lists.get(), (int32_t) ntb, nlevels,
+            a, ft, lcoll_starts.get(), lcoll_lists.get(), (int32_t) ntb, nlevels, jobs,
             c1.starts.get(), c1.lists.get(), st->l3_starts.get(), st->l3_lists.get(),
             st->with_extent ? cs.starts.get() : nullptr,
             st->with_extent ? cs.lists.get() : nullptr);
+        int32_t njobs = 0;
+        BT_CHECK(read_i32(ctx, jobs.count, &njobs));
+        if (njobs > 0)
+            copy_rank_blocks_kernel<<<njobs, 256, 0, ctx->stream>>>(
+                jobs.dst, jobs.src, jobs.len, st->src_by_rank.get(), c1.lists.get());
     }
     BT_CHECK(tmark(ctx, st, "trav:list1+list3"));
     BT_HIP_CHECK(hipGetLastError());

@@ -20,7 +20,51 @@
 struct FastTree {
     const int32_t *dfs_rank;      // [nboxes] preorder rank
     const int32_t *box_of_rank;   // [nboxes]
+    const int32_t *subtree_size;  // [nboxes] boxes in the subtree (incl. the box)
+    const int32_t *src_prefix;    // [nboxes+1] #source boxes with rank < r
+    const int32_t *src_by_rank;   // source boxes in depth-first order
 };
+
+// A target box WITH children (target extents) has every source box of its own
+// subtree in list 1 -- a contiguous range of preorder ranks.  Those entries are
+// copied by copy_rank_blocks_kernel instead of being walked by one thread (the
+// root's walk alone was 80 ms at 1e8 sources).
+struct BlockJobs {
+    int32_t *count;               // number of jobs (atomic)
+    int32_t *dst;                 // offset into the list-1 array
+    int32_t *src;                 // offset into src_by_rank
+    int32_t *len;
+};
+
+template <class T, int D>
+struct SourceRankFlag {
+    const Node<T, D> *nodes;
+    const int32_t *box_of_rank;
+    __device__ int32_t operator()(int64_t r) const
+    {
+        return ((nodes[box_of_rank[r]].lf >> 8) & BT_BOX_IS_SOURCE_BOX) ? 1 : 0;
+    }
+};
+
+template <class T, int D>
+__global__ __launch_bounds__(256) void compact_sources_by_rank_kernel(SourceRankFlag<T, D> f,
+        int32_t nboxes, const int32_t *prefix, int32_t *src_by_rank)
+{
+    const int32_t r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= nboxes) return;
+    if (f(r)) src_by_rank[prefix[r]] = f.box_of_rank[r];
+}
+
+// one workgroup per job (the largest job, the root's, is a 12 MB copy at 1e8 points)
+__global__ __launch_bounds__(256) void copy_rank_blocks_kernel(const int32_t *dst,
+        const int32_t *src, const int32_t *len, const int32_t *src_by_rank, int32_t *lists)
+{
+    const int32_t j = blockIdx.x;
+    const int32_t n = len[j];
+    const int32_t *in = src_by_rank + src[j];
+    int32_t *out = lists + dst[j];
+    for (int32_t i = threadIdx.x; i < n; i += 256) out[i] = in[i];
+}
 
 // ---- structure check --------------------------------------------------------------
 
@@ -357,10 +401,9 @@ struct L1Emit {
 template <class T, int D, bool FILL>
 __global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree ft,
         const int32_t *lcoll_starts, const int32_t *lcoll_lists, int32_t ntb, int nlevels,
-        int32_t *l1_cs, int32_t *l1_lists,
+        BlockJobs jobs, int32_t *l1_cs, int32_t *l1_lists,
         int32_t *l3_cs, int32_t *l3_lists, int32_t *close_cs, int32_t *close_lists)
 {
-    constexpr int C = 1 << D;
     const int32_t tbn = blockIdx.x * 256 + threadIdx.x;
     if (tbn >= ntb) return;
     const int32_t b = a.target_boxes[tbn];
@@ -372,30 +415,17 @@ __global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree 
 
     if (box_flags(a, 0) & BT_BOX_IS_SOURCE_BOX) e1(0);           // traversal.py:489-495
 
-    // b itself, and (target boxes with children: extents only) its own subtree
+    // b itself; the sources inside b (target boxes with children: extents only) are a
+    // contiguous block of preorder ranks, accounted for here and copied separately
     if (level >= 1) {
         const uint8_t fl = box_flags(a, b);
         if (fl & BT_BOX_IS_SOURCE_BOX) e1(b);
     }
+    int32_t blk_len = 0, blk_src = 0;
+    const int32_t my_rank = ft.dfs_rank[b];
     if (box_flags(a, b) & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
-        Walk w;
-        w.init(b);
-        while (w.go) {
-            const int32_t wb = child_of<D>(a, w.parent, w.mnr);
-            if (wb) {
-                T wc[D];
-                load_center(a, wb, wc);
-                if (adj<T, D>(a.root_extent, center, level, wc, box_level(a, wb))) {
-                    const uint8_t wf = box_flags(a, wb);
-                    if (wf & BT_BOX_IS_SOURCE_BOX) e1(wb);
-                    if (wf & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
-                        w.push(wb);
-                        continue;
-                    }
-                }
-            }
-            w.template advance<C>();
-        }
+        blk_src = ft.src_prefix[my_rank + 1];
+        blk_len = ft.src_prefix[my_rank + ft.subtree_size[b]] - blk_src;
     }
 
     // coarser levels: source-box colleagues of the ancestors, and the ancestors
@@ -422,7 +452,7 @@ __global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree 
         gen_list3<T, D>(a, tbn, em, ec, e1);
         for (int l = 0; l < nlevels; ++l) l3_cs[(int64_t) l * ntb + tbn] = em.c[l];
         if (close_cs) close_cs[tbn] = ec.n;
-        l1_cs[tbn] = e1.n;
+        l1_cs[tbn] = e1.n + blk_len;
     } else {
         L3WriteMain em;
         em.lists = l3_lists;
@@ -432,6 +462,20 @@ __global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree 
         if (close_lists) gen_list3<T, D>(a, tbn, em, ec, e1);
         else gen_list3<T, D>(a, tbn, em, dummy, e1);
         sort_i32_inplace(e1.out, e1.n);                 // depth-first preorder
-        for (int i = 0; i < e1.n; ++i) e1.out[i] = ft.box_of_rank[e1.out[i]];
+        int32_t k = e1.n;
+        if (blk_len > 0) {
+            // entries with rank <= rank(b) stay, the rest moves behind the block
+            k = 0;
+            while (k < e1.n && e1.out[k] <= my_rank) ++k;
+            for (int i = e1.n - 1; i >= k; --i)
+                e1.out[i + blk_len] = ft.box_of_rank[e1.out[i]];
+            const int32_t j = atomicAdd(jobs.count, 1);
+            jobs.dst[j] = (int32_t) (e1.out - l1_lists) + k;
+            jobs.src[j] = blk_src;
+            jobs.len[j] = blk_len;
+        } else {
+            for (int i = k; i < e1.n; ++i) e1.out[i] = ft.box_of_rank[e1.out[i]];
+        }
+        for (int i = 0; i < k && i < e1.n; ++i) e1.out[i] = ft.box_of_rank[e1.out[i]];
     }
 }
