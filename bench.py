@@ -41,7 +41,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"])
     ap.add_argument("--n", type=int, default=None, help="override particle count per GPU")
-    ap.add_argument("--cpu-sample", type=int, default=1_000_000,
+    ap.add_argument("--cpu-sample", type=int, default=16_000_000,
                     help="particles in the CPU-baseline sample (0 disables)")
     ap.add_argument("--mpb", type=int, default=64)
     return ap.parse_args()
@@ -208,8 +208,17 @@ def main():
         pass_ms = float(np.mean([s[0] for s in sort_ms]))
         n_sorted = sort_ms[-1][2]
         achieved = 24.0 * n_sorted / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes,
+        # corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_pmc_onesweep.json)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_onesweep.json")))
+            if int(pmc["n_pairs"]) == int(n_sorted):
+                traffic = pmc["traffic_bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
-            "metric": "particles/sec tree build+traversal (3D); radix-sort HBM GB/s vs peak",
+            "metric": "particles/sec tree build+traversal, 3D 10^8 pts; radix-sort HBM GB/s vs peak",
             "value": value,
             "unit": "particles/s",
             "n_gpus": world,
@@ -230,12 +239,13 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "onesweep_kernel<u64> (one 8-bit digit pass of the Morton-key sort)",
+                "kernel": "bt::onesweep_kernel<unsigned long, 512, 16, 4, *> "
+                          "(one 8-bit digit pass of the 64-bit Morton-key sort)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_launch": 24.0 * n_sorted,
                 "avg_launch_ms": pass_ms,
                 "passes_per_sort": sort_ms[-1][1],
