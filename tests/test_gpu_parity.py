@@ -264,3 +264,76 @@ def test_uniform_config_c2_small(actx, oracle):
     p = [rng.random(10**6) for _ in range(3)]
     htree, _, htrav, _ = build_both(actx, oracle, p, max_particles_in_box=64, trav_kw={})
     check_traversal(htree, htrav)
+
+
+@pytest.mark.parametrize("sat", [True, False])
+def test_one_dimensional(actx, oracle, sat):
+    # test/test_fmm.py:146 exercises dims=1
+    s = normal_particles(5 * 10**4, 1, np.float64, seed=15)
+    t = None if sat else normal_particles(2 * 10**4, 1, np.float64, seed=16)
+    htree, _, htrav, _ = build_both(actx, oracle, s, targets=t, max_particles_in_box=30,
+                                    trav_kw={})
+    pot = constant_one_potentials(htree, htrav)
+    assert np.all(pot == 5 * 10**4)
+
+
+def test_float32_traversal(actx, oracle):
+    # test/test_fmm.py:672-719 (float32 coordinates)
+    s = normal_particles(10**5, 3, np.float32, seed=15)
+    htree, _, htrav, _ = build_both(actx, oracle, s, max_particles_in_box=30, trav_kw={})
+    pot = constant_one_potentials(htree, htrav)
+    assert np.all(pot == 10**5)
+
+
+def test_full_size_properties_c2(actx):
+    """BASELINE configs[1] at full size (3D uniform 1e7, mpb=64): size-independent
+    properties instead of the oracle (which would need minutes)."""
+    import torch
+    from boxtree_amd import FMMTraversalBuilder, TreeBuilder
+    n = 10**7
+    g = torch.Generator(device="cuda")
+    g.manual_seed(15)
+    pts = [torch.rand(n, generator=g, dtype=torch.float64, device="cuda") for _ in range(3)]
+    tree, _ = TreeBuilder(actx)(actx, pts, max_particles_in_box=64)
+    trav, _ = FMMTraversalBuilder(actx)(actx, tree)
+
+    usi = tree.user_source_ids.long()
+    # a permutation, and its inverse
+    assert int(torch.bincount(usi, minlength=n).max()) == 1
+    assert bool((usi[tree.sorted_target_ids.long()] == torch.arange(n, device="cuda")).all())
+    # coordinates are the gathered inputs
+    for d in range(3):
+        assert bool((tree.sources[d] == pts[d][usi]).all())
+    nb = tree.nboxes
+    starts = tree.box_source_starts.long()
+    cumul = tree.box_source_counts_cumul.long()
+    nonchild = tree.box_source_counts_nonchild.long()
+    child = tree.box_child_ids[:, :nb].long()
+    kid_sum = torch.where(child != 0, cumul[child], torch.zeros_like(child)).sum(dim=0)
+    assert bool((nonchild + kid_sum == cumul).all())
+    assert int(cumul[0]) == n and int(nonchild.sum()) == n
+    leaf = (child == 0).all(dim=0)
+    assert int(cumul[leaf].max()) <= 64
+    assert bool((cumul[~leaf] > 64).all())
+    # inside a leaf the particles are in ascending user order (stable renumbering)
+    owner = torch.repeat_interleave(torch.arange(nb, device="cuda")[leaf], cumul[leaf])
+    order = torch.argsort(starts[leaf])
+    owner_sorted = torch.repeat_interleave(
+        torch.arange(nb, device="cuda")[leaf][order], cumul[leaf][order])
+    same_leaf = owner_sorted[1:] == owner_sorted[:-1]
+    assert bool((usi[1:][same_leaf] > usi[:-1][same_leaf]).all())
+    del owner
+    # every particle lies inside its leaf box
+    lev = tree.box_levels.long()
+    half = 0.5 * float(tree.root_extent) / (2.0 ** lev.double())
+    ctr = tree.box_centers[:, :nb]
+    for d in range(3):
+        x = tree.sources[d]
+        lo = (ctr[d] - half)[owner_sorted]
+        hi = (ctr[d] + half)[owner_sorted]
+        assert bool(((x >= lo - 1e-12) & (x < hi + 1e-12)).all())
+    # constant-one completeness on the device lists
+    htree = actx.to_numpy(tree)
+    htrav = actx.to_numpy(trav)
+    pot = constant_one_potentials(htree, htrav)
+    assert np.all(pot == n)
