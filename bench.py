@@ -148,19 +148,22 @@ def main():
     build_kw = dict(w["kw"])
     particles, targets = w["particles"], w["targets"]
 
-    if distributed:
-        from boxtree_amd.distributed import exchange_particles
-        particles, targets, build_kw, xstats = exchange_particles(
-            actx, dist, particles, targets, build_kw)
     torch.cuda.synchronize()
+    xinfo = {}
 
     stage_acc: dict[str, float] = {}
     sort_ms = []
     info = {}
 
     def step():
-        tree, _ = tb(actx, particles, targets=targets,
-                     max_particles_in_box=args.mpb, **build_kw)
+        p_, t_, kw_ = particles, targets, build_kw
+        if distributed:
+            # the exchange is part of the path (and of the timed step) for N > 1
+            from boxtree_amd.distributed import exchange_particles
+            p_, t_, kw_, xs = exchange_particles(actx, dist, particles, targets, build_kw)
+            xinfo.update(exchange_bytes_sent_rank0=int(xs["bytes_sent"]),
+                         owned_particles_rank0=int(len(p_[0])))
+        tree, _ = tb(actx, p_, targets=t_, max_particles_in_box=args.mpb, **kw_)
         st = _lib.SortStats()
         actx.lib.bt_get_sort_stats(actx.handle, st)
         trav, _ = tg(actx, tree)
@@ -236,6 +239,7 @@ def main():
                 "nboxes": info.get("nboxes"), "nlevels": info.get("nlevels"),
                 "list1_entries": info.get("n_list1"), "list2_entries": info.get("n_list2"),
                 "parallelism": f"{world} rank(s), one per GPU, shard by top-level Morton cell",
+                **xinfo,
             },
             "roofline": {
                 "bound": "hbm",

@@ -143,6 +143,7 @@ EXPORTED_SYMBOLS = [
     "bt_bbox", "bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32", "bt_get_sort_stats",
     "bt_tree_build", "bt_tree_export", "bt_get_stage_times",
     "bt_traversal_build", "bt_traversal_export",
+    "bt_morton_cells", "bt_bucket_permutation", "bt_gather",
 ]
 
 _lib = None
@@ -182,6 +183,11 @@ def load():
     lib.bt_get_stage_times.argtypes = [vp, ct.POINTER(StageTimes)]
     lib.bt_traversal_build.argtypes = [vp, ct.POINTER(TravParams), ct.POINTER(TravSizes)]
     lib.bt_traversal_export.argtypes = [vp, ct.POINTER(TravArrays)]
+    lib.bt_morton_cells.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), ct.c_int64,
+                                    ct.POINTER(ct.c_double), ct.POINTER(ct.c_double),
+                                    ct.c_int, vp, vp]
+    lib.bt_bucket_permutation.argtypes = [vp, vp, ct.c_int64, vp, ct.c_int, vp]
+    lib.bt_gather.argtypes = [vp, ct.c_int, vp, vp, ct.c_int64, vp]
     if lib.bt_abi_version() != 1:
         raise RuntimeError("libboxtree_hip.so ABI version mismatch")
     _lib = lib

@@ -1,0 +1,149 @@
+// Kernels for the multi-GPU exchange step (boxtree_amd/distributed.py): top-level
+// Morton cell of every particle + cell histogram, stable bucketing by owner rank
+// (one digit pass of the radix sort), and the gather that fills the send buffers.
+// The collectives themselves (RCCL all-reduce / all-to-all over xGMI) are issued
+// from Python through torch.distributed.
+#include "bt_common.hpp"
+#include "bt_prims.hpp"
+#include "bt_sort.hpp"
+
+using namespace bt;
+
+namespace {
+
+template <class T, int D>
+struct CellArgs {
+    const T *x[D];
+    T bmin[D], bmax[D];
+    int64_t n;
+    int level;
+};
+
+// same float expression as the key kernel (tbk:374-376) at level `level`
+template <class T, int D>
+__global__ __launch_bounds__(256) void morton_cells_kernel(CellArgs<T, D> a, uint32_t *cells,
+                                                           int32_t *hist)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    uint32_t cell = 0;
+    const uint32_t top = (1u << a.level) - 1u;
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        const T gmin = a.bmin[ax];
+        const T gext = a.bmax[ax] - gmin;
+        uint32_t v = (uint32_t) (((a.x[ax][i] - gmin) / gext) * (T) (1u << a.level));
+        v = v > top ? top : v;
+        for (int b = 0; b < a.level; ++b)
+            cell |= ((v >> b) & 1u) << (D * b + (D - 1 - ax));       // x most significant
+    }
+    cells[i] = cell;
+    atomicAdd(&hist[cell], 1);
+}
+
+__global__ __launch_bounds__(256) void owner_keys_kernel(int64_t n, const uint32_t *cells,
+        const int32_t *owner_of_cell, uint32_t *keys)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = (uint32_t) owner_of_cell[cells[i]];
+}
+
+template <class U>
+__global__ __launch_bounds__(256) void gather_perm_kernel(int64_t n, const uint32_t *perm,
+        const U *__restrict__ in, U *__restrict__ out)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = in[perm[i]];
+}
+
+template <class T, int D>
+int cells_impl(bt_context *ctx, const void *const *coords, int64_t n, const double *bmin,
+               const double *bmax, int level, uint32_t *cells, int32_t *hist)
+{
+    CellArgs<T, D> a;
+    for (int ax = 0; ax < D; ++ax) {
+        a.x[ax] = (const T *) coords[ax];
+        a.bmin[ax] = (T) bmin[ax];
+        a.bmax[ax] = (T) bmax[ax];
+    }
+    a.n = n;
+    a.level = level;
+    if (n > 0)
+        morton_cells_kernel<T, D><<<(unsigned) div_up(n, 256), 256, 0, ctx->stream>>>(a, cells, hist);
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bt_morton_cells(bt_context *ctx, int dims, int coord_kind, const void *const *coords,
+                    int64_t n, const double *bbox_min, const double *bbox_max, int level,
+                    uint32_t *cells_out, int32_t *hist_inout)
+{
+    if (!ctx || !coords || !bbox_min || !bbox_max || n < 0 || dims < 1 || dims > BT_MAX_DIMS
+            || level < 1 || dims * level > 24 || (n > 0 && (!cells_out || !hist_inout))) {
+        set_error("bt_morton_cells: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    const bool f64 = coord_kind == BT_F64;
+    switch (dims) {
+    case 1: return f64 ? cells_impl<double, 1>(ctx, coords, n, bbox_min, bbox_max, level, cells_out, hist_inout)
+                       : cells_impl<float, 1>(ctx, coords, n, bbox_min, bbox_max, level, cells_out, hist_inout);
+    case 2: return f64 ? cells_impl<double, 2>(ctx, coords, n, bbox_min, bbox_max, level, cells_out, hist_inout)
+                       : cells_impl<float, 2>(ctx, coords, n, bbox_min, bbox_max, level, cells_out, hist_inout);
+    default: return f64 ? cells_impl<double, 3>(ctx, coords, n, bbox_min, bbox_max, level, cells_out, hist_inout)
+                        : cells_impl<float, 3>(ctx, coords, n, bbox_min, bbox_max, level, cells_out, hist_inout);
+    }
+}
+
+int bt_bucket_permutation(bt_context *ctx, const uint32_t *cells, int64_t n,
+                          const int32_t *owner_of_cell, int nranks, uint32_t *perm_out)
+{
+    if (!ctx || n < 0 || nranks < 1 || nranks > 256 || (n > 0 && (!cells || !owner_of_cell || !perm_out))) {
+        set_error("bt_bucket_permutation: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (n == 0) return BT_OK;
+    BT_CHECK(reset_status(ctx));
+    Buf<uint32_t> ka, kb, vb;
+    BT_CHECK(ka.alloc(ctx->pool, n));
+    BT_CHECK(kb.alloc(ctx->pool, n));
+    BT_CHECK(vb.alloc(ctx->pool, n));
+    owner_keys_kernel<<<(unsigned) div_up(n, 256), 256, 0, ctx->stream>>>(n, cells, owner_of_cell, ka.get());
+    int bits = 1;
+    while ((1 << bits) < nranks) ++bits;
+    bool in_b = false;
+    // one stable digit pass over (owner, 0..n-1): perm = original indices grouped by owner
+    BT_CHECK(radix_sort_pairs<uint32_t>(ctx, ka.get(), vb.get(), kb.get(), perm_out, n, 0, bits,
+                                        true, &in_b));
+    if (!in_b)
+        BT_HIP_CHECK(hipMemcpyAsync(perm_out, vb.get(), (size_t) n * 4, hipMemcpyDeviceToDevice,
+                                    ctx->stream));
+    return check_status(ctx);
+}
+
+int bt_gather(bt_context *ctx, int elem_size, const void *in, const uint32_t *perm, int64_t n,
+              void *out)
+{
+    if (!ctx || n < 0 || (elem_size != 4 && elem_size != 8) || (n > 0 && (!in || !perm || !out))) {
+        set_error("bt_gather: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (n == 0) return BT_OK;
+    const unsigned blocks = (unsigned) div_up(n, 256);
+    if (elem_size == 8)
+        gather_perm_kernel<uint64_t><<<blocks, 256, 0, ctx->stream>>>(n, perm, (const uint64_t *) in, (uint64_t *) out);
+    else
+        gather_perm_kernel<uint32_t><<<blocks, 256, 0, ctx->stream>>>(n, perm, (const uint32_t *) in, (uint32_t *) out);
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+}  // extern "C"

@@ -23,11 +23,14 @@ exchange step that precedes the per-rank single-GPU pipeline:
    rank because each owns whole, heavy cells).
 
 Status (round 1): steps 1-5 implemented with ``torch.distributed`` collectives
-(backend "nccl" = RCCL on GPUs, "gloo" in the CPU tests); per-particle cell
-index / bucketing use torch tensor ops (plumbing), not yet dedicated HIP
-kernels.  Not yet done: global box renumbering across ranks and halo exchange
-for interaction lists that cross ownership boundaries -- each rank's traversal
-covers its own subtree only.
+(backend "nccl" = RCCL on GPUs, "gloo" in the CPU tests).  On a GPU the
+per-particle work (cell index + histogram, stable bucketing by owner, gather
+into send order) runs in the library's HIP kernels (``bt_morton_cells``,
+``bt_bucket_permutation`` = one onesweep digit pass, ``bt_gather``); with
+``actx=None`` (the gloo CPU tests of the plan/exchange logic) the same routing
+is computed with torch tensor ops.  Not yet done: global box renumbering across
+ranks and halo exchange for interaction lists that cross ownership boundaries --
+each rank's traversal covers its own subtree only.
 """
 
 from __future__ import annotations
@@ -131,26 +134,74 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         top_level = 5 if dims == 3 else (7 if dims == 2 else 12)
     ncells = 1 << (dims * top_level)
 
-    def cells_of(arrs):
-        return morton_cells(arrs, bbox_min, bbox_max, top_level)
+    native = actx is not None and particles[0].is_cuda
 
-    src_cells = cells_of(particles)
-    hist = torch.bincount(src_cells, minlength=ncells)
+    def cells_of(arrs):
+        """(cells, hist) -- HIP kernel on the GPU, torch ops in the CPU tests."""
+        if not native:
+            c = morton_cells(arrs, bbox_min, bbox_max, top_level)
+            return c, torch.bincount(c, minlength=ncells)
+        import ctypes as ct
+        from boxtree_amd import _lib
+        n = len(arrs[0])
+        cells = torch.empty(n, dtype=torch.int32, device=dev)
+        hist = torch.zeros(ncells, dtype=torch.int32, device=dev)
+        ptrs = (ct.c_void_p * dims)(*[a.data_ptr() for a in arrs])
+        bmin = (ct.c_double * dims)(*[float(v) for v in bbox_min])
+        bmax = (ct.c_double * dims)(*[float(v) for v in bbox_max])
+        kind = _lib.BT_F64 if arrs[0].dtype == torch.float64 else _lib.BT_F32
+        actx.sync_in()
+        _lib.check(actx.lib.bt_morton_cells(
+            actx.handle, dims, kind, ptrs, n, bmin, bmax, top_level,
+            ct.c_void_p(cells.data_ptr()), ct.c_void_p(hist.data_ptr())))
+        return cells, hist.long()
+
+    src_cells, hist = cells_of(particles)
     tgt_cells = None
     if targets is not None:
-        tgt_cells = cells_of(targets)
-        hist = hist + torch.bincount(tgt_cells, minlength=ncells)
+        tgt_cells, thist = cells_of(targets)
+        hist = hist + thist
     dist.all_reduce(hist)
     owner = partition_cells(hist.cpu().numpy(), world)
     owner_t = torch.from_numpy(owner).to(dev)
 
     stats = {"bytes_sent": 0, "top_level": top_level}
 
+    def send_order(cells):
+        """(order, send_counts): original indices grouped by owner, stable."""
+        if not native:
+            dest = owner_t[cells]
+            return torch.argsort(dest, stable=True), torch.bincount(dest, minlength=world)
+        import ctypes as ct
+        from boxtree_amd import _lib
+        n = len(cells)
+        perm = torch.empty(n, dtype=torch.int32, device=dev)
+        owner32 = owner_t.to(torch.int32)
+        actx.sync_in()
+        _lib.check(actx.lib.bt_bucket_permutation(
+            actx.handle, ct.c_void_p(cells.data_ptr()), n, ct.c_void_p(owner32.data_ptr()),
+            world, ct.c_void_p(perm.data_ptr())))
+        # per-owner counts from the cell histogram of THIS rank's points
+        local_hist = torch.bincount(cells.long(), minlength=ncells)
+        send_counts = torch.zeros(world, dtype=torch.int64, device=dev)
+        send_counts.index_add_(0, owner_t, local_hist)
+        return perm, send_counts
+
+    def take(a, order):
+        if not native:
+            return a[order].contiguous()
+        import ctypes as ct
+        from boxtree_amd import _lib
+        out = torch.empty_like(a)
+        actx.sync_in()
+        _lib.check(actx.lib.bt_gather(
+            actx.handle, a.element_size(), ct.c_void_p(a.data_ptr()),
+            ct.c_void_p(order.data_ptr()), len(a), ct.c_void_p(out.data_ptr())))
+        return out
+
     def route(arrs, cells, extra):
         """all-to-all-v of the coordinate arrays (+ extras) by owner of `cells`."""
-        dest = owner_t[cells]
-        order = torch.argsort(dest, stable=True)
-        send_counts = torch.bincount(dest, minlength=world)
+        order, send_counts = send_order(cells)
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts)
         s_split = send_counts.cpu().tolist()
@@ -158,7 +209,7 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         nrecv = int(sum(r_split))
         outs = []
         for a in list(arrs) + list(extra):
-            send = a[order].contiguous()
+            send = take(a.contiguous(), order)
             recv = torch.empty(nrecv, dtype=a.dtype, device=dev)
             dist.all_to_all_single(recv, send, r_split, s_split)
             outs.append(recv)

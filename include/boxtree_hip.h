@@ -241,6 +241,25 @@ typedef struct {
 
 int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *out);
 
+/* ---- multi-GPU exchange helpers (no counterpart in the reference, which never
+ *      builds the tree in parallel: boxtree/distributed/__init__.py:183-199) ---- */
+
+/* Level-`level` Morton cell of every point (same float expression as the key
+ * kernel) into cells_out[n]; hist_inout[2^(dims*level)] (device, int32) is
+ * incremented per point. */
+int bt_morton_cells(bt_context *ctx, int dims, int coord_kind, const void *const *coords,
+                    int64_t n, const double *bbox_min, const double *bbox_max, int level,
+                    uint32_t *cells_out, int32_t *hist_inout);
+
+/* perm_out[n]: original indices grouped by owner_of_cell[cells[i]] (ascending
+ * owner, original order inside a group) -- the send order of the all-to-all. */
+int bt_bucket_permutation(bt_context *ctx, const uint32_t *cells, int64_t n,
+                          const int32_t *owner_of_cell, int nranks, uint32_t *perm_out);
+
+/* out[i] = in[perm[i]] for 4- or 8-byte elements */
+int bt_gather(bt_context *ctx, int elem_size, const void *in, const uint32_t *perm, int64_t n,
+              void *out);
+
 #ifdef __cplusplus
 }
 #endif

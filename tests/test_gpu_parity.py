@@ -337,3 +337,48 @@ def test_full_size_properties_c2(actx):
     htrav = actx.to_numpy(trav)
     pot = constant_one_potentials(htree, htrav)
     assert np.all(pot == n)
+
+
+# ---- multi-GPU exchange kernels (single GPU: routing only, no collective) ----------
+
+@pytest.mark.parametrize("dims,level", [(3, 5), (2, 7)])
+def test_shard_kernels_match_torch_routing(actx, dims, level):
+    import torch
+    from boxtree_amd import _lib
+    from boxtree_amd.distributed import morton_cells, partition_cells
+    n = 300001
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    pts = [torch.randn(n, generator=g, dtype=torch.float64, device="cuda") for _ in range(dims)]
+    bmin = np.array([float(p.min()) for p in pts])
+    ext = max(float(p.max()) - float(p.min()) for p in pts) * (1 + 1e-4)
+    bmax = bmin + ext
+    ncells = 1 << (dims * level)
+    ref_cells = morton_cells(pts, bmin, bmax, level)
+
+    cells = torch.empty(n, dtype=torch.int32, device="cuda")
+    hist = torch.zeros(ncells, dtype=torch.int32, device="cuda")
+    ptrs = (ct.c_void_p * dims)(*[p.data_ptr() for p in pts])
+    cmin = (ct.c_double * dims)(*bmin.tolist())
+    cmax = (ct.c_double * dims)(*bmax.tolist())
+    torch.cuda.synchronize()
+    _lib.check(actx.lib.bt_morton_cells(actx.handle, dims, _lib.BT_F64, ptrs, n, cmin, cmax, level,
+                                        ct.c_void_p(cells.data_ptr()), ct.c_void_p(hist.data_ptr())))
+    assert bool((cells.long() == ref_cells).all())
+    assert bool((hist.long() == torch.bincount(ref_cells, minlength=ncells)).all())
+
+    world = 8
+    owner = partition_cells(hist.cpu().numpy(), world)
+    owner_t = torch.from_numpy(owner).cuda()
+    owner32 = owner_t.to(torch.int32)
+    perm = torch.empty(n, dtype=torch.int32, device="cuda")
+    _lib.check(actx.lib.bt_bucket_permutation(actx.handle, ct.c_void_p(cells.data_ptr()), n,
+                                              ct.c_void_p(owner32.data_ptr()), world,
+                                              ct.c_void_p(perm.data_ptr())))
+    ref_perm = torch.argsort(owner_t[ref_cells], stable=True)
+    assert bool((perm.long() == ref_perm).all())
+
+    out = torch.empty_like(pts[0])
+    _lib.check(actx.lib.bt_gather(actx.handle, 8, ct.c_void_p(pts[0].data_ptr()),
+                                  ct.c_void_p(perm.data_ptr()), n, ct.c_void_p(out.data_ptr())))
+    assert bool((out == pts[0][ref_perm]).all())
