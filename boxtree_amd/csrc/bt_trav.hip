@@ -16,7 +16,6 @@ using namespace bt;
 
 namespace {
 
-constexpr int MAX_WALK = 40;      // walk stack depth (tree levels <= 32)
 
 template <class T> struct Eps;
 template <> struct Eps<float> { static constexpr float v = 1.1920928955078125e-07f; };
@@ -126,14 +125,20 @@ __device__ __forceinline__ bool adj(T root_extent, const T *tc, int tl, const T 
     return adj_nbhd<T, D>(root_extent, tc, tl, (T) 1, sc, sl);
 }
 
-// walk state: traversal.py:98-160
+// walk state: traversal.py:98-160.  The stack lives in LDS (one column per
+// thread): private arrays would go to scratch, and kernels that use scratch get
+// only ~8 wave slots per CU here (measured on list13_kernel).  An entry packs the
+// parent box and the child slot to resume at: box | slot << 28 (boxes < 2^28 is
+// checked on the host).
+constexpr int WALK_THREADS = 256;
+
 struct Walk {
-    int32_t box_stack[MAX_WALK];
-    int8_t mnr_stack[MAX_WALK];
+    int32_t *stk;      // LDS, element i at stk[i * WALK_THREADS]
     int size;
     int32_t parent;
     int mnr;
     bool go;
+    __device__ __forceinline__ explicit Walk(int32_t *lds_column) : stk(lds_column) {}
     __device__ __forceinline__ void init(int32_t start) { size = 0; parent = start; mnr = 0; go = true; }
     template <int C>
     __device__ __forceinline__ void advance()
@@ -142,17 +147,25 @@ struct Walk {
             ++mnr;
             if (mnr < C) break;
             go = size > 0;
-            if (go) { --size; parent = box_stack[size]; mnr = mnr_stack[size]; }
-            else break;
+            if (go) {
+                --size;
+                const int32_t e = stk[size * WALK_THREADS];
+                parent = e & 0x0fffffff;
+                mnr = e >> 28;
+            } else break;
         }
     }
     __device__ __forceinline__ void push(int32_t nb)
     {
-        box_stack[size] = parent; mnr_stack[size] = (int8_t) mnr;
-        if (size < MAX_WALK - 1) ++size;
+        stk[size * WALK_THREADS] = parent | (mnr << 28);
+        ++size;
         parent = nb; mnr = 0;
     }
 };
+
+// dynamic LDS of the walk kernels: [walk_cap][256] stack entries, then (list 3)
+// [nlevels][256] per-level counters
+extern __shared__ __attribute__((aligned(16))) int32_t s_walk_lds[];
 
 // ---- emitters ---------------------------------------------------------------
 
@@ -175,7 +188,7 @@ __device__ __forceinline__ void gen_colleagues(const TravArgs<T, D> &a, int32_t 
     T center[D];
     load_center(a, box_id, center);
     const int level = box_level(a, box_id);
-    Walk w;
+    Walk w(s_walk_lds + threadIdx.x);
     w.init(0);
     while (w.go) {
         const int32_t wb = child_of<D>(a, w.parent, w.mnr);
@@ -211,7 +224,7 @@ __device__ __forceinline__ void gen_list1(const TravArgs<T, D> &a, int32_t tbn, 
     load_center(a, box_id, center);
     const int level = box_level(a, box_id);
     if (box_flags(a, 0) & BT_BOX_IS_SOURCE_BOX) emit(0);
-    Walk w;
+    Walk w(s_walk_lds + threadIdx.x);
     w.init(0);
     while (w.go) {
         const int32_t wb = child_of<D>(a, w.parent, w.mnr);
@@ -310,7 +323,7 @@ __device__ __forceinline__ void gen_list3(const TravArgs<T, D> &a, int32_t tbn, 
         // nothing below a colleague without source children can be emitted
         // (flag consistency is part of the verified structure)
         if (a.fast && !(cfl & BT_BOX_HAS_SOURCE_CHILD_BOXES)) continue;
-        Walk w;
+        Walk w(s_walk_lds + threadIdx.x);
         w.init(nws);
         while (w.go) {
             const int32_t wb = child_of<D>(a, w.parent, w.mnr);
@@ -470,37 +483,39 @@ __global__ __launch_bounds__(256) void list_kernel(TravArgs<T, D> a, int32_t n,
     }
 }
 
-constexpr int L3_MAXLEV = 40;
-
+// per-level counters / cursors of list 3 live in LDS columns as well
 struct L3CountMain {
-    int32_t c[L3_MAXLEV];
-    __device__ __forceinline__ void operator()(int lev, int32_t) { ++c[lev]; }
+    int32_t *c;        // LDS column, element l at c[l * WALK_THREADS]
+    __device__ __forceinline__ void operator()(int lev, int32_t) { ++c[lev * WALK_THREADS]; }
 };
 struct L3WriteMain {
     int32_t *lists;
-    int32_t cur[L3_MAXLEV];
-    __device__ __forceinline__ void operator()(int lev, int32_t b) { lists[cur[lev]++] = b; }
+    int32_t *cur;      // LDS column
+    __device__ __forceinline__ void operator()(int lev, int32_t b)
+    {
+        lists[cur[lev * WALK_THREADS]++] = b;
+    }
 };
 
 // counts layout: [nlevels][ntb] (level-major) for the main list, [ntb] for close
 template <class T, int D, bool FILL>
 __global__ __launch_bounds__(256) void list3_kernel(TravArgs<T, D> a, int32_t ntb, int nlevels,
-        int32_t *main_cs, int32_t *main_lists, int32_t *close_cs, int32_t *close_lists)
+        int walk_cap, int32_t *main_cs, int32_t *main_lists, int32_t *close_cs, int32_t *close_lists)
 {
     const int32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= ntb) return;
+    int32_t *lvl = s_walk_lds + walk_cap * WALK_THREADS + threadIdx.x;
     if (!FILL) {
-        L3CountMain em;
-        for (int l = 0; l < nlevels; ++l) em.c[l] = 0;
+        L3CountMain em{lvl};
+        for (int l = 0; l < nlevels; ++l) lvl[l * WALK_THREADS] = 0;
         CountEmit ec;
         NoL1 no1;
         gen_list3<T, D>(a, i, em, ec, no1);
-        for (int l = 0; l < nlevels; ++l) main_cs[(int64_t) l * ntb + i] = em.c[l];
+        for (int l = 0; l < nlevels; ++l) main_cs[(int64_t) l * ntb + i] = lvl[l * WALK_THREADS];
         if (close_cs) close_cs[i] = ec.n;
     } else {
-        L3WriteMain em;
-        em.lists = main_lists;
-        for (int l = 0; l < nlevels; ++l) em.cur[l] = main_cs[(int64_t) l * ntb + i];
+        L3WriteMain em{main_lists, lvl};
+        for (int l = 0; l < nlevels; ++l) lvl[l * WALK_THREADS] = main_cs[(int64_t) l * ntb + i];
         WriteEmit ec{close_lists ? close_lists + close_cs[i] : nullptr};
         CountEmit dummy;
         NoL1 no1;
@@ -798,6 +813,9 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     const int64_t B = p.nboxes;
     const int nlevels = p.nlevels;
     const int32_t *ls = p.level_start_box_nrs;       // host
+    const int walk_cap = nlevels + 1;
+    const size_t walk_lds = (size_t) walk_cap * WALK_THREADS * 4;
+    const size_t lvl_lds = (size_t) nlevels * WALK_THREADS * 4;
 
     // depth-first preorder ranks
     BT_CHECK(st->subtree_size.alloc(ctx->pool, B));
@@ -921,8 +939,8 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         CsrList &cs = st->close_smaller;
         cs.n = ntb;
         if (st->with_extent) BT_CHECK(cs.starts.alloc(ctx->pool, ntb + 1));
-        list13_kernel<T, D, false><<<nblk(ntb), 256, 0, ctx->stream>>>(
-            a, ft, lcoll_starts.get(), lcoll_lists.get(), (int32_t) ntb, nlevels, jobs,
+        list13_kernel<T, D, false><<<nblk(ntb), 256, walk_lds + lvl_lds, ctx->stream>>>(
+            a, ft, lcoll_starts.get(), lcoll_lists.get(), (int32_t) ntb, nlevels, walk_cap, jobs,
             c1.starts.get(), nullptr, st->l3_starts.get(), nullptr,
             st->with_extent ? cs.starts.get() : nullptr, nullptr);
         int64_t total3 = 0;
@@ -934,8 +952,8 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             BT_CHECK(counts_to_starts(ctx, cs.starts, ntb, &cs.total));
             BT_CHECK(cs.lists.alloc(ctx->pool, cs.total));
         }
-        list13_kernel<T, D, true><<<nblk(ntb), 256, 0, ctx->stream>>>(
-            a, ft, lcoll_starts.get(), lcoll_lists.get(), (int32_t) ntb, nlevels, jobs,
+        list13_kernel<T, D, true><<<nblk(ntb), 256, walk_lds + lvl_lds, ctx->stream>>>(
+            a, ft, lcoll_starts.get(), lcoll_lists.get(), (int32_t) ntb, nlevels, walk_cap, jobs,
             c1.starts.get(), c1.lists.get(), st->l3_starts.get(), st->l3_lists.get(),
             st->with_extent ? cs.starts.get() : nullptr,
             st->with_extent ? cs.lists.get() : nullptr);
@@ -958,6 +976,9 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     const int nlevels = p.nlevels;
     const bool sat = p.sources_are_targets;
     st->with_extent = p.sources_have_extent || p.targets_have_extent;
+    const int walk_cap = nlevels + 1;
+    const size_t walk_lds = (size_t) walk_cap * WALK_THREADS * 4;
+    const size_t lvl_lds = (size_t) nlevels * WALK_THREADS * 4;
 
     BT_CHECK(tmark(ctx, st, "trav:start"));
     // T1
@@ -1039,10 +1060,10 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
             CsrList &c = st->coll;
             c.n = B;
             BT_CHECK(c.starts.alloc(ctx->pool, B + 1));
-            list_kernel<T, D, GEN_COLL, false><<<nblk(B), 256, 0, ctx->stream>>>(a, (int32_t) B, c.starts.get(), nullptr);
+            list_kernel<T, D, GEN_COLL, false><<<nblk(B), 256, walk_lds, ctx->stream>>>(a, (int32_t) B, c.starts.get(), nullptr);
             BT_CHECK(counts_to_starts(ctx, c.starts, B, &c.total));
             BT_CHECK(c.lists.alloc(ctx->pool, c.total));
-            list_kernel<T, D, GEN_COLL, true><<<nblk(B), 256, 0, ctx->stream>>>(a, (int32_t) B, c.starts.get(), c.lists.get());
+            list_kernel<T, D, GEN_COLL, true><<<nblk(B), 256, walk_lds, ctx->stream>>>(a, (int32_t) B, c.starts.get(), c.lists.get());
         }
         a.coll_starts = st->coll.starts.get();
         a.coll_lists = st->coll.lists.get();
@@ -1053,10 +1074,10 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
             CsrList &c = st->l1;
             c.n = st->ntb;
             BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
-            list_kernel<T, D, GEN_L1, false><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), nullptr);
+            list_kernel<T, D, GEN_L1, false><<<nblk(c.n), 256, walk_lds, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), nullptr);
             BT_CHECK(counts_to_starts(ctx, c.starts, c.n, &c.total));
             BT_CHECK(c.lists.alloc(ctx->pool, c.total));
-            list_kernel<T, D, GEN_L1, true><<<nblk(c.n), 256, 0, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), c.lists.get());
+            list_kernel<T, D, GEN_L1, true><<<nblk(c.n), 256, walk_lds, ctx->stream>>>(a, (int32_t) c.n, c.starts.get(), c.lists.get());
         }
         BT_CHECK(tmark(ctx, st, "trav:list1"));
         // T5 list 2
@@ -1085,8 +1106,8 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         CsrList &cs = st->close_smaller;
         cs.n = ntb;
         if (st->with_extent) BT_CHECK(cs.starts.alloc(ctx->pool, ntb + 1));
-        list3_kernel<T, D, false><<<nblk(ntb), 256, 0, ctx->stream>>>(
-            a, (int32_t) ntb, nlevels, st->l3_starts.get(), nullptr,
+        list3_kernel<T, D, false><<<nblk(ntb), 256, walk_lds + lvl_lds, ctx->stream>>>(
+            a, (int32_t) ntb, nlevels, walk_cap, st->l3_starts.get(), nullptr,
             st->with_extent ? cs.starts.get() : nullptr, nullptr);
         int64_t total = 0;
         BT_CHECK(counts_to_starts(ctx, st->l3_starts, nflat, &total));
@@ -1095,8 +1116,8 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
             BT_CHECK(counts_to_starts(ctx, cs.starts, ntb, &cs.total));
             BT_CHECK(cs.lists.alloc(ctx->pool, cs.total));
         }
-        list3_kernel<T, D, true><<<nblk(ntb), 256, 0, ctx->stream>>>(
-            a, (int32_t) ntb, nlevels, st->l3_starts.get(), st->l3_lists.get(),
+        list3_kernel<T, D, true><<<nblk(ntb), 256, walk_lds + lvl_lds, ctx->stream>>>(
+            a, (int32_t) ntb, nlevels, walk_cap, st->l3_starts.get(), st->l3_lists.get(),
             st->with_extent ? cs.starts.get() : nullptr,
             st->with_extent ? cs.lists.get() : nullptr);
 
@@ -1189,6 +1210,10 @@ int bt_traversal_build(bt_context *ctx, const bt_trav_params *p, bt_trav_sizes *
     if (p->sources_have_extent) {
         set_error("trees with source extent are not supported for traversal generation");
         return BT_ERR_UNSUPPORTED;                       // traversal.py:2002-2006
+    }
+    if (p->nboxes >= ((int64_t) 1 << 28)) {
+        set_error("bt_traversal_build: more than 2^28 boxes are not supported");
+        return BT_ERR_UNSUPPORTED;
     }
     if (p->nlevels < 1 || p->nlevels > 32 || p->nboxes < 1 || !p->level_start_box_nrs) {
         set_error("bt_traversal_build: bad nlevels/nboxes");

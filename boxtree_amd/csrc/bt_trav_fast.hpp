@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void list1_fast_kernel(TravArgs<T, D> a, FastT
 
     // finer boxes: descend like traversal.py:501-547, but only inside box u
     auto descend = [&](int32_t u) {
-        Walk w;
+        Walk w(s_walk_lds + threadIdx.x);
         w.init(u);
         while (w.go) {
             const int32_t wb = child_of<D>(a, w.parent, w.mnr);
@@ -401,7 +401,7 @@ struct L1Emit {
 template <class T, int D, bool FILL>
 __global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree ft,
         const int32_t *lcoll_starts, const int32_t *lcoll_lists, int32_t ntb, int nlevels,
-        BlockJobs jobs, int32_t *l1_cs, int32_t *l1_lists,
+        int walk_cap, BlockJobs jobs, int32_t *l1_cs, int32_t *l1_lists,
         int32_t *l3_cs, int32_t *l3_lists, int32_t *close_cs, int32_t *close_lists)
 {
     const int32_t tbn = blockIdx.x * 256 + threadIdx.x;
@@ -445,18 +445,18 @@ __global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree 
 
     // colleagues and everything below them: list 3 walk, which also yields the
     // list-1 boxes at the colleagues' level and finer
+    int32_t *lvl = s_walk_lds + walk_cap * WALK_THREADS + threadIdx.x;
     if (!FILL) {
-        L3CountMain em;
-        for (int l = 0; l < nlevels; ++l) em.c[l] = 0;
+        L3CountMain em{lvl};
+        for (int l = 0; l < nlevels; ++l) lvl[l * WALK_THREADS] = 0;
         CountEmit ec;
         gen_list3<T, D>(a, tbn, em, ec, e1);
-        for (int l = 0; l < nlevels; ++l) l3_cs[(int64_t) l * ntb + tbn] = em.c[l];
+        for (int l = 0; l < nlevels; ++l) l3_cs[(int64_t) l * ntb + tbn] = lvl[l * WALK_THREADS];
         if (close_cs) close_cs[tbn] = ec.n;
         l1_cs[tbn] = e1.n + blk_len;
     } else {
-        L3WriteMain em;
-        em.lists = l3_lists;
-        for (int l = 0; l < nlevels; ++l) em.cur[l] = l3_cs[(int64_t) l * ntb + tbn];
+        L3WriteMain em{l3_lists, lvl};
+        for (int l = 0; l < nlevels; ++l) lvl[l * WALK_THREADS] = l3_cs[(int64_t) l * ntb + tbn];
         WriteEmit ec{close_lists ? close_lists + close_cs[tbn] : nullptr};
         CountEmit dummy;
         if (close_lists) gen_list3<T, D>(a, tbn, em, ec, e1);
