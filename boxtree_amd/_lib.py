@@ -143,7 +143,7 @@ EXPORTED_SYMBOLS = [
     "bt_bbox", "bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32", "bt_get_sort_stats",
     "bt_tree_build", "bt_tree_export", "bt_get_stage_times",
     "bt_traversal_build", "bt_traversal_export",
-    "bt_morton_cells", "bt_bucket_permutation", "bt_gather",
+    "bt_morton_cells", "bt_bucket_permutation", "bt_gather", "bt_gather_pack", "bt_unpack",
 ]
 
 _lib = None
@@ -188,6 +188,8 @@ def load():
                                     ct.c_int, vp, vp]
     lib.bt_bucket_permutation.argtypes = [vp, vp, ct.c_int64, vp, ct.c_int, vp]
     lib.bt_gather.argtypes = [vp, ct.c_int, vp, vp, ct.c_int64, vp]
+    lib.bt_gather_pack.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), vp, ct.c_int64, vp]
+    lib.bt_unpack.argtypes = [vp, ct.c_int, ct.c_int, vp, ct.c_int64, ct.POINTER(vp)]
     if lib.bt_abi_version() != 1:
         raise RuntimeError("libboxtree_hip.so ABI version mismatch")
     _lib = lib

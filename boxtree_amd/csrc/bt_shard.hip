@@ -7,6 +7,8 @@
 #include "bt_prims.hpp"
 #include "bt_sort.hpp"
 
+#include <algorithm>
+
 using namespace bt;
 
 namespace {
@@ -41,6 +43,40 @@ __global__ __launch_bounds__(256) void morton_cells_kernel(CellArgs<T, D> a, uin
     atomicAdd(&hist[cell], 1);
 }
 
+// same, with the histogram privatised in LDS (up to 2^15 cells = 128 KiB, one
+// workgroup per CU): 1e8 global atomics on 32 K addresses cost ~5 ms otherwise
+constexpr int CELLS_LDS_MAX = 1 << 15;
+
+template <class T, int D>
+__global__ __launch_bounds__(1024) void morton_cells_lds_kernel(CellArgs<T, D> a, uint32_t *cells,
+                                                                int32_t *hist, int ncells)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
+    for (int c = threadIdx.x; c < ncells; c += 1024) s_hist[c] = 0;
+    __syncthreads();
+    const uint32_t top = (1u << a.level) - 1u;
+    const int64_t stride = (int64_t) gridDim.x * 1024;
+    for (int64_t i = (int64_t) blockIdx.x * 1024 + threadIdx.x; i < a.n; i += stride) {
+        uint32_t cell = 0;
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) {
+            const T gmin = a.bmin[ax];
+            const T gext = a.bmax[ax] - gmin;
+            uint32_t v = (uint32_t) (((a.x[ax][i] - gmin) / gext) * (T) (1u << a.level));
+            v = v > top ? top : v;
+            for (int b = 0; b < a.level; ++b)
+                cell |= ((v >> b) & 1u) << (D * b + (D - 1 - ax));
+        }
+        cells[i] = cell;
+        atomicAdd(&s_hist[cell], 1u);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < ncells; c += 1024) {
+        const uint32_t v = s_hist[c];
+        if (v) atomicAdd(&hist[c], (int32_t) v);
+    }
+}
+
 __global__ __launch_bounds__(256) void owner_keys_kernel(int64_t n, const uint32_t *cells,
         const int32_t *owner_of_cell, uint32_t *keys)
 {
@@ -56,6 +92,52 @@ __global__ __launch_bounds__(256) void gather_perm_kernel(int64_t n, const uint3
     if (i < n) out[i] = in[perm[i]];
 }
 
+// out[i*D + ax] = in[ax][perm[i]]: the D coordinates of a particle travel together
+template <class U, int D>
+struct PackArgs { const U *in[D]; };
+
+template <class U, int D>
+__global__ __launch_bounds__(256) void gather_pack_kernel(int64_t n, const uint32_t *perm,
+        PackArgs<U, D> a, U *__restrict__ out)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = perm[i];
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) out[i * D + ax] = a.in[ax][j];
+}
+
+template <class U, int D>
+struct UnpackArgs { U *out[D]; };
+
+template <class U, int D>
+__global__ __launch_bounds__(256) void unpack_kernel(int64_t n, const U *__restrict__ in,
+                                                     UnpackArgs<U, D> a)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) a.out[ax][i] = in[i * D + ax];
+}
+
+template <class U, int D>
+int pack_impl(bt_context *ctx, const void *const *in, const uint32_t *perm, int64_t n, void *out)
+{
+    PackArgs<U, D> a;
+    for (int ax = 0; ax < D; ++ax) a.in[ax] = (const U *) in[ax];
+    gather_pack_kernel<U, D><<<(unsigned) div_up(n, 256), 256, 0, ctx->stream>>>(n, perm, a, (U *) out);
+    return BT_OK;
+}
+
+template <class U, int D>
+int unpack_impl(bt_context *ctx, const void *in, int64_t n, void *const *out)
+{
+    UnpackArgs<U, D> a;
+    for (int ax = 0; ax < D; ++ax) a.out[ax] = (U *) out[ax];
+    unpack_kernel<U, D><<<(unsigned) div_up(n, 256), 256, 0, ctx->stream>>>(n, (const U *) in, a);
+    return BT_OK;
+}
+
 template <class T, int D>
 int cells_impl(bt_context *ctx, const void *const *coords, int64_t n, const double *bmin,
                const double *bmax, int level, uint32_t *cells, int32_t *hist)
@@ -68,8 +150,14 @@ int cells_impl(bt_context *ctx, const void *const *coords, int64_t n, const doub
     }
     a.n = n;
     a.level = level;
-    if (n > 0)
+    const int ncells = 1 << (D * level);
+    if (n > 0 && ncells <= CELLS_LDS_MAX) {
+        const unsigned blocks = (unsigned) std::min<int64_t>(div_up(n, 1024), ctx->num_cus);
+        morton_cells_lds_kernel<T, D><<<blocks, 1024, (size_t) ncells * 4, ctx->stream>>>(
+            a, cells, hist, ncells);
+    } else if (n > 0) {
         morton_cells_kernel<T, D><<<(unsigned) div_up(n, 256), 256, 0, ctx->stream>>>(a, cells, hist);
+    }
     BT_HIP_CHECK(hipGetLastError());
     BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return BT_OK;
@@ -141,6 +229,58 @@ int bt_gather(bt_context *ctx, int elem_size, const void *in, const uint32_t *pe
         gather_perm_kernel<uint64_t><<<blocks, 256, 0, ctx->stream>>>(n, perm, (const uint64_t *) in, (uint64_t *) out);
     else
         gather_perm_kernel<uint32_t><<<blocks, 256, 0, ctx->stream>>>(n, perm, (const uint32_t *) in, (uint32_t *) out);
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+
+int bt_gather_pack(bt_context *ctx, int dims, int elem_size, const void *const *in,
+                   const uint32_t *perm, int64_t n, void *out)
+{
+    if (!ctx || n < 0 || dims < 1 || dims > BT_MAX_DIMS || (elem_size != 4 && elem_size != 8)
+            || (n > 0 && (!in || !perm || !out))) {
+        set_error("bt_gather_pack: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (n == 0) return BT_OK;
+    int s = BT_OK;
+    if (elem_size == 8) {
+        s = dims == 1 ? pack_impl<uint64_t, 1>(ctx, in, perm, n, out)
+          : dims == 2 ? pack_impl<uint64_t, 2>(ctx, in, perm, n, out)
+                      : pack_impl<uint64_t, 3>(ctx, in, perm, n, out);
+    } else {
+        s = dims == 1 ? pack_impl<uint32_t, 1>(ctx, in, perm, n, out)
+          : dims == 2 ? pack_impl<uint32_t, 2>(ctx, in, perm, n, out)
+                      : pack_impl<uint32_t, 3>(ctx, in, perm, n, out);
+    }
+    BT_CHECK(s);
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+int bt_unpack(bt_context *ctx, int dims, int elem_size, const void *in, int64_t n, void *const *out)
+{
+    if (!ctx || n < 0 || dims < 1 || dims > BT_MAX_DIMS || (elem_size != 4 && elem_size != 8)
+            || (n > 0 && (!in || !out))) {
+        set_error("bt_unpack: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (n == 0) return BT_OK;
+    int s = BT_OK;
+    if (elem_size == 8) {
+        s = dims == 1 ? unpack_impl<uint64_t, 1>(ctx, in, n, out)
+          : dims == 2 ? unpack_impl<uint64_t, 2>(ctx, in, n, out)
+                      : unpack_impl<uint64_t, 3>(ctx, in, n, out);
+    } else {
+        s = dims == 1 ? unpack_impl<uint32_t, 1>(ctx, in, n, out)
+          : dims == 2 ? unpack_impl<uint32_t, 2>(ctx, in, n, out)
+                      : unpack_impl<uint32_t, 3>(ctx, in, n, out);
+    }
+    BT_CHECK(s);
     BT_HIP_CHECK(hipGetLastError());
     BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return BT_OK;

@@ -156,18 +156,19 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
             ct.c_void_p(cells.data_ptr()), ct.c_void_p(hist.data_ptr())))
         return cells, hist.long()
 
-    src_cells, hist = cells_of(particles)
-    tgt_cells = None
+    src_cells, src_hist = cells_of(particles)
+    hist = src_hist.clone()
+    tgt_cells = tgt_hist = None
     if targets is not None:
-        tgt_cells, thist = cells_of(targets)
-        hist = hist + thist
+        tgt_cells, tgt_hist = cells_of(targets)
+        hist = hist + tgt_hist
     dist.all_reduce(hist)
     owner = partition_cells(hist.cpu().numpy(), world)
     owner_t = torch.from_numpy(owner).to(dev)
 
     stats = {"bytes_sent": 0, "top_level": top_level}
 
-    def send_order(cells):
+    def send_order(cells, local_hist):
         """(order, send_counts): original indices grouped by owner, stable."""
         if not native:
             dest = owner_t[cells]
@@ -182,7 +183,6 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
             actx.handle, ct.c_void_p(cells.data_ptr()), n, ct.c_void_p(owner32.data_ptr()),
             world, ct.c_void_p(perm.data_ptr())))
         # per-owner counts from the cell histogram of THIS rank's points
-        local_hist = torch.bincount(cells.long(), minlength=ncells)
         send_counts = torch.zeros(world, dtype=torch.int64, device=dev)
         send_counts.index_add_(0, owner_t, local_hist)
         return perm, send_counts
@@ -199,16 +199,40 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
             ct.c_void_p(order.data_ptr()), len(a), ct.c_void_p(out.data_ptr())))
         return out
 
-    def route(arrs, cells, extra):
+    def route(arrs, cells, local_hist, extra):
         """all-to-all-v of the coordinate arrays (+ extras) by owner of `cells`."""
-        order, send_counts = send_order(cells)
+        order, send_counts = send_order(cells, local_hist)
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts)
         s_split = send_counts.cpu().tolist()
         r_split = recv_counts.cpu().tolist()
         nrecv = int(sum(r_split))
         outs = []
-        for a in list(arrs) + list(extra):
+        if native:
+            # coordinates travel interleaved: one message per peer instead of d
+            import ctypes as ct
+            from boxtree_amd import _lib
+            d = len(arrs)
+            n = len(arrs[0])
+            es = arrs[0].element_size()
+            send = torch.empty(n * d, dtype=arrs[0].dtype, device=dev)
+            ptrs = (ct.c_void_p * d)(*[a.contiguous().data_ptr() for a in arrs])
+            actx.sync_in()
+            _lib.check(actx.lib.bt_gather_pack(
+                actx.handle, d, es, ptrs, ct.c_void_p(order.data_ptr()), n,
+                ct.c_void_p(send.data_ptr())))
+            recv = torch.empty(nrecv * d, dtype=arrs[0].dtype, device=dev)
+            dist.all_to_all_single(recv, send, [r * d for r in r_split], [c * d for c in s_split])
+            outs = [torch.empty(nrecv, dtype=arrs[0].dtype, device=dev) for _ in range(d)]
+            optrs = (ct.c_void_p * d)(*[o.data_ptr() for o in outs])
+            actx.sync_in()
+            _lib.check(actx.lib.bt_unpack(actx.handle, d, es, ct.c_void_p(recv.data_ptr()),
+                                          nrecv, optrs))
+            stats["bytes_sent"] += (n - s_split[rank]) * es * d
+            rest = list(extra)
+        else:
+            rest = list(arrs) + list(extra)
+        for a in rest:
             send = take(a.contiguous(), order)
             recv = torch.empty(nrecv, dtype=a.dtype, device=dev)
             dist.all_to_all_single(recv, send, r_split, s_split)
@@ -217,13 +241,13 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         return outs[:len(arrs)], outs[len(arrs):]
 
     new_particles, extra = route(
-        particles, src_cells, [source_radii] if source_radii is not None else [])
+        particles, src_cells, src_hist, [source_radii] if source_radii is not None else [])
     if source_radii is not None:
         build_kw["source_radii"] = extra[0]
     new_targets = None
     if targets is not None:
         new_targets, extra = route(
-            targets, tgt_cells, [target_radii] if target_radii is not None else [])
+            targets, tgt_cells, tgt_hist, [target_radii] if target_radii is not None else [])
         if target_radii is not None:
             build_kw["target_radii"] = extra[0]
 

@@ -260,6 +260,14 @@ int bt_bucket_permutation(bt_context *ctx, const uint32_t *cells, int64_t n,
 int bt_gather(bt_context *ctx, int elem_size, const void *in, const uint32_t *perm, int64_t n,
               void *out);
 
+/* send buffer of the all-to-all: out[i*dims + ax] = in[ax][perm[i]] (one message
+ * per peer carries all coordinates), and its inverse on the receiving side:
+ * out[ax][i] = in[i*dims + ax]. */
+int bt_gather_pack(bt_context *ctx, int dims, int elem_size, const void *const *in,
+                   const uint32_t *perm, int64_t n, void *out);
+int bt_unpack(bt_context *ctx, int dims, int elem_size, const void *in, int64_t n,
+              void *const *out);
+
 #ifdef __cplusplus
 }
 #endif
