@@ -142,7 +142,7 @@ EXPORTED_SYMBOLS = [
     "bt_abi_version", "bt_create", "bt_destroy", "bt_trim", "bt_last_error_string",
     "bt_bbox", "bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32", "bt_get_sort_stats",
     "bt_tree_build", "bt_tree_export", "bt_get_stage_times",
-    "bt_traversal_build", "bt_traversal_export",
+    "bt_traversal_build", "bt_traversal_export", "bt_merge_csr_lists",
     "bt_morton_cells", "bt_bucket_permutation", "bt_gather", "bt_gather_pack", "bt_unpack",
 ]
 
@@ -183,6 +183,8 @@ def load():
     lib.bt_get_stage_times.argtypes = [vp, ct.POINTER(StageTimes)]
     lib.bt_traversal_build.argtypes = [vp, ct.POINTER(TravParams), ct.POINTER(TravSizes)]
     lib.bt_traversal_export.argtypes = [vp, ct.POINTER(TravArrays)]
+    lib.bt_merge_csr_lists.argtypes = [vp, ct.c_int, ct.POINTER(vp), ct.POINTER(vp),
+                                       ct.c_int64, vp, vp]
     lib.bt_morton_cells.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), ct.c_int64,
                                     ct.POINTER(ct.c_double), ct.POINTER(ct.c_double),
                                     ct.c_int, vp, vp]

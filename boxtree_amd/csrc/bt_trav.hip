@@ -643,6 +643,36 @@ __global__ __launch_bounds__(256) void merge_copy_kernel(int32_t n, MergeCount m
 
 #include "bt_trav_fast.hpp"
 
+// ---- merging CSR lists row by row (_ListMerger, traversal.py:1153-1344) ----------
+
+struct MergeRows {
+    int nlists;
+    const int32_t *starts[4];
+    const int32_t *lists[4];
+};
+
+struct MergeRowCount {
+    MergeRows m;
+    __device__ int32_t operator()(int64_t i) const
+    {
+        int32_t c = 0;
+        for (int k = 0; k < m.nlists; ++k) c += m.starts[k][i + 1] - m.starts[k][i];
+        return c;
+    }
+};
+
+__global__ __launch_bounds__(256) void merge_rows_kernel(int32_t n, MergeRows m,
+        const int32_t *new_starts, int32_t *new_lists)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int32_t o = new_starts[i];
+    for (int k = 0; k < m.nlists; ++k) {
+        const int32_t s = m.starts[k][i], e = m.starts[k][i + 1];
+        for (int32_t j = s; j < e; ++j) new_lists[o++] = m.lists[k][j];
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1299,6 +1329,30 @@ int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
     }
     BT_HIP_CHECK(hipGetLastError());
     BT_CHECK(tmark(ctx, st, "trav:export"));
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+
+int bt_merge_csr_lists(bt_context *ctx, int nlists, const int32_t *const *starts,
+                       const int32_t *const *lists, int64_t nrows, int32_t *out_starts,
+                       int32_t *out_lists)
+{
+    if (!ctx || nlists < 1 || nlists > 4 || !starts || !lists || nrows < 0 || !out_starts) {
+        set_error("bt_merge_csr_lists: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    MergeRows m{};
+    m.nlists = nlists;
+    for (int k = 0; k < nlists; ++k) { m.starts[k] = starts[k]; m.lists[k] = lists[k]; }
+    MergeRowCount f{m};
+    BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, f, nrows, out_starts,
+                                                      (int32_t *) nullptr, true)));
+    if (nrows > 0 && out_lists)
+        merge_rows_kernel<<<nblk(nrows), 256, 0, ctx->stream>>>((int32_t) nrows, m, out_starts,
+                                                                out_lists);
+    BT_HIP_CHECK(hipGetLastError());
     BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return BT_OK;
 }

@@ -83,39 +83,33 @@ class FMMTraversalInfo(_Container):
         return len(self.target_or_target_parent_boxes)
 
     def merge_close_lists(self, actx, debug=False):
-        """Merge the "close" lists into list 1 (traversal.py:1650-1693).
-
-        Host-side (numpy) for now: this is a consumer-side convenience, not
-        part of the list-building hot path."""
+        """Return a new :class:`FMMTraversalInfo` with the "close" lists merged
+        into list 1 and set to *None* (traversal.py:1650-1693)."""
         import torch
-
-        def host(a):
-            return a.cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
-
-        starts = [host(s) for s in (self.neighbor_source_boxes_starts,
-                                    self.from_sep_close_smaller_starts,
-                                    self.from_sep_close_bigger_starts)]
-        lists = [host(s) for s in (self.neighbor_source_boxes_lists,
-                                   self.from_sep_close_smaller_lists,
-                                   self.from_sep_close_bigger_lists)]
-        n = len(starts[0]) - 1
-        counts = sum(np.diff(s) for s in starts)
-        new_starts = np.zeros(n + 1, np.int32)
-        np.cumsum(counts, out=new_starts[1:])
-        new_lists = np.empty(int(new_starts[-1]), np.int32)
-        cur = new_starts[:-1].astype(np.int64).copy()
-        for s, lst in zip(starts, lists):
-            cnt = np.diff(s)
-            owner = np.repeat(np.arange(n), cnt)
-            within = np.arange(len(lst)) - np.repeat(s[:-1], cnt)
-            new_lists[cur[owner] + within] = lst
-            cur += cnt
-        conv = actx.from_numpy if isinstance(self.neighbor_source_boxes_starts,
-                                             torch.Tensor) else (lambda x: x)
+        starts = [self.neighbor_source_boxes_starts, self.from_sep_close_smaller_starts,
+                  self.from_sep_close_bigger_starts]
+        lists = [self.neighbor_source_boxes_lists, self.from_sep_close_smaller_lists,
+                 self.from_sep_close_bigger_lists]
+        on_host = not isinstance(starts[0], torch.Tensor)
+        dstarts = [actx.from_numpy(np.ascontiguousarray(a)) if on_host else a.contiguous()
+                   for a in starts]
+        dlists = [actx.from_numpy(np.ascontiguousarray(a)) if on_host else a.contiguous()
+                  for a in lists]
+        nrows = len(dstarts[0]) - 1
+        total = sum(len(x) for x in dlists)
+        new_starts = actx.empty(nrows + 1, np.int32)
+        new_lists = actx.empty(total, np.int32)
+        sp = (ct.c_void_p * 3)(*[x.data_ptr() for x in dstarts])
+        lp = (ct.c_void_p * 3)(*[x.data_ptr() for x in dlists])
+        actx.sync_in()
+        _lib.check(actx.lib.bt_merge_csr_lists(
+            actx.handle, 3, sp, lp, nrows, ptr(new_starts), ptr(new_lists)))
+        if on_host:
+            new_starts, new_lists = actx.to_numpy(new_starts), actx.to_numpy(new_lists)
         return dataclasses.replace(
             self,
-            neighbor_source_boxes_starts=conv(new_starts),
-            neighbor_source_boxes_lists=conv(new_lists),
+            neighbor_source_boxes_starts=new_starts,
+            neighbor_source_boxes_lists=new_lists,
             from_sep_close_smaller_starts=None,
             from_sep_close_smaller_lists=None,
             from_sep_close_bigger_starts=None,

@@ -241,6 +241,14 @@ typedef struct {
 
 int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *out);
 
+/* Row-wise concatenation of up to 4 CSR lists with equal row count
+ * (FMMTraversalInfo.merge_close_lists, traversal.py:1650-1693 / _ListMerger
+ * :1222-1344): out row i = lists[0] row i ++ lists[1] row i ++ ...  out_starts has
+ * nrows+1 entries; out_lists must hold the sum of the input list lengths. */
+int bt_merge_csr_lists(bt_context *ctx, int nlists, const int32_t *const *starts,
+                       const int32_t *const *lists, int64_t nrows, int32_t *out_starts,
+                       int32_t *out_lists);
+
 /* ---- multi-GPU exchange helpers (no counterpart in the reference, which never
  *      builds the tree in parallel: boxtree/distributed/__init__.py:183-199) ---- */
 

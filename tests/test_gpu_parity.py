@@ -382,3 +382,33 @@ def test_shard_kernels_match_torch_routing(actx, dims, level):
     _lib.check(actx.lib.bt_gather(actx.handle, 8, ct.c_void_p(pts[0].data_ptr()),
                                   ct.c_void_p(perm.data_ptr()), n, ct.c_void_p(out.data_ptr())))
     assert bool((out == pts[0][ref_perm]).all())
+
+
+def test_merge_close_lists(actx, oracle):
+    # traversal.py:1650-1693; consumer: test_fmm.py:231-233
+    s = normal_particles(3 * 10**4, 3, np.float64, seed=15)
+    t = normal_particles(10**4, 3, np.float64, seed=16)
+    tr = 2**np.random.default_rng(12).uniform(-10, 0, (10**4,))
+    from boxtree_amd import FMMTraversalBuilder, TreeBuilder
+    tree, _ = TreeBuilder(actx)(actx, [actx.from_numpy(a) for a in s],
+                                targets=[actx.from_numpy(a) for a in t],
+                                target_radii=actx.from_numpy(tr), stick_out_factor=0.25,
+                                max_particles_in_box=30)
+    trav, _ = FMMTraversalBuilder(actx)(actx, tree)
+    merged = actx.to_numpy(trav.merge_close_lists(actx))
+    h = actx.to_numpy(trav)
+    assert merged.from_sep_close_smaller_starts is None
+    n = len(h.target_boxes)
+    for i in range(0, n, max(1, n // 500)):
+        exp = np.concatenate([
+            h.neighbor_source_boxes_lists[h.neighbor_source_boxes_starts[i]:
+                                          h.neighbor_source_boxes_starts[i + 1]],
+            h.from_sep_close_smaller_lists[h.from_sep_close_smaller_starts[i]:
+                                           h.from_sep_close_smaller_starts[i + 1]],
+            h.from_sep_close_bigger_lists[h.from_sep_close_bigger_starts[i]:
+                                          h.from_sep_close_bigger_starts[i + 1]]])
+        got = merged.neighbor_source_boxes_lists[merged.neighbor_source_boxes_starts[i]:
+                                                 merged.neighbor_source_boxes_starts[i + 1]]
+        assert np.array_equal(exp, got)
+    pot = constant_one_potentials(actx.to_numpy(tree), merged)
+    assert np.all(pot == 3 * 10**4)
