@@ -284,7 +284,8 @@ struct NoL1 {
 // boxes this walk descends through).
 template <class T, int D, class EM, class EC, class E1>
 __device__ __forceinline__ void gen_list3(const TravArgs<T, D> &a, int32_t tbn, EM &emit_main,
-                                          EC &emit_close, E1 &emit_l1)
+                                          EC &emit_close, E1 &emit_l1,
+                                          int32_t coll_first = 0, int32_t coll_count = -1)
 {
     constexpr int C = 1 << D;
     const int32_t tgt = a.target_boxes[tbn];
@@ -310,7 +311,11 @@ __device__ __forceinline__ void gen_list3(const TravArgs<T, D> &a, int32_t tbn, 
         }
     }
 
-    const int32_t s0 = a.coll_starts[tgt], s1 = a.coll_starts[tgt + 1];
+    int32_t s0 = a.coll_starts[tgt], s1 = a.coll_starts[tgt + 1];
+    if (coll_count >= 0) {          // only colleagues [coll_first, coll_first + coll_count)
+        s0 += coll_first;
+        s1 = (s0 + coll_count < s1) ? s0 + coll_count : s1;
+    }
     for (int32_t i = s0; i < s1; ++i) {
         const int32_t nws = a.coll_lists[i];
         if (nws == tgt) continue;
@@ -948,45 +953,80 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             a, (int32_t) B, lcoll_starts.get(), lcoll_lists.get());
     }
 
-    // lists 1 and 3 (+ close smaller) in one walk per target box
+    // lists 1 and 3 (+ close smaller) in one walk per work item
     {
         const int64_t ntb = st->ntb;
-        const int64_t nflat = (int64_t) nlevels * ntb;
+        // work items: heavy target boxes (far above the leaf level) get one item per
+        // colleague, see make_items_kernel
+        const int heavy_max_level = nlevels - 4;
+        Buf<int32_t> first_item, item_tbn, item_slot;
+        BT_CHECK(first_item.alloc(ctx->pool, ntb + 1));
+        make_items_kernel<T, D, false><<<nblk(ntb), 256, 0, ctx->stream>>>(
+            a, (int32_t) ntb, heavy_max_level, first_item.get(), nullptr, nullptr);
+        int64_t nitems = 0;
+        BT_CHECK(counts_to_starts(ctx, first_item, ntb, &nitems));
+        BT_CHECK(item_tbn.alloc(ctx->pool, nitems));
+        BT_CHECK(item_slot.alloc(ctx->pool, nitems));
+        make_items_kernel<T, D, true><<<nblk(ntb), 256, 0, ctx->stream>>>(
+            a, (int32_t) ntb, heavy_max_level, first_item.get(), item_tbn.get(), item_slot.get());
+
+        const int64_t nflat = (int64_t) nlevels * nitems;
         if (nflat >= ((int64_t) 1 << 31)) {
             set_error("list 3 bookkeeping exceeds int32 range");
             return BT_ERR_UNSUPPORTED;
         }
+        Buf<int32_t> l1_item, l3_item, close_item;
+        BT_CHECK(l1_item.alloc(ctx->pool, nitems + 1));
+        BT_CHECK(l3_item.alloc(ctx->pool, nflat + 1));
+        if (st->with_extent) BT_CHECK(close_item.alloc(ctx->pool, nitems + 1));
+        list13_kernel<T, D, false><<<nblk(nitems), 256, walk_lds + lvl_lds, ctx->stream>>>(
+            a, ft, lcoll_starts.get(), lcoll_lists.get(), item_tbn.get(), item_slot.get(),
+            (int32_t) nitems, nlevels, walk_cap, l1_item.get(), nullptr, l3_item.get(), nullptr,
+            st->with_extent ? close_item.get() : nullptr, nullptr);
+
         CsrList &c1 = st->l1;
         c1.n = ntb;
+        CsrList &cs = st->close_smaller;
+        cs.n = ntb;
+        int64_t total3 = 0;
+        BT_CHECK(counts_to_starts(ctx, l1_item, nitems, &c1.total));
+        BT_CHECK(counts_to_starts(ctx, l3_item, nflat, &total3));
+        BT_CHECK(c1.lists.alloc(ctx->pool, c1.total));
+        BT_CHECK(st->l3_lists.alloc(ctx->pool, total3));
+        if (st->with_extent) {
+            BT_CHECK(counts_to_starts(ctx, close_item, nitems, &cs.total));
+            BT_CHECK(cs.lists.alloc(ctx->pool, cs.total));
+        }
+        list13_kernel<T, D, true><<<nblk(nitems), 256, walk_lds + lvl_lds, ctx->stream>>>(
+            a, ft, lcoll_starts.get(), lcoll_lists.get(), item_tbn.get(), item_slot.get(),
+            (int32_t) nitems, nlevels, walk_cap, l1_item.get(), c1.lists.get(), l3_item.get(),
+            st->l3_lists.get(), st->with_extent ? close_item.get() : nullptr,
+            st->with_extent ? cs.lists.get() : nullptr);
+
+        // per-box starts from the per-item starts (items of a box are consecutive)
         BT_CHECK(c1.starts.alloc(ctx->pool, ntb + 1));
-        BT_CHECK(st->l3_starts.alloc(ctx->pool, nflat + 1));
-        // at most one block-copy job per target box that has children
+        gather_starts_kernel<<<nblk(ntb + 1), 256, 0, ctx->stream>>>(
+            (int32_t) ntb, first_item.get(), l1_item.get(), (int32_t) c1.total, c1.starts.get());
+        if (st->with_extent) {
+            BT_CHECK(cs.starts.alloc(ctx->pool, ntb + 1));
+            gather_starts_kernel<<<nblk(ntb + 1), 256, 0, ctx->stream>>>(
+                (int32_t) ntb, first_item.get(), close_item.get(), (int32_t) cs.total,
+                cs.starts.get());
+        }
+        const int64_t nflat_box = (int64_t) nlevels * ntb;
+        BT_CHECK(st->l3_starts.alloc(ctx->pool, nflat_box + 1));
+        l3_box_starts_kernel<<<nblk(nflat_box + 1), 256, 0, ctx->stream>>>(
+            nflat_box, (int32_t) ntb, (int32_t) nitems, nlevels, first_item.get(), l3_item.get(),
+            st->l3_starts.get());
+
+        // list 1: order by depth-first rank, insert the own-subtree blocks
         Buf<int32_t> jobbuf;
         BT_CHECK(jobbuf.alloc(ctx->pool, 3 * ntb + 1));
         BlockJobs jobs{jobbuf.get(), jobbuf.get() + 1, jobbuf.get() + 1 + ntb,
                        jobbuf.get() + 1 + 2 * ntb};
         BT_HIP_CHECK(hipMemsetAsync(jobbuf.get(), 0, 4, ctx->stream));
-        CsrList &cs = st->close_smaller;
-        cs.n = ntb;
-        if (st->with_extent) BT_CHECK(cs.starts.alloc(ctx->pool, ntb + 1));
-        list13_kernel<T, D, false><<<nblk(ntb), 256, walk_lds + lvl_lds, ctx->stream>>>(
-            a, ft, lcoll_starts.get(), lcoll_lists.get(), (int32_t) ntb, nlevels, walk_cap, jobs,
-            c1.starts.get(), nullptr, st->l3_starts.get(), nullptr,
-            st->with_extent ? cs.starts.get() : nullptr, nullptr);
-        int64_t total3 = 0;
-        BT_CHECK(counts_to_starts(ctx, c1.starts, ntb, &c1.total));
-        BT_CHECK(counts_to_starts(ctx, st->l3_starts, nflat, &total3));
-        BT_CHECK(c1.lists.alloc(ctx->pool, c1.total));
-        BT_CHECK(st->l3_lists.alloc(ctx->pool, total3));
-        if (st->with_extent) {
-            BT_CHECK(counts_to_starts(ctx, cs.starts, ntb, &cs.total));
-            BT_CHECK(cs.lists.alloc(ctx->pool, cs.total));
-        }
-        list13_kernel<T, D, true><<<nblk(ntb), 256, walk_lds + lvl_lds, ctx->stream>>>(
-            a, ft, lcoll_starts.get(), lcoll_lists.get(), (int32_t) ntb, nlevels, walk_cap, jobs,
-            c1.starts.get(), c1.lists.get(), st->l3_starts.get(), st->l3_lists.get(),
-            st->with_extent ? cs.starts.get() : nullptr,
-            st->with_extent ? cs.lists.get() : nullptr);
+        l1_finalize_kernel<T, D><<<nblk(ntb), 256, 0, ctx->stream>>>(
+            a, ft, (int32_t) ntb, c1.starts.get(), c1.lists.get(), jobs);
         int32_t njobs = 0;
         BT_CHECK(read_i32(ctx, jobs.count, &njobs));
         if (njobs > 0)

@@ -398,84 +398,152 @@ struct L1Emit {
     }
 };
 
+// Work items.  A target box far above the leaf level has long lists and one thread
+// walking all of its colleagues' subtrees is a serial tail (2.7 ms at 1e8 points);
+// such "heavy" boxes are split into one item per colleague (+ one for the box
+// itself and its coarser neighbours).  Items of a box are consecutive, so the
+// per-item output segments concatenate to the box's lists in colleague order.
+constexpr int SLOT_ALL = -1, SLOT_SELF = -2;
+
 template <class T, int D, bool FILL>
-__global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree ft,
-        const int32_t *lcoll_starts, const int32_t *lcoll_lists, int32_t ntb, int nlevels,
-        int walk_cap, BlockJobs jobs, int32_t *l1_cs, int32_t *l1_lists,
-        int32_t *l3_cs, int32_t *l3_lists, int32_t *close_cs, int32_t *close_lists)
+__global__ __launch_bounds__(256) void make_items_kernel(TravArgs<T, D> a, int32_t ntb,
+        int heavy_max_level, int32_t *cnt_or_first, int32_t *item_tbn, int32_t *item_slot)
 {
     const int32_t tbn = blockIdx.x * 256 + threadIdx.x;
     if (tbn >= ntb) return;
+    const int32_t b = a.target_boxes[tbn];
+    const int32_t ncoll = a.coll_starts[b + 1] - a.coll_starts[b];
+    const bool heavy = box_level(a, b) <= heavy_max_level && ncoll > 1;
+    if (!FILL) {
+        cnt_or_first[tbn] = heavy ? ncoll + 1 : 1;
+    } else {
+        int32_t it = cnt_or_first[tbn];
+        if (!heavy) {
+            item_tbn[it] = tbn; item_slot[it] = SLOT_ALL;
+        } else {
+            item_tbn[it] = tbn; item_slot[it] = SLOT_SELF;
+            for (int32_t k = 0; k < ncoll; ++k) { item_tbn[it + 1 + k] = tbn; item_slot[it + 1 + k] = k; }
+        }
+    }
+}
+
+template <class T, int D, bool FILL>
+__global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree ft,
+        const int32_t *lcoll_starts, const int32_t *lcoll_lists,
+        const int32_t *item_tbn, const int32_t *item_slot, int32_t nitems, int nlevels,
+        int walk_cap, int32_t *l1_cs, int32_t *l1_lists,
+        int32_t *l3_cs, int32_t *l3_lists, int32_t *close_cs, int32_t *close_lists)
+{
+    const int32_t item = blockIdx.x * 256 + threadIdx.x;
+    if (item >= nitems) return;
+    const int32_t tbn = item_tbn[item];
+    const int slot = item_slot[item];
     const int32_t b = a.target_boxes[tbn];
     T center[D];
     load_center(a, b, center);
     const int level = box_level(a, b);
 
-    L1Emit e1{ft.dfs_rank, FILL ? l1_lists + l1_cs[tbn] : nullptr, 0};
+    L1Emit e1{ft.dfs_rank, FILL ? l1_lists + l1_cs[item] : nullptr, 0};
 
-    if (box_flags(a, 0) & BT_BOX_IS_SOURCE_BOX) e1(0);           // traversal.py:489-495
-
-    // b itself; the sources inside b (target boxes with children: extents only) are a
-    // contiguous block of preorder ranks, accounted for here and copied separately
-    if (level >= 1) {
-        const uint8_t fl = box_flags(a, b);
-        if (fl & BT_BOX_IS_SOURCE_BOX) e1(b);
+    int32_t blk_len = 0;
+    if (slot < 0) {
+        if (box_flags(a, 0) & BT_BOX_IS_SOURCE_BOX) e1(0);       // traversal.py:489-495
+        // b itself; the sources inside b (target boxes with children: extents only) are
+        // a contiguous block of preorder ranks: space is reserved here, the entries are
+        // written by l1_finalize_kernel / copy_rank_blocks_kernel
+        if (level >= 1 && (box_flags(a, b) & BT_BOX_IS_SOURCE_BOX)) e1(b);
+        // coarser levels: source-box colleagues of the ancestors, and the ancestors
+        if (level >= 2) {
+            int32_t anc = a.parent[b];
+            for (int k = level - 1; k >= 1; --k, anc = a.parent[anc]) {
+                if (box_flags(a, anc) & BT_BOX_IS_SOURCE_BOX) e1(anc);
+                const int32_t s0 = lcoll_starts[anc], s1 = lcoll_starts[anc + 1];
+                for (int32_t i = s0; i < s1; ++i) {
+                    const int32_t u = lcoll_lists[i];
+                    T uc[D];
+                    load_center(a, u, uc);
+                    if (adj<T, D>(a.root_extent, center, level, uc, k)) e1(u);
+                }
+            }
+        }
     }
+
+    // the box's LAST item reserves the space of the own-subtree block at the end of
+    // the box's list-1 segment
+    {
+        const int32_t ncoll = a.coll_starts[b + 1] - a.coll_starts[b];
+        const bool last_item = slot == SLOT_ALL || slot == ncoll - 1;
+        if (last_item && (box_flags(a, b) & BT_BOX_HAS_SOURCE_CHILD_BOXES)) {
+            const int32_t my_rank = ft.dfs_rank[b];
+            blk_len = ft.src_prefix[my_rank + ft.subtree_size[b]] - ft.src_prefix[my_rank + 1];
+        }
+    }
+
+    // colleagues and everything below them: list 3 walk, which also yields the
+    // list-1 boxes at the colleagues' level and finer
+    const int32_t cfirst = slot >= 0 ? slot : 0;
+    const int32_t ccount = slot >= 0 ? 1 : (slot == SLOT_SELF ? 0 : -1);
+    int32_t *lvl = s_walk_lds + walk_cap * WALK_THREADS + threadIdx.x;
+    if (!FILL) {
+        L3CountMain em{lvl};
+        for (int l = 0; l < nlevels; ++l) lvl[l * WALK_THREADS] = 0;
+        CountEmit ec;
+        gen_list3<T, D>(a, tbn, em, ec, e1, cfirst, ccount);
+        for (int l = 0; l < nlevels; ++l)
+            l3_cs[(int64_t) l * nitems + item] = lvl[l * WALK_THREADS];
+        if (close_cs) close_cs[item] = ec.n;
+        l1_cs[item] = e1.n + blk_len;
+    } else {
+        L3WriteMain em{l3_lists, lvl};
+        for (int l = 0; l < nlevels; ++l)
+            lvl[l * WALK_THREADS] = l3_cs[(int64_t) l * nitems + item];
+        WriteEmit ec{close_lists ? close_lists + close_cs[item] : nullptr};
+        CountEmit dummy;
+        if (close_lists) gen_list3<T, D>(a, tbn, em, ec, e1, cfirst, ccount);
+        else gen_list3<T, D>(a, tbn, em, dummy, e1, cfirst, ccount);
+    }
+}
+
+// one thread per target box: order list 1 by depth-first rank (the items wrote ranks),
+// open the gap for the own-subtree block and turn ranks into box ids
+template <class T, int D>
+__global__ __launch_bounds__(256) void l1_finalize_kernel(TravArgs<T, D> a, FastTree ft,
+        int32_t ntb, const int32_t *l1_starts, int32_t *l1_lists, BlockJobs jobs)
+{
+    const int32_t tbn = blockIdx.x * 256 + threadIdx.x;
+    if (tbn >= ntb) return;
+    const int32_t b = a.target_boxes[tbn];
+    int32_t *out = l1_lists + l1_starts[tbn];
+    const int32_t n_all = l1_starts[tbn + 1] - l1_starts[tbn];
     int32_t blk_len = 0, blk_src = 0;
     const int32_t my_rank = ft.dfs_rank[b];
     if (box_flags(a, b) & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
         blk_src = ft.src_prefix[my_rank + 1];
         blk_len = ft.src_prefix[my_rank + ft.subtree_size[b]] - blk_src;
     }
-
-    // coarser levels: source-box colleagues of the ancestors, and the ancestors
-    if (level >= 2) {
-        int32_t anc = a.parent[b];
-        for (int k = level - 1; k >= 1; --k, anc = a.parent[anc]) {
-            if (box_flags(a, anc) & BT_BOX_IS_SOURCE_BOX) e1(anc);
-            const int32_t s0 = lcoll_starts[anc], s1 = lcoll_starts[anc + 1];
-            for (int32_t i = s0; i < s1; ++i) {
-                const int32_t u = lcoll_lists[i];
-                T uc[D];
-                load_center(a, u, uc);
-                if (adj<T, D>(a.root_extent, center, level, uc, k)) e1(u);
-            }
-        }
+    const int32_t n = n_all - blk_len;              // the ranks; the reserved space follows
+    sort_i32_inplace(out, n);                       // depth-first preorder
+    int32_t k = n;
+    if (blk_len > 0) {
+        k = 0;
+        while (k < n && out[k] <= my_rank) ++k;
+        for (int32_t i = n - 1; i >= k; --i) out[i + blk_len] = ft.box_of_rank[out[i]];
+        const int32_t j = atomicAdd(jobs.count, 1);
+        jobs.dst[j] = l1_starts[tbn] + k;
+        jobs.src[j] = blk_src;
+        jobs.len[j] = blk_len;
     }
+    for (int32_t i = 0; i < k; ++i) out[i] = ft.box_of_rank[out[i]];
+}
 
-    // colleagues and everything below them: list 3 walk, which also yields the
-    // list-1 boxes at the colleagues' level and finer
-    int32_t *lvl = s_walk_lds + walk_cap * WALK_THREADS + threadIdx.x;
-    if (!FILL) {
-        L3CountMain em{lvl};
-        for (int l = 0; l < nlevels; ++l) lvl[l * WALK_THREADS] = 0;
-        CountEmit ec;
-        gen_list3<T, D>(a, tbn, em, ec, e1);
-        for (int l = 0; l < nlevels; ++l) l3_cs[(int64_t) l * ntb + tbn] = lvl[l * WALK_THREADS];
-        if (close_cs) close_cs[tbn] = ec.n;
-        l1_cs[tbn] = e1.n + blk_len;
-    } else {
-        L3WriteMain em{l3_lists, lvl};
-        for (int l = 0; l < nlevels; ++l) lvl[l * WALK_THREADS] = l3_cs[(int64_t) l * ntb + tbn];
-        WriteEmit ec{close_lists ? close_lists + close_cs[tbn] : nullptr};
-        CountEmit dummy;
-        if (close_lists) gen_list3<T, D>(a, tbn, em, ec, e1);
-        else gen_list3<T, D>(a, tbn, em, dummy, e1);
-        sort_i32_inplace(e1.out, e1.n);                 // depth-first preorder
-        int32_t k = e1.n;
-        if (blk_len > 0) {
-            // entries with rank <= rank(b) stay, the rest moves behind the block
-            k = 0;
-            while (k < e1.n && e1.out[k] <= my_rank) ++k;
-            for (int i = e1.n - 1; i >= k; --i)
-                e1.out[i + blk_len] = ft.box_of_rank[e1.out[i]];
-            const int32_t j = atomicAdd(jobs.count, 1);
-            jobs.dst[j] = (int32_t) (e1.out - l1_lists) + k;
-            jobs.src[j] = blk_src;
-            jobs.len[j] = blk_len;
-        } else {
-            for (int i = k; i < e1.n; ++i) e1.out[i] = ft.box_of_rank[e1.out[i]];
-        }
-        for (int i = 0; i < k && i < e1.n; ++i) e1.out[i] = ft.box_of_rank[e1.out[i]];
-    }
+// l3 bookkeeping per (level, target box) from the per-(level, item) starts
+__global__ __launch_bounds__(256) void l3_box_starts_kernel(int64_t nflat_box, int32_t ntb,
+        int32_t nitems, int nlevels, const int32_t *first_item, const int32_t *item_starts,
+        int32_t *box_starts)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i > nflat_box) return;
+    if (i == nflat_box) { box_starts[i] = item_starts[(int64_t) nlevels * nitems]; return; }
+    const int64_t lev = i / ntb, tbn = i % ntb;
+    box_starts[i] = item_starts[lev * nitems + first_item[tbn]];
 }
