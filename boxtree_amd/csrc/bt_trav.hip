@@ -10,6 +10,7 @@
 #include "bt_prims.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <vector>
 
 using namespace bt;
@@ -958,7 +959,11 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         const int64_t ntb = st->ntb;
         // work items: heavy target boxes (far above the leaf level) get one item per
         // colleague, see make_items_kernel
-        const int heavy_max_level = nlevels - 4;
+        static const int heavy_margin = [] {
+            const char *e = getenv("BT_HEAVY_MARGIN");      // tuning aid
+            return e ? atoi(e) : 3;
+        }();
+        const int heavy_max_level = nlevels - heavy_margin;
         Buf<int32_t> first_item, item_tbn, item_slot;
         BT_CHECK(first_item.alloc(ctx->pool, ntb + 1));
         make_items_kernel<T, D, false><<<nblk(ntb), 256, 0, ctx->stream>>>(

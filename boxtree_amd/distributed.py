@@ -115,7 +115,7 @@ def partition_cells(global_hist, world):
 def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
                        top_level=None, return_plan=False):
     """Steps 1-4.  Returns ``(particles, targets, build_kw, stats)`` for the local
-    ``TreeBuilder`` call; ``build_kw`` gains ``bbox=`` (the global root box) and
+    ``TreeBuilder`` call; ``build_kw`` gains ``_root_box=`` (the global root box) and
     the exchanged ``target_radii`` if present."""
     import torch
     build_kw = dict(build_kw or {})
@@ -251,8 +251,10 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         if target_radii is not None:
             build_kw["target_radii"] = extra[0]
 
-    build_kw["bbox"] = np.array(
-        [[bbox_min[i], bbox_max[i]] for i in range(dims)], dtype=bbox_min.dtype)
+    # hand the agreed root box to TreeBuilder verbatim (the public ``bbox=`` path
+    # re-derives root_extent from max-min and asserts squareness to 1e-15, which a
+    # rounded ``min + extent`` need not satisfy)
+    build_kw["_root_box"] = (bbox_min, bbox_max, root_extent)
     if return_plan:
         stats["owner"] = owner
         stats["bbox_min"], stats["bbox_max"] = bbox_min, bbox_max

@@ -200,7 +200,21 @@ class TreeBuilder:
                 bbox_auto[f"min_{ax}"] = min(bbox_auto[f"min_{ax}"], bbox_t[f"min_{ax}"])
                 bbox_auto[f"max_{ax}"] = max(bbox_auto[f"max_{ax}"], bbox_t[f"max_{ax}"])
 
-        if bbox is None:
+        root_box = kwargs.get("_root_box")
+        if root_box is not None:
+            # (bbox_min, bbox_max, root_extent) agreed on by all ranks of a sharded
+            # build (boxtree_amd/distributed.py): already the result of the host
+            # arithmetic below on the GLOBAL bounding box, used verbatim
+            bbox_min = np.array(root_box[0], dtype=coord_dtype)
+            bbox_max = np.array(root_box[1], dtype=coord_dtype)
+            root_extent = coord_dtype.type(root_box[2])
+            bbox = bbox_auto.copy()
+            for i, ax in enumerate(axis_names):
+                assert bbox_min[i] <= bbox_auto[f"min_{ax}"]
+                assert bbox_max[i] > bbox_auto[f"max_{ax}"]
+                bbox[f"min_{ax}"] = bbox_min[i]
+                bbox[f"max_{ax}"] = bbox_max[i]
+        elif bbox is None:
             bbox = bbox_auto.copy()
             root_extent = max(
                 bbox[f"max_{ax}"] - bbox[f"min_{ax}"]

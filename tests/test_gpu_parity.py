@@ -412,3 +412,46 @@ def test_merge_close_lists(actx, oracle):
         assert np.array_equal(exp, got)
     pot = constant_one_potentials(actx.to_numpy(tree), merged)
     assert np.all(pot == 3 * 10**4)
+
+
+def test_sharded_build_union_equals_global_tree(actx):
+    """What the N-GPU build relies on (distributed.py step 5): with the global root
+    box, the trees built per owner over contiguous Morton ranges of heavy top-level
+    cells are exactly the global tree restricted to those cells."""
+    import torch
+    from boxtree_amd import TreeBuilder
+    from boxtree_amd.distributed import ROOT_EXTENT_STRETCH_FACTOR, morton_cells, partition_cells
+    rng = np.random.default_rng(7)
+    n, world, level = 400000, 4, 3
+    pts = [torch.from_numpy(rng.random(n)).cuda() for _ in range(3)]
+    gmin = np.array([float(p.min()) for p in pts])
+    gmax = np.array([float(p.max()) for p in pts])
+    root_extent = max(gmax - gmin) * (1 + ROOT_EXTENT_STRETCH_FACTOR)
+    bbox_min = gmin.copy()
+    bbox_max = bbox_min + root_extent
+    cells = morton_cells(pts, bbox_min, bbox_max, level)
+    hist = torch.bincount(cells, minlength=1 << (3 * level)).cpu().numpy()
+    owner = torch.from_numpy(partition_cells(hist, world)).cuda()[cells]
+    tb = TreeBuilder(actx)
+
+    def leaves(tree):
+        t = actx.to_numpy(tree)
+        nb = t.nboxes
+        leaf = (t.box_child_ids[:, :nb] == 0).all(axis=0)
+        rows = np.concatenate([t.box_levels[leaf][None, :].astype(np.float64),
+                               t.box_centers[:, :nb][:, leaf],
+                               t.box_source_counts_cumul[leaf][None, :].astype(np.float64)])
+        rows = rows.T
+        return rows[np.lexsort(rows.T[::-1])]
+
+    gtree, _ = tb(actx, pts, max_particles_in_box=30)
+    parts = []
+    for r in range(world):
+        m = owner == r
+        sub = [p[m].contiguous() for p in pts]
+        tree, _ = tb(actx, sub, max_particles_in_box=30,
+                     _root_box=(bbox_min, bbox_max, root_extent))
+        parts.append(leaves(tree))
+    union = np.concatenate(parts)
+    union = union[np.lexsort(union.T[::-1])]
+    assert np.array_equal(union, leaves(gtree))
