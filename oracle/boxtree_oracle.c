@@ -16,6 +16,7 @@
 #define COORD_MAX DBL_MAX
 #include "boxtree_oracle_impl.h"
 #include "boxtree_oracle_trav_impl.h"
+#include "boxtree_oracle_aq_impl.h"
 #undef COORD_T
 #undef SFX
 #undef COORD_SQRT
@@ -29,6 +30,7 @@
 #define COORD_MAX FLT_MAX
 #include "boxtree_oracle_impl.h"
 #include "boxtree_oracle_trav_impl.h"
+#include "boxtree_oracle_aq_impl.h"
 #undef COORD_T
 #undef SFX
 #undef COORD_SQRT

@@ -149,8 +149,17 @@ def _make_structs(cf):
             ("from_sep_close_bigger", BuiltListC),
         ]
 
+    class AqTree(ct.Structure):
+        _fields_ = [
+            ("dims", ct.c_int32), ("nlevels", ct.c_int32),
+            ("nboxes", ct.c_int64), ("aligned_nboxes", ct.c_int64),
+            ("root_extent", cf), ("bbox_min", cf * MAXDIM),
+            ("box_centers", P(cf)), ("box_levels", P(ct.c_uint8)),
+            ("box_child_ids", P(ct.c_int32)), ("box_flags", P(ct.c_uint8)),
+        ]
+
     return SimpleNamespace(TreeIn=TreeIn, TreeOut=TreeOut, BuiltListC=BuiltListC,
-                           TravIn=TravIn, TravOut=TravOut)
+                           TravIn=TravIn, TravOut=TravOut, AqTree=AqTree)
 
 
 _STRUCTS = {}
@@ -631,6 +640,115 @@ def build_traversal(tree, well_sep_is_n_away=1, from_sep_smaller_crit=None,
     r.ntarget_boxes = len(r.target_boxes)
     r.ntarget_or_target_parent_boxes = len(r.target_or_target_parent_boxes)
     return r
+
+# }}}
+
+
+# {{{ area queries (boxtree/area_query.py)
+
+def _aq_tree(tree, keep):
+    coord_dtype = np.dtype(tree.coord_dtype)
+    S = _structs(coord_dtype)
+    cf = _ctype(coord_dtype)
+
+    def c(arr, dtype):
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        keep.append(a)
+        return a
+
+    t = S.AqTree()
+    t.dims = tree.dimensions
+    t.nlevels = int(tree.nlevels)
+    t.nboxes = tree.nboxes
+    t.aligned_nboxes = tree.aligned_nboxes
+    t.root_extent = float(coord_dtype.type(tree.root_extent))
+    for d in range(tree.dimensions):
+        t.bbox_min[d] = float(coord_dtype.type(tree.bounding_box[0][d]))
+    t.box_centers = _ptr(c(tree.box_centers, coord_dtype), cf)
+    t.box_levels = _ptr(c(tree.box_levels, np.uint8), ct.c_uint8)
+    t.box_child_ids = _ptr(c(tree.box_child_ids, np.int32), ct.c_int32)
+    t.box_flags = _ptr(c(tree.box_flags, np.uint8), ct.c_uint8)
+    return t
+
+
+def peer_lists(tree):
+    """PeerListFinder.__call__ (area_query.py:1152-1192) -> PeerListLookup fields."""
+    keep = []
+    t = _aq_tree(tree, keep)
+    S = _structs(tree.coord_dtype)
+    bl = S.BuiltListC()
+    fn = getattr(_lib(), "orc_peer_lists" + _sfx(tree.coord_dtype))
+    fn.restype = ct.c_int
+    if fn(ct.byref(t), ct.byref(bl)) != 0:
+        raise RuntimeError("oracle peer list build failed")
+    r = _built_list(bl)
+    return SimpleNamespace(tree=tree, peer_list_starts=r.starts, peer_lists=r.lists)
+
+
+def _check_balls(tree, ball_centers, ball_radii):
+    # area_query.py:764-768
+    dts = {np.dtype(bc.dtype) for bc in ball_centers}
+    if len(dts) != 1 or dts.pop() != np.dtype(tree.coord_dtype):
+        raise TypeError("ball_centers dtype must match tree.coord_dtype")
+    if np.dtype(ball_radii.dtype) != np.dtype(tree.coord_dtype):
+        raise TypeError("ball_radii dtype must match tree.coord_dtype")
+
+
+def _aq_call(name, tree, ball_centers, ball_radii, pl, out):
+    _check_balls(tree, ball_centers, ball_radii)
+    if pl is None:
+        pl = peer_lists(tree)
+    if len(pl.peer_list_starts) != tree.nboxes + 1:                 # :781-782
+        raise ValueError("size of peer lists must match with number of boxes")
+    keep = []
+    t = _aq_tree(tree, keep)
+    cf = _ctype(tree.coord_dtype)
+    bcs = [np.ascontiguousarray(bc) for bc in ball_centers]
+    radii = np.ascontiguousarray(ball_radii)
+    arr = (ct.POINTER(cf) * len(bcs))(*[_ptr(b, cf) for b in bcs])
+    starts = np.ascontiguousarray(pl.peer_list_starts, np.int32)
+    lists = np.ascontiguousarray(pl.peer_lists, np.int32)
+    fn = getattr(_lib(), name + _sfx(tree.coord_dtype))
+    fn.restype = ct.c_int
+    st = fn(ct.byref(t), _ptr(starts, ct.c_int32), _ptr(lists, ct.c_int32),
+            ct.c_int64(len(radii)), arr, _ptr(radii, cf), out)
+    if st != 0:
+        raise RuntimeError(f"oracle {name} failed")
+
+
+def area_query(tree, ball_centers, ball_radii, peer_lists=None):
+    """AreaQueryBuilder.__call__ (area_query.py:744-812)."""
+    S = _structs(tree.coord_dtype)
+    bl = S.BuiltListC()
+    _aq_call("orc_area_query", tree, ball_centers, ball_radii, peer_lists, ct.byref(bl))
+    r = _built_list(bl)
+    return SimpleNamespace(tree=tree, leaves_near_ball_starts=r.starts,
+                           leaves_near_ball_lists=r.lists)
+
+
+def leaves_to_balls(tree, ball_centers, ball_radii, peer_lists=None):
+    """LeavesToBallsLookupBuilder.__call__ (area_query.py:847-924): expand the
+    starts into ball numbers, stable key-value sort by box number."""
+    aq = area_query(tree, ball_centers, ball_radii, peer_lists)
+    nballs = len(ball_radii)
+    expanded = np.repeat(np.arange(nballs, dtype=np.int32),
+                         np.diff(aq.leaves_near_ball_starts))
+    order = np.argsort(aq.leaves_near_ball_lists, kind="stable")
+    lists = expanded[order].astype(np.int32)
+    counts = np.bincount(aq.leaves_near_ball_lists, minlength=tree.nboxes)
+    starts = np.zeros(tree.nboxes + 1, np.int32)
+    starts[1:] = np.cumsum(counts)
+    return SimpleNamespace(tree=tree, balls_near_box_starts=starts,
+                           balls_near_box_lists=lists)
+
+
+def space_invader_query(tree, ball_centers, ball_radii, peer_lists=None):
+    """SpaceInvaderQueryBuilder.__call__ (area_query.py:970-1056): float32
+    maxima, cast to the coordinate dtype at the end."""
+    out = np.zeros(tree.nboxes, np.float32)
+    _aq_call("orc_space_invader", tree, ball_centers, ball_radii, peer_lists,
+             _ptr(out, ct.c_float))
+    return out.astype(tree.coord_dtype)
 
 # }}}
 
