@@ -15,6 +15,8 @@ fallback: without a HIP device or the built library, constructing an array
 context raises.
 """
 
+from boxtree_amd.area_query import (
+    AreaQueryBuilder, LeavesToBallsLookupBuilder, PeerListFinder, SpaceInvaderQueryBuilder)
 from boxtree_amd.array_context import HIPArrayContext
 from boxtree_amd.bounding_box import BoundingBoxFinder
 from boxtree_amd.tools import make_normal_particle_array
@@ -23,6 +25,8 @@ from boxtree_amd.tree import Tree, TreeOfBoxes, box_flags_enum
 from boxtree_amd.tree_build import MaxLevelsExceeded, TreeBuilder
 
 __all__ = [
+    "AreaQueryBuilder", "LeavesToBallsLookupBuilder", "PeerListFinder",
+    "SpaceInvaderQueryBuilder",
     "BoundingBoxFinder", "BuiltList", "FMMTraversalBuilder", "FMMTraversalInfo",
     "HIPArrayContext", "MaxLevelsExceeded", "Tree", "TreeBuilder", "TreeOfBoxes",
     "box_flags_enum", "make_normal_particle_array",

@@ -138,11 +138,24 @@ class TravArrays(ct.Structure):
 
 
 # every symbol include/boxtree_hip.h declares
+class AqTree(ct.Structure):
+    """bt_aq_tree"""
+    _fields_ = [
+        ("dims", ct.c_int32), ("coord_kind", ct.c_int32), ("nlevels", ct.c_int32),
+        ("nboxes", ct.c_int64), ("aligned_nboxes", ct.c_int64),
+        ("root_extent", ct.c_double), ("bbox_min", ct.c_double * 3),
+        ("box_centers", vp), ("box_levels", vp), ("box_child_ids", vp), ("box_flags", vp),
+        ("box_parent_ids", vp), ("level_start_box_nrs", ct.POINTER(ct.c_int32)),
+    ]
+
+
 EXPORTED_SYMBOLS = [
     "bt_abi_version", "bt_create", "bt_destroy", "bt_trim", "bt_last_error_string",
     "bt_bbox", "bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32", "bt_get_sort_stats",
     "bt_tree_build", "bt_tree_export", "bt_get_stage_times",
     "bt_traversal_build", "bt_traversal_export", "bt_merge_csr_lists",
+    "bt_peer_lists_build", "bt_area_query_build", "bt_csr_export", "bt_leaves_to_balls",
+    "bt_space_invader_query",
     "bt_morton_cells", "bt_bucket_permutation", "bt_gather", "bt_gather_pack", "bt_unpack",
 ]
 
@@ -185,6 +198,13 @@ def load():
     lib.bt_traversal_export.argtypes = [vp, ct.POINTER(TravArrays)]
     lib.bt_merge_csr_lists.argtypes = [vp, ct.c_int, ct.POINTER(vp), ct.POINTER(vp),
                                        ct.c_int64, vp, vp]
+    lib.bt_peer_lists_build.argtypes = [vp, ct.POINTER(AqTree), ct.POINTER(ct.c_int64)]
+    lib.bt_area_query_build.argtypes = [vp, ct.POINTER(AqTree), vp, vp, ct.c_int64,
+                                        ct.POINTER(vp), vp, ct.POINTER(ct.c_int64)]
+    lib.bt_csr_export.argtypes = [vp, vp, vp]
+    lib.bt_leaves_to_balls.argtypes = [vp, ct.c_int64, ct.c_int64, vp, vp, ct.c_int64, vp, vp]
+    lib.bt_space_invader_query.argtypes = [vp, ct.POINTER(AqTree), vp, vp, ct.c_int64,
+                                           ct.POINTER(vp), vp, vp]
     lib.bt_morton_cells.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), ct.c_int64,
                                     ct.POINTER(ct.c_double), ct.POINTER(ct.c_double),
                                     ct.c_int, vp, vp]

@@ -105,6 +105,7 @@ private:
 
 struct TreeState;   // bt_tree.hip
 struct TravState;   // bt_trav.hip
+struct AqState;     // bt_area_query.hip
 
 struct bt_context {
     int device = 0;
@@ -116,6 +117,7 @@ struct bt_context {
     bt::DeviceStatus *h_status = nullptr;     // pinned host mirror
     TreeState *tree = nullptr;
     TravState *trav = nullptr;
+    AqState *aq = nullptr;
     // timing of the last bt_radix_sort call (HIP events on ctx->stream)
     float last_sort_pass_ms = 0.f;
     int last_sort_passes = 0;

@@ -102,6 +102,7 @@ int check_status(bt_context *ctx)
 
 void bt_free_tree_state(bt_context *ctx);   // bt_tree.hip
 void bt_free_trav_state(bt_context *ctx);   // bt_trav.hip
+void bt_free_aq_state(bt_context *ctx);     // bt_area_query.hip
 
 extern "C" {
 
@@ -150,6 +151,7 @@ void bt_destroy(bt_context *ctx)
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     bt_free_tree_state(ctx);
     bt_free_trav_state(ctx);
+    bt_free_aq_state(ctx);
     ctx->pool.release_all();
     if (ctx->d_status) (void) hipFree(ctx->d_status);
     if (ctx->h_status) (void) hipHostFree(ctx->h_status);
@@ -163,6 +165,7 @@ int bt_trim(bt_context *ctx)
     BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     bt_free_tree_state(ctx);
     bt_free_trav_state(ctx);
+    bt_free_aq_state(ctx);
     ctx->pool.release_all();
     return BT_OK;
 }

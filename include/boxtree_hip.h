@@ -249,6 +249,58 @@ int bt_merge_csr_lists(bt_context *ctx, int nlists, const int32_t *const *starts
                        const int32_t *const *lists, int64_t nrows, int32_t *out_starts,
                        int32_t *out_lists);
 
+/* ---- area queries (boxtree/area_query.py) -------------------------------- */
+
+/* The tree arrays an area query reads, in boxtree.Tree layout (device pointers). */
+typedef struct {
+    int32_t dims, coord_kind;
+    int32_t nlevels;
+    int64_t nboxes, aligned_nboxes;
+    double root_extent;
+    double bbox_min[3];                    /* tree.bounding_box[0] */
+    const void *box_centers;               /* [d, aligned] */
+    const uint8_t *box_levels;
+    const int32_t *box_child_ids;          /* [2^d, aligned] */
+    const uint8_t *box_flags;
+    const int32_t *box_parent_ids;         /* peer lists only */
+    const int32_t *level_start_box_nrs;    /* HOST pointer, [nlevels+1]; peer lists only */
+} bt_aq_tree;
+
+/* PeerListFinder.__call__ (area_query.py:1152-1192; kernel :393-475).  Builds the
+ * CSR peer lists of all boxes into the context; *n_entries = len(peer_lists).
+ * Fetch with bt_csr_export(starts[nboxes+1], lists[n_entries]). */
+int bt_peer_lists_build(bt_context *ctx, const bt_aq_tree *tree, int64_t *n_entries);
+
+/* AreaQueryBuilder.__call__ (area_query.py:744-812; kernels :172-366): for every
+ * l^inf ball the leaves that overlap it.  ball_centers[dims] and ball_radii are
+ * device arrays of the tree's coordinate type.  Result held in the context:
+ * bt_csr_export(leaves_near_ball_starts[nballs+1], leaves_near_ball_lists[n]). */
+int bt_area_query_build(bt_context *ctx, const bt_aq_tree *tree,
+                        const int32_t *peer_list_starts, const int32_t *peer_lists,
+                        int64_t nballs, const void *const *ball_centers,
+                        const void *ball_radii, int64_t *n_entries);
+
+/* Copies (device to device) the CSR built by the last bt_peer_lists_build /
+ * bt_area_query_build and releases it. */
+int bt_csr_export(bt_context *ctx, int32_t *starts, int32_t *lists);
+
+/* LeavesToBallsLookupBuilder.__call__ (area_query.py:847-924): transposes an
+ * area query result -- (ball, leaf) pairs stably sorted by leaf.
+ * balls_near_box_starts[nboxes+1], balls_near_box_lists[n_entries]. */
+int bt_leaves_to_balls(bt_context *ctx, int64_t nballs, int64_t nboxes,
+                       const int32_t *leaves_near_ball_starts,
+                       const int32_t *leaves_near_ball_lists, int64_t n_entries,
+                       int32_t *balls_near_box_starts, int32_t *balls_near_box_lists);
+
+/* SpaceInvaderQueryBuilder.__call__ (area_query.py:970-1056; kernel :613-651):
+ * out[nboxes] (float32, like the reference's kernel; zeroed here) receives per
+ * leaf the largest l^inf distance from its centre to the centre of a ball that
+ * overlaps it. */
+int bt_space_invader_query(bt_context *ctx, const bt_aq_tree *tree,
+                           const int32_t *peer_list_starts, const int32_t *peer_lists,
+                           int64_t nballs, const void *const *ball_centers,
+                           const void *ball_radii, float *out);
+
 /* ---- multi-GPU exchange helpers (no counterpart in the reference, which never
  *      builds the tree in parallel: boxtree/distributed/__init__.py:183-199) ---- */
 
