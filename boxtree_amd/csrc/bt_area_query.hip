@@ -2,8 +2,9 @@
 // (boxtree/area_query.py) for gfx950.
 //
 //   peer lists      top-down, one launch per level: the peers of a box are the
-//                   peers of its parent, each either kept or replaced by its
-//                   adjacent children.  Same lists, same order as the reference's
+//                   peers of its parent, each either kept, replaced by its
+//                   adjacent children, or (not touching the box) replaced by the
+//                   first ancestor that does when no child of that ancestor does.  Same lists, same order as the reference's
 //                   walk from the root (area_query.py:393-475), which re-descends
 //                   from box 0 for every box.
 //   area query      one thread per ball: guiding box (:172-292), then a pruned
@@ -71,12 +72,36 @@ __global__ __launch_bounds__(256) void peer_level_kernel(AqTree<T, D> t, int32_t
     const int np = counts[par];
     int n = 0;
     bool overflow = false;
+    int32_t last_anc = -1;
     auto emit = [&](int32_t x) { if (n < P) out[n++] = x; else overflow = true; };
     for (int i = 0; i < np; ++i) {
         const int32_t p = prow[i];
         const Node<T, D> pn = t.nodes[p];
         const int pl = (int) (pn.lf & 0xffu);
-        if (!adj<T, D>(t.root_extent, me.c, level, pn.c, pl)) continue;
+        if (!adj<T, D>(t.root_extent, me.c, level, pn.c, pl)) {
+            // The walk for b stops above p, at the first ancestor a of p that
+            // touches b: a is a peer of b when none of its children touches b
+            // (children of a may have been pruned away next to b).  All peers of
+            // the parent below a are consecutive, so a is looked at once.
+            int32_t a = t.parent[p];
+            Node<T, D> an = t.nodes[a];
+            while (a != 0 && !adj<T, D>(t.root_extent, me.c, level, an.c, (int) (an.lf & 0xffu))) {
+                a = t.parent[a];
+                an = t.nodes[a];
+            }
+            if (a == last_anc) continue;
+            last_anc = a;
+            bool any = false;
+#pragma unroll
+            for (int m = 0; m < C; ++m) {
+                const int32_t c = t.child_t[(int64_t) a * C + m];
+                if (!c) continue;
+                const Node<T, D> cn = t.nodes[c];
+                any |= adj<T, D>(t.root_extent, me.c, level, cn.c, (int) (an.lf & 0xffu) + 1);
+            }
+            if (!any) emit(a);
+            continue;
+        }
         if (!(pn.lf & HAS_CHILDREN) || pl + 1 < level) {
             // a leaf, or a bigger box none of whose children touches the parent
             emit(p);

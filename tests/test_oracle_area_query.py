@@ -30,9 +30,13 @@ def brute_force_area_query(tree, ball_centers, ball_radii):
     return res
 
 
-def check_area_query(tree, aq, ball_centers, ball_radii):
-    expect = brute_force_area_query(tree, ball_centers, ball_radii)
+def check_area_query(tree, aq, ball_centers, ball_radii, first=None):
+    """Brute-force check (of the first *first* balls only, if given)."""
     assert len(aq.leaves_near_ball_starts) == len(ball_radii) + 1
+    if first is not None:
+        ball_centers = [b[:first] for b in ball_centers]
+        ball_radii = ball_radii[:first]
+    expect = brute_force_area_query(tree, ball_centers, ball_radii)
     for i, e in enumerate(expect):
         s, t = aq.leaves_near_ball_starts[i:i + 2]
         found = aq.leaves_near_ball_lists[s:t]
