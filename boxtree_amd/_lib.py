@@ -156,6 +156,7 @@ EXPORTED_SYMBOLS = [
     "bt_traversal_build", "bt_traversal_export", "bt_merge_csr_lists",
     "bt_peer_lists_build", "bt_area_query_build", "bt_csr_export", "bt_leaves_to_balls",
     "bt_space_invader_query",
+    "bt_filter_targets_user_order", "bt_filter_targets_tree_order", "bt_link_point_sources",
     "bt_morton_cells", "bt_bucket_permutation", "bt_gather", "bt_gather_pack", "bt_unpack",
 ]
 
@@ -205,6 +206,11 @@ def load():
     lib.bt_leaves_to_balls.argtypes = [vp, ct.c_int64, ct.c_int64, vp, vp, ct.c_int64, vp, vp]
     lib.bt_space_invader_query.argtypes = [vp, ct.POINTER(AqTree), vp, vp, ct.c_int64,
                                            ct.POINTER(vp), vp, vp]
+    lib.bt_filter_targets_user_order.argtypes = [vp, ct.c_int64, ct.c_int64, vp, vp, vp, vp,
+                                                 vp, vp, ct.POINTER(ct.c_int64)]
+    lib.bt_filter_targets_tree_order.argtypes = [vp, ct.c_int64, ct.c_int64, vp, vp, vp, vp,
+                                                 vp, vp, vp, ct.POINTER(ct.c_int64)]
+    lib.bt_link_point_sources.argtypes = [vp, ct.c_int64, ct.c_int64, ct.c_int64] + [vp] * 11
     lib.bt_morton_cells.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), ct.c_int64,
                                     ct.POINTER(ct.c_double), ct.POINTER(ct.c_double),
                                     ct.c_int, vp, vp]

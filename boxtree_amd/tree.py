@@ -179,3 +179,186 @@ class Tree(_Container):
         crit = ((self.box_source_starts <= isource)
                 & (isource < self.box_source_starts + self.box_source_counts_nonchild))
         return int(np.where(crit)[0])
+
+
+# {{{ tree with linked point sources (boxtree/tree.py:690-949)
+
+@dataclass(frozen=True)
+class TreeWithLinkedPointSources(Tree):
+    """A :class:`Tree` whose (extent-having) sources are expanded into point
+    sources; the additional fields of boxtree/tree.py:762-769."""
+    npoint_sources: int
+    point_source_starts: Any
+    point_source_counts: Any
+    point_sources: Any
+    user_point_source_ids: Any
+    box_point_source_starts: Any
+    box_point_source_counts_nonchild: Any
+    box_point_source_counts_cumul: Any
+
+
+def _gather(actx, src, ids):
+    """src[ids] through the library's gather kernel."""
+    import ctypes as ct
+
+    from boxtree_amd import _lib
+    src = src.contiguous()
+    out = actx.torch.empty(ids.shape[0], dtype=src.dtype, device=src.device)
+    if ids.shape[0]:
+        actx.sync_in()
+        _lib.check(actx.lib.bt_gather(
+            actx.handle, src.element_size(), ct.c_void_p(src.data_ptr()),
+            ct.c_void_p(ids.data_ptr()), int(ids.shape[0]), ct.c_void_p(out.data_ptr())))
+    return out
+
+
+def _dev(actx, a):
+    t = actx.from_numpy(a) if isinstance(a, np.ndarray) else a
+    return t.contiguous()
+
+
+def link_point_sources(actx, tree, point_source_starts, point_sources, *, debug=False):
+    r"""Links point sources to the extent-having sources of *tree*
+    (boxtree/tree.py:772-949).
+
+    :arg point_source_starts: ``point_source_starts[isrc]`` and ``[isrc+1]`` delimit
+        the point sources of source *isrc* (user source order) in *point_sources*.
+    :arg point_sources: an object array of (XYZ) point coordinate arrays.
+    """
+    import ctypes as ct
+
+    from boxtree_amd import _lib
+    from boxtree_amd.array_context import make_obj_array, np_dtype_of, ptr
+
+    if not tree.sources_have_extent:
+        raise ValueError("only allowed on trees whose sources have extent")
+    pss = _dev(actx, point_source_starts)
+    if np_dtype_of(pss) != np.int32:
+        raise TypeError("point_source_starts must have the tree's particle_id_dtype (int32)")
+    nsources = int(tree.nsources)
+    nboxes = int(tree.nboxes)
+    if pss.shape[0] != nsources + 1:
+        raise ValueError("point_source_starts must have nsources+1 entries")
+    ends = actx.to_numpy(pss[[0, nsources]])
+    npoint_sources = int(ends[1]) - int(ends[0])
+    e = actx.empty
+    i32 = np.int32
+    to_starts, to_counts = e(nsources, i32), e(nsources, i32)
+    ids = e(npoint_sources, i32)
+    bstarts, bnonchild, bcumul = e(nboxes, i32), e(nboxes, i32), e(nboxes, i32)
+    usi = _dev(actx, tree.user_source_ids)
+    bss = _dev(actx, tree.box_source_starts)
+    bsn = _dev(actx, tree.box_source_counts_nonchild)
+    bsc = _dev(actx, tree.box_source_counts_cumul)
+    actx.sync_in()
+    code = actx.lib.bt_link_point_sources(
+        actx.handle, nsources, nboxes, npoint_sources, ptr(pss), ptr(usi), ptr(bss), ptr(bsn),
+        ptr(bsc), ptr(to_starts), ptr(to_counts), ptr(ids), ptr(bstarts), ptr(bnonchild),
+        ptr(bcumul))
+    if code == _lib.BT_ERR_INVALID:
+        raise ValueError(actx.lib.bt_last_error_string().decode())
+    _lib.check(code)
+    tree_order_point_sources = make_obj_array(
+        [_gather(actx, _dev(actx, point_sources[i]), ids) for i in range(tree.dimensions)])
+    if debug:
+        h = actx.to_numpy(ids)
+        assert np.all(h >= 0) and np.all(h < npoint_sources)
+    tree_attrs = {f.name: getattr(tree, f.name) for f in dataclasses.fields(tree)}
+    result = TreeWithLinkedPointSources(
+        npoint_sources=npoint_sources,
+        point_source_starts=to_starts,
+        point_source_counts=to_counts,
+        point_sources=tree_order_point_sources,
+        user_point_source_ids=ids,
+        box_point_source_starts=bstarts,
+        box_point_source_counts_nonchild=bnonchild,
+        box_point_source_counts_cumul=bcumul,
+        **tree_attrs)
+    return actx.freeze(result)
+
+# }}}
+
+
+# {{{ particle list filter (boxtree/tree.py:957-1243)
+
+@dataclass(frozen=True)
+class FilteredTargetListsInUserOrder(_Container):
+    """Per box the flagged targets, as user-order target numbers (CSR:
+    ``target_starts [nboxes+1]``, ``target_lists``); boxtree/tree.py:957-998."""
+    nfiltered_targets: int
+    target_starts: Any
+    target_lists: Any
+
+
+@dataclass(frozen=True)
+class FilteredTargetListsInTreeOrder(_Container):
+    """A renumbering of the flagged targets that keeps the targets of a box
+    consecutive; boxtree/tree.py:1001-1055."""
+    nfiltered_targets: int
+    box_target_starts: Any
+    box_target_counts_nonchild: Any
+    targets: Any
+    unfiltered_from_filtered_target_indices: Any
+
+
+class ParticleListFilter:
+    """boxtree/tree.py:1059-1241"""
+
+    def __init__(self, array_context):
+        self._setup_actx = array_context
+
+    def _inputs(self, actx, tree, flags):
+        from boxtree_amd.array_context import np_dtype_of
+        flags = _dev(actx, flags)
+        if np_dtype_of(flags) != np.int8:
+            raise TypeError("flags must be an array of int8")
+        if flags.shape[0] != tree.ntargets:
+            raise ValueError("flags must have one entry per target")
+        return (flags, _dev(actx, tree.sorted_target_ids), _dev(actx, tree.box_target_starts),
+                _dev(actx, tree.box_target_counts_nonchild))
+
+    def filter_target_lists_in_user_order(self, actx, tree, flags):
+        """:arg flags: int8 [ntargets] in user target order; nonzero = keep."""
+        import ctypes as ct
+
+        from boxtree_amd import _lib
+        from boxtree_amd.array_context import ptr
+        flags, sti, bts, btc = self._inputs(actx, tree, flags)
+        nboxes, ntargets = int(tree.nboxes), int(tree.ntargets)
+        starts = actx.empty(nboxes + 1, np.int32)
+        lists = actx.empty(ntargets, np.int32)
+        n = ct.c_int64(0)
+        actx.sync_in()
+        _lib.check(actx.lib.bt_filter_targets_user_order(
+            actx.handle, nboxes, ntargets, ptr(flags), ptr(sti), ptr(bts), ptr(btc),
+            ptr(starts), ptr(lists), ct.byref(n)))
+        result = FilteredTargetListsInUserOrder(
+            nfiltered_targets=int(n.value), target_starts=starts,
+            target_lists=lists[:n.value])
+        return actx.freeze(result)
+
+    def filter_target_lists_in_tree_order(self, actx, tree, flags):
+        """:arg flags: int8 [ntargets] in user target order; nonzero = keep."""
+        import ctypes as ct
+
+        from boxtree_amd import _lib
+        from boxtree_amd.array_context import make_obj_array, ptr
+        flags, sti, bts, btc = self._inputs(actx, tree, flags)
+        nboxes, ntargets = int(tree.nboxes), int(tree.ntargets)
+        starts_f = actx.empty(nboxes, np.int32)
+        counts_f = actx.empty(nboxes, np.int32)
+        uff = actx.empty(ntargets, np.int32)
+        n = ct.c_int64(0)
+        actx.sync_in()
+        _lib.check(actx.lib.bt_filter_targets_tree_order(
+            actx.handle, nboxes, ntargets, ptr(flags), ptr(sti), ptr(bts), ptr(btc),
+            ptr(starts_f), ptr(counts_f), ptr(uff), ct.byref(n)))
+        uff = uff[:n.value].contiguous()
+        targets = make_obj_array([_gather(actx, _dev(actx, t), uff) for t in tree.targets])
+        result = FilteredTargetListsInTreeOrder(
+            nfiltered_targets=int(n.value), box_target_starts=starts_f,
+            box_target_counts_nonchild=counts_f, targets=targets,
+            unfiltered_from_filtered_target_indices=uff)
+        return actx.freeze(result)
+
+# }}}

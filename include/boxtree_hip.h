@@ -301,6 +301,45 @@ int bt_space_invader_query(bt_context *ctx, const bt_aq_tree *tree,
                            int64_t nballs, const void *const *ball_centers,
                            const void *ball_radii, float *out);
 
+/* ---- target filtering and point-source linking (boxtree/tree.py) ----------- */
+
+/* ParticleListFilter.filter_target_lists_in_user_order (tree.py:1115-1150): per
+ * box the user-order numbers of its (non-child) targets whose flag is nonzero.
+ * target_starts[nboxes+1]; target_lists needs room for ntargets entries, the
+ * first *nfiltered are valid. */
+int bt_filter_targets_user_order(bt_context *ctx, int64_t nboxes, int64_t ntargets,
+                                 const int8_t *user_order_flags, const int32_t *sorted_target_ids,
+                                 const int32_t *box_target_starts,
+                                 const int32_t *box_target_counts_nonchild,
+                                 int32_t *target_starts, int32_t *target_lists,
+                                 int64_t *nfiltered);
+
+/* ParticleListFilter.filter_target_lists_in_tree_order (tree.py:1175-1241;
+ * tree_build_kernels.py:1951-2021): renumbering of the flagged targets in tree
+ * order.  Outputs [nboxes], [nboxes], [ntargets capacity; *nfiltered valid]. */
+int bt_filter_targets_tree_order(bt_context *ctx, int64_t nboxes, int64_t ntargets,
+                                 const int8_t *user_order_flags, const int32_t *sorted_target_ids,
+                                 const int32_t *box_target_starts,
+                                 const int32_t *box_target_counts_nonchild,
+                                 int32_t *box_target_starts_filtered,
+                                 int32_t *box_target_counts_nonchild_filtered,
+                                 int32_t *unfiltered_from_filtered, int64_t *nfiltered);
+
+/* link_point_sources (tree.py:772-949; tree_build_kernels.py:1871-1947).
+ * point_source_starts[nsources+1] is in user source order; npoint_sources must be
+ * the number of point sources it describes (the size of user_point_source_ids).
+ * Outputs: [nsources] x2, [npoint_sources], [nboxes] x3. */
+int bt_link_point_sources(bt_context *ctx, int64_t nsources, int64_t nboxes,
+                          int64_t npoint_sources, const int32_t *point_source_starts,
+                          const int32_t *user_source_ids, const int32_t *box_source_starts,
+                          const int32_t *box_source_counts_nonchild,
+                          const int32_t *box_source_counts_cumul,
+                          int32_t *tree_order_point_source_starts,
+                          int32_t *tree_order_point_source_counts,
+                          int32_t *user_point_source_ids, int32_t *box_point_source_starts,
+                          int32_t *box_point_source_counts_nonchild,
+                          int32_t *box_point_source_counts_cumul);
+
 /* ---- multi-GPU exchange helpers (no counterpart in the reference, which never
  *      builds the tree in parallel: boxtree/distributed/__init__.py:183-199) ---- */
 

@@ -752,4 +752,110 @@ def space_invader_query(tree, ball_centers, ball_radii, peer_lists=None):
 
 # }}}
 
+# {{{ target filtering and point-source linking (boxtree/tree.py:772-949, :1059-1243)
+
+def filter_target_lists_in_user_order(tree, flags):
+    """ParticleListFilter.filter_target_lists_in_user_order (tree.py:1115-1150;
+    generator :1085-1113)."""
+    flags = np.asarray(flags)
+    ntargets = tree.ntargets
+    user_target_ids = np.zeros(ntargets, tree.sorted_target_ids.dtype)          # :1126-1129
+    user_target_ids[tree.sorted_target_ids] = np.arange(ntargets, dtype=user_target_ids.dtype)
+    starts = np.zeros(tree.nboxes + 1, np.int32)
+    lists = []
+    for i in range(tree.nboxes):                                                # :1093-1106
+        b_t_start = int(tree.box_target_starts[i])
+        b_t_count = int(tree.box_target_counts_nonchild[i])
+        ids = user_target_ids[b_t_start:b_t_start + b_t_count]
+        ids = ids[flags[ids] != 0]
+        lists.append(ids)
+        starts[i + 1] = starts[i] + len(ids)
+    lists = (np.concatenate(lists) if lists else np.zeros(0)).astype(np.int32)
+    return SimpleNamespace(nfiltered_targets=len(lists), target_starts=starts,
+                           target_lists=lists)
+
+
+def filter_target_lists_in_tree_order(tree, flags):
+    """ParticleListFilter.filter_target_lists_in_tree_order (tree.py:1175-1241);
+    TREE_ORDER_TARGET_FILTER_SCAN_TPL / _INDEX_TPL (tree_build_kernels.py:1951-2021)."""
+    flags = np.asarray(flags)
+    ntargets = tree.ntargets
+    tree_order_flags = np.zeros(ntargets, np.int8)                               # :1184-1185
+    tree_order_flags[tree.sorted_target_ids] = flags
+    ones = (tree_order_flags != 0).astype(np.int64)
+    item = np.cumsum(ones)
+    prev_item = item - ones
+    filtered_from_unfiltered = prev_item.astype(np.int32)                       # tbk:1966
+    nfiltered = int(item[-1]) if ntargets else 0
+    unfiltered_from_filtered = np.nonzero(ones)[0].astype(np.int32)             # tbk:1967-1968
+    targets = [np.asarray(t)[unfiltered_from_filtered] for t in tree.targets]   # :1203-1206
+    nboxes = tree.nboxes
+    bstarts = np.zeros(nboxes, np.int32)
+    bcounts = np.zeros(nboxes, np.int32)
+    for i in range(nboxes):                                                      # tbk:1990-2018
+        ustart = int(tree.box_target_starts[i])
+        ucount = int(tree.box_target_counts_nonchild[i])
+        # the reference reads filtered_from_unfiltered[ustart] unguarded; an empty
+        # box that starts at ntargets would read past the end -- take nfiltered there
+        fstart = int(filtered_from_unfiltered[ustart]) if ustart < ntargets else nfiltered
+        bstarts[i] = fstart
+        if ucount > 0:
+            upost = ustart + ucount
+            fpost = int(filtered_from_unfiltered[upost]) if upost < ntargets else nfiltered
+            bcounts[i] = fpost - fstart
+    return SimpleNamespace(nfiltered_targets=nfiltered, box_target_starts=bstarts,
+                           box_target_counts_nonchild=bcounts, targets=targets,
+                           unfiltered_from_filtered_target_indices=unfiltered_from_filtered)
+
+
+def link_point_sources(tree, point_source_starts, point_sources):
+    """link_point_sources (tree.py:772-949); kernels tree_build_kernels.py:1871-1947.
+    Sources without point sources write nothing (the reference's multi_put of their
+    start index collides with the next source's / runs past the end)."""
+    if not tree.sources_have_extent:
+        raise ValueError("only allowed on trees whose sources have extent")
+    pss = np.asarray(point_source_starts).astype(np.int64)
+    usi = np.asarray(tree.user_source_ids).astype(np.int64)
+    lengths = pss[usi + 1] - pss[usi]                                            # tbk:1884-1887
+    item = np.cumsum(lengths)
+    prev_item = item - lengths
+    to_starts = prev_item.astype(np.int32)                                       # tbk:1891
+    to_counts = lengths.astype(np.int32)
+    npoint_sources = int(item[-1]) if len(item) else 0
+    ids = np.ones(npoint_sources, np.int64)                                      # :846-853
+    boundaries = np.zeros(npoint_sources, np.int8)
+    nz = lengths > 0
+    ids[prev_item[nz]] = pss[usi][nz]
+    boundaries[prev_item[nz]] = 1                                                # :860-869
+    # segmented inclusive scan, tbk:1903-1912
+    seg = np.cumsum(boundaries) - 1
+    seg_first = np.nonzero(boundaries)[0]
+    csum = np.cumsum(ids)
+    base = csum[seg_first] - ids[seg_first]
+    user_point_source_ids = (csum - base[seg]).astype(np.int32) if npoint_sources else \
+        np.zeros(0, np.int32)
+    tree_order_point_sources = [np.asarray(ps)[user_point_source_ids] for ps in point_sources]
+    nboxes = tree.nboxes
+    bstarts = np.zeros(nboxes, np.int32)
+    out = {"nonchild": np.zeros(nboxes, np.int32), "cumul": np.zeros(nboxes, np.int32)}
+    src_counts = {"nonchild": tree.box_source_counts_nonchild,
+                  "cumul": tree.box_source_counts_cumul}
+    for ibox in range(nboxes):                                                   # tbk:1914-1947
+        s_start = int(tree.box_source_starts[ibox])
+        ps_start = int(to_starts[s_start]) if s_start < len(to_starts) else npoint_sources
+        bstarts[ibox] = ps_start
+        for kind in ("nonchild", "cumul"):
+            s_count = int(src_counts[kind][ibox])
+            if s_count:
+                last = s_start + s_count - 1
+                out[kind][ibox] = int(to_starts[last]) + int(to_counts[last]) - ps_start
+    return SimpleNamespace(
+        npoint_sources=npoint_sources, point_source_starts=to_starts,
+        point_source_counts=to_counts, point_sources=tree_order_point_sources,
+        user_point_source_ids=user_point_source_ids, box_point_source_starts=bstarts,
+        box_point_source_counts_nonchild=out["nonchild"],
+        box_point_source_counts_cumul=out["cumul"])
+
+# }}}
+
 # vim: foldmethod=marker

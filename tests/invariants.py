@@ -238,7 +238,7 @@ def check_traversal(tree, trav):
         assert lst[-1] == len(ref)
 
 
-def constant_one_potentials(tree, trav):
+def constant_one_potentials(tree, trav, filtered_user=None, filtered_tree=None):
     """Restatement of drive_fmm (boxtree/fmm.py:342-532) with the constant-one
     wrangler (boxtree/constant_one.py:50-237) and unit source weights.  Every
     target must end up with potential == nsources (test_fmm.py:141-391).
@@ -307,6 +307,25 @@ def constant_one_potentials(tree, trav):
 
     # eval_locals
     pot_box += local[trav.target_boxes]
+
+    if filtered_user is not None:
+        # test_fmm.py:128-138: the lists hold user target numbers; potentials come
+        # back in user order (constant_one.py:78)
+        pot = np.zeros(tree.ntargets, np.int64)
+        for itb, ibox in enumerate(trav.target_boxes):
+            ids = filtered_user.target_lists[
+                filtered_user.target_starts[ibox]:filtered_user.target_starts[ibox + 1]]
+            pot[tree.sorted_target_ids[ids]] += pot_box[itb]
+        return pot[tree.sorted_target_ids]
+    if filtered_tree is not None:
+        # test_fmm.py:103-125
+        potf = np.zeros(filtered_tree.nfiltered_targets, np.int64)
+        for itb, ibox in enumerate(trav.target_boxes):
+            s = filtered_tree.box_target_starts[ibox]
+            potf[s:s + filtered_tree.box_target_counts_nonchild[ibox]] += pot_box[itb]
+        allpot = np.zeros(tree.ntargets, np.int64)
+        allpot[filtered_tree.unfiltered_from_filtered_target_indices] = potf
+        return allpot[tree.sorted_target_ids]
 
     pot = np.zeros(tree.ntargets, np.int64)
     filled = np.zeros(tree.ntargets, bool)
