@@ -160,7 +160,8 @@ def main():
         if distributed:
             # the exchange is part of the path (and of the timed step) for N > 1
             from boxtree_amd.distributed import exchange_particles
-            p_, t_, kw_, xs = exchange_particles(actx, dist, particles, targets, build_kw)
+            p_, t_, kw_, xs = exchange_particles(
+                actx, dist, particles, targets, build_kw, max_particles_in_box=args.mpb)
             xinfo.update(exchange_bytes_sent_rank0=int(xs["bytes_sent"]),
                          owned_particles_rank0=int(len(p_[0])))
         tree, _ = tb(actx, p_, targets=t_, max_particles_in_box=args.mpb, **kw_)

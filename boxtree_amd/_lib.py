@@ -47,6 +47,7 @@ class TreeParams(ct.Structure):
         ("stick_out_factor", ct.c_double),
         ("bbox_min", ct.c_double * BT_MAX_DIMS), ("bbox_max", ct.c_double * BT_MAX_DIMS),
         ("root_extent", ct.c_double),
+        ("top_level", ct.c_int32), ("top_cell_prefix", vp),
     ]
 
 

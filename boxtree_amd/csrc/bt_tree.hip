@@ -267,7 +267,18 @@ struct BuildArgs {
     int b0, nprev;              // boxes of level-1: [b0, b0+nprev)
     int new_level_start;
     int adaptive;
+    int top_level;              // sharded builds: levels above it use global counts
+    const int64_t *top_prefix;  // [C^top_level + 1] or null
 };
+
+// global particle count of the box with Morton path `path` at `level` <= top_level
+template <int D>
+__device__ __forceinline__ int32_t top_weight(const BuildArgs &a, uint64_t path, int level)
+{
+    const int sh = D * (a.top_level - level);
+    const int64_t w = a.top_prefix[(path + 1) << sh] - a.top_prefix[path << sh];
+    return (w > (int64_t) INT_MAX) ? INT_MAX : (int32_t) w;
+}
 
 __device__ __forceinline__ int32_t range_weight(const BuildArgs &a, int lo, int hi)
 {
@@ -288,12 +299,13 @@ __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
     const int l = a.level;
 
     int lo = 0, e = 0, s = 0;
+    uint64_t prefix = 0;
     if (active) {
         s = a.box_start[b];
         e = s + a.box_count[b];
         if (l - 1 < a.L && e > s) {
             const int pshift = a.capbits + D * (a.L - (l - 1));
-            const uint64_t prefix = (pshift >= 64) ? 0 : (a.keys[s] >> pshift);
+            prefix = (pshift >= 64) ? 0 : (a.keys[s] >> pshift);
             const int cshift = a.capbits + D * (a.L - l);
             if (m == 0) {
                 if (EXT) {
@@ -317,7 +329,9 @@ __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
     const int first = __shfl(lo, 0, C);     // start of the child-bound range
     if (!active) return;
 
-    const int32_t W = range_weight(a, first, e);                 // tbk:569-573
+    int32_t W = range_weight(a, first, e);                       // tbk:569-573
+    const bool top = a.top_prefix && l - 1 < a.top_level && e > s;
+    if (top) W = top_weight<D>(a, prefix, l - 1);
     bool split;
     if (a.adaptive) split = W > a.max_weight;                    // tbk:577-591
     else split = true;
@@ -334,7 +348,9 @@ __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
     const uint64_t bal = __ballot(nonempty);
     const int gshift = (threadIdx.x & 63) / C * C;
     const uint32_t gmask = (uint32_t) ((bal >> gshift) & ((1ull << C) - 1));
-    if (split && range_weight(a, lo, hi) > a.max_weight) {       // tbk:600-610
+    const int32_t Wc = top ? top_weight<D>(a, (prefix << D) | (uint64_t) m, l)
+                           : range_weight(a, lo, hi);
+    if (split && cnt > 0 && Wc > a.max_weight) {                 // tbk:600-610
         // one (idempotent) store per wave at most, and none once the flag is up:
         // millions of same-address atomics serialise in L2
         if (__hip_atomic_load(&a.flags->have_oversize, __ATOMIC_RELAXED,
@@ -894,6 +910,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         a.level = level; a.L = st->L; a.capbits = st->capbits;
         a.b0 = b0; a.nprev = nprev;
         a.adaptive = p.kind != BT_KIND_NON_ADAPTIVE;
+        a.top_level = p.top_level;
+        a.top_prefix = p.top_cell_prefix;
 
         const unsigned blocks = (unsigned) div_up((int64_t) nprev * C, 256);
         if (EXT) count_children_kernel<D, true><<<blocks, 256, 0, ctx->stream>>>(a);
@@ -1172,6 +1190,17 @@ int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
     }
     const bool sat = p->ntargets < 0;
     const bool have_extent = p->source_radii || p->target_radii;
+    if (p->top_cell_prefix) {
+        if (p->top_level < 1 || p->dims * p->top_level > 30) {
+            set_error("bt_tree_build: top_level %d out of range", p->top_level);
+            return BT_ERR_INVALID;
+        }
+        if (have_extent || p->refine_weights || p->kind != BT_KIND_ADAPTIVE) {
+            set_error("sharded builds (top_cell_prefix) support kind='adaptive' with point "
+                      "particles and unit refine weights only");
+            return BT_ERR_UNSUPPORTED;
+        }
+    }
     if (have_extent && sat) {
         set_error("must specify targets when specifying any kind of radii");
         return BT_ERR_INVALID;

@@ -101,19 +101,125 @@ def morton_cells(arrays, bbox_min, bbox_max, level):
     return cell
 
 
-def partition_cells(global_hist, world):
+def top_tree_plan(global_hist, dims, top_level, max_particles_in_box):
+    """The top of the GLOBAL tree (levels 0..top_level), a pure function of the
+    all-reduced level-``top_level`` cell histogram (kind="adaptive", point
+    particles, unit weights: a box splits iff it holds more than
+    *max_particles_in_box* particles, tree_build_kernels.py:577-591; empty boxes
+    are pruned).  Cell and box indices are Morton paths, x most significant in
+    every digit, i.e. the order of the reference's box numbering within a level.
+
+    Returns a dict: ``counts[l]``, ``exists[l]``, ``split[l]`` (arrays over the
+    C^l paths of level l), ``index[l]`` (number of a box among the existing boxes of
+    its level), ``nboxes[l]``, ``unit_start`` (for every level-k cell the first cell
+    of the frontier box -- leaf above level k or the cell itself -- it lies in) and
+    ``cell_prefix`` (exclusive prefix sum of the histogram, length C^k + 1)."""
+    C = 1 << dims
+    k = int(top_level)
+    hist = np.asarray(global_hist, dtype=np.int64)
+    assert hist.shape == (C ** k,)
+    counts = [None] * (k + 1)
+    counts[k] = hist
+    for lev in range(k - 1, -1, -1):
+        counts[lev] = counts[lev + 1].reshape(-1, C).sum(axis=1)
+    exists = [None] * (k + 1)
+    split = [None] * (k + 1)
+    exists[0] = np.ones(1, dtype=bool)
+    for lev in range(k + 1):
+        split[lev] = exists[lev] & (counts[lev] > max_particles_in_box)
+        if lev < k:
+            exists[lev + 1] = np.repeat(split[lev], C) & (counts[lev + 1] > 0)
+    cells = np.arange(C ** k, dtype=np.int64)
+    leaf_level = np.full(C ** k, k, dtype=np.int64)
+    for lev in range(k - 1, -1, -1):
+        anc = cells >> (dims * (k - lev))
+        leaf_level = np.where(split[lev][anc], leaf_level, lev)
+    sh = dims * (k - leaf_level)
+    unit_start = (cells >> sh) << sh
+    prefix = np.zeros(C ** k + 1, dtype=np.int64)
+    np.cumsum(hist, out=prefix[1:])
+    return dict(
+        dims=dims, top_level=k, max_particles_in_box=int(max_particles_in_box),
+        counts=counts, exists=exists, split=split,
+        index=[np.cumsum(e) - 1 for e in exists],
+        nboxes=[int(e.sum()) for e in exists],
+        unit_start=unit_start, cell_prefix=prefix)
+
+
+def partition_cells(global_hist, world, unit_start=None):
     """Step 3: owner rank of every cell; contiguous Morton ranges balanced by
-    particle count.  Pure function of the (identical) global histogram."""
+    particle count.  Pure function of the (identical) global histogram.  With
+    *unit_start* (:func:`top_tree_plan`) all cells of a frontier box of the global
+    top tree get the owner of its first cell, so no global leaf straddles ranks."""
     counts = np.asarray(global_hist, dtype=np.int64)
     total = int(counts.sum())
     cum = np.cumsum(counts) - counts           # exclusive prefix
     # cell goes to the rank whose ideal range contains its first particle
     owner = np.minimum((cum * world) // max(total, 1), world - 1).astype(np.int64)
+    if unit_start is not None:
+        owner = owner[unit_start]
     return owner
 
 
+def global_box_numbering(plan, level_counts_by_rank, rank):
+    """Step 5: the numbers the boxes of rank *rank*'s local tree carry in the global
+    (single-GPU) tree.  *level_counts_by_rank* [world][nlevels_max]: boxes per level
+    of every rank's local tree (all-gathered).  Boxes above ``top_level`` are shared
+    between ranks and numbered by their Morton path (:func:`top_tree_plan`); below,
+    ranks own increasing Morton ranges, so a level is the concatenation of the
+    ranks' level slices.
+
+    Returns ``(global_level_start_box_nrs, deep_base)``: ``deep_base[l]`` is the
+    global number of this rank's first level-l box, for l > top_level."""
+    k = plan["top_level"]
+    lc = np.asarray(level_counts_by_rank, dtype=np.int64)
+    nlevels = int((lc > 0).sum(axis=1).max())     # the deepest local tree
+    starts = np.zeros(nlevels + 1, dtype=np.int64)
+    deep_base = np.zeros(nlevels, dtype=np.int64)
+    for lev in range(nlevels):
+        if lev <= k:
+            n = plan["nboxes"][lev]
+        else:
+            n = int(lc[:, lev].sum())
+            deep_base[lev] = starts[lev] + int(lc[:rank, lev].sum())
+        starts[lev + 1] = starts[lev] + n
+    return starts, deep_base
+
+
+def local_to_global_box_ids(tree, plan, global_level_starts, deep_base, bbox_min, root_extent):
+    """int64 tensor [local nboxes] of global box numbers (see
+    :func:`global_box_numbering`).  Boxes at levels <= top_level are located by the
+    Morton path of their centre."""
+    import torch
+    k = plan["top_level"]
+    dims = plan["dims"]
+    lsb = np.asarray(tree.level_start_box_nrs if isinstance(tree.level_start_box_nrs, np.ndarray)
+                     else tree.level_start_box_nrs.cpu().numpy(), dtype=np.int64)
+    nboxes = int(tree.nboxes)
+    centers = tree.box_centers
+    dev = centers.device
+    out = torch.empty(nboxes, dtype=torch.int64, device=dev)
+    for lev in range(len(lsb) - 1):
+        b0, b1 = int(lsb[lev]), int(lsb[lev + 1])
+        if b1 <= b0:
+            continue
+        if lev > k:
+            out[b0:b1] = torch.arange(b1 - b0, device=dev) + int(deep_base[lev])
+            continue
+        path = torch.zeros(b1 - b0, dtype=torch.int64, device=dev)
+        for ax in range(dims):
+            # centres sit at (i + 1/2) / 2^lev of the root box: floor is robust
+            v = ((centers[ax, b0:b1].double() - float(bbox_min[ax])) / float(root_extent)
+                 * float(1 << lev)).floor().long().clamp_(0, (1 << lev) - 1)
+            for b in range(lev):
+                path |= ((v >> b) & 1) << (dims * b + (dims - 1 - ax))
+        index = torch.from_numpy(plan["index"][lev]).to(dev)
+        out[b0:b1] = index[path] + int(global_level_starts[lev])
+    return out
+
+
 def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
-                       top_level=None, return_plan=False):
+                       top_level=None, return_plan=False, max_particles_in_box=None):
     """Steps 1-4.  Returns ``(particles, targets, build_kw, stats)`` for the local
     ``TreeBuilder`` call; ``build_kw`` gains ``_root_box=`` (the global root box) and
     the exchanged ``target_radii`` if present."""
@@ -163,7 +269,16 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         tgt_cells, tgt_hist = cells_of(targets)
         hist = hist + tgt_hist
     dist.all_reduce(hist)
-    owner = partition_cells(hist.cpu().numpy(), world)
+    ghist = hist.cpu().numpy()
+    # With point particles and unit weights the top of the global tree follows from
+    # the histogram alone: ownership respects its leaves and the local builds split
+    # the shared top boxes where the global tree does (TreeBuilder ``_top_tree``).
+    plan = None
+    if (max_particles_in_box is not None and source_radii is None and target_radii is None
+            and build_kw.get("refine_weights") is None
+            and build_kw.get("kind", "adaptive") == "adaptive"):
+        plan = top_tree_plan(ghist, dims, top_level, max_particles_in_box)
+    owner = partition_cells(ghist, world, None if plan is None else plan["unit_start"])
     owner_t = torch.from_numpy(owner).to(dev)
 
     stats = {"bytes_sent": 0, "top_level": top_level}
@@ -255,8 +370,54 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
     # re-derives root_extent from max-min and asserts squareness to 1e-15, which a
     # rounded ``min + extent`` need not satisfy)
     build_kw["_root_box"] = (bbox_min, bbox_max, root_extent)
+    if plan is not None and native:
+        build_kw["_top_tree"] = (top_level, torch.from_numpy(plan["cell_prefix"]).to(dev))
+    stats["plan"] = plan
+    stats["bbox_min"], stats["bbox_max"] = bbox_min, bbox_max
+    stats["root_extent"] = root_extent
     if return_plan:
         stats["owner"] = owner
-        stats["bbox_min"], stats["bbox_max"] = bbox_min, bbox_max
-        stats["root_extent"] = root_extent
     return new_particles, new_targets, build_kw, stats
+
+
+def number_sharded_tree(dist, tree, stats):
+    """Step 5 for the local *tree* of this rank (built from the output of
+    :func:`exchange_particles`, whose *stats* carry the top-tree plan): all-gathers
+    the per-level box counts and particle counts and returns the placement of the
+    local tree inside the global one::
+
+        box_ids                      int64 [local nboxes]: global box numbers
+        global_level_start_box_nrs   int64 [global nlevels + 1]
+        source_offset/target_offset  global tree-order index of local particle 0
+        nboxes, nsources, ntargets   global totals
+
+    Renumbering the local arrays with these gives, rank by rank, exactly the
+    slices of the tree a single GPU builds from the concatenated input
+    (tests/test_gpu_parity.py::test_sharded_build_global_numbering)."""
+    import torch
+    plan = stats.get("plan")
+    if plan is None:
+        raise NotImplementedError(
+            "global numbering needs the top-tree plan: kind='adaptive', point particles, "
+            "unit refine weights, max_particles_in_box passed to exchange_particles")
+    world = dist.get_world_size()
+    rank = dist.get_rank()
+    lsb = tree.level_start_box_nrs
+    lsb = np.asarray(lsb if isinstance(lsb, np.ndarray) else lsb.cpu().numpy(), dtype=np.int64)
+    nmax = 64
+    dev = tree.box_centers.device
+    mine = torch.zeros(nmax + 2, dtype=torch.int64, device=dev)
+    mine[:len(lsb) - 1] = torch.from_numpy(np.diff(lsb)).to(dev)
+    mine[nmax] = int(tree.nsources)
+    mine[nmax + 1] = int(tree.ntargets)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    allc = torch.stack(gathered).cpu().numpy()
+    starts, deep_base = global_box_numbering(plan, allc[:, :nmax], rank)
+    box_ids = local_to_global_box_ids(tree, plan, starts, deep_base, stats["bbox_min"],
+                                      stats["root_extent"])
+    return dict(
+        box_ids=box_ids, global_level_start_box_nrs=starts,
+        source_offset=int(allc[:rank, nmax].sum()), target_offset=int(allc[:rank, nmax + 1].sum()),
+        nboxes=int(starts[-1]), nsources=int(allc[:, nmax].sum()),
+        ntargets=int(allc[:, nmax + 1].sum()))

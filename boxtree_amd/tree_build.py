@@ -284,6 +284,14 @@ class TreeBuilder:
             tp.bbox_min[i] = float(bbox[f"min_{ax}"])
             tp.bbox_max[i] = float(bbox[f"max_{ax}"])
         tp.root_extent = float(coord_dtype.type(root_extent))
+        top_tree = kwargs.get("_top_tree")
+        if top_tree is not None:
+            # (top_level, int64 device tensor [C^top_level + 1]): global cell counts
+            # of a sharded build, see boxtree_amd/distributed.py
+            tp.top_level = int(top_tree[0])
+            top_prefix = top_tree[1].contiguous()
+            assert top_prefix.shape[0] == (1 << (dimensions * tp.top_level)) + 1
+            tp.top_cell_prefix = ptr(top_prefix)
 
         sizes = _lib.TreeSizes()
         actx.sync_in()

@@ -131,6 +131,13 @@ typedef struct {
     double bbox_min[BT_MAX_DIMS];
     double bbox_max[BT_MAX_DIMS];
     double root_extent;
+    /* Sharded builds only (no counterpart in the reference): this call sees the
+     * particles of a contiguous Morton range of level-`top_level` cells of a larger
+     * point set.  top_cell_prefix[2^(dims*top_level) + 1] (device) is the exclusive
+     * prefix sum of the GLOBAL particle counts of those cells; boxes above
+     * top_level split where the global tree does.  NULL: a self-contained build. */
+    int32_t top_level;
+    const int64_t *top_cell_prefix;
 } bt_tree_params;
 
 typedef struct {

@@ -455,3 +455,97 @@ def test_sharded_build_union_equals_global_tree(actx):
     union = np.concatenate(parts)
     union = union[np.lexsort(union.T[::-1])]
     assert np.array_equal(union, leaves(gtree))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dist_kind", ["normal", "uniform", "clustered"])
+@pytest.mark.parametrize("dims", [2, 3])
+def test_sharded_build_global_numbering(actx, dims, dist_kind):
+    """distributed.py steps 3-5 without a process group: the ranks' trees, built
+    from their shares with the global root box and top-tree counts and renumbered by
+    global_box_numbering, are slices of the tree one GPU builds from all points --
+    same box numbers, same particle order."""
+    import torch
+    from boxtree_amd import TreeBuilder
+    from boxtree_amd.distributed import (ROOT_EXTENT_STRETCH_FACTOR, global_box_numbering,
+                                         local_to_global_box_ids, morton_cells,
+                                         partition_cells, top_tree_plan)
+    rng = np.random.default_rng(11)
+    n, world, level, mpb = 300000, 4, 3 if dims == 3 else 4, 30
+    if dist_kind == "normal":
+        host = [rng.standard_normal(n) for _ in range(dims)]
+    elif dist_kind == "uniform":
+        host = [rng.random(n) for _ in range(dims)]
+    else:       # a dense blob plus a thin background: light and empty top cells
+        host = [np.concatenate([0.02 * rng.standard_normal(n - 500) + 0.7, rng.random(500)])
+                for _ in range(dims)]
+    pts = [torch.from_numpy(h).cuda() for h in host]
+    gmin = np.array([float(p.min()) for p in pts])
+    gmax = np.array([float(p.max()) for p in pts])
+    root_extent = max(gmax - gmin) * (1 + ROOT_EXTENT_STRETCH_FACTOR)
+    bbox_min = gmin.copy()
+    bbox_max = bbox_min + root_extent
+    cells = morton_cells(pts, bbox_min, bbox_max, level)
+    C = 1 << dims
+    hist = torch.bincount(cells, minlength=C ** level).cpu().numpy()
+    plan = top_tree_plan(hist, dims, level, mpb)
+    owner_of_cell = partition_cells(hist, world, plan["unit_start"])
+    assert np.all(np.diff(owner_of_cell) >= 0)
+    owner = torch.from_numpy(owner_of_cell).cuda()[cells]
+    prefix = torch.from_numpy(plan["cell_prefix"]).cuda()
+    tb = TreeBuilder(actx)
+    g = actx.to_numpy(tb(actx, pts, max_particles_in_box=mpb)[0])
+
+    locs, gids = [], []
+    for r in range(world):
+        sel = torch.nonzero(owner == r).flatten()
+        sub = [p[sel].contiguous() for p in pts]
+        tree, _ = tb(actx, sub, max_particles_in_box=mpb,
+                     _root_box=(bbox_min, bbox_max, root_extent), _top_tree=(level, prefix))
+        locs.append(tree)
+        gids.append(sel.cpu().numpy())
+    nmax = 64
+    lc = np.zeros((world, nmax), np.int64)
+    for r, t in enumerate(locs):
+        d = np.diff(actx.to_numpy(t.level_start_box_nrs))
+        lc[r, :len(d)] = d
+    hits = np.zeros(g.nboxes, np.int64)
+    cumul = np.zeros(g.nboxes, np.int64)
+    src_off = 0
+    for r, t in enumerate(locs):
+        starts, deep = global_box_numbering(plan, lc, r)
+        assert np.array_equal(starts, g.level_start_box_nrs)
+        m = local_to_global_box_ids(t, plan, starts, deep, bbox_min, root_extent).cpu().numpy()
+        h = actx.to_numpy(t)
+        nb = h.nboxes
+        assert len(set(m.tolist())) == nb
+        hits[m] += 1
+        assert np.array_equal(g.box_levels[m], h.box_levels)
+        assert np.array_equal(g.box_centers[:, m], h.box_centers[:, :nb])
+        assert np.array_equal(g.box_parent_ids[m], m[h.box_parent_ids])
+        ch = h.box_child_ids[:, :nb]
+        mapped = np.where(ch != 0, m[ch], 0)
+        gch = g.box_child_ids[:, m]
+        deep_box = h.box_levels > level
+        assert np.array_equal(mapped[:, deep_box], gch[:, deep_box])
+        assert np.all((mapped == 0) | (mapped == gch))          # shared top boxes: a subset
+        cumul[m] += h.box_source_counts_cumul
+        for name in ("box_source_counts_cumul", "box_source_counts_nonchild", "box_flags"):
+            assert np.array_equal(getattr(g, name)[m][deep_box], getattr(h, name)[deep_box])
+        assert np.array_equal(g.box_source_starts[m][deep_box],
+                              h.box_source_starts[deep_box] + src_off)
+        # a shared top box starts where its first owner's share starts
+        first = hits[m] == 1
+        top_first = first & ~deep_box
+        assert np.array_equal(g.box_source_starts[m][top_first],
+                              h.box_source_starts[top_first] + src_off)
+        # particle order: the rank's slice of the global tree order
+        ns = h.nsources
+        assert np.array_equal(g.user_source_ids[src_off:src_off + ns], gids[r][h.user_source_ids])
+        for ax in range(dims):
+            assert np.array_equal(g.sources[ax][src_off:src_off + ns], h.sources[ax])
+        src_off += ns
+    assert src_off == n
+    assert np.all(hits >= 1)
+    assert np.all(hits[g.box_levels > level] == 1)
+    assert np.array_equal(cumul, g.box_source_counts_cumul)
