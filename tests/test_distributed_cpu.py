@@ -109,3 +109,116 @@ def test_partition_cells_is_deterministic():
     assert np.all(np.diff(o1) >= 0) and o1.min() == 0 and o1.max() == 7
     loads = np.bincount(o1, weights=hist, minlength=8)
     assert loads.max() < 1.2 * hist.sum() / 8
+
+
+def _reference_top_tree(hist, dims, k, mpb):
+    """Plain recursive statement of the top of the adaptive tree."""
+    C = 1 << dims
+    boxes = {0: [0]}        # level -> paths of existing boxes
+
+    def count(level, path):
+        sh = dims * (k - level)
+        return int(hist[path << sh:(path + 1) << sh].sum())
+
+    leaves = []             # (level, path) of frontier boxes
+    for lev in range(k):
+        nxt = []
+        for path in boxes[lev]:
+            if count(lev, path) > mpb:
+                for m in range(C):
+                    child = path * C + m
+                    if count(lev + 1, child) > 0:
+                        nxt.append(child)
+            else:
+                leaves.append((lev, path))
+        boxes[lev + 1] = nxt
+    leaves += [(k, p) for p in boxes[k]]
+    return boxes, leaves
+
+
+@pytest.mark.parametrize("dims,k", [(2, 4), (3, 3)])
+def test_top_tree_plan_and_numbering(dims, k):
+    from boxtree_amd.distributed import global_box_numbering, partition_cells, top_tree_plan
+    rng = np.random.default_rng(3)
+    C = 1 << dims
+    hist = rng.integers(0, 40, C ** k)
+    hist[rng.random(C ** k) < 0.5] = 0
+    hist[: C ** k // 4] = rng.integers(0, 2, C ** k // 4)       # a sparse quarter
+    mpb = 30
+    plan = top_tree_plan(hist, dims, k, mpb)
+    boxes, leaves = _reference_top_tree(hist, dims, k, mpb)
+    for lev in range(k + 1):
+        assert np.nonzero(plan["exists"][lev])[0].tolist() == boxes[lev]
+        assert plan["nboxes"][lev] == len(boxes[lev])
+        assert plan["index"][lev][boxes[lev]].tolist() == list(range(len(boxes[lev])))
+    # every frontier box is one ownership unit
+    world = 3
+    owner = partition_cells(hist, world, plan["unit_start"])
+    assert np.all(np.diff(owner) >= 0)
+    for lev, path in leaves:
+        sh = dims * (k - lev)
+        assert len(set(owner[path << sh:(path + 1) << sh].tolist())) == 1
+        assert np.all(plan["unit_start"][path << sh:(path + 1) << sh] == path << sh)
+    assert plan["cell_prefix"][-1] == hist.sum() and plan["cell_prefix"][0] == 0
+
+    # numbering: shared top levels by plan, deep levels rank-major
+    lc = np.zeros((world, 64), np.int64)
+    for r in range(world):
+        lc[r, :k + 1] = 1                      # (content of the top levels is not used)
+        lc[r, k + 1:k + 4] = rng.integers(1, 50, 3)
+    lc[2, k + 3] = 0                           # rank 2's tree is one level shallower
+    for r in range(world):
+        starts, deep = global_box_numbering(plan, lc, r)
+        assert len(starts) == k + 5
+        for lev in range(k + 1):
+            assert starts[lev + 1] - starts[lev] == len(boxes[lev])
+        for lev in range(k + 1, k + 4):
+            assert starts[lev + 1] - starts[lev] == lc[:, lev].sum()
+            assert deep[lev] == starts[lev] + lc[:r, lev].sum()
+
+
+def _plan_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from boxtree_amd.distributed import exchange_particles, morton_cells
+        rng = np.random.default_rng(40 + rank)
+        n = 30000
+        # a dense blob and a thin background: light top cells exist
+        pts = [torch.from_numpy(np.concatenate([0.05 * rng.standard_normal(n - 300) + 0.6,
+                                                rng.random(300)])) for _ in range(3)]
+        newp, _, nkw, st = exchange_particles(None, dist, pts, None, {}, top_level=3,
+                                              return_plan=True, max_particles_in_box=30)
+        cells = morton_cells(newp, st["bbox_min"], st["bbox_max"], 3).numpy()
+        plan = st["plan"]
+        q.put(dict(rank=rank, owner=st["owner"], cells=cells, unit_start=plan["unit_start"],
+                   total=int(plan["cell_prefix"][-1]), n=len(newp[0]),
+                   has_top=("_top_tree" in nkw)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_with_top_tree_plan_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    a, b = results
+    assert np.array_equal(a["owner"], b["owner"]) and np.array_equal(a["unit_start"], b["unit_start"])
+    assert a["total"] == b["total"] == 60000 == a["n"] + b["n"]
+    owner, unit = a["owner"], a["unit_start"]
+    assert np.all(np.diff(owner) >= 0)
+    assert np.array_equal(owner, owner[unit])       # frontier boxes are not cut
+    for r in results:
+        assert np.all(owner[r["cells"]] == r["rank"])
+        assert not r["has_top"]                     # device prefix only on the GPU path
