@@ -157,6 +157,7 @@ def main():
 
     def step():
         p_, t_, kw_ = particles, targets, build_kw
+        xs = None
         if distributed:
             # the exchange is part of the path (and of the timed step) for N > 1
             from boxtree_amd.distributed import exchange_particles
@@ -167,13 +168,26 @@ def main():
         tree, _ = tb(actx, p_, targets=t_, max_particles_in_box=args.mpb, **kw_)
         st = _lib.SortStats()
         actx.lib.bt_get_sort_stats(actx.handle, st)
-        trav, _ = tg(actx, tree)
         times = dict(tb.last_stage_times)
+        if distributed and xs["plan"] is not None:
+            # global box numbers, box arrays of all ranks, then the interaction lists
+            # of this rank's boxes (cross-boundary lists included)
+            from boxtree_amd.distributed import gather_global_box_tree, number_sharded_tree
+            num = number_sharded_tree(dist, tree, xs)
+            gtree = gather_global_box_tree(actx, dist, tree, num)
+            trav, _ = tg(actx, gtree, _target_boxes_mask=num["target_boxes_mask"],
+                         _active_level_ranges=num["active_level_ranges"])
+            xinfo.update(global_nboxes=int(num["nboxes"]), sharded_traversal="global box "
+                         "arrays all-gathered; lists for own boxes + shared top levels")
+            nboxes, nlevels = int(num["nboxes"]), int(gtree.nlevels)
+        else:
+            trav, _ = tg(actx, tree)
+            nboxes, nlevels = int(tree.nboxes), int(tree.nlevels)
         stt = _lib.StageTimes()
         actx.lib.bt_get_stage_times(actx.handle, stt)
         for i in range(stt.n):
             times[stt.name[i].decode()] = float(stt.ms[i])
-        info.update(nboxes=int(tree.nboxes), nlevels=int(tree.nlevels),
+        info.update(nboxes=nboxes, nlevels=nlevels,
                     n_list1=int(trav.neighbor_source_boxes_lists.shape[0]),
                     n_list2=int(trav.from_sep_siblings_lists.shape[0]),
                     n_colleagues=int(trav.same_level_non_well_sep_boxes_lists.shape[0]))

@@ -98,6 +98,7 @@ class TravParams(ct.Structure):
         ("from_sep_smaller_min_nsources_cumul", ct.c_int32),
         ("source_boxes_mask", vp), ("source_parent_boxes_mask", vp),
         ("force_generic", ct.c_int32),
+        ("target_boxes_mask", vp), ("active_level_ranges", ct.POINTER(ct.c_int32)),
     ]
 
 

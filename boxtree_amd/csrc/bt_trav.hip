@@ -785,7 +785,24 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     Buf<int32_t> totals_d;
     BT_CHECK(totals_d.alloc(ctx->pool, 2));
     for (int lev = 1; lev < nlevels; ++lev) {
-        const int32_t b0 = ls[lev], nb = ls[lev + 1] - ls[lev];
+        int32_t b0 = ls[lev], nb = ls[lev + 1] - ls[lev];
+        if (p.active_level_ranges) {        // sharded traversal: this rank's boxes only
+            b0 = p.active_level_ranges[2 * lev];
+            nb = p.active_level_ranges[2 * lev + 1] - b0;
+        }
+        // keep both CSR start arrays monotone over the boxes outside the range
+        auto fill_outside = [&](int32_t lo, int32_t hi, int64_t cv, int64_t lv) {
+            if (hi <= lo) return;
+            fill_i32_kernel<<<nblk(hi - lo), 256, 0, ctx->stream>>>(hi - lo, (int32_t) cv,
+                                                                   coll.starts.get() + lo);
+            fill_i32_kernel<<<nblk(hi - lo), 256, 0, ctx->stream>>>(hi - lo, (int32_t) lv,
+                                                                   l2_by_box.get() + lo);
+        };
+        if (nb <= 0) {
+            fill_outside(ls[lev], ls[lev + 1] + (lev == nlevels - 1 ? 1 : 0), coll_total, l2_total);
+            continue;
+        }
+        fill_outside(ls[lev], b0, coll_total, l2_total);
         Buf<int32_t> ccnt, lcnt, crel, lrel;
         BT_CHECK(ccnt.alloc(ctx->pool, nb));
         BT_CHECK(lcnt.alloc(ctx->pool, nb));
@@ -816,6 +833,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         coll_l2_kernel<T, D, true><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(a, b0, nb, of);
         coll_total += h_tot[0];
         l2_total += h_tot[1];
+        fill_outside(b0 + nb + 1, ls[lev + 1] + (lev == nlevels - 1 ? 1 : 0), coll_total, l2_total);
     }
     coll.total = coll_total;
     a.coll_starts = coll.starts.get();
@@ -952,13 +970,14 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     BT_CHECK(compact_boxes(ctx, p, BT_BOX_IS_SOURCE_BOX, p.source_boxes_mask, st->source_boxes, &st->nsb));
     BT_CHECK(compact_boxes(ctx, p, BT_BOX_HAS_SOURCE_CHILD_BOXES, p.source_parent_boxes_mask,
                            st->source_parent_boxes, &st->nspb));
-    BT_CHECK(compact_boxes(ctx, p, BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX, nullptr,
-                           st->ttp_boxes, &st->nttp));
-    if (sat) {
+    BT_CHECK(compact_boxes(ctx, p, BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX,
+                           p.target_boxes_mask, st->ttp_boxes, &st->nttp));
+    if (sat && !p.target_boxes_mask) {
         st->target_boxes = st->source_boxes.get();
         st->ntb = st->nsb;
     } else {
-        BT_CHECK(compact_boxes(ctx, p, BT_BOX_IS_TARGET_BOX, nullptr, st->target_boxes_buf, &st->ntb));
+        BT_CHECK(compact_boxes(ctx, p, BT_BOX_IS_TARGET_BOX, p.target_boxes_mask,
+                               st->target_boxes_buf, &st->ntb));
         st->target_boxes = st->target_boxes_buf.get();
     }
 
@@ -1227,7 +1246,7 @@ int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
     BT_HIP_CHECK(hipSetDevice(ctx->device));
     const int nl = st->nlevels;
     BT_CHECK(copy_i32(ctx, o->source_boxes, st->source_boxes.get(), st->nsb));
-    if (!st->p.sources_are_targets)
+    if (!st->p.sources_are_targets || st->p.target_boxes_mask)
         BT_CHECK(copy_i32(ctx, o->target_boxes, st->target_boxes, st->ntb));
     BT_CHECK(copy_i32(ctx, o->source_parent_boxes, st->source_parent_boxes.get(), st->nspb));
     BT_CHECK(copy_i32(ctx, o->target_or_target_parent_boxes, st->ttp_boxes.get(), st->nttp));

@@ -237,6 +237,12 @@ __global__ __launch_bounds__(256) void add_base_kernel(int32_t n, const int32_t 
     if (i < n) dst[i] = rel[i] + base;
 }
 
+__global__ __launch_bounds__(256) void fill_i32_kernel(int32_t n, int32_t value, int32_t *dst)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = value;
+}
+
 __global__ __launch_bounds__(256) void gather_starts_kernel(int32_t n, const int32_t *boxes,
         const int32_t *starts_by_box, int32_t total, int32_t *out)
 {

@@ -186,6 +186,28 @@ def global_box_numbering(plan, level_counts_by_rank, rank):
     return starts, deep_base
 
 
+def active_boxes(plan, global_level_starts, deep_base, level_counts, device=None):
+    """Step 6: the boxes rank-local lists are built for -- every box of the shared
+    top levels plus the rank's own boxes below -- as ``(mask, ranges)``: an int8
+    mask over the global boxes and per level the box range [begin, end) holding
+    them (``_target_boxes_mask`` / ``_active_level_ranges`` of
+    :class:`~boxtree_amd.traversal.FMMTraversalBuilder`)."""
+    import torch
+    k = plan["top_level"]
+    nlevels = len(global_level_starts) - 1
+    ranges = np.zeros((nlevels, 2), dtype=np.int32)
+    mask = torch.zeros(int(global_level_starts[-1]), dtype=torch.int8, device=device)
+    for lev in range(nlevels):
+        if lev <= k:
+            b0, b1 = int(global_level_starts[lev]), int(global_level_starts[lev + 1])
+        else:
+            b0 = int(deep_base[lev])
+            b1 = b0 + int(level_counts[lev])
+        ranges[lev] = (b0, b1)
+        mask[b0:b1] = 1
+    return mask, ranges
+
+
 def local_to_global_box_ids(tree, plan, global_level_starts, deep_base, bbox_min, root_extent):
     """int64 tensor [local nboxes] of global box numbers (see
     :func:`global_box_numbering`).  Boxes at levels <= top_level are located by the
@@ -416,8 +438,74 @@ def number_sharded_tree(dist, tree, stats):
     starts, deep_base = global_box_numbering(plan, allc[:, :nmax], rank)
     box_ids = local_to_global_box_ids(tree, plan, starts, deep_base, stats["bbox_min"],
                                       stats["root_extent"])
+    mask, ranges = active_boxes(plan, starts, deep_base, allc[rank, :nmax], dev)
     return dict(
+        nboxes_by_rank=allc[:, :nmax].sum(axis=1), target_boxes_mask=mask,
+        active_level_ranges=ranges, deep_base=deep_base,
         box_ids=box_ids, global_level_start_box_nrs=starts,
         source_offset=int(allc[:rank, nmax].sum()), target_offset=int(allc[:rank, nmax + 1].sum()),
         nboxes=int(starts[-1]), nsources=int(allc[:, nmax].sum()),
         ntargets=int(allc[:, nmax + 1].sum()))
+
+
+def gather_global_box_tree(actx, dist, tree, numbering):
+    """Step 6: all-gathers the box arrays of the ranks' local trees into the global
+    numbering.  Every rank gets the complete :class:`~boxtree_amd.tree.TreeOfBoxes`
+    (centres, levels, flags, parents, children, level starts) the traversal kernels
+    walk; particles stay where they are.  ``box_flags`` of the shared top boxes are
+    the OR, ``box_child_ids`` the union of the ranks' views."""
+    import torch
+
+    from boxtree_amd.tree import TreeOfBoxes
+    world = dist.get_world_size()
+    dims = int(tree.dimensions)
+    C = 1 << dims
+    nb = int(tree.nboxes)
+    ids = numbering["box_ids"]
+    dev = ids.device
+    nmax = int(np.max(numbering["nboxes_by_rank"]))
+    B = int(numbering["nboxes"])
+    aligned = -(-B // 32) * 32
+    ch = tree.box_child_ids[:, :nb].long()
+    ch_g = torch.where(ch != 0, ids[ch], torch.zeros_like(ch)).to(torch.int32)
+    par_g = ids[tree.box_parent_ids.long()].to(torch.int32)
+
+    def gathered(t, fill=0):
+        """[world][nmax, ...] views of every rank's (padded) array."""
+        pad = torch.full((nmax,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=dev)
+        pad[:nb] = t
+        out = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(out, pad)
+        return out
+
+    g_ids = gathered(ids.to(torch.int32))
+    g_ctr = gathered(tree.box_centers[:, :nb].t().contiguous())
+    g_lev = gathered(tree.box_levels)
+    g_flg = gathered(tree.box_flags)
+    g_par = gathered(par_g)
+    g_ch = gathered(ch_g.t().contiguous())
+    centers = torch.zeros((dims, aligned), dtype=tree.box_centers.dtype, device=dev)
+    levels = torch.zeros(B, dtype=torch.uint8, device=dev)
+    flags = torch.zeros(B, dtype=torch.uint8, device=dev)
+    parents = torch.zeros(B, dtype=torch.int32, device=dev)
+    children = torch.zeros((C, aligned), dtype=torch.int32, device=dev)
+    for r in range(world):
+        n = int(numbering["nboxes_by_rank"][r])
+        if n == 0:
+            continue
+        gi = g_ids[r][:n].long()
+        centers[:, gi] = g_ctr[r][:n].t()
+        levels[gi] = g_lev[r][:n]
+        parents[gi] = g_par[r][:n]
+        # shared top boxes are seen by several ranks (ids are unique within a rank)
+        flags[gi] |= g_flg[r][:n]
+        children[:, gi] = torch.maximum(children[:, gi], g_ch[r][:n].t())
+    starts = numbering["global_level_start_box_nrs"].astype(np.int32)
+    coord_dtype = np.dtype(str(tree.box_centers.dtype).replace("torch.", ""))
+    return TreeOfBoxes(
+        root_extent=tree.root_extent, box_centers=centers, box_parent_ids=parents,
+        box_child_ids=children, box_levels=levels, box_flags=flags,
+        level_start_box_nrs=starts, box_id_dtype=np.dtype(np.int32),
+        box_level_dtype=np.dtype(np.uint8), coord_dtype=coord_dtype,
+        sources_have_extent=False, targets_have_extent=False, extent_norm=None,
+        stick_out_factor=tree.stick_out_factor, _is_pruned=True)

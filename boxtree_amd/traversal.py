@@ -136,7 +136,7 @@ class FMMTraversalBuilder:
     def __call__(self, actx, tree, wait_for=None, debug=False,
                  _from_sep_smaller_min_nsources_cumul=None,
                  source_boxes_mask=None, source_parent_boxes_mask=None,
-                 _force_generic=None):
+                 _force_generic=None, _target_boxes_mask=None, _active_level_ranges=None):
         """Same arguments, return value ``(trav, event)`` and exceptions as
         ``FMMTraversalBuilder.__call__`` (traversal.py:1969-1990).
 
@@ -235,6 +235,15 @@ class FMMTraversalBuilder:
             import os
             _force_generic = os.environ.get("BOXTREE_HIP_FORCE_GENERIC", "0") == "1"
         tp.force_generic = int(bool(_force_generic))
+        # sharded traversals (boxtree_amd/distributed.py step 6): lists of a subset
+        # of the target boxes of a tree whose box arrays are complete
+        tbm = dev(_target_boxes_mask)
+        tp.target_boxes_mask = ptr(tbm)
+        alr = None
+        if _active_level_ranges is not None:
+            alr = np.ascontiguousarray(_active_level_ranges, dtype=np.int32).reshape(-1)
+            assert alr.shape[0] == 2 * nlevels
+            tp.active_level_ranges = alr.ctypes.data_as(ct.POINTER(ct.c_int32))
 
         lib = actx.lib
         sizes = _lib.TravSizes()
@@ -256,7 +265,8 @@ class FMMTraversalBuilder:
         source_boxes = e(int(sizes.nsource_boxes), i32)
         source_parent_boxes = e(int(sizes.nsource_parent_boxes), i32)
         target_or_target_parent_boxes = e(nttp, i32)
-        target_boxes = source_boxes if sources_are_targets else e(ntb, i32)
+        target_boxes = (source_boxes if sources_are_targets and tbm is None
+                        else e(ntb, i32))
         out.source_boxes = ptr(source_boxes)
         out.target_boxes = ptr(target_boxes)
         out.source_parent_boxes = ptr(source_parent_boxes)

@@ -209,6 +209,15 @@ typedef struct {
     int32_t force_generic;     /* 1: always use the walk-from-root kernels (any tree);
                                   0: use the parent-colleague kernels when the box
                                   numbering is verified level-major/depth-first      */
+    /* Sharded traversals only (no counterpart in the reference): build the lists of
+     * a subset of the target boxes of a tree whose box arrays are complete.
+     * target_boxes_mask[nboxes] (device, or NULL = all) filters target_boxes and
+     * target_or_target_parent_boxes the way source_boxes_mask filters source_boxes;
+     * active_level_ranges[2*nlevels] (HOST, or NULL) gives per level the box range
+     * [begin, end) that contains every masked box and their ancestors -- colleague
+     * lists are only built (and only valid) inside these ranges. */
+    const int8_t *target_boxes_mask;
+    const int32_t *active_level_ranges;
 } bt_trav_params;
 
 typedef struct {

@@ -222,3 +222,85 @@ def test_exchange_with_top_tree_plan_world2():
     for r in results:
         assert np.all(owner[r["cells"]] == r["rank"])
         assert not r["has_top"]                     # device prefix only on the GPU path
+
+
+def _gather_worker(rank, world, port, q):
+    """Steps 5+6 over gloo with CPU-built local trees (the oracle stands in for the
+    device build here; the device build itself is checked in the gpu tests)."""
+    import sys
+    from types import SimpleNamespace
+
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from oracle import oracle
+        from boxtree_amd.distributed import (gather_global_box_tree, morton_cells,
+                                             number_sharded_tree, partition_cells,
+                                             top_tree_plan)
+        dims, k, mpb = 2, 2, 30
+        rng = np.random.default_rng(77)
+        allpts = [rng.random(20000) * 1.9 + 0.05 for _ in range(dims)]     # same on all ranks
+        bbox = np.array([[0.0, 2.0]] * dims)
+        tp = [torch.from_numpy(a) for a in allpts]
+        cells = morton_cells(tp, bbox[:, 0], bbox[:, 1], k).numpy()
+        hist = np.bincount(cells, minlength=4 ** k)
+        assert hist.min() > mpb            # every top cell is heavy: no top-tree hint needed
+        plan = top_tree_plan(hist, dims, k, mpb)
+        owner = partition_cells(hist, world, plan["unit_start"])
+        mine = owner[cells] == rank
+        ot = oracle.build_tree([a[mine] for a in allpts], max_particles_in_box=mpb, bbox=bbox)
+        tree = SimpleNamespace(
+            dimensions=dims, nboxes=ot.nboxes, nsources=ot.nsources, ntargets=ot.ntargets,
+            level_start_box_nrs=ot.level_start_box_nrs, root_extent=ot.root_extent,
+            stick_out_factor=ot.stick_out_factor,
+            box_centers=torch.from_numpy(ot.box_centers), box_levels=torch.from_numpy(ot.box_levels),
+            box_flags=torch.from_numpy(ot.box_flags),
+            box_parent_ids=torch.from_numpy(ot.box_parent_ids),
+            box_child_ids=torch.from_numpy(ot.box_child_ids))
+        stats = dict(plan=plan, bbox_min=bbox[:, 0], root_extent=ot.root_extent)
+        num = number_sharded_tree(dist, tree, stats)
+        gt = gather_global_box_tree(None, dist, tree, num)
+        res = dict(rank=rank, nboxes=num["nboxes"], starts=num["global_level_start_box_nrs"],
+                   centers=gt.box_centers.numpy(), levels=gt.box_levels.numpy(),
+                   flags=gt.box_flags.numpy(), parents=gt.box_parent_ids.numpy(),
+                   children=gt.box_child_ids.numpy(), src_off=num["source_offset"],
+                   ranges=num["active_level_ranges"])
+        if rank == 0:
+            g = oracle.build_tree(allpts, max_particles_in_box=mpb, bbox=bbox)
+            res["g"] = dict(nboxes=g.nboxes, starts=g.level_start_box_nrs,
+                            centers=g.box_centers, levels=g.box_levels, flags=g.box_flags,
+                            parents=g.box_parent_ids, children=g.box_child_ids)
+        q.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_number_and_gather_world2(oracle):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted([q.get(timeout=300) for _ in range(2)], key=lambda r: r["rank"])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = results[0]["g"]
+    for r in results:
+        # every rank holds the box arrays of the tree one process builds from all points
+        assert r["nboxes"] == g["nboxes"]
+        assert np.array_equal(r["starts"], g["starts"])
+        for name in ("centers", "levels", "flags", "parents", "children"):
+            assert np.array_equal(r[name], g[name]), name
+    assert results[0]["src_off"] == 0 and results[1]["src_off"] > 0
+    # the ranks' deep ranges tile every level
+    r0, r1 = results[0]["ranges"], results[1]["ranges"]
+    for lev in range(3, len(r0)):
+        assert r0[lev][1] == r1[lev][0]
+        assert r0[lev][0] == g["starts"][lev] and r1[lev][1] == g["starts"][lev + 1]

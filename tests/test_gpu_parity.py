@@ -556,3 +556,93 @@ def test_sharded_build_global_numbering(actx, dims, dist_kind):
     assert np.all(hits >= 1)
     assert np.all(hits[g.box_levels > level] == 1)
     assert np.array_equal(cumul, g.box_source_counts_cumul)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,dist_kind", [(3, "uniform"), (3, "clustered"), (2, "normal")])
+def test_sharded_traversal_is_a_slice_of_the_global_one(actx, dims, dist_kind):
+    """distributed.py step 6: the lists built for one rank's boxes (all shared top
+    boxes + its own subtrees) on the complete box arrays are the rows of the
+    single-GPU traversal for those boxes."""
+    import torch
+    from boxtree_amd import FMMTraversalBuilder, TreeBuilder
+    from boxtree_amd.distributed import (ROOT_EXTENT_STRETCH_FACTOR, active_boxes,
+                                         global_box_numbering, morton_cells, partition_cells,
+                                         top_tree_plan)
+    rng = np.random.default_rng(12)
+    n, world, level, mpb = 200000, 3, 3 if dims == 3 else 4, 30
+    if dist_kind == "normal":
+        host = [rng.standard_normal(n) for _ in range(dims)]
+    elif dist_kind == "uniform":
+        host = [rng.random(n) for _ in range(dims)]
+    else:
+        host = [np.concatenate([0.03 * rng.standard_normal(n - 500) + 0.6, rng.random(500)])
+                for _ in range(dims)]
+    pts = [torch.from_numpy(h).cuda() for h in host]
+    gmin = np.array([float(p.min()) for p in pts])
+    gmax = np.array([float(p.max()) for p in pts])
+    root_extent = max(gmax - gmin) * (1 + ROOT_EXTENT_STRETCH_FACTOR)
+    bbox_min = gmin.copy()
+    cells = morton_cells(pts, bbox_min, bbox_min + root_extent, level).cpu().numpy()
+    C = 1 << dims
+    hist = np.bincount(cells, minlength=C ** level)
+    plan = top_tree_plan(hist, dims, level, mpb)
+    owner_of_cell = partition_cells(hist, world, plan["unit_start"])
+    tree, _ = TreeBuilder(actx)(actx, pts, max_particles_in_box=mpb)
+    g = actx.to_numpy(tree)
+    full = actx.to_numpy(FMMTraversalBuilder(actx)(actx, tree)[0])
+
+    # boxes per level and rank, as the ranks' local trees would report them: a box
+    # below the top levels belongs to the owner of its level-`level` cell
+    lvl = g.box_levels.astype(np.int64)
+    nb = g.nboxes
+    path = np.zeros(nb, np.int64)
+    for ax in range(dims):
+        v = np.floor((g.box_centers[ax, :nb] - bbox_min[ax]) / root_extent * 2.0 ** lvl).astype(np.int64)
+        for b in range(int(lvl.max()) + 1):
+            path |= ((v >> b) & 1) << (dims * b + (dims - 1 - ax))
+    deep = lvl > level
+    cell_of_box = path >> np.where(deep, dims * (lvl - level), 0)
+    box_owner = np.where(deep, owner_of_cell[np.where(deep, cell_of_box, 0)], -1)
+    lc = np.zeros((world, 64), np.int64)
+    for r in range(world):
+        lc[r, :level + 1] = 1
+        for lev in range(level + 1, g.nlevels):
+            lc[r, lev] = int(np.sum((lvl == lev) & (box_owner == r)))
+
+    def rows(starts, lists, sel):
+        return [lists[starts[i]:starts[i + 1]].tolist() for i in sel]
+
+    for r in range(world):
+        starts, deep_base = global_box_numbering(plan, lc, r)
+        assert np.array_equal(starts, g.level_start_box_nrs)
+        mask, ranges = active_boxes(plan, starts, deep_base, lc[r], "cuda")
+        hm = mask.cpu().numpy().astype(bool)
+        assert np.array_equal(hm, (~deep) | (box_owner == r))
+        t = actx.to_numpy(FMMTraversalBuilder(actx)(
+            actx, tree, _target_boxes_mask=mask, _active_level_ranges=ranges)[0])
+        sel_t = np.nonzero(hm[full.target_boxes])[0]
+        sel_p = np.nonzero(hm[full.target_or_target_parent_boxes])[0]
+        assert np.array_equal(t.target_boxes, full.target_boxes[sel_t])
+        assert np.array_equal(t.target_or_target_parent_boxes,
+                              full.target_or_target_parent_boxes[sel_p])
+        assert np.array_equal(t.source_boxes, full.source_boxes)
+        act = np.nonzero(hm)[0]
+        assert rows(t.same_level_non_well_sep_boxes_starts, t.same_level_non_well_sep_boxes_lists,
+                    act) == rows(full.same_level_non_well_sep_boxes_starts,
+                                 full.same_level_non_well_sep_boxes_lists, act)
+        assert np.all(np.diff(t.same_level_non_well_sep_boxes_starts) >= 0)
+        for name, sel in (("neighbor_source_boxes", sel_t), ("from_sep_siblings", sel_p),
+                          ("from_sep_bigger", sel_p)):
+            got = rows(getattr(t, name + "_starts"), getattr(t, name + "_lists"),
+                       range(len(sel)))
+            want = rows(getattr(full, name + "_starts"), getattr(full, name + "_lists"), sel)
+            assert got == want, name
+        for lev in range(g.nlevels):
+            a, b = t.from_sep_smaller_by_level[lev], full.from_sep_smaller_by_level[lev]
+            got = {int(tb): a.lists[a.starts[i]:a.starts[i + 1]].tolist()
+                   for i, tb in enumerate(t.target_boxes_sep_smaller_by_source_level[lev])}
+            want = {int(tb): b.lists[b.starts[i]:b.starts[i + 1]].tolist()
+                    for i, tb in enumerate(full.target_boxes_sep_smaller_by_source_level[lev])
+                    if hm[tb]}
+            assert got == want
