@@ -44,6 +44,8 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=16_000_000,
                     help="particles in the CPU-baseline sample (0 disables)")
     ap.add_argument("--mpb", type=int, default=64)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 code path (exchange, numbering, gather) even with one rank")
     return ap.parse_args()
 
 
@@ -128,8 +130,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
