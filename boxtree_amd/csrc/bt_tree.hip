@@ -267,6 +267,7 @@ struct BuildArgs {
     int b0, nprev;              // boxes of level-1: [b0, b0+nprev)
     int new_level_start;
     int adaptive;
+    int keep_empty;             // skip_prune: empty children become boxes too
     int top_level;              // sharded builds: levels above it use global counts
     const int64_t *top_prefix;  // [C^top_level + 1] or null
 };
@@ -341,10 +342,12 @@ __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
         }
         split = false;
     }
-    if (e == s) split = false;   // (pruned trees have no empty boxes)
+    // empty boxes exist only with skip_prune; "non-adaptive" splits them like any
+    // other box of the level (tbk:593-597), "adaptive" never does (weight 0)
+    if (e == s && (a.adaptive || !a.keep_empty)) split = false;
 
     const int cnt = hi - lo;
-    const bool nonempty = split && cnt > 0;
+    const bool nonempty = split && (cnt > 0 || a.keep_empty);
     const uint64_t bal = __ballot(nonempty);
     const int gshift = (threadIdx.x & 63) / C * C;
     const uint32_t gmask = (uint32_t) ((bal >> gshift) & ((1ull << C) - 1));
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256) void write_children_kernel(BuildArgs a, T *cen
         lo = a.bounds[(int64_t) bl * (C + 1) + m];
         hi = a.bounds[(int64_t) bl * (C + 1) + m + 1];
     }
-    const bool nonempty = split && hi > lo;
+    const bool nonempty = split && (hi > lo || a.keep_empty);
     const uint64_t bal = __ballot(nonempty);
     if (!active) return;
     const int gshift = (threadIdx.x & 63) / C * C;
@@ -393,7 +396,9 @@ __global__ __launch_bounds__(256) void write_children_kernel(BuildArgs a, T *cen
     int32_t child_id = 0;
     if (nonempty) {
         child_id = a.new_level_start + a.offsets[bl] + rank;     // tbk:667 (after pruning)
-        a.box_start[child_id] = lo;
+        // an empty child (skip_prune) keeps start 0: tbk:680-695 only sets the start
+        // "if the new box has particles to begin with"
+        a.box_start[child_id] = hi > lo ? lo : 0;
         a.box_count[child_id] = hi - lo;
         a.box_parent[child_id] = b;
         a.box_level[child_id] = (uint8_t) a.level;
@@ -912,6 +917,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         a.adaptive = p.kind != BT_KIND_NON_ADAPTIVE;
         a.top_level = p.top_level;
         a.top_prefix = p.top_cell_prefix;
+        a.keep_empty = p.skip_prune ? 1 : 0;
 
         const unsigned blocks = (unsigned) div_up((int64_t) nprev * C, 256);
         if (EXT) count_children_kernel<D, true><<<blocks, 256, 0, ctx->stream>>>(a);
@@ -1179,10 +1185,6 @@ int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
     if (p->kind != BT_KIND_ADAPTIVE && p->kind != BT_KIND_NON_ADAPTIVE) {
         set_error("unknown tree kind %d", p->kind);
         return BT_ERR_INVALID;
-    }
-    if (p->skip_prune) {
-        set_error("skip_prune (unpruned trees) is not implemented");
-        return BT_ERR_UNSUPPORTED;
     }
     if (p->max_leaf_refine_weight <= 0) {
         set_error("'max_leaf_refine_weight' must be positive");

@@ -433,7 +433,7 @@ class TreeBuilder:
             box_target_bounding_box_min=box_target_bounding_box_min,
             box_target_bounding_box_max=box_target_bounding_box_max,
 
-            _is_pruned=True,
+            _is_pruned=not kwargs.get("skip_prune"),
         )
 
         return actx.freeze(tree), DoneEvent()

@@ -646,3 +646,30 @@ def test_sharded_traversal_is_a_slice_of_the_global_one(actx, dims, dist_kind):
                     for i, tb in enumerate(full.target_boxes_sep_smaller_by_source_level[lev])
                     if hm[tb]}
             assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["adaptive", "non-adaptive"])
+def test_skip_prune(actx, oracle, dims, kind):
+    """Unpruned trees (tree_build.py:1328-1332: skip_prune keeps the empty
+    children of every split box)."""
+    from boxtree_amd import FMMTraversalBuilder, TreeBuilder
+    p = normal_particles(20000, dims, np.float64, seed=3)
+    htree, otree, _, _ = build_both(actx, oracle, p, max_particles_in_box=25, kind=kind,
+                                    skip_prune=True)
+    assert not htree._is_pruned
+    assert np.any(htree.box_source_counts_cumul == 0) or dims == 1
+    tree, _ = TreeBuilder(actx)(actx, [actx.from_numpy(x) for x in p],
+                                max_particles_in_box=25, skip_prune=True)
+    with pytest.raises(ValueError):         # traversal.py:1999-2000
+        FMMTraversalBuilder(actx)(actx, tree)
+
+
+@pytest.mark.gpu
+def test_skip_prune_source_target_extents(actx, oracle):
+    s = normal_particles(20000, 3, np.float64, seed=12)
+    t = normal_particles(30000, 3, np.float64, seed=19)
+    tr = 2 ** np.random.default_rng(13).uniform(-10, 0, 30000)
+    build_both(actx, oracle, s, targets=t, target_radii=tr, stick_out_factor=0.25,
+               max_particles_in_box=20, skip_prune=True)
