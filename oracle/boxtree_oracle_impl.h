@@ -38,7 +38,7 @@
 
 enum { ORC_OK = 0, ORC_ERR_MAX_LEVELS = 1, ORC_ERR_ALLOC = 2, ORC_ERR_INTERNAL = 3 };
 enum { ORC_NORM_NONE = 0, ORC_NORM_LINF = 1, ORC_NORM_L2 = 2 };
-enum { ORC_KIND_ADAPTIVE = 0, ORC_KIND_NON_ADAPTIVE = 2 };
+enum { ORC_KIND_ADAPTIVE = 0, ORC_KIND_ADAPTIVE_LEVEL_RESTRICTED = 1, ORC_KIND_NON_ADAPTIVE = 2 };
 enum { ORC_CRIT_STATIC_LINF = 0, ORC_CRIT_PRECISE_LINF = 1, ORC_CRIT_STATIC_L2 = 2 };
 
 /* box flags: boxtree/tree.py:109-145 */
@@ -276,6 +276,25 @@ static inline int32_t SFX(orc_get_count)(const orc_mc_t *c, int morton_nr)
         if (ptr) { memcpy(np_, ptr, (size_t) (oldn) * sizeof(type)); free(ptr); } \
         ptr = np_; } while (0)
 
+/* is_adjacent_or_overlapping as instantiated for LEVEL_RESTRICT_TPL
+ * (traversal.py:279-318 via tbk:960-965; target = walk box, source = my box) */
+static inline int SFX(orc_lr_is_adj)(int dims, COORD_T root_extent,
+        const COORD_T *target_center, int target_level,
+        const COORD_T *source_center, int source_level)
+{
+    COORD_T target_rad = (root_extent * 1 / (COORD_T) (1 << (target_level + 1)));
+    COORD_T source_rad = (root_extent * 1 / (COORD_T) (1 << (source_level + 1)));
+    COORD_T rad_sum = ((2 * ((COORD_T) 1 - 1) + 1) * target_rad + source_rad);
+    COORD_T slack = rad_sum + ((target_rad < source_rad) ? target_rad : source_rad);
+    COORD_T l_inf_dist = 0;
+    for (int i = 0; i < dims; ++i) {
+        COORD_T d = target_center[i] - source_center[i];
+        d = (d < 0) ? -d : d;
+        l_inf_dist = (d > l_inf_dist) ? d : l_inf_dist;
+    }
+    return l_inf_dist <= slack;
+}
+
 /* ---- TreeBuilder.__call__ from "allocate data" on: tree_build.py:512-1878 - */
 
 int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
@@ -286,6 +305,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
     const int64_t N = in->nsrcntgts;
     const int have_extent = in->extent_norm != ORC_NORM_NONE;
     const int adaptive = in->kind != ORC_KIND_NON_ADAPTIVE;
+    const int level_restrict = in->kind == ORC_KIND_ADAPTIVE_LEVEL_RESTRICTED;  /* :606-611 */
     const int32_t max_w = in->max_leaf_refine_weight;
 
     memset(out, 0, sizeof(*out));
@@ -300,6 +320,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
     int64_t nboxes_alloc = 0;
     int32_t *split_box_ids = NULL, *box_srcntgt_starts = NULL, *box_parent_ids = NULL;
     int32_t *box_srcntgt_counts_cumul = NULL, *box_has_children = NULL;
+    int32_t *force_split_box = NULL;     /* :606-611 (level restriction only) */
     int32_t *box_child_ids[ORC_MAXC] = {0};
     COORD_T *box_centers[ORC_MAXDIM] = {0};
     uint8_t *box_levels = NULL;
@@ -342,6 +363,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
             ORC_GROW(box_parent_ids, int32_t, nboxes_alloc, na_); \
             ORC_GROW(box_srcntgt_counts_cumul, int32_t, nboxes_alloc, na_); \
             ORC_GROW(box_has_children, int32_t, nboxes_alloc, na_); \
+            ORC_GROW(force_split_box, int32_t, nboxes_alloc, na_); \
             ORC_GROW(box_levels, uint8_t, nboxes_alloc, na_); \
             ORC_GROW(box_morton_bin_counts, orc_mc_t, nboxes_alloc, na_); \
             for (int m_ = 0; m_ < C; ++m_) \
@@ -367,6 +389,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
     int32_t have_oversize_split_box = 0;
 
     int level = (total_refine_weight > max_w) ? 1 : 0;                 /* :676 */
+    int final_level_restrict_iteration = 0;                            /* :695 */
 
     while (level) {
         if (level + 1 >= in->nlevels_max) {                            /* :705-709 */
@@ -418,6 +441,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
                 else
                     do_split = (blevel + 1 == level)
                         && (box_srcntgt_counts_cumul[i] - nonchild_srcntgts_in_box >= 0);
+                if (level_restrict) do_split = do_split || force_split_box[i];  /* tbk:593-595 */
                 if (do_split) {                                        /* tbk:596-611 */
                     result += C;
                     box_has_children[i] = 1;
@@ -440,20 +464,85 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
             new_level_used_box_counts[l] =
                 split_box_ids[last_box_on_prev_level] - level_start_box_nrs[l];
         }
-        /* without level restriction no renumbering is ever needed (:826-832) */
-        int64_t nboxes_new = (int64_t) level_start_box_nrs[nlev_starts - 1]
-            + new_level_used_box_counts[nlev_starts - 1];
+        /* :788-1005.  Only level restriction makes upper levels grow (children of
+         * force-split boxes are appended to their level).  The reference pads the
+         * levels (lr_lookbehind) so that this rarely needs a renumbering; padding
+         * changes how often boxes are renumbered, never their relative order, so
+         * this restatement uses none: whenever a level is too short for its new
+         * used-box count all boxes are renumbered order-preservingly (:826-900,
+         * :912-1005) and the level iteration is restarted (:1005 "continue"). */
+        int needs_renumbering = 0;
         for (int l = 0; l + 1 < nlev_starts; ++l)
             if (new_level_used_box_counts[l]
-                    > level_start_box_nrs[l + 1] - level_start_box_nrs[l]) {
-                status = ORC_ERR_INTERNAL; goto done;
+                    > level_start_box_nrs[l + 1] - level_start_box_nrs[l])
+                needs_renumbering = 1;
+        if (needs_renumbering) {
+            if (!level_restrict) { status = ORC_ERR_INTERNAL; goto done; }   /* :832 */
+            const int nl = nlev_starts - 1;          /* == level: existing levels */
+            int32_t *new_starts = (int32_t *) calloc((size_t) nl + 2, 4);
+            for (int l = 0; l < nl; ++l) {
+                int32_t cur = level_start_box_nrs[l + 1] - level_start_box_nrs[l];
+                int32_t need = new_level_used_box_counts[l];
+                new_starts[l + 1] = new_starts[l] + (need > cur ? need : cur);
             }
+            const int64_t old_box_count = level_start_box_nrs[nl];
+            const int64_t new_box_count = new_starts[nl];
+            int32_t *dst = (int32_t *) calloc((size_t) old_box_count + 1, 4);
+            for (int l = 0; l < nl; ++l) {                              /* :861-869 */
+                int32_t len = level_start_box_nrs[l + 1] - level_start_box_nrs[l];
+                for (int32_t j = 0; j < len; ++j)
+                    dst[level_start_box_nrs[l] + j] = new_starts[l] + j;
+            }
+            const int64_t old_alloc = nboxes_alloc;
+            int64_t na = nboxes_alloc;
+            while (na < new_box_count + 1) na *= 2;
+#define ORC_REMAP(arr, type, mapvals) do { \
+                type *n_ = (type *) calloc((size_t) na, sizeof(type)); \
+                if (!n_) { status = ORC_ERR_ALLOC; goto done; } \
+                for (int64_t i_ = 0; i_ < old_box_count; ++i_) { \
+                    type v_ = arr[i_]; \
+                    if (mapvals) v_ = (type) dst[(int64_t) v_]; \
+                    n_[dst[i_]] = v_; } \
+                free(arr); arr = n_; } while (0)
+            ORC_REMAP(split_box_ids, int32_t, 0);
+            /* orc_mc_t is a struct: plain copy */
+            {
+                orc_mc_t *n_ = (orc_mc_t *) calloc((size_t) na, sizeof(orc_mc_t));
+                if (!n_) { status = ORC_ERR_ALLOC; goto done; }
+                for (int64_t i_ = 0; i_ < old_box_count; ++i_) n_[dst[i_]] = box_morton_bin_counts[i_];
+                free(box_morton_bin_counts); box_morton_bin_counts = n_;
+            }
+            ORC_REMAP(force_split_box, int32_t, 0);
+            ORC_REMAP(box_srcntgt_starts, int32_t, 0);
+            ORC_REMAP(box_srcntgt_counts_cumul, int32_t, 0);
+            ORC_REMAP(box_has_children, int32_t, 0);
+            for (int d_ = 0; d_ < dims; ++d_) ORC_REMAP(box_centers[d_], COORD_T, 0);
+            for (int m_ = 0; m_ < C; ++m_) ORC_REMAP(box_child_ids[m_], int32_t, 1);
+            ORC_REMAP(box_parent_ids, int32_t, 1);
+            {                                                           /* :975-983 */
+                uint8_t *n_ = (uint8_t *) calloc((size_t) na, 1);
+                if (!n_) { status = ORC_ERR_ALLOC; goto done; }
+                for (int l = 0; l < nl; ++l)
+                    for (int32_t j = new_starts[l]; j < new_starts[l + 1]; ++j) n_[j] = (uint8_t) l;
+                free(box_levels); box_levels = n_;
+            }
+#undef ORC_REMAP
+            (void) old_alloc;
+            nboxes_alloc = na;
+            for (int64_t i = 0; i < N; ++i)                             /* :985-987 */
+                srcntgt_box_ids[i] = dst[srcntgt_box_ids[i]];
+            for (int l = 0; l <= nl; ++l) level_start_box_nrs[l] = new_starts[l];
+            free(new_starts); free(dst);
+            continue;                                                   /* :1005 */
+        }
+        int64_t nboxes_new = (int64_t) level_start_box_nrs[nlev_starts - 1]
+            + new_level_used_box_counts[nlev_starts - 1];
 
         ORC_ENSURE_BOXES(nboxes_new);      /* :912-1005 (contents preserved) */
 
         if (level_start_box_nrs[nlev_starts - 1] == nboxes_new) {      /* :1016-1025 */
-            if (have_extent) { level -= 1; break; }
-            status = ORC_ERR_INTERNAL; goto done;
+            if (have_extent && !final_level_restrict_iteration) { level -= 1; break; }
+            if (!final_level_restrict_iteration) { status = ORC_ERR_INTERNAL; goto done; }
         }
 
         /* :1029-1038 */
@@ -465,6 +554,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
         /* K5 box_splitter over all boxes (:1072, tbk:646-711) */
         for (int64_t ibox = 0; ibox < nboxes_new; ++ibox) {
             int do_split_box = box_has_children[ibox] && (box_levels[ibox] + 1 == level);
+            if (level_restrict) do_split_box = do_split_box || force_split_box[ibox];  /* tbk:651-653 */
             if (!do_split_box) continue;
             orc_mc_t bmc = box_morton_bin_counts[ibox];
             for (int mnr = 0; mnr < C; ++mnr) {
@@ -497,6 +587,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
         for (int64_t i = 0; i < N; ++i) {
             int32_t ibox = srcntgt_box_ids[i];
             int do_split_box = box_has_children[ibox] && (box_levels[ibox] + 1 == level);
+            if (level_restrict) do_split_box = do_split_box || force_split_box[ibox];  /* tbk:748-750 */
             if (!do_split_box) {
                 new_user_srcntgt_ids[i] = user_srcntgt_ids[i];
                 new_srcntgt_box_ids[i] = ibox;
@@ -519,6 +610,90 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
           new_user_srcntgt_ids = t; }
         { int32_t *t = srcntgt_box_ids; srcntgt_box_ids = new_srcntgt_box_ids;
           new_srcntgt_box_ids = t; }
+
+        /* enforce level restriction on upper levels: :1125-1224 */
+        if (final_level_restrict_iteration) {                          /* :1127-1143 */
+            if (have_oversize_split_box || level_used_box_counts[nlev_used - 1] != 0) {
+                status = ORC_ERR_INTERNAL; goto done;
+            }
+            nlev_used -= 1;
+            nlev_starts -= 1;
+            level -= 1;
+            break;
+        }
+        if (level_restrict) {
+            for (int64_t i = 0; i < nboxes_new; ++i) force_split_box[i] = 0;   /* :1155 */
+            int did_upper_level_split = 0;
+            /* upper_level = level-2 .. 1 (:1163-1172): the parent level already has
+             * a 2-to-1 ratio with the level just built */
+            for (int upper_level = level - 2; upper_level >= 1; --upper_level) {
+                const int32_t upper_level_start = level_start_box_nrs[upper_level];
+                const int32_t upper_level_box_count = level_used_box_counts[upper_level];
+                int have_upper_level_split_box = 0;
+                /* LEVEL_RESTRICT_TPL: tbk:825-913 */
+                for (int32_t box_id = upper_level_start;
+                        box_id < upper_level_start + upper_level_box_count; ++box_id) {
+                    if (box_has_children[box_id]) continue;
+                    int32_t walk_box_stack[128]; int walk_morton_nr_stack[128];
+                    int walk_stack_size = 0; int32_t walk_parent_box_id = 0;
+                    int walk_morton_nr = 0; int continue_walk = 1;
+                    while (continue_walk) {
+                        int32_t child_box_id = box_child_ids[walk_morton_nr][walk_parent_box_id];
+                        if (child_box_id) {
+                            int child_level = walk_stack_size + 1;
+                            int is_adjacent;
+                            if (child_box_id == box_id) {
+                                is_adjacent = 0;
+                            } else {
+                                COORD_T bc[ORC_MAXDIM], cc[ORC_MAXDIM];
+                                for (int d = 0; d < dims; ++d) {
+                                    bc[d] = box_centers[d][box_id];
+                                    cc[d] = box_centers[d][child_box_id];
+                                }
+                                is_adjacent = SFX(orc_lr_is_adj)(dims, in->root_extent,
+                                        cc, child_level, bc, upper_level);
+                            }
+                            if (is_adjacent) {
+                                if (box_has_children[child_box_id]) {
+                                    if (child_level <= 1 + upper_level) {
+                                        walk_box_stack[walk_stack_size] = walk_parent_box_id;
+                                        walk_morton_nr_stack[walk_stack_size] = walk_morton_nr;
+                                        ++walk_stack_size;
+                                        walk_parent_box_id = child_box_id; walk_morton_nr = 0;
+                                        continue;
+                                    }
+                                } else {
+                                    if (child_level == 2 + upper_level || (
+                                            child_level == 1 + upper_level
+                                            && force_split_box[child_box_id])) {
+                                        force_split_box[box_id] = 1;
+                                        have_upper_level_split_box = 1;
+                                        continue_walk = 0;
+                                    }
+                                }
+                            }
+                        }
+                        while (1) {                                    /* walk_advance */
+                            ++walk_morton_nr;
+                            if (walk_morton_nr < C) break;
+                            continue_walk = (walk_stack_size > 0);
+                            if (continue_walk) {
+                                --walk_stack_size;
+                                walk_parent_box_id = walk_box_stack[walk_stack_size];
+                                walk_morton_nr = walk_morton_nr_stack[walk_stack_size];
+                            } else break;
+                        }
+                    }
+                }
+                if (!have_upper_level_split_box) break;                 /* :1201-1202 */
+                did_upper_level_split = 1;
+            }
+            if (!have_oversize_split_box && did_upper_level_split) {    /* :1216-1224 */
+                final_level_restrict_iteration = 1;
+                level += 1;
+                continue;
+            }
+        }
 
         if (!have_oversize_split_box) break;                           /* :1228-1230 */
         level += 1;
@@ -871,7 +1046,7 @@ done:
     free(morton_bin_counts); free(morton_nrs); free(box_start_flags);
     free(srcntgt_box_ids); free(user_srcntgt_ids);
     free(new_user_srcntgt_ids); free(new_srcntgt_box_ids);
-    free(split_box_ids); free(box_srcntgt_starts); free(box_parent_ids);
+    free(split_box_ids); free(box_srcntgt_starts); free(box_parent_ids); free(force_split_box);
     free(box_srcntgt_counts_cumul); free(box_has_children);
     for (int m = 0; m < ORC_MAXC; ++m) free(box_child_ids[m]);
     for (int d = 0; d < ORC_MAXDIM; ++d) free(box_centers[d]);

@@ -213,7 +213,7 @@ def bounding_box(particles, radii=None):
 
 # {{{ tree build
 
-_KINDS = {"adaptive": 0, "non-adaptive": 2}
+_KINDS = {"adaptive": 0, "adaptive-level-restricted": 1, "non-adaptive": 2}
 _NORMS = {None: 0, "linf": 1, "l2": 2}
 
 
@@ -230,8 +230,6 @@ def build_tree(particles, kind="adaptive", max_particles_in_box=None,
     # {{{ input processing: tree_build.py:223-295
     if kind not in ["adaptive", "adaptive-level-restricted", "non-adaptive"]:
         raise ValueError(f"unknown tree kind: '{kind}'")
-    if kind == "adaptive-level-restricted":
-        raise NotImplementedError("oracle: level-restricted trees not restated")
 
     dimensions = len(particles)
     axis_names = AXIS_NAMES[:dimensions]
