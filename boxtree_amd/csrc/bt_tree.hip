@@ -19,6 +19,7 @@
 #include "bt_common.hpp"
 #include "bt_prims.hpp"
 #include "bt_sort.hpp"
+#include "bt_geom.hpp"
 
 #include <algorithm>
 #include <climits>
@@ -268,6 +269,7 @@ struct BuildArgs {
     int new_level_start;
     int adaptive;
     int keep_empty;             // skip_prune: empty children become boxes too
+    const int32_t *parent_list; // level restriction: force-split these boxes (any level)
     int top_level;              // sharded builds: levels above it use global counts
     const int64_t *top_prefix;  // [C^top_level + 1] or null
 };
@@ -296,8 +298,9 @@ __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int bl = t / C, m = t % C;
     const bool active = bl < a.nprev;
-    const int b = a.b0 + (active ? bl : 0);
-    const int l = a.level;
+    const bool forced = a.parent_list != nullptr;
+    const int b = forced ? a.parent_list[active ? bl : 0] : a.b0 + (active ? bl : 0);
+    const int l = forced ? (int) a.box_level[b] + 1 : a.level;
 
     int lo = 0, e = 0, s = 0;
     uint64_t prefix = 0;
@@ -334,7 +337,8 @@ __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
     const bool top = a.top_prefix && l - 1 < a.top_level && e > s;
     if (top) W = top_weight<D>(a, prefix, l - 1);
     bool split;
-    if (a.adaptive) split = W > a.max_weight;                    // tbk:577-591
+    if (forced) split = true;                                    // tbk:593-595
+    else if (a.adaptive) split = W > a.max_weight;               // tbk:577-591
     else split = true;
     if (l - 1 >= a.L) {
         if (split && e > s && (a.adaptive || W > a.max_weight)) {
@@ -344,7 +348,7 @@ __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
     }
     // empty boxes exist only with skip_prune; "non-adaptive" splits them like any
     // other box of the level (tbk:593-597), "adaptive" never does (weight 0)
-    if (e == s && (a.adaptive || !a.keep_empty)) split = false;
+    if (e == s && (a.adaptive || !a.keep_empty) && !forced) split = false;
 
     const int cnt = hi - lo;
     const bool nonempty = split && (cnt > 0 || a.keep_empty);
@@ -379,7 +383,9 @@ __global__ __launch_bounds__(256) void write_children_kernel(BuildArgs a, T *cen
     const int t = blockIdx.x * 256 + threadIdx.x;
     const int bl = t / C, m = t % C;
     const bool active = bl < a.nprev;
-    const int b = a.b0 + (active ? bl : 0);
+    const bool forced = a.parent_list != nullptr;
+    const int b = forced ? a.parent_list[active ? bl : 0] : a.b0 + (active ? bl : 0);
+    const int level = forced ? (int) a.box_level[b] + 1 : a.level;
     const bool split = active && a.box_haschild[b];
     int lo = 0, hi = 0;
     if (split) {
@@ -401,11 +407,11 @@ __global__ __launch_bounds__(256) void write_children_kernel(BuildArgs a, T *cen
         a.box_start[child_id] = hi > lo ? lo : 0;
         a.box_count[child_id] = hi - lo;
         a.box_parent[child_id] = b;
-        a.box_level[child_id] = (uint8_t) a.level;
+        a.box_level[child_id] = (uint8_t) level;
         a.box_haschild[child_id] = 0;
         a.box_nonchild[child_id] = 0;
         // tbk:698-705: centre = parent centre +/- root_extent / 2^(1+level)
-        const T radius = (root_extent * 1 / (T) (1ull << (1 + a.level)));
+        const T radius = (root_extent * 1 / (T) (1ull << (1 + level)));
 #pragma unroll
         for (int ax = 0; ax < D; ++ax) {
             const bool has_bit = (m >> (D - 1 - ax)) & 1;
@@ -802,6 +808,350 @@ int ensure_box_capacity(bt_context *ctx, TreeState *st, int64_t need, size_t coo
     return BT_OK;
 }
 
+
+// ---------------------------------------------------------------------------
+// kind = "adaptive-level-restricted" (tree_build.py:606-611, 1125-1224;
+// tree_build_kernels.py:825-972).  The reference interleaves three things per
+// level-loop trip: the regular split that creates the new level, the split of
+// the boxes flagged in the previous trip ("force split", children appended to
+// the END of their level), and an upward pass that flags leaves with a
+// neighbouring leaf two levels deeper.  Box numbers therefore depend on the trip
+// in which a box was created.  Here boxes are kept in creation order while the
+// loop runs (no renumbering); the final numbers are the stable sort of the
+// creation order by level, which is exactly what the reference's
+// order-preserving renumberings and the final gap/empty-box removal produce.
+// Children of every split are all created (empty ones matter for the balance)
+// and empty boxes are dropped at the end unless skip_prune.
+// ---------------------------------------------------------------------------
+
+// LEVEL_RESTRICT_TPL (tbk:825-913): one thread per box; only leaves of
+// `upper_level` do anything.
+template <class T, int D>
+__global__ __launch_bounds__(WALK_THREADS) void lr_pass_kernel(int32_t nboxes, int upper_level,
+        T root_extent, const uint8_t *box_level, const uint8_t *box_haschild,
+        const int32_t *box_child, const T *centers, int32_t *force_split, int32_t *have_split)
+{
+    constexpr int C = 1 << D;
+    const int32_t box_id = blockIdx.x * WALK_THREADS + threadIdx.x;
+    if (box_id >= nboxes) return;
+    if ((int) box_level[box_id] != upper_level || box_haschild[box_id]) return;
+    T bc[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) bc[d] = centers[(int64_t) box_id * D + d];
+    Walk w(s_walk_lds + threadIdx.x);
+    w.init(0);
+    while (w.go) {
+        const int32_t child = box_child[(int64_t) w.parent * C + w.mnr];
+        if (child) {
+            const int child_level = w.size + 1;
+            bool is_adjacent = false;
+            if (child != box_id) {
+                T cc[D];
+#pragma unroll
+                for (int d = 0; d < D; ++d) cc[d] = centers[(int64_t) child * D + d];
+                is_adjacent = adj<T, D>(root_extent, cc, child_level, bc, upper_level);
+            }
+            if (is_adjacent) {
+                if (box_haschild[child]) {
+                    if (child_level <= 1 + upper_level) { w.push(child); continue; }
+                } else if (child_level == 2 + upper_level
+                           || (child_level == 1 + upper_level && force_split[child])) {
+                    force_split[box_id] = 1;
+                    __hip_atomic_store(have_split, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+            }
+        }
+        w.template advance<C>();
+    }
+}
+
+struct NonZeroI32 {
+    const int32_t *f;
+    __device__ int32_t operator()(int64_t i) const { return f[i] != 0; }
+};
+
+__global__ __launch_bounds__(256) void lr_compact_flagged_kernel(int32_t n, const int32_t *flag,
+        const int32_t *pos, const uint8_t *box_level, uint32_t *levels_out, uint32_t *ids_out)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    levels_out[pos[i]] = box_level[i];
+    ids_out[pos[i]] = (uint32_t) i;
+}
+
+__global__ __launch_bounds__(256) void lr_mark_haschild_kernel(int32_t n, const uint32_t *list,
+                                                               uint8_t *box_haschild)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) box_haschild[list[i]] = 1;
+}
+
+__global__ __launch_bounds__(256) void lr_levels_kernel(int32_t n, const uint8_t *box_level,
+                                                        uint32_t *keys)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) keys[i] = box_level[i];
+}
+
+struct LrKeep {
+    const uint32_t *order;
+    const int32_t *box_count;
+    int keep_empty;
+    __device__ int32_t operator()(int64_t i) const
+    {
+        return (keep_empty || box_count[order[i]] > 0) ? 1 : 0;
+    }
+};
+
+__global__ __launch_bounds__(256) void lr_final_ids_kernel(int32_t n, LrKeep keep, const int32_t *pos,
+        const uint8_t *box_level, int32_t *final_of_raw, int32_t *level_counts)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t raw = keep.order[i];
+    const bool k = keep(i) != 0;
+    final_of_raw[raw] = k ? pos[i] : 0;     // pruned boxes map to 0 (tree_build.py:1337-1340)
+    if (k) atomicAdd(&level_counts[box_level[raw]], 1);
+}
+
+template <class T, int D>
+struct LrArrays {
+    int32_t *start, *count, *parent, *nonchild, *child;
+    uint8_t *level, *haschild;
+    T *centers;
+};
+
+template <class T, int D>
+__global__ __launch_bounds__(256) void lr_renumber_kernel(int32_t n, LrKeep keep, const int32_t *pos,
+        const int32_t *final_of_raw, LrArrays<T, D> in, LrArrays<T, D> out)
+{
+    constexpr int C = 1 << D;
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !keep(i)) return;
+    const uint32_t raw = keep.order[i];
+    const int32_t f = pos[i];
+    out.start[f] = in.start[raw];
+    out.count[f] = in.count[raw];
+    out.parent[f] = final_of_raw[in.parent[raw]];
+    out.nonchild[f] = in.nonchild[raw];
+    out.level[f] = in.level[raw];
+    out.haschild[f] = in.haschild[raw];
+#pragma unroll
+    for (int m = 0; m < C; ++m) {
+        const int32_t c = in.child[(int64_t) raw * C + m];
+        out.child[(int64_t) f * C + m] = c ? final_of_raw[c] : 0;
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) out.centers[(int64_t) f * D + d] = in.centers[(int64_t) raw * D + d];
+}
+
+template <class T, int D>
+int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
+{
+    constexpr int C = 1 << D;
+    const bt_tree_params &p = st->p;
+    const bool EXT = st->have_extent;
+    Buf<LevelFlags> d_flags;
+    BT_CHECK(d_flags.alloc(ctx->pool, 1));
+    Buf<int32_t> d_have;
+    BT_CHECK(d_have.alloc(ctx->pool, 1));
+
+    auto make_args = [&](BuildArgs &a) {
+        a = BuildArgs{};
+        a.keys = keys;
+        a.wprefix = st->wprefix.get();
+        a.box_start = st->box_start.get(); a.box_count = st->box_count.get();
+        a.box_parent = st->box_parent.get(); a.box_nonchild = st->box_nonchild.get();
+        a.box_child = st->box_child.get();
+        a.box_level = st->box_level.get(); a.box_haschild = st->box_haschild.get();
+        a.flags = d_flags.get(); a.status = ctx->d_status;
+        a.max_weight = p.max_leaf_refine_weight;
+        a.L = st->L; a.capbits = st->capbits;
+        a.adaptive = 1;
+        a.keep_empty = 1;
+    };
+
+    // splits the boxes [b0, b0+n) of one level, or the listed boxes (forced)
+    auto split = [&](int level, int64_t b0, int64_t n, const uint32_t *list, int *total_new,
+                     int *oversize) -> int {
+        Buf<int32_t> bounds, nnew, offsets;
+        BT_CHECK(bounds.alloc(ctx->pool, n * (C + 1)));
+        BT_CHECK(nnew.alloc(ctx->pool, n));
+        BT_CHECK(offsets.alloc(ctx->pool, n));
+        BT_HIP_CHECK(hipMemsetAsync(d_flags.get(), 0, sizeof(LevelFlags), ctx->stream));
+        BuildArgs a;
+        make_args(a);
+        a.bounds = bounds.get(); a.nnew = nnew.get(); a.offsets = offsets.get();
+        a.level = level; a.b0 = (int) b0; a.nprev = (int) n;
+        a.parent_list = (const int32_t *) list;
+        const unsigned blocks = (unsigned) div_up(n * C, 256);
+        if (EXT) count_children_kernel<D, true><<<blocks, 256, 0, ctx->stream>>>(a);
+        else count_children_kernel<D, false><<<blocks, 256, 0, ctx->stream>>>(a);
+        ScanNnew sn{nnew.get()};
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, sn, n, offsets.get(),
+                                                          &d_flags.get()->total_new)));
+        LevelFlags hf;
+        BT_HIP_CHECK(hipMemcpyAsync(&hf, d_flags.get(), sizeof(hf), hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        *total_new = hf.total_new;
+        *oversize = hf.have_oversize;
+        if (hf.total_new == 0) return BT_OK;
+        BT_CHECK(ensure_box_capacity(ctx, st, st->nboxes + hf.total_new, sizeof(T)));
+        make_args(a);      // buffers may have moved
+        a.bounds = bounds.get(); a.nnew = nnew.get(); a.offsets = offsets.get();
+        a.level = level; a.b0 = (int) b0; a.nprev = (int) n;
+        a.parent_list = (const int32_t *) list;
+        a.new_level_start = (int) st->nboxes;
+        write_children_kernel<T, D><<<blocks, 256, 0, ctx->stream>>>(a, (T *) st->centers.get(),
+                                                                     (T) p.root_extent);
+        BT_HIP_CHECK(hipGetLastError());
+        st->nboxes += hf.total_new;
+        return BT_OK;
+    };
+
+    int level = 1;
+    bool final_iteration = false;               // tree_build.py:695
+    int64_t reg_b0 = 0, reg_n = 1;              // the regular boxes of level-1
+    Buf<uint32_t> fl_levels, fl_ids, fl_levels_b, fl_ids_b;
+    const uint32_t *flagged = nullptr;
+    int64_t nflagged = 0;
+    while (true) {
+        int total_new = 0, oversize = 0;
+        if (!final_iteration) {
+            const int64_t first_new = st->nboxes;
+            BT_CHECK(split(level, reg_b0, reg_n, nullptr, &total_new, &oversize));
+            if (total_new == 0) {
+                // tree_build.py:1016-1025: nothing new on this level (extents); the split
+                // scan has already marked the flagged boxes as parents (tbk:596-598)
+                if (nflagged > 0)
+                    lr_mark_haschild_kernel<<<(unsigned) div_up(nflagged, 256), 256, 0, ctx->stream>>>(
+                        (int32_t) nflagged, flagged, st->box_haschild.get());
+                break;
+            }
+            reg_b0 = first_new;
+            reg_n = total_new;
+        }
+        if (nflagged > 0) {
+            int forced_new = 0, dummy = 0;
+            BT_CHECK(split(0, 0, nflagged, flagged, &forced_new, &dummy));
+            nflagged = 0;
+        }
+        if (final_iteration) break;             // :1127-1143
+
+        // upward pass: :1145-1224
+        const int32_t nb = (int32_t) st->nboxes;
+        Buf<int32_t> force;
+        BT_CHECK(force.alloc(ctx->pool, nb));
+        BT_HIP_CHECK(hipMemsetAsync(force.get(), 0, (size_t) nb * 4, ctx->stream));
+        bool did_upper_level_split = false;
+        const size_t lds = (size_t) (level + 2) * WALK_THREADS * 4;
+        for (int upper_level = level - 2; upper_level >= 1; --upper_level) {
+            BT_HIP_CHECK(hipMemsetAsync(d_have.get(), 0, 4, ctx->stream));
+            lr_pass_kernel<T, D><<<(unsigned) div_up(nb, WALK_THREADS), WALK_THREADS, lds, ctx->stream>>>(
+                nb, upper_level, (T) p.root_extent, st->box_level.get(), st->box_haschild.get(),
+                st->box_child.get(), (const T *) st->centers.get(), force.get(), d_have.get());
+            int32_t have = 0;
+            BT_HIP_CHECK(hipMemcpyAsync(&have, d_have.get(), 4, hipMemcpyDeviceToHost, ctx->stream));
+            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            if (!have) break;                   // :1201-1202
+            did_upper_level_split = true;
+        }
+        if (did_upper_level_split) {
+            // flagged boxes ordered by (level, creation order): the order in which the
+            // split scan hands out their children's numbers (tbk:514-640)
+            Buf<int32_t> pos;
+            BT_CHECK(pos.alloc(ctx->pool, (int64_t) nb + 1));
+            BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, NonZeroI32{force.get()}, nb,
+                                                              pos.get(), (int32_t *) nullptr, true)));
+            int32_t nf = 0;
+            BT_HIP_CHECK(hipMemcpyAsync(&nf, pos.get() + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
+            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            BT_CHECK(fl_levels.alloc(ctx->pool, nf));
+            BT_CHECK(fl_ids.alloc(ctx->pool, nf));
+            BT_CHECK(fl_levels_b.alloc(ctx->pool, nf));
+            BT_CHECK(fl_ids_b.alloc(ctx->pool, nf));
+            lr_compact_flagged_kernel<<<(unsigned) div_up(nb, 256), 256, 0, ctx->stream>>>(
+                nb, force.get(), pos.get(), st->box_level.get(), fl_levels.get(), fl_ids.get());
+            bool in_b = false;
+            BT_CHECK(radix_sort_pairs<uint32_t>(ctx, fl_levels.get(), fl_ids.get(), fl_levels_b.get(),
+                                                fl_ids_b.get(), nf, 0, 8, false, &in_b));
+            flagged = in_b ? fl_ids_b.get() : fl_ids.get();
+            nflagged = nf;
+        }
+        if (!oversize && did_upper_level_split) {   // :1216-1224
+            final_iteration = true;
+            level += 1;
+            continue;
+        }
+        if (!oversize) break;                   // :1228-1230
+        level += 1;
+        if (level > st->L + 1) break;           // defensive; max_levels flag is set on device
+    }
+    BT_CHECK(check_status(ctx));
+
+    // ---- final numbers: creation order -> (level, creation order), empty boxes out ----
+    const int32_t nraw = (int32_t) st->nboxes;
+    Buf<uint32_t> ka, kb, va, vb;
+    BT_CHECK(ka.alloc(ctx->pool, nraw));
+    BT_CHECK(kb.alloc(ctx->pool, nraw));
+    BT_CHECK(va.alloc(ctx->pool, nraw));
+    BT_CHECK(vb.alloc(ctx->pool, nraw));
+    lr_levels_kernel<<<(unsigned) div_up(nraw, 256), 256, 0, ctx->stream>>>(nraw, st->box_level.get(),
+                                                                           ka.get());
+    bool in_b = false;
+    BT_CHECK(radix_sort_pairs<uint32_t>(ctx, ka.get(), va.get(), kb.get(), vb.get(), nraw, 0, 8, true,
+                                        &in_b));
+    const uint32_t *order = in_b ? vb.get() : va.get();
+    LrKeep keep{order, st->box_count.get(), p.skip_prune ? 1 : 0};
+    Buf<int32_t> pos, final_of_raw, level_counts;
+    BT_CHECK(pos.alloc(ctx->pool, (int64_t) nraw + 1));
+    BT_CHECK(final_of_raw.alloc(ctx->pool, nraw));
+    BT_CHECK(level_counts.alloc(ctx->pool, BT_MAX_LEVELS));
+    BT_HIP_CHECK(hipMemsetAsync(level_counts.get(), 0, BT_MAX_LEVELS * 4, ctx->stream));
+    BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, keep, nraw, pos.get(), (int32_t *) nullptr,
+                                                      true)));
+    lr_final_ids_kernel<<<(unsigned) div_up(nraw, 256), 256, 0, ctx->stream>>>(
+        nraw, keep, pos.get(), st->box_level.get(), final_of_raw.get(), level_counts.get());
+    int32_t h_counts[BT_MAX_LEVELS];
+    int32_t nfinal = 0;
+    BT_HIP_CHECK(hipMemcpyAsync(h_counts, level_counts.get(), sizeof(h_counts), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    BT_HIP_CHECK(hipMemcpyAsync(&nfinal, pos.get() + nraw, 4, hipMemcpyDeviceToHost, ctx->stream));
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+
+    Buf<int32_t> n_start, n_count, n_parent, n_nonchild, n_child;
+    Buf<uint8_t> n_level, n_haschild;
+    Buf<unsigned char> n_centers;
+    const int64_t cap = std::max<int64_t>(nfinal, 1);
+    BT_CHECK(n_start.alloc(ctx->pool, cap));
+    BT_CHECK(n_count.alloc(ctx->pool, cap));
+    BT_CHECK(n_parent.alloc(ctx->pool, cap));
+    BT_CHECK(n_nonchild.alloc(ctx->pool, cap));
+    BT_CHECK(n_child.alloc(ctx->pool, cap * C));
+    BT_CHECK(n_level.alloc(ctx->pool, cap));
+    BT_CHECK(n_haschild.alloc(ctx->pool, cap));
+    BT_CHECK(n_centers.alloc(ctx->pool, cap * D * (int64_t) sizeof(T)));
+    LrArrays<T, D> in{st->box_start.get(), st->box_count.get(), st->box_parent.get(),
+                      st->box_nonchild.get(), st->box_child.get(), st->box_level.get(),
+                      st->box_haschild.get(), (T *) st->centers.get()};
+    LrArrays<T, D> out{n_start.get(), n_count.get(), n_parent.get(), n_nonchild.get(), n_child.get(),
+                       n_level.get(), n_haschild.get(), (T *) n_centers.get()};
+    lr_renumber_kernel<T, D><<<(unsigned) div_up(nraw, 256), 256, 0, ctx->stream>>>(
+        nraw, keep, pos.get(), final_of_raw.get(), in, out);
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    st->box_start.swap(n_start); st->box_count.swap(n_count); st->box_parent.swap(n_parent);
+    st->box_nonchild.swap(n_nonchild); st->box_child.swap(n_child); st->box_level.swap(n_level);
+    st->box_haschild.swap(n_haschild); st->centers.swap(n_centers);
+    st->nboxes = nfinal;
+    st->cap = cap;
+    st->level_start = {0};
+    for (int l = 0; l < BT_MAX_LEVELS && h_counts[l] > 0; ++l)
+        st->level_start.push_back(st->level_start.back() + h_counts[l]);
+    return BT_OK;
+}
+
 template <class T, int D>
 int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
 {
@@ -893,7 +1243,9 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     struct HostFree { LevelFlags *p; ~HostFree() { (void) hipHostFree(p); } } host_free{h_flags};
 
     int level = 1;
-    while (N > 0) {
+    const bool level_restricted = p.kind == BT_KIND_ADAPTIVE_LEVEL_RESTRICTED;
+    if (level_restricted && N > 0) BT_CHECK((lr_build_boxes<T, D>(ctx, st, keys)));
+    while (N > 0 && !level_restricted) {
         const int b0 = st->level_start[level - 1];
         const int nprev = st->level_start[level] - b0;
         Buf<int32_t> bounds, nnew, offsets;
@@ -1178,11 +1530,8 @@ int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
         set_error("bt_tree_build: unknown coord_kind %d", p->coord_kind);
         return BT_ERR_INVALID;
     }
-    if (p->kind == BT_KIND_ADAPTIVE_LEVEL_RESTRICTED) {
-        set_error("kind='adaptive-level-restricted' is not implemented yet");
-        return BT_ERR_UNSUPPORTED;
-    }
-    if (p->kind != BT_KIND_ADAPTIVE && p->kind != BT_KIND_NON_ADAPTIVE) {
+    if (p->kind != BT_KIND_ADAPTIVE && p->kind != BT_KIND_NON_ADAPTIVE
+            && p->kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED) {
         set_error("unknown tree kind %d", p->kind);
         return BT_ERR_INVALID;
     }
