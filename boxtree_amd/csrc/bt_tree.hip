@@ -23,6 +23,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <cstdlib>
 #include <cmath>
 
 using namespace bt;
@@ -1195,13 +1196,31 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     const uint64_t *keys = st->keys_a.get();
     uint32_t *ids = st->ids_a.get();
     uint32_t *ids_other = st->ids_b.get();
+    // Only the key bits of the levels the tree actually reaches need to be in
+    // order: boxes of level l are cut by the top D*l bits, and the order inside a
+    // leaf is fixed up by user id afterwards.  Five digit passes (40 bits: 13
+    // levels in 3D, 20 in 2D) cover all but pathologically clustered inputs; if
+    // the level loop gets deeper, the remaining bits are sorted then (below).
+    // Extents keep the full sort: the cap sits in the LOWEST key bits.
+    const int keybits = D * st->L + st->capbits;
+    int sorted_high_bits = keybits;
+    static const bool partial_sort_ok = [] {
+        const char *e = getenv("BT_FULL_SORT");      // debugging aid: 1 = always sort all bits
+        return !(e && atoi(e));
+    }();
+    if (partial_sort_ok && !EXT && !p.refine_weights && keybits > 40
+            && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED)
+        sorted_high_bits = 40;
+    uint64_t *keys_cur = st->keys_a.get(), *keys_oth = st->keys_b.get();
     if (N > 0) {
         bool in_b = false;
-        const int keybits = D * st->L + st->capbits;
         BT_CHECK(radix_sort_pairs<uint64_t>(ctx, st->keys_a.get(), st->ids_a.get(),
-                                            st->keys_b.get(), st->ids_b.get(), N, 0, keybits,
-                                            true, &in_b));
-        if (in_b) { keys = st->keys_b.get(); ids = st->ids_b.get(); ids_other = st->ids_a.get(); }
+                                            st->keys_b.get(), st->ids_b.get(), N,
+                                            keybits - sorted_high_bits, keybits, true, &in_b));
+        if (in_b) {
+            keys = st->keys_b.get(); ids = st->ids_b.get(); ids_other = st->ids_a.get();
+            keys_cur = st->keys_b.get(); keys_oth = st->keys_a.get();
+        }
     }
     BT_CHECK(mark(ctx, st, "sort"));
 
@@ -1246,6 +1265,17 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     const bool level_restricted = p.kind == BT_KIND_ADAPTIVE_LEVEL_RESTRICTED;
     if (level_restricted && N > 0) BT_CHECK((lr_build_boxes<T, D>(ctx, st, keys)));
     while (N > 0 && !level_restricted) {
+        if (D * level > sorted_high_bits) {
+            // deeper than the sorted key bits reach: order all bits now.  Box ranges
+            // stay valid (the order of the top bits does not change); ties keep
+            // whatever order they have, the fix-up sorts leaves by user id anyway.
+            bool in_b = false;
+            BT_CHECK(radix_sort_pairs<uint64_t>(ctx, keys_cur, ids, keys_oth, ids_other, N, 0,
+                                                keybits, false, &in_b));
+            if (in_b) { std::swap(keys_cur, keys_oth); std::swap(ids, ids_other); }
+            keys = keys_cur;
+            sorted_high_bits = keybits;
+        }
         const int b0 = st->level_start[level - 1];
         const int nprev = st->level_start[level] - b0;
         Buf<int32_t> bounds, nnew, offsets;

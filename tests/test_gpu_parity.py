@@ -673,3 +673,18 @@ def test_skip_prune_source_target_extents(actx, oracle):
     tr = 2 ** np.random.default_rng(13).uniform(-10, 0, 30000)
     build_both(actx, oracle, s, targets=t, target_radii=tr, stick_out_factor=0.25,
                max_particles_in_box=20, skip_prune=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,spread", [(3, 1e-5), (2, 1e-7), (3, 1e-2)])
+def test_deep_tree_beyond_the_presorted_bits(actx, oracle, dims, spread):
+    """Trees deeper than the 40 key bits sorted up front (13 levels in 3D, 20 in
+    2D): the level loop sorts the remaining bits on demand."""
+    rng = np.random.default_rng(8)
+    n = 40000
+    p = [np.concatenate([rng.random(n // 2), 0.3 + spread * rng.standard_normal(n // 2)])
+         for _ in range(dims)]
+    htree, otree, _, _ = build_both(actx, oracle, p, max_particles_in_box=8, trav_kw={})
+    if spread < 1e-3:
+        assert htree.nlevels > (14 if dims == 3 else 21)
+    check_tree(htree, p, max_particles_in_box=8)
