@@ -811,7 +811,24 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         a.coll_starts = coll.starts.get();
         a.coll_lists = coll.lists.get();
         CollL2Out oc{ccnt.get(), lcnt.get(), nullptr, nullptr};
-        coll_l2_kernel<T, D, false><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(a, b0, nb, oc);
+        // parents of the boxes [b0, b0+nb): the boxes of the level above (or, for a
+        // sharded traversal, its active range)
+        int32_t p0 = ls[lev - 1], np = ls[lev] - ls[lev - 1];
+        if (p.active_level_ranges) {
+            p0 = p.active_level_ranges[2 * (lev - 1)];
+            np = p.active_level_ranges[2 * (lev - 1) + 1] - p0;
+        }
+        static const bool per_box = [] {
+            // tuning aid; measured on c3: per-box (batched loads) 4.9 ms, per-parent
+            // wave 6.0 ms -- both are bound by the latency of dependent loads
+            const char *e = getenv("BT_COLL_PER_BOX");
+            return !e || atoi(e);
+        }();
+        if (per_box)
+            coll_l2_kernel<T, D, false><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(a, b0, nb, oc);
+        else
+            coll_l2_parent_kernel<T, D, false><<<nblk((int64_t) np * 64), 256, 0, ctx->stream>>>(
+                a, p0, np, b0, nb, oc);
         ScanI32 fc{ccnt.get()}, fl{lcnt.get()};
         BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, fc, nb, crel.get(), totals_d.get(), true)));
         BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, fl, nb, lrel.get(), totals_d.get() + 1, true)));
@@ -830,7 +847,11 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
                                                               l2_by_box.get() + b0);
         a.coll_lists = coll.lists.get();
         CollL2Out of{coll.starts.get(), l2_by_box.get(), coll.lists.get(), l2_lists.get()};
-        coll_l2_kernel<T, D, true><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(a, b0, nb, of);
+        if (per_box)
+            coll_l2_kernel<T, D, true><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(a, b0, nb, of);
+        else
+            coll_l2_parent_kernel<T, D, true><<<nblk((int64_t) np * 64), 256, 0, ctx->stream>>>(
+                a, p0, np, b0, nb, of);
         coll_total += h_tot[0];
         l2_total += h_tot[1];
         fill_outside(b0 + nb + 1, ls[lev + 1] + (lev == nlevels - 1 ? 1 : 0), coll_total, l2_total);
