@@ -345,7 +345,12 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         r_split = recv_counts.cpu().tolist()
         nrecv = int(sum(r_split))
         outs = []
-        if native:
+        # one packed message per peer, unless a message would reach 2 GiB (counts
+        # inside the collective are not reliably 64-bit: a 2.4 GB self-message
+        # came back corrupted on one rank) -- then one message per coordinate
+        d_ = len(arrs)
+        biggest = max(max(s_split), max(r_split)) * d_ * arrs[0].element_size()
+        if native and biggest < 2**31 - 1:
             # coordinates travel interleaved: one message per peer instead of d
             import ctypes as ct
             from boxtree_amd import _lib
