@@ -731,54 +731,20 @@ int grow_buf(bt_context *ctx, Buf<U> &buf, int64_t used, int64_t need)
     return BT_OK;
 }
 
-// colleagues + list 2 (top-down from the parent's colleagues) and list 1 (from the
-// ancestors' colleagues), see bt_trav_fast.hpp
 template <class T, int D>
-int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
+int coll_l2_two_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<int32_t> &l2_by_box,
+                     Buf<int32_t> &l2_lists, int64_t *l2_total_out)
 {
     constexpr int C = 1 << D;
     const bt_trav_params &p = st->p;
     const int64_t B = p.nboxes;
     const int nlevels = p.nlevels;
     const int32_t *ls = p.level_start_box_nrs;       // host
-    const int walk_cap = nlevels + 1;
-    const size_t walk_lds = (size_t) walk_cap * WALK_THREADS * 4;
-    const size_t lvl_lds = (size_t) nlevels * WALK_THREADS * 4;
-
-    // depth-first preorder ranks
-    BT_CHECK(st->subtree_size.alloc(ctx->pool, B));
-    BT_CHECK(st->dfs_rank.alloc(ctx->pool, B));
-    BT_CHECK(st->box_of_rank.alloc(ctx->pool, B));
-    for (int lev = nlevels - 1; lev >= 0; --lev)
-        subtree_size_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
-            ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
-            st->subtree_size.get());
-    for (int lev = 0; lev < nlevels; ++lev)
-        dfs_rank_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
-            ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
-            st->subtree_size.get(), st->dfs_rank.get(), st->box_of_rank.get());
-    // source boxes in depth-first order (+ prefix counts over ranks)
-    BT_CHECK(st->src_rank_prefix.alloc(ctx->pool, B + 1));
-    {
-        SourceRankFlag<T, D> f{a.nodes, st->box_of_rank.get()};
-        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, f, B, st->src_rank_prefix.get(),
-                                                          (int32_t *) nullptr, true)));
-        BT_CHECK(st->src_by_rank.alloc(ctx->pool, st->nsb + 1));
-        compact_sources_by_rank_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
-            f, (int32_t) B, st->src_rank_prefix.get(), st->src_by_rank.get());
-    }
-    FastTree ft{st->dfs_rank.get(), st->box_of_rank.get(), st->subtree_size.get(),
-                st->src_rank_prefix.get(), st->src_by_rank.get()};
-
-    // colleagues + list 2, level by level
     CsrList &coll = st->coll;
-    coll.n = B;
     BT_CHECK(coll.starts.alloc(ctx->pool, B + 1));
-    Buf<int32_t> l2_by_box;
     BT_CHECK(l2_by_box.alloc(ctx->pool, B + 1));
     BT_HIP_CHECK(hipMemsetAsync(coll.starts.get(), 0, (size_t) (B + 1) * 4, ctx->stream));
     BT_HIP_CHECK(hipMemsetAsync(l2_by_box.get(), 0, (size_t) (B + 1) * 4, ctx->stream));
-    Buf<int32_t> l2_lists;
     BT_CHECK(grow_buf(ctx, coll.lists, 0, std::max<int64_t>(B * 10, 1024)));
     BT_CHECK(grow_buf(ctx, l2_lists, 0, std::max<int64_t>(B * 40, 1024)));
     int64_t coll_total = 0, l2_total = 0;
@@ -857,6 +823,148 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         fill_outside(b0 + nb + 1, ls[lev + 1] + (lev == nlevels - 1 ? 1 : 0), coll_total, l2_total);
     }
     coll.total = coll_total;
+    a.coll_starts = coll.starts.get();
+    a.coll_lists = coll.lists.get();
+    *l2_total_out = l2_total;
+    return BT_OK;
+}
+
+// colleagues in fixed-stride rows, list 2 via per-level scratch rows: every test once
+template <class T, int D>
+int coll_l2_single_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<int32_t> &l2_by_box,
+                        Buf<int32_t> &l2_lists, int64_t *l2_total_out)
+{
+    constexpr int C = 1 << D;
+    constexpr int P = (D == 1 ? 3 : D == 2 ? 9 : 27) - 1;
+    constexpr int S = (D == 1 ? 6 : D == 2 ? 36 : 216) - (P + 1);
+    const bt_trav_params &p = st->p;
+    const int64_t B = p.nboxes;
+    const int nlevels = p.nlevels;
+    const int32_t *ls = p.level_start_box_nrs;       // host
+    CsrList &coll = st->coll;
+    Buf<int32_t> coll_rows, coll_cnt;
+    BT_CHECK(coll_rows.alloc(ctx->pool, B * P));
+    BT_CHECK(coll_cnt.alloc(ctx->pool, B));
+    BT_HIP_CHECK(hipMemsetAsync(coll_cnt.get(), 0, (size_t) B * 4, ctx->stream));
+    BT_CHECK(l2_by_box.alloc(ctx->pool, B + 1));
+    BT_HIP_CHECK(hipMemsetAsync(l2_by_box.get(), 0, (size_t) (B + 1) * 4, ctx->stream));
+    BT_CHECK(grow_buf(ctx, l2_lists, 0, std::max<int64_t>(B * 40, 1024)));
+    int64_t l2_total = 0;
+    Buf<int32_t> total_d;
+    BT_CHECK(total_d.alloc(ctx->pool, 1));
+    for (int lev = 1; lev < nlevels; ++lev) {
+        int32_t b0 = ls[lev], nb = ls[lev + 1] - ls[lev];
+        if (p.active_level_ranges) {        // sharded traversal: this rank's boxes only
+            b0 = p.active_level_ranges[2 * lev];
+            nb = p.active_level_ranges[2 * lev + 1] - b0;
+        }
+        const int32_t lev_end = ls[lev + 1] + (lev == nlevels - 1 ? 1 : 0);
+        auto fill_outside = [&](int32_t lo, int32_t hi, int64_t lv) {
+            if (hi > lo)
+                fill_i32_kernel<<<nblk(hi - lo), 256, 0, ctx->stream>>>(hi - lo, (int32_t) lv,
+                                                                       l2_by_box.get() + lo);
+        };
+        if (nb <= 0) { fill_outside(ls[lev], lev_end, l2_total); continue; }
+        fill_outside(ls[lev], b0, l2_total);
+        Buf<int32_t> l2_rows, l2_cnt, l2_rel;
+        BT_CHECK(l2_rows.alloc(ctx->pool, (int64_t) nb * S));
+        BT_CHECK(l2_cnt.alloc(ctx->pool, nb));
+        BT_CHECK(l2_rel.alloc(ctx->pool, nb + 1));
+        coll_l2_rows_kernel<T, D><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(
+            a, b0, nb, coll_rows.get(), coll_cnt.get(), l2_rows.get(), l2_cnt.get());
+        ScanI32 fl{l2_cnt.get()};
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, fl, nb, l2_rel.get(), total_d.get(), true)));
+        int32_t h_tot = 0;
+        BT_HIP_CHECK(hipMemcpyAsync(&h_tot, total_d.get(), 4, hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (l2_total + h_tot >= ((int64_t) 1 << 31)) {
+            set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference)");
+            return BT_ERR_UNSUPPORTED;
+        }
+        BT_CHECK(grow_buf(ctx, l2_lists, l2_total, l2_total + h_tot));
+        add_base_kernel<<<nblk(nb + 1), 256, 0, ctx->stream>>>(nb + 1, l2_rel.get(), (int32_t) l2_total,
+                                                              l2_by_box.get() + b0);
+        compact_strided_rows_kernel<<<nblk((int64_t) nb * 16), 256, 0, ctx->stream>>>(
+            nb, S, l2_rows.get(), l2_rel.get(), (int32_t) l2_total, l2_lists.get());
+        l2_total += h_tot;
+        fill_outside(b0 + nb + 1, lev_end, l2_total);
+    }
+    // colleague CSR from the rows
+    BT_CHECK(coll.starts.alloc(ctx->pool, B + 1));
+    {
+        ScanI32 fc{coll_cnt.get()};
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, fc, B, coll.starts.get(),
+                                                          (int32_t *) nullptr, true)));
+        int32_t t = 0;
+        BT_CHECK(read_i32(ctx, coll.starts.get() + B, &t));
+        if (t < 0) {
+            set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference)");
+            return BT_ERR_UNSUPPORTED;
+        }
+        coll.total = t;
+        BT_CHECK(coll.lists.alloc(ctx->pool, t));
+        compact_strided_rows_kernel<<<nblk(B * 16), 256, 0, ctx->stream>>>(
+            B, P, coll_rows.get(), coll.starts.get(), 0, coll.lists.get());
+    }
+    BT_HIP_CHECK(hipGetLastError());
+    *l2_total_out = l2_total;
+    return BT_OK;
+}
+
+// colleagues + list 2 (top-down from the parent's colleagues) and list 1 (from the
+// ancestors' colleagues), see bt_trav_fast.hpp
+template <class T, int D>
+int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
+{
+    (void) sizeof(int[1 << D]);
+    const bt_trav_params &p = st->p;
+    const int64_t B = p.nboxes;
+    const int nlevels = p.nlevels;
+    const int32_t *ls = p.level_start_box_nrs;       // host
+    const int walk_cap = nlevels + 1;
+    const size_t walk_lds = (size_t) walk_cap * WALK_THREADS * 4;
+    const size_t lvl_lds = (size_t) nlevels * WALK_THREADS * 4;
+
+    // depth-first preorder ranks
+    BT_CHECK(st->subtree_size.alloc(ctx->pool, B));
+    BT_CHECK(st->dfs_rank.alloc(ctx->pool, B));
+    BT_CHECK(st->box_of_rank.alloc(ctx->pool, B));
+    for (int lev = nlevels - 1; lev >= 0; --lev)
+        subtree_size_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
+            ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
+            st->subtree_size.get());
+    for (int lev = 0; lev < nlevels; ++lev)
+        dfs_rank_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
+            ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
+            st->subtree_size.get(), st->dfs_rank.get(), st->box_of_rank.get());
+    // source boxes in depth-first order (+ prefix counts over ranks)
+    BT_CHECK(st->src_rank_prefix.alloc(ctx->pool, B + 1));
+    {
+        SourceRankFlag<T, D> f{a.nodes, st->box_of_rank.get()};
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, f, B, st->src_rank_prefix.get(),
+                                                          (int32_t *) nullptr, true)));
+        BT_CHECK(st->src_by_rank.alloc(ctx->pool, st->nsb + 1));
+        compact_sources_by_rank_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
+            f, (int32_t) B, st->src_rank_prefix.get(), st->src_by_rank.get());
+    }
+    FastTree ft{st->dfs_rank.get(), st->box_of_rank.get(), st->subtree_size.get(),
+                st->src_rank_prefix.get(), st->src_by_rank.get()};
+
+    // colleagues + list 2, level by level
+    CsrList &coll = st->coll;
+    coll.n = B;
+    Buf<int32_t> l2_by_box;
+    Buf<int32_t> l2_lists;
+    int64_t l2_total = 0;
+    static const bool two_pass_env = [] {
+        const char *e = getenv("BT_COLL_TWO_PASS");     // tuning aid: the count+fill kernels
+        return e && atoi(e);
+    }();
+    if (p.well_sep_is_n_away == 1 && !two_pass_env) {
+        BT_CHECK((coll_l2_single_pass<T, D>(ctx, st, a, l2_by_box, l2_lists, &l2_total)));
+    } else {
+        BT_CHECK((coll_l2_two_pass<T, D>(ctx, st, a, l2_by_box, l2_lists, &l2_total)));
+    }
     a.coll_starts = coll.starts.get();
     a.coll_lists = coll.lists.get();
     BT_CHECK(tmark(ctx, st, "trav:colleagues+list2"));

@@ -252,6 +252,94 @@ __global__ __launch_bounds__(256) void coll_l2_kernel(TravArgs<T, D> a, int32_t 
     }
 }
 
+// Single-pass variant of coll_l2_kernel (well_sep_is_n_away == 1): no count pass.
+// Colleagues go to fixed-stride rows (a box has at most 3^d - 1 of them) that the
+// next level reads directly; list 2 goes to a per-level scratch row (at most
+// 6^d - 3^d entries) and is compacted into the CSR afterwards.  Every adjacency
+// test and every node load happens once instead of twice.
+template <class T, int D>
+__global__ __launch_bounds__(256) void coll_l2_rows_kernel(TravArgs<T, D> a, int32_t b0, int32_t nb,
+        int32_t *coll_rows, int32_t *coll_cnt, int32_t *l2_rows, int32_t *l2_cnt)
+{
+    constexpr int C = 1 << D;
+    constexpr int P = (D == 1 ? 3 : D == 2 ? 9 : 27) - 1;
+    constexpr int S = (D == 1 ? 6 : D == 2 ? 36 : 216) - (P + 1);
+    const int32_t t = blockIdx.x * 256 + threadIdx.x;
+    const int32_t g = t / C;
+    const int m = t % C;
+    if (g >= nb) return;                 // whole groups drop out together
+    const int32_t b = b0 + g;
+    const int lane = threadIdx.x & 63;
+    const int gshift = lane / C * C;
+    const uint64_t lanes_below = (1ull << m) - 1ull;
+
+    T center[D];
+    load_center(a, b, center);
+    const int level = box_level(a, b);
+    const int32_t p = a.parent[b];
+    const bool ttp = box_flags(a, b) & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX);
+    const int32_t *prow = coll_rows + (int64_t) p * P;
+    const int32_t n = coll_cnt[p];
+    int ins = 0;                         // depth-first position of p among its colleagues
+    for (int i = 0; i < n; ++i) ins += (prow[i] < p) ? 1 : 0;
+
+    int32_t *crow = coll_rows + (int64_t) b * P;
+    int32_t *lrow = l2_rows + (int64_t) g * S;
+    int32_t ccur = 0, lcur = 0;
+    constexpr int UNR = 4;
+    for (int i0 = 0; i0 <= n; i0 += UNR) {
+        int32_t cs[UNR], chs[UNR];
+        uint32_t lfs[UNR];
+        T ccs[UNR][D];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int i = i0 + u;
+            cs[u] = (i > n) ? 0 : (i < ins) ? prow[i] : (i == ins ? p : prow[i - 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) chs[u] = (i0 + u <= n) ? child_of<D>(a, cs[u], m) : 0;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const Node<T, D> nd = a.nodes[chs[u]];
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) ccs[u][ax] = nd.c[ax];
+            lfs[u] = nd.lf;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (i0 + u > n) break;
+            const int32_t c = cs[u], ch = chs[u];
+            bool is_coll = false, is_l2 = false;
+            if (ch != 0 && ch != b) {
+                const bool a_or_o = adj_nbhd<T, D>(a.root_extent, center, level, (T) 1,
+                                                   ccs[u], (int) (lfs[u] & 0xffu));
+                is_coll = a_or_o;                                   // traversal.py:429-442
+                is_l2 = !a_or_o && c != p && ttp;                   // traversal.py:588-597
+            }
+            const uint64_t bc = (__ballot(is_coll) >> gshift) & ((1ull << C) - 1);
+            const uint64_t bl = (__ballot(is_l2) >> gshift) & ((1ull << C) - 1);
+            if (is_coll) crow[ccur + __popcll(bc & lanes_below)] = ch;
+            if (is_l2) lrow[lcur + __popcll(bl & lanes_below)] = ch;
+            ccur += __popcll(bc);
+            lcur += __popcll(bl);
+        }
+    }
+    if (m == 0) { coll_cnt[b] = ccur; l2_cnt[g] = lcur; }
+}
+
+// rows[r][0..count) -> lists[base + starts[r] ...); 16 lanes per row
+__global__ __launch_bounds__(256) void compact_strided_rows_kernel(int64_t nrows, int stride,
+        const int32_t *rows, const int32_t *starts, int32_t base, int32_t *lists)
+{
+    const int64_t gid = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = gid >> 4;
+    const int lane = (int) (gid & 15);
+    if (r >= nrows) return;
+    const int32_t s = starts[r], e = starts[r + 1];
+    const int32_t *row = rows + r * stride;
+    for (int32_t k = lane; k < e - s; k += 16) lists[(int64_t) base + s + k] = row[k];
+}
+
 // Same lists, one WAVE per parent box: the candidates (children of the parent's
 // colleagues and of the parent itself, <= 27*8 in 3D) are loaded once and tested
 // against all children of the parent -- an eighth of the node loads of the
