@@ -158,6 +158,7 @@ EXPORTED_SYMBOLS = [
     "bt_traversal_build", "bt_traversal_export", "bt_merge_csr_lists",
     "bt_peer_lists_build", "bt_area_query_build", "bt_csr_export", "bt_leaves_to_balls",
     "bt_space_invader_query",
+    "bt_fmm_box_particle_sums", "bt_fmm_csr_sum", "bt_fmm_box_to_particles", "bt_fmm_tree_sweep",
     "bt_filter_targets_user_order", "bt_filter_targets_tree_order", "bt_link_point_sources",
     "bt_morton_cells", "bt_bucket_permutation", "bt_gather", "bt_gather_pack", "bt_unpack",
 ]
@@ -213,6 +214,10 @@ def load():
     lib.bt_filter_targets_tree_order.argtypes = [vp, ct.c_int64, ct.c_int64, vp, vp, vp, vp,
                                                  vp, vp, vp, ct.POINTER(ct.c_int64)]
     lib.bt_link_point_sources.argtypes = [vp, ct.c_int64, ct.c_int64, ct.c_int64] + [vp] * 11
+    lib.bt_fmm_box_particle_sums.argtypes = [vp, ct.c_int64, vp, vp, vp, vp, vp, ct.c_int]
+    lib.bt_fmm_csr_sum.argtypes = [vp, ct.c_int64, vp, vp, vp, vp, vp, ct.c_int]
+    lib.bt_fmm_box_to_particles.argtypes = [vp, ct.c_int64, vp, vp, vp, vp, vp, vp, ct.c_int]
+    lib.bt_fmm_tree_sweep.argtypes = [vp, ct.c_int64, vp, vp, ct.c_int64, ct.c_int, vp, vp]
     lib.bt_morton_cells.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), ct.c_int64,
                                     ct.POINTER(ct.c_double), ct.POINTER(ct.c_double),
                                     ct.c_int, vp, vp]

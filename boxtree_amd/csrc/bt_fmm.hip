@@ -1,0 +1,186 @@
+// Device kernels of the constant-one expansion wrangler (boxtree/constant_one.py:49-237)
+// that drive_fmm (boxtree/fmm.py:342-532) calls: every "expansion" is one float64
+// per box, every translation a sum.  Used to check interaction lists for
+// completeness at full problem size (each target must receive the total source
+// weight exactly once).
+#include "bt_common.hpp"
+#include "bt_prims.hpp"
+
+using namespace bt;
+
+namespace {
+
+// out[box] (+)= sum of values[start[box] : start[box]+count[box]]; one wave per listed box
+__global__ __launch_bounds__(256) void box_particle_sum_kernel(int64_t n, const int32_t *boxes,
+        const int32_t *starts, const int32_t *counts, const double *values, double *out,
+        int accumulate)
+{
+    const int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    if (i >= n) return;
+    const int32_t b = boxes ? boxes[i] : (int32_t) i;
+    const int64_t s = starts[b], c = counts[b];
+    double acc = 0;
+    for (int64_t j = lane; j < c; j += WAVE) acc += values[s + j];
+#pragma unroll
+    for (int off = WAVE / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) out[b] = accumulate ? out[b] + acc : acc;
+}
+
+// out[i] = sum over row i of box_values[lists[.]]; 8 lanes per row
+__global__ __launch_bounds__(256) void csr_sum_kernel(int64_t nrows, const int32_t *starts,
+        const int32_t *lists, const double *box_values, double *out)
+{
+    const int64_t gid = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = gid >> 3;
+    const int lane = (int) (gid & 7);
+    double acc = 0;
+    if (i < nrows) {
+        const int32_t s = starts[i], e = starts[i + 1];
+        for (int32_t j = s + lane; j < e; j += 8) acc += box_values[lists[j]];
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 8);
+    if (i < nrows && lane == 0) out[i] = acc;
+}
+
+// dst[row_boxes[i]] += row_values[i]
+__global__ __launch_bounds__(256) void scatter_add_rows_kernel(int64_t nrows, const int32_t *row_boxes,
+        const double *row_values, double *dst)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < nrows) dst[row_boxes[i]] += row_values[i];      // row boxes are distinct
+}
+
+// pot[start[b] : start[b]+count[b]] (+)= row_values[i] (or box_values[b]); one wave per row
+__global__ __launch_bounds__(256) void box_to_particles_kernel(int64_t nrows, const int32_t *row_boxes,
+        const int32_t *starts, const int32_t *counts, const double *row_values,
+        const double *box_values, double *pot, int accumulate)
+{
+    const int64_t i = ((int64_t) blockIdx.x * 256 + threadIdx.x) / WAVE;
+    const int lane = threadIdx.x % WAVE;
+    if (i >= nrows) return;
+    const int32_t b = row_boxes[i];
+    const double v = row_values ? row_values[i] : box_values[b];
+    const int64_t s = starts[b], c = counts[b];
+    for (int64_t j = lane; j < c; j += WAVE) pot[s + j] = accumulate ? pot[s + j] + v : v;
+}
+
+// coarsen_multipoles (constant_one.py:102-123): box += sum of its children
+__global__ __launch_bounds__(256) void add_children_kernel(int64_t n, const int32_t *boxes,
+        const int32_t *child_ids, int64_t aligned, int nchildren, double *vals)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t b = boxes[i];
+    double acc = vals[b];
+    for (int m = 0; m < nchildren; ++m) {
+        const int32_t c = child_ids[(int64_t) m * aligned + b];
+        if (c) acc += vals[c];
+    }
+    vals[b] = acc;
+}
+
+// refine_locals (constant_one.py:214-223): box += parent
+__global__ __launch_bounds__(256) void add_parent_kernel(int64_t n, const int32_t *boxes,
+        const int32_t *parent_ids, double *vals)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t b = boxes[i];
+    vals[b] += vals[parent_ids[b]];
+}
+
+unsigned blocks_for(int64_t threads) { return (unsigned) std::max<int64_t>(1, div_up(threads, 256)); }
+
+}  // namespace
+
+extern "C" {
+
+int bt_fmm_box_particle_sums(bt_context *ctx, int64_t n, const int32_t *boxes,
+                             const int32_t *box_starts, const int32_t *box_counts,
+                             const double *values, double *out, int accumulate)
+{
+    if (!ctx || n < 0 || !box_starts || !box_counts || !out || (n > 0 && !values)) {
+        set_error("bt_fmm_box_particle_sums: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (n > 0)
+        box_particle_sum_kernel<<<blocks_for(n * WAVE), 256, 0, ctx->stream>>>(
+            n, boxes, box_starts, box_counts, values, out, accumulate);
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+int bt_fmm_csr_sum(bt_context *ctx, int64_t nrows, const int32_t *starts, const int32_t *lists,
+                   const double *box_values, const int32_t *row_boxes, double *out,
+                   int scatter_add)
+{
+    if (!ctx || nrows < 0 || !starts || !box_values || !out || (scatter_add && !row_boxes)) {
+        set_error("bt_fmm_csr_sum: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (nrows > 0) {
+        if (!scatter_add) {
+            csr_sum_kernel<<<blocks_for(nrows * 8), 256, 0, ctx->stream>>>(nrows, starts, lists,
+                                                                          box_values, out);
+        } else {
+            Buf<double> rows;
+            BT_CHECK(rows.alloc(ctx->pool, nrows));
+            csr_sum_kernel<<<blocks_for(nrows * 8), 256, 0, ctx->stream>>>(nrows, starts, lists,
+                                                                          box_values, rows.get());
+            scatter_add_rows_kernel<<<blocks_for(nrows), 256, 0, ctx->stream>>>(nrows, row_boxes,
+                                                                               rows.get(), out);
+            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+    }
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+int bt_fmm_box_to_particles(bt_context *ctx, int64_t nrows, const int32_t *row_boxes,
+                            const int32_t *box_starts, const int32_t *box_counts,
+                            const double *row_values, const double *box_values, double *pot,
+                            int accumulate)
+{
+    if (!ctx || nrows < 0 || !box_starts || !box_counts || !pot || (nrows > 0 && !row_boxes)
+            || (!row_values && !box_values)) {
+        set_error("bt_fmm_box_to_particles: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (nrows > 0)
+        box_to_particles_kernel<<<blocks_for(nrows * WAVE), 256, 0, ctx->stream>>>(
+            nrows, row_boxes, box_starts, box_counts, row_values, box_values, pot, accumulate);
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+int bt_fmm_tree_sweep(bt_context *ctx, int64_t n, const int32_t *boxes, const int32_t *child_ids,
+                      int64_t aligned_nboxes, int nchildren, const int32_t *parent_ids,
+                      double *box_values)
+{
+    if (!ctx || n < 0 || !box_values || (n > 0 && !boxes) || (!child_ids && !parent_ids)) {
+        set_error("bt_fmm_tree_sweep: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (n > 0) {
+        if (child_ids)
+            add_children_kernel<<<blocks_for(n), 256, 0, ctx->stream>>>(n, boxes, child_ids,
+                                                                       aligned_nboxes, nchildren,
+                                                                       box_values);
+        else
+            add_parent_kernel<<<blocks_for(n), 256, 0, ctx->stream>>>(n, boxes, parent_ids, box_values);
+    }
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+}  // extern "C"

@@ -356,6 +356,39 @@ int bt_link_point_sources(bt_context *ctx, int64_t nsources, int64_t nboxes,
                           int32_t *box_point_source_counts_nonchild,
                           int32_t *box_point_source_counts_cumul);
 
+/* ---- constant-one FMM evaluation (boxtree/constant_one.py:49-237, driven by
+ *      boxtree/fmm.py:342-532): one float64 per box stands for an expansion ---- */
+
+/* out[b] (+)= sum(values[box_starts[b] : box_starts[b]+box_counts[b]]) for the n
+ * listed boxes (boxes == NULL: boxes 0..n-1).  form_multipoles (:86-97) and the
+ * per-source-box weights that eval_direct / form_locals add up (:125-146, :190-212). */
+int bt_fmm_box_particle_sums(bt_context *ctx, int64_t n, const int32_t *boxes,
+                             const int32_t *box_starts, const int32_t *box_counts,
+                             const double *values, double *out, int accumulate);
+
+/* Row sums of a CSR interaction list: r[i] = sum(box_values[lists[starts[i]:starts[i+1]]]).
+ * scatter_add == 0: out[i] = r[i] (out has nrows entries);
+ * scatter_add == 1: out[row_boxes[i]] += r[i] (out is indexed by box number) --
+ * multipole_to_local (:148-166), form_locals (:190-212). */
+int bt_fmm_csr_sum(bt_context *ctx, int64_t nrows, const int32_t *starts, const int32_t *lists,
+                   const double *box_values, const int32_t *row_boxes, double *out,
+                   int scatter_add);
+
+/* pot[box_starts[b] : +box_counts[b]] (+)= v for the boxes b = row_boxes[i], with
+ * v = row_values[i] (row_values != NULL) or box_values[b]: eval_direct (:144),
+ * eval_multipoles (:186), eval_locals (:225-235). */
+int bt_fmm_box_to_particles(bt_context *ctx, int64_t nrows, const int32_t *row_boxes,
+                            const int32_t *box_starts, const int32_t *box_counts,
+                            const double *row_values, const double *box_values, double *pot,
+                            int accumulate);
+
+/* One level of an upward (child_ids != NULL: box += its children, coarsen_multipoles
+ * :99-123) or downward (parent_ids: box += its parent, refine_locals :214-223) sweep
+ * over the listed boxes. */
+int bt_fmm_tree_sweep(bt_context *ctx, int64_t n, const int32_t *boxes, const int32_t *child_ids,
+                      int64_t aligned_nboxes, int nchildren, const int32_t *parent_ids,
+                      double *box_values);
+
 /* ---- multi-GPU exchange helpers (no counterpart in the reference, which never
  *      builds the tree in parallel: boxtree/distributed/__init__.py:183-199) ---- */
 
