@@ -218,6 +218,9 @@ def load():
     lib.bt_fmm_csr_sum.argtypes = [vp, ct.c_int64, vp, vp, vp, vp, vp, ct.c_int]
     lib.bt_fmm_box_to_particles.argtypes = [vp, ct.c_int64, vp, vp, vp, vp, vp, vp, ct.c_int]
     lib.bt_fmm_tree_sweep.argtypes = [vp, ct.c_int64, vp, vp, ct.c_int64, ct.c_int, vp, vp]
+    lib.bt_translation_classes.argtypes = [
+        vp, ct.c_int, ct.c_int, ct.c_int64, vp, vp, vp, ct.c_int64, vp, ct.c_int64, ct.c_double,
+        vp, ct.c_int, ct.c_int, ct.c_int, vp, vp, ct.POINTER(ct.c_int32)]
     lib.bt_morton_cells.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), ct.c_int64,
                                     ct.POINTER(ct.c_double), ct.POINTER(ct.c_double),
                                     ct.c_int, vp, vp]

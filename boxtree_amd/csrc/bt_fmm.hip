@@ -91,6 +91,47 @@ __global__ __launch_bounds__(256) void add_parent_kernel(int64_t n, const int32_
     vals[b] += vals[parent_ids[b]];
 }
 
+
+// TRANSLATION_CLASS_FINDER_TEMPLATE (translation_classes.py:62-189): one thread per
+// list-2 entry
+template <class T, int D>
+__global__ __launch_bounds__(256) void translation_class_kernel(int64_t n, const int32_t *lists,
+        const int32_t *starts, const int32_t *ttp_boxes, int64_t nttp, const T *box_centers,
+        int64_t aligned, T root_extent, const uint8_t *box_levels, int nway, int per_level,
+        int32_t *classes, int32_t *class_is_used, int32_t *error_flag)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t source_box_id = lists[i];
+    int64_t lo = 0, hi = nttp;          // last row with starts[row] <= i
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t) starts[mid] <= i) lo = mid; else hi = mid;
+    }
+    const int32_t target_box_id = ttp_boxes[lo];
+    const int level = box_levels[source_box_id];
+    if (level != (int) box_levels[target_box_id]) { atomicOr(error_flag, 1); return; }
+    // get_normalized_translation_vector, :71-85
+    const T diam = 2 * (root_extent * 1 / (T) (1 << (level + 1)));
+    const int dim_bound = 2 * nway + 1;
+    const int base = 4 * nway + 3;
+    int result = 0, mult = 1;
+    bool bad = false;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        const T tc = box_centers[aligned * d + target_box_id];
+        const T sc = box_centers[aligned * d + source_box_id];
+        const int v = (int) rint((tc - sc) / diam);
+        bad |= !(-dim_bound <= v && v <= dim_bound);           // :108-114
+        result += (2 * nway + 1 + v) * mult;                    // :116-122
+        mult *= base;
+    }
+    if (bad) { atomicOr(error_flag, 1); return; }
+    if (per_level) result += level * mult;                      // :177-180 (mult == base^D)
+    classes[i] = result;
+    if (!class_is_used[result]) atomicOr(&class_is_used[result], 1);
+}
+
 unsigned blocks_for(int64_t threads) { return (unsigned) std::max<int64_t>(1, div_up(threads, 256)); }
 
 }  // namespace
@@ -179,6 +220,49 @@ int bt_fmm_tree_sweep(bt_context *ctx, int64_t n, const int32_t *boxes, const in
             add_parent_kernel<<<blocks_for(n), 256, 0, ctx->stream>>>(n, boxes, parent_ids, box_values);
     }
     BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+int bt_translation_classes(bt_context *ctx, int dims, int coord_kind, int64_t n_entries,
+                           const int32_t *from_sep_siblings_lists,
+                           const int32_t *from_sep_siblings_starts,
+                           const int32_t *target_or_target_parent_boxes, int64_t nttp,
+                           const void *box_centers, int64_t aligned_nboxes, double root_extent,
+                           const uint8_t *box_levels, int well_sep_is_n_away, int per_level,
+                           int nclasses, int32_t *classes, int32_t *class_is_used, int32_t *error)
+{
+    if (!ctx || dims < 1 || dims > 3 || n_entries < 0 || nttp < 0 || nclasses < 1
+            || !from_sep_siblings_starts || !box_centers || !box_levels || !class_is_used || !error
+            || (n_entries > 0 && (!from_sep_siblings_lists || !target_or_target_parent_boxes
+                                  || !classes))) {
+        set_error("bt_translation_classes: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    Buf<int32_t> d_err;
+    BT_CHECK(d_err.alloc(ctx->pool, 1));
+    BT_HIP_CHECK(hipMemsetAsync(d_err.get(), 0, 4, ctx->stream));
+    BT_HIP_CHECK(hipMemsetAsync(class_is_used, 0, (size_t) nclasses * 4, ctx->stream));
+    if (n_entries > 0) {
+        const unsigned blocks = blocks_for(n_entries);
+#define TC_LAUNCH(T, D)                                                                      \
+        translation_class_kernel<T, D><<<blocks, 256, 0, ctx->stream>>>(                      \
+            n_entries, from_sep_siblings_lists, from_sep_siblings_starts,                    \
+            target_or_target_parent_boxes, nttp, (const T *) box_centers, aligned_nboxes,    \
+            (T) root_extent, box_levels, well_sep_is_n_away, per_level, classes,             \
+            class_is_used, d_err.get())
+        if (coord_kind == BT_F64) {
+            if (dims == 1) TC_LAUNCH(double, 1); else if (dims == 2) TC_LAUNCH(double, 2);
+            else TC_LAUNCH(double, 3);
+        } else {
+            if (dims == 1) TC_LAUNCH(float, 1); else if (dims == 2) TC_LAUNCH(float, 2);
+            else TC_LAUNCH(float, 3);
+        }
+#undef TC_LAUNCH
+        BT_HIP_CHECK(hipGetLastError());
+    }
+    BT_HIP_CHECK(hipMemcpyAsync(error, d_err.get(), 4, hipMemcpyDeviceToHost, ctx->stream));
     BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return BT_OK;
 }

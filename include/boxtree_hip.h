@@ -389,6 +389,20 @@ int bt_fmm_tree_sweep(bt_context *ctx, int64_t n, const int32_t *boxes, const in
                       int64_t aligned_nboxes, int nchildren, const int32_t *parent_ids,
                       double *box_values);
 
+/* TranslationClassesBuilder.compute_translation_classes (translation_classes.py:325-378;
+ * kernel :62-189), shared by RotationClassesBuilder (rotation_classes.py:166-177):
+ * classes[i] = class of the translation from list-2 entry i to its target box,
+ * class_is_used[nclasses] (zeroed here) marks the classes that occur; nclasses =
+ * (4n+3)^d, times nlevels if per_level.  *error != 0: a pair of boxes on different
+ * levels or further apart than 2n+1 boxes (ValueError upstream). */
+int bt_translation_classes(bt_context *ctx, int dims, int coord_kind, int64_t n_entries,
+                           const int32_t *from_sep_siblings_lists,
+                           const int32_t *from_sep_siblings_starts,
+                           const int32_t *target_or_target_parent_boxes, int64_t nttp,
+                           const void *box_centers, int64_t aligned_nboxes, double root_extent,
+                           const uint8_t *box_levels, int well_sep_is_n_away, int per_level,
+                           int nclasses, int32_t *classes, int32_t *class_is_used, int32_t *error);
+
 /* ---- multi-GPU exchange helpers (no counterpart in the reference, which never
  *      builds the tree in parallel: boxtree/distributed/__init__.py:183-199) ---- */
 

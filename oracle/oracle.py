@@ -856,4 +856,95 @@ def link_point_sources(tree, point_source_starts, point_sources):
 
 # }}}
 
+# {{{ translation / rotation classes (boxtree/translation_classes.py, rotation_classes.py)
+
+def translation_classes(tree, trav, is_translation_per_level=True):
+    """TranslationClassesBuilder.__call__ (translation_classes.py:380-442; kernel
+    :62-189).  -> (classes per list-2 entry, distance vectors [d, nclasses_used],
+    level starts)."""
+    nway = trav.well_sep_is_n_away
+    dims = tree.dimensions
+    coord = np.dtype(tree.coord_dtype).type
+    per_level = (4 * nway + 3) ** dims
+    nclasses = per_level * (tree.nlevels if is_translation_per_level else 1)
+    lists, starts = trav.from_sep_siblings_lists, trav.from_sep_siblings_starts
+    ttp = trav.target_or_target_parent_boxes
+    raw = np.zeros(len(lists), np.int32)
+    used = np.zeros(nclasses, np.int32)
+    for itgt, tgt in enumerate(ttp):
+        for i in range(starts[itgt], starts[itgt + 1]):
+            src = lists[i]
+            level = int(tree.box_levels[src])
+            if level != int(tree.box_levels[tgt]):
+                raise ValueError("could not compute translation classes")
+            diam = coord(2) * (coord(tree.root_extent) * coord(1) / coord(1 << (level + 1)))
+            result, mult = 0, 1
+            for d in range(dims):
+                v = int(np.rint((tree.box_centers[d, tgt] - tree.box_centers[d, src]) / diam))
+                if not -(2 * nway + 1) <= v <= 2 * nway + 1:
+                    raise ValueError("could not compute translation classes")
+                result += (2 * nway + 1 + v) * mult
+                mult *= 4 * nway + 3
+            if is_translation_per_level:
+                result += level * per_level
+            raw[i] = result
+            used[result] = 1
+    dense = np.full(nclasses, -1, np.int32)
+    dist = []
+    level_starts = np.zeros(tree.nlevels + 1, np.int32)
+    visited = np.zeros(tree.nlevels + 1, bool)
+    count = 0
+    for cls in range(nclasses):
+        level, c = divmod(cls, per_level)
+        if not visited[level]:
+            level_starts[level] = count
+            visited[level] = True
+        if not used[cls]:
+            continue
+        dense[cls] = count
+        vec = np.zeros(dims, np.int32)
+        for d in range(dims):
+            vec[d] = c % (4 * nway + 3) - (2 * nway + 1)
+            c //= 4 * nway + 3
+        dist.append(vec * tree.root_extent / (1 << level))
+        count += 1
+    level_starts[tree.nlevels] = count
+    level_starts[:tree.nlevels][~visited[:tree.nlevels]] = count
+    distances = (np.array(dist, dtype=tree.coord_dtype).T if dist
+                 else np.zeros((dims, 0), tree.coord_dtype))
+    return SimpleNamespace(
+        raw_classes=raw, class_is_used=used,
+        from_sep_siblings_translation_classes=dense[raw],
+        from_sep_siblings_translation_class_to_distance_vector=distances,
+        from_sep_siblings_translation_classes_level_starts=level_starts)
+
+
+def rotation_classes(tree, trav):
+    """RotationClassesBuilder.__call__ (rotation_classes.py:163-198)."""
+    import math
+    tc = translation_classes(tree, trav, is_translation_per_level=False)
+    nway, dims = trav.well_sep_is_n_away, tree.dimensions
+    base, shift = 4 * nway + 3, 2 * nway + 1
+    rot_of = np.full(base ** dims, -1, np.int32)
+    by_angle, angles = {}, []
+    for cls in np.flatnonzero(tc.class_is_used):
+        c = int(cls)
+        vec = np.zeros(dims, np.int32)
+        for d in range(dims):
+            vec[d] = c % base - shift
+            c //= base
+        g = 0
+        for e in vec:
+            g = math.gcd(g, abs(int(e)))
+        vec = vec // g
+        angle = np.arccos(vec[-1] / np.linalg.norm(vec))
+        if angle not in by_angle:
+            by_angle[angle] = len(angles)
+            angles.append(angle)
+        rot_of[cls] = by_angle[angle]
+    return SimpleNamespace(from_sep_siblings_rotation_classes=rot_of[tc.raw_classes],
+                           from_sep_siblings_rotation_class_to_angle=np.array(angles))
+
+# }}}
+
 # vim: foldmethod=marker
