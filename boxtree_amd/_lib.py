@@ -184,6 +184,12 @@ def load():
             f"{LIB_PATH} not found: the HIP extension has not been built "
             "(run `python -c 'import __graft_entry__ as g; g.build()'` or "
             "`make -C boxtree_amd/csrc`). boxtree_amd has no CPU fallback.")
+    # PyTorch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so).  It
+    # must be in the process BEFORE this library is loaded: then the dynamic linker
+    # binds libboxtree_hip.so to that copy and both share one runtime (streams,
+    # device pointers).  The other order maps /opt/rocm's runtime as well, and the
+    # second runtime finds no device.
+    import torch  # noqa: F401
     lib = ct.CDLL(LIB_PATH)
     lib.bt_abi_version.restype = ct.c_int
     lib.bt_last_error_string.restype = ct.c_char_p
