@@ -688,3 +688,107 @@ def test_deep_tree_beyond_the_presorted_bits(actx, oracle, dims, spread):
     if spread < 1e-3:
         assert htree.nlevels > (14 if dims == 3 else 21)
     check_tree(htree, p, max_particles_in_box=8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,world,dist_kind", [(3, 3, "sphere"), (3, 4, "uniform"),
+                                                  (2, 2, "normal")])
+def test_multi_rank_pipeline_in_process(dims, world, dist_kind):
+    """The whole N-rank path of distributed.py / bench.py (global bbox, cell
+    histogram, exchange, per-rank build, numbering, box all-gather, per-rank lists)
+    with the ranks as threads on one GPU and an in-process torch.distributed
+    stand-in: every rank ends up with the box arrays of the tree one rank builds
+    from all points, and its lists are the rows of the global traversal."""
+    import threading
+
+    import torch
+    from fake_dist import FakeWorld
+    from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
+    from boxtree_amd.distributed import (exchange_particles, gather_global_box_tree,
+                                         number_sharded_tree)
+    n_per, mpb = 60000, 30
+    top_level = 3 if dims == 3 else 4
+
+    def chunk(rank):
+        rng = np.random.default_rng(100 + rank)
+        if dist_kind == "sphere":
+            v = rng.standard_normal((dims, n_per))
+            v /= np.sqrt((v * v).sum(axis=0))
+            return [np.ascontiguousarray(v[i]) for i in range(dims)]
+        if dist_kind == "uniform":
+            return [rng.random(n_per) for _ in range(dims)]
+        return [rng.standard_normal(n_per) for _ in range(dims)]
+
+    chunks = [chunk(r) for r in range(world)]
+    fw = FakeWorld(world)
+    results = [None] * world
+    errors = []
+
+    def run(rank):
+        try:
+            actx = HIPArrayContext(0)
+            dist = fw.rank_view(rank)
+            pts = [torch.from_numpy(a).cuda() for a in chunks[rank]]
+            p2, _, kw, stats = exchange_particles(actx, dist, pts, None, {}, top_level=top_level,
+                                                  max_particles_in_box=mpb)
+            tree, _ = TreeBuilder(actx)(actx, p2, max_particles_in_box=mpb, **kw)
+            num = number_sharded_tree(dist, tree, stats)
+            gtree = gather_global_box_tree(actx, dist, tree, num)
+            trav, _ = FMMTraversalBuilder(actx)(
+                actx, gtree, _target_boxes_mask=num["target_boxes_mask"],
+                _active_level_ranges=num["active_level_ranges"])
+            results[rank] = dict(num=num, gtree=actx.to_numpy(gtree), trav=actx.to_numpy(trav),
+                                 nlocal=int(tree.nsources),
+                                 mask=num["target_boxes_mask"].cpu().numpy().astype(bool))
+        except BaseException as e:      # noqa: BLE001
+            errors.append((rank, repr(e)))
+            try:
+                fw.barrier.abort()
+            except Exception:           # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+
+    # the single-rank reference over the concatenated input
+    actx = HIPArrayContext(0)
+    allpts = [torch.from_numpy(np.concatenate([c[ax] for c in chunks])).cuda()
+              for ax in range(dims)]
+    gt, _ = TreeBuilder(actx)(actx, allpts, max_particles_in_box=mpb)
+    full = actx.to_numpy(FMMTraversalBuilder(actx)(actx, gt)[0])
+    g = actx.to_numpy(gt)
+    assert sum(r["nlocal"] for r in results) == world * n_per
+
+    def rows(starts, lists, sel):
+        return [lists[starts[i]:starts[i + 1]].tolist() for i in sel]
+
+    covered = np.zeros(g.nboxes, bool)
+    for r in results:
+        t, tr, hm = r["gtree"], r["trav"], r["mask"]
+        assert r["num"]["nboxes"] == g.nboxes
+        assert np.array_equal(t.level_start_box_nrs, g.level_start_box_nrs)
+        for name in ("box_centers", "box_levels", "box_parent_ids", "box_child_ids", "box_flags"):
+            assert np.array_equal(getattr(t, name), getattr(g, name)), name
+        covered |= hm
+        sel_t = np.nonzero(hm[full.target_boxes])[0]
+        sel_p = np.nonzero(hm[full.target_or_target_parent_boxes])[0]
+        assert np.array_equal(tr.target_boxes, full.target_boxes[sel_t])
+        for name, sel in (("neighbor_source_boxes", sel_t), ("from_sep_siblings", sel_p),
+                          ("from_sep_bigger", sel_p)):
+            got = rows(getattr(tr, name + "_starts"), getattr(tr, name + "_lists"),
+                       range(len(sel)))
+            want = rows(getattr(full, name + "_starts"), getattr(full, name + "_lists"), sel)
+            assert got == want, name
+        for lev in range(g.nlevels):
+            a, b = tr.from_sep_smaller_by_level[lev], full.from_sep_smaller_by_level[lev]
+            got = {int(tb): a.lists[a.starts[i]:a.starts[i + 1]].tolist()
+                   for i, tb in enumerate(tr.target_boxes_sep_smaller_by_source_level[lev])}
+            want = {int(tb): b.lists[b.starts[i]:b.starts[i + 1]].tolist()
+                    for i, tb in enumerate(full.target_boxes_sep_smaller_by_source_level[lev])
+                    if hm[tb]}
+            assert got == want
+    assert covered.all()
