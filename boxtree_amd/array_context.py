@@ -110,6 +110,20 @@ def _torch_dtype(torch, dtype):
     }[dtype]
 
 
+def as_device_array(actx, a):
+    """Device tensor for *a*: numpy arrays are uploaded, torch tensors pass through,
+    anything exposing ``__cuda_array_interface__`` (CuPy, Numba, ... device arrays)
+    is wrapped without a copy."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return actx.from_numpy(a)
+    torch = actx.torch
+    if not isinstance(a, torch.Tensor) and hasattr(a, "__cuda_array_interface__"):
+        return torch.as_tensor(a, device=actx.device)
+    return a
+
+
 def np_dtype_of(t):
     """numpy dtype of a torch tensor / numpy array."""
     if isinstance(t, np.ndarray):

@@ -180,8 +180,8 @@ class FMMTraversalBuilder:
         def dev(a):
             if a is None:
                 return None
-            t = actx.from_numpy(a) if isinstance(a, np.ndarray) else a
-            return t.contiguous()
+            from boxtree_amd.array_context import as_device_array
+            return as_device_array(actx, a).contiguous()
 
         nlevels = int(tree.nlevels)
         sources_are_targets = getattr(tree, "sources_are_targets", True)

@@ -92,8 +92,8 @@ class TreeBuilder:
         def dev(a):
             if a is None:
                 return None
-            t = actx.from_numpy(a) if isinstance(a, np.ndarray) else a
-            return t.contiguous()
+            from boxtree_amd.array_context import as_device_array
+            return as_device_array(actx, a).contiguous()
 
         particles = [dev(p) for p in particles]
         coord_dtypes = {np_dtype_of(p) for p in particles}

@@ -792,3 +792,23 @@ def test_multi_rank_pipeline_in_process(dims, world, dist_kind):
                     if hm[tb]}
             assert got == want
     assert covered.all()
+
+
+@pytest.mark.gpu
+def test_cuda_array_interface_inputs(actx, oracle):
+    """SURVEY 8b input layout: any object exposing __cuda_array_interface__ is
+    accepted as a coordinate array (wrapped without a copy)."""
+    from boxtree_amd import TreeBuilder
+
+    class Foreign:
+        def __init__(self, t):
+            self._t = t
+            self.__cuda_array_interface__ = t.__cuda_array_interface__
+
+        def __len__(self):
+            return len(self._t)
+
+    p = normal_particles(5000, 3, np.float64, seed=2)
+    dev = [actx.from_numpy(x) for x in p]
+    tree, _ = TreeBuilder(actx)(actx, [Foreign(t) for t in dev], max_particles_in_box=30)
+    assert_same_tree(actx.to_numpy(tree), oracle.build_tree(p, max_particles_in_box=30))
