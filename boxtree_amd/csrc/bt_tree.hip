@@ -1439,7 +1439,7 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
         // destination windows of ~100 MB; measured at 10^8 ids: 1 window 2.26 ms,
         // 2: 2.11, 4: 1.86, 8: 2.47 (every window re-reads the ids)
         const int id_windows = id_windows_env > 0 ? id_windows_env
-            : (int) std::min<int64_t>(4, std::max<int64_t>(1, N / (24 << 20)));
+            : (int) std::min<int64_t>(4, std::max<int64_t>(1, N / (20 << 20)));
         if (sat && id_windows > 1) {
             copy_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(N, st->ids, o->user_source_ids);
             for (int w = 0; w < id_windows; ++w) {
