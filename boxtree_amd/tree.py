@@ -77,6 +77,25 @@ class TreeOfBoxes(_Container):
             return len(self.level_start_box_nrs) - 1
         return int(self.box_levels.max()) + 1
 
+    # helpers of the reference's class (boxtree/tree.py:266-287); numpy-backed trees
+    @property
+    def leaf_boxes(self):
+        boxes = np.arange(self.nboxes, dtype=self.box_id_dtype)
+        return boxes[self.box_flags & box_flags_enum.IS_LEAF_BOX != 0]
+
+    @property
+    def bounding_box(self):
+        lows = self.box_centers[:, 0] - 0.5 * self.root_extent
+        return lows, lows + self.root_extent
+
+    def get_box_size(self, ibox):
+        return self.root_extent * 0.5 ** int(self.box_levels[ibox])
+
+    def get_box_extent(self, ibox):
+        box_size = self.get_box_size(ibox)
+        extent_low = self.box_centers[:, ibox] - 0.5 * box_size
+        return extent_low, extent_low + box_size
+
 
 @dataclass(frozen=True)
 class Tree(_Container):
