@@ -211,32 +211,39 @@ def active_boxes(plan, global_level_starts, deep_base, level_counts, device=None
 def local_to_global_box_ids(tree, plan, global_level_starts, deep_base, bbox_min, root_extent):
     """int64 tensor [local nboxes] of global box numbers (see
     :func:`global_box_numbering`).  Boxes at levels <= top_level are located by the
-    Morton path of their centre."""
+    Morton path of their centre (a few ten thousand boxes: done on the host),
+    deeper boxes by their position in the rank's level slice."""
     import torch
     k = plan["top_level"]
     dims = plan["dims"]
     lsb = np.asarray(tree.level_start_box_nrs if isinstance(tree.level_start_box_nrs, np.ndarray)
                      else tree.level_start_box_nrs.cpu().numpy(), dtype=np.int64)
+    nlev = len(lsb) - 1
     nboxes = int(tree.nboxes)
     centers = tree.box_centers
     dev = centers.device
-    out = torch.empty(nboxes, dtype=torch.int64, device=dev)
-    for lev in range(len(lsb) - 1):
+    # deep levels: global = local + (deep_base[level] - local level start)
+    shift = np.zeros(max(nlev, 1), dtype=np.int64)
+    for lev in range(k + 1, nlev):
+        shift[lev] = int(deep_base[lev]) - int(lsb[lev])
+    levels = tree.box_levels[:nboxes].long()
+    out = torch.arange(nboxes, dtype=torch.int64, device=dev) + torch.from_numpy(shift).to(dev)[levels]
+    # shared top levels
+    ntop = int(lsb[min(k + 1, nlev)])
+    ctr = centers[:, :ntop].double().cpu().numpy()
+    lev_h = np.repeat(np.arange(min(k + 1, nlev)), np.diff(lsb[:min(k + 1, nlev) + 1]))
+    path = np.zeros(ntop, dtype=np.int64)
+    for ax in range(dims):
+        # centres sit at (i + 1/2) / 2^level of the root box: floor is robust
+        v = np.floor((ctr[ax] - float(bbox_min[ax])) / float(root_extent) * 2.0 ** lev_h).astype(np.int64)
+        v = np.clip(v, 0, (1 << lev_h) - 1)
+        for bit in range(k):
+            path |= ((v >> bit) & 1) << (dims * bit + (dims - 1 - ax))
+    gid = np.empty(ntop, dtype=np.int64)
+    for lev in range(min(k + 1, nlev)):
         b0, b1 = int(lsb[lev]), int(lsb[lev + 1])
-        if b1 <= b0:
-            continue
-        if lev > k:
-            out[b0:b1] = torch.arange(b1 - b0, device=dev) + int(deep_base[lev])
-            continue
-        path = torch.zeros(b1 - b0, dtype=torch.int64, device=dev)
-        for ax in range(dims):
-            # centres sit at (i + 1/2) / 2^lev of the root box: floor is robust
-            v = ((centers[ax, b0:b1].double() - float(bbox_min[ax])) / float(root_extent)
-                 * float(1 << lev)).floor().long().clamp_(0, (1 << lev) - 1)
-            for b in range(lev):
-                path |= ((v >> b) & 1) << (dims * b + (dims - 1 - ax))
-        index = torch.from_numpy(plan["index"][lev]).to(dev)
-        out[b0:b1] = index[path] + int(global_level_starts[lev])
+        gid[b0:b1] = plan["index"][lev][path[b0:b1]] + int(global_level_starts[lev])
+    out[:ntop] = torch.from_numpy(gid).to(dev)
     return out
 
 
@@ -457,8 +464,10 @@ def gather_global_box_tree(actx, dist, tree, numbering):
     """Step 6: all-gathers the box arrays of the ranks' local trees into the global
     numbering.  Every rank gets the complete :class:`~boxtree_amd.tree.TreeOfBoxes`
     (centres, levels, flags, parents, children, level starts) the traversal kernels
-    walk; particles stay where they are.  ``box_flags`` of the shared top boxes are
-    the OR, ``box_child_ids`` the union of the ranks' views."""
+    walk; particles stay where they are.  ``box_child_ids`` of the shared top boxes
+    are the union of the ranks' views (their other fields agree between ranks).
+    Two collectives: one int32 record per box (number, parent, level, flags,
+    children) and the centres."""
     import torch
 
     from boxtree_amd.tree import TreeOfBoxes
@@ -468,43 +477,40 @@ def gather_global_box_tree(actx, dist, tree, numbering):
     nb = int(tree.nboxes)
     ids = numbering["box_ids"]
     dev = ids.device
-    nmax = int(np.max(numbering["nboxes_by_rank"]))
+    counts = [int(c) for c in numbering["nboxes_by_rank"]]
+    nmax = max(counts)
     B = int(numbering["nboxes"])
     aligned = -(-B // 32) * 32
     ch = tree.box_child_ids[:, :nb].long()
-    ch_g = torch.where(ch != 0, ids[ch], torch.zeros_like(ch)).to(torch.int32)
-    par_g = ids[tree.box_parent_ids.long()].to(torch.int32)
-
-    def gathered(t, fill=0):
-        """[world][nmax, ...] views of every rank's (padded) array."""
-        pad = torch.full((nmax,) + tuple(t.shape[1:]), fill, dtype=t.dtype, device=dev)
-        pad[:nb] = t
-        out = [torch.empty_like(pad) for _ in range(world)]
-        dist.all_gather(out, pad)
-        return out
-
-    g_ids = gathered(ids.to(torch.int32))
-    g_ctr = gathered(tree.box_centers[:, :nb].t().contiguous())
-    g_lev = gathered(tree.box_levels)
-    g_flg = gathered(tree.box_flags)
-    g_par = gathered(par_g)
-    g_ch = gathered(ch_g.t().contiguous())
+    rec = torch.zeros((nmax, C + 4), dtype=torch.int32, device=dev)
+    rec[:nb, 0] = ids.to(torch.int32)
+    rec[:nb, 1] = ids[tree.box_parent_ids[:nb].long()].to(torch.int32)
+    rec[:nb, 2] = tree.box_levels[:nb].to(torch.int32)
+    rec[:nb, 3] = tree.box_flags[:nb].to(torch.int32)
+    rec[:nb, 4:] = torch.where(ch != 0, ids[ch], torch.zeros_like(ch)).to(torch.int32).t()
+    ctr = torch.zeros((nmax, dims), dtype=tree.box_centers.dtype, device=dev)
+    ctr[:nb] = tree.box_centers[:, :nb].t()
+    g_rec = [torch.empty_like(rec) for _ in range(world)]
+    g_ctr = [torch.empty_like(ctr) for _ in range(world)]
+    dist.all_gather(g_rec, rec)
+    dist.all_gather(g_ctr, ctr)
+    rec_all = torch.cat([g_rec[r][:counts[r]] for r in range(world)])
+    ctr_all = torch.cat([g_ctr[r][:counts[r]] for r in range(world)])
+    gi = rec_all[:, 0].long()
     centers = torch.zeros((dims, aligned), dtype=tree.box_centers.dtype, device=dev)
+    centers[:, gi] = ctr_all.t()
     levels = torch.zeros(B, dtype=torch.uint8, device=dev)
+    levels[gi] = rec_all[:, 2].to(torch.uint8)
     flags = torch.zeros(B, dtype=torch.uint8, device=dev)
+    flags[gi] = rec_all[:, 3].to(torch.uint8)
     parents = torch.zeros(B, dtype=torch.int32, device=dev)
-    children = torch.zeros((C, aligned), dtype=torch.int32, device=dev)
-    for r in range(world):
-        n = int(numbering["nboxes_by_rank"][r])
-        if n == 0:
-            continue
-        gi = g_ids[r][:n].long()
-        centers[:, gi] = g_ctr[r][:n].t()
-        levels[gi] = g_lev[r][:n]
-        parents[gi] = g_par[r][:n]
-        # shared top boxes are seen by several ranks (ids are unique within a rank)
-        flags[gi] |= g_flg[r][:n]
-        children[:, gi] = torch.maximum(children[:, gi], g_ch[r][:n].t())
+    parents[gi] = rec_all[:, 1]
+    # shared top boxes come from several ranks, each knowing the children that hold
+    # its own particles: merge by maximum (absent = 0)
+    children_t = torch.zeros((aligned, C), dtype=torch.int32, device=dev)
+    children_t.scatter_reduce_(0, gi[:, None].expand(-1, C), rec_all[:, 4:], "amax",
+                               include_self=True)
+    children = children_t.t().contiguous()
     starts = numbering["global_level_start_box_nrs"].astype(np.int32)
     coord_dtype = np.dtype(str(tree.box_centers.dtype).replace("torch.", ""))
     return TreeOfBoxes(
