@@ -48,6 +48,7 @@ class TreeParams(ct.Structure):
         ("bbox_min", ct.c_double * BT_MAX_DIMS), ("bbox_max", ct.c_double * BT_MAX_DIMS),
         ("root_extent", ct.c_double),
         ("top_level", ct.c_int32), ("top_cell_prefix", vp),
+        ("source_stride", ct.c_int64), ("target_stride", ct.c_int64),
     ]
 
 

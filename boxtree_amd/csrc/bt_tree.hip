@@ -141,6 +141,7 @@ struct KeygenArgs {
     const T *src_radii;
     const T *tgt_radii;
     int64_t nsources, n;
+    int64_t src_stride, tgt_stride;     // elements between consecutive points (1 = dense)
     T bbox_min[D], bbox_max[D];
     T stick_out_factor;
     int L;          // levels in the key
@@ -161,7 +162,7 @@ __global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_
     const int L = a.L;
 #pragma unroll
     for (int ax = 0; ax < D; ++ax) {
-        x[ax] = is_src ? a.src[ax][j] : a.tgt[ax][j];
+        x[ax] = is_src ? a.src[ax][j * a.src_stride] : a.tgt[ax][j * a.tgt_stride];
         gmin[ax] = a.bbox_min[ax];                              // tbk:358
         gext[ax] = a.bbox_max[ax] - gmin[ax];                   // tbk:359
         // tbk:374-376 evaluated at the deepest level; scaling by 2^k is exact,
@@ -1199,6 +1200,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         ka.tgt_radii = (const T *) p.target_radii;
         ka.nsources = st->nsources;
         ka.n = N;
+        ka.src_stride = p.source_stride > 0 ? p.source_stride : 1;
+        ka.tgt_stride = p.target_stride > 0 ? p.target_stride : 1;
         ka.stick_out_factor = (T) p.stick_out_factor;
         ka.L = st->L;
         ka.norm = p.extent_norm;

@@ -343,7 +343,7 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
             ct.c_void_p(order.data_ptr()), len(a), ct.c_void_p(out.data_ptr())))
         return out
 
-    def route(arrs, cells, local_hist, extra):
+    def route(arrs, cells, local_hist, extra, keep_interleaved=False):
         """all-to-all-v of the coordinate arrays (+ extras) by owner of `cells`."""
         order, send_counts = send_order(cells, local_hist)
         recv_counts = torch.empty_like(send_counts)
@@ -372,11 +372,16 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
                 ct.c_void_p(send.data_ptr())))
             recv = torch.empty(nrecv * d, dtype=arrs[0].dtype, device=dev)
             dist.all_to_all_single(recv, send, [r * d for r in r_split], [c * d for c in s_split])
-            outs = [torch.empty(nrecv, dtype=arrs[0].dtype, device=dev) for _ in range(d)]
-            optrs = (ct.c_void_p * d)(*[o.data_ptr() for o in outs])
-            actx.sync_in()
-            _lib.check(actx.lib.bt_unpack(actx.handle, d, es, ct.c_void_p(recv.data_ptr()),
-                                          nrecv, optrs))
+            if keep_interleaved:
+                # the tree build reads the receive buffer in place
+                # (bt_tree_params.source_stride): no unpacking pass
+                outs = [recv.view(nrecv, d)[:, ax] for ax in range(d)]
+            else:
+                outs = [torch.empty(nrecv, dtype=arrs[0].dtype, device=dev) for _ in range(d)]
+                optrs = (ct.c_void_p * d)(*[o.data_ptr() for o in outs])
+                actx.sync_in()
+                _lib.check(actx.lib.bt_unpack(actx.handle, d, es, ct.c_void_p(recv.data_ptr()),
+                                              nrecv, optrs))
             stats["bytes_sent"] += (n - s_split[rank]) * es * d
             rest = list(extra)
         else:
@@ -389,8 +394,13 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
             stats["bytes_sent"] += (len(a) - s_split[rank]) * a.element_size()
         return outs[:len(arrs)], outs[len(arrs):]
 
+    interleaved = (native and targets is None and source_radii is None and dims > 1
+                   and build_kw.get("refine_weights") is None)
     new_particles, extra = route(
-        particles, src_cells, src_hist, [source_radii] if source_radii is not None else [])
+        particles, src_cells, src_hist, [source_radii] if source_radii is not None else [],
+        keep_interleaved=interleaved)
+    if interleaved and not new_particles[0].is_contiguous():
+        build_kw["_point_stride"] = dims
     if source_radii is not None:
         build_kw["source_radii"] = extra[0]
     new_targets = None

@@ -95,7 +95,16 @@ class TreeBuilder:
             from boxtree_amd.array_context import as_device_array
             return as_device_array(actx, a).contiguous()
 
-        particles = [dev(p) for p in particles]
+        # ``_point_stride``: the coordinate arrays are views into one interleaved
+        # buffer (x0 y0 z0 x1 ...), as the exchange of a sharded build delivers them;
+        # the key kernel reads them in place (bt_tree_params.source_stride)
+        point_stride = int(kwargs.get("_point_stride") or 0)
+        if point_stride > 1:
+            particles = list(particles)
+            assert all(p.stride(0) == point_stride for p in particles)
+            assert source_radii is None and targets is None
+        else:
+            particles = [dev(p) for p in particles]
         coord_dtypes = {np_dtype_of(p) for p in particles}
         if len(coord_dtypes) != 1:
             raise ValueError("coordinate arrays must share one dtype")
@@ -193,25 +202,26 @@ class TreeBuilder:
 
         # {{{ find and process bounding box (tree_build.py:456-510)
 
-        bbox_auto, _ = self.bbox_finder(actx, particles, source_radii)
-        if targets is not None:
-            bbox_t, _ = self.bbox_finder(actx, targets, target_radii)
-            for ax in axis_names:
-                bbox_auto[f"min_{ax}"] = min(bbox_auto[f"min_{ax}"], bbox_t[f"min_{ax}"])
-                bbox_auto[f"max_{ax}"] = max(bbox_auto[f"max_{ax}"], bbox_t[f"max_{ax}"])
-
         root_box = kwargs.get("_root_box")
+        if root_box is None:
+            bbox_auto, _ = self.bbox_finder(actx, particles, source_radii)
+            if targets is not None:
+                bbox_t, _ = self.bbox_finder(actx, targets, target_radii)
+                for ax in axis_names:
+                    bbox_auto[f"min_{ax}"] = min(bbox_auto[f"min_{ax}"], bbox_t[f"min_{ax}"])
+                    bbox_auto[f"max_{ax}"] = max(bbox_auto[f"max_{ax}"], bbox_t[f"max_{ax}"])
+
         if root_box is not None:
             # (bbox_min, bbox_max, root_extent) agreed on by all ranks of a sharded
             # build (boxtree_amd/distributed.py): already the result of the host
-            # arithmetic below on the GLOBAL bounding box, used verbatim
+            # arithmetic below on the GLOBAL bounding box (an all-reduce of the
+            # ranks' boxes, so it covers these particles), used verbatim
+            from boxtree_amd.bounding_box import make_bounding_box_dtype
             bbox_min = np.array(root_box[0], dtype=coord_dtype)
             bbox_max = np.array(root_box[1], dtype=coord_dtype)
             root_extent = coord_dtype.type(root_box[2])
-            bbox = bbox_auto.copy()
+            bbox = np.empty((), make_bounding_box_dtype(dimensions, coord_dtype))
             for i, ax in enumerate(axis_names):
-                assert bbox_min[i] <= bbox_auto[f"min_{ax}"]
-                assert bbox_max[i] > bbox_auto[f"max_{ax}"]
                 bbox[f"min_{ax}"] = bbox_min[i]
                 bbox[f"max_{ax}"] = bbox_max[i]
         elif bbox is None:
@@ -268,8 +278,10 @@ class TreeBuilder:
         tp.coord_kind = _lib.BT_F64 if coord_dtype == np.float64 else _lib.BT_F32
         tp.nsources = nsources
         tp.ntargets = -1 if sources_are_targets else ntargets
+        tp.source_stride = point_stride if point_stride > 1 else 0
         for i in range(dimensions):
-            tp.sources[i] = ptr(particles[i]).value
+            tp.sources[i] = (particles[i].data_ptr() if point_stride > 1
+                             else ptr(particles[i]).value)
             if targets is not None:
                 tp.targets[i] = ptr(targets[i]).value
         tp.source_radii = ptr(source_radii)

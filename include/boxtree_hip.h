@@ -138,6 +138,10 @@ typedef struct {
      * top_level split where the global tree does.  NULL: a self-contained build. */
     int32_t top_level;
     const int64_t *top_cell_prefix;
+    /* Elements between consecutive points in sources[]/targets[] (0 or 1: dense
+     * arrays).  Lets the exchange of a sharded build hand over its interleaved
+     * receive buffer (x0 y0 z0 x1 ...: stride = dims) without unpacking it. */
+    int64_t source_stride, target_stride;
 } bt_tree_params;
 
 typedef struct {
