@@ -247,6 +247,51 @@ def local_to_global_box_ids(tree, plan, global_level_starts, deep_base, bbox_min
     return out
 
 
+# Largest single peer-to-peer message handed to all_to_all_single.  Measured on
+# MI355X / RCCL (one rank sending to itself): a 1.44 GB message arrived with its
+# second half corrupted, 0.96 GB arrived intact -- messages stay well below 1 GiB.
+A2A_MESSAGE_LIMIT_BYTES = 512 << 20
+
+
+def all_to_all_chunked(dist, recv, send, r_split, s_split, limit_bytes=None):
+    """``dist.all_to_all_single(recv, send, r_split, s_split)`` in as many rounds as
+    it takes to keep every peer-to-peer message below *limit_bytes*.  Round k moves
+    the k-th slice of every peer's segment; sender and receiver cut a segment of
+    length c at ``floor(k*c/R)``, so both sides agree without communicating."""
+    import torch
+    if limit_bytes is None:
+        limit_bytes = A2A_MESSAGE_LIMIT_BYTES
+    es = send.element_size()
+    biggest = max(max(s_split, default=0), max(r_split, default=0)) * es
+    # every rank must run the same number of rounds
+    t = torch.tensor([biggest], dtype=torch.int64, device=send.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    biggest = int(t.item())
+    rounds = max(1, -(-biggest // limit_bytes))
+    if rounds == 1:
+        dist.all_to_all_single(recv, send, list(r_split), list(s_split))
+        return 1
+    s_off = np.concatenate([[0], np.cumsum(s_split)]).astype(np.int64)
+    r_off = np.concatenate([[0], np.cumsum(r_split)]).astype(np.int64)
+
+    def cut(c, k):
+        return (k * int(c)) // rounds
+
+    for k in range(rounds):
+        s_sub = [cut(c, k + 1) - cut(c, k) for c in s_split]
+        r_sub = [cut(c, k + 1) - cut(c, k) for c in r_split]
+        send_k = torch.cat([send[s_off[p] + cut(s_split[p], k):s_off[p] + cut(s_split[p], k + 1)]
+                            for p in range(len(s_split))])
+        recv_k = torch.empty(int(sum(r_sub)), dtype=recv.dtype, device=recv.device)
+        dist.all_to_all_single(recv_k, send_k, r_sub, s_sub)
+        off = 0
+        for p in range(len(r_split)):
+            recv[r_off[p] + cut(r_split[p], k):r_off[p] + cut(r_split[p], k + 1)] = \
+                recv_k[off:off + r_sub[p]]
+            off += r_sub[p]
+    return rounds
+
+
 def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
                        top_level=None, return_plan=False, max_particles_in_box=None):
     """Steps 1-4.  Returns ``(particles, targets, build_kw, stats)`` for the local
@@ -352,12 +397,8 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         r_split = recv_counts.cpu().tolist()
         nrecv = int(sum(r_split))
         outs = []
-        # one packed message per peer, unless a message would reach 2 GiB (counts
-        # inside the collective are not reliably 64-bit: a 2.4 GB self-message
-        # came back corrupted on one rank) -- then one message per coordinate
         d_ = len(arrs)
-        biggest = max(max(s_split), max(r_split)) * d_ * arrs[0].element_size()
-        if native and biggest < 2**31 - 1:
+        if native:
             # coordinates travel interleaved: one message per peer instead of d
             import ctypes as ct
             from boxtree_amd import _lib
@@ -371,7 +412,7 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
                 actx.handle, d, es, ptrs, ct.c_void_p(order.data_ptr()), n,
                 ct.c_void_p(send.data_ptr())))
             recv = torch.empty(nrecv * d, dtype=arrs[0].dtype, device=dev)
-            dist.all_to_all_single(recv, send, [r * d for r in r_split], [c * d for c in s_split])
+            all_to_all_chunked(dist, recv, send, [r * d for r in r_split], [c * d for c in s_split])
             if keep_interleaved:
                 # the tree build reads the receive buffer in place
                 # (bt_tree_params.source_stride): no unpacking pass
@@ -389,7 +430,7 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         for a in rest:
             send = take(a.contiguous(), order)
             recv = torch.empty(nrecv, dtype=a.dtype, device=dev)
-            dist.all_to_all_single(recv, send, r_split, s_split)
+            all_to_all_chunked(dist, recv, send, r_split, s_split)
             outs.append(recv)
             stats["bytes_sent"] += (len(a) - s_split[rank]) * a.element_size()
         return outs[:len(arrs)], outs[len(arrs):]

@@ -23,7 +23,11 @@ def _worker(rank, world, port, dims, with_targets, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        import boxtree_amd.distributed as bd
         from boxtree_amd.distributed import exchange_particles, morton_cells
+        if with_targets:
+            # force the multi-round all-to-all (messages capped at 20 kB here)
+            bd.A2A_MESSAGE_LIMIT_BYTES = 20000
         rng = np.random.default_rng(15 + rank)
         n = 20000 + 1000 * rank
         pts = [torch.from_numpy(rng.standard_normal(n)) for _ in range(dims)]
@@ -304,3 +308,48 @@ def test_number_and_gather_world2(oracle):
     for lev in range(3, len(r0)):
         assert r0[lev][1] == r1[lev][0]
         assert r0[lev][0] == g["starts"][lev] and r1[lev][1] == g["starts"][lev + 1]
+
+
+def _chunk_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from boxtree_amd.distributed import all_to_all_chunked
+        rng = np.random.default_rng(rank)
+        s_split = [[700, 1301, 0], [5, 2048, 999], [1234, 1, 77]][rank]
+        send = torch.from_numpy(rng.random(sum(s_split)))
+        counts = torch.tensor(s_split)
+        rc = torch.empty_like(counts)
+        dist.all_to_all_single(rc, counts)
+        r_split = rc.tolist()
+        want = torch.empty(sum(r_split), dtype=send.dtype)
+        dist.all_to_all_single(want, send, r_split, s_split)
+        res = {}
+        for limit in (8 * 100, 8 * 333, 8 * 5000):
+            got = torch.full_like(want, -1.0)
+            rounds = all_to_all_chunked(dist, got, send, r_split, s_split, limit_bytes=limit)
+            res[limit] = (rounds, bool(torch.equal(got, want)))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_all_to_all_chunked_world3():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chunk_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=300) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res in results.items():
+        for limit, (rounds, ok) in res.items():
+            assert ok, (rank, limit)
+        assert res[8 * 100][0] >= 13 and res[8 * 5000][0] == 1

@@ -812,3 +812,34 @@ def test_cuda_array_interface_inputs(actx, oracle):
     dev = [actx.from_numpy(x) for x in p]
     tree, _ = TreeBuilder(actx)(actx, [Foreign(t) for t in dev], max_particles_in_box=30)
     assert_same_tree(actx.to_numpy(tree), oracle.build_tree(p, max_particles_in_box=30))
+
+
+@pytest.mark.gpu
+def test_exchange_large_messages_nccl_single_rank():
+    """Regression: a 1.44 GB all_to_all_single message (6*10^7 packed 3D points, one
+    rank sending to itself over RCCL) arrived with its second half corrupted; the
+    exchange now moves such buffers in rounds of at most 512 MiB per message."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+    from boxtree_amd import HIPArrayContext
+    from boxtree_amd.distributed import exchange_particles
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    try:
+        actx = HIPArrayContext(0)
+        n = 6 * 10**7
+        g = torch.Generator(device="cuda")
+        g.manual_seed(3)
+        pts = [torch.rand(n, generator=g, dtype=torch.float64, device="cuda") for _ in range(3)]
+        p2, _, kw, st = exchange_particles(actx, dist, pts, None, {}, max_particles_in_box=64)
+        torch.cuda.synchronize()
+        assert kw.get("_point_stride") == 3
+        for a, b in zip(pts, p2):
+            assert bool(torch.equal(a, b))          # one rank: nothing moves
+    finally:
+        dist.destroy_process_group()
