@@ -541,10 +541,24 @@ def gather_global_box_tree(actx, dist, tree, numbering):
     rec[:nb, 4:] = torch.where(ch != 0, ids[ch], torch.zeros_like(ch)).to(torch.int32).t()
     ctr = torch.zeros((nmax, dims), dtype=tree.box_centers.dtype, device=dev)
     ctr[:nb] = tree.box_centers[:, :nb].t()
-    g_rec = [torch.empty_like(rec) for _ in range(world)]
-    g_ctr = [torch.empty_like(ctr) for _ in range(world)]
-    dist.all_gather(g_rec, rec)
-    dist.all_gather(g_ctr, ctr)
+    def all_gather_rows(t):
+        """all_gather of a [nmax, w] tensor, rows in slabs below the message limit."""
+        out = [torch.empty_like(t) for _ in range(world)]
+        row_bytes = max(1, t.shape[1] * t.element_size())
+        step = max(1, A2A_MESSAGE_LIMIT_BYTES // row_bytes)
+        if t.shape[0] <= step:
+            dist.all_gather(out, t)
+            return out
+        for r0 in range(0, t.shape[0], step):
+            part = t[r0:r0 + step].contiguous()
+            got = [torch.empty_like(part) for _ in range(world)]
+            dist.all_gather(got, part)
+            for r in range(world):
+                out[r][r0:r0 + step] = got[r]
+        return out
+
+    g_rec = all_gather_rows(rec)
+    g_ctr = all_gather_rows(ctr)
     rec_all = torch.cat([g_rec[r][:counts[r]] for r in range(world)])
     ctr_all = torch.cat([g_ctr[r][:counts[r]] for r in range(world)])
     gi = rec_all[:, 0].long()
