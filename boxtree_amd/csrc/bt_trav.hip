@@ -1069,7 +1069,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         BlockJobs jobs{jobbuf.get(), jobbuf.get() + 1, jobbuf.get() + 1 + ntb,
                        jobbuf.get() + 1 + 2 * ntb};
         BT_HIP_CHECK(hipMemsetAsync(jobbuf.get(), 0, 4, ctx->stream));
-        l1_finalize_kernel<T, D><<<nblk(ntb), 256, 0, ctx->stream>>>(
+        l1_finalize32_kernel<T, D><<<nblk(ntb * 32), 256, 0, ctx->stream>>>(
             a, ft, (int32_t) ntb, c1.starts.get(), c1.lists.get(), jobs);
         int32_t njobs = 0;
         BT_CHECK(read_i32(ctx, jobs.count, &njobs));

@@ -758,6 +758,59 @@ __global__ __launch_bounds__(256) void l1_finalize_kernel(TravArgs<T, D> a, Fast
     for (int32_t i = 0; i < k; ++i) out[i] = ft.box_of_rank[out[i]];
 }
 
+// Same as l1_finalize_kernel with 32 lanes per target box: lists of up to 32 ranks
+// (nearly all of them) are ordered by counting in registers; longer ones by lane 0.
+template <class T, int D>
+__global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, FastTree ft,
+        int32_t ntb, const int32_t *l1_starts, int32_t *l1_lists, BlockJobs jobs)
+{
+    const int32_t gid = blockIdx.x * 256 + threadIdx.x;
+    const int32_t tbn = gid >> 5;
+    const int lane = gid & 31;
+    if (tbn >= ntb) return;                          // whole 32-groups drop out together
+    const int32_t b = a.target_boxes[tbn];
+    int32_t *out = l1_lists + l1_starts[tbn];
+    const int32_t n_all = l1_starts[tbn + 1] - l1_starts[tbn];
+    int32_t blk_len = 0, blk_src = 0;
+    const int32_t my_rank = ft.dfs_rank[b];
+    if (box_flags(a, b) & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
+        blk_src = ft.src_prefix[my_rank + 1];
+        blk_len = ft.src_prefix[my_rank + ft.subtree_size[b]] - blk_src;
+    }
+    const int32_t n = n_all - blk_len;
+    if (n <= 32) {
+        const int32_t v = lane < n ? out[lane] : INT32_MAX;
+        int r = 0, k = 0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int32_t o = __shfl(v, j, 32);
+            r += (o < v) ? 1 : 0;                    // ranks are distinct
+            k += (o <= my_rank) ? 1 : 0;             // entries before the own-subtree block
+        }
+        if (lane < n) out[r < k ? r : r + blk_len] = ft.box_of_rank[v];
+        if (blk_len > 0 && lane == 0) {
+            const int32_t j = atomicAdd(jobs.count, 1);
+            jobs.dst[j] = l1_starts[tbn] + k;
+            jobs.src[j] = blk_src;
+            jobs.len[j] = blk_len;
+        }
+        return;
+    }
+    if (lane != 0) return;
+    sort_i32_inplace(out, n);
+    int32_t k = n;
+    if (blk_len > 0) {
+        k = 0;
+        while (k < n && out[k] <= my_rank) ++k;
+        for (int32_t i = n - 1; i >= k; --i) out[i + blk_len] = ft.box_of_rank[out[i]];
+        const int32_t j = atomicAdd(jobs.count, 1);
+        jobs.dst[j] = l1_starts[tbn] + k;
+        jobs.src[j] = blk_src;
+        jobs.len[j] = blk_len;
+    }
+    for (int32_t i = 0; i < k; ++i) out[i] = ft.box_of_rank[out[i]];
+}
+
 // l3 bookkeeping per (level, target box) from the per-(level, item) starts
 __global__ __launch_bounds__(256) void l3_box_starts_kernel(int64_t nflat_box, int32_t ntb,
         int32_t nitems, int nlevels, const int32_t *first_item, const int32_t *item_starts,
