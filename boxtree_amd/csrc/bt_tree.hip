@@ -1231,8 +1231,25 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         return !(e && atoi(e));
     }();
     if (partial_sort_ok && !EXT && !p.refine_weights && keybits > 40
-            && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED)
-        sorted_high_bits = 40;
+            && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED) {
+        // depth estimate: points on a (D-1)-dimensional set (surfaces are the deep
+        // case in practice) fill 2^(D-1) children per split, plus two levels of
+        // slack; a sharded build is as deep as the GLOBAL point set makes it
+        double npts = (double) N;
+        if (p.top_cell_prefix) {
+            int64_t total = 0;
+            BT_HIP_CHECK(hipMemcpyAsync(&total, p.top_cell_prefix + ((int64_t) 1 << (D * p.top_level)),
+                                        8, hipMemcpyDeviceToHost, ctx->stream));
+            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            npts = (double) total;
+        }
+        const double per_leaf = std::max(1.0, npts / std::max(1, p.max_leaf_refine_weight));
+        const int fan = D > 1 ? D - 1 : 1;
+        const int est_levels = (int) std::ceil(std::log2(per_leaf) / fan) + 2;
+        int bits = ((D * est_levels + 7) / 8) * 8;
+        bits = std::max(40, bits);
+        if (bits < keybits) sorted_high_bits = bits;
+    }
     uint64_t *keys_cur = st->keys_a.get(), *keys_oth = st->keys_b.get();
     if (N > 0) {
         bool in_b = false;
