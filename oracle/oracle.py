@@ -947,4 +947,100 @@ def rotation_classes(tree, trav):
 
 # }}}
 
+# {{{ cost model (boxtree/cost.py)
+
+def _xlat_costs(dims, nlevels, level_to_order, params, taylor=False):
+    """fmm_cost_factors_for_kernels_from_model (cost.py:387-435) with the PDE-aware
+    (:152-166) or Taylor (:169-180) translation cost model evaluated numerically."""
+    ncoeffs = [(level_to_order[i] + 1) ** (dims if taylor else dims - 1) for i in range(nlevels)]
+    pas = (dims == 3) and not taylor
+
+    def e2e(ns, nt):                                                     # cost.py:135-150
+        if pas:
+            return ns ** (3 / 2) + ns ** (1 / 2) * nt + nt ** (3 / 2)
+        return ns * nt
+
+    f = np.float64
+    return {
+        "p2m_cost": np.array([params["c_p2m"] * ncoeffs[i] for i in range(nlevels)], f),
+        "m2m_cost": np.array([params["c_m2m"] * e2e(ncoeffs[i + 1], ncoeffs[i])
+                              for i in range(nlevels - 1)], f),
+        "c_p2p": params["c_p2p"],
+        "m2l_cost": np.array([params["c_m2l"] * e2e(ncoeffs[i], ncoeffs[i])
+                              for i in range(nlevels)], f),
+        "m2p_cost": np.array([params["c_m2p"] * ncoeffs[i] for i in range(nlevels)], f),
+        "p2l_cost": np.array([params["c_p2l"] * ncoeffs[i] for i in range(nlevels)], f),
+        "l2l_cost": np.array([params["c_l2l"] * e2e(ncoeffs[i], ncoeffs[i + 1])
+                              for i in range(nlevels - 1)], f),
+        "l2p_cost": np.array([params["c_l2p"] * ncoeffs[i] for i in range(nlevels)], f),
+    }
+
+
+def cost_model(tree, trav, level_to_order, calibration_params, taylor=False):
+    """_PythonFMMCostModel (cost.py:1264-1440) driven by cost_per_box / cost_per_stage
+    (:445-624).  -> (cost_per_box [nboxes], cost_per_stage dict)."""
+    nlevels = tree.nlevels
+    tc = _xlat_costs(tree.dimensions, nlevels, level_to_order, calibration_params, taylor)
+    nsrc = tree.box_source_counts_nonchild
+    ntgt = tree.box_target_counts_nonchild
+    levels = tree.box_levels
+
+    np2m = np.zeros(len(trav.source_boxes))                              # :1265-1277
+    for i, b in enumerate(trav.source_boxes):
+        np2m[i] = nsrc[b] * tc["p2m_cost"][levels[b]]
+
+    ndirect = np.zeros(len(trav.target_boxes))                           # :1279-1312
+    for i in range(len(trav.target_boxes)):
+        for st, li in ((trav.neighbor_source_boxes_starts, trav.neighbor_source_boxes_lists),
+                       (trav.from_sep_close_smaller_starts, trav.from_sep_close_smaller_lists),
+                       (trav.from_sep_close_bigger_starts, trav.from_sep_close_bigger_lists)):
+            if st is not None:
+                ndirect[i] += nsrc[li[st[i]:st[i + 1]]].sum()
+    direct = ntgt[trav.target_boxes] * ndirect * tc["c_p2p"]            # :1314-1322
+
+    ttp = trav.target_or_target_parent_boxes
+    nm2l = tc["m2l_cost"][levels[ttp]] * np.diff(trav.from_sep_siblings_starts)   # :1324-1335
+
+    nm2p = np.zeros(tree.nboxes)                                         # :1337-1353
+    for ilevel, ssn in enumerate(trav.from_sep_smaller_by_level):
+        for i, b in enumerate(trav.target_boxes_sep_smaller_by_source_level[ilevel]):
+            nm2p[b] += ntgt[b] * (ssn.starts[i + 1] - ssn.starts[i]) * tc["m2p_cost"][ilevel]
+
+    np2l = np.zeros(len(ttp))                                            # :1355-1367
+    st, li = trav.from_sep_bigger_starts, trav.from_sep_bigger_lists
+    for i in range(len(ttp)):
+        src = li[st[i]:st[i + 1]]
+        np2l[i] = (nsrc[src] * tc["p2l_cost"][levels[src]]).sum()
+
+    nl2p = ntgt[trav.target_boxes] * tc["l2p_cost"][levels[trav.target_boxes]]  # :1369-1385
+
+    coarsen = 0.0                                                        # :1387-1412
+    lsp = trav.level_start_source_parent_box_nrs
+    for source_level in range(nlevels - 1, 2, -1):
+        target_level = source_level - 1
+        boxes = trav.source_parent_boxes[lsp[target_level]:lsp[target_level + 1]]
+        coarsen += tc["m2m_cost"][target_level] * int(
+            (tree.box_child_ids[:, boxes] != 0).sum())
+    refine = 0.0                                                         # :1414-1424
+    ltt = trav.level_start_target_or_target_parent_box_nrs
+    for target_lev in range(1, nlevels):
+        refine += (ltt[target_lev + 1] - ltt[target_lev]) * tc["l2l_cost"][target_lev - 1]
+
+    per_box = np.zeros(tree.nboxes)                                      # :487-523
+    per_box[trav.source_boxes] += np2m
+    per_box[trav.target_boxes] += direct
+    per_box[ttp] += nm2l
+    per_box += nm2p
+    per_box[ttp] += np2l
+    per_box[trav.target_boxes] += nl2p
+    per_stage = {
+        "form_multipoles": np2m.sum(), "coarsen_multipoles": coarsen,
+        "eval_direct": direct.sum(), "multipole_to_local": nm2l.sum(),
+        "eval_multipoles": nm2p.sum(), "form_locals": np2l.sum(),
+        "refine_locals": refine, "eval_locals": nl2p.sum(),
+    }
+    return per_box, per_stage
+
+# }}}
+
 # vim: foldmethod=marker
