@@ -832,7 +832,8 @@ int coll_l2_two_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<int3
 // colleagues in fixed-stride rows, list 2 via per-level scratch rows: every test once
 template <class T, int D>
 int coll_l2_single_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<int32_t> &l2_by_box,
-                        Buf<int32_t> &l2_lists, int64_t *l2_total_out)
+                        Buf<int32_t> &l2_lists, int64_t *l2_total_out, Buf<int32_t> &srccoll_rows,
+                        Buf<int32_t> &srccoll_cnt)
 {
     constexpr int C = 1 << D;
     constexpr int P = (D == 1 ? 3 : D == 2 ? 9 : 27) - 1;
@@ -846,6 +847,9 @@ int coll_l2_single_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<i
     BT_CHECK(coll_rows.alloc(ctx->pool, B * P));
     BT_CHECK(coll_cnt.alloc(ctx->pool, B));
     BT_HIP_CHECK(hipMemsetAsync(coll_cnt.get(), 0, (size_t) B * 4, ctx->stream));
+    BT_CHECK(srccoll_rows.alloc(ctx->pool, B * P));
+    BT_CHECK(srccoll_cnt.alloc(ctx->pool, B));
+    BT_HIP_CHECK(hipMemsetAsync(srccoll_cnt.get(), 0, (size_t) B * 4, ctx->stream));
     BT_CHECK(l2_by_box.alloc(ctx->pool, B + 1));
     BT_HIP_CHECK(hipMemsetAsync(l2_by_box.get(), 0, (size_t) (B + 1) * 4, ctx->stream));
     BT_CHECK(grow_buf(ctx, l2_lists, 0, std::max<int64_t>(B * 40, 1024)));
@@ -871,7 +875,8 @@ int coll_l2_single_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<i
         BT_CHECK(l2_cnt.alloc(ctx->pool, nb));
         BT_CHECK(l2_rel.alloc(ctx->pool, nb + 1));
         coll_l2_rows_kernel<T, D><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(
-            a, b0, nb, coll_rows.get(), coll_cnt.get(), l2_rows.get(), l2_cnt.get());
+            a, b0, nb, coll_rows.get(), coll_cnt.get(), l2_rows.get(), l2_cnt.get(),
+            srccoll_rows.get(), srccoll_cnt.get());
         ScanI32 fl{l2_cnt.get()};
         BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, fl, nb, l2_rel.get(), total_d.get(), true)));
         int32_t h_tot = 0;
@@ -960,8 +965,11 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         const char *e = getenv("BT_COLL_TWO_PASS");     // tuning aid: the count+fill kernels
         return e && atoi(e);
     }();
-    if (p.well_sep_is_n_away == 1 && !two_pass_env) {
-        BT_CHECK((coll_l2_single_pass<T, D>(ctx, st, a, l2_by_box, l2_lists, &l2_total)));
+    Buf<int32_t> srccoll_rows, srccoll_cnt;     // single-pass path only
+    const bool single_pass = p.well_sep_is_n_away == 1 && !two_pass_env;
+    if (single_pass) {
+        BT_CHECK((coll_l2_single_pass<T, D>(ctx, st, a, l2_by_box, l2_lists, &l2_total,
+                                            srccoll_rows, srccoll_cnt)));
     } else {
         BT_CHECK((coll_l2_two_pass<T, D>(ctx, st, a, l2_by_box, l2_lists, &l2_total)));
     }
@@ -980,9 +988,16 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         c.lists.swap(l2_lists);
     }
 
-    // source-box colleagues: what the ancestors contribute to list 1
+    // source-box colleagues: what the ancestors contribute to list 1.  The single-pass
+    // colleague kernel already produced them as fixed-stride rows.
     Buf<int32_t> lcoll_starts, lcoll_lists;
-    {
+    constexpr int COLL_STRIDE = (D == 1 ? 3 : D == 2 ? 9 : 27) - 1;
+    int lcoll_stride = 0;
+    if (single_pass) {
+        lcoll_starts.swap(srccoll_cnt);
+        lcoll_lists.swap(srccoll_rows);
+        lcoll_stride = COLL_STRIDE;
+    } else {
         BT_CHECK(lcoll_starts.alloc(ctx->pool, B + 1));
         filter_source_colleagues_kernel<T, D, false><<<nblk(B), 256, 0, ctx->stream>>>(
             a, (int32_t) B, lcoll_starts.get(), nullptr);
@@ -1026,7 +1041,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         list13_kernel<T, D, false><<<nblk(nitems), 256, walk_lds + lvl_lds, ctx->stream>>>(
             a, ft, lcoll_starts.get(), lcoll_lists.get(), item_tbn.get(), item_slot.get(),
             (int32_t) nitems, nlevels, walk_cap, l1_item.get(), nullptr, l3_item.get(), nullptr,
-            st->with_extent ? close_item.get() : nullptr, nullptr);
+            st->with_extent ? close_item.get() : nullptr, nullptr, lcoll_stride);
 
         CsrList &c1 = st->l1;
         c1.n = ntb;
@@ -1045,7 +1060,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             a, ft, lcoll_starts.get(), lcoll_lists.get(), item_tbn.get(), item_slot.get(),
             (int32_t) nitems, nlevels, walk_cap, l1_item.get(), c1.lists.get(), l3_item.get(),
             st->l3_lists.get(), st->with_extent ? close_item.get() : nullptr,
-            st->with_extent ? cs.lists.get() : nullptr);
+            st->with_extent ? cs.lists.get() : nullptr, lcoll_stride);
 
         // per-box starts from the per-item starts (items of a box are consecutive)
         BT_CHECK(c1.starts.alloc(ctx->pool, ntb + 1));

@@ -259,7 +259,8 @@ __global__ __launch_bounds__(256) void coll_l2_kernel(TravArgs<T, D> a, int32_t 
 // test and every node load happens once instead of twice.
 template <class T, int D>
 __global__ __launch_bounds__(256) void coll_l2_rows_kernel(TravArgs<T, D> a, int32_t b0, int32_t nb,
-        int32_t *coll_rows, int32_t *coll_cnt, int32_t *l2_rows, int32_t *l2_cnt)
+        int32_t *coll_rows, int32_t *coll_cnt, int32_t *l2_rows, int32_t *l2_cnt,
+        int32_t *srccoll_rows, int32_t *srccoll_cnt)
 {
     constexpr int C = 1 << D;
     constexpr int P = (D == 1 ? 3 : D == 2 ? 9 : 27) - 1;
@@ -285,7 +286,8 @@ __global__ __launch_bounds__(256) void coll_l2_rows_kernel(TravArgs<T, D> a, int
 
     int32_t *crow = coll_rows + (int64_t) b * P;
     int32_t *lrow = l2_rows + (int64_t) g * S;
-    int32_t ccur = 0, lcur = 0;
+    int32_t *srow = srccoll_rows + (int64_t) b * P;   // colleagues that are source boxes
+    int32_t ccur = 0, lcur = 0, scur = 0;
     constexpr int UNR = 4;
     for (int i0 = 0; i0 <= n; i0 += UNR) {
         int32_t cs[UNR], chs[UNR];
@@ -316,15 +318,19 @@ __global__ __launch_bounds__(256) void coll_l2_rows_kernel(TravArgs<T, D> a, int
                 is_coll = a_or_o;                                   // traversal.py:429-442
                 is_l2 = !a_or_o && c != p && ttp;                   // traversal.py:588-597
             }
+            const bool is_src = is_coll && ((lfs[u] >> 8) & BT_BOX_IS_SOURCE_BOX);
             const uint64_t bc = (__ballot(is_coll) >> gshift) & ((1ull << C) - 1);
             const uint64_t bl = (__ballot(is_l2) >> gshift) & ((1ull << C) - 1);
+            const uint64_t bs = (__ballot(is_src) >> gshift) & ((1ull << C) - 1);
             if (is_coll) crow[ccur + __popcll(bc & lanes_below)] = ch;
             if (is_l2) lrow[lcur + __popcll(bl & lanes_below)] = ch;
+            if (is_src) srow[scur + __popcll(bs & lanes_below)] = ch;
             ccur += __popcll(bc);
             lcur += __popcll(bl);
+            scur += __popcll(bs);
         }
     }
-    if (m == 0) { coll_cnt[b] = ccur; l2_cnt[g] = lcur; }
+    if (m == 0) { coll_cnt[b] = ccur; l2_cnt[g] = lcur; srccoll_cnt[b] = scur; }
 }
 
 // rows[r][0..count) -> lists[base + starts[r] ...); 16 lanes per row
@@ -654,8 +660,10 @@ __global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree 
         const int32_t *lcoll_starts, const int32_t *lcoll_lists,
         const int32_t *item_tbn, const int32_t *item_slot, int32_t nitems, int nlevels,
         int walk_cap, int32_t *l1_cs, int32_t *l1_lists,
-        int32_t *l3_cs, int32_t *l3_lists, int32_t *close_cs, int32_t *close_lists)
+        int32_t *l3_cs, int32_t *l3_lists, int32_t *close_cs, int32_t *close_lists,
+        int lcoll_stride)
 {
+    // lcoll_stride > 0: lcoll_lists are fixed-stride rows, lcoll_starts their counts
     const int32_t item = blockIdx.x * 256 + threadIdx.x;
     if (item >= nitems) return;
     const int32_t tbn = item_tbn[item];
@@ -679,8 +687,9 @@ __global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree 
             int32_t anc = a.parent[b];
             for (int k = level - 1; k >= 1; --k, anc = a.parent[anc]) {
                 if (box_flags(a, anc) & BT_BOX_IS_SOURCE_BOX) e1(anc);
-                const int32_t s0 = lcoll_starts[anc], s1 = lcoll_starts[anc + 1];
-                for (int32_t i = s0; i < s1; ++i) {
+                const int64_t s0 = lcoll_stride ? (int64_t) anc * lcoll_stride : lcoll_starts[anc];
+                const int64_t s1 = lcoll_stride ? s0 + lcoll_starts[anc] : lcoll_starts[anc + 1];
+                for (int64_t i = s0; i < s1; ++i) {
                     const int32_t u = lcoll_lists[i];
                     T uc[D];
                     load_center(a, u, uc);
