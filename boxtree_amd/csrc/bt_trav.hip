@@ -44,6 +44,10 @@ struct TravArgs {
     const int32_t *target_boxes; int32_t ntarget_boxes;
     const int32_t *ttp_boxes; int32_t nttp;
     const int32_t *coll_starts, *coll_lists;
+    // colleagues that are source boxes, as fixed-stride rows (single-pass colleague
+    // kernel only; srccoll_stride == 0 otherwise)
+    const int32_t *srccoll_rows, *srccoll_cnt;
+    int srccoll_stride;
 };
 
 template <class T, int D>
@@ -329,10 +333,13 @@ __device__ __forceinline__ void gen_list4(const TravArgs<T, D> &a, int32_t it, E
     if (a.nway == 1) { wl = tl - 1; cur = tparent; }
     else { wl = tl; cur = tgt; }
     for (; wl != 0; --wl, cur = a.parent[cur]) {
-        const int32_t s0 = a.coll_starts[cur], s1 = a.coll_starts[cur + 1];
-        for (int32_t i = s0; i < s1; ++i) {
-            const int32_t sb = a.coll_lists[i];
-            if (!(box_flags(a, sb) & BT_BOX_IS_SOURCE_BOX)) continue;
+        const bool rows = a.srccoll_stride != 0;
+        const int64_t s0 = rows ? (int64_t) cur * a.srccoll_stride : a.coll_starts[cur];
+        const int64_t s1 = rows ? s0 + a.srccoll_cnt[cur] : a.coll_starts[cur + 1];
+        const int32_t *src = rows ? a.srccoll_rows : a.coll_lists;
+        for (int64_t i = s0; i < s1; ++i) {
+            const int32_t sb = src[i];
+            if (!rows && !(box_flags(a, sb) & BT_BOX_IS_SOURCE_BOX)) continue;
             T sc[D];
             load_center(a, sb, sc);
             if (adj<T, D>(a.root_extent, tc, tl, sc, wl)) continue;
@@ -585,6 +592,7 @@ struct TravState {
     int nlevels = 0;
     bool with_extent = false;
     Buf<int32_t> source_boxes, target_boxes_buf, source_parent_boxes, ttp_boxes;
+    Buf<int32_t> srccoll_rows, srccoll_cnt;
     int64_t nsb = 0, ntb = 0, nspb = 0, nttp = 0;
     const int32_t *target_boxes = nullptr;
     Buf<int32_t> lev_starts;           // [4][nlevels+1]
@@ -965,7 +973,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         const char *e = getenv("BT_COLL_TWO_PASS");     // tuning aid: the count+fill kernels
         return e && atoi(e);
     }();
-    Buf<int32_t> srccoll_rows, srccoll_cnt;     // single-pass path only
+    Buf<int32_t> &srccoll_rows = st->srccoll_rows, &srccoll_cnt = st->srccoll_cnt;
     const bool single_pass = p.well_sep_is_n_away == 1 && !two_pass_env;
     if (single_pass) {
         BT_CHECK((coll_l2_single_pass<T, D>(ctx, st, a, l2_by_box, l2_lists, &l2_total,
@@ -990,22 +998,28 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
 
     // source-box colleagues: what the ancestors contribute to list 1.  The single-pass
     // colleague kernel already produced them as fixed-stride rows.
-    Buf<int32_t> lcoll_starts, lcoll_lists;
+    Buf<int32_t> lcoll_starts_buf, lcoll_lists_buf;
+    const int32_t *lcoll_starts = nullptr, *lcoll_lists = nullptr;
     constexpr int COLL_STRIDE = (D == 1 ? 3 : D == 2 ? 9 : 27) - 1;
     int lcoll_stride = 0;
     if (single_pass) {
-        lcoll_starts.swap(srccoll_cnt);
-        lcoll_lists.swap(srccoll_rows);
+        lcoll_starts = srccoll_cnt.get();
+        lcoll_lists = srccoll_rows.get();
         lcoll_stride = COLL_STRIDE;
+        a.srccoll_rows = srccoll_rows.get();       // list 4 walks the same rows
+        a.srccoll_cnt = srccoll_cnt.get();
+        a.srccoll_stride = COLL_STRIDE;
     } else {
-        BT_CHECK(lcoll_starts.alloc(ctx->pool, B + 1));
+        BT_CHECK(lcoll_starts_buf.alloc(ctx->pool, B + 1));
         filter_source_colleagues_kernel<T, D, false><<<nblk(B), 256, 0, ctx->stream>>>(
-            a, (int32_t) B, lcoll_starts.get(), nullptr);
+            a, (int32_t) B, lcoll_starts_buf.get(), nullptr);
         int64_t tot = 0;
-        BT_CHECK(counts_to_starts(ctx, lcoll_starts, B, &tot));
-        BT_CHECK(lcoll_lists.alloc(ctx->pool, tot));
+        BT_CHECK(counts_to_starts(ctx, lcoll_starts_buf, B, &tot));
+        BT_CHECK(lcoll_lists_buf.alloc(ctx->pool, tot));
         filter_source_colleagues_kernel<T, D, true><<<nblk(B), 256, 0, ctx->stream>>>(
-            a, (int32_t) B, lcoll_starts.get(), lcoll_lists.get());
+            a, (int32_t) B, lcoll_starts_buf.get(), lcoll_lists_buf.get());
+        lcoll_starts = lcoll_starts_buf.get();
+        lcoll_lists = lcoll_lists_buf.get();
     }
 
     // lists 1 and 3 (+ close smaller) in one walk per work item
@@ -1039,7 +1053,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         BT_CHECK(l3_item.alloc(ctx->pool, nflat + 1));
         if (st->with_extent) BT_CHECK(close_item.alloc(ctx->pool, nitems + 1));
         list13_kernel<T, D, false><<<nblk(nitems), 256, walk_lds + lvl_lds, ctx->stream>>>(
-            a, ft, lcoll_starts.get(), lcoll_lists.get(), item_tbn.get(), item_slot.get(),
+            a, ft, lcoll_starts, lcoll_lists, item_tbn.get(), item_slot.get(),
             (int32_t) nitems, nlevels, walk_cap, l1_item.get(), nullptr, l3_item.get(), nullptr,
             st->with_extent ? close_item.get() : nullptr, nullptr, lcoll_stride);
 
@@ -1057,7 +1071,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             BT_CHECK(cs.lists.alloc(ctx->pool, cs.total));
         }
         list13_kernel<T, D, true><<<nblk(nitems), 256, walk_lds + lvl_lds, ctx->stream>>>(
-            a, ft, lcoll_starts.get(), lcoll_lists.get(), item_tbn.get(), item_slot.get(),
+            a, ft, lcoll_starts, lcoll_lists, item_tbn.get(), item_slot.get(),
             (int32_t) nitems, nlevels, walk_cap, l1_item.get(), c1.lists.get(), l3_item.get(),
             st->l3_lists.get(), st->with_extent ? close_item.get() : nullptr,
             st->with_extent ? cs.lists.get() : nullptr, lcoll_stride);
