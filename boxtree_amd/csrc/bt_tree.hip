@@ -473,10 +473,13 @@ __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, cons
     const int b = (blockIdx.x * 256 + threadIdx.x) >> 6;
     const int lane = threadIdx.x & 63;
     if (b >= nboxes) return;
-    // a split box's own particles share one key: the stable sort left them in id order
-    if (box_haschild[b]) return;
+    // (three independent loads issued together: the kernel is bound by the latency
+    // of its dependent global loads, not by the sorting network)
+    const uint8_t has_children = box_haschild[b];
     const int n = box_count[b];
-    if (n <= 1) return;
+    const int s = box_start[b];
+    // a split box's own particles share one key: the stable sort left them in id order
+    if (has_children || n <= 1) return;
     if (n > 64) {
         if (lane == 0) {
             if (n <= SEG_BLOCK_MAX) large_list[atomicAdd(&flags->n_large, 1)] = b;
@@ -484,7 +487,6 @@ __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, cons
         }
         return;
     }
-    const int s = box_start[b];
     uint32_t v = (lane < n) ? ids[s + lane] : 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 2; k <= 64; k <<= 1) {
