@@ -587,8 +587,18 @@ struct CsrList {
     int64_t n = 0, total = 0;
 };
 
+// list 2 of one level still in its scratch rows (single-pass colleague kernel): the
+// compaction into the CSR runs at export time, straight into the caller's buffer
+struct L2Pending {
+    Buf<int32_t> rows, rel;
+    int32_t nb = 0;
+    int64_t base = 0;
+    int stride = 0;
+};
+
 struct TravState {
     bt_trav_params p{};
+    std::vector<L2Pending> l2_pending;
     int nlevels = 0;
     bool with_extent = false;
     Buf<int32_t> source_boxes, target_boxes_buf, source_parent_boxes, ttp_boxes;
@@ -860,7 +870,7 @@ int coll_l2_single_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<i
     BT_HIP_CHECK(hipMemsetAsync(srccoll_cnt.get(), 0, (size_t) B * 4, ctx->stream));
     BT_CHECK(l2_by_box.alloc(ctx->pool, B + 1));
     BT_HIP_CHECK(hipMemsetAsync(l2_by_box.get(), 0, (size_t) (B + 1) * 4, ctx->stream));
-    BT_CHECK(grow_buf(ctx, l2_lists, 0, std::max<int64_t>(B * 40, 1024)));
+    st->l2_pending.clear();
     int64_t l2_total = 0;
     Buf<int32_t> total_d;
     BT_CHECK(total_d.alloc(ctx->pool, 1));
@@ -894,11 +904,17 @@ int coll_l2_single_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<i
             set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference)");
             return BT_ERR_UNSUPPORTED;
         }
-        BT_CHECK(grow_buf(ctx, l2_lists, l2_total, l2_total + h_tot));
         add_base_kernel<<<nblk(nb + 1), 256, 0, ctx->stream>>>(nb + 1, l2_rel.get(), (int32_t) l2_total,
                                                               l2_by_box.get() + b0);
-        compact_strided_rows_kernel<<<nblk((int64_t) nb * 16), 256, 0, ctx->stream>>>(
-            nb, S, l2_rows.get(), l2_rel.get(), (int32_t) l2_total, l2_lists.get());
+        {
+            L2Pending pend;
+            pend.rows.swap(l2_rows);
+            pend.rel.swap(l2_rel);
+            pend.nb = nb;
+            pend.base = l2_total;
+            pend.stride = S;
+            st->l2_pending.push_back(std::move(pend));
+        }
         l2_total += h_tot;
         fill_outside(b0 + nb + 1, lev_end, l2_total);
     }
@@ -1420,7 +1436,16 @@ int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
     };
     BT_CHECK(put(st->coll, o->same_level_non_well_sep_boxes_starts, o->same_level_non_well_sep_boxes_lists));
     BT_CHECK(put(st->l1, o->neighbor_source_boxes_starts, o->neighbor_source_boxes_lists));
-    BT_CHECK(put(st->l2, o->from_sep_siblings_starts, o->from_sep_siblings_lists));
+    if (st->l2_pending.empty()) {
+        BT_CHECK(put(st->l2, o->from_sep_siblings_starts, o->from_sep_siblings_lists));
+    } else {
+        BT_CHECK(copy_i32(ctx, o->from_sep_siblings_starts, st->l2.starts.get(), st->l2.n + 1));
+        for (const L2Pending &pend : st->l2_pending)
+            compact_strided_rows_kernel<<<nblk((int64_t) pend.nb * 16), 256, 0, ctx->stream>>>(
+                pend.nb, pend.stride, pend.rows.get(), pend.rel.get(), (int32_t) pend.base,
+                o->from_sep_siblings_lists);
+        BT_HIP_CHECK(hipGetLastError());
+    }
     BT_CHECK(put(st->l4, o->from_sep_bigger_starts, o->from_sep_bigger_lists));
     if (st->with_extent) {
         BT_CHECK(put(st->close_smaller, o->from_sep_close_smaller_starts, o->from_sep_close_smaller_lists));
