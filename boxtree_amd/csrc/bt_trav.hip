@@ -498,20 +498,30 @@ struct NonEmptyPred {
     __device__ int32_t operator()(int64_t i) const { return starts[i + 1] > starts[i] ? 1 : 0; }
 };
 
+// values at the level boundaries of two flat [nlevels*ntb + 1] arrays -> small arrays
+__global__ void l3_level_marks_kernel(int nlevels, int64_t ntb, const int32_t *starts,
+                                      const int32_t *scan, int32_t *out /* [2][nlevels+1] */)
+{
+    const int l = threadIdx.x;
+    if (l > nlevels) return;
+    out[l] = starts[(int64_t) l * ntb];
+    out[nlevels + 1 + l] = scan[(int64_t) l * ntb];
+}
+
 __global__ __launch_bounds__(256) void l3_compress_kernel(int32_t ntb, const int32_t *lev_starts,
-        int32_t lev_base, const int32_t *cidx /* [ntb+1] exclusive scan of nonempty */,
-        const int32_t *target_boxes, int32_t *o_starts, int32_t *o_nonempty,
+        int32_t lev_base, const int32_t *cidx /* [ntb+1] slice of the flat scan of nonempty */,
+        int32_t cidx_base, const int32_t *target_boxes, int32_t *o_starts, int32_t *o_nonempty,
         int32_t *o_cidx, int32_t *o_tboxes, int32_t lev_total)
 {
     const int32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i > ntb) return;
-    if (o_cidx) o_cidx[i] = cidx[i];
+    if (o_cidx) o_cidx[i] = cidx[i] - cidx_base;
     if (i == ntb) {
-        o_starts[cidx[ntb]] = lev_total;
+        o_starts[cidx[ntb] - cidx_base] = lev_total;
         return;
     }
     if (lev_starts[i + 1] > lev_starts[i]) {
-        const int32_t k = cidx[i];
+        const int32_t k = cidx[i] - cidx_base;
         o_starts[k] = lev_starts[i] - lev_base;
         o_nonempty[k] = i;
         o_tboxes[k] = target_boxes[i];
@@ -611,8 +621,8 @@ struct TravState {
     // list 3: flat level-major
     Buf<int32_t> l3_starts;            // [nlevels*ntb + 1]
     Buf<int32_t> l3_lists;
-    Buf<int32_t> l3_cidx;              // [nlevels][ntb+1]
-    std::vector<int64_t> l3_level_base, l3_level_count, l3_nonempty;
+    Buf<int32_t> l3_cidx;              // flat scan [nlevels*ntb + 1]
+    std::vector<int64_t> l3_level_base, l3_level_count, l3_nonempty, l3_cidx_base;
     Buf<int32_t> subtree_size, dfs_rank, box_of_rank, src_rank_prefix, src_by_rank;
     Buf<unsigned char> nodes;          // packed Node<T, D>[nboxes]
     Buf<int32_t> child_t;              // [nboxes][C]
@@ -706,30 +716,31 @@ int l3_postprocess(bt_context *ctx, TravState *st)
 {
     const int nlevels = st->nlevels;
     const int64_t ntb = st->ntb;
-    {
-        // per-level bases + nonempty counts
-        std::vector<int32_t> h_base((size_t) nlevels + 1);
-        for (int l = 0; l <= nlevels; ++l)
-            BT_HIP_CHECK(hipMemcpyAsync(&h_base[l], st->l3_starts.get() + (int64_t) l * ntb, 4,
-                                        hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        st->l3_level_base.assign((size_t) nlevels, 0);
-        st->l3_level_count.assign((size_t) nlevels, 0);
-        st->l3_nonempty.assign((size_t) nlevels, 0);
-        BT_CHECK(st->l3_cidx.alloc(ctx->pool, (int64_t) nlevels * (ntb + 1)));
-        for (int l = 0; l < nlevels; ++l) {
-            st->l3_level_base[l] = h_base[l];
-            st->l3_level_count[l] = h_base[l + 1] - h_base[l];
-            NonEmptyPred ne{st->l3_starts.get() + (int64_t) l * ntb};
-            int32_t *cidx = st->l3_cidx.get() + (int64_t) l * (ntb + 1);
-            BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, ne, ntb, cidx, (int32_t *) nullptr, true)));
-        }
-        std::vector<int32_t> h_ne((size_t) nlevels);
-        for (int l = 0; l < nlevels; ++l)
-            BT_HIP_CHECK(hipMemcpyAsync(&h_ne[l], st->l3_cidx.get() + (int64_t) l * (ntb + 1) + ntb, 4,
-                                        hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        for (int l = 0; l < nlevels; ++l) st->l3_nonempty[l] = h_ne[l];
+    const int64_t nflat = (int64_t) nlevels * ntb;
+    // One exclusive scan of "list (level, target box) is non-empty" over the flat
+    // [level][target box] layout; level l's compressed indices are the slice
+    // [l*ntb, (l+1)*ntb] minus the value at its start.
+    BT_CHECK(st->l3_cidx.alloc(ctx->pool, nflat + 1));
+    NonEmptyPred ne{st->l3_starts.get()};
+    BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, ne, nflat, st->l3_cidx.get(),
+                                                      (int32_t *) nullptr, true)));
+    Buf<int32_t> marks;
+    BT_CHECK(marks.alloc(ctx->pool, 2 * (nlevels + 1)));
+    l3_level_marks_kernel<<<1, 128, 0, ctx->stream>>>(nlevels, ntb, st->l3_starts.get(),
+                                                     st->l3_cidx.get(), marks.get());
+    std::vector<int32_t> h((size_t) 2 * (nlevels + 1));
+    BT_HIP_CHECK(hipMemcpyAsync(h.data(), marks.get(), h.size() * 4, hipMemcpyDeviceToHost,
+                                ctx->stream));
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    st->l3_level_base.assign((size_t) nlevels, 0);
+    st->l3_level_count.assign((size_t) nlevels, 0);
+    st->l3_nonempty.assign((size_t) nlevels, 0);
+    st->l3_cidx_base.assign((size_t) nlevels, 0);
+    for (int l = 0; l < nlevels; ++l) {
+        st->l3_level_base[l] = h[l];
+        st->l3_level_count[l] = h[l + 1] - h[l];
+        st->l3_cidx_base[l] = h[nlevels + 1 + l];
+        st->l3_nonempty[l] = h[nlevels + 1 + l + 1] - h[nlevels + 1 + l];
     }
     return BT_OK;
 }
@@ -1461,7 +1472,7 @@ int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
                           st->l3_lists.get() + st->l3_level_base[l], st->l3_level_count[l]));
         l3_compress_kernel<<<nblk(ntb + 1), 256, 0, ctx->stream>>>(
             (int32_t) ntb, st->l3_starts.get() + (int64_t) l * ntb, (int32_t) st->l3_level_base[l],
-            st->l3_cidx.get() + (int64_t) l * (ntb + 1), st->target_boxes,
+            st->l3_cidx.get() + (int64_t) l * ntb, (int32_t) st->l3_cidx_base[l], st->target_boxes,
             o->from_sep_smaller_starts[l], o->from_sep_smaller_nonempty_indices[l],
             o->from_sep_smaller_compressed_indices[l], o->target_boxes_sep_smaller[l],
             (int32_t) st->l3_level_count[l]);
