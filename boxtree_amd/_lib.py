@@ -162,6 +162,7 @@ EXPORTED_SYMBOLS = [
     "bt_fmm_box_particle_sums", "bt_fmm_csr_sum", "bt_fmm_box_to_particles", "bt_fmm_tree_sweep",
     "bt_translation_classes",
     "bt_filter_targets_user_order", "bt_filter_targets_tree_order", "bt_link_point_sources",
+    "bt_box_morton_paths", "bt_let_build",
     "bt_morton_cells", "bt_bucket_permutation", "bt_gather", "bt_gather_pack", "bt_unpack",
 ]
 
@@ -229,6 +230,11 @@ def load():
     lib.bt_translation_classes.argtypes = [
         vp, ct.c_int, ct.c_int, ct.c_int64, vp, vp, vp, ct.c_int64, vp, ct.c_int64, ct.c_double,
         vp, ct.c_int, ct.c_int, ct.c_int, vp, vp, ct.POINTER(ct.c_int32)]
+    lib.bt_box_morton_paths.argtypes = [vp, ct.c_int, ct.c_int, ct.c_int64, ct.c_int64, vp, vp,
+                                        ct.POINTER(ct.c_double), ct.c_double, vp]
+    lib.bt_let_build.argtypes = [vp, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_int32), vp,
+                                 ct.c_int64, ct.POINTER(ct.c_double), ct.POINTER(ct.c_double),
+                                 ct.c_double, vp, vp, vp]
     lib.bt_morton_cells.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), ct.c_int64,
                                     ct.POINTER(ct.c_double), ct.POINTER(ct.c_double),
                                     ct.c_int, vp, vp]

@@ -287,3 +287,183 @@ int bt_unpack(bt_context *ctx, int dims, int elem_size, const void *in, int64_t 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Local essential tree (LET) of a sharded traversal: the shared top levels, the
+// rank's own subtrees and the subtrees of the neighbouring cells of other ranks,
+// assembled from Morton paths (boxtree_amd/distributed.py step 6).
+// ---------------------------------------------------------------------------
+
+namespace {
+
+// Morton path of a box from its centre: centres sit at (i + 1/2) / 2^level of the
+// root box, so floor((c - min) / extent * 2^level) recovers i exactly.
+template <class T, int D>
+__global__ __launch_bounds__(256) void box_paths_kernel(int64_t nboxes, int64_t aligned,
+        const T *centers, const uint8_t *levels, double bmin0, double bmin1, double bmin2,
+        double root_extent, uint64_t *paths)
+{
+    const int64_t b = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (b >= nboxes) return;
+    const int level = levels[b];
+    const double bmin[3] = {bmin0, bmin1, bmin2};
+    uint64_t path = 0;
+    const double scale = (double) (1ull << level);
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        const double t = ((double) centers[(int64_t) ax * aligned + b] - bmin[ax]) / root_extent * scale;
+        int64_t v = (int64_t) floor(t);
+        v = v < 0 ? 0 : (v >= (int64_t) scale ? (int64_t) scale - 1 : v);
+        for (int bit = 0; bit < level; ++bit)
+            path |= (uint64_t) ((v >> bit) & 1) << (D * bit + (D - 1 - ax));
+    }
+    paths[b] = path;
+}
+
+// position of `key` in the ascending array a[lo, hi), or -1
+__device__ __forceinline__ int64_t find_path(const uint64_t *a, int64_t lo, int64_t hi, uint64_t key)
+{
+    int64_t l = lo, h = hi;
+    while (l < h) {
+        const int64_t mid = (l + h) >> 1;
+        if (a[mid] < key) l = mid + 1; else h = mid;
+    }
+    return (l < hi && a[l] == key) ? l : -1;
+}
+
+// one thread per (box, child slot): parents and children by path lookup
+template <int D>
+__global__ __launch_bounds__(256) void let_link_kernel(int32_t b0, int32_t b1, int32_t prev0,
+        int32_t next1, int64_t aligned, const uint64_t *paths, int32_t *parent_ids,
+        int32_t *child_ids, int32_t *missing_parent)
+{
+    constexpr int C = 1 << D;
+    const int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int64_t g = t / C;
+    const int m = (int) (t % C);
+    if (g >= b1 - b0) return;
+    const int32_t b = b0 + (int32_t) g;
+    const uint64_t p = paths[b];
+    const int64_t c = find_path(paths, b1, next1, (p << D) | (uint64_t) m);     // next level
+    child_ids[(int64_t) m * aligned + b] = c < 0 ? 0 : (int32_t) c;
+    if (m == 0) {
+        if (b == 0) { parent_ids[0] = 0; return; }
+        const int64_t par = find_path(paths, prev0, b0, p >> D);                // previous level
+        parent_ids[b] = par < 0 ? 0 : (int32_t) par;
+        if (par < 0) atomicExch(missing_parent, 1);
+    }
+}
+
+// child centre = parent centre +/- root_extent / 2^(1+level): the builder's own
+// chain of roundings (tree_build_kernels.py:698-705), level by level
+template <class T, int D>
+__global__ __launch_bounds__(256) void let_centers_kernel(int32_t b0, int32_t b1, int level,
+        int64_t aligned, const uint64_t *paths, const int32_t *parent_ids, T root_extent,
+        T *centers)
+{
+    const int32_t b = b0 + blockIdx.x * 256 + threadIdx.x;
+    if (b >= b1) return;
+    const int32_t par = parent_ids[b];
+    const int m = (int) (paths[b] & ((1u << D) - 1));
+    const T radius = (root_extent * 1 / (T) (1ull << (1 + level)));
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        const bool has_bit = (m >> (D - 1 - ax)) & 1;
+        const T pc = centers[(int64_t) ax * aligned + par];
+        centers[(int64_t) ax * aligned + b] = has_bit ? pc + radius : pc - radius;
+    }
+}
+
+template <class T, int D>
+int let_build_impl(bt_context *ctx, int nlevels, const int32_t *level_starts, const uint64_t *paths,
+                   int64_t aligned, const double *bbox_min, const double *bbox_max,
+                   double root_extent, int32_t *parent_ids, int32_t *child_ids, T *centers)
+{
+    constexpr int C = 1 << D;
+    const int32_t nboxes = level_starts[nlevels];
+    Buf<int32_t> d_missing;
+    BT_CHECK(d_missing.alloc(ctx->pool, 1));
+    BT_HIP_CHECK(hipMemsetAsync(d_missing.get(), 0, 4, ctx->stream));
+    for (int lev = 0; lev < nlevels; ++lev) {
+        const int32_t b0 = level_starts[lev], b1 = level_starts[lev + 1];
+        if (b1 <= b0) continue;
+        const int32_t prev0 = lev > 0 ? level_starts[lev - 1] : 0;
+        const int32_t next1 = lev + 2 <= nlevels ? level_starts[lev + 2] : b1;
+        let_link_kernel<D><<<(unsigned) div_up((int64_t) (b1 - b0) * C, 256), 256, 0, ctx->stream>>>(
+            b0, b1, prev0, next1, aligned, paths, parent_ids, child_ids, d_missing.get());
+    }
+    // root centre: tree_build.py:585-590
+    T root[D];
+    for (int ax = 0; ax < D; ++ax) {
+        const T mn = (T) bbox_min[ax], mx = (T) bbox_max[ax];
+        root[ax] = mn + (mx - mn) / 2;
+        BT_HIP_CHECK(hipMemcpyAsync(centers + (int64_t) ax * aligned, &root[ax], sizeof(T),
+                                    hipMemcpyHostToDevice, ctx->stream));
+    }
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));        // `root` goes out of scope
+    for (int lev = 1; lev < nlevels; ++lev) {
+        const int32_t b0 = level_starts[lev], b1 = level_starts[lev + 1];
+        if (b1 <= b0) continue;
+        let_centers_kernel<T, D><<<(unsigned) div_up(b1 - b0, 256), 256, 0, ctx->stream>>>(
+            b0, b1, lev, aligned, paths, parent_ids, (T) root_extent, centers);
+    }
+    BT_HIP_CHECK(hipGetLastError());
+    int32_t missing = 0;
+    BT_HIP_CHECK(hipMemcpyAsync(&missing, d_missing.get(), 4, hipMemcpyDeviceToHost, ctx->stream));
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (missing) {
+        set_error("bt_let_build: a box has no parent among the boxes of the level above "
+                  "(%d boxes)", nboxes);
+        return BT_ERR_INVALID;
+    }
+    return BT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bt_box_morton_paths(bt_context *ctx, int dims, int coord_kind, int64_t nboxes,
+                        int64_t aligned_nboxes, const void *box_centers, const uint8_t *box_levels,
+                        const double *bbox_min, double root_extent, uint64_t *paths)
+{
+    if (!ctx || dims < 1 || dims > 3 || nboxes < 0 || !box_centers || !box_levels || !bbox_min
+            || !paths || (coord_kind != BT_F32 && coord_kind != BT_F64)) {
+        set_error("bt_box_morton_paths: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (nboxes == 0) return BT_OK;
+    const unsigned blocks = (unsigned) div_up(nboxes, 256);
+    const double m0 = bbox_min[0], m1 = dims > 1 ? bbox_min[1] : 0, m2 = dims > 2 ? bbox_min[2] : 0;
+#define BP(T, D) box_paths_kernel<T, D><<<blocks, 256, 0, ctx->stream>>>(                    \
+        nboxes, aligned_nboxes, (const T *) box_centers, box_levels, m0, m1, m2, root_extent, paths)
+    if (coord_kind == BT_F64) { if (dims == 1) BP(double, 1); else if (dims == 2) BP(double, 2); else BP(double, 3); }
+    else { if (dims == 1) BP(float, 1); else if (dims == 2) BP(float, 2); else BP(float, 3); }
+#undef BP
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return BT_OK;
+}
+
+int bt_let_build(bt_context *ctx, int dims, int coord_kind, int nlevels,
+                 const int32_t *level_start_box_nrs, const uint64_t *paths, int64_t aligned_nboxes,
+                 const double *bbox_min, const double *bbox_max, double root_extent,
+                 int32_t *box_parent_ids, int32_t *box_child_ids, void *box_centers)
+{
+    if (!ctx || dims < 1 || dims > 3 || nlevels < 1 || nlevels > BT_MAX_LEVELS
+            || !level_start_box_nrs || !paths || !bbox_min || !bbox_max || !box_parent_ids
+            || !box_child_ids || !box_centers || (coord_kind != BT_F32 && coord_kind != BT_F64)) {
+        set_error("bt_let_build: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+#define LB(T, D) return let_build_impl<T, D>(ctx, nlevels, level_start_box_nrs, paths,            \
+        aligned_nboxes, bbox_min, bbox_max, root_extent, box_parent_ids, box_child_ids,           \
+        (T *) box_centers)
+    if (coord_kind == BT_F64) { if (dims == 1) LB(double, 1); else if (dims == 2) LB(double, 2); else LB(double, 3); }
+    else { if (dims == 1) LB(float, 1); else if (dims == 2) LB(float, 2); else LB(float, 3); }
+#undef LB
+}
+
+}  // extern "C"

@@ -48,6 +48,7 @@ struct TravArgs {
     // kernel only; srccoll_stride == 0 otherwise)
     const int32_t *srccoll_rows, *srccoll_cnt;
     int srccoll_stride;
+    const int8_t *target_mask;      // sharded traversals: boxes whose lists are wanted
 };
 
 template <class T, int D>
@@ -1203,6 +1204,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     a.min_nsources_cumul = p.from_sep_smaller_min_nsources_cumul;
     a.targets_have_extent = p.targets_have_extent;
     a.close_lists_exist = st->with_extent;
+    a.target_mask = p.target_boxes_mask;
     a.target_boxes = st->target_boxes; a.ntarget_boxes = (int32_t) st->ntb;
     a.ttp_boxes = st->ttp_boxes.get(); a.nttp = (int32_t) st->nttp;
 

@@ -185,7 +185,8 @@ __global__ __launch_bounds__(256) void coll_l2_kernel(TravArgs<T, D> a, int32_t 
     load_center(a, b, center);
     const int level = box_level(a, b);
     const int32_t p = a.parent[b];
-    const bool ttp = box_flags(a, b) & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX);
+    const bool ttp = (box_flags(a, b) & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX))
+        && (!a.target_mask || a.target_mask[b]);    // list 2 only for wanted boxes
     const int32_t ps = a.coll_starts[p];
     const int32_t n = a.coll_starts[p + 1] - ps;
     int ins = 0;                         // depth-first position of p among its colleagues
@@ -278,7 +279,8 @@ __global__ __launch_bounds__(256) void coll_l2_rows_kernel(TravArgs<T, D> a, int
     load_center(a, b, center);
     const int level = box_level(a, b);
     const int32_t p = a.parent[b];
-    const bool ttp = box_flags(a, b) & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX);
+    const bool ttp = (box_flags(a, b) & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX))
+        && (!a.target_mask || a.target_mask[b]);    // list 2 only for wanted boxes
     const int32_t *prow = coll_rows + (int64_t) p * P;
     const int32_t n = coll_cnt[p];
     int ins = 0;                         // depth-first position of p among its colleagues
@@ -375,7 +377,8 @@ __global__ __launch_bounds__(256) void coll_l2_parent_kernel(TravArgs<T, D> a, i
         ttp[k] = false;
         if (b) {
             load_center(a, b, cen[k]);
-            ttp[k] = box_flags(a, b) & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX);
+            ttp[k] = (box_flags(a, b) & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX))
+                && (!a.target_mask || a.target_mask[b]);
         }
     }
     if (!any) return;

@@ -460,8 +460,7 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
     stats["plan"] = plan
     stats["bbox_min"], stats["bbox_max"] = bbox_min, bbox_max
     stats["root_extent"] = root_extent
-    if return_plan:
-        stats["owner"] = owner
+    stats["owner"] = owner
     return new_particles, new_targets, build_kw, stats
 
 
@@ -585,3 +584,206 @@ def gather_global_box_tree(actx, dist, tree, numbering):
         box_level_dtype=np.dtype(np.uint8), coord_dtype=coord_dtype,
         sources_have_extent=False, targets_have_extent=False, extent_norm=None,
         stick_out_factor=tree.stick_out_factor, _is_pruned=True)
+
+
+# {{{ local essential tree (step 6 without the global all-gather)
+
+def _cell_grid(values, dims, k):
+    """Morton-indexed cell array -> [2^k]^dims grid (axis 0 = x)."""
+    n = 1 << k
+    cells = np.arange(n ** dims, dtype=np.int64)
+    coords = []
+    for ax in range(dims):
+        v = np.zeros_like(cells)
+        for bit in range(k):
+            v |= ((cells >> (dims * bit + (dims - 1 - ax))) & 1) << bit
+        coords.append(v)
+    grid = np.zeros((n,) * dims, dtype=values.dtype)
+    grid[tuple(coords)] = values
+    return grid, coords
+
+
+def _cells_needed_by(owner, dims, k, rank, world, ring):
+    """need[q] = boolean array over cells: my cells within *ring* cells (Chebyshev) of
+    a cell owned by rank q -- the subtrees q's lists can reach."""
+    grid, coords = _cell_grid(np.asarray(owner, dtype=np.int64), dims, k)
+    n = 1 << k
+    mine = grid == rank
+    need = np.zeros((world, n ** dims), dtype=bool)
+    for q in range(world):
+        if q == rank:
+            continue
+        theirs = grid == q
+        if not theirs.any():
+            continue
+        near = np.zeros_like(theirs)
+        shifts = range(-ring, ring + 1)
+        import itertools
+        for off in itertools.product(shifts, repeat=dims):
+            src = [slice(max(0, -o), n - max(0, o)) for o in off]
+            dst = [slice(max(0, o), n - max(0, -o)) for o in off]
+            near[tuple(dst)] |= theirs[tuple(src)]
+        need[q] = (near & mine)[tuple(coords)]
+    return need
+
+
+def build_local_essential_tree(actx, dist, tree, stats, numbering, well_sep_is_n_away=1):
+    """Step 6 with a halo instead of the all-gather of :func:`gather_global_box_tree`:
+    the tree this rank needs for the lists of its own boxes -- the shared top levels
+    (known to every rank from the plan), its own subtrees, and the subtrees of the
+    cells of other ranks within *well_sep_is_n_away* cells of its own cells, which
+    those ranks send as (Morton path, level, flags, global number) records.  Boxes
+    are numbered level-major, Morton order within a level (what the parent-colleague
+    kernels expect); parents, children and centres are recomputed from the paths.
+
+    Returns ``(let, info)``: *let* a :class:`~boxtree_amd.tree.TreeOfBoxes`, *info*
+    with ``target_boxes_mask`` / ``active_level_ranges`` for
+    :class:`~boxtree_amd.traversal.FMMTraversalBuilder` and ``global_box_ids``
+    (LET number -> global number)."""
+    import ctypes as ct
+
+    import torch
+
+    from boxtree_amd import _lib
+    from boxtree_amd.tree import TreeOfBoxes
+    plan = stats["plan"]
+    if plan is None:
+        raise NotImplementedError("the local essential tree needs the top-tree plan")
+    world, rank = dist.get_world_size(), dist.get_rank()
+    dims, k = plan["dims"], plan["top_level"]
+    C = 1 << dims
+    nb = int(tree.nboxes)
+    dev = tree.box_centers.device
+    coord_t = tree.box_centers.dtype
+    coord_dtype = np.dtype(str(coord_t).replace("torch.", ""))
+    gstarts = numbering["global_level_start_box_nrs"]
+    nlev = len(gstarts) - 1
+    ntop_levels = min(k + 1, nlev)
+    bbox_min, bbox_max = stats["bbox_min"], stats["bbox_max"]
+    root_extent = stats["root_extent"]
+    kind = _lib.BT_F64 if coord_dtype == np.float64 else _lib.BT_F32
+
+    # -- Morton paths of my boxes ------------------------------------------------------
+    paths = torch.empty(nb, dtype=torch.int64, device=dev)
+    bmin = (ct.c_double * 3)(*[float(v) for v in bbox_min], *([0.0] * (3 - dims)))
+    actx.sync_in()
+    _lib.check(actx.lib.bt_box_morton_paths(
+        actx.handle, dims, kind, nb, int(tree.aligned_nboxes),
+        ct.c_void_p(tree.box_centers.data_ptr()), ct.c_void_p(tree.box_levels.data_ptr()), bmin,
+        float(root_extent), ct.c_void_p(paths.data_ptr())))
+    levels = tree.box_levels[:nb].long()
+    deep = levels > k
+    gids = numbering["box_ids"]
+    meta = levels.to(torch.int32) | (tree.box_flags[:nb].to(torch.int32) << 8)
+
+    # -- halo: my deep boxes in the cells other ranks' lists can reach -----------------------
+    need = _cells_needed_by(stats["owner"], dims, k, rank, world, int(well_sep_is_n_away))
+    deep_idx = torch.nonzero(deep).flatten()
+    cell_of_deep = paths[deep_idx] >> (dims * (levels[deep_idx] - k))
+    send_idx, s_split = [], []
+    need_t = torch.from_numpy(need).to(dev)
+    for q in range(world):
+        if q == rank or not need[q].any():
+            s_split.append(0)
+            continue
+        sel = deep_idx[need_t[q][cell_of_deep]]
+        send_idx.append(sel)
+        s_split.append(int(sel.shape[0]))
+    send_idx = torch.cat(send_idx) if send_idx else deep_idx[:0]
+    counts = torch.tensor(s_split, dtype=torch.int64, device=dev)
+    rcounts = torch.empty_like(counts)
+    dist.all_to_all_single(rcounts, counts)
+    r_split = [int(c) for c in rcounts.cpu().tolist()]
+    nrecv = sum(r_split)
+
+    def route(t):
+        out = torch.empty(nrecv, dtype=t.dtype, device=dev)
+        all_to_all_chunked(dist, out, t[send_idx].contiguous(), r_split, s_split)
+        return out
+
+    h_paths, h_meta, h_gids = route(paths), route(meta), route(gids.to(torch.int32))
+
+    # -- the box set: top levels from the plan, my deep boxes, the halo ------------------------
+    lvl_paths, lvl_meta, lvl_gid, lvl_mine = [], [], [], []
+    owner = np.asarray(stats["owner"], dtype=np.int64)
+    for lev in range(ntop_levels):
+        p = np.nonzero(plan["exists"][lev])[0].astype(np.int64)
+        internal = plan["split"][lev][p]
+        flags = np.where(internal, 12, 3).astype(np.int32)      # tree.py:109-145 (sources = targets)
+        # lists of the shared internal boxes are built by every rank, those of a top
+        # LEAF only by the rank that owns its cells
+        first_cell = p << (dims * (k - lev))
+        lvl_paths.append(torch.from_numpy(p).to(dev))
+        lvl_meta.append(torch.from_numpy(lev | (flags << 8)).to(dev))
+        lvl_gid.append(torch.from_numpy((int(gstarts[lev]) + np.arange(len(p))).astype(np.int32)).to(dev))
+        lvl_mine.append(torch.from_numpy(internal | (owner[first_cell] == rank)).to(dev))
+    d_paths = torch.cat([paths[deep_idx], h_paths])
+    d_meta = torch.cat([meta[deep_idx], h_meta])
+    d_gid = torch.cat([gids[deep_idx].to(torch.int32), h_gids])
+    d_mine = torch.cat([torch.ones(int(deep_idx.shape[0]), dtype=torch.bool, device=dev),
+                        torch.zeros(nrecv, dtype=torch.bool, device=dev)])
+    d_lev = (d_meta & 0xff).long()
+    ranges = np.zeros((nlev, 2), dtype=np.int32)
+    level_starts = [0]
+    for lev in range(nlev):
+        if lev < ntop_levels:
+            n_lev = int(lvl_paths[lev].shape[0])
+            ranges[lev] = (level_starts[-1], level_starts[-1] + n_lev)
+        else:
+            sel = torch.nonzero(d_lev == lev).flatten()
+            n_lev = int(sel.shape[0])
+            keys = d_paths[sel].contiguous()
+            order = torch.empty(n_lev, dtype=torch.int32, device=dev)
+            keys_out = torch.empty_like(keys)
+            vals = torch.arange(n_lev, dtype=torch.int32, device=dev)
+            if n_lev:
+                actx.sync_in()
+                _lib.check(actx.lib.bt_radix_sort_u64_u32(
+                    actx.handle, ct.c_void_p(keys.data_ptr()), ct.c_void_p(vals.data_ptr()),
+                    ct.c_void_p(keys_out.data_ptr()), ct.c_void_p(order.data_ptr()), n_lev, 0,
+                    min(64, dims * lev)))
+            sel = sel[order.long()]
+            lvl_paths.append(keys_out)
+            lvl_meta.append(d_meta[sel])
+            lvl_gid.append(d_gid[sel])
+            mine = d_mine[sel]
+            lvl_mine.append(mine)
+            mine_idx = torch.nonzero(mine).flatten()
+            if int(mine_idx.shape[0]):
+                lo, hi = int(mine_idx[0]), int(mine_idx[-1]) + 1
+                assert hi - lo == int(mine_idx.shape[0])       # my Morton range is contiguous
+                ranges[lev] = (level_starts[-1] + lo, level_starts[-1] + hi)
+            else:
+                ranges[lev] = (level_starts[-1], level_starts[-1])
+        level_starts.append(level_starts[-1] + n_lev)
+    B = level_starts[-1]
+    aligned = -(-B // 32) * 32
+    all_paths = torch.cat(lvl_paths).contiguous()
+    all_meta = torch.cat(lvl_meta)
+    let_gid = torch.cat(lvl_gid).contiguous()
+    mask = torch.cat(lvl_mine).to(torch.int8).contiguous()
+
+    parents = torch.zeros(B, dtype=torch.int32, device=dev)
+    children = torch.zeros((C, aligned), dtype=torch.int32, device=dev)
+    centers = torch.zeros((dims, aligned), dtype=coord_t, device=dev)
+    lsb = np.asarray(level_starts, dtype=np.int32)
+    bmax = (ct.c_double * 3)(*[float(v) for v in bbox_max], *([0.0] * (3 - dims)))
+    actx.sync_in()
+    _lib.check(actx.lib.bt_let_build(
+        actx.handle, dims, kind, nlev, lsb.ctypes.data_as(ct.POINTER(ct.c_int32)),
+        ct.c_void_p(all_paths.data_ptr()), aligned, bmin, bmax, float(root_extent),
+        ct.c_void_p(parents.data_ptr()), ct.c_void_p(children.data_ptr()),
+        ct.c_void_p(centers.data_ptr())))
+    let = TreeOfBoxes(
+        root_extent=tree.root_extent, box_centers=centers, box_parent_ids=parents,
+        box_child_ids=children, box_levels=(all_meta & 0xff).to(torch.uint8),
+        box_flags=((all_meta >> 8) & 0xff).to(torch.uint8), level_start_box_nrs=lsb,
+        box_id_dtype=np.dtype(np.int32), box_level_dtype=np.dtype(np.uint8),
+        coord_dtype=coord_dtype, sources_have_extent=False, targets_have_extent=False,
+        extent_norm=None, stick_out_factor=tree.stick_out_factor, _is_pruned=True)
+    info = dict(target_boxes_mask=mask, active_level_ranges=ranges, global_box_ids=let_gid,
+                halo_boxes_received=nrecv, halo_boxes_sent=int(send_idx.shape[0]),
+                nboxes=B)
+    return let, info
+
+# }}}

@@ -434,6 +434,22 @@ int bt_gather_pack(bt_context *ctx, int dims, int elem_size, const void *const *
 int bt_unpack(bt_context *ctx, int dims, int elem_size, const void *in, int64_t n,
               void *const *out);
 
+/* Morton path (x most significant in every digit, level*dims bits) of every box,
+ * from its centre and level. */
+int bt_box_morton_paths(bt_context *ctx, int dims, int coord_kind, int64_t nboxes,
+                        int64_t aligned_nboxes, const void *box_centers, const uint8_t *box_levels,
+                        const double *bbox_min, double root_extent, uint64_t *paths);
+
+/* Links a tree given as Morton paths: boxes are level-major (level_start_box_nrs,
+ * HOST, [nlevels+1]) and ascending by path within a level.  Writes box_parent_ids
+ * [nboxes], box_child_ids [2^d][aligned] (0 where the child is not in the set) and
+ * box_centers [d][aligned] by the builder's own arithmetic (root centre, then
+ * parent centre +/- half the child's size).  BT_ERR_INVALID if a box has no parent. */
+int bt_let_build(bt_context *ctx, int dims, int coord_kind, int nlevels,
+                 const int32_t *level_start_box_nrs, const uint64_t *paths, int64_t aligned_nboxes,
+                 const double *bbox_min, const double *bbox_max, double root_extent,
+                 int32_t *box_parent_ids, int32_t *box_child_ids, void *box_centers);
+
 #ifdef __cplusplus
 }
 #endif

@@ -843,3 +843,138 @@ def test_exchange_large_messages_nccl_single_rank():
             assert bool(torch.equal(a, b))          # one rank: nothing moves
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dims,world,dist_kind,nway", [(3, 3, "sphere", 1), (3, 4, "uniform", 1),
+                                                       (2, 2, "normal", 1), (2, 4, "uniform", 2),
+                                                       (3, 8, "sphere", 1)])
+def test_multi_rank_local_essential_tree(dims, world, dist_kind, nway):
+    """Step 6 with a halo (build_local_essential_tree): the lists a rank builds on its
+    local essential tree, mapped to global box numbers, are the rows of the global
+    traversal for the rank's boxes -- and the tree itself matches the global tree box
+    for box (centres, levels, flags, parent/child links)."""
+    import threading
+
+    import torch
+    from fake_dist import FakeWorld
+    from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
+    from boxtree_amd.distributed import (build_local_essential_tree, exchange_particles,
+                                         number_sharded_tree)
+    n_per, mpb = 40000, 30
+    top_level = 3 if dims == 3 else 4
+
+    def chunk(rank):
+        rng = np.random.default_rng(200 + rank)
+        if dist_kind == "sphere":
+            v = rng.standard_normal((dims, n_per))
+            v /= np.sqrt((v * v).sum(axis=0))
+            return [np.ascontiguousarray(v[i]) for i in range(dims)]
+        if dist_kind == "uniform":
+            return [rng.random(n_per) for _ in range(dims)]
+        return [rng.standard_normal(n_per) for _ in range(dims)]
+
+    chunks = [chunk(r) for r in range(world)]
+    fw = FakeWorld(world)
+    results = [None] * world
+    errors = []
+
+    def run(rank):
+        try:
+            actx = HIPArrayContext(0)
+            dist = fw.rank_view(rank)
+            pts = [torch.from_numpy(a).cuda() for a in chunks[rank]]
+            p2, _, kw, stats = exchange_particles(actx, dist, pts, None, {}, top_level=top_level,
+                                                  max_particles_in_box=mpb)
+            tree, _ = TreeBuilder(actx)(actx, p2, max_particles_in_box=mpb, **kw)
+            num = number_sharded_tree(dist, tree, stats)
+            let, info = build_local_essential_tree(actx, dist, tree, stats, num,
+                                                   well_sep_is_n_away=nway)
+            trav, _ = FMMTraversalBuilder(actx, well_sep_is_n_away=nway)(
+                actx, let, _target_boxes_mask=info["target_boxes_mask"],
+                _active_level_ranges=info["active_level_ranges"])
+            results[rank] = dict(let=actx.to_numpy(let), trav=actx.to_numpy(trav),
+                                 gid=info["global_box_ids"].cpu().numpy().astype(np.int64),
+                                 mask=info["target_boxes_mask"].cpu().numpy().astype(bool),
+                                 nhalo=info["halo_boxes_received"], nboxes=info["nboxes"],
+                                 nglobal=num["nboxes"])
+        except BaseException as e:      # noqa: BLE001
+            import traceback
+            errors.append((rank, repr(e), traceback.format_exc()[-1500:]))
+            try:
+                fw.barrier.abort()
+            except Exception:           # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=600)
+    assert not errors, errors
+
+    actx = HIPArrayContext(0)
+    allpts = [torch.from_numpy(np.concatenate([c[ax] for c in chunks])).cuda()
+              for ax in range(dims)]
+    gt, _ = TreeBuilder(actx)(actx, allpts, max_particles_in_box=mpb)
+    full = actx.to_numpy(FMMTraversalBuilder(actx, well_sep_is_n_away=nway)(actx, gt)[0])
+    g = actx.to_numpy(gt)
+
+    def rows(starts, lists, sel, m=None):
+        out = []
+        for i in sel:
+            r = lists[starts[i]:starts[i + 1]]
+            out.append((m[r] if m is not None else r).tolist())
+        return out
+
+    pos_t = {int(b): i for i, b in enumerate(full.target_boxes)}
+    pos_p = {int(b): i for i, b in enumerate(full.target_or_target_parent_boxes)}
+    deep_cover = np.zeros(g.nboxes, np.int64)
+    for r in results:
+        t, tr, gid, hm = r["let"], r["trav"], r["gid"], r["mask"]
+        nb = t.nboxes
+        assert r["nglobal"] == g.nboxes and nb <= g.nboxes
+        if world > 2:
+            assert nb < g.nboxes                   # a halo, not the whole tree
+        assert len(set(gid.tolist())) == nb
+        # the LET is the global tree restricted to its boxes
+        assert np.array_equal(t.box_levels, g.box_levels[gid])
+        assert np.array_equal(t.box_flags, g.box_flags[gid])
+        assert np.array_equal(t.box_centers[:, :nb], g.box_centers[:, gid])
+        assert np.array_equal(gid[t.box_parent_ids], g.box_parent_ids[gid])
+        ch = t.box_child_ids[:, :nb]
+        mapped = np.where(ch != 0, gid[ch], 0)
+        assert np.all((mapped == 0) | (mapped == g.box_child_ids[:, gid]))
+        mine_deep = hm & (t.box_levels > top_level)
+        assert np.array_equal(mapped[:, mine_deep], g.box_child_ids[:, gid[mine_deep]])
+        deep_cover[gid[mine_deep]] += 1
+        # lists, mapped to global numbers
+        gt_boxes = gid[tr.target_boxes]
+        assert np.all(hm[tr.target_boxes])
+        sel_t = [pos_t[int(b)] for b in gt_boxes]
+        gp_boxes = gid[tr.target_or_target_parent_boxes]
+        sel_p = [pos_p[int(b)] for b in gp_boxes]
+        assert rows(tr.neighbor_source_boxes_starts, tr.neighbor_source_boxes_lists,
+                    range(len(sel_t)), gid) == rows(full.neighbor_source_boxes_starts,
+                                                    full.neighbor_source_boxes_lists, sel_t)
+        for name in ("from_sep_siblings", "from_sep_bigger"):
+            got = rows(getattr(tr, name + "_starts"), getattr(tr, name + "_lists"),
+                       range(len(sel_p)), gid)
+            want = rows(getattr(full, name + "_starts"), getattr(full, name + "_lists"), sel_p)
+            assert got == want, name
+        act = np.nonzero(hm)[0]
+        assert rows(tr.same_level_non_well_sep_boxes_starts, tr.same_level_non_well_sep_boxes_lists,
+                    act, gid) == rows(full.same_level_non_well_sep_boxes_starts,
+                                      full.same_level_non_well_sep_boxes_lists, gid[act])
+        hm_global = np.zeros(g.nboxes, bool)
+        hm_global[gid[hm]] = True
+        for lev in range(g.nlevels):
+            a, b = tr.from_sep_smaller_by_level[lev], full.from_sep_smaller_by_level[lev]
+            got = {int(gid[tb]): gid[a.lists[a.starts[i]:a.starts[i + 1]]].tolist()
+                   for i, tb in enumerate(tr.target_boxes_sep_smaller_by_source_level[lev])}
+            want = {int(tb): b.lists[b.starts[i]:b.starts[i + 1]].tolist()
+                    for i, tb in enumerate(full.target_boxes_sep_smaller_by_source_level[lev])
+                    if hm_global[tb]}
+            assert got == want
+    # every box below the top levels is some rank's own, exactly once
+    assert np.all(deep_cover[g.box_levels > top_level] == 1)
