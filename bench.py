@@ -178,13 +178,24 @@ def main():
         if distributed and xs["plan"] is not None:
             # global box numbers, box arrays of all ranks, then the interaction lists
             # of this rank's boxes (cross-boundary lists included)
-            from boxtree_amd.distributed import gather_global_box_tree, number_sharded_tree
+            from boxtree_amd.distributed import (build_local_essential_tree,
+                                                 gather_global_box_tree, number_sharded_tree)
             num = number_sharded_tree(dist, tree, xs)
-            gtree = gather_global_box_tree(actx, dist, tree, num)
-            trav, _ = tg(actx, gtree, _target_boxes_mask=num["target_boxes_mask"],
-                         _active_level_ranges=num["active_level_ranges"])
-            xinfo.update(global_nboxes=int(num["nboxes"]), sharded_traversal="global box "
-                         "arrays all-gathered; lists for own boxes + shared top levels")
+            if os.environ.get("BOXTREE_HIP_SHARDED", "let") == "gather":
+                # every rank gets ALL box arrays (simple, not scalable)
+                gtree = gather_global_box_tree(actx, dist, tree, num)
+                mask, ranges = num["target_boxes_mask"], num["active_level_ranges"]
+                how = "global box arrays all-gathered"
+            else:
+                # local essential tree: shared top levels + own subtrees + halo subtrees
+                gtree, let = build_local_essential_tree(actx, dist, tree, xs, num)
+                mask, ranges = let["target_boxes_mask"], let["active_level_ranges"]
+                how = "local essential tree (halo of neighbouring cells)"
+                xinfo.update(let_nboxes_rank0=int(let["nboxes"]),
+                             halo_boxes_received_rank0=int(let["halo_boxes_received"]))
+            trav, _ = tg(actx, gtree, _target_boxes_mask=mask, _active_level_ranges=ranges)
+            xinfo.update(global_nboxes=int(num["nboxes"]), sharded_traversal=how
+                         + "; lists for own boxes + shared top levels")
             nboxes, nlevels = int(num["nboxes"]), int(gtree.nlevels)
         else:
             trav, _ = tg(actx, tree)

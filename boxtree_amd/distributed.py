@@ -588,16 +588,22 @@ def gather_global_box_tree(actx, dist, tree, numbering):
 
 # {{{ local essential tree (step 6 without the global all-gather)
 
+_CELL_COORDS = {}
+
+
 def _cell_grid(values, dims, k):
     """Morton-indexed cell array -> [2^k]^dims grid (axis 0 = x)."""
     n = 1 << k
-    cells = np.arange(n ** dims, dtype=np.int64)
-    coords = []
-    for ax in range(dims):
-        v = np.zeros_like(cells)
-        for bit in range(k):
-            v |= ((cells >> (dims * bit + (dims - 1 - ax))) & 1) << bit
-        coords.append(v)
+    if (dims, k) not in _CELL_COORDS:
+        cells = np.arange(n ** dims, dtype=np.int64)
+        coords = []
+        for ax in range(dims):
+            v = np.zeros_like(cells)
+            for bit in range(k):
+                v |= ((cells >> (dims * bit + (dims - 1 - ax))) & 1) << bit
+            coords.append(v)
+        _CELL_COORDS[dims, k] = coords
+    coords = _CELL_COORDS[dims, k]
     grid = np.zeros((n,) * dims, dtype=values.dtype)
     grid[tuple(coords)] = values
     return grid, coords
@@ -704,58 +710,97 @@ def build_local_essential_tree(actx, dist, tree, stats, numbering, well_sep_is_n
     h_paths, h_meta, h_gids = route(paths), route(meta), route(gids.to(torch.int32))
 
     # -- the box set: top levels from the plan, my deep boxes, the halo ------------------------
-    lvl_paths, lvl_meta, lvl_gid, lvl_mine = [], [], [], []
     owner = np.asarray(stats["owner"], dtype=np.int64)
+    t_paths, t_meta, t_gid, t_mine, top_counts = [], [], [], [], []
     for lev in range(ntop_levels):
         p = np.nonzero(plan["exists"][lev])[0].astype(np.int64)
         internal = plan["split"][lev][p]
-        flags = np.where(internal, 12, 3).astype(np.int32)      # tree.py:109-145 (sources = targets)
+        flags = np.where(internal, 12, 3).astype(np.int64)      # tree.py:109-145 (sources = targets)
         # lists of the shared internal boxes are built by every rank, those of a top
         # LEAF only by the rank that owns its cells
         first_cell = p << (dims * (k - lev))
-        lvl_paths.append(torch.from_numpy(p).to(dev))
-        lvl_meta.append(torch.from_numpy(lev | (flags << 8)).to(dev))
-        lvl_gid.append(torch.from_numpy((int(gstarts[lev]) + np.arange(len(p))).astype(np.int32)).to(dev))
-        lvl_mine.append(torch.from_numpy(internal | (owner[first_cell] == rank)).to(dev))
+        t_paths.append(p)
+        t_meta.append(lev | (flags << 8))
+        t_gid.append(int(gstarts[lev]) + np.arange(len(p), dtype=np.int64))
+        t_mine.append((internal | (owner[first_cell] == rank)).astype(np.int64))
+        top_counts.append(len(p))
+    top = torch.from_numpy(np.stack([np.concatenate(t_paths), np.concatenate(t_meta),
+                                     np.concatenate(t_gid), np.concatenate(t_mine)])).to(dev)
+    lvl_paths = [top[0]]
+    lvl_meta = [top[1].to(torch.int32)]
+    lvl_gid = [top[2].to(torch.int32)]
+    lvl_mine = [top[3] != 0]
     d_paths = torch.cat([paths[deep_idx], h_paths])
     d_meta = torch.cat([meta[deep_idx], h_meta])
     d_gid = torch.cat([gids[deep_idx].to(torch.int32), h_gids])
-    d_mine = torch.cat([torch.ones(int(deep_idx.shape[0]), dtype=torch.bool, device=dev),
-                        torch.zeros(nrecv, dtype=torch.bool, device=dev)])
+    nd = int(d_paths.shape[0])
+    n_mine = int(deep_idx.shape[0])
     d_lev = (d_meta & 0xff).long()
+    # order the deep boxes by (level, Morton path): a stable sort by the path
+    # left-aligned to the deepest level (ancestors tie with their first
+    # descendants), then a stable one-digit sort by level
+    lmax = nlev - 1
+    order = torch.arange(nd, dtype=torch.int32, device=dev)
+    if nd:
+        key = (d_paths << (dims * (lmax - d_lev))).contiguous()
+        key_out = torch.empty_like(key)
+        order1 = torch.empty_like(order)
+        actx.sync_in()
+        _lib.check(actx.lib.bt_radix_sort_u64_u32(
+            actx.handle, ct.c_void_p(key.data_ptr()), ct.c_void_p(order.data_ptr()),
+            ct.c_void_p(key_out.data_ptr()), ct.c_void_p(order1.data_ptr()), nd, 0,
+            max(1, min(64, dims * lmax))))
+        lev_key = d_lev[order1.long()].to(torch.int32).contiguous()
+        lev_out = torch.empty_like(lev_key)
+        order = torch.empty_like(order1)
+        actx.sync_in()
+        _lib.check(actx.lib.bt_radix_sort_u32_u32(
+            actx.handle, ct.c_void_p(lev_key.data_ptr()), ct.c_void_p(order1.data_ptr()),
+            ct.c_void_p(lev_out.data_ptr()), ct.c_void_p(order.data_ptr()), nd, 0, 8))
+    order = order.long()
+    s_paths, s_meta, s_gid = d_paths[order], d_meta[order], d_gid[order]
+    s_mine = order < n_mine
+    s_lev = (s_meta & 0xff).long()
+    # (sorted by level: boundaries by binary search, no histogram atomics)
+    bounds = torch.searchsorted(s_lev.contiguous(),
+                                torch.arange(nlev + 1, device=dev)).cpu().numpy()
+    deep_counts = np.diff(bounds)
+    # my boxes of a level are one contiguous run (my cells are one Morton range)
+    mpos = torch.nonzero(s_mine).flatten()          # ascending; levels non-decreasing
+    mlev = s_lev[mpos].contiguous()
+    probe = torch.arange(nlev, device=dev)
+    lo = torch.searchsorted(mlev, probe).cpu().numpy()
+    hi = torch.searchsorted(mlev, probe, right=True).cpu().numpy()
+    mpos_h = None
+    mine_counts = hi - lo
+    first_h = np.zeros(nlev, dtype=np.int64)
+    last_h = np.zeros(nlev, dtype=np.int64)
+    if int(mpos.shape[0]):
+        ends = torch.from_numpy(np.stack([np.minimum(lo, len(mlev) - 1),
+                                          np.maximum(hi - 1, 0)])).to(dev)
+        mpos_h = mpos[ends].cpu().numpy()
+        first_h, last_h = mpos_h[0], mpos_h[1]
     ranges = np.zeros((nlev, 2), dtype=np.int32)
     level_starts = [0]
+    ntop = int(sum(top_counts))
+    deep_off = 0
     for lev in range(nlev):
         if lev < ntop_levels:
-            n_lev = int(lvl_paths[lev].shape[0])
+            n_lev = int(top_counts[lev])
             ranges[lev] = (level_starts[-1], level_starts[-1] + n_lev)
         else:
-            sel = torch.nonzero(d_lev == lev).flatten()
-            n_lev = int(sel.shape[0])
-            keys = d_paths[sel].contiguous()
-            order = torch.empty(n_lev, dtype=torch.int32, device=dev)
-            keys_out = torch.empty_like(keys)
-            vals = torch.arange(n_lev, dtype=torch.int32, device=dev)
-            if n_lev:
-                actx.sync_in()
-                _lib.check(actx.lib.bt_radix_sort_u64_u32(
-                    actx.handle, ct.c_void_p(keys.data_ptr()), ct.c_void_p(vals.data_ptr()),
-                    ct.c_void_p(keys_out.data_ptr()), ct.c_void_p(order.data_ptr()), n_lev, 0,
-                    min(64, dims * lev)))
-            sel = sel[order.long()]
-            lvl_paths.append(keys_out)
-            lvl_meta.append(d_meta[sel])
-            lvl_gid.append(d_gid[sel])
-            mine = d_mine[sel]
-            lvl_mine.append(mine)
-            mine_idx = torch.nonzero(mine).flatten()
-            if int(mine_idx.shape[0]):
-                lo, hi = int(mine_idx[0]), int(mine_idx[-1]) + 1
-                assert hi - lo == int(mine_idx.shape[0])       # my Morton range is contiguous
-                ranges[lev] = (level_starts[-1] + lo, level_starts[-1] + hi)
+            n_lev = int(deep_counts[lev])
+            if mine_counts[lev]:
+                assert last_h[lev] - first_h[lev] + 1 == mine_counts[lev]
+                ranges[lev] = (ntop + first_h[lev], ntop + last_h[lev] + 1)
             else:
                 ranges[lev] = (level_starts[-1], level_starts[-1])
+            deep_off += n_lev
         level_starts.append(level_starts[-1] + n_lev)
+    lvl_paths.append(s_paths)
+    lvl_meta.append(s_meta)
+    lvl_gid.append(s_gid)
+    lvl_mine.append(s_mine)
     B = level_starts[-1]
     aligned = -(-B // 32) * 32
     all_paths = torch.cat(lvl_paths).contiguous()

@@ -12,7 +12,8 @@ import torch.distributed as dist
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
-from boxtree_amd.distributed import exchange_particles, gather_global_box_tree, number_sharded_tree
+from boxtree_amd.distributed import (build_local_essential_tree, exchange_particles,
+                                     gather_global_box_tree, number_sharded_tree)
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10**8
 actx = HIPArrayContext(0)
@@ -38,11 +39,15 @@ for it in range(3):
     t2 = T()
     num = number_sharded_tree(dist, tree, st)
     t3 = T()
-    gt = gather_global_box_tree(actx, dist, tree, num)
+    if os.environ.get("BOXTREE_HIP_SHARDED", "let") == "gather":
+        gt = gather_global_box_tree(actx, dist, tree, num)
+        mask, ranges = num["target_boxes_mask"], num["active_level_ranges"]
+    else:
+        gt, let = build_local_essential_tree(actx, dist, tree, st, num)
+        mask, ranges = let["target_boxes_mask"], let["active_level_ranges"]
     t4 = T()
-    trav, _ = tg(actx, gt, _target_boxes_mask=num["target_boxes_mask"],
-                 _active_level_ranges=num["active_level_ranges"])
+    trav, _ = tg(actx, gt, _target_boxes_mask=mask, _active_level_ranges=ranges)
     t5 = T()
     print(f"exchange {1e3*(t1-t0):.2f}  build {1e3*(t2-t1):.2f}  number {1e3*(t3-t2):.2f}  "
-          f"gather {1e3*(t4-t3):.2f}  traversal {1e3*(t5-t4):.2f}  total {1e3*(t5-t0):.2f} ms")
+          f"LET/gather {1e3*(t4-t3):.2f}  traversal {1e3*(t5-t4):.2f}  total {1e3*(t5-t0):.2f} ms")
 dist.destroy_process_group()
