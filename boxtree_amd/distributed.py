@@ -609,27 +609,31 @@ def _cell_grid(values, dims, k):
     return grid, coords
 
 
-def _cells_needed_by(owner, dims, k, rank, world, ring):
+def _cells_needed_by(owner, dims, k, rank, world, ring, counts=None):
     """need[q] = boolean array over cells: my cells within *ring* cells (Chebyshev) of
     a cell owned by rank q -- the subtrees q's lists can reach."""
-    grid, coords = _cell_grid(np.asarray(owner, dtype=np.int64), dims, k)
+    import itertools
+    owner = np.asarray(owner, dtype=np.int64)
     n = 1 << k
-    mine = grid == rank
+    index_grid, coords = _cell_grid(np.arange(n ** dims, dtype=np.int64), dims, k)
+    mine = owner == rank
+    if counts is not None:
+        mine &= np.asarray(counts) > 0             # empty cells hold no boxes
+    my_cells = np.nonzero(mine)[0]
     need = np.zeros((world, n ** dims), dtype=bool)
-    for q in range(world):
-        if q == rank:
+    if len(my_cells) == 0:
+        return need
+    xyz = [c[my_cells] for c in coords]
+    for off in itertools.product(range(-ring, ring + 1), repeat=dims):
+        if not any(off):
             continue
-        theirs = grid == q
-        if not theirs.any():
-            continue
-        near = np.zeros_like(theirs)
-        shifts = range(-ring, ring + 1)
-        import itertools
-        for off in itertools.product(shifts, repeat=dims):
-            src = [slice(max(0, -o), n - max(0, o)) for o in off]
-            dst = [slice(max(0, o), n - max(0, -o)) for o in off]
-            near[tuple(dst)] |= theirs[tuple(src)]
-        need[q] = (near & mine)[tuple(coords)]
+        nb = [x + o for x, o in zip(xyz, off)]
+        ok = np.ones(len(my_cells), dtype=bool)
+        for v in nb:
+            ok &= (v >= 0) & (v < n)
+        q = owner[index_grid[tuple(v[ok] for v in nb)]]
+        need[q, my_cells[ok]] = True
+    need[rank] = False
     return need
 
 
@@ -683,7 +687,8 @@ def build_local_essential_tree(actx, dist, tree, stats, numbering, well_sep_is_n
     meta = levels.to(torch.int32) | (tree.box_flags[:nb].to(torch.int32) << 8)
 
     # -- halo: my deep boxes in the cells other ranks' lists can reach -----------------------
-    need = _cells_needed_by(stats["owner"], dims, k, rank, world, int(well_sep_is_n_away))
+    need = _cells_needed_by(stats["owner"], dims, k, rank, world, int(well_sep_is_n_away),
+                            counts=plan["counts"][k])
     deep_idx = torch.nonzero(deep).flatten()
     cell_of_deep = paths[deep_idx] >> (dims * (levels[deep_idx] - k))
     send_idx, s_split = [], []
