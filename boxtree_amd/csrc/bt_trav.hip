@@ -678,21 +678,34 @@ int read_i32(bt_context *ctx, const int32_t *d, int32_t *h)
     return BT_OK;
 }
 
+// exclusive scan of list lengths into int32 starts (n+1 entries), accumulated in 64
+// bits: the total comes back exactly and a list beyond the int32 CSR limit of the
+// reference is an error instead of a wrapped count
+template <class F>
+int scan_list_counts(bt_context *ctx, F f, int64_t n, int32_t *starts, int64_t *total)
+{
+    Buf<int64_t> d_total;
+    BT_CHECK(d_total.alloc(ctx->pool, 1));
+    BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, f, n, starts, d_total.get(), true)));
+    int64_t t = 0;
+    BT_HIP_CHECK(hipMemcpyAsync(&t, d_total.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (t >= ((int64_t) 1 << 31)) {
+        set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference): "
+                  "%lld", (long long) t);
+        return BT_ERR_UNSUPPORTED;
+    }
+    *total = t;
+    return BT_OK;
+}
+
 // counts (in `cs`, n entries) -> exclusive starts in place (n+1 entries) + total on host
 int counts_to_starts(bt_context *ctx, Buf<int32_t> &cs, int64_t n, int64_t *total)
 {
     Buf<int32_t> tmp;
     BT_CHECK(tmp.alloc(ctx->pool, n + 1));
-    ScanI32 f{cs.get()};
-    BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, f, n, tmp.get(), (int32_t *) nullptr, true)));
+    BT_CHECK(scan_list_counts(ctx, ScanI32{cs.get()}, n, tmp.get(), total));
     cs.swap(tmp);
-    int32_t t = 0;
-    BT_CHECK(read_i32(ctx, cs.get() + n, &t));
-    if (t < 0) {
-        set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference)");
-        return BT_ERR_UNSUPPORTED;
-    }
-    *total = t;
     return BT_OK;
 }
 
@@ -825,12 +838,9 @@ int coll_l2_two_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<int3
         else
             coll_l2_parent_kernel<T, D, false><<<nblk((int64_t) np * 64), 256, 0, ctx->stream>>>(
                 a, p0, np, b0, nb, oc);
-        ScanI32 fc{ccnt.get()}, fl{lcnt.get()};
-        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, fc, nb, crel.get(), totals_d.get(), true)));
-        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, fl, nb, lrel.get(), totals_d.get() + 1, true)));
-        int32_t h_tot[2] = {0, 0};
-        BT_HIP_CHECK(hipMemcpyAsync(h_tot, totals_d.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        int64_t h_tot[2] = {0, 0};
+        BT_CHECK(scan_list_counts(ctx, ScanI32{ccnt.get()}, nb, crel.get(), &h_tot[0]));
+        BT_CHECK(scan_list_counts(ctx, ScanI32{lcnt.get()}, nb, lrel.get(), &h_tot[1]));
         if (coll_total + h_tot[0] >= ((int64_t) 1 << 31) || l2_total + h_tot[1] >= ((int64_t) 1 << 31)) {
             set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference)");
             return BT_ERR_UNSUPPORTED;
@@ -907,11 +917,8 @@ int coll_l2_single_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<i
         coll_l2_rows_kernel<T, D><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(
             a, b0, nb, coll_rows.get(), coll_cnt.get(), l2_rows.get(), l2_cnt.get(),
             srccoll_rows.get(), srccoll_cnt.get());
-        ScanI32 fl{l2_cnt.get()};
-        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, fl, nb, l2_rel.get(), total_d.get(), true)));
-        int32_t h_tot = 0;
-        BT_HIP_CHECK(hipMemcpyAsync(&h_tot, total_d.get(), 4, hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        int64_t h_tot = 0;
+        BT_CHECK(scan_list_counts(ctx, ScanI32{l2_cnt.get()}, nb, l2_rel.get(), &h_tot));
         if (l2_total + h_tot >= ((int64_t) 1 << 31)) {
             set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference)");
             return BT_ERR_UNSUPPORTED;
@@ -933,15 +940,8 @@ int coll_l2_single_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<i
     // colleague CSR from the rows
     BT_CHECK(coll.starts.alloc(ctx->pool, B + 1));
     {
-        ScanI32 fc{coll_cnt.get()};
-        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, fc, B, coll.starts.get(),
-                                                          (int32_t *) nullptr, true)));
-        int32_t t = 0;
-        BT_CHECK(read_i32(ctx, coll.starts.get() + B, &t));
-        if (t < 0) {
-            set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference)");
-            return BT_ERR_UNSUPPORTED;
-        }
+        int64_t t = 0;
+        BT_CHECK(scan_list_counts(ctx, ScanI32{coll_cnt.get()}, B, coll.starts.get(), &t));
         coll.total = t;
         BT_CHECK(coll.lists.alloc(ctx->pool, t));
         compact_strided_rows_kernel<<<nblk(B * 16), 256, 0, ctx->stream>>>(

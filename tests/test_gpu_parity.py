@@ -978,3 +978,17 @@ def test_multi_rank_local_essential_tree(dims, world, dist_kind, nway):
             assert got == want
     # every box below the top levels is some rank's own, exactly once
     assert np.all(deep_cover[g.box_levels > top_level] == 1)
+
+
+@pytest.mark.gpu
+def test_list_beyond_int32_csr_limit_raises(actx):
+    """2*10^8 uniform 3D points, mpb 64: list 2 would hold 3.1*10^9 entries -- past the
+    int32 CSR starts of the reference.  An error, not a wrapped count."""
+    import torch
+    from boxtree_amd import FMMTraversalBuilder, TreeBuilder
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1)
+    pts = [torch.rand(2 * 10**8, generator=g, dtype=torch.float32, device="cuda") for _ in range(3)]
+    tree, _ = TreeBuilder(actx)(actx, pts, max_particles_in_box=64)
+    with pytest.raises(NotImplementedError, match="int32 CSR limit"):
+        FMMTraversalBuilder(actx)(actx, tree)
