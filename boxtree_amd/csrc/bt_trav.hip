@@ -49,6 +49,7 @@ struct TravArgs {
     const int32_t *srccoll_rows, *srccoll_cnt;
     int srccoll_stride;
     const int8_t *target_mask;      // sharded traversals: boxes whose lists are wanted
+    const int32_t *dfs_rank;        // preorder rank (parent-colleague kernels)
 };
 
 template <class T, int D>
@@ -988,6 +989,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         compact_sources_by_rank_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
             f, (int32_t) B, st->src_rank_prefix.get(), st->src_by_rank.get());
     }
+    a.dfs_rank = st->dfs_rank.get();
     FastTree ft{st->dfs_rank.get(), st->box_of_rank.get(), st->subtree_size.get(),
                 st->src_rank_prefix.get(), st->src_by_rank.get()};
 

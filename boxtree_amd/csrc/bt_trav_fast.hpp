@@ -13,8 +13,8 @@
 // radius (traversal.py:257-276), and the parity tests compare both paths with
 // the walk-based oracle.
 //
-// Output order.  The walks emit in depth-first order.  Within one level that is
-// ascending box id here; across levels (list 1) entries are ordered by the
+// Output order.  The walks emit in depth-first order (within one level that is
+// ascending box id for trees numbered in Morton order, not for level-restricted ones); across levels (list 1) entries are ordered by the
 // depth-first preorder rank of the box, computed once per tree.
 
 struct FastTree {
@@ -101,15 +101,10 @@ __global__ __launch_bounds__(256) void check_structure_kernel(int32_t nboxes, in
             ok = ok && levels[b] == levels[p] + 1;
             const int slot = find_slot<D>(child, aligned, p, b);
             ok = ok && slot >= 0;
-            const int32_t q = b - 1;
-            ok = ok && levels[q] <= levels[b];
-            if (ok && levels[q] == levels[b] && q > 0) {
-                const int32_t pq = parent[q];
-                if (pq >= 0 && pq < nboxes) {
-                    const int sq = find_slot<D>(child, aligned, pq, q);
-                    ok = ok && (pq < p || (pq == p && sq < slot));
-                } else ok = false;
-            }
+            // level-major numbering; the order within a level is free (level-restricted
+            // trees append force-split children at the end of their level): every
+            // order-sensitive step works on depth-first ranks
+            ok = ok && levels[b - 1] <= levels[b];
             // flag consistency: anything with sources below must be reachable
             if (flags[b] & (BT_BOX_IS_SOURCE_BOX | BT_BOX_HAS_SOURCE_CHILD_BOXES))
                 ok = ok && (flags[p] & BT_BOX_HAS_SOURCE_CHILD_BOXES);
@@ -190,7 +185,9 @@ __global__ __launch_bounds__(256) void coll_l2_kernel(TravArgs<T, D> a, int32_t 
     const int32_t ps = a.coll_starts[p];
     const int32_t n = a.coll_starts[p + 1] - ps;
     int ins = 0;                         // depth-first position of p among its colleagues
-    for (int i = 0; i < n; ++i) ins += (a.coll_lists[ps + i] < p) ? 1 : 0;
+    const int32_t prank = a.dfs_rank[p];     // (ranks, not box numbers: the boxes of a level
+                                             // need not be numbered in depth-first order)
+    for (int i = 0; i < n; ++i) ins += (a.dfs_rank[a.coll_lists[ps + i]] < prank) ? 1 : 0;
 
     int32_t ccnt = 0, lcnt = 0;
     int32_t ccur = 0, lcur = 0;
@@ -284,7 +281,8 @@ __global__ __launch_bounds__(256) void coll_l2_rows_kernel(TravArgs<T, D> a, int
     const int32_t *prow = coll_rows + (int64_t) p * P;
     const int32_t n = coll_cnt[p];
     int ins = 0;                         // depth-first position of p among its colleagues
-    for (int i = 0; i < n; ++i) ins += (prow[i] < p) ? 1 : 0;
+    const int32_t prank = a.dfs_rank[p];
+    for (int i = 0; i < n; ++i) ins += (a.dfs_rank[prow[i]] < prank) ? 1 : 0;
 
     int32_t *crow = coll_rows + (int64_t) b * P;
     int32_t *lrow = l2_rows + (int64_t) g * S;
@@ -395,7 +393,7 @@ __global__ __launch_bounds__(256) void coll_l2_parent_kernel(TravArgs<T, D> a, i
     int ins = 0;                         // depth-first position of p among its colleagues
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
-        ins += __popcll(__ballot(i < n && a.coll_lists[ps + i] < p));
+        ins += __popcll(__ballot(i < n && a.dfs_rank[a.coll_lists[ps + i]] < a.dfs_rank[p]));
     }
 
     int32_t ccur[C], lcur[C];
