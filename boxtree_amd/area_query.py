@@ -88,9 +88,8 @@ def _aq_tree(actx, tree, need_levels):
     t.box_flags = ptr(dev(tree.box_flags))
     if need_levels:
         t.box_parent_ids = ptr(dev(tree.box_parent_ids))
-        if tree.level_start_box_nrs is None:
-            raise NotImplementedError("trees without level_start_box_nrs")
-        lsb = np.ascontiguousarray(actx.to_numpy(tree.level_start_box_nrs), dtype=np.int32)
+        from boxtree_amd.tree import level_start_box_nrs_of
+        lsb = level_start_box_nrs_of(actx, tree)
         keep.append(lsb)
         t.level_start_box_nrs = lsb.ctypes.data_as(ct.POINTER(ct.c_int32))
     return t, keep

@@ -195,10 +195,8 @@ class FMMTraversalBuilder:
         box_flags = dev(tree.box_flags)
         box_parent_ids = dev(tree.box_parent_ids)
         assert np_dtype_of(box_centers) == coord_dtype
-        level_start_box_nrs = tree.level_start_box_nrs
-        if level_start_box_nrs is None:
-            raise NotImplementedError("trees without level_start_box_nrs")
-        lsb = np.ascontiguousarray(actx.to_numpy(level_start_box_nrs), dtype=np.int32)
+        from boxtree_amd.tree import level_start_box_nrs_of
+        lsb = level_start_box_nrs_of(actx, tree)
 
         tp = _lib.TravParams()
         tp.dims = dims

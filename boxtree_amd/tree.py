@@ -216,6 +216,24 @@ class TreeWithLinkedPointSources(Tree):
     box_point_source_counts_cumul: Any
 
 
+def level_start_box_nrs_of(actx, tree):
+    """Host int32 [nlevels+1] level starts of *tree*; derived from ``box_levels`` when
+    the tree does not carry them (a :class:`TreeOfBoxes` may have
+    ``level_start_box_nrs=None``, boxtree/tree.py:236) -- which needs the boxes to be
+    numbered level by level."""
+    if tree.level_start_box_nrs is not None:
+        return np.ascontiguousarray(actx.to_numpy(tree.level_start_box_nrs), dtype=np.int32)
+    levels = np.asarray(actx.to_numpy(tree.box_levels), dtype=np.int64)
+    if len(levels) == 0 or levels[0] != 0 or np.any(np.diff(levels) < 0):
+        raise NotImplementedError(
+            "trees without level_start_box_nrs must number their boxes level by level")
+    nlevels = int(levels[-1]) + 1
+    counts = np.bincount(levels, minlength=nlevels)
+    starts = np.zeros(nlevels + 1, dtype=np.int32)
+    starts[1:] = np.cumsum(counts)
+    return starts
+
+
 def _gather(actx, src, ids):
     """src[ids] through the library's gather kernel."""
     import ctypes as ct

@@ -992,3 +992,27 @@ def test_list_beyond_int32_csr_limit_raises(actx):
     tree, _ = TreeBuilder(actx)(actx, pts, max_particles_in_box=64)
     with pytest.raises(NotImplementedError, match="int32 CSR limit"):
         FMMTraversalBuilder(actx)(actx, tree)
+
+
+@pytest.mark.gpu
+def test_tree_of_boxes_without_level_starts(actx, oracle):
+    """A TreeOfBoxes with level_start_box_nrs=None (allowed by boxtree/tree.py:236) is
+    accepted by the traversal and the peer-list builders."""
+    from boxtree_amd import FMMTraversalBuilder, PeerListFinder, TreeBuilder, TreeOfBoxes
+    p = normal_particles(20000, 3, np.float64, seed=4)
+    tree, _ = TreeBuilder(actx)(actx, [actx.from_numpy(x) for x in p], max_particles_in_box=30)
+    tob = TreeOfBoxes(
+        root_extent=tree.root_extent, box_centers=tree.box_centers,
+        box_parent_ids=tree.box_parent_ids, box_child_ids=tree.box_child_ids,
+        box_levels=tree.box_levels, box_flags=tree.box_flags, level_start_box_nrs=None,
+        box_id_dtype=np.dtype(np.int32), box_level_dtype=np.dtype(np.uint8),
+        coord_dtype=np.dtype(np.float64), sources_have_extent=False,
+        targets_have_extent=False, extent_norm=None, stick_out_factor=0.0, _is_pruned=True)
+    assert tob.nlevels == tree.nlevels
+    otree = oracle.build_tree(p, max_particles_in_box=30)
+    trav, _ = FMMTraversalBuilder(actx)(actx, tob)
+    assert_same_traversal(actx.to_numpy(trav), oracle.build_traversal(otree))
+    pl, _ = PeerListFinder(actx)(actx, tob)
+    opl = oracle.peer_lists(otree)
+    assert np.array_equal(actx.to_numpy(pl.peer_list_starts), opl.peer_list_starts)
+    assert np.array_equal(actx.to_numpy(pl.peer_lists), opl.peer_lists)
