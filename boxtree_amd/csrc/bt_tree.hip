@@ -889,6 +889,89 @@ __global__ __launch_bounds__(WALK_THREADS) void lr_pass_kernel(int32_t nboxes, i
     }
 }
 
+// Morton path of the boxes [b0, b1) created by the last split (raw numbering):
+// parent's path, then the child slot
+template <int D>
+__global__ __launch_bounds__(256) void lr_paths_kernel(int32_t b0, int32_t b1,
+        const int32_t *box_parent, const int32_t *box_child, uint64_t *paths)
+{
+    constexpr int C = 1 << D;
+    const int32_t b = b0 + blockIdx.x * 256 + threadIdx.x;
+    if (b >= b1) return;
+    const int32_t p = box_parent[b];
+    int slot = 0;
+#pragma unroll
+    for (int m = 0; m < C; ++m)
+        if (box_child[(int64_t) p * C + m] == b) slot = m;
+    paths[b] = (paths[p] << D) | (uint64_t) slot;
+}
+
+// The level-restriction pass turned around: instead of every leaf of `upper_level`
+// walking the tree from the root for a finer neighbour (lr_pass_kernel), every
+// SOURCE -- a leaf two levels finer, or a leaf one level finer that is already
+// flagged -- looks up the <= 3^d boxes of `upper_level` around it by descending along
+// their Morton paths, and flags those that are leaves and pass the reference's own
+// float adjacency test.  Touching boxes are exactly the integer neighbours, so the
+// flagged set is the same (tbk:880-900).
+template <class T, int D>
+__global__ __launch_bounds__(256) void lr_mark_kernel(int32_t nboxes, int src_level,
+        int upper_level, int require_flag, T root_extent, const uint8_t *box_level,
+        const uint8_t *box_haschild, const int32_t *box_child, const T *centers,
+        const uint64_t *paths, int32_t *force_split, int32_t *have_split)
+{
+    constexpr int C = 1 << D;
+    const int32_t s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= nboxes) return;
+    if ((int) box_level[s] != src_level || box_haschild[s]) return;
+    if (require_flag && !force_split[s]) return;
+    const uint64_t path = paths[s];
+    int64_t cell[D];
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        int64_t v = 0;
+        for (int bit = 0; bit < src_level; ++bit)
+            v |= (int64_t) ((path >> (D * bit + (D - 1 - ax))) & 1) << bit;
+        cell[ax] = v >> (src_level - upper_level);          // ancestor cell at upper_level
+    }
+    T sc[D];
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) sc[ax] = centers[(int64_t) s * D + ax];
+    const int64_t ncell = (int64_t) 1 << upper_level;
+    constexpr int NOFF = D == 1 ? 3 : D == 2 ? 9 : 27;
+    for (int o = 0; o < NOFF; ++o) {
+        int64_t nb[D];
+        bool inside = true;
+        int oo = o;
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) {
+            nb[ax] = cell[ax] + (oo % 3) - 1;
+            oo /= 3;
+            inside = inside && nb[ax] >= 0 && nb[ax] < ncell;
+        }
+        if (!inside) continue;
+        // descend from the root along the neighbour cell's digits
+        int32_t cur = 0;
+        int lev = 0;
+        for (; lev < upper_level; ++lev) {
+            int digit = 0;
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax)
+                digit |= (int) ((nb[ax] >> (upper_level - 1 - lev)) & 1) << (D - 1 - ax);
+            const int32_t ch = box_child[(int64_t) cur * C + digit];
+            if (!ch) break;
+            cur = ch;
+        }
+        if (lev != upper_level || box_haschild[cur] || cur == s) continue;
+        T tc[D];
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) tc[ax] = centers[(int64_t) cur * D + ax];
+        if (adj<T, D>(root_extent, sc, src_level, tc, upper_level)) {
+            force_split[cur] = 1;
+            __hip_atomic_store(have_split, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 struct NonZeroI32 {
     const int32_t *f;
     __device__ int32_t operator()(int64_t i) const { return f[i] != 0; }
@@ -928,14 +1011,32 @@ struct LrKeep {
 };
 
 __global__ __launch_bounds__(256) void lr_final_ids_kernel(int32_t n, LrKeep keep, const int32_t *pos,
-        const uint8_t *box_level, int32_t *final_of_raw, int32_t *level_counts)
+        int32_t *final_of_raw)
 {
     const int32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t raw = keep.order[i];
     const bool k = keep(i) != 0;
     final_of_raw[raw] = k ? pos[i] : 0;     // pruned boxes map to 0 (tree_build.py:1337-1340)
-    if (k) atomicAdd(&level_counts[box_level[raw]], 1);
+}
+
+// kept boxes per level: the boxes are sorted by level, so a level is a range of the
+// sorted order and its count a difference of the keep-scan (one thread per level; a
+// per-box atomicAdd on a dozen counters serialises: 35 ms for 3*10^6 boxes)
+__global__ void lr_level_counts_kernel(int32_t n, const uint32_t *sorted_levels, const int32_t *pos,
+                                       int32_t *level_counts)
+{
+    const uint32_t l = threadIdx.x;
+    if (l >= BT_MAX_LEVELS) return;
+    auto lower = [&](uint32_t key) {
+        int32_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            if (sorted_levels[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    level_counts[l] = pos[lower(l + 1)] - pos[lower(l)];
 }
 
 template <class T, int D>
@@ -1033,6 +1134,38 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
         return BT_OK;
     };
 
+    static const bool walk_pass = [] {
+        const char *e = getenv("BT_LR_WALK");           // debugging aid: the literal walk
+        return e && atoi(e);
+    }();
+    Buf<uint64_t> box_path;
+    int64_t path_cap = 0, paths_done = 1;
+    auto update_paths = [&]() -> int {
+        if (st->nboxes > path_cap) {
+            Buf<uint64_t> nbuf;
+            const int64_t ncap = std::max<int64_t>(st->cap, st->nboxes);
+            BT_CHECK(nbuf.alloc(ctx->pool, ncap));
+            if (path_cap > 0)
+                BT_HIP_CHECK(hipMemcpyAsync(nbuf.get(), box_path.get(), (size_t) paths_done * 8,
+                                            hipMemcpyDeviceToDevice, ctx->stream));
+            else
+                BT_HIP_CHECK(hipMemsetAsync(nbuf.get(), 0, 8, ctx->stream));   // root: path 0
+            box_path.swap(nbuf);
+            path_cap = ncap;
+        }
+        return BT_OK;
+    };
+    // paths of the boxes [from, nboxes): parents are older boxes, one launch per split
+    auto extend_paths = [&](int64_t from) -> int {
+        BT_CHECK(update_paths());
+        if (st->nboxes > from)
+            lr_paths_kernel<D><<<(unsigned) div_up(st->nboxes - from, 256), 256, 0, ctx->stream>>>(
+                (int32_t) from, (int32_t) st->nboxes, st->box_parent.get(), st->box_child.get(),
+                box_path.get());
+        paths_done = st->nboxes;
+        return BT_OK;
+    };
+
     int level = 1;
     bool final_iteration = false;               // tree_build.py:695
     int64_t reg_b0 = 0, reg_n = 1;              // the regular boxes of level-1
@@ -1054,10 +1187,13 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
             }
             reg_b0 = first_new;
             reg_n = total_new;
+            BT_CHECK(extend_paths(first_new));
         }
         if (nflagged > 0) {
             int forced_new = 0, dummy = 0;
+            const int64_t first_forced = st->nboxes;
             BT_CHECK(split(0, 0, nflagged, flagged, &forced_new, &dummy));
+            BT_CHECK(extend_paths(first_forced));
             nflagged = 0;
         }
         if (final_iteration) break;             // :1127-1143
@@ -1071,9 +1207,19 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
         const size_t lds = (size_t) (level + 2) * WALK_THREADS * 4;
         for (int upper_level = level - 2; upper_level >= 1; --upper_level) {
             BT_HIP_CHECK(hipMemsetAsync(d_have.get(), 0, 4, ctx->stream));
-            lr_pass_kernel<T, D><<<(unsigned) div_up(nb, WALK_THREADS), WALK_THREADS, lds, ctx->stream>>>(
-                nb, upper_level, (T) p.root_extent, st->box_level.get(), st->box_haschild.get(),
-                st->box_child.get(), (const T *) st->centers.get(), force.get(), d_have.get());
+            if (walk_pass) {
+                lr_pass_kernel<T, D><<<(unsigned) div_up(nb, WALK_THREADS), WALK_THREADS, lds, ctx->stream>>>(
+                    nb, upper_level, (T) p.root_extent, st->box_level.get(), st->box_haschild.get(),
+                    st->box_child.get(), (const T *) st->centers.get(), force.get(), d_have.get());
+            } else {
+                // leaves two levels finer, then flagged leaves one level finer (flagged
+                // by the previous, finer step of this pass)
+                for (int k = 2; k >= 1; --k)
+                    lr_mark_kernel<T, D><<<(unsigned) div_up(nb, 256), 256, 0, ctx->stream>>>(
+                        nb, upper_level + k, upper_level, k == 1, (T) p.root_extent,
+                        st->box_level.get(), st->box_haschild.get(), st->box_child.get(),
+                        (const T *) st->centers.get(), box_path.get(), force.get(), d_have.get());
+            }
             int32_t have = 0;
             BT_HIP_CHECK(hipMemcpyAsync(&have, d_have.get(), 4, hipMemcpyDeviceToHost, ctx->stream));
             BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1135,7 +1281,9 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
     BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, keep, nraw, pos.get(), (int32_t *) nullptr,
                                                       true)));
     lr_final_ids_kernel<<<(unsigned) div_up(nraw, 256), 256, 0, ctx->stream>>>(
-        nraw, keep, pos.get(), st->box_level.get(), final_of_raw.get(), level_counts.get());
+        nraw, keep, pos.get(), final_of_raw.get());
+    lr_level_counts_kernel<<<1, BT_MAX_LEVELS, 0, ctx->stream>>>(nraw, in_b ? kb.get() : ka.get(),
+                                                                pos.get(), level_counts.get());
     int32_t h_counts[BT_MAX_LEVELS];
     int32_t nfinal = 0;
     BT_HIP_CHECK(hipMemcpyAsync(h_counts, level_counts.get(), sizeof(h_counts), hipMemcpyDeviceToHost,
