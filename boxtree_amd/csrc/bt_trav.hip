@@ -1128,8 +1128,40 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         BlockJobs jobs{jobbuf.get(), jobbuf.get() + 1, jobbuf.get() + 1 + ntb,
                        jobbuf.get() + 1 + 2 * ntb};
         BT_HIP_CHECK(hipMemsetAsync(jobbuf.get(), 0, 4, ctx->stream));
+        Buf<uint8_t> tier;
+        Buf<int32_t> tier_present;
+        BT_CHECK(tier.alloc(ctx->pool, ntb));
+        BT_CHECK(tier_present.alloc(ctx->pool, 2));
+        BT_HIP_CHECK(hipMemsetAsync(tier.get(), 0, (size_t) ntb, ctx->stream));
+        BT_HIP_CHECK(hipMemsetAsync(tier_present.get(), 0, 8, ctx->stream));
         l1_finalize32_kernel<T, D><<<nblk(ntb * 32), 256, 0, ctx->stream>>>(
-            a, ft, (int32_t) ntb, c1.starts.get(), c1.lists.get(), jobs);
+            a, ft, (int32_t) ntb, c1.starts.get(), c1.lists.get(), jobs, tier.get(),
+            tier_present.get());
+        int32_t h_present[2] = {0, 0};
+        BT_HIP_CHECK(hipMemcpyAsync(h_present, tier_present.get(), 8, hipMemcpyDeviceToHost,
+                                    ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        for (int which = 1; which <= 2; ++which) {
+            if (!h_present[which - 1]) continue;
+            TierIs pr{tier.get(), (uint8_t) which};
+            Buf<int32_t> pos, list;
+            BT_CHECK(pos.alloc(ctx->pool, ntb + 1));
+            BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, pr, ntb, pos.get(),
+                                                              (int32_t *) nullptr, true)));
+            int32_t cnt = 0;
+            BT_CHECK(read_i32(ctx, pos.get() + ntb, &cnt));
+            if (cnt == 0) continue;
+            BT_CHECK(list.alloc(ctx->pool, cnt));
+            compact_tier_kernel<<<nblk(ntb), 256, 0, ctx->stream>>>((int32_t) ntb, pr, pos.get(),
+                                                                   list.get());
+            if (which == 1)
+                l1_finalize_wave_kernel<T, D><<<(unsigned) div_up(cnt, 4), 256, 0, ctx->stream>>>(
+                    a, ft, list.get(), cnt, c1.starts.get(), c1.lists.get(), jobs);
+            else
+                l1_finalize_block_kernel<T, D><<<cnt, 256, 0, ctx->stream>>>(
+                    a, ft, list.get(), c1.starts.get(), c1.lists.get(), jobs);
+            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));    // `list` is freed on scope exit
+        }
         int32_t njobs = 0;
         BT_CHECK(read_i32(ctx, jobs.count, &njobs));
         if (njobs > 0)

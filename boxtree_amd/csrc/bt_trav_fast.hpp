@@ -770,9 +770,27 @@ __global__ __launch_bounds__(256) void l1_finalize_kernel(TravArgs<T, D> a, Fast
 
 // Same as l1_finalize_kernel with 32 lanes per target box: lists of up to 32 ranks
 // (nearly all of them) are ordered by counting in registers; longer ones by lane 0.
+constexpr int L1_BLOCK_MAX = 8192;
+constexpr int L1_WAVE_MAX = 1024;
+
+struct TierIs {
+    const uint8_t *tier;
+    uint8_t value;
+    __device__ int32_t operator()(int64_t i) const { return tier[i] == value ? 1 : 0; }
+};
+
+__global__ __launch_bounds__(256) void compact_tier_kernel(int32_t n, TierIs pr, const int32_t *pos,
+                                                           int32_t *out)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && pr(i)) out[pos[i]] = i;
+}
+
 template <class T, int D>
 __global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, FastTree ft,
-        int32_t ntb, const int32_t *l1_starts, int32_t *l1_lists, BlockJobs jobs)
+        int32_t ntb, const int32_t *l1_starts, int32_t *l1_lists, BlockJobs jobs,
+        uint8_t *tier /* [ntb], zeroed: 1 = wave kernel, 2 = workgroup kernel */,
+        int32_t *tier_present /* [2], zeroed */)
 {
     const int32_t gid = blockIdx.x * 256 + threadIdx.x;
     const int32_t tbn = gid >> 5;
@@ -807,6 +825,11 @@ __global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, Fa
         return;
     }
     if (lane != 0) return;
+    // longer rows are left to a wave (LDS ranking) or a workgroup (LDS sort); they are
+    // collected by a scan over `tier`, not by atomic appends (a million appends to one
+    // counter serialise)
+    if (n <= L1_WAVE_MAX && tier) { tier[tbn] = 1; tier_present[0] = 1; return; }
+    if (n <= L1_BLOCK_MAX && tier) { tier[tbn] = 2; tier_present[1] = 1; return; }
     sort_i32_inplace(out, n);
     int32_t k = n;
     if (blk_len > 0) {
@@ -819,6 +842,102 @@ __global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, Fa
         jobs.len[j] = blk_len;
     }
     for (int32_t i = 0; i < k; ++i) out[i] = ft.box_of_rank[out[i]];
+}
+
+// list 1 of listed target boxes with 32 < entries <= L1_WAVE_MAX: one wave per box
+// stages the ranks in LDS and every lane finds the final position of its entries by
+// counting the smaller ones (ranks are distinct)
+template <class T, int D>
+__global__ __launch_bounds__(256) void l1_finalize_wave_kernel(TravArgs<T, D> a, FastTree ft,
+        const int32_t *mid_list, int32_t nmid, const int32_t *l1_starts, int32_t *l1_lists,
+        BlockJobs jobs)
+{
+    __shared__ int32_t s_all[4][L1_WAVE_MAX];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int32_t idx = blockIdx.x * 4 + w;
+    if (idx >= nmid) return;
+    int32_t *s_v = s_all[w];
+    const int32_t tbn = mid_list[idx];
+    const int32_t b = a.target_boxes[tbn];
+    int32_t *out = l1_lists + l1_starts[tbn];
+    const int32_t n_all = l1_starts[tbn + 1] - l1_starts[tbn];
+    int32_t blk_len = 0, blk_src = 0;
+    const int32_t my_rank = ft.dfs_rank[b];
+    if (box_flags(a, b) & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
+        blk_src = ft.src_prefix[my_rank + 1];
+        blk_len = ft.src_prefix[my_rank + ft.subtree_size[b]] - blk_src;
+    }
+    const int32_t n = n_all - blk_len;
+    for (int i = lane; i < n; i += 64) s_v[i] = out[i];
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    int32_t k0 = 0;                                  // entries before the own-subtree block
+    for (int base = 0; base < n; base += 64)
+        k0 += __popcll(__ballot(base + lane < n && s_v[base + lane] <= my_rank));
+    for (int i = lane; i < n; i += 64) {
+        const int32_t v = s_v[i];
+        int32_t r = 0;
+        for (int j = 0; j < n; ++j) r += (s_v[j] < v) ? 1 : 0;      // broadcast LDS reads
+        out[r < k0 ? r : r + blk_len] = ft.box_of_rank[v];
+    }
+    if (blk_len > 0 && lane == 0) {
+        const int32_t j = atomicAdd(jobs.count, 1);
+        jobs.dst[j] = l1_starts[tbn] + k0;
+        jobs.src[j] = blk_src;
+        jobs.len[j] = blk_len;
+    }
+}
+
+// list 1 of one listed target box (32 < entries <= L1_BLOCK_MAX): bitonic sort of the
+// ranks in LDS by one workgroup, then the same placement as above
+template <class T, int D>
+__global__ __launch_bounds__(256) void l1_finalize_block_kernel(TravArgs<T, D> a, FastTree ft,
+        const int32_t *big_list, const int32_t *l1_starts, int32_t *l1_lists, BlockJobs jobs)
+{
+    __shared__ int32_t s_v[L1_BLOCK_MAX];
+    const int32_t tbn = big_list[blockIdx.x];
+    const int32_t b = a.target_boxes[tbn];
+    int32_t *out = l1_lists + l1_starts[tbn];
+    const int32_t n_all = l1_starts[tbn + 1] - l1_starts[tbn];
+    int32_t blk_len = 0, blk_src = 0;
+    const int32_t my_rank = ft.dfs_rank[b];
+    if (box_flags(a, b) & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
+        blk_src = ft.src_prefix[my_rank + 1];
+        blk_len = ft.src_prefix[my_rank + ft.subtree_size[b]] - blk_src;
+    }
+    const int32_t n = n_all - blk_len;
+    int m = 64;
+    while (m < n) m <<= 1;
+    for (int i = threadIdx.x; i < m; i += 256) s_v[i] = (i < n) ? out[i] : INT32_MAX;
+    __syncthreads();
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < m; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const int32_t x = s_v[i], y = s_v[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { s_v[i] = y; s_v[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // entries before the own-subtree block: ranks <= my_rank (binary search, sorted)
+    int32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (s_v[mid] <= my_rank) lo = mid + 1; else hi = mid;
+    }
+    const int32_t k0 = lo;
+    for (int i = threadIdx.x; i < n; i += 256)
+        out[i < k0 ? i : i + blk_len] = ft.box_of_rank[s_v[i]];
+    if (blk_len > 0 && threadIdx.x == 0) {
+        const int32_t j = atomicAdd(jobs.count, 1);
+        jobs.dst[j] = l1_starts[tbn] + k0;
+        jobs.src[j] = blk_src;
+        jobs.len[j] = blk_len;
+    }
 }
 
 // l3 bookkeeping per (level, target box) from the per-(level, item) starts
