@@ -163,6 +163,9 @@ EXPORTED_SYMBOLS = [
     "bt_translation_classes",
     "bt_filter_targets_user_order", "bt_filter_targets_tree_order", "bt_link_point_sources",
     "bt_box_morton_paths", "bt_let_build",
+    "bt_dfs_order", "bt_partition_work", "bt_ancestor_mask", "bt_mark_list_boxes",
+    "bt_local_particles", "bt_modify_target_flags", "bt_box_to_user_ranks",
+    "bt_boxes_used_by_ranks",
     "bt_morton_cells", "bt_bucket_permutation", "bt_gather", "bt_gather_pack", "bt_unpack",
 ]
 
@@ -235,6 +238,17 @@ def load():
     lib.bt_let_build.argtypes = [vp, ct.c_int, ct.c_int, ct.c_int, ct.POINTER(ct.c_int32), vp,
                                  ct.c_int64, ct.POINTER(ct.c_double), ct.POINTER(ct.c_double),
                                  ct.c_double, vp, vp, vp]
+    i32p, i64p = ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int64)
+    lib.bt_dfs_order.argtypes = [vp, ct.c_int, ct.c_int, i32p, ct.c_int64, ct.c_int64, vp, vp]
+    lib.bt_partition_work.argtypes = [vp, ct.c_int64, vp, vp, ct.c_int, i32p]
+    lib.bt_ancestor_mask.argtypes = [vp, ct.c_int64, vp, vp, vp]
+    lib.bt_mark_list_boxes.argtypes = [vp, ct.c_int64, vp, vp, vp, vp, vp, vp]
+    lib.bt_local_particles.argtypes = [vp, ct.c_int64, ct.c_int64, vp, vp, vp, vp, vp, vp, vp,
+                                       vp, i64p]
+    lib.bt_modify_target_flags.argtypes = [vp, ct.c_int64, vp, vp, vp]
+    lib.bt_box_to_user_ranks.argtypes = [vp, ct.c_int, ct.c_int64, vp, vp, vp, i64p]
+    lib.bt_boxes_used_by_ranks.argtypes = [vp, ct.c_int64, vp, ct.c_int, ct.c_int, vp, vp, vp,
+                                           i64p]
     lib.bt_morton_cells.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), ct.c_int64,
                                     ct.POINTER(ct.c_double), ct.POINTER(ct.c_double),
                                     ct.c_int, vp, vp]

@@ -1,4 +1,4 @@
-// Kernels for the multi-GPU exchange step (boxtree_amd/distributed.py): top-level
+// Kernels for the multi-GPU exchange step (boxtree_amd/distributed/__init__.py): top-level
 // Morton cell of every particle + cell histogram, stable bucketing by owner rank
 // (one digit pass of the radix sort), and the gather that fills the send buffers.
 // The collectives themselves (RCCL all-reduce / all-to-all over xGMI) are issued
@@ -291,7 +291,7 @@ int bt_unpack(bt_context *ctx, int dims, int elem_size, const void *in, int64_t 
 // ---------------------------------------------------------------------------
 // Local essential tree (LET) of a sharded traversal: the shared top levels, the
 // rank's own subtrees and the subtrees of the neighbouring cells of other ranks,
-// assembled from Morton paths (boxtree_amd/distributed.py step 6).
+// assembled from Morton paths (boxtree_amd/distributed/__init__.py step 6).
 // ---------------------------------------------------------------------------
 
 namespace {

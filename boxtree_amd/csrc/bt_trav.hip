@@ -985,7 +985,9 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         SourceRankFlag<T, D> f{a.nodes, st->box_of_rank.get()};
         BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, f, B, st->src_rank_prefix.get(),
                                                           (int32_t *) nullptr, true)));
-        BT_CHECK(st->src_by_rank.alloc(ctx->pool, st->nsb + 1));
+        // with a source_boxes_mask (local trees of the distributed FMM) st->nsb counts
+        // the masked list only; the lists here refer to every box flagged as a source
+        BT_CHECK(st->src_by_rank.alloc(ctx->pool, (p.source_boxes_mask ? B : st->nsb) + 1));
         compact_sources_by_rank_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
             f, (int32_t) B, st->src_rank_prefix.get(), st->src_by_rank.get());
     }

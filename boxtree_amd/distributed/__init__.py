@@ -22,15 +22,20 @@ exchange step that precedes the per-rank single-GPU pipeline:
    (a level->=k box lies inside one cell; the shared top levels split on every
    rank because each owns whole, heavy cells).
 
-Status (round 1): steps 1-5 implemented with ``torch.distributed`` collectives
-(backend "nccl" = RCCL on GPUs, "gloo" in the CPU tests).  On a GPU the
-per-particle work (cell index + histogram, stable bucketing by owner, gather
-into send order) runs in the library's HIP kernels (``bt_morton_cells``,
-``bt_bucket_permutation`` = one onesweep digit pass, ``bt_gather``); with
-``actx=None`` (the gloo CPU tests of the plan/exchange logic) the same routing
-is computed with torch tensor ops.  Not yet done: global box renumbering across
-ranks and halo exchange for interaction lists that cross ownership boundaries --
-each rank's traversal covers its own subtree only.
+Steps 1-5 use ``torch.distributed`` collectives (backend "nccl" = RCCL on GPUs,
+"gloo" in the CPU tests).  On a GPU the per-particle work (cell index + histogram,
+stable bucketing by owner, gather into send order) runs in the library's HIP
+kernels (``bt_morton_cells``, ``bt_bucket_permutation`` = one onesweep digit
+pass, ``bt_gather``); with ``actx=None`` (the gloo CPU tests of the plan/exchange
+logic) the same routing is computed with torch tensor ops.  Global box numbering
+(:func:`number_sharded_tree`) and the cross-boundary traversal
+(:func:`build_local_essential_tree`, or :func:`gather_global_box_tree`) follow
+further down.
+
+The second half of this package is the reference's own distributed interface --
+FMM *evaluation* on a replicated global tree: :mod:`.partition`,
+:mod:`.local_tree`, :mod:`.local_traversal`, :mod:`.calculation` and
+:class:`DistributedFMMRunner` below (boxtree/distributed/__init__.py:156-311).
 """
 
 from __future__ import annotations
@@ -835,5 +840,121 @@ def build_local_essential_tree(actx, dist, tree, stats, numbering, well_sep_is_n
                 halo_boxes_received=nrecv, halo_boxes_sent=int(send_idx.shape[0]),
                 nboxes=B)
     return let, info
+
+# }}}
+
+
+# {{{ distributed FMM evaluation on a replicated global tree
+#     (boxtree/distributed/__init__.py:156-311)
+
+def broadcast_tree(actx, tree, comm, src=0):
+    """Every rank returns a device copy of rank *src*'s *tree* (the others pass
+    ``None``): one object broadcast of the field layout, then one broadcast per
+    array, GPU to GPU."""
+    import dataclasses
+    import torch
+    from boxtree_amd.array_context import _torch_dtype, make_obj_array, np_dtype_of
+    if comm.get_world_size() == 1:
+        return tree
+    is_src = comm.get_rank() == src
+
+    def describe(v):
+        if isinstance(v, torch.Tensor):
+            return ("array", tuple(v.shape), np_dtype_of(v).str)
+        if isinstance(v, np.ndarray) and v.dtype.char == "O":
+            return ("objarray", [describe(a) for a in v])
+        return ("value", v)
+
+    layout = [None]
+    if is_src:
+        memo = {}
+        fields = []
+        for f in dataclasses.fields(tree):
+            v = getattr(tree, f.name)
+            alias = memo.setdefault(id(v), f.name)
+            fields.append((f.name, ("alias", alias) if alias != f.name else describe(v)))
+        layout = [(type(tree), fields)]
+    comm.broadcast_object_list(layout, src=src)
+    cls, fields = layout[0]
+
+    def move(desc, v):
+        if desc[0] == "array":
+            t = (v.contiguous() if is_src else
+                 torch.empty(desc[1], dtype=_torch_dtype(torch, np.dtype(desc[2])),
+                             device=actx.device))
+            if t.numel():
+                comm.broadcast(t, src=src)
+            return t
+        if desc[0] == "objarray":
+            return make_obj_array([move(d, v[i] if is_src else None)
+                                   for i, d in enumerate(desc[1])])
+        return desc[1]
+
+    out = {}
+    for name, desc in fields:
+        if desc[0] == "alias":
+            out[name] = out[desc[1]]
+        else:
+            out[name] = move(desc, getattr(tree, name) if is_src else None)
+    return tree if is_src else cls(**out)
+
+
+def make_distributed_wrangler(actx, global_tree, traversal_builder, wrangler_factory,
+                              calibration_params, comm):
+    """Collective.  Replicates rank 0's *global_tree*, builds the global traversal on
+    every rank, cuts the boxes into per-rank shares by modelled cost, and returns
+    ``(wrangler, src_idx_all_ranks, tgt_idx_all_ranks)`` with the wrangler made by
+    ``wrangler_factory(local_traversal, global_traversal)``
+    (boxtree/distributed/__init__.py:156-271).  The index lists are only populated on
+    rank 0."""
+    import warnings
+    from boxtree_amd.cost import FMMCostModel
+    from boxtree_amd.distributed.calculation import gather_to_root
+    from boxtree_amd.distributed.local_traversal import generate_local_travs
+    from boxtree_amd.distributed.local_tree import generate_local_tree
+    from boxtree_amd.distributed.partition import partition_work
+
+    global_tree = broadcast_tree(actx, global_tree, comm)
+    global_trav, _ = traversal_builder(actx, global_tree)
+
+    cost_per_box = None
+    if comm.get_rank() == 0:
+        if calibration_params is None:
+            warnings.warn("Calibration parameters for the cost model are not supplied. "
+                          "The default one will be used.", stacklevel=2)
+            calibration_params = FMMCostModel.get_unit_calibration_params()
+        # a wrangler on the global traversal, for its expansion orders
+        global_wrangler = wrangler_factory(global_trav, global_trav)
+        cost_per_box = FMMCostModel().cost_per_box(
+            actx, global_trav, global_wrangler.level_orders, calibration_params)
+    responsible_boxes_list = partition_work(actx, cost_per_box, global_trav, comm)
+
+    local_tree, src_idx, tgt_idx = generate_local_tree(
+        actx, global_trav, responsible_boxes_list, comm)
+    src_idx_all_ranks = gather_to_root(actx, comm, src_idx)
+    tgt_idx_all_ranks = gather_to_root(actx, comm, tgt_idx)
+    local_trav = generate_local_travs(actx, local_tree, traversal_builder)
+    wrangler = wrangler_factory(local_trav, global_trav)
+    return wrangler, src_idx_all_ranks, tgt_idx_all_ranks
+
+
+class DistributedFMMRunner:
+    """Sets up and runs a distributed point FMM (boxtree/distributed/__init__.py:
+    274-311): *global_tree* matters on rank 0 only, *comm* is ``torch.distributed``
+    (or an object with its collectives), potentials come back on rank 0."""
+
+    def __init__(self, array_context, global_tree, traversal_builder, wrangler_factory,
+                 calibration_params=None, comm=None):
+        if comm is None:
+            import torch.distributed as comm
+        self.wrangler, self.src_idx_all_ranks, self.tgt_idx_all_ranks = \
+            make_distributed_wrangler(array_context, global_tree, traversal_builder,
+                                      wrangler_factory, calibration_params, comm)
+
+    def drive_dfmm(self, actx, source_weights):
+        from boxtree_amd.fmm import drive_fmm
+        return drive_fmm(actx, self.wrangler, source_weights,
+                         global_src_idx_all_ranks=self.src_idx_all_ranks,
+                         global_tgt_idx_all_ranks=self.tgt_idx_all_ranks)
 
 # }}}

@@ -233,7 +233,7 @@ class FMMTraversalBuilder:
             import os
             _force_generic = os.environ.get("BOXTREE_HIP_FORCE_GENERIC", "0") == "1"
         tp.force_generic = int(bool(_force_generic))
-        # sharded traversals (boxtree_amd/distributed.py step 6): lists of a subset
+        # sharded traversals (boxtree_amd/distributed/__init__.py step 6): lists of a subset
         # of the target boxes of a tree whose box arrays are complete
         tbm = dev(_target_boxes_mask)
         tp.target_boxes_mask = ptr(tbm)

@@ -213,7 +213,7 @@ class TreeBuilder:
 
         if root_box is not None:
             # (bbox_min, bbox_max, root_extent) agreed on by all ranks of a sharded
-            # build (boxtree_amd/distributed.py): already the result of the host
+            # build (boxtree_amd/distributed/__init__.py): already the result of the host
             # arithmetic below on the GLOBAL bounding box (an all-reduce of the
             # ranks' boxes, so it covers these particles), used verbatim
             from boxtree_amd.bounding_box import make_bounding_box_dtype
@@ -299,7 +299,7 @@ class TreeBuilder:
         top_tree = kwargs.get("_top_tree")
         if top_tree is not None:
             # (top_level, int64 device tensor [C^top_level + 1]): global cell counts
-            # of a sharded build, see boxtree_amd/distributed.py
+            # of a sharded build, see boxtree_amd/distributed/__init__.py
             tp.top_level = int(top_tree[0])
             top_prefix = top_tree[1].contiguous()
             assert top_prefix.shape[0] == (1 << (dimensions * tp.top_level)) + 1

@@ -450,6 +450,67 @@ int bt_let_build(bt_context *ctx, int dims, int coord_kind, int nlevels,
                  const double *bbox_min, const double *bbox_max, double root_extent,
                  int32_t *box_parent_ids, int32_t *box_child_ids, void *box_centers);
 
+/* ---- work partition and local trees of the distributed FMM evaluation
+ *      (boxtree/distributed/partition.py, local_tree.py, calculation.py) ---- */
+
+/* get_box_ids_dfs_order (distributed/partition.py:39-57): preorder in which the
+ * reference's explicit stack visits the boxes, i.e. children in DESCENDING Morton
+ * child number.  level_start_box_nrs is HOST memory [nlevels+1]; dfs_order [nboxes]. */
+int bt_dfs_order(bt_context *ctx, int nchildren, int nlevels, const int32_t *level_start_box_nrs,
+                 int64_t nboxes, int64_t aligned_nboxes, const int32_t *box_child_ids,
+                 int32_t *dfs_order);
+
+/* partition_work (distributed/partition.py:60-121): cuts the depth-first order
+ * into nranks consecutive segments of about equal cost.  Segment s ends at the
+ * first box whose running cost exceeds (s+1)*total/nranks, one box ends at most
+ * one segment, the last rank takes the rest.  cost_per_box is f64 [nboxes] on the
+ * device; segments is HOST memory [nranks][2] = [start, end) in depth-first
+ * positions (ranks the loop never reaches get [nboxes, nboxes)). */
+int bt_partition_work(bt_context *ctx, int64_t nboxes, const int32_t *dfs_order,
+                      const double *cost_per_box, int nranks, int32_t *segments);
+
+/* get_ancestor_boxes_mask (distributed/partition.py:167-188): ancestors[b] = 1 iff
+ * b is a proper ancestor of a box in the mask.  Both [nboxes], int8. */
+int bt_ancestor_mask(bt_context *ctx, int64_t nboxes, const int32_t *box_parent_ids,
+                     const int8_t *boxes_mask, int8_t *ancestors);
+
+/* add_interaction_list_boxes_kernel (distributed/partition.py:134-164): for every
+ * row i with (mask_a | mask_b)[box_list[i]] set, out_mask[lists[j]] = 1 for the
+ * row's entries.  mask_b may be NULL; out_mask is updated, not cleared. */
+int bt_mark_list_boxes(bt_context *ctx, int64_t nrows, const int32_t *box_list,
+                       const int8_t *mask_a, const int8_t *mask_b, const int32_t *starts,
+                       const int32_t *lists, int8_t *out_mask);
+
+/* construct_local_particles_and_lists (distributed/local_tree.py:198-283): the
+ * particles a rank keeps are those owned (counts_nonchild) by boxes in box_mask.
+ * Outputs: local starts / counts_nonchild / counts_cumul [nboxes], particle_idx
+ * (capacity nparticles, *nlocal valid, ascending global tree-order indices). */
+int bt_local_particles(bt_context *ctx, int64_t nboxes, int64_t nparticles, const int8_t *box_mask,
+                       const int32_t *box_particle_starts,
+                       const int32_t *box_particle_counts_nonchild,
+                       const int32_t *box_particle_counts_cumul, int32_t *local_starts,
+                       int32_t *local_counts_nonchild, int32_t *local_counts_cumul,
+                       int32_t *particle_idx, int64_t *nlocal);
+
+/* modify_target_flags_kernel (distributed/local_tree.py:155-185): rebuilds
+ * BT_BOX_IS_TARGET_BOX / BT_BOX_HAS_TARGET_CHILD_BOXES from the local counts. */
+int bt_modify_target_flags(bt_context *ctx, int64_t nboxes, const int32_t *counts_nonchild,
+                           const int32_t *counts_cumul, uint8_t *box_flags);
+
+/* box_to_user_rank CSR (distributed/local_tree.py:368-399): masks is [nranks][nboxes]
+ * int8 (rank-major, as gathered); starts [nboxes+1]; with lists == NULL only starts
+ * and *nentries are produced, otherwise lists [*nentries] holds each box's user
+ * ranks ascending. */
+int bt_box_to_user_ranks(bt_context *ctx, int nranks, int64_t nboxes, const int8_t *masks,
+                         int32_t *starts, int32_t *lists, int64_t *nentries);
+
+/* find_boxes_used_by_subrange + compaction (distributed/calculation.py:191-262,
+ * 335-352): ascending list of the boxes with contributing[b] != 0 that have a user
+ * rank in [rank_lo, rank_hi).  boxes has capacity nboxes. */
+int bt_boxes_used_by_ranks(bt_context *ctx, int64_t nboxes, const int8_t *contributing,
+                           int rank_lo, int rank_hi, const int32_t *box_to_user_rank_starts,
+                           const int32_t *box_to_user_rank_lists, int32_t *boxes, int64_t *n);
+
 #ifdef __cplusplus
 }
 #endif

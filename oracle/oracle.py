@@ -1044,3 +1044,131 @@ def cost_model(tree, trav, level_to_order, calibration_params, taylor=False):
 # }}}
 
 # vim: foldmethod=marker
+
+
+# ---- distributed FMM evaluation: work partition and local trees ----------------------
+# (test infrastructure like everything in this file; plain Python/numpy loops)
+
+def dfs_order(tree):
+    """get_box_ids_dfs_order (boxtree/distributed/partition.py:39-57): explicit
+    stack, children pushed in ascending child number, hence popped descending."""
+    order = np.empty(tree.nboxes, dtype=np.int32)
+    idx = 0
+    stack = [0]
+    nchildren = 2 ** tree.dimensions
+    while stack:
+        b = stack.pop()
+        order[idx] = b
+        idx += 1
+        for c in range(nchildren):
+            ch = int(tree.box_child_ids[c][b])
+            if ch > 0:
+                stack.append(ch)
+    assert idx == tree.nboxes
+    return order
+
+
+def partition_work_segments(cost_per_box, order, nranks):
+    """The root-rank loop of partition_work (distributed/partition.py:92-116).
+    -> int32 [nranks, 2] of [start, end) depth-first positions; ranks the loop never
+    reaches (their rows stay uninitialised upstream) get [nboxes, nboxes)."""
+    nboxes = len(order)
+    if nranks > nboxes:
+        raise RuntimeError("fewer boxes than ranks")                       # :77-79
+    total = np.sum(cost_per_box)
+    seg = np.full((nranks, 2), nboxes, dtype=np.int32)
+    s = 0
+    start = 0
+    count = 0
+    for i in range(nboxes):
+        if s + 1 == nranks:
+            seg[s] = [start, nboxes]
+            break
+        count += cost_per_box[order[i]]
+        if count > (s + 1) * total / nranks or i == nboxes - 1:
+            seg[s] = [start, i + 1]
+            start = i + 1
+            s += 1
+    return seg
+
+
+def box_masks(tree, trav, responsible_boxes_list):
+    """get_box_masks (distributed/partition.py:301-357) -> dict of four int8 masks."""
+    nboxes = tree.nboxes
+    resp = np.zeros(nboxes, np.int8)
+    resp[responsible_boxes_list] = 1
+
+    anc = np.zeros(nboxes, np.int8)                                       # :167-188
+    last = resp.copy()
+    while last.any():
+        new = np.zeros(nboxes, np.int8)
+        for b in np.nonzero(last)[0]:
+            if b != 0:
+                new[tree.box_parent_ids[b]] = 1
+        new = new & ~anc.astype(bool)
+        anc = anc | new
+        last = new
+
+    def add(box_list, mask, starts, lists, out):                          # :134-164
+        for i, b in enumerate(box_list):
+            if mask[b]:
+                out[lists[starts[i]:starts[i + 1]]] = 1
+
+    both = resp | anc
+    psrc = resp.copy()                                                    # :191-245
+    add(trav.target_boxes, resp, trav.neighbor_source_boxes_starts,
+        trav.neighbor_source_boxes_lists, psrc)
+    add(trav.target_or_target_parent_boxes, both, trav.from_sep_bigger_starts,
+        trav.from_sep_bigger_lists, psrc)
+    if tree.targets_have_extent:
+        if trav.from_sep_close_smaller_starts is not None:
+            add(trav.target_boxes, resp, trav.from_sep_close_smaller_starts,
+                trav.from_sep_close_smaller_lists, psrc)
+        if trav.from_sep_close_bigger_starts is not None:
+            add(trav.target_boxes, both, trav.from_sep_close_bigger_starts,
+                trav.from_sep_close_bigger_lists, psrc)
+
+    msrc = np.zeros(nboxes, np.int8)                                      # :248-298
+    add(trav.target_or_target_parent_boxes, both, trav.from_sep_siblings_starts,
+        trav.from_sep_siblings_lists, msrc)
+    for ilevel in range(tree.nlevels):
+        ssn = trav.from_sep_smaller_by_level[ilevel]
+        add(trav.target_boxes_sep_smaller_by_source_level[ilevel], resp, ssn.starts,
+            ssn.lists, msrc)
+    return dict(responsible_boxes=resp, ancestor_boxes=anc, point_src_boxes=psrc,
+                multipole_src_boxes=msrc)
+
+
+def local_particles_and_lists(box_mask, starts, counts_nonchild, counts_cumul, nparticles):
+    """construct_local_particles_and_lists (distributed/local_tree.py:198-283), index
+    part.  -> (local_starts, local_counts_nonchild, local_counts_cumul, particle_idx)."""
+    pmask = np.zeros(nparticles, np.int32)
+    for b in np.nonzero(box_mask)[0]:
+        pmask[starts[b]:starts[b] + counts_nonchild[b]] = 1
+    scan = np.zeros(nparticles + 1, np.int64)
+    scan[1:] = np.cumsum(pmask)
+    lstarts = scan[starts]
+    lnonchild = np.where(box_mask, counts_nonchild, 0)
+    lcumul = scan[starts + counts_cumul] - scan[starts]
+    return (lstarts.astype(np.int32), lnonchild.astype(np.int32), lcumul.astype(np.int32),
+            np.nonzero(pmask)[0].astype(np.int32))
+
+
+def box_to_user_ranks(masks):
+    """Compressed [nranks, nboxes] multipole-user masks (local_tree.py:368-399)."""
+    nranks, nboxes = masks.shape
+    starts = np.zeros(nboxes + 1, np.int32)
+    lists = []
+    for b in range(nboxes):
+        users = [r for r in range(nranks) if masks[r, b]]
+        lists.extend(users)
+        starts[b + 1] = len(lists)
+    return starts, np.array(lists, dtype=np.int32)
+
+
+def modify_target_flags(box_flags, counts_nonchild, counts_cumul):
+    """modify_target_flags_kernel (local_tree.py:155-185)."""
+    f = box_flags & ~np.uint8(2 | 8)
+    f = f | np.where(counts_nonchild != 0, 2, 0).astype(np.uint8)
+    f = f | np.where(counts_nonchild < counts_cumul, 8, 0).astype(np.uint8)
+    return f.astype(np.uint8)

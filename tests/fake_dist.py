@@ -1,7 +1,7 @@
 """An in-process stand-in for ``torch.distributed`` (test infrastructure): the
 ranks are threads of one process sharing one GPU, collectives are implemented
 with a barrier and direct tensor copies.  Lets the complete N-rank pipeline of
-boxtree_amd/distributed.py run on a single-GPU box; RCCL itself is not involved."""
+boxtree_amd/distributed/__init__.py run on a single-GPU box; RCCL itself is not involved."""
 
 import threading
 
@@ -50,6 +50,20 @@ class FakeDist:
         res = {"sum": stack.sum(0), "min": stack.amin(0), "max": stack.amax(0)}[op]
         self._sync()
         t.copy_(res.to(t.dtype))
+
+    def broadcast(self, t, src=0):
+        self._w.slots[self._rank] = t
+        self._sync()
+        if self._rank != src:
+            t.copy_(self._w.slots[src])
+        self._sync()
+
+    def broadcast_object_list(self, objs, src=0):
+        self._w.slots[self._rank] = objs
+        self._sync()
+        if self._rank != src:
+            objs[:] = list(self._w.slots[src])
+        self._sync()
 
     def all_gather(self, out_list, t):
         self._w.slots[self._rank] = t

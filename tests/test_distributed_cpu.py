@@ -1,5 +1,5 @@
 """N>1 path on CPU: world_size-2 gloo run of the particle exchange that precedes
-the per-rank tree build (boxtree_amd/distributed.py).  No GPU needed."""
+the per-rank tree build (boxtree_amd/distributed/__init__.py).  No GPU needed."""
 
 import os
 import socket
