@@ -160,6 +160,7 @@ def main():
     stage_acc: dict[str, float] = {}
     sort_ms = []
     info = {}
+    last_exchange = {}
 
     def step():
         p_, t_, kw_ = particles, targets, build_kw
@@ -171,6 +172,7 @@ def main():
                 actx, dist, particles, targets, build_kw, max_particles_in_box=args.mpb)
             xinfo.update(exchange_bytes_sent_rank0=int(xs["bytes_sent"]),
                          owned_particles_rank0=int(len(p_[0])))
+            last_exchange["events"] = xs.get("a2a_events", [])
         tree, _ = tb(actx, p_, targets=t_, max_particles_in_box=args.mpb, **kw_)
         st = _lib.SortStats()
         actx.lib.bt_get_sort_stats(actx.handle, st)
@@ -237,6 +239,13 @@ def main():
     else:
         n_total = n_local
 
+    if rank == 0 and last_exchange.get("events"):
+        # payload all-to-all of the last step: every peer sits on its own xGMI link
+        a2a_ms = sum(e0.elapsed_time(e1) for e0, e1 in last_exchange["events"])
+        xinfo["exchange_a2a_ms_rank0"] = a2a_ms
+        if world > 1 and a2a_ms > 0:
+            xinfo["exchange_GBps_per_link_rank0"] = (
+                xinfo["exchange_bytes_sent_rank0"] / (world - 1) / (a2a_ms * 1e-3) / 1e9)
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = n_total * args.steps / elapsed
@@ -290,7 +299,12 @@ def main():
         }
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, args.mpb)
-        print(json.dumps(out))
+        # RCCL writes its banner through C stdio, which is block-buffered when stdout
+        # is a pipe: push it out first so that the JSON line is the last line
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
 

@@ -331,27 +331,23 @@ __device__ __forceinline__ int64_t find_path(const uint64_t *a, int64_t lo, int6
     return (l < hi && a[l] == key) ? l : -1;
 }
 
-// one thread per (box, child slot): parents and children by path lookup
+// one thread per box: the parent by path lookup in the level above; the box then
+// enters itself into its parent's child row (rows are cleared beforehand, a slot
+// nobody claims stays 0)
 template <int D>
 __global__ __launch_bounds__(256) void let_link_kernel(int32_t b0, int32_t b1, int32_t prev0,
-        int32_t next1, int64_t aligned, const uint64_t *paths, int32_t *parent_ids,
-        int32_t *child_ids, int32_t *missing_parent)
+        int64_t aligned, const uint64_t *paths, int32_t *parent_ids, int32_t *child_ids,
+        int32_t *missing_parent)
 {
     constexpr int C = 1 << D;
-    const int64_t t = (int64_t) blockIdx.x * 256 + threadIdx.x;
-    const int64_t g = t / C;
-    const int m = (int) (t % C);
-    if (g >= b1 - b0) return;
-    const int32_t b = b0 + (int32_t) g;
+    const int32_t b = b0 + (int32_t) (blockIdx.x * 256 + threadIdx.x);
+    if (b >= b1) return;
+    if (b == 0) { parent_ids[0] = 0; return; }
     const uint64_t p = paths[b];
-    const int64_t c = find_path(paths, b1, next1, (p << D) | (uint64_t) m);     // next level
-    child_ids[(int64_t) m * aligned + b] = c < 0 ? 0 : (int32_t) c;
-    if (m == 0) {
-        if (b == 0) { parent_ids[0] = 0; return; }
-        const int64_t par = find_path(paths, prev0, b0, p >> D);                // previous level
-        parent_ids[b] = par < 0 ? 0 : (int32_t) par;
-        if (par < 0) atomicExch(missing_parent, 1);
-    }
+    const int64_t par = find_path(paths, prev0, b0, p >> D);
+    parent_ids[b] = par < 0 ? 0 : (int32_t) par;
+    if (par < 0) { atomicExch(missing_parent, 1); return; }
+    child_ids[(int64_t) (p & (uint64_t) (C - 1)) * aligned + par] = b;
 }
 
 // child centre = parent centre +/- root_extent / 2^(1+level): the builder's own
@@ -384,13 +380,13 @@ int let_build_impl(bt_context *ctx, int nlevels, const int32_t *level_starts, co
     Buf<int32_t> d_missing;
     BT_CHECK(d_missing.alloc(ctx->pool, 1));
     BT_HIP_CHECK(hipMemsetAsync(d_missing.get(), 0, 4, ctx->stream));
+    BT_HIP_CHECK(hipMemsetAsync(child_ids, 0, (size_t) C * (size_t) aligned * 4, ctx->stream));
     for (int lev = 0; lev < nlevels; ++lev) {
         const int32_t b0 = level_starts[lev], b1 = level_starts[lev + 1];
         if (b1 <= b0) continue;
         const int32_t prev0 = lev > 0 ? level_starts[lev - 1] : 0;
-        const int32_t next1 = lev + 2 <= nlevels ? level_starts[lev + 2] : b1;
-        let_link_kernel<D><<<(unsigned) div_up((int64_t) (b1 - b0) * C, 256), 256, 0, ctx->stream>>>(
-            b0, b1, prev0, next1, aligned, paths, parent_ids, child_ids, d_missing.get());
+        let_link_kernel<D><<<(unsigned) div_up(b1 - b0, 256), 256, 0, ctx->stream>>>(
+            b0, b1, prev0, aligned, paths, parent_ids, child_ids, d_missing.get());
     }
     // root centre: tree_build.py:585-590
     T root[D];

@@ -258,40 +258,57 @@ def local_to_global_box_ids(tree, plan, global_level_starts, deep_base, bbox_min
 A2A_MESSAGE_LIMIT_BYTES = 512 << 20
 
 
-def all_to_all_chunked(dist, recv, send, r_split, s_split, limit_bytes=None):
+def all_to_all_chunked(dist, recv, send, r_split, s_split, limit_bytes=None,
+                       biggest_bytes=None):
     """``dist.all_to_all_single(recv, send, r_split, s_split)`` in as many rounds as
     it takes to keep every peer-to-peer message below *limit_bytes*.  Round k moves
     the k-th slice of every peer's segment; sender and receiver cut a segment of
-    length c at ``floor(k*c/R)``, so both sides agree without communicating."""
+    length c at ``floor(k*c/R)``, so both sides agree without communicating.  A
+    rank's segment for itself never enters the collective: it is one device copy.
+    *biggest_bytes*: the largest peer-to-peer message of ANY rank, if the caller
+    already knows it (saves the MAX all-reduce that agrees on the round count)."""
     import torch
     if limit_bytes is None:
         limit_bytes = A2A_MESSAGE_LIMIT_BYTES
     es = send.element_size()
-    biggest = max(max(s_split, default=0), max(r_split, default=0)) * es
-    # every rank must run the same number of rounds
-    t = torch.tensor([biggest], dtype=torch.int64, device=send.device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    biggest = int(t.item())
-    rounds = max(1, -(-biggest // limit_bytes))
-    if rounds == 1:
-        dist.all_to_all_single(recv, send, list(r_split), list(s_split))
-        return 1
+    me = dist.get_rank()
+    s_split, r_split = list(s_split), list(r_split)
     s_off = np.concatenate([[0], np.cumsum(s_split)]).astype(np.int64)
     r_off = np.concatenate([[0], np.cumsum(r_split)]).astype(np.int64)
+    assert s_split[me] == r_split[me]
+    s_peer, r_peer = list(s_split), list(r_split)
+    s_peer[me] = r_peer[me] = 0
+    biggest = max(max(s_peer, default=0), max(r_peer, default=0)) * es
+    # every rank must run the same number of rounds
+    if biggest_bytes is not None:
+        assert biggest_bytes >= biggest
+        biggest = int(biggest_bytes)
+    else:
+        t = torch.tensor([biggest], dtype=torch.int64, device=send.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        biggest = int(t.item())
+    rounds = max(1, -(-biggest // limit_bytes))
+    if rounds == 1 and s_split[me] * es <= limit_bytes:
+        dist.all_to_all_single(recv, send, r_split, s_split)
+        return 1
+    if s_split[me]:
+        recv[r_off[me]:r_off[me + 1]].copy_(send[s_off[me]:s_off[me + 1]])
+    if biggest == 0:
+        return 1
 
     def cut(c, k):
         return (k * int(c)) // rounds
 
     for k in range(rounds):
-        s_sub = [cut(c, k + 1) - cut(c, k) for c in s_split]
-        r_sub = [cut(c, k + 1) - cut(c, k) for c in r_split]
-        send_k = torch.cat([send[s_off[p] + cut(s_split[p], k):s_off[p] + cut(s_split[p], k + 1)]
-                            for p in range(len(s_split))])
+        s_sub = [cut(c, k + 1) - cut(c, k) for c in s_peer]
+        r_sub = [cut(c, k + 1) - cut(c, k) for c in r_peer]
+        send_k = torch.cat([send[s_off[p] + cut(s_peer[p], k):s_off[p] + cut(s_peer[p], k + 1)]
+                            for p in range(len(s_peer))])
         recv_k = torch.empty(int(sum(r_sub)), dtype=recv.dtype, device=recv.device)
         dist.all_to_all_single(recv_k, send_k, r_sub, s_sub)
         off = 0
-        for p in range(len(r_split)):
-            recv[r_off[p] + cut(r_split[p], k):r_off[p] + cut(r_split[p], k + 1)] = \
+        for p in range(len(r_peer)):
+            recv[r_off[p] + cut(r_peer[p], k):r_off[p] + cut(r_peer[p], k + 1)] = \
                 recv_k[off:off + r_sub[p]]
             off += r_sub[p]
     return rounds
@@ -311,8 +328,24 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
     target_radii = build_kw.get("target_radii")
     source_radii = build_kw.get("source_radii")
 
+    import os
+    import time
+    times = {} if os.environ.get("BOXTREE_HIP_EXCHANGE_TIMES") else None
+    t_last = [time.perf_counter()]
+
+    def tick(name):
+        # diagnostic only (BOXTREE_HIP_EXCHANGE_TIMES=1): synchronising sub-stage timer
+        if times is None:
+            return
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        now = time.perf_counter()
+        times[name] = times.get(name, 0.0) + 1e3 * (now - t_last[0])
+        t_last[0] = now
+
     bbox_min, bbox_max, root_extent = global_root_box(
         actx, dist, particles, targets, source_radii, target_radii)
+    tick("root box")
 
     if top_level is None:
         # enough cells for a balanced split, few enough for a tiny all-reduce
@@ -347,8 +380,10 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
     if targets is not None:
         tgt_cells, tgt_hist = cells_of(targets)
         hist = hist + tgt_hist
+    tick("cells")
     dist.all_reduce(hist)
     ghist = hist.cpu().numpy()
+    tick("hist allreduce")
     # With point particles and unit weights the top of the global tree follows from
     # the histogram alone: ownership respects its leaves and the local builds split
     # the shared top boxes where the global tree does (TreeBuilder ``_top_tree``).
@@ -359,6 +394,7 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         plan = top_tree_plan(ghist, dims, top_level, max_particles_in_box)
     owner = partition_cells(ghist, world, None if plan is None else plan["unit_start"])
     owner_t = torch.from_numpy(owner).to(dev)
+    tick("plan (host)")
 
     stats = {"bytes_sent": 0, "top_level": top_level}
 
@@ -393,13 +429,28 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
             ct.c_void_p(order.data_ptr()), len(a), ct.c_void_p(out.data_ptr())))
         return out
 
+    def timed_a2a(recv, send, r_split, s_split):
+        # device time of the payload collectives, for the per-link rate bench.py
+        # reports (events on the stream the collective is enqueued on; resolved by
+        # the caller after its own synchronisation)
+        if dev.type != "cuda":
+            all_to_all_chunked(dist, recv, send, r_split, s_split)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        all_to_all_chunked(dist, recv, send, r_split, s_split)
+        e1.record()
+        stats.setdefault("a2a_events", []).append((e0, e1))
+
     def route(arrs, cells, local_hist, extra, keep_interleaved=False):
         """all-to-all-v of the coordinate arrays (+ extras) by owner of `cells`."""
         order, send_counts = send_order(cells, local_hist)
+        tick("bucket")
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts)
         s_split = send_counts.cpu().tolist()
         r_split = recv_counts.cpu().tolist()
+        tick("counts a2a")
         nrecv = int(sum(r_split))
         outs = []
         d_ = len(arrs)
@@ -416,8 +467,10 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
             _lib.check(actx.lib.bt_gather_pack(
                 actx.handle, d, es, ptrs, ct.c_void_p(order.data_ptr()), n,
                 ct.c_void_p(send.data_ptr())))
+            tick("pack")
             recv = torch.empty(nrecv * d, dtype=arrs[0].dtype, device=dev)
-            all_to_all_chunked(dist, recv, send, [r * d for r in r_split], [c * d for c in s_split])
+            timed_a2a(recv, send, [r * d for r in r_split], [c * d for c in s_split])
+            tick("payload a2a")
             if keep_interleaved:
                 # the tree build reads the receive buffer in place
                 # (bt_tree_params.source_stride): no unpacking pass
@@ -435,7 +488,7 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         for a in rest:
             send = take(a.contiguous(), order)
             recv = torch.empty(nrecv, dtype=a.dtype, device=dev)
-            all_to_all_chunked(dist, recv, send, r_split, s_split)
+            timed_a2a(recv, send, r_split, s_split)
             outs.append(recv)
             stats["bytes_sent"] += (len(a) - s_split[rank]) * a.element_size()
         return outs[:len(arrs)], outs[len(arrs):]
@@ -466,6 +519,9 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
     stats["bbox_min"], stats["bbox_max"] = bbox_min, bbox_max
     stats["root_extent"] = root_extent
     stats["owner"] = owner
+    if times is not None:
+        tick("rest")
+        stats["times_ms"] = times
     return new_particles, new_targets, build_kw, stats
 
 
@@ -678,6 +734,19 @@ def build_local_essential_tree(actx, dist, tree, stats, numbering, well_sep_is_n
     root_extent = stats["root_extent"]
     kind = _lib.BT_F64 if coord_dtype == np.float64 else _lib.BT_F32
 
+    import os
+    import time
+    times = {} if os.environ.get("BOXTREE_HIP_EXCHANGE_TIMES") else None
+    t_last = [time.perf_counter()]
+
+    def tick(name):     # diagnostic only, see exchange_particles
+        if times is None:
+            return
+        torch.cuda.synchronize()
+        now = time.perf_counter()
+        times[name] = times.get(name, 0.0) + 1e3 * (now - t_last[0])
+        t_last[0] = now
+
     # -- Morton paths of my boxes ------------------------------------------------------
     paths = torch.empty(nb, dtype=torch.int64, device=dev)
     bmin = (ct.c_double * 3)(*[float(v) for v in bbox_min], *([0.0] * (3 - dims)))
@@ -690,6 +759,7 @@ def build_local_essential_tree(actx, dist, tree, stats, numbering, well_sep_is_n
     deep = levels > k
     gids = numbering["box_ids"]
     meta = levels.to(torch.int32) | (tree.box_flags[:nb].to(torch.int32) << 8)
+    tick("paths+meta")
 
     # -- halo: my deep boxes in the cells other ranks' lists can reach -----------------------
     need = _cells_needed_by(stats["owner"], dims, k, rank, world, int(well_sep_is_n_away),
@@ -706,18 +776,32 @@ def build_local_essential_tree(actx, dist, tree, stats, numbering, well_sep_is_n
         send_idx.append(sel)
         s_split.append(int(sel.shape[0]))
     send_idx = torch.cat(send_idx) if send_idx else deep_idx[:0]
-    counts = torch.tensor(s_split, dtype=torch.int64, device=dev)
+    # one record per box: (path, level | flags << 8 | global id << 32).  The counts
+    # exchange also carries every rank's largest message, so all ranks know the
+    # round count of the payload exchange without a further collective.
+    rec_bytes = 16
+    counts = torch.tensor([[c, max(s_split) * rec_bytes] for c in s_split], dtype=torch.int64,
+                          device=dev).reshape(-1)
     rcounts = torch.empty_like(counts)
     dist.all_to_all_single(rcounts, counts)
-    r_split = [int(c) for c in rcounts.cpu().tolist()]
+    rc = rcounts.cpu().numpy().reshape(world, 2)
+    r_split = [int(c) for c in rc[:, 0]]
+    biggest = int(max(rc[:, 1].max(), max(s_split) * rec_bytes))
     nrecv = sum(r_split)
-
-    def route(t):
-        out = torch.empty(nrecv, dtype=t.dtype, device=dev)
-        all_to_all_chunked(dist, out, t[send_idx].contiguous(), r_split, s_split)
-        return out
-
-    h_paths, h_meta, h_gids = route(paths), route(meta), route(gids.to(torch.int32))
+    h_paths = paths[:0]
+    h_meta = meta[:0]
+    h_gids = gids[:0].to(torch.int32)
+    if biggest:
+        rec = torch.stack([paths[send_idx],
+                           meta[send_idx].long() | (gids[send_idx].long() << 32)], dim=1)
+        got = torch.empty(nrecv * 2, dtype=torch.int64, device=dev)
+        all_to_all_chunked(dist, got, rec.reshape(-1), [2 * c for c in r_split],
+                           [2 * c for c in s_split], biggest_bytes=biggest)
+        got = got.view(nrecv, 2)
+        h_paths = got[:, 0]
+        h_meta = (got[:, 1] & 0xffffffff).to(torch.int32)
+        h_gids = (got[:, 1] >> 32).to(torch.int32)
+    tick("halo exchange")
 
     # -- the box set: top levels from the plan, my deep boxes, the halo ------------------------
     owner = np.asarray(stats["owner"], dtype=np.int64)
@@ -746,6 +830,7 @@ def build_local_essential_tree(actx, dist, tree, stats, numbering, well_sep_is_n
     nd = int(d_paths.shape[0])
     n_mine = int(deep_idx.shape[0])
     d_lev = (d_meta & 0xff).long()
+    tick("concat")
     # order the deep boxes by (level, Morton path): a stable sort by the path
     # left-aligned to the deepest level (ancestors tie with their first
     # descendants), then a stable one-digit sort by level
@@ -768,6 +853,7 @@ def build_local_essential_tree(actx, dist, tree, stats, numbering, well_sep_is_n
             actx.handle, ct.c_void_p(lev_key.data_ptr()), ct.c_void_p(order1.data_ptr()),
             ct.c_void_p(lev_out.data_ptr()), ct.c_void_p(order.data_ptr()), nd, 0, 8))
     order = order.long()
+    tick("sort")
     s_paths, s_meta, s_gid = d_paths[order], d_meta[order], d_gid[order]
     s_mine = order < n_mine
     s_lev = (s_meta & 0xff).long()
@@ -791,6 +877,7 @@ def build_local_essential_tree(actx, dist, tree, stats, numbering, well_sep_is_n
         mpos_h = mpos[ends].cpu().numpy()
         first_h, last_h = mpos_h[0], mpos_h[1]
     ranges = np.zeros((nlev, 2), dtype=np.int32)
+    tick("reorder+bounds")
     level_starts = [0]
     ntop = int(sum(top_counts))
     deep_off = 0
@@ -817,9 +904,10 @@ def build_local_essential_tree(actx, dist, tree, stats, numbering, well_sep_is_n
     all_meta = torch.cat(lvl_meta)
     let_gid = torch.cat(lvl_gid).contiguous()
     mask = torch.cat(lvl_mine).to(torch.int8).contiguous()
+    tick("assemble")
 
     parents = torch.zeros(B, dtype=torch.int32, device=dev)
-    children = torch.zeros((C, aligned), dtype=torch.int32, device=dev)
+    children = torch.empty((C, aligned), dtype=torch.int32, device=dev)   # cleared by bt_let_build
     centers = torch.zeros((dims, aligned), dtype=coord_t, device=dev)
     lsb = np.asarray(level_starts, dtype=np.int32)
     bmax = (ct.c_double * 3)(*[float(v) for v in bbox_max], *([0.0] * (3 - dims)))
@@ -836,9 +924,12 @@ def build_local_essential_tree(actx, dist, tree, stats, numbering, well_sep_is_n
         box_id_dtype=np.dtype(np.int32), box_level_dtype=np.dtype(np.uint8),
         coord_dtype=coord_dtype, sources_have_extent=False, targets_have_extent=False,
         extent_norm=None, stick_out_factor=tree.stick_out_factor, _is_pruned=True)
+    tick("links")
     info = dict(target_boxes_mask=mask, active_level_ranges=ranges, global_box_ids=let_gid,
                 halo_boxes_received=nrecv, halo_boxes_sent=int(send_idx.shape[0]),
                 nboxes=B)
+    if times is not None:
+        info["times_ms"] = times
     return let, info
 
 # }}}

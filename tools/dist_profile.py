@@ -39,6 +39,7 @@ for it in range(3):
     t2 = T()
     num = number_sharded_tree(dist, tree, st)
     t3 = T()
+    let = None
     if os.environ.get("BOXTREE_HIP_SHARDED", "let") == "gather":
         gt = gather_global_box_tree(actx, dist, tree, num)
         mask, ranges = num["target_boxes_mask"], num["active_level_ranges"]
@@ -48,6 +49,10 @@ for it in range(3):
     t4 = T()
     trav, _ = tg(actx, gt, _target_boxes_mask=mask, _active_level_ranges=ranges)
     t5 = T()
+    if "times_ms" in st:
+        print("   exchange:", "  ".join(f"{k} {v:.2f}" for k, v in st["times_ms"].items()))
+    if "times_ms" in let if isinstance(let, dict) else False:
+        print("   LET:", "  ".join(f"{k} {v:.2f}" for k, v in let["times_ms"].items()))
     print(f"exchange {1e3*(t1-t0):.2f}  build {1e3*(t2-t1):.2f}  number {1e3*(t3-t2):.2f}  "
           f"LET/gather {1e3*(t4-t3):.2f}  traversal {1e3*(t5-t4):.2f}  total {1e3*(t5-t0):.2f} ms")
 dist.destroy_process_group()
