@@ -17,21 +17,46 @@ void set_error(const char *fmt, ...)
     g_last_error = buf;
 }
 
-int Pool::alloc(void **out, size_t bytes)
+// Requests are rounded up to a size class (16 classes per power of two, at most
+// 6.25 % over the request) and a cached block is reused only for its own class.
+// The builders ask for the same sizes in the same order on every call, so after
+// one repetition every class holds as many blocks as are ever live at once and no
+// call reaches hipMalloc again.  (A best-fit search with a tolerance instead lets a
+// request take a block that a later, larger request needs, which then allocates --
+// a cascade that costs a multi-millisecond hipMalloc per step for many steps.)
+static size_t size_class(size_t bytes)
 {
     bytes = (bytes + 255) & ~(size_t) 255;
-    // best fit among free blocks
-    int best = -1;
-    for (int i = 0; i < (int) blocks_.size(); ++i) {
-        const Block &b = blocks_[i];
-        if (!b.used && b.size >= bytes && (best < 0 || b.size < blocks_[best].size))
-            best = i;
-    }
-    // accept a cached block only if it wastes < 2x
-    if (best >= 0 && blocks_[best].size <= 2 * bytes + (1 << 20)) {
-        blocks_[best].used = true;
-        *out = blocks_[best].ptr;
-        return BT_OK;
+    int bits = 0;
+    for (size_t v = bytes; v; v >>= 1) ++bits;
+    if (bits <= 12) return bytes;
+    const int shift = bits - 5;
+    return ((bytes + ((size_t) 1 << shift) - 1) >> shift) << shift;
+}
+
+int Pool::alloc(void **out, size_t bytes)
+{
+    bytes = size_class(bytes);
+    for (auto &b : blocks_)
+        if (!b.used && b.size == bytes) {
+            b.used = true;
+            *out = b.ptr;
+            return BT_OK;
+        }
+    // a new block is needed.  If the idle blocks (left over from calls with other
+    // sizes) outweigh what is in use, give them back first so that a long-lived
+    // context does not hoard memory other allocators in the process could use.
+    {
+        size_t idle = 0, busy = bytes;
+        for (auto &b : blocks_) (b.used ? busy : idle) += b.size;
+        if (idle > 2 * busy + ((size_t) 1 << 30)) {
+            std::vector<Block> keep;
+            for (auto &b : blocks_) {
+                if (b.used) keep.push_back(b);
+                else { (void) hipFree(b.ptr); reserved_ -= b.size; }
+            }
+            blocks_.swap(keep);
+        }
     }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
