@@ -4,10 +4,14 @@ Python front-end of the CPU oracle (``oracle/boxtree_oracle.c``): a restatement
 of inducer/boxtree's ``TreeBuilder.__call__`` (boxtree/tree_build.py:145-1878)
 and ``FMMTraversalBuilder.__call__`` (boxtree/traversal.py:1969-2345).
 
-PARITY UNPINNED: the reference cannot be imported here (pyopencl, arraycontext,
-pytools, mako are absent, no OpenCL device) and its tests hold no golden
-vectors; this restatement is validated against the invariants the reference's
-tests assert (tests/test_oracle_invariants.py).
+PARITY UNPINNED for the kernels: the reference's OpenCL path cannot be imported
+here (pyopencl, arraycontext, pytools, mako are absent, no OpenCL device) and its
+tests hold no golden vectors; this restatement is validated against the invariants
+the reference's tests assert (tests/test_oracle_invariants.py).  The plain-Python
+parts of the reference DO run here: tests/golden/make_reference_vectors.py runs
+its drive_fmm + constant-one wrangler on this oracle's trees and lists, and its
+depth-first order / work partition / communication pattern / rotation-class code,
+and tests/test_reference_vectors.py holds the restatements below to those outputs.
 
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this module.  The host-side numpy arithmetic (root box, argument

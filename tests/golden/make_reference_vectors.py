@@ -1,0 +1,294 @@
+#!/usr/bin/env python
+"""Generates tests/golden/reference_vectors.npz by RUNNING the reference.
+
+Most of the reference cannot run in the build container: its kernels are OpenCL
+inside Mako templates and pyopencl / arraycontext / pytools are absent (DESIGN.md
+section 2).  A few pieces are plain Python + numpy, though, and those are executed
+here, unmodified, from the files under /root/reference (which never travel to the
+GPU box -- only the vectors written by this script do):
+
+* ``boxtree.fmm.drive_fmm`` with ``boxtree.constant_one.ConstantOneExpansionWrangler``
+  (fmm.py:342-532, constant_one.py:49-237) -- the reference's own consumer of a tree
+  and its interaction lists.  It is run on the trees and traversals the CPU oracle
+  builds for the cases of make_golden.py, with unit and with random weights, and
+  the result of every stage is stored.  That the reference's consumer, reading
+  the oracle's arrays by the reference's conventions, gives every target the total
+  source weight is the acceptance test of test/test_fmm.py:141-391.
+* ``AllReduceCommPattern`` (tools.py:756-855).
+* ``get_box_ids_dfs_order`` and the root-rank loop of ``partition_work``
+  (distributed/partition.py:39-121), run with a stand-in communicator object that
+  records what ``Scatter`` hands to every rank.
+* ``RotationClassesBuilder.vec_gcd / compute_rotation_classes`` and
+  ``TranslationClassesBuilder.ntranslation_classes_per_level /
+  translation_class_to_normalized_vector`` (rotation_classes.py:102-162,
+  translation_classes.py:302-322).
+
+How they are loaded: ``boxtree.fmm`` and ``boxtree.constant_one`` are imported as
+modules (a bare ``boxtree`` package object keeps ``boxtree/__init__.py``, which needs
+pyopencl, from running; the one absent import they make, ``pytools.ProcessLogger``,
+is a progress logger and is given a no-op here).  The other pieces live in modules
+whose top-level imports need pyopencl/mako, so their function and class definitions
+are compiled on their own from the parsed source file and executed with numpy as
+the only global.  Nothing of the reference's text is written to the repository.
+
+    python tests/golden/make_reference_vectors.py     # needs /root/reference
+"""
+import ast
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+OUT = os.path.join(HERE, "reference_vectors.npz")
+
+
+# {{{ loading reference code
+
+def definitions(relpath, names, inside=None):
+    """Compiles the named top-level definitions of a reference file (or, with
+    *inside*, the named methods of that class, as plain functions)."""
+    path = os.path.join(REF, relpath)
+    tree = ast.parse(open(path).read(), filename=path)
+    body = tree.body
+    if inside is not None:
+        body = next(n for n in body if isinstance(n, ast.ClassDef) and n.name == inside).body
+    picked = [n for n in body
+              if isinstance(n, (ast.FunctionDef, ast.ClassDef)) and n.name in names]
+    assert sorted(n.name for n in picked) == sorted(names), (relpath, names)
+    for n in picked:
+        if isinstance(n, ast.FunctionDef):
+            n.decorator_list = []          # @staticmethod / @log_process
+            n.returns = None
+            for a in n.args.args + n.args.kwonlyargs:
+                a.annotation = None
+    ns = {"np": np}
+    exec(compile(ast.Module(body=picked, type_ignores=[]), path, "exec"), ns)
+    return [ns[name] for name in names]
+
+
+def import_fmm_and_constant_one():
+    pkg = types.ModuleType("boxtree")
+    pkg.__path__ = [os.path.join(REF, "boxtree")]
+    sys.modules["boxtree"] = pkg
+
+    class ProcessLogger:                   # pytools' progress logger: logging only
+        def __init__(self, *args, **kwargs):
+            pass
+
+        def done(self, *args, **kwargs):
+            pass
+
+    pytools = types.ModuleType("pytools")
+    pytools.ProcessLogger = ProcessLogger
+    sys.modules["pytools"] = pytools
+    sys.dont_write_bytecode = True
+    import boxtree.constant_one as constant_one
+    import boxtree.fmm as fmm
+    return fmm, constant_one
+
+# }}}
+
+
+# {{{ drive_fmm + ConstantOneExpansionWrangler on the oracle's trees
+
+def fmm_vectors(out):
+    import make_golden as mg
+    from oracle import oracle
+    oracle.build_lib()
+    fmm, constant_one = import_fmm_and_constant_one()
+
+    class Recording(constant_one.ConstantOneExpansionWrangler):
+        """Stores what each stage returns (the stage code itself is the reference's)."""
+        def __init__(self, tree_indep, traversal):
+            super().__init__(tree_indep, traversal)
+            self.stages = {}
+
+    def record(name):
+        base = getattr(constant_one.ConstantOneExpansionWrangler, name)
+
+        def method(self, *args, **kwargs):
+            result = base(self, *args, **kwargs)
+            n = sum(k.startswith(name) for k in self.stages)
+            self.stages[f"{name}_{n}"] = np.array(result, copy=True)
+            return result
+        return method
+
+    for name in ("form_multipoles", "coarsen_multipoles", "eval_direct", "multipole_to_local",
+                 "eval_multipoles", "form_locals", "refine_locals", "eval_locals"):
+        setattr(Recording, name, record(name))
+
+    for name, case in mg.CASES.items():
+        _inp, tree, trav = mg.build(oracle, case)
+        trav.tree = tree
+        rng = np.random.default_rng(1000 + case["seed"])
+        for label, weights in (("ones", np.ones(tree.nsources)),
+                               ("rand", rng.integers(1, 1000, tree.nsources).astype(np.float64))):
+            wrangler = Recording(constant_one.ConstantOneTreeIndependentDataForWrangler(), trav)
+            pot = fmm.drive_fmm(None, wrangler, [weights])
+            # the reference's acceptance criterion (test/test_fmm.py:384-391)
+            assert np.all(pot == weights.sum()), (name, label)
+            out[f"fmm/{name}/{label}/weights"] = weights
+            out[f"fmm/{name}/{label}/potentials"] = pot
+            for k, v in wrangler.stages.items():
+                out[f"fmm/{name}/{label}/{k}"] = v
+        print(f"drive_fmm + ConstantOneExpansionWrangler on oracle case {name}: "
+              f"potentials == total weight at all {tree.ntargets} targets")
+
+# }}}
+
+
+# {{{ AllReduceCommPattern
+
+def comm_pattern_vectors(out):
+    cls, = definitions("boxtree/tools.py", ["AllReduceCommPattern"])
+    sizes = list(range(1, 41)) + [64, 100]
+    rows = []            # size, rank, stage, sink, nsources, source0, source1, msg_lo, msg_hi
+    for size in sizes:
+        for rank in range(size):
+            pat = cls(rank, size)
+            stage = 0
+            while not pat.done():
+                sinks, sources = sorted(pat.sinks()), sorted(pat.sources())
+                lo, hi = pat.messages()
+                assert len(sinks) == 1 and len(sources) <= 2
+                rows.append([size, rank, stage, sinks[0], len(sources),
+                             sources[0] if sources else -1,
+                             sources[1] if len(sources) > 1 else -1, lo, hi])
+                pat.advance()
+                stage += 1
+    out["comm_pattern/rows"] = np.array(rows, dtype=np.int32)
+    print(f"AllReduceCommPattern: {len(rows)} (size, rank, stage) rows")
+
+# }}}
+
+
+# {{{ depth-first order and partition_work
+
+class _Comm:
+    """Stands in for the MPI communicator: rank 0 of *size*; keeps what Scatter sends."""
+    def __init__(self, size):
+        self.size = size
+        self.scattered = None
+
+    def Get_rank(self):
+        return 0
+
+    def Get_size(self):
+        return self.size
+
+    def Scatter(self, sendbuf, recvbuf, root=0):
+        self.scattered = np.array(sendbuf, copy=True)
+        recvbuf[:] = sendbuf[0]
+
+
+def partition_vectors(out):
+    from types import SimpleNamespace
+
+    from oracle import oracle
+    oracle.build_lib()
+    dfs, part = definitions("boxtree/distributed/partition.py",
+                            ["get_box_ids_dfs_order", "partition_work"])
+    part.__globals__["get_box_ids_dfs_order"] = dfs
+    idx = 0
+    for dims, n, mpb, seed in ((2, 300, 5, 1), (3, 2000, 10, 2), (3, 500, 3, 3), (2, 40, 1, 4)):
+        rng = np.random.default_rng(seed)
+        pts = [rng.standard_normal(n) for _ in range(dims)]
+        tree = oracle.build_tree(pts, max_particles_in_box=mpb)
+        rtree = SimpleNamespace(nboxes=tree.nboxes, dimensions=dims,
+                                box_id_dtype=np.dtype(np.int32),
+                                box_child_ids=tree.box_child_ids)
+        order = dfs(rtree)
+        trav = SimpleNamespace(tree=rtree)
+        costs = {
+            "random": rng.integers(0, 100, tree.nboxes).astype(np.float64),
+            "ones": np.ones(tree.nboxes),
+            "float": rng.random(tree.nboxes) * 3.7,
+            "one_hot_last": np.eye(1, tree.nboxes, int(order[-1]))[0] * 9.0,
+            "few": np.where(rng.random(tree.nboxes) < 0.01, 500.0, 0.0),
+        }
+        out[f"partition/{idx}/box_child_ids"] = tree.box_child_ids[:, :tree.nboxes]
+        out[f"partition/{idx}/dims"] = np.array(dims)
+        out[f"partition/{idx}/dfs_order"] = order
+        for cname, cost in costs.items():
+            out[f"partition/{idx}/cost/{cname}"] = cost
+            for size in (1, 2, 3, 4, 7, 16):
+                # segments left unassigned by the loop stay uninitialised upstream:
+                # pre-fill what np.empty hands out so that they are recognisable
+                comm = _Comm(size)
+                mine = part(cost, trav, comm)
+                seg = comm.scattered.astype(np.int64)
+                assert np.array_equal(mine, order[seg[0, 0]:seg[0, 1]])
+                # rows the loop wrote: all up to the last one with a plausible range
+                written = 0
+                start = 0
+                for s in range(size):
+                    if seg[s, 0] == start and start <= seg[s, 1] <= tree.nboxes and (
+                            seg[s, 1] > seg[s, 0]):
+                        written = s + 1
+                        start = seg[s, 1]
+                    else:
+                        break
+                out[f"partition/{idx}/segments/{cname}/{size}"] = seg[:written].astype(np.int32)
+        idx += 1
+    out["partition/ncases"] = np.array(idx)
+    print(f"get_box_ids_dfs_order / partition_work: {idx} trees")
+
+# }}}
+
+
+# {{{ translation / rotation class arithmetic
+
+def class_vectors(out):
+    from types import SimpleNamespace
+    nper, tovec = definitions("boxtree/translation_classes.py",
+                              ["ntranslation_classes_per_level",
+                               "translation_class_to_normalized_vector"],
+                              inside="TranslationClassesBuilder")
+    vec_gcd, compute = definitions("boxtree/rotation_classes.py",
+                                   ["vec_gcd", "compute_rotation_classes"],
+                                   inside="RotationClassesBuilder")
+    tcb = SimpleNamespace(ntranslation_classes_per_level=nper)
+    tcb.translation_class_to_normalized_vector = lambda n, d, c: tovec(tcb, n, d, c)
+    rcb = SimpleNamespace(tcb=tcb, vec_gcd=vec_gcd)
+    for nway in (1, 2, 3):
+        for dims in (2, 3):
+            ncls = nper(nway, dims)
+            vecs = np.array([tovec(tcb, nway, dims, c) for c in range(ncls)])
+            # the classes list 2 can produce: not adjacent, within 2n+1 boxes
+            used = [c for c in range(ncls)
+                    if np.max(np.abs(vecs[c])) > nway and np.max(np.abs(vecs[c])) <= 2 * nway + 1]
+            rng = np.random.default_rng(nway * 10 + dims)
+            some = sorted(rng.choice(used, size=max(1, len(used) // 3), replace=False).tolist())
+            out[f"classes/{nway}_{dims}/vectors"] = vecs.astype(np.int32)
+            for label, sel in (("all", used), ("some", some)):
+                to_rot, angles = compute(rcb, nway, dims, sel)
+                out[f"classes/{nway}_{dims}/{label}/used"] = np.array(sel, dtype=np.int32)
+                out[f"classes/{nway}_{dims}/{label}/to_rot_class"] = to_rot
+                out[f"classes/{nway}_{dims}/{label}/angles"] = np.array(angles, np.float64)
+    print("translation / rotation class arithmetic: n-away 1..3, 2D and 3D")
+
+# }}}
+
+
+def main():
+    if not os.path.isdir(REF):
+        raise SystemExit("needs the reference checkout at /root/reference")
+    out = {}
+    comm_pattern_vectors(out)
+    partition_vectors(out)
+    class_vectors(out)
+    fmm_vectors(out)
+    np.savez_compressed(OUT, **out)
+    print(f"{len(out)} arrays -> {OUT} ({os.path.getsize(OUT) / 1e6:.2f} MB)")
+
+
+if __name__ == "__main__":
+    main()

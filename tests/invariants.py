@@ -336,3 +336,74 @@ def constant_one_potentials(tree, trav, filtered_user=None, filtered_tree=None):
         filled[s:e] = True
     assert filled.all()
     return pot
+
+
+def constant_one_stages(tree, trav, weights):
+    """drive_fmm (boxtree/fmm.py:342-532) with the constant-one wrangler
+    (boxtree/constant_one.py:50-237), *weights* in user source order, returning what
+    every stage returns, keyed like tests/golden/make_reference_vectors.py keys the
+    reference's own run: ``<stage>_<call number>``, plus ``weights``/``potentials``."""
+    nb = tree.nboxes
+    w = np.asarray(weights, np.float64)[tree.user_source_ids]
+    out = {"weights": np.asarray(weights, np.float64)}
+    starts, cnt = tree.box_source_starts, tree.box_source_counts_nonchild
+    box_w = np.array([w[starts[b]:starts[b] + cnt[b]].sum() for b in range(nb)])
+
+    def rows(st, li, values):
+        return np.array([values[li[st[i]:st[i + 1]]].sum() for i in range(len(st) - 1)])
+
+    def to_targets(boxes, per_box):
+        pot = np.zeros(tree.ntargets)
+        for v, b in zip(per_box, boxes):
+            s = tree.box_target_starts[b]
+            pot[s:s + tree.box_target_counts_nonchild[b]] += v
+        return pot
+
+    mpoles = np.zeros(nb)
+    mpoles[trav.source_boxes] += box_w[trav.source_boxes]
+    out["form_multipoles_0"] = mpoles.copy()
+    lsp = trav.level_start_source_parent_box_nrs
+    for source_level in range(tree.nlevels - 1, 2, -1):
+        start, stop = lsp[source_level - 1:source_level + 1]
+        for ibox in trav.source_parent_boxes[start:stop]:
+            ch = tree.box_child_ids[:, ibox]
+            mpoles[ibox] += mpoles[ch[ch != 0]].sum()
+    out["coarsen_multipoles_0"] = mpoles.copy()
+
+    ndirect = 0
+
+    def direct(st, li):
+        nonlocal ndirect
+        out[f"eval_direct_{ndirect}"] = to_targets(trav.target_boxes, rows(st, li, box_w))
+        ndirect += 1
+        return out[f"eval_direct_{ndirect - 1}"]
+
+    pot = direct(trav.neighbor_source_boxes_starts, trav.neighbor_source_boxes_lists)
+    ttp = trav.target_or_target_parent_boxes
+    local = np.zeros(nb)
+    local[ttp] += rows(trav.from_sep_siblings_starts, trav.from_sep_siblings_lists, mpoles)
+    out["multipole_to_local_0"] = local.copy()
+    m2p = np.zeros(tree.ntargets)
+    for level, ssn in enumerate(trav.from_sep_smaller_by_level):
+        m2p += to_targets(trav.target_boxes_sep_smaller_by_source_level[level],
+                          rows(ssn.starts, ssn.lists, mpoles))
+    out["eval_multipoles_0"] = m2p
+    pot = pot + m2p
+    if trav.from_sep_close_smaller_starts is not None:
+        pot = pot + direct(trav.from_sep_close_smaller_starts, trav.from_sep_close_smaller_lists)
+    p2l = np.zeros(nb)
+    p2l[ttp] += rows(trav.from_sep_bigger_starts, trav.from_sep_bigger_lists, box_w)
+    out["form_locals_0"] = p2l
+    local = local + p2l
+    if trav.from_sep_close_bigger_starts is not None:
+        pot = pot + direct(trav.from_sep_close_bigger_starts, trav.from_sep_close_bigger_lists)
+    ltt = trav.level_start_target_or_target_parent_box_nrs
+    for target_lev in range(1, tree.nlevels):
+        start, stop = ltt[target_lev:target_lev + 2]
+        boxes = ttp[start:stop]
+        local[boxes] += local[tree.box_parent_ids[boxes]]
+    out["refine_locals_0"] = local.copy()
+    out["eval_locals_0"] = to_targets(trav.target_boxes, local[trav.target_boxes])
+    pot = pot + out["eval_locals_0"]
+    out["potentials"] = pot[tree.sorted_target_ids]
+    return out
