@@ -14,7 +14,8 @@ sys.path.insert(0, os.path.join(HERE, "golden"))
 import make_golden as mg  # noqa: E402
 
 NAMES = sorted(os.path.splitext(os.path.basename(f))[0]
-               for f in glob.glob(os.path.join(HERE, "golden", "*.npz")))
+               for f in glob.glob(os.path.join(HERE, "golden", "*.npz"))
+               if os.path.basename(f) != "reference_vectors.npz")   # test_reference_vectors.py
 
 
 def compare_with_fixture(name, inp, tree, trav):
