@@ -983,8 +983,16 @@ def _xlat_costs(dims, nlevels, level_to_order, params, taylor=False):
 def cost_model(tree, trav, level_to_order, calibration_params, taylor=False):
     """_PythonFMMCostModel (cost.py:1264-1440) driven by cost_per_box / cost_per_stage
     (:445-624).  -> (cost_per_box [nboxes], cost_per_stage dict)."""
+    tc = _xlat_costs(tree.dimensions, tree.nlevels, level_to_order, calibration_params, taylor)
+    per_box, per_stage, _ = cost_model_from_factors(tree, trav, tc)
+    return per_box, per_stage
+
+
+def cost_model_from_factors(tree, trav, tc):
+    """The per-stage loops of _PythonFMMCostModel (cost.py:1264-1424) for given
+    per-level translation costs *tc*.  -> (per_box, per_stage, pieces), *pieces* keyed
+    by the reference's method names."""
     nlevels = tree.nlevels
-    tc = _xlat_costs(tree.dimensions, nlevels, level_to_order, calibration_params, taylor)
     nsrc = tree.box_source_counts_nonchild
     ntgt = tree.box_target_counts_nonchild
     levels = tree.box_levels
@@ -1043,7 +1051,13 @@ def cost_model(tree, trav, level_to_order, calibration_params, taylor=False):
         "eval_multipoles": nm2p.sum(), "form_locals": np2l.sum(),
         "refine_locals": refine, "eval_locals": nl2p.sum(),
     }
-    return per_box, per_stage
+    pieces = {
+        "process_form_multipoles": np2m, "get_ndirect_sources_per_target_box": ndirect,
+        "process_direct": direct, "process_list2": nm2l, "process_list3": nm2p,
+        "process_list4": np2l, "process_eval_locals": nl2p,
+        "process_coarsen_multipoles": coarsen, "process_refine_locals": refine,
+    }
+    return per_box, per_stage, pieces
 
 # }}}
 

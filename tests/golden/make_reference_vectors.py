@@ -18,6 +18,9 @@ GPU box -- only the vectors written by this script do):
 * ``get_box_ids_dfs_order`` and the root-rank loop of ``partition_work``
   (distributed/partition.py:39-121), run with a stand-in communicator object that
   records what ``Scatter`` hands to every rank.
+* the per-stage loops of ``_PythonFMMCostModel`` (cost.py:1264-1360), with given
+  per-level cost factors (the symbolic translation-cost model above them needs
+  pymbolic, which is absent), on the oracle's trees and lists.
 * ``RotationClassesBuilder.vec_gcd / compute_rotation_classes`` and
   ``TranslationClassesBuilder.ntranslation_classes_per_level /
   translation_class_to_normalized_vector`` (rotation_classes.py:102-162,
@@ -278,6 +281,55 @@ def class_vectors(out):
 # }}}
 
 
+# {{{ per-stage loops of the Python cost model
+
+COST_METHODS = ["process_form_multipoles", "get_ndirect_sources_per_target_box",
+                "process_direct", "process_list2", "process_list3", "process_list4",
+                "process_eval_locals", "process_coarsen_multipoles", "process_refine_locals"]
+
+
+def cost_factors(case_seed, nlevels):
+    """Integer-valued per-level factors (exactly summable in any order)."""
+    rng = np.random.default_rng(5000 + case_seed)
+    f = {k: rng.integers(1, 50, nlevels).astype(np.float64)
+         for k in ("p2m_cost", "m2l_cost", "m2p_cost", "p2l_cost", "l2p_cost", "m2m_cost",
+                   "l2l_cost")}
+    f["c_p2p"] = np.float64(rng.integers(1, 9))
+    return f
+
+
+def cost_vectors(out):
+    import make_golden as mg
+    from oracle import oracle
+    oracle.build_lib()
+    fns = dict(zip(COST_METHODS, definitions("boxtree/cost.py", COST_METHODS,
+                                             inside="_PythonFMMCostModel")))
+    for name, case in mg.CASES.items():
+        _inp, tree, trav = mg.build(oracle, case)
+        trav.tree = tree
+        f = cost_factors(case["seed"], tree.nlevels)
+        pre = f"cost/{name}/"
+        r = {}
+        r["process_form_multipoles"] = fns["process_form_multipoles"](None, None, trav,
+                                                                      f["p2m_cost"])
+        nd = fns["get_ndirect_sources_per_target_box"](None, None, trav)
+        r["get_ndirect_sources_per_target_box"] = nd
+        r["process_direct"] = fns["process_direct"](None, None, trav, nd, f["c_p2p"])
+        r["process_list2"] = fns["process_list2"](None, None, trav, f["m2l_cost"])
+        r["process_list3"] = fns["process_list3"](None, None, trav, f["m2p_cost"])
+        r["process_list4"] = fns["process_list4"](None, None, trav, f["p2l_cost"])
+        r["process_eval_locals"] = fns["process_eval_locals"](None, None, trav, f["l2p_cost"])
+        r["process_coarsen_multipoles"] = fns["process_coarsen_multipoles"](
+            None, None, trav, f["m2m_cost"])
+        r["process_refine_locals"] = fns["process_refine_locals"](None, None, trav,
+                                                                  f["l2l_cost"])
+        for k, v in r.items():
+            out[pre + k] = np.asarray(v, dtype=np.float64)
+    print(f"_PythonFMMCostModel stage loops on {len(mg.CASES)} oracle cases")
+
+# }}}
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("needs the reference checkout at /root/reference")
@@ -285,6 +337,7 @@ def main():
     comm_pattern_vectors(out)
     partition_vectors(out)
     class_vectors(out)
+    cost_vectors(out)
     fmm_vectors(out)
     np.savez_compressed(OUT, **out)
     print(f"{len(out)} arrays -> {OUT} ({os.path.getsize(OUT) / 1e6:.2f} MB)")

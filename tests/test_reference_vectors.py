@@ -204,3 +204,57 @@ def test_device_dfs_order_and_partition_match_reference():
             want = VEC[key]
             assert np.array_equal(seg[:len(want)], want), key
             assert np.all(seg[len(want):] == nboxes), key
+
+
+COST_KEYS = ("process_form_multipoles", "get_ndirect_sources_per_target_box", "process_direct",
+             "process_list2", "process_list3", "process_list4", "process_eval_locals",
+             "process_coarsen_multipoles", "process_refine_locals")
+
+
+@pytest.mark.parametrize("name", sorted(mg.CASES))
+def test_cost_model_loops_match_reference(oracle, name):
+    """oracle.cost_model's per-stage pieces == the reference's _PythonFMMCostModel loops
+    (run on the same oracle tree with the same per-level factors)."""
+    import make_reference_vectors as mrv
+    _inp, tree, trav = mg.build(oracle, mg.CASES[name])
+    tc = mrv.cost_factors(mg.CASES[name]["seed"], tree.nlevels)
+    _, _, pieces = oracle.cost_model_from_factors(tree, trav, tc)
+    for k in COST_KEYS:
+        assert np.array_equal(np.asarray(pieces[k], np.float64), VEC[f"cost/{name}/{k}"]), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(mg.CASES))
+def test_device_cost_model_loops_match_reference(name):
+    import make_reference_vectors as mrv
+    from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
+    from boxtree_amd.cost import FMMCostModel
+    actx = HIPArrayContext(0)
+    case = mg.CASES[name]
+    inp = mg.make_inputs(case)
+    kw = dict(case["kw"])
+    if inp["targets"] is not None:
+        kw["targets"] = [actx.from_numpy(t) for t in inp["targets"]]
+    if inp["target_radii"] is not None:
+        kw["target_radii"] = actx.from_numpy(inp["target_radii"])
+    tree, _ = TreeBuilder(actx)(actx, [actx.from_numpy(p) for p in inp["particles"]], **kw)
+    trav, _ = FMMTraversalBuilder(actx, **case.get("trav_kw", {}))(actx, tree)
+    f = {k: (actx.from_numpy(v) if np.ndim(v) else float(v))
+         for k, v in mrv.cost_factors(case["seed"], int(tree.nlevels)).items()}
+    m = FMMCostModel()
+    nd = m.get_ndirect_sources_per_target_box(actx, trav)
+    got = {
+        "process_form_multipoles": m.process_form_multipoles(actx, trav, f["p2m_cost"]),
+        "get_ndirect_sources_per_target_box": nd,
+        "process_direct": m.process_direct(actx, trav, nd, f["c_p2p"]),
+        "process_list2": m.process_list2(actx, trav, f["m2l_cost"]),
+        "process_list3": m.process_list3(actx, trav, f["m2p_cost"]),
+        "process_list4": m.process_list4(actx, trav, f["p2l_cost"]),
+        "process_eval_locals": m.process_eval_locals(actx, trav, f["l2p_cost"]),
+        "process_coarsen_multipoles": m.process_coarsen_multipoles(actx, trav, f["m2m_cost"]),
+        "process_refine_locals": m.process_refine_locals(actx, trav, f["l2l_cost"]),
+    }
+    for k in COST_KEYS:
+        v = got[k]
+        v = v.cpu().numpy() if hasattr(v, "cpu") else np.float64(v)
+        assert np.array_equal(np.asarray(v, np.float64), VEC[f"cost/{name}/{k}"]), k
