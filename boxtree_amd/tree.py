@@ -296,7 +296,10 @@ def link_point_sources(actx, tree, point_source_starts, point_sources, *, debug=
         raise ValueError(actx.lib.bt_last_error_string().decode())
     _lib.check(code)
     tree_order_point_sources = make_obj_array(
-        [_gather(actx, _dev(actx, point_sources[i]), ids) for i in range(tree.dimensions)])
+        # flat storage order, like cl_array.take upstream: the reference's own test
+        # passes [nsources, npoint_sources_per_source] arrays (test/test_tree.py:638-646)
+        [_gather(actx, _dev(actx, point_sources[i]).reshape(-1), ids)
+         for i in range(tree.dimensions)])
     if debug:
         h = actx.to_numpy(ids)
         assert np.all(h >= 0) and np.all(h < npoint_sources)

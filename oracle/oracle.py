@@ -836,7 +836,10 @@ def link_point_sources(tree, point_source_starts, point_sources):
     base = csum[seg_first] - ids[seg_first]
     user_point_source_ids = (csum - base[seg]).astype(np.int32) if npoint_sources else \
         np.zeros(0, np.int32)
-    tree_order_point_sources = [np.asarray(ps)[user_point_source_ids] for ps in point_sources]
+    # cl_array.take indexes the flat storage (test/test_tree.py:638-646 passes
+    # [nsources, npoint_sources_per_source] arrays)
+    tree_order_point_sources = [np.asarray(ps).reshape(-1)[user_point_source_ids]
+                                for ps in point_sources]
     nboxes = tree.nboxes
     bstarts = np.zeros(nboxes, np.int32)
     out = {"nonchild": np.zeros(nboxes, np.int32), "cumul": np.zeros(nboxes, np.int32)}

@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # marks the reference's test files carry (tests/test_reference_suite.py compiles them)
+    for name in ("opencl", "area_query", "geo_lookup", "mpi"):
+        config.addinivalue_line("markers", f"{name}: mark of the reference's own tests")
 
 
 @pytest.fixture(scope="session")

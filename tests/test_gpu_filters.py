@@ -117,6 +117,31 @@ def test_link_point_sources(actx, oracle, dims, per_source):
     check_point_sources(otree, starts, point_sources, owner, h)
 
 
+def test_link_point_sources_2d_point_arrays(actx, oracle):
+    """The reference's own test hands [nsources, k] arrays (test/test_tree.py:638-656);
+    cl_array.take indexes their flat storage."""
+    from boxtree_amd.tree import link_point_sources
+    dims, nsources, k = 3, 2000, 8
+    rng = np.random.default_rng(8)
+    sources = normal(nsources, dims, 3)
+    radii = 2.0 ** rng.uniform(-10, 0, nsources)
+    kw = dict(source_radii=radii, targets=normal(400, dims, 4), stick_out_factor=0.25,
+              max_particles_in_box=10)
+    tree = device_tree(actx, None, sources, **kw)
+    otree = oracle.build_tree(sources, **kw)
+    point_sources = [s[:, None] + radii[:, None] * rng.uniform(-1, 1, (nsources, k))
+                     for s in sources]
+    starts = np.arange(0, (nsources + 1) * k, k, dtype=np.int32)
+    r = actx.to_numpy(link_point_sources(actx, tree, actx.from_numpy(starts),
+                                         [actx.from_numpy(p) for p in point_sources]))
+    o = oracle.link_point_sources(otree, starts, point_sources)
+    assert r.npoint_sources == o.npoint_sources == nsources * k
+    same(r.user_point_source_ids, o.user_point_source_ids)
+    for ax in range(dims):
+        same(r.point_sources[ax], o.point_sources[ax])
+        same(r.point_sources[ax], point_sources[ax].reshape(-1)[o.user_point_source_ids])
+
+
 def test_link_point_sources_errors(actx):
     from boxtree_amd.tree import link_point_sources
     sources = normal(500, 2, 1)
