@@ -5,11 +5,15 @@
  * and traversal kernels (reference = /root/reference, version 2024.10).  Only
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  *
- * PARITY UNPINNED: the reference cannot be imported or compiled in this
- * environment (pyopencl/arraycontext/pytools/mako absent, no OpenCL device) and
- * its test-suite holds no golden vectors.  This restatement follows the cited
- * reference lines and is validated against every invariant the reference's own
- * tests assert (tests/test_oracle_invariants.py), not against reference output.
+ * PARITY UNPINNED at the bit level: the reference's OpenCL kernels cannot be
+ * imported or compiled in this environment (pyopencl/arraycontext/pytools/mako
+ * absent, no OpenCL device) and its test-suite holds no golden vectors, so box
+ * numbering, particle order within a leaf and list order follow the cited
+ * reference lines, not reference output.  What the reference CAN do here it does:
+ * its own test functions run against this oracle (tests/test_reference_suite.py,
+ * 93 parameterisations) and its pure-Python modules (drive_fmm + constant-one
+ * wrangler, cost-model loops, partition, ...) run on this oracle's output
+ * (tests/golden/make_reference_vectors.py, tests/test_reference_vectors.py).
  *
  * This header is a "template": it is included once per coordinate type with
  *   COORD_T   float | double
