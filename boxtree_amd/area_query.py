@@ -63,8 +63,11 @@ def _aq_tree(actx, tree, need_levels):
     coord_dtype = np.dtype(tree.coord_dtype)
     keep = []
 
-    def dev(a):
+    def dev(a, dtype=None):
         t = actx.from_numpy(a) if isinstance(a, np.ndarray) else a
+        if dtype is not None:
+            # a TreeOfBoxes from boxtree.tree_of_boxes carries int32 levels
+            t = t.to(dtype)
         t = t.contiguous()
         keep.append(t)
         return t
@@ -83,11 +86,17 @@ def _aq_tree(actx, tree, need_levels):
     if np_dtype_of(box_centers) != coord_dtype:
         raise TypeError("tree.box_centers dtype must match tree.coord_dtype")
     t.box_centers = ptr(box_centers)
-    t.box_levels = ptr(dev(tree.box_levels))
-    t.box_child_ids = ptr(dev(tree.box_child_ids))
-    t.box_flags = ptr(dev(tree.box_flags))
+    torch = actx.torch
+    t.box_levels = ptr(dev(tree.box_levels, torch.uint8))
+    t.box_child_ids = ptr(dev(tree.box_child_ids, torch.int32))
+    t.box_flags = ptr(dev(tree.box_flags, torch.uint8))
     if need_levels:
-        t.box_parent_ids = ptr(dev(tree.box_parent_ids))
+        parents = dev(tree.box_parent_ids, torch.int32)
+        if int(parents[0]) != 0:            # root parent -1 in a TreeOfBoxes
+            parents = parents.clone()
+            parents[0] = 0
+            keep.append(parents)
+        t.box_parent_ids = ptr(parents)
         from boxtree_amd.tree import level_start_box_nrs_of
         lsb = level_start_box_nrs_of(actx, tree)
         keep.append(lsb)

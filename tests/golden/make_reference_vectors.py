@@ -21,6 +21,14 @@ GPU box -- only the vectors written by this script do):
 * the per-stage loops of ``_PythonFMMCostModel`` (cost.py:1264-1360), with given
   per-level cost factors (the symbolic translation-cost model above them needs
   pymbolic, which is absent), on the oracle's trees and lists.
+* ``boxtree.tree_of_boxes`` (make_tree_of_boxes_root, uniform and flagged refinement,
+  coarsening, _sort_boxes_by_level; tree_of_boxes.py:123-465) -- plain numpy.  It is
+  imported as a module; the ``TreeOfBoxes`` / ``box_flags_enum`` it imports from
+  ``boxtree.tree`` (which needs pyopencl) are the field-for-field containers of
+  boxtree_amd, ``pytools.single_valued`` is given its two-line meaning.  The pure-box
+  trees it makes (numbered the reference's way: level by level, NOT in Morton
+  order, every box flagged source and target, int32 levels, root parent -1) are
+  stored as traversal INPUTS.
 * ``RotationClassesBuilder.vec_gcd / compute_rotation_classes`` and
   ``TranslationClassesBuilder.ntranslation_classes_per_level /
   translation_class_to_normalized_vector`` (rotation_classes.py:102-162,
@@ -330,6 +338,94 @@ def cost_vectors(out):
 # }}}
 
 
+# {{{ trees of boxes made by the reference
+
+def tob_vectors(out):
+    import dataclasses
+    import operator
+
+    from boxtree_amd.tree import TreeOfBoxes, box_flags_enum
+    pkg = types.ModuleType("boxtree")
+    pkg.__path__ = [os.path.join(REF, "boxtree")]
+    tree_mod = types.ModuleType("boxtree.tree")
+    tree_mod.TreeOfBoxes = TreeOfBoxes
+    tree_mod.box_flags_enum = box_flags_enum
+    pkg.tree = tree_mod
+
+    def single_valued(iterable, equality_pred=operator.eq):
+        it = iter(iterable)
+        first = next(it)
+        for other in it:
+            assert equality_pred(other, first)
+        return first
+
+    pytools = types.ModuleType("pytools")
+    pytools.single_valued = single_valued
+    saved = {k: sys.modules.get(k) for k in ("boxtree", "boxtree.tree", "pytools",
+                                             "boxtree.tree_of_boxes")}
+    sys.modules.update({"boxtree": pkg, "boxtree.tree": tree_mod, "pytools": pytools})
+    sys.modules.pop("boxtree.tree_of_boxes", None)
+    try:
+        import boxtree.tree_of_boxes as tobm
+        _tob_cases(out, tobm, box_flags_enum)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
+def _tob_cases(out, tobm, box_flags_enum):
+    import dataclasses
+
+    def store(name, tob):
+        tob = tobm._sort_boxes_by_level(tob)
+        for f in dataclasses.fields(tob):
+            v = getattr(tob, f.name)
+            if isinstance(v, np.ndarray):
+                out[f"tob/{name}/{f.name}"] = v
+        out[f"tob/{name}/root_extent"] = np.asarray(tob.root_extent)
+        return tob
+
+    names = []
+    # test/test_tree_of_boxes.py:240-270: 2D, three uniform refinements
+    radius = np.pi
+    for dim, nlev, label in ((2, 3, "uniform_2d"), (3, 2, "uniform_3d"), (1, 4, "uniform_1d")):
+        lower = np.zeros(dim) - radius / 2
+        tob = tobm.make_tree_of_boxes_root((lower, lower + radius))
+        for _ in range(nlev):
+            tob = tobm.uniformly_refine_tree_of_boxes(tob)
+        store(label, tob)
+        names.append(label)
+    # flagged refinement of random leaves, then some coarsening
+    for dim, seed, label in ((2, 1, "adaptive_2d"), (3, 2, "adaptive_3d")):
+        rng = np.random.default_rng(seed)
+        tob = tobm.make_tree_of_boxes_root((np.zeros(dim), np.ones(dim)))
+        tob = tobm.uniformly_refine_tree_of_boxes(tob)
+        for _ in range(4 if dim == 2 else 3):
+            leaf = tob.box_flags & box_flags_enum.IS_LEAF_BOX != 0
+            flags = leaf & (rng.random(tob.nboxes) < 0.4)
+            tob = tobm.refine_tree_of_boxes(tob, flags)
+        store(label, tob)
+        names.append(label)
+        # coarsen: parents all of whose children are leaves, a random third of them
+        child = tob.box_child_ids
+        leaf = tob.box_flags & box_flags_enum.IS_LEAF_BOX != 0
+        cand = [b for b in range(tob.nboxes)
+                if not leaf[b] and all(leaf[c] for c in child[:, b] if c)]
+        pick = [b for b in cand if rng.random() < 0.34]
+        cflags = np.zeros(tob.nboxes, bool)
+        for b in pick:
+            cflags[[c for c in child[:, b] if c]] = True
+        store(label + "_coarsened", tobm.coarsen_tree_of_boxes(tob, cflags))
+        names.append(label + "_coarsened")
+    out["tob/names"] = np.array(names)
+    print(f"boxtree.tree_of_boxes: {len(names)} pure-box trees ({', '.join(names)})")
+
+# }}}
+
+
 def main():
     if not os.path.isdir(REF):
         raise SystemExit("needs the reference checkout at /root/reference")
@@ -338,6 +434,7 @@ def main():
     partition_vectors(out)
     class_vectors(out)
     cost_vectors(out)
+    tob_vectors(out)
     fmm_vectors(out)
     np.savez_compressed(OUT, **out)
     print(f"{len(out)} arrays -> {OUT} ({os.path.getsize(OUT) / 1e6:.2f} MB)")

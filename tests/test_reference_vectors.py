@@ -258,3 +258,107 @@ def test_device_cost_model_loops_match_reference(name):
         v = got[k]
         v = v.cpu().numpy() if hasattr(v, "cpu") else np.float64(v)
         assert np.array_equal(np.asarray(v, np.float64), VEC[f"cost/{name}/{k}"]), k
+
+
+# {{{ pure-box trees made by the reference's boxtree.tree_of_boxes
+
+TOB_NAMES = [str(n) for n in VEC["tob/names"]]
+TOB_TRAV_FIELDS = [f for f in mg.TRAV_FIELDS if "close" not in f]
+
+
+def _reference_tob(name):
+    """The tree exactly as the reference's functions return it (int32 levels, root
+    parent -1, no level starts, [2^d, nboxes] child ids, IS_LEAF_BOX flags)."""
+    from boxtree_amd.tree import TreeOfBoxes
+    pre = f"tob/{name}/"
+    a = {k[len(pre):]: VEC[k] for k in VEC.files if k.startswith(pre)}
+    return TreeOfBoxes(
+        root_extent=a["root_extent"][()], box_centers=a["box_centers"],
+        box_parent_ids=a["box_parent_ids"], box_child_ids=a["box_child_ids"],
+        box_levels=a["box_levels"], box_flags=a["box_flags"], level_start_box_nrs=None,
+        box_id_dtype=np.dtype(np.int32), box_level_dtype=np.dtype(np.int32),
+        coord_dtype=a["box_centers"].dtype, sources_have_extent=False,
+        targets_have_extent=False, extent_norm="linf", stick_out_factor=0, _is_pruned=True)
+
+
+def _oracle_view(tob):
+    levels = np.asarray(tob.box_levels)
+    nlevels = int(levels.max()) + 1
+    starts = np.concatenate([[0], np.cumsum(np.bincount(levels, minlength=nlevels))])
+    parents = np.array(tob.box_parent_ids, np.int32)
+    parents[0] = 0                              # a Tree's root is its own parent
+    return SimpleNamespace(
+        coord_dtype=np.dtype(tob.coord_dtype), dimensions=tob.box_centers.shape[0],
+        nboxes=len(levels), aligned_nboxes=len(levels), nlevels=nlevels,
+        root_extent=tob.root_extent, box_centers=np.ascontiguousarray(tob.box_centers),
+        box_levels=levels.astype(np.uint8), box_child_ids=np.ascontiguousarray(
+            tob.box_child_ids, dtype=np.int32),
+        box_flags=np.asarray(tob.box_flags, np.uint8), box_parent_ids=parents,
+        level_start_box_nrs=starts.astype(np.int32), sources_are_targets=True,
+        sources_have_extent=False, targets_have_extent=False, extent_norm="linf",
+        stick_out_factor=0, _is_pruned=True)
+
+
+@pytest.mark.parametrize("name", TOB_NAMES)
+def test_oracle_traversal_of_reference_made_box_trees(oracle, name):
+    """Structure of the fixtures + the oracle's lists on them: every box is source and
+    target, so list 1 of a box must hold the box itself, colleagues are symmetric,
+    and list 2 entries sit on the same level, non-adjacent, under adjacent parents."""
+    tob = _reference_tob(name)
+    t = _oracle_view(tob)
+    assert np.all(np.diff(t.box_levels.astype(int)) >= 0)
+    for b in range(1, t.nboxes):
+        assert b in tob.box_child_ids[:, tob.box_parent_ids[b]]
+    trav = oracle.build_traversal(t)
+    assert np.array_equal(trav.source_boxes, np.arange(t.nboxes))
+    st, li = trav.neighbor_source_boxes_starts, trav.neighbor_source_boxes_lists
+    for i, b in enumerate(trav.target_boxes):
+        assert b in li[st[i]:st[i + 1]]
+    st, li = trav.same_level_non_well_sep_boxes_starts, trav.same_level_non_well_sep_boxes_lists
+    coll = [set(li[st[b]:st[b + 1]]) for b in range(t.nboxes)]
+    for b in range(t.nboxes):
+        for c in coll[b]:
+            assert b in coll[c] and t.box_levels[c] == t.box_levels[b]
+    st, li = trav.from_sep_siblings_starts, trav.from_sep_siblings_lists
+    for i, b in enumerate(trav.target_or_target_parent_boxes):
+        for s in li[st[i]:st[i + 1]]:
+            assert t.box_levels[s] == t.box_levels[b] and s not in coll[b]
+            assert t.box_parent_ids[s] in coll[t.box_parent_ids[b]]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", TOB_NAMES)
+def test_device_traversal_of_reference_made_box_trees(oracle, name):
+    """FMMTraversalBuilder takes the reference's TreeOfBoxes as is (numpy arrays,
+    test/test_tree_of_boxes.py:240-270) and gives the oracle's lists."""
+    from boxtree_amd import FMMTraversalBuilder, HIPArrayContext
+    actx = HIPArrayContext(0)
+    tob = _reference_tob(name)
+    want = oracle.build_traversal(_oracle_view(tob))
+    got = actx.to_numpy(FMMTraversalBuilder(actx)(actx, tob)[0])
+    for f in TOB_TRAV_FIELDS:
+        assert np.array_equal(getattr(got, f), getattr(want, f)), f
+    for lev, bl in enumerate(want.from_sep_smaller_by_level):
+        g = got.from_sep_smaller_by_level[lev]
+        assert np.array_equal(g.starts, bl.starts) and np.array_equal(g.lists, bl.lists)
+        assert np.array_equal(got.target_boxes_sep_smaller_by_source_level[lev],
+                              want.target_boxes_sep_smaller_by_source_level[lev])
+
+# }}}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["adaptive_2d", "adaptive_3d_coarsened"])
+def test_device_peer_lists_of_reference_made_box_trees(oracle, name):
+    from boxtree_amd import HIPArrayContext
+    from boxtree_amd.area_query import PeerListFinder
+    actx = HIPArrayContext(0)
+    tob = _reference_tob(name)
+    view = _oracle_view(tob)
+    lows = view.box_centers[:, 0] - 0.5 * view.root_extent
+    view.bounding_box = (lows, lows + view.root_extent)
+    want = oracle.peer_lists(view)
+    got, _ = PeerListFinder(actx)(actx, tob)
+    got = actx.to_numpy(got)
+    assert np.array_equal(got.peer_list_starts, want.peer_list_starts)
+    assert np.array_equal(got.peer_lists, want.peer_lists)
