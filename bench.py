@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4"])
+    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
     ap.add_argument("--n", type=int, default=None, help="override particle count per GPU")
     ap.add_argument("--cpu-sample", type=int, default=16_000_000,
                     help="particles in the CPU-baseline sample (0 disables)")
@@ -56,8 +56,10 @@ def make_workload(torch, device, workload, n, seed):
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     f64 = torch.float64
-    if workload == "c2":
-        n = n or 10**7
+    if workload in ("c2", "c5"):
+        # c5 = BASELINE configs[4]: 10^9 uniform points over 8 GPUs, 1.25*10^8 per rank
+        # (rank g draws its chunk with seed 15+g)
+        n = n or (10**7 if workload == "c2" else 125 * 10**6)
         pts = [torch.rand(n, generator=g, dtype=f64, device=device) for _ in range(3)]
         return dict(name="3D uniform random, sources=targets", n=n, particles=pts,
                     targets=None, kw={})
@@ -85,7 +87,7 @@ def make_workload(torch, device, workload, n, seed):
 def make_workload_numpy(workload, n, seed):
     """Same recipes on the host for the CPU baseline sample."""
     rng = np.random.default_rng(seed)
-    if workload == "c2":
+    if workload in ("c2", "c5"):
         return dict(particles=[rng.random(n) for _ in range(3)], targets=None, kw={})
     if workload == "c3":
         v = rng.standard_normal((3, n))
