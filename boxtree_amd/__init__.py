@@ -21,15 +21,15 @@ from boxtree_amd.array_context import HIPArrayContext
 from boxtree_amd.bounding_box import BoundingBoxFinder
 from boxtree_amd.tools import make_normal_particle_array
 from boxtree_amd.traversal import BuiltList, FMMTraversalBuilder, FMMTraversalInfo
-from boxtree_amd.tree import Tree, TreeOfBoxes, box_flags_enum
-from boxtree_amd.tree_build import MaxLevelsExceeded, TreeBuilder
+from boxtree_amd.tree import Tree, TreeOfBoxes, TreeWithLinkedPointSources, box_flags_enum
+from boxtree_amd.tree_build import ExtentNorm, MaxLevelsExceeded, TreeBuilder, TreeKind
 
 __all__ = [
     "AreaQueryBuilder", "LeavesToBallsLookupBuilder", "PeerListFinder",
     "SpaceInvaderQueryBuilder",
     "BoundingBoxFinder", "BuiltList", "FMMTraversalBuilder", "FMMTraversalInfo",
-    "HIPArrayContext", "MaxLevelsExceeded", "Tree", "TreeBuilder", "TreeOfBoxes",
-    "box_flags_enum", "make_normal_particle_array",
+    "ExtentNorm", "HIPArrayContext", "MaxLevelsExceeded", "Tree", "TreeBuilder", "TreeKind",
+    "TreeOfBoxes", "TreeWithLinkedPointSources", "box_flags_enum", "make_normal_particle_array",
 ]
 
 __version__ = "0.1"

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 import ctypes as ct
 import logging
-from typing import Any
+from typing import Any, Literal
 
 import numpy as np
 
@@ -27,6 +27,11 @@ logger = logging.getLogger(__name__)
 
 class MaxLevelsExceeded(RuntimeError):   # tree_build.py:79
     pass
+
+
+# tree_build.py:83-88
+TreeKind = Literal["adaptive", "adaptive-level-restricted", "non-adaptive"]
+ExtentNorm = Literal["l2", "linf"]
 
 
 class TreeBuilder:
