@@ -148,9 +148,15 @@ struct KeygenArgs {
     int norm;       // BT_NORM_*
 };
 
+// Records of the interleaved coordinate copy: 3-D points are padded to four
+// coordinates so that a record never straddles a 32-byte DRAM sector (f64) -- the
+// tree-order gather is bound by the number of sectors it touches.
+template <int D>
+struct PackStride { static constexpr int value = D == 3 ? 4 : D; };
+
 template <class T, int D, bool EXT>
 __global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_t *__restrict__ keys,
-                                                     T *__restrict__ packed /* [n][D] */)
+                                                     T *__restrict__ packed /* [n][PackStride<D>] */)
 {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
@@ -171,8 +177,14 @@ __global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_
     }
     // interleaved copy: the tree-order gather later needs ONE random access per
     // particle instead of one per axis
+    {
+        constexpr int PS = PackStride<D>::value;
+        T rec[PS];
 #pragma unroll
-    for (int ax = 0; ax < D; ++ax) packed[i * D + ax] = x[ax];
+        for (int ax = 0; ax < PS; ++ax) rec[ax] = ax < D ? x[ax] : (T) 0;
+#pragma unroll
+        for (int ax = 0; ax < PS; ++ax) packed[i * PS + ax] = rec[ax];
+    }
 
     int cap = L;
     if (EXT) {
@@ -613,9 +625,10 @@ __global__ __launch_bounds__(256) void gather_packed_kernel(int64_t n, const int
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int64_t id = from_ids[i];            // srcntgt numbering
+    constexpr int PS = PackStride<D>::value;
     T c[D];
 #pragma unroll
-    for (int ax = 0; ax < D; ++ax) c[ax] = packed[id * D + ax];     // tbk:1170-1186
+    for (int ax = 0; ax < D; ++ax) c[ax] = packed[id * PS + ax];    // tbk:1170-1186
 #pragma unroll
     for (int ax = 0; ax < D; ++ax) g.out[ax][i] = c[ax];
 }
@@ -1372,7 +1385,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         ka.L = st->L;
         ka.norm = p.extent_norm;
         const unsigned blocks = (unsigned) div_up(N, 256);
-        BT_CHECK(st->packed.alloc(ctx->pool, N * D * (int64_t) sizeof(T)));
+        BT_CHECK(st->packed.alloc(ctx->pool, N * PackStride<D>::value * (int64_t) sizeof(T)));
         T *packed = (T *) st->packed.get();
         if (EXT) keygen_kernel<T, D, true><<<blocks, 256, 0, ctx->stream>>>(ka, st->keys_a.get(), packed);
         else keygen_kernel<T, D, false><<<blocks, 256, 0, ctx->stream>>>(ka, st->keys_a.get(), packed);
