@@ -193,7 +193,14 @@ __global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_
         else        { if (a.tgt_radii) radius = a.tgt_radii[j]; }
         const T one_half = ((T) 1) / 2;
         const T brf = (T) ((1. + (double) a.stick_out_factor) * (double) one_half);   // tbk:342-346
-        for (int l = 1; l <= L; ++l) {
+        // A point (radius 0) lies inside every box of its own path, at least
+        // stick_out_factor/2 box sizes away from the stick-out limit; with a factor
+        // of 1/64 or more that margin exceeds any rounding in the expressions below
+        // by orders of magnitude at every level of the key, so the test cannot fire
+        // and the walk (nineteen divisions per particle) is skipped.  Smaller
+        // factors, where a point within rounding of a box face could stop, walk.
+        const int lmax = (radius == (T) 0 && a.stick_out_factor >= (T) 0.015625) ? 0 : L;
+        for (int l = 1; l <= lmax; ++l) {
             const T size_factor = ((T) 1) / ((T) (1u << l));    // tbk:328-329
             bool stop = false;
             T center[D];
