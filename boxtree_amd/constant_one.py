@@ -6,8 +6,6 @@ here runnable at full problem size."""
 
 from __future__ import annotations
 
-import ctypes as ct
-
 import numpy as np
 
 from boxtree_amd import _lib

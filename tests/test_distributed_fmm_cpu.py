@@ -68,8 +68,7 @@ def _mpole_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from boxtree_amd.distributed.calculation import (DistributedExpansionWranglerMixin,
-                                                         gather_to_root, scatter_from_root)
+        from boxtree_amd.distributed.calculation import DistributedExpansionWranglerMixin
         from oracle import oracle as orc
         actx = SimpleNamespace(torch=torch, device=torch.device("cpu"))
         rng = np.random.default_rng(77)            # same stream on every rank
