@@ -106,28 +106,42 @@ __global__ __launch_bounds__(1024) void scan_tile_sums_kernel(AccT *tile_sums, i
     if (threadIdx.x == 0 && d_total) *d_total = carry;
 }
 
+// Elements are assigned to lanes wave-striped (item k of lane l = wave chunk + 64 k + l):
+// every load and store instruction of a wave covers one contiguous 256-byte (int32)
+// stretch.  (A blocked assignment -- 16 consecutive elements per thread -- makes each
+// instruction touch 64 different lines; measured 0.57 TB/s on a 5*10^7-element scan.)
 template <class AccT, class OutT, class F>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(F f, int64_t n,
         const AccT *tile_sums, OutT *out, bool write_total_at_n)
 {
-    __shared__ AccT s_tmp[SCAN_THREADS / 64 + 1];
-    const int64_t base = (int64_t) blockIdx.x * SCAN_TILE + (int64_t) threadIdx.x * SCAN_ITEMS;
-    AccT v[SCAN_ITEMS];
-    AccT acc = 0;
+    constexpr int NW = SCAN_THREADS / 64;
+    __shared__ AccT s_wave[NW];
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const int64_t wave_base = (int64_t) blockIdx.x * SCAN_TILE + (int64_t) w * (64 * SCAN_ITEMS);
+    AccT v[SCAN_ITEMS], ex[SCAN_ITEMS];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        int64_t i = base + k;
+        const int64_t i = wave_base + k * 64 + lane;
         v[k] = (i < n) ? f(i) : (AccT) 0;
-        acc += v[k];
     }
-    AccT ex = block_exclusive_scan<AccT, SCAN_THREADS>(acc, s_tmp, (AccT *) nullptr);
-    AccT run = tile_sums[blockIdx.x] + ex;
+    AccT carry = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        int64_t i = base + k;
-        if (i < n) out[i] = (OutT) run;
-        run += v[k];
-        if (write_total_at_n && i + 1 == n) out[n] = (OutT) run;
+        const AccT incl = wave_inclusive_scan(v[k]);
+        ex[k] = carry + incl - v[k];
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) s_wave[w] = carry;
+    __syncthreads();
+    AccT run = tile_sums[blockIdx.x];
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+        if (i < w) run += s_wave[i];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = wave_base + k * 64 + lane;
+        if (i < n) out[i] = (OutT) (run + ex[k]);
+        if (write_total_at_n && i + 1 == n) out[n] = (OutT) (run + ex[k] + v[k]);
     }
 }
 
