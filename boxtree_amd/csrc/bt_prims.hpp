@@ -5,6 +5,8 @@
 
 #include "bt_common.hpp"
 
+#include <type_traits>
+
 namespace bt {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -106,6 +108,12 @@ __global__ __launch_bounds__(1024) void scan_tile_sums_kernel(AccT *tile_sums, i
     if (threadIdx.x == 0 && d_total) *d_total = carry;
 }
 
+template <class AccT, class OutT, bool NARROW = (std::is_integral<OutT>::value
+                                                && sizeof(OutT) == 4 && sizeof(AccT) == 8)>
+struct ScanIntraTile { using type = AccT; };
+template <class AccT, class OutT>
+struct ScanIntraTile<AccT, OutT, true> { using type = uint32_t; };
+
 // Elements are assigned to lanes wave-striped (item k of lane l = wave chunk + 64 k + l):
 // every load and store instruction of a wave covers one contiguous 256-byte (int32)
 // stretch.  (A blocked assignment -- 16 consecutive elements per thread -- makes each
@@ -115,19 +123,24 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(F f, int64_t n
         const AccT *tile_sums, OutT *out, bool write_total_at_n)
 {
     constexpr int NW = SCAN_THREADS / 64;
-    __shared__ AccT s_wave[NW];
+    // Inside a tile the sums are carried in the width of the output: with 32-bit
+    // outputs and 64-bit accumulation (list lengths checked against the int32 CSR
+    // limit) a tile's own partial sums fit 32 bits whenever the result is
+    // representable at all, and the wave scans cost half the shuffles.
+    using W = typename ScanIntraTile<AccT, OutT>::type;
+    __shared__ W s_wave[NW];
     const int w = threadIdx.x >> 6, lane = lane_id();
     const int64_t wave_base = (int64_t) blockIdx.x * SCAN_TILE + (int64_t) w * (64 * SCAN_ITEMS);
-    AccT v[SCAN_ITEMS], ex[SCAN_ITEMS];
+    W v[SCAN_ITEMS], ex[SCAN_ITEMS];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const int64_t i = wave_base + k * 64 + lane;
-        v[k] = (i < n) ? f(i) : (AccT) 0;
+        v[k] = (i < n) ? (W) f(i) : (W) 0;
     }
-    AccT carry = 0;
+    W carry = 0;
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
-        const AccT incl = wave_inclusive_scan(v[k]);
+        const W incl = wave_inclusive_scan(v[k]);
         ex[k] = carry + incl - v[k];
         carry += __shfl(incl, 63, 64);
     }
@@ -136,12 +149,12 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(F f, int64_t n
     AccT run = tile_sums[blockIdx.x];
 #pragma unroll
     for (int i = 0; i < NW; ++i)
-        if (i < w) run += s_wave[i];
+        if (i < w) run += (AccT) s_wave[i];
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; ++k) {
         const int64_t i = wave_base + k * 64 + lane;
-        if (i < n) out[i] = (OutT) (run + ex[k]);
-        if (write_total_at_n && i + 1 == n) out[n] = (OutT) (run + ex[k] + v[k]);
+        if (i < n) out[i] = (OutT) (run + (AccT) ex[k]);
+        if (write_total_at_n && i + 1 == n) out[n] = (OutT) (run + (AccT) ex[k] + (AccT) v[k]);
     }
 }
 
