@@ -1489,7 +1489,20 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     int level = 1;
     const bool level_restricted = p.kind == BT_KIND_ADAPTIVE_LEVEL_RESTRICTED;
     if (level_restricted && N > 0) BT_CHECK((lr_build_boxes<T, D>(ctx, st, keys)));
-    while (N > 0 && !level_restricted) {
+    // tree_build.py:676: the level loop is not entered at all when the root is not
+    // overfull -- this also keeps a non-adaptive tree, which otherwise splits every
+    // box of a level, at a single box
+    bool enter_loop = N > 0 && !level_restricted;
+    if (enter_loop && p.kind == BT_KIND_NON_ADAPTIVE) {
+        int64_t total = N;
+        if (st->wprefix.get()) {
+            BT_HIP_CHECK(hipMemcpyAsync(&total, st->wprefix.get() + N, 8, hipMemcpyDeviceToHost,
+                                        ctx->stream));
+            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+        if (total <= (int64_t) p.max_leaf_refine_weight) enter_loop = false;
+    }
+    while (enter_loop) {
         if (D * level > sorted_high_bits) {
             // deeper than the sorted key bits reach: order all bits now.  Box ranges
             // stay valid (the order of the top bits does not change); ties keep
@@ -1862,7 +1875,10 @@ int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
             set_error("bt_tree_build: NULL coordinate array");
             return BT_ERR_INVALID;
         }
-        if (!(p->bbox_max[ax] > p->bbox_min[ax]) && N > 0) {
+        // max == min on every axis (a single point, or all points coincident) is a
+        // tree of one box unless that box would have to split, which no depth can
+        // achieve: MaxLevelsExceeded, like the level loop upstream
+        if (!(p->bbox_max[ax] >= p->bbox_min[ax]) && N > 0) {
             set_error("bt_tree_build: empty bounding box on axis %d", ax);
             return BT_ERR_INVALID;
         }
