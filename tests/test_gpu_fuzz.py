@@ -17,8 +17,16 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 @pytest.mark.parametrize("first_seed", [0, 1000, 2000])
 def test_random_configurations(first_seed):
     import fuzz_parity
-    stats = fuzz_parity.run(80, first_seed, verbose=False)
+    stats = fuzz_parity.run(80, first_seed, verbose=False, aux=False)
     assert stats["ok"] + stats["max_levels"] == 80 and stats["ok"] >= 70
+
+
+def test_random_configurations_with_the_callers_next_to_the_path():
+    """... plus peer lists, area / space-invader queries, target filters, translation
+    and rotation classes, cost-model loops, depth-first order and work partition."""
+    import fuzz_parity
+    stats = fuzz_parity.run(40, 3000, verbose=False, aux=True)
+    assert stats["ok"] + stats["max_levels"] == 40 and stats["ok"] >= 35
 
 
 @pytest.mark.parametrize("kind", ["adaptive", "non-adaptive", "adaptive-level-restricted"])

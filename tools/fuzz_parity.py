@@ -88,7 +88,121 @@ def make_case(seed):
     return particles, targets, kw, trav_kw
 
 
-def run(ncases, first_seed, verbose=True):
+def check_aux(actx, oracle, seed, tree, otree, trav, otrav, kw):
+    """The callers next to the path, on the same random tree: peer lists, area query,
+    leaves-to-balls, space invader, target filters, translation/rotation classes,
+    cost model loops, depth-first order and work partition."""
+    import ctypes as ct
+
+    from boxtree_amd import (AreaQueryBuilder, LeavesToBallsLookupBuilder, PeerListFinder,
+                             SpaceInvaderQueryBuilder)
+    from boxtree_amd.array_context import ptr
+    from boxtree_amd.tree import ParticleListFilter
+    rng = np.random.default_rng(10**6 + seed)
+    dims = otree.dimensions
+    dtype = np.dtype(otree.coord_dtype)
+
+    def eq(a, b, what):
+        a = a.cpu().numpy() if hasattr(a, "cpu") else np.asarray(a)
+        assert a.shape == np.asarray(b).shape and np.array_equal(a, b), what
+
+    if otree._is_pruned and not otree.sources_have_extent:
+        pl, _ = PeerListFinder(actx)(actx, tree)
+        opl = oracle.peer_lists(otree)
+        eq(pl.peer_list_starts, opl.peer_list_starts, "peer starts")
+        eq(pl.peer_lists, opl.peer_lists, "peer lists")
+        nballs = int(rng.choice([1, 40, 700]))
+        lo = np.array([float(v) for v in otree.bounding_box[0]])
+        ext = float(otree.root_extent) or 1.0
+        bc = [(lo[ax] + ext * rng.uniform(-0.3, 1.3, nballs)).astype(dtype) for ax in range(dims)]
+        br = (ext * 2.0 ** rng.uniform(-12, 0.5, nballs)).astype(dtype)
+        dbc, dbr = [actx.from_numpy(b) for b in bc], actx.from_numpy(br)
+        aq, _ = AreaQueryBuilder(actx)(actx, tree, dbc, dbr)
+        oaq = oracle.area_query(otree, bc, br)
+        eq(aq.leaves_near_ball_starts, oaq.leaves_near_ball_starts, "aq starts")
+        eq(aq.leaves_near_ball_lists, oaq.leaves_near_ball_lists, "aq lists")
+        lbl, _ = LeavesToBallsLookupBuilder(actx)(actx, tree, dbc, dbr)
+        olbl = oracle.leaves_to_balls(otree, bc, br)
+        eq(lbl.balls_near_box_starts, olbl.balls_near_box_starts, "lbl starts")
+        eq(lbl.balls_near_box_lists, olbl.balls_near_box_lists, "lbl lists")
+        siq, _ = SpaceInvaderQueryBuilder(actx)(actx, tree, dbc, dbr)
+        eq(siq, oracle.space_invader_query(otree, bc, br), "space invader")
+
+    flags = (rng.random(otree.ntargets) < rng.choice([0.0, 0.3, 1.0])).astype(np.int8)
+    plf = ParticleListFilter(actx)
+    fu = plf.filter_target_lists_in_user_order(actx, tree, actx.from_numpy(flags))
+    ofu = oracle.filter_target_lists_in_user_order(otree, flags)
+    eq(fu.target_starts, ofu.target_starts, "filter user starts")
+    eq(fu.target_lists, ofu.target_lists, "filter user lists")
+    ft = plf.filter_target_lists_in_tree_order(actx, tree, actx.from_numpy(flags))
+    oft = oracle.filter_target_lists_in_tree_order(otree, flags)
+    assert int(ft.nfiltered_targets) == int(oft.nfiltered_targets)
+    eq(ft.box_target_starts, oft.box_target_starts, "filter tree starts")
+    eq(ft.box_target_counts_nonchild, oft.box_target_counts_nonchild, "filter tree counts")
+    eq(ft.unfiltered_from_filtered_target_indices, oft.unfiltered_from_filtered_target_indices,
+       "filter tree index")
+
+    if trav is None:
+        return
+    from boxtree_amd.cost import FMMCostModel
+    from boxtree_amd.distributed.partition import get_box_ids_dfs_order
+    from boxtree_amd.rotation_classes import RotationClassesBuilder
+    from boxtree_amd.translation_classes import TranslationClassesBuilder
+    otrav.tree = otree
+    otrav.well_sep_is_n_away = trav.well_sep_is_n_away
+    if dims > 1:
+        per_level = bool(rng.integers(0, 2))
+        tc, _ = TranslationClassesBuilder(actx)(actx, trav, tree,
+                                                is_translation_per_level=per_level)
+        otc = oracle.translation_classes(otree, otrav, is_translation_per_level=per_level)
+        for name in ("from_sep_siblings_translation_classes",
+                     "from_sep_siblings_translation_class_to_distance_vector",
+                     "from_sep_siblings_translation_classes_level_starts"):
+            eq(getattr(tc, name), getattr(otc, name), name)
+        rc, _ = RotationClassesBuilder(actx)(actx, trav, tree)
+        orc = oracle.rotation_classes(otree, otrav)
+        eq(rc.from_sep_siblings_rotation_classes, orc.from_sep_siblings_rotation_classes, "rot")
+        eq(rc.from_sep_siblings_rotation_class_to_angle,
+           orc.from_sep_siblings_rotation_class_to_angle, "rot angles")
+
+    nlevels = int(otree.nlevels)
+    tcost = {k: rng.integers(1, 40, nlevels).astype(np.float64)
+             for k in ("p2m_cost", "m2l_cost", "m2p_cost", "p2l_cost", "l2p_cost", "m2m_cost",
+                       "l2l_cost")}
+    tcost["c_p2p"] = np.float64(rng.integers(1, 9))
+    _, _, pieces = oracle.cost_model_from_factors(otree, otrav, tcost)
+    m = FMMCostModel()
+    d = {k: (actx.from_numpy(v) if np.ndim(v) else float(v)) for k, v in tcost.items()}
+    nd = m.get_ndirect_sources_per_target_box(actx, trav)
+    got = {
+        "process_form_multipoles": m.process_form_multipoles(actx, trav, d["p2m_cost"]),
+        "get_ndirect_sources_per_target_box": nd,
+        "process_direct": m.process_direct(actx, trav, nd, d["c_p2p"]),
+        "process_list2": m.process_list2(actx, trav, d["m2l_cost"]),
+        "process_list3": m.process_list3(actx, trav, d["m2p_cost"]),
+        "process_list4": m.process_list4(actx, trav, d["p2l_cost"]),
+        "process_eval_locals": m.process_eval_locals(actx, trav, d["l2p_cost"]),
+        "process_coarsen_multipoles": m.process_coarsen_multipoles(actx, trav, d["m2m_cost"]),
+        "process_refine_locals": m.process_refine_locals(actx, trav, d["l2l_cost"]),
+    }
+    for k, v in got.items():
+        v = v.cpu().numpy() if hasattr(v, "cpu") else np.float64(v)
+        assert np.array_equal(np.asarray(v, np.float64), np.asarray(pieces[k], np.float64)), k
+
+    order = get_box_ids_dfs_order(actx, tree)
+    oorder = oracle.dfs_order(otree)
+    eq(order, oorder, "dfs order")
+    nranks = int(rng.choice([1, 2, 5, 8]))
+    if nranks <= otree.nboxes:
+        cost = rng.integers(0, 50, otree.nboxes).astype(np.float64)
+        seg = np.zeros((nranks, 2), np.int32)
+        assert actx.lib.bt_partition_work(
+            actx.handle, int(otree.nboxes), ptr(order), ptr(actx.from_numpy(cost)), nranks,
+            seg.ctypes.data_as(ct.POINTER(ct.c_int32))) == 0
+        assert np.array_equal(seg, oracle.partition_work_segments(cost, oorder, nranks))
+
+
+def run(ncases, first_seed, verbose=True, aux=True):
     from compare import assert_same_traversal, assert_same_tree
     from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
     from boxtree_amd.tree_build import MaxLevelsExceeded
@@ -125,6 +239,7 @@ def run(ncases, first_seed, verbose=True):
             continue
         try:
             assert_same_tree(actx.to_numpy(tree), otree)
+            trav = otrav = None
             if trav_kw is not None:
                 tkw = dict(trav_kw)
                 otrav = oracle.build_traversal(otree, **tkw)
@@ -132,6 +247,8 @@ def run(ncases, first_seed, verbose=True):
                     trav, _ = FMMTraversalBuilder(actx, **tkw)(actx, tree,
                                                                _force_generic=force_generic)
                     assert_same_traversal(actx.to_numpy(trav), otrav)
+            if aux and otree.nboxes <= 20000:
+                check_aux(actx, oracle, seed, tree, otree, trav, otrav, kw)
         except AssertionError:
             print(f"MISMATCH at seed {seed}: dims={len(particles)} n={len(particles[0])} kw="
                   f"{ {k: (v if np.ndim(v) == 0 else '...') for k, v in kw.items()} } "
