@@ -1914,7 +1914,9 @@ int bt_tree_export(bt_context *ctx, const bt_tree_arrays *o)
     }
     BT_HIP_CHECK(hipSetDevice(ctx->device));
     const bool need_tgt = !st->sat;
-    if (!o->user_source_ids || !o->sorted_target_ids || !o->box_source_starts
+    // (zero-length particle arrays may come as NULL: an empty rank of a sharded build)
+    if ((!o->user_source_ids && st->nsources > 0) || (!o->sorted_target_ids && st->ntargets > 0)
+            || !o->box_source_starts
             || !o->box_source_counts_nonchild || !o->box_source_counts_cumul
             || !o->box_parent_ids || !o->box_child_ids || !o->box_centers || !o->box_levels
             || !o->box_flags || !o->box_source_bounding_box_min || !o->box_source_bounding_box_max

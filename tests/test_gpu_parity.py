@@ -854,6 +854,27 @@ def test_multi_rank_local_essential_tree(dims, world, dist_kind, nway):
     local essential tree, mapped to global box numbers, are the rows of the global
     traversal for the rank's boxes -- and the tree itself matches the global tree box
     for box (centres, levels, flags, parent/child links)."""
+    check_multi_rank_let(dims, world, dist_kind, nway)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_multi_rank_local_essential_tree_random(seed):
+    """The same check on random rank counts, sizes, distributions, leaf sizes and
+    top levels."""
+    rng = np.random.default_rng(7000 + seed)
+    dims = int(rng.choice([2, 3]))
+    check_multi_rank_let(
+        dims, world=int(rng.integers(2, 9)),
+        dist_kind=str(rng.choice(["sphere", "uniform", "normal", "clustered"])),
+        nway=int(rng.choice([1, 1, 2])), n_per=int(rng.choice([3000, 20000, 50000])),
+        mpb=int(rng.choice([8, 30, 64])),
+        top_level=int(rng.integers(2, 5) if dims == 3 else rng.integers(3, 6)),
+        seed=int(rng.integers(0, 10**6)), expect_partial=False)
+
+
+def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_level=None,
+                         seed=200, expect_partial=True):
     import threading
 
     import torch
@@ -861,11 +882,14 @@ def test_multi_rank_local_essential_tree(dims, world, dist_kind, nway):
     from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
     from boxtree_amd.distributed import (build_local_essential_tree, exchange_particles,
                                          number_sharded_tree)
-    n_per, mpb = 40000, 30
-    top_level = 3 if dims == 3 else 4
+    if top_level is None:
+        top_level = 3 if dims == 3 else 4
 
     def chunk(rank):
-        rng = np.random.default_rng(200 + rank)
+        rng = np.random.default_rng(seed + rank)
+        if dist_kind == "clustered":
+            return [np.where(rng.random(n_per) < 0.5, 0.3 + 1e-2 * rng.standard_normal(n_per),
+                             rng.standard_normal(n_per)) for _ in range(dims)]
         if dist_kind == "sphere":
             v = rng.standard_normal((dims, n_per))
             v /= np.sqrt((v * v).sum(axis=0))
@@ -934,7 +958,7 @@ def test_multi_rank_local_essential_tree(dims, world, dist_kind, nway):
         t, tr, gid, hm = r["let"], r["trav"], r["gid"], r["mask"]
         nb = t.nboxes
         assert r["nglobal"] == g.nboxes and nb <= g.nboxes
-        if world > 2:
+        if world > 2 and expect_partial:
             assert nb < g.nboxes                   # a halo, not the whole tree
         assert len(set(gid.tolist())) == nb
         # the LET is the global tree restricted to its boxes
