@@ -82,7 +82,7 @@ def make_case(seed):
         bbox = np.empty((dims, 2), dtype)
         bbox[:, 0], bbox[:, 1] = lo, hi
         kw["bbox"] = bbox
-    if kind == "adaptive" and rng.random() < 0.1 and "target_radii" not in kw:
+    if rng.random() < 0.12 and "target_radii" not in kw:
         kw["skip_prune"] = True
         trav_kw = None                           # traversal needs a pruned tree
     return particles, targets, kw, trav_kw
