@@ -891,6 +891,9 @@ int coll_l2_single_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<i
     BT_CHECK(srccoll_rows.alloc(ctx->pool, B * P));
     BT_CHECK(srccoll_cnt.alloc(ctx->pool, B));
     BT_HIP_CHECK(hipMemsetAsync(srccoll_cnt.get(), 0, (size_t) B * 4, ctx->stream));
+    Buf<int32_t> coll_ins;
+    BT_CHECK(coll_ins.alloc(ctx->pool, B));
+    BT_HIP_CHECK(hipMemsetAsync(coll_ins.get(), 0, (size_t) B * 4, ctx->stream));
     BT_CHECK(l2_by_box.alloc(ctx->pool, B + 1));
     BT_HIP_CHECK(hipMemsetAsync(l2_by_box.get(), 0, (size_t) (B + 1) * 4, ctx->stream));
     st->l2_pending.clear();
@@ -917,7 +920,7 @@ int coll_l2_single_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<i
         BT_CHECK(l2_rel.alloc(ctx->pool, nb + 1));
         coll_l2_rows_kernel<T, D><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(
             a, b0, nb, coll_rows.get(), coll_cnt.get(), l2_rows.get(), l2_cnt.get(),
-            srccoll_rows.get(), srccoll_cnt.get());
+            srccoll_rows.get(), srccoll_cnt.get(), coll_ins.get());
         int64_t h_tot = 0;
         BT_CHECK(scan_list_counts(ctx, ScanI32{l2_cnt.get()}, nb, l2_rel.get(), &h_tot));
         if (l2_total + h_tot >= ((int64_t) 1 << 31)) {

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void coll_l2_kernel(TravArgs<T, D> a, int32_t 
 template <class T, int D>
 __global__ __launch_bounds__(256) void coll_l2_rows_kernel(TravArgs<T, D> a, int32_t b0, int32_t nb,
         int32_t *coll_rows, int32_t *coll_cnt, int32_t *l2_rows, int32_t *l2_cnt,
-        int32_t *srccoll_rows, int32_t *srccoll_cnt)
+        int32_t *srccoll_rows, int32_t *srccoll_cnt, int32_t *coll_ins)
 {
     constexpr int C = 1 << D;
     constexpr int P = (D == 1 ? 3 : D == 2 ? 9 : 27) - 1;
@@ -280,9 +280,9 @@ __global__ __launch_bounds__(256) void coll_l2_rows_kernel(TravArgs<T, D> a, int
         && (!a.target_mask || a.target_mask[b]);    // list 2 only for wanted boxes
     const int32_t *prow = coll_rows + (int64_t) p * P;
     const int32_t n = coll_cnt[p];
-    int ins = 0;                         // depth-first position of p among its colleagues
-    const int32_t prank = a.dfs_rank[p];
-    for (int i = 0; i < n; ++i) ins += (a.dfs_rank[prow[i]] < prank) ? 1 : 0;
+    // depth-first position of p among its colleagues: recorded when p's own row was
+    // made (the number of colleagues emitted before the walk reached p itself)
+    const int ins = coll_ins[p];
 
     int32_t *crow = coll_rows + (int64_t) b * P;
     int32_t *lrow = l2_rows + (int64_t) g * S;
@@ -322,6 +322,8 @@ __global__ __launch_bounds__(256) void coll_l2_rows_kernel(TravArgs<T, D> a, int
             const uint64_t bc = (__ballot(is_coll) >> gshift) & ((1ull << C) - 1);
             const uint64_t bl = (__ballot(is_l2) >> gshift) & ((1ull << C) - 1);
             const uint64_t bs = (__ballot(is_src) >> gshift) & ((1ull << C) - 1);
+            // the candidates come in depth-first order; b itself is one of them
+            if (ch == b) coll_ins[b] = ccur + __popcll(bc & lanes_below);
             if (is_coll) crow[ccur + __popcll(bc & lanes_below)] = ch;
             if (is_l2) lrow[lcur + __popcll(bl & lanes_below)] = ch;
             if (is_src) srow[scur + __popcll(bs & lanes_below)] = ch;
