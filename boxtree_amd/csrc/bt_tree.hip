@@ -485,15 +485,16 @@ struct SegSortFlags {
     int32_t has_huge;     // some run > SEG_BLOCK_MAX
 };
 
+// Half a wave per box, up to two ids per lane: the kernel is bound by the latency of
+// its dependent global loads (count, start, ids), so two boxes per wave keep twice as
+// many of them in flight; the 64-element network's j=32 stage is register-local.
 __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, const int32_t *box_start,
         const int32_t *box_count, const uint8_t *box_haschild, uint32_t *ids,
         int32_t *large_list, SegSortFlags *flags)
 {
-    const int b = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
+    const int b = (blockIdx.x * 256 + threadIdx.x) >> 5;
+    const int lane = threadIdx.x & 31;
     if (b >= nboxes) return;
-    // (three independent loads issued together: the kernel is bound by the latency
-    // of its dependent global loads, not by the sorting network)
     const uint8_t has_children = box_haschild[b];
     const int n = box_count[b];
     const int s = box_start[b];
@@ -506,19 +507,38 @@ __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, cons
         }
         return;
     }
-    uint32_t v = (lane < n) ? ids[s + lane] : 0xFFFFFFFFu;
+    uint32_t v0 = (lane < n) ? ids[s + lane] : 0xFFFFFFFFu;
+    uint32_t v1 = (lane + 32 < n) ? ids[s + lane + 32] : 0xFFFFFFFFu;
+    // element index of v0 is `lane`, of v1 `lane + 32`
+    auto cmpx = [&](uint32_t v, int idx, int k, int j) {
+        const uint32_t o = __shfl_xor(v, j, 32);
+        const bool up = (idx & k) == 0;
+        const bool lower = (idx & j) == 0;
+        const uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
+        return (lower == up) ? mn : mx;
+    };
 #pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
+    for (int k = 2; k <= 32; k <<= 1) {
 #pragma unroll
         for (int j = k >> 1; j > 0; j >>= 1) {
-            const uint32_t o = __shfl_xor(v, j, 64);
-            const bool up = (lane & k) == 0;
-            const bool lower = (lane & j) == 0;
-            const uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
-            v = (lower == up) ? mn : mx;
+            v0 = cmpx(v0, lane, k, j);
+            if (n > 32) v1 = cmpx(v1, lane + 32, k, j);
         }
     }
-    if (lane < n) ids[s + lane] = v;
+    if (n > 32) {
+        // k = 64: both halves ascending overall; j = 32 pairs v0 with v1 of the same lane
+        {
+            const uint32_t mn = v0 < v1 ? v0 : v1, mx = v0 < v1 ? v1 : v0;
+            v0 = mn; v1 = mx;
+        }
+#pragma unroll
+        for (int j = 16; j > 0; j >>= 1) {
+            v0 = cmpx(v0, lane, 64, j);
+            v1 = cmpx(v1, lane + 32, 64, j);
+        }
+    }
+    if (lane < n) ids[s + lane] = v0;
+    if (lane + 32 < n) ids[s + lane + 32] = v1;
 }
 
 __global__ __launch_bounds__(256) void segment_sort_block_kernel(const int32_t *large_list,
@@ -1580,7 +1600,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         BT_CHECK(large_list.alloc(ctx->pool, N / 64 + 1));
         BT_CHECK(sflags.alloc(ctx->pool, 1));
         BT_HIP_CHECK(hipMemsetAsync(sflags.get(), 0, sizeof(SegSortFlags), ctx->stream));
-        segment_sort_wave_kernel<<<(unsigned) div_up(st->nboxes * 64, 256), 256, 0, ctx->stream>>>(
+        segment_sort_wave_kernel<<<(unsigned) div_up(st->nboxes * 32, 256), 256, 0, ctx->stream>>>(
             (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_haschild.get(),
             ids, large_list.get(), sflags.get());
         SegSortFlags hf;
