@@ -1139,7 +1139,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         BT_CHECK(tier_present.alloc(ctx->pool, 2));
         BT_HIP_CHECK(hipMemsetAsync(tier.get(), 0, (size_t) ntb, ctx->stream));
         BT_HIP_CHECK(hipMemsetAsync(tier_present.get(), 0, 8, ctx->stream));
-        l1_finalize32_kernel<T, D><<<nblk(ntb * 32), 256, 0, ctx->stream>>>(
+        l1_finalize32_kernel<T, D><<<nblk(ntb * 16), 256, 0, ctx->stream>>>(
             a, ft, (int32_t) ntb, c1.starts.get(), c1.lists.get(), jobs, tier.get(),
             tier_present.get());
         int32_t h_present[2] = {0, 0};

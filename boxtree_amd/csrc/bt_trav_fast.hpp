@@ -794,10 +794,12 @@ __global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, Fa
         uint8_t *tier /* [ntb], zeroed: 1 = wave kernel, 2 = workgroup kernel */,
         int32_t *tier_present /* [2], zeroed */)
 {
+    // sixteen lanes per box, two entries per lane: four boxes' chains of dependent
+    // loads (box -> rank -> row -> box_of_rank) are in flight per wave
     const int32_t gid = blockIdx.x * 256 + threadIdx.x;
-    const int32_t tbn = gid >> 5;
-    const int lane = gid & 31;
-    if (tbn >= ntb) return;                          // whole 32-groups drop out together
+    const int32_t tbn = gid >> 4;
+    const int lane = gid & 15;
+    if (tbn >= ntb) return;                          // whole 16-groups drop out together
     const int32_t b = a.target_boxes[tbn];
     int32_t *out = l1_lists + l1_starts[tbn];
     const int32_t n_all = l1_starts[tbn + 1] - l1_starts[tbn];
@@ -809,15 +811,20 @@ __global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, Fa
     }
     const int32_t n = n_all - blk_len;
     if (n <= 32) {
-        const int32_t v = lane < n ? out[lane] : INT32_MAX;
-        int r = 0, k = 0;
+        const int32_t v0 = lane < n ? out[lane] : INT32_MAX;
+        const int32_t v1 = lane + 16 < n ? out[lane + 16] : INT32_MAX;
+        int r0 = 0, r1 = 0, k = 0;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
-            const int32_t o = __shfl(v, j, 32);
-            r += (o < v) ? 1 : 0;                    // ranks are distinct
-            k += (o <= my_rank) ? 1 : 0;             // entries before the own-subtree block
+        for (int j = 0; j < 16; ++j) {
+            const int32_t o0 = __shfl(v0, j, 16), o1 = __shfl(v1, j, 16);
+            r0 += ((o0 < v0) ? 1 : 0) + ((o1 < v0) ? 1 : 0);     // ranks are distinct
+            r1 += ((o0 < v1) ? 1 : 0) + ((o1 < v1) ? 1 : 0);
+            k += ((o0 <= my_rank) ? 1 : 0) + ((o1 <= my_rank) ? 1 : 0);   // before the own block
         }
-        if (lane < n) out[r < k ? r : r + blk_len] = ft.box_of_rank[v];
+        const int32_t w0 = lane < n ? ft.box_of_rank[v0] : 0;
+        const int32_t w1 = lane + 16 < n ? ft.box_of_rank[v1] : 0;
+        if (lane < n) out[r0 < k ? r0 : r0 + blk_len] = w0;
+        if (lane + 16 < n) out[r1 < k ? r1 : r1 + blk_len] = w1;
         if (blk_len > 0 && lane == 0) {
             const int32_t j = atomicAdd(jobs.count, 1);
             jobs.dst[j] = l1_starts[tbn] + k;
