@@ -948,7 +948,7 @@ int coll_l2_single_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<i
         BT_CHECK(scan_list_counts(ctx, ScanI32{coll_cnt.get()}, B, coll.starts.get(), &t));
         coll.total = t;
         BT_CHECK(coll.lists.alloc(ctx->pool, t));
-        compact_strided_rows_kernel<<<nblk(B * 16), 256, 0, ctx->stream>>>(
+        compact_strided_rows_kernel<8><<<nblk(B * 8), 256, 0, ctx->stream>>>(
             B, P, coll_rows.get(), coll.starts.get(), 0, coll.lists.get());
     }
     BT_HIP_CHECK(hipGetLastError());
@@ -1493,7 +1493,7 @@ int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
     } else {
         BT_CHECK(copy_i32(ctx, o->from_sep_siblings_starts, st->l2.starts.get(), st->l2.n + 1));
         for (const L2Pending &pend : st->l2_pending)
-            compact_strided_rows_kernel<<<nblk((int64_t) pend.nb * 16), 256, 0, ctx->stream>>>(
+            compact_strided_rows_kernel<16><<<nblk((int64_t) pend.nb * 16), 256, 0, ctx->stream>>>(
                 pend.nb, pend.stride, pend.rows.get(), pend.rel.get(), (int32_t) pend.base,
                 o->from_sep_siblings_lists);
         BT_HIP_CHECK(hipGetLastError());

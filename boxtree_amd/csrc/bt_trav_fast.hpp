@@ -335,17 +335,20 @@ __global__ __launch_bounds__(256) void coll_l2_rows_kernel(TravArgs<T, D> a, int
     if (m == 0) { coll_cnt[b] = ccur; l2_cnt[g] = lcur; srccoll_cnt[b] = scur; }
 }
 
-// rows[r][0..count) -> lists[base + starts[r] ...); 16 lanes per row
+// rows[r][0..count) -> lists[base + starts[r] ...); LANES lanes per row (measured at
+// 5*10^6 boxes: colleague rows, <= 26 entries, are fastest with 8; list-2 rows, ~40
+// entries on average, with 16)
+template <int LANES>
 __global__ __launch_bounds__(256) void compact_strided_rows_kernel(int64_t nrows, int stride,
         const int32_t *rows, const int32_t *starts, int32_t base, int32_t *lists)
 {
     const int64_t gid = (int64_t) blockIdx.x * 256 + threadIdx.x;
-    const int64_t r = gid >> 4;
-    const int lane = (int) (gid & 15);
+    const int64_t r = gid / LANES;
+    const int lane = (int) (gid % LANES);
     if (r >= nrows) return;
     const int32_t s = starts[r], e = starts[r + 1];
     const int32_t *row = rows + r * stride;
-    for (int32_t k = lane; k < e - s; k += 16) lists[(int64_t) base + s + k] = row[k];
+    for (int32_t k = lane; k < e - s; k += LANES) lists[(int64_t) base + s + k] = row[k];
 }
 
 // Same lists, one WAVE per parent box: the candidates (children of the parent's
