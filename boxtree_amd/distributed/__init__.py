@@ -652,6 +652,9 @@ def gather_global_box_tree(actx, dist, tree, numbering):
 _CELL_COORDS = {}
 
 
+_CELL_INDEX_GRID = {}
+
+
 def _cell_grid(values, dims, k):
     """Morton-indexed cell array -> [2^k]^dims grid (axis 0 = x)."""
     n = 1 << k
@@ -672,29 +675,38 @@ def _cell_grid(values, dims, k):
 
 def _cells_needed_by(owner, dims, k, rank, world, ring, counts=None):
     """need[q] = boolean array over cells: my cells within *ring* cells (Chebyshev) of
-    a cell owned by rank q -- the subtrees q's lists can reach."""
-    import itertools
+    a cell owned by rank q -- the subtrees q's lists can reach.  Per rank q: the set
+    of q's cells is dilated by *ring* along every axis of the cell grid (whole-array
+    shifts) and intersected with my non-empty cells."""
     owner = np.asarray(owner, dtype=np.int64)
     n = 1 << k
-    index_grid, coords = _cell_grid(np.arange(n ** dims, dtype=np.int64), dims, k)
+    key = (dims, k)
+    if key not in _CELL_INDEX_GRID:
+        _CELL_INDEX_GRID[key] = _cell_grid(np.arange(n ** dims, dtype=np.int64), dims, k)
+    index_grid, _ = _CELL_INDEX_GRID[key]
+    owner_grid = owner[index_grid]
     mine = owner == rank
     if counts is not None:
-        mine &= np.asarray(counts) > 0             # empty cells hold no boxes
-    my_cells = np.nonzero(mine)[0]
+        mine = mine & (np.asarray(counts) > 0)      # empty cells hold no boxes
     need = np.zeros((world, n ** dims), dtype=bool)
-    if len(my_cells) == 0:
+    if not mine.any():
         return need
-    xyz = [c[my_cells] for c in coords]
-    for off in itertools.product(range(-ring, ring + 1), repeat=dims):
-        if not any(off):
+    mine_grid = mine[index_grid]
+    for q in np.unique(owner):
+        q = int(q)
+        if q == rank:
             continue
-        nb = [x + o for x, o in zip(xyz, off)]
-        ok = np.ones(len(my_cells), dtype=bool)
-        for v in nb:
-            ok &= (v >= 0) & (v < n)
-        q = owner[index_grid[tuple(v[ok] for v in nb)]]
-        need[q, my_cells[ok]] = True
-    need[rank] = False
+        d = owner_grid == q
+        for ax in range(dims):
+            acc = d.copy()
+            for sh in range(1, ring + 1):
+                lo = [slice(None)] * dims
+                hi = [slice(None)] * dims
+                lo[ax], hi[ax] = slice(0, n - sh), slice(sh, n)
+                acc[tuple(lo)] |= d[tuple(hi)]
+                acc[tuple(hi)] |= d[tuple(lo)]
+            d = acc
+        need[q, index_grid[d & mine_grid]] = True
     return need
 
 
