@@ -651,13 +651,13 @@ __global__ __launch_bounds__(256) void gather_packed_kernel(int64_t n, const int
 {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int64_t id = from_ids[i];            // srcntgt numbering
+    const int64_t id = __builtin_nontemporal_load(&from_ids[i]);   // srcntgt numbering
     constexpr int PS = PackStride<D>::value;
     T c[D];
 #pragma unroll
     for (int ax = 0; ax < D; ++ax) c[ax] = packed[id * PS + ax];    // tbk:1170-1186
 #pragma unroll
-    for (int ax = 0; ax < D; ++ax) g.out[ax][i] = c[ax];
+    for (int ax = 0; ax < D; ++ax) __builtin_nontemporal_store(c[ax], &g.out[ax][i]);
 }
 
 template <class T>
