@@ -124,7 +124,7 @@ typedef struct {
     int32_t max_leaf_refine_weight; /* = max_particles_in_box when weights NULL   */
     int32_t kind;              /* BT_KIND_* */
     int32_t extent_norm;       /* BT_NORM_* (NONE when no radii)                  */
-    int32_t skip_prune;        /* debugging kwarg of the reference (unsupported)  */
+    int32_t skip_prune;        /* keep empty boxes (tree_build.py:1328, undocumented there) */
     double stick_out_factor;
     /* root box exactly as computed on the host by tree_build.py:456-510
      * (values representable in the coordinate type):                       */
