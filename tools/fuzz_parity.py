@@ -237,6 +237,14 @@ def run(ncases, first_seed, verbose=True, aux=True):
         if oerr is not None:
             stats["max_levels"] += 1
             continue
+        if otree.nlevels >= 31:
+            # Boxes on level 30 and below: upstream computes their centres with
+            # ``1 << (1 + new_level)`` on a 32-bit int (tree_build_kernels.py:698),
+            # which is -2^31 at level 30 -- the oracle restates that literally and
+            # mirrors the two children of a level-29 box; the device keeps the
+            # geometrically correct centres (deviations).
+            stats["beyond_int_shift"] = stats.get("beyond_int_shift", 0) + 1
+            continue
         try:
             assert_same_tree(actx.to_numpy(tree), otree)
             trav = otrav = None
