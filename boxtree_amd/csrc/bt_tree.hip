@@ -146,6 +146,7 @@ struct KeygenArgs {
     T stick_out_factor;
     int L;          // levels in the key
     int norm;       // BT_NORM_*
+    int point_skip_levels;   // levels 1..this cannot stop a particle of radius 0
 };
 
 // Records of the interleaved coordinate copy: 3-D points are padded to four
@@ -194,13 +195,15 @@ __global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_
         const T one_half = ((T) 1) / 2;
         const T brf = (T) ((1. + (double) a.stick_out_factor) * (double) one_half);   // tbk:342-346
         // A point (radius 0) lies inside every box of its own path, at least
-        // stick_out_factor/2 box sizes away from the stick-out limit; with a factor
-        // of 1/64 or more that margin exceeds any rounding in the expressions below
-        // by orders of magnitude at every level of the key, so the test cannot fire
-        // and the walk (nineteen divisions per particle) is skipped.  Smaller
-        // factors, where a point within rounding of a box face could stop, walk.
-        const int lmax = (radius == (T) 0 && a.stick_out_factor >= (T) 0.015625) ? 0 : L;
-        for (int l = 1; l <= lmax; ++l) {
+        // stick_out_factor/2 box sizes away from the stick-out limit.  As long as that
+        // margin exceeds the rounding of the expressions below by a wide factor (the
+        // host works out down to which level it does, from the bounding box, the
+        // factor and the precision of T) the test cannot fire, and the walk starts
+        // below those levels: all of them in double precision, the first ~14 in
+        // single.  Deeper, where a box is smaller than the spacing of T around the
+        // point, upstream's test does fire for points, and so does this one.
+        const int lfirst = (radius == (T) 0) ? a.point_skip_levels + 1 : 1;
+        for (int l = lfirst; l <= L; ++l) {
             const T size_factor = ((T) 1) / ((T) (1u << l));    // tbk:328-329
             bool stop = false;
             T center[D];
@@ -1411,6 +1414,19 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         ka.stick_out_factor = (T) p.stick_out_factor;
         ka.L = st->L;
         ka.norm = p.extent_norm;
+        {
+            // margin at level l: (stick_out_factor / 2) * extent * 2^-l; rounding of the
+            // cell assignment, the centre and the limit: a few spacings of T at the
+            // magnitude of the coordinates.  Require margin >= 128 spacings.
+            double scale = std::fabs(p.root_extent);
+            for (int ax = 0; ax < D; ++ax)
+                scale = std::max(scale, std::max(std::fabs(p.bbox_min[ax]), std::fabs(p.bbox_max[ax])));
+            const double eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
+            const double ratio = p.stick_out_factor * p.root_extent / (256.0 * eps * scale);
+            int skip = 0;
+            if (ratio > 1.0) skip = (int) std::floor(std::log2(ratio));
+            ka.point_skip_levels = std::max(0, std::min(skip, st->L));
+        }
         const unsigned blocks = (unsigned) div_up(N, 256);
         BT_CHECK(st->packed.alloc(ctx->pool, N * PackStride<D>::value * (int64_t) sizeof(T)));
         T *packed = (T *) st->packed.get();
