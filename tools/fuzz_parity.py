@@ -59,7 +59,9 @@ def make_case(seed):
     if rng.random() < 0.4:
         targets = points(int(rng.choice([1, 50, 2000, 15000])), shift=float(rng.random()))
     trav_kw = {"well_sep_is_n_away": int(rng.choice([1, 1, 2]))}
-    if targets is not None and rng.random() < 0.5:
+    # (level-restricted trees with extents are left out: upstream's own result there
+    # has boxes flagged as split whose children never materialise)
+    if targets is not None and kind != "adaptive-level-restricted" and rng.random() < 0.5:
         nt = len(targets[0])
         kw["target_radii"] = (2.0 ** rng.uniform(-12, -2, nt)).astype(dtype)
         kw["stick_out_factor"] = float(rng.choice([0.0, 0.1, 0.25]))
