@@ -18,7 +18,8 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def test_random_configurations(first_seed):
     import fuzz_parity
     stats = fuzz_parity.run(80, first_seed, verbose=False, aux=False)
-    assert stats["ok"] + stats["max_levels"] + stats.get("beyond_int_shift", 0) == 80
+    assert (stats["ok"] + stats["max_levels"] + stats.get("beyond_int_shift", 0)
+            + stats.get("beyond_key_depth", 0)) == 80
     assert stats["ok"] >= 70
 
 
@@ -27,7 +28,8 @@ def test_random_configurations_with_the_callers_next_to_the_path():
     and rotation classes, cost-model loops, depth-first order and work partition."""
     import fuzz_parity
     stats = fuzz_parity.run(40, 3000, verbose=False, aux=True)
-    assert stats["ok"] + stats["max_levels"] + stats.get("beyond_int_shift", 0) == 40
+    assert (stats["ok"] + stats["max_levels"] + stats.get("beyond_int_shift", 0)
+            + stats.get("beyond_key_depth", 0)) == 40
     assert stats["ok"] >= 35
 
 

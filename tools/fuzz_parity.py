@@ -235,6 +235,14 @@ def run(ncases, first_seed, verbose=True, aux=True):
                   f"kw={ {k: (v if np.ndim(v) == 0 else '...') for k, v in kw.items()} }",
                   flush=True)
             raise
+        if oerr is None and derr is not None:
+            # documented deviation: the 64-bit key addresses min(31, 63 // d) levels
+            # (min(31, 57 // d) with extents); deeper trees raise instead of differing
+            dims_ = len(particles)
+            key_levels = min(31, (57 if "target_radii" in kw else 63) // dims_)
+            assert otree.nlevels - 1 > key_levels, (seed, otree.nlevels, key_levels)
+            stats["beyond_key_depth"] = stats.get("beyond_key_depth", 0) + 1
+            continue
         assert (oerr is None) == (derr is None), (seed, oerr, derr)
         if oerr is not None:
             stats["max_levels"] += 1
