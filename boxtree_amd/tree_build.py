@@ -453,6 +453,22 @@ class TreeBuilder:
             _is_pruned=not kwargs.get("skip_prune"),
         )
 
+        if srcntgts_have_extent and kind == "adaptive-level-restricted":
+            # Upstream never tests this combination, and its algorithm -- followed line
+            # by line by the oracle, and mirrored here -- can leave a box without
+            # children whose particles are not all its own: particles no leaf owns
+            # (tools/fuzz_parity.py seed 100310 with lr_extents=True; DESIGN.md section
+            # 2).  Such a tree is not handed out.
+            nb = int(tree.nboxes)
+            childless = (tree.box_child_ids[:, :nb] == 0).all(dim=0)
+            orphaned = childless & (
+                (tree.box_source_counts_nonchild != tree.box_source_counts_cumul)
+                | (tree.box_target_counts_nonchild != tree.box_target_counts_cumul))
+            if bool(orphaned.any()):
+                raise RuntimeError(
+                    "kind='adaptive-level-restricted' with particle extents left "
+                    f"{int(orphaned.sum())} boxes whose particles no leaf owns; this input "
+                    "is not supported")
         return actx.freeze(tree), DoneEvent()
 
 # vim: foldmethod=marker

@@ -210,6 +210,23 @@ def test_argument_errors(actx):
            target_radii=actx.from_numpy(np.zeros(10, np.float32)))
 
 
+def test_level_restriction_with_extents_refuses_orphaned_particles(actx):
+    """upstream's algorithm can leave particles that no leaf owns
+    when level restriction meets extents; such a tree is not handed out."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "tools"))
+    import fuzz_parity
+    from boxtree_amd import TreeBuilder
+    p, t, kw, _ = fuzz_parity.make_case(100310, lr_extents=True)
+    assert kw["kind"] == "adaptive-level-restricted" and "target_radii" in kw
+    dkw = dict(kw, target_radii=actx.from_numpy(kw["target_radii"]))
+    with pytest.raises(RuntimeError, match="no leaf owns"):
+        TreeBuilder(actx)(actx, [actx.from_numpy(a) for a in p],
+                          targets=[actx.from_numpy(a) for a in t], **dkw)
+
+
 # ---- traversals ---------------------------------------------------------------------
 
 @pytest.mark.parametrize("dims,sat", [(2, True), (2, False), (3, True), (3, False)])

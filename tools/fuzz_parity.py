@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def make_case(seed):
+def make_case(seed, lr_extents=False):
     rng = np.random.default_rng(seed)
     dims = int(rng.choice([1, 2, 3], p=[0.1, 0.4, 0.5]))
     dtype = np.float64 if rng.random() < 0.7 else np.float32
@@ -61,7 +61,8 @@ def make_case(seed):
     trav_kw = {"well_sep_is_n_away": int(rng.choice([1, 1, 2]))}
     # (level-restricted trees with extents are left out: upstream's own result there
     # has boxes flagged as split whose children never materialise)
-    if targets is not None and kind != "adaptive-level-restricted" and rng.random() < 0.5:
+    if (targets is not None and (lr_extents or kind != "adaptive-level-restricted")
+            and rng.random() < 0.5):
         nt = len(targets[0])
         kw["target_radii"] = (2.0 ** rng.uniform(-12, -2, nt)).astype(dtype)
         kw["stick_out_factor"] = float(rng.choice([0.0, 0.1, 0.25]))
