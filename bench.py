@@ -11,6 +11,8 @@ Workloads (BASELINE.json configs):
   c2  3D uniform, 10^7 sources=targets, max_particles_in_box=64
   c3  3D sphere surface, 10^8 points, max_particles_in_box=64   (default: the
       configuration the metric "3D 10^8 pts" is quoted on)
+  c3c the clustered variant of c3: z -> sign(z)|z|^(1/4), renormalised
+  c1  2D uniform, 10^5 points, max_particles_in_box=30 (the reference's CPU-runnable case)
   c4  3D 10^8 sources + 10^7 targets with target radii, stick_out_factor=0.25
 For --gpus N > 1 every rank holds its own chunk of the workload (weak scaling):
 global bounding box by RCCL all-reduce, particles exchanged all-to-all by
@@ -39,11 +41,11 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c3c", "c4", "c5"])
     ap.add_argument("--n", type=int, default=None, help="override particle count per GPU")
     ap.add_argument("--cpu-sample", type=int, default=16_000_000,
                     help="particles in the CPU-baseline sample (0 disables)")
-    ap.add_argument("--mpb", type=int, default=64)
+    ap.add_argument("--mpb", type=int, default=None)
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 code path (exchange, numbering, gather) even with one rank")
     return ap.parse_args()
@@ -63,14 +65,27 @@ def make_workload(torch, device, workload, n, seed):
         pts = [torch.rand(n, generator=g, dtype=f64, device=device) for _ in range(3)]
         return dict(name="3D uniform random, sources=targets", n=n, particles=pts,
                     targets=None, kw={})
-    if workload == "c3":
+    if workload == "c1":
+        n = n or 10**5
+        pts = [torch.rand(n, generator=g, dtype=f64, device=device) for _ in range(2)]
+        return dict(name="2D uniform random, sources=targets", n=n, particles=pts,
+                    targets=None, kw={})
+    if workload in ("c3", "c3c"):
         n = n or 10**8
         v = [torch.randn(n, generator=g, dtype=f64, device=device) for _ in range(3)]
         nrm = torch.sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2])
         pts = [(c / nrm).contiguous() for c in v]
         del v, nrm
-        return dict(name="3D sphere-surface points, sources=targets", n=n, particles=pts,
-                    targets=None, kw={})
+        name = "3D sphere-surface points, sources=targets"
+        if workload == "c3c":
+            # polar-cap concentration: z -> sign(z)|z|^(1/4), renormalised
+            z = torch.sign(pts[2]) * torch.abs(pts[2]) ** 0.25
+            nrm = torch.sqrt(pts[0] * pts[0] + pts[1] * pts[1] + z * z)
+            pts = [(pts[0] / nrm).contiguous(), (pts[1] / nrm).contiguous(),
+                   (z / nrm).contiguous()]
+            del z, nrm
+            name = "3D sphere surface clustered towards the poles, sources=targets"
+        return dict(name=name, n=n, particles=pts, targets=None, kw={})
     if workload == "c4":
         n = n or 10**8
         nt = max(n // 10, 1)
@@ -89,18 +104,30 @@ def make_workload_numpy(workload, n, seed):
     rng = np.random.default_rng(seed)
     if workload in ("c2", "c5"):
         return dict(particles=[rng.random(n) for _ in range(3)], targets=None, kw={})
-    if workload == "c3":
+    if workload == "c1":
+        return dict(particles=[rng.random(n) for _ in range(2)], targets=None, kw={})
+    if workload in ("c3", "c3c"):
         v = rng.standard_normal((3, n))
         v /= np.sqrt((v * v).sum(axis=0))
+        if workload == "c3c":
+            v[2] = np.sign(v[2]) * np.abs(v[2]) ** 0.25
+            v /= np.sqrt((v * v).sum(axis=0))
         return dict(particles=[np.ascontiguousarray(v[i]) for i in range(3)],
                     targets=None, kw={})
     if workload == "c4":
+        # sources default_rng(15), targets default_rng(16), radii
+        # 2**default_rng(12).uniform(-10, 0) * 2^-7
         nt = max(n // 10, 1)
+        trng = np.random.default_rng(seed + 1)
         return dict(particles=[rng.random(n) for _ in range(3)],
-                    targets=[rng.random(nt) for _ in range(3)],
-                    kw=dict(target_radii=2.0 ** (-10.0 * rng.random(nt)) * 2.0 ** -7,
+                    targets=[trng.random(nt) for _ in range(3)],
+                    kw=dict(target_radii=2.0 ** np.random.default_rng(12).uniform(-10, 0, nt)
+                            * 2.0 ** -7,
                             stick_out_factor=0.25))
     raise ValueError(workload)
+
+
+WORKLOAD_MPB = {"c1": 30}      # max_particles_in_box of a workload (64 unless listed)
 
 # }}}
 
@@ -126,6 +153,8 @@ def cpu_baseline(workload, n_sample, mpb):
 
 def main():
     args = parse_args()
+    if args.mpb is None:
+        args.mpb = WORKLOAD_MPB.get(args.workload, 64)
     import torch
     import torch.distributed as dist
 

@@ -41,16 +41,18 @@ class ConstantOneExpansionWrangler:
 
     def _source_box_weights(self, actx, src_weights):
         """[nboxes] sum of the weights of each box's own sources."""
-        key = src_weights.data_ptr()
-        if self._box_weight_cache is not None and self._box_weight_cache[0] == key:
-            return self._box_weight_cache[1]
+        # keyed on the tensor object and its version counter: an address alone is
+        # recycled by the caching allocator for the next call's weights
+        c = self._box_weight_cache
+        if c is not None and c[0] is src_weights and c[1] == src_weights._version:
+            return c[2]
         tree = self.tree
         out = actx.zeros(int(tree.nboxes), np.float64)
         actx.sync_in()
         self._call(actx, actx.lib.bt_fmm_box_particle_sums(
             actx.handle, int(tree.nboxes), None, ptr(tree.box_source_starts),
             ptr(tree.box_source_counts_nonchild), ptr(src_weights), ptr(out), 0))
-        self._box_weight_cache = (key, out)
+        self._box_weight_cache = (src_weights, src_weights._version, out)
         return out
 
     def _csr_rows(self, actx, starts, lists, box_values):

@@ -288,9 +288,9 @@ def all_to_all_chunked(dist, recv, send, r_split, s_split, limit_bytes=None,
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         biggest = int(t.item())
     rounds = max(1, -(-biggest // limit_bytes))
-    if rounds == 1 and s_split[me] * es <= limit_bytes:
-        dist.all_to_all_single(recv, send, r_split, s_split)
-        return 1
+    # The self segment is always a device copy and every decision below uses the
+    # globally agreed `biggest` only: a choice that depended on a rank's own segment
+    # sizes could send some ranks into a collective the others skip.
     if s_split[me]:
         recv[r_off[me]:r_off[me + 1]].copy_(send[s_off[me]:s_off[me + 1]])
     if biggest == 0:
@@ -388,7 +388,10 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
     # the histogram alone: ownership respects its leaves and the local builds split
     # the shared top boxes where the global tree does (TreeBuilder ``_top_tree``).
     plan = None
-    if (max_particles_in_box is not None and source_radii is None and target_radii is None
+    # (separate targets: the flags of the shared top boxes would need per-cell source
+    # AND target counts; the plan is for sources == targets)
+    if (max_particles_in_box is not None and targets is None
+            and source_radii is None and target_radii is None
             and build_kw.get("refine_weights") is None
             and build_kw.get("kind", "adaptive") == "adaptive"):
         plan = top_tree_plan(ghist, dims, top_level, max_particles_in_box)

@@ -276,12 +276,14 @@ class FMMTraversalBuilder:
         out.source_parent_boxes = ptr(source_parent_boxes)
         out.target_or_target_parent_boxes = ptr(target_or_target_parent_boxes)
 
-        lev = {}
-        for name in ("level_start_source_box_nrs", "level_start_target_box_nrs",
+        # the four level-start arrays are host arrays in the reference
+        # (traversal.py:2091 actx.to_numpy(result)): one device block, one transfer
+        lev_names = ("level_start_source_box_nrs", "level_start_target_box_nrs",
                      "level_start_source_parent_box_nrs",
-                     "level_start_target_or_target_parent_box_nrs"):
-            lev[name] = e(nlevels + 1, i32)
-            setattr(out, name, ptr(lev[name]))
+                     "level_start_target_or_target_parent_box_nrs")
+        lev_block = e(4 * (nlevels + 1), i32)
+        for k, name in enumerate(lev_names):
+            setattr(out, name, ct.c_void_p(lev_block.data_ptr() + 4 * k * (nlevels + 1)))
 
         def csr(prefix, n, total):
             starts = e(n + 1, i32)
@@ -315,6 +317,8 @@ class FMMTraversalBuilder:
             l3.append((nne, cnt, arrs))
 
         _lib.check(lib.bt_traversal_export(actx.handle, ct.byref(out)))
+        lev_host = lev_block.cpu().numpy().reshape(4, nlevels + 1)
+        lev = {name: np.ascontiguousarray(lev_host[k]) for k, name in enumerate(lev_names)}
 
         from_sep_smaller_by_level = make_obj_array([
             BuiltList(count=cnt, starts=a["starts"], lists=a["lists"],

@@ -85,7 +85,11 @@ class TreeOfBoxes(_Container):
 
     @property
     def bounding_box(self):
-        lows = self.box_centers[:, 0] - 0.5 * self.root_extent
+        # host values also for device-resident box arrays (local essential trees)
+        c0 = self.box_centers[:, 0]
+        if not isinstance(c0, np.ndarray):
+            c0 = c0.detach().cpu().numpy()
+        lows = c0 - 0.5 * self.root_extent
         return lows, lows + self.root_extent
 
     def get_box_size(self, ibox):

@@ -125,3 +125,18 @@ def test_fmm_completeness(oracle, dims, ns, nt, ext, extent_norm, crit,
                                   from_sep_smaller_crit=crit)
     pot = constant_one_potentials(tree, trav)
     assert np.all(pot == ns)
+
+
+def test_config_c1_exact_recipe(oracle):
+    """BASELINE configs[0] (the reference's CPU-runnable case): 2D uniform,
+    default_rng(15).random, 10^5 sources = targets, max_particles_in_box = 30 --
+    tree invariants, traversal connectivity and interaction completeness."""
+    from bench import WORKLOAD_MPB, make_workload_numpy
+    w = make_workload_numpy("c1", 10**5, 15)
+    mpb = WORKLOAD_MPB["c1"]
+    tree = oracle.build_tree(w["particles"], max_particles_in_box=mpb)
+    check_tree(tree, w["particles"], max_particles_in_box=mpb)
+    trav = oracle.build_traversal(tree)
+    check_traversal(tree, trav)
+    pot = constant_one_potentials(tree, trav)
+    assert np.all(pot == tree.nsources)
