@@ -127,6 +127,20 @@ struct bt_context {
     int last_sort64_passes = 0;
     int64_t last_sort64_n = 0;
     float stage_ms[32] = {0};
+    // single-pass scan (bt_prims.hpp): tile descriptors tagged with a generation,
+    // one never-reset ticket counter; both survive from call to call
+    uint64_t *scan_desc = nullptr;
+    int64_t scan_desc_cap = 0;
+    uint32_t *scan_ticket = nullptr;
+    uint32_t scan_ticket_base = 0;
+    uint32_t scan_gen = 0;
+    // sort timing is resolved lazily (bt_get_sort_stats): events of the last sort
+    void *sort_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int sort_ev_passes = 0, sort_ev_first_identity = 0, sort_ev_key_bytes = 0;
+    int64_t sort_ev_n = 0;
+    bool sort_ev_pending = false;
+    // statistics of the last build (host-side counters)
+    int n_host_syncs = 0;
 };
 
 namespace bt {

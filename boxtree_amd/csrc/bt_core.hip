@@ -1,6 +1,7 @@
 // Context, error strings, caching device allocator.
 #include "bt_common.hpp"
 
+#include <algorithm>
 #include <cstdarg>
 
 namespace bt {
@@ -96,6 +97,38 @@ void Pool::release_all()
     reserved_ = 0;
 }
 
+// descriptor storage and ticket base of the next single-pass scan (bt_prims.hpp)
+int scan_prepare(bt_context *ctx, int64_t ntiles, uint32_t *gen, uint32_t *ticket_base)
+{
+    if (!ctx->scan_ticket) {
+        BT_HIP_CHECK(hipMalloc((void **) &ctx->scan_ticket, 256));
+        BT_HIP_CHECK(hipMemsetAsync(ctx->scan_ticket, 0, 256, ctx->stream));
+        ctx->scan_ticket_base = 0;
+    }
+    bool fresh = false;
+    if (ntiles > ctx->scan_desc_cap) {
+        int64_t cap = std::max<int64_t>(4096, ctx->scan_desc_cap);
+        while (cap < ntiles) cap *= 2;
+        if (ctx->scan_desc) {
+            // earlier scans on this stream still read the old array
+            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            (void) hipFree(ctx->scan_desc);
+            ctx->scan_desc = nullptr;
+        }
+        BT_HIP_CHECK(hipMalloc((void **) &ctx->scan_desc, (size_t) cap * 8));
+        ctx->scan_desc_cap = cap;
+        fresh = true;
+    }
+    ctx->scan_gen = (ctx->scan_gen + 1) & ((1u << 22) - 1);
+    if (ctx->scan_gen == 0) { ctx->scan_gen = 1; fresh = true; }     // tags wrapped
+    if (fresh)
+        BT_HIP_CHECK(hipMemsetAsync(ctx->scan_desc, 0, (size_t) ctx->scan_desc_cap * 8, ctx->stream));
+    *gen = ctx->scan_gen;
+    *ticket_base = ctx->scan_ticket_base;
+    ctx->scan_ticket_base += (uint32_t) ntiles;
+    return BT_OK;
+}
+
 int reset_status(bt_context *ctx)
 {
     BT_HIP_CHECK(hipMemsetAsync(ctx->d_status, 0, sizeof(DeviceStatus), ctx->stream));
@@ -179,6 +212,8 @@ void bt_destroy(bt_context *ctx)
     bt_free_aq_state(ctx);
     ctx->pool.release_all();
     if (ctx->d_status) (void) hipFree(ctx->d_status);
+    if (ctx->scan_desc) (void) hipFree(ctx->scan_desc);
+    if (ctx->scan_ticket) (void) hipFree(ctx->scan_ticket);
     if (ctx->h_status) (void) hipHostFree(ctx->h_status);
     if (ctx->own_stream && ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;

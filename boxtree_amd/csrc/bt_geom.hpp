@@ -13,7 +13,14 @@ struct alignas(16) Node {
     uint32_t lf;        // level | flags << 8
 };
 
-template <class T, int D>
+// child_t entries of the traversal carry two flag bits of the child next to its
+// number (boxes < 2^28 is checked on the host): a tree walk then reads one word per
+// step instead of the child's node.
+constexpr uint32_t CH_ID_MASK = (1u << 28) - 1u;
+constexpr uint32_t CH_SRC = 1u << 28;       // child is a source box
+constexpr uint32_t CH_HSC = 1u << 29;       // child has source child boxes
+
+template <class T, int D, bool PACK_FLAGS = false>
 __global__ __launch_bounds__(256) void pack_nodes_kernel(int32_t nboxes, int64_t aligned,
         const T *centers, const uint8_t *levels, const uint8_t *flags, const int32_t *child,
         Node<T, D> *nodes, int32_t *child_t)
@@ -27,7 +34,16 @@ __global__ __launch_bounds__(256) void pack_nodes_kernel(int32_t nboxes, int64_t
     n.lf = (uint32_t) levels[b] | ((uint32_t) flags[b] << 8);
     nodes[b] = n;
 #pragma unroll
-    for (int m = 0; m < C; ++m) child_t[(int64_t) b * C + m] = child[(int64_t) m * aligned + b];
+    for (int m = 0; m < C; ++m) {
+        const int32_t c = child[(int64_t) m * aligned + b];
+        uint32_t e = (uint32_t) c;
+        if (PACK_FLAGS && c > 0 && c < nboxes) {
+            const uint8_t cf = flags[c];
+            if (cf & BT_BOX_IS_SOURCE_BOX) e |= CH_SRC;
+            if (cf & BT_BOX_HAS_SOURCE_CHILD_BOXES) e |= CH_HSC;
+        }
+        child_t[(int64_t) b * C + m] = (int32_t) e;
+    }
 }
 
 template <class T>

@@ -158,8 +158,138 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_final_kernel(F f, int64_t n
     }
 }
 
+// ---------------------------------------------------------------------------
+// single-pass variant (chained scan with decoupled look-back): ONE launch, the
+// input is read once.  Tiles take tickets from a counter that is never reset (the
+// host passes the value it has at launch: stream order makes that exact), so a tile
+// only ever waits for tiles that are resident or finished.  A tile publishes one
+// relaxed agent-scope 64-bit word {generation:22 | flag:2 | value:40} -- the data is
+// the flag -- first its aggregate, then its inclusive prefix; the generation tag
+// makes stale words of earlier scans in the same (persistent) array invisible, so
+// nothing is cleared between calls.  Values saturate at 2^40-1: every caller that
+// scans into 32-bit outputs treats totals >= 2^31 as an error anyway.
+// ---------------------------------------------------------------------------
+
+constexpr uint64_t SP_VAL_MASK = (1ull << 40) - 1;
+constexpr uint32_t SP_AGG = 1, SP_PREFIX = 2;
+constexpr uint32_t SP_GEN_MASK = (1u << 22) - 1;
+constexpr uint32_t SP_SPIN_LIMIT = 1u << 24;
+
+__device__ __forceinline__ uint64_t sp_pack(uint32_t gen, uint32_t flag, uint64_t v)
+{
+    if (v > SP_VAL_MASK) v = SP_VAL_MASK;
+    return ((uint64_t) gen << 42) | ((uint64_t) flag << 40) | v;
+}
+
+__device__ __forceinline__ uint64_t sp_add_sat(uint64_t a, uint64_t b)
+{
+    const uint64_t r = a + b;
+    return r > SP_VAL_MASK ? SP_VAL_MASK : r;
+}
+
+template <class AccT, class OutT, class F>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_single_pass_kernel(F f, int64_t n, OutT *out,
+        AccT *d_total, bool write_total_at_n, uint64_t *desc, uint32_t *ticket_counter,
+        uint32_t ticket_base, uint32_t gen, DeviceStatus *status)
+{
+    constexpr int NW = SCAN_THREADS / 64;
+    using W = uint32_t;
+    __shared__ uint32_t s_tile;
+    __shared__ W s_wave[NW];
+    __shared__ uint64_t s_wave_tot[NW];
+    __shared__ uint64_t s_excl;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket_counter, 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const int w = threadIdx.x >> 6, lane = lane_id();
+    const int64_t wave_base = (int64_t) tile * SCAN_TILE + (int64_t) w * (64 * SCAN_ITEMS);
+    W v[SCAN_ITEMS], ex[SCAN_ITEMS];
+    uint64_t mine = 0;                 // exact (64-bit) sum of this lane's items
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = wave_base + k * 64 + lane;
+        const AccT x = (i < n) ? (AccT) f(i) : (AccT) 0;
+        v[k] = (W) x;
+        mine += (uint64_t) x;
+    }
+    W carry = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const W incl = wave_inclusive_scan(v[k]);
+        ex[k] = carry + incl - v[k];
+        carry += __shfl(incl, 63, 64);
+    }
+    mine = wave_reduce_sum(mine);
+    if (lane == 0) { s_wave[w] = carry; s_wave_tot[w] = mine; }
+    __syncthreads();
+    if (w == 0) {
+        uint64_t agg = 0;
+#pragma unroll
+        for (int i = 0; i < NW; ++i) agg += s_wave_tot[i];
+        uint64_t excl = 0;
+        if (tile == 0) {
+            if (lane == 0)
+                __hip_atomic_store(desc, sp_pack(gen, SP_PREFIX, agg), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0)
+                __hip_atomic_store(desc + tile, sp_pack(gen, SP_AGG, agg), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            int64_t look = (int64_t) tile - 1;
+            uint32_t spins = 0;
+            while (true) {
+                const int64_t idx = look - lane;
+                uint64_t word = sp_pack(gen, SP_PREFIX, 0);     // before tile 0: prefix 0
+                if (idx >= 0)
+                    word = __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t flag = (uint32_t) (word >> 40) & 3u;
+                const bool valid = (uint32_t) (word >> 42) == gen && flag != 0;
+                const uint64_t is_prefix = __ballot(valid && flag == SP_PREFIX);
+                const uint64_t invalid = __ballot(!valid);
+                const int first_prefix = is_prefix ? __builtin_ctzll(is_prefix) : 64;
+                const int first_invalid = invalid ? __builtin_ctzll(invalid) : 64;
+                if (first_invalid <= first_prefix && first_invalid < 64) {
+                    // a descriptor this window needs is not there yet
+                    if (++spins > SP_SPIN_LIMIT) {
+                        if (lane == 0) atomicExch(&status->internal, 77);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    continue;
+                }
+                uint64_t val = (lane <= first_prefix) ? (word & SP_VAL_MASK) : 0ull;
+                val = wave_reduce_sum(val);
+                excl = sp_add_sat(excl, val);
+                if (first_prefix < 64) break;
+                look -= 64;
+            }
+            if (lane == 0)
+                __hip_atomic_store(desc + tile, sp_pack(gen, SP_PREFIX, sp_add_sat(excl, agg)),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_excl = excl;
+        const int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+        if (lane == 0 && (int64_t) tile == ntiles - 1) {
+            const uint64_t tot = sp_add_sat(excl, agg);
+            if (d_total) *d_total = (AccT) tot;
+            if (write_total_at_n) out[n] = (OutT) tot;
+        }
+    }
+    __syncthreads();
+    uint64_t run = s_excl;
+#pragma unroll
+    for (int i = 0; i < NW; ++i)
+        if (i < w) run += (uint64_t) s_wave[i];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const int64_t i = wave_base + k * 64 + lane;
+        if (i < n) out[i] = (OutT) (run + (uint64_t) ex[k]);
+    }
+}
+
+int scan_prepare(bt_context *ctx, int64_t ntiles, uint32_t *gen, uint32_t *ticket_base);   // bt_core.hip
+
 // out must have n (+1 if write_total_at_n) elements.  d_total may be null.
-// tile_sums scratch: div_up(n, SCAN_TILE) AccT elements.
 template <class AccT, class OutT, class F>
 int device_exclusive_scan(bt_context *ctx, F f, int64_t n, OutT *out, AccT *d_total,
                           bool write_total_at_n = false)
@@ -170,16 +300,28 @@ int device_exclusive_scan(bt_context *ctx, F f, int64_t n, OutT *out, AccT *d_to
         return BT_OK;
     }
     const int64_t ntiles = div_up(n, SCAN_TILE);
-    Buf<AccT> sums;
-    BT_CHECK(sums.alloc(ctx->pool, ntiles));
-    scan_reduce_kernel<AccT, F><<<(unsigned) ntiles, SCAN_THREADS, 0, ctx->stream>>>(f, n, sums.get());
-    scan_tile_sums_kernel<AccT><<<1, 1024, 0, ctx->stream>>>(sums.get(), ntiles, d_total);
-    scan_final_kernel<AccT, OutT, F><<<(unsigned) ntiles, SCAN_THREADS, 0, ctx->stream>>>(
-        f, n, sums.get(), out, write_total_at_n);
-    BT_HIP_CHECK(hipGetLastError());
-    return BT_OK;
-    // note: `sums` returns to the pool here; the pool never hands memory to
-    // another stream and all work is stream-ordered, so reuse is safe.
+    if constexpr (std::is_integral<AccT>::value && sizeof(OutT) == 4) {
+        uint32_t gen = 0, base = 0;
+        BT_CHECK(scan_prepare(ctx, ntiles, &gen, &base));
+        scan_single_pass_kernel<AccT, OutT, F><<<(unsigned) ntiles, SCAN_THREADS, 0, ctx->stream>>>(
+            f, n, out, d_total, write_total_at_n, ctx->scan_desc, ctx->scan_ticket, base, gen,
+            ctx->d_status);
+        BT_HIP_CHECK(hipGetLastError());
+        return BT_OK;
+    } else {
+        // wide outputs (weight prefix sums, floating-point costs): reduce, scan the
+        // tile sums, rescan
+        Buf<AccT> sums;
+        BT_CHECK(sums.alloc(ctx->pool, ntiles));
+        scan_reduce_kernel<AccT, F><<<(unsigned) ntiles, SCAN_THREADS, 0, ctx->stream>>>(f, n, sums.get());
+        scan_tile_sums_kernel<AccT><<<1, 1024, 0, ctx->stream>>>(sums.get(), ntiles, d_total);
+        scan_final_kernel<AccT, OutT, F><<<(unsigned) ntiles, SCAN_THREADS, 0, ctx->stream>>>(
+            f, n, sums.get(), out, write_total_at_n);
+        BT_HIP_CHECK(hipGetLastError());
+        return BT_OK;
+        // note: `sums` returns to the pool here; the pool never hands memory to
+        // another stream and all work is stream-ordered, so reuse is safe.
+    }
 }
 
 }  // namespace bt

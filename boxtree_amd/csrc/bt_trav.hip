@@ -11,6 +11,8 @@
 #include "bt_geom.hpp"
 
 #include <algorithm>
+#include <climits>
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
@@ -48,6 +50,7 @@ struct TravArgs {
     // kernel only; srccoll_stride == 0 otherwise)
     const int32_t *srccoll_rows, *srccoll_cnt;
     int srccoll_stride;
+    uint32_t srccoll_id_mask;       // row entries carry lattice codes above these bits
     const int8_t *target_mask;      // sharded traversals: boxes whose lists are wanted
     const int32_t *dfs_rank;        // preorder rank (parent-colleague kernels)
 };
@@ -67,7 +70,7 @@ __device__ __forceinline__ uint8_t box_flags(const TravArgs<T, D> &a, int32_t bo
 template <int D, class T>
 __device__ __forceinline__ int32_t child_of(const TravArgs<T, D> &a, int32_t box, int m)
 {
-    return a.child_t[(int64_t) box * (1 << D) + m];
+    return (int32_t) ((uint32_t) a.child_t[(int64_t) box * (1 << D) + m] & CH_ID_MASK);
 }
 
 template <class T, int D>
@@ -340,7 +343,7 @@ __device__ __forceinline__ void gen_list4(const TravArgs<T, D> &a, int32_t it, E
         const int64_t s1 = rows ? s0 + a.srccoll_cnt[cur] : a.coll_starts[cur + 1];
         const int32_t *src = rows ? a.srccoll_rows : a.coll_lists;
         for (int64_t i = s0; i < s1; ++i) {
-            const int32_t sb = src[i];
+            const int32_t sb = rows ? (int32_t) ((uint32_t) src[i] & a.srccoll_id_mask) : src[i];
             if (!rows && !(box_flags(a, sb) & BT_BOX_IS_SOURCE_BOX)) continue;
             T sc[D];
             load_center(a, sb, sc);
@@ -559,6 +562,7 @@ __global__ __launch_bounds__(256) void merge_copy_kernel(int32_t n, MergeCount m
 }
 
 #include "bt_trav_fast.hpp"
+#include "bt_trav_v2.hpp"
 
 // ---- merging CSR lists row by row (_ListMerger, traversal.py:1153-1344) ----------
 
@@ -629,6 +633,10 @@ struct TravState {
     Buf<unsigned char> nodes;          // packed Node<T, D>[nboxes]
     Buf<int32_t> child_t;              // [nboxes][C]
     bool fast = false;
+    bool lattice = false;              // bt_trav_v2.hpp kernels apply
+    bool has_blocks = true;            // some target box has source boxes below it
+    Buf<unsigned char> cells;          // ICell[nboxes]
+    Buf<uint8_t> slot_of;
     std::vector<std::pair<const char *, hipEvent_t>> events;
     bool built = false;
 };
@@ -1044,6 +1052,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         a.srccoll_rows = srccoll_rows.get();       // list 4 walks the same rows
         a.srccoll_cnt = srccoll_cnt.get();
         a.srccoll_stride = COLL_STRIDE;
+        a.srccoll_id_mask = ~0u;
     } else {
         BT_CHECK(lcoll_starts_buf.alloc(ctx->pool, B + 1));
         filter_source_colleagues_kernel<T, D, false><<<nblk(B), 256, 0, ctx->stream>>>(
@@ -1161,17 +1170,343 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
                                                                    list.get());
             if (which == 1)
                 l1_finalize_wave_kernel<T, D><<<(unsigned) div_up(cnt, 4), 256, 0, ctx->stream>>>(
-                    a, ft, list.get(), cnt, c1.starts.get(), c1.lists.get(), jobs);
+                    a, ft, list.get(), pos.get() + ntb, c1.starts.get(), c1.lists.get(), jobs);
             else
                 l1_finalize_block_kernel<T, D><<<cnt, 256, 0, ctx->stream>>>(
-                    a, ft, list.get(), c1.starts.get(), c1.lists.get(), jobs);
+                    a, ft, list.get(), pos.get() + ntb, c1.starts.get(), c1.lists.get(), jobs);
             BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));    // `list` is freed on scope exit
         }
         int32_t njobs = 0;
         BT_CHECK(read_i32(ctx, jobs.count, &njobs));
         if (njobs > 0)
             copy_rank_blocks_kernel<<<njobs, 256, 0, ctx->stream>>>(
-                jobs.dst, jobs.src, jobs.len, st->src_by_rank.get(), c1.lists.get());
+                jobs.count, jobs.dst, jobs.src, jobs.len, st->src_by_rank.get(), c1.lists.get());
+    }
+    BT_CHECK(tmark(ctx, st, "trav:list1+list3"));
+    BT_HIP_CHECK(hipGetLastError());
+    return BT_OK;
+}
+
+// ---- lattice kernels (bt_trav_v2.hpp): colleagues, lists 1-3, close-smaller -------------
+//
+// Everything is counted first (rows with exact counts), the totals of all lists come
+// back in ONE host synchronisation, then every list is written to its final place.
+
+__global__ __launch_bounds__(256) void gather_i32_kernel(int32_t n, const int32_t *idx,
+                                                         const int32_t *src, int32_t *dst)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+
+// out[i] = starts_by_box[boxes[i]] (i < n), out[n] = starts_by_box[last]
+__global__ __launch_bounds__(256) void gather_starts_dev_kernel(int32_t n, const int32_t *boxes,
+        const int32_t *starts_by_box, int32_t last, int32_t *out)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = starts_by_box[boxes[i]];
+    if (i == n) out[n] = starts_by_box[last];
+}
+
+template <class T, int D>
+int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
+{
+    constexpr int C = 1 << D;
+    constexpr int P = V2Dims<D>::P;
+    const bt_trav_params &p = st->p;
+    const int64_t B = p.nboxes;
+    const int nlevels = p.nlevels;
+    const int32_t *ls = p.level_start_box_nrs;       // host
+    const int walk_cap = nlevels + 1;
+    const size_t walk_lds = (size_t) walk_cap * WALK_THREADS * 4;
+    const size_t lvl_lds = (size_t) nlevels * WALK_THREADS * 4;
+    const int64_t ntb = st->ntb;
+    const bool with_blocks = st->has_blocks;
+
+    // ---- per-tree tables ----------------------------------------------------------
+    BT_CHECK(st->subtree_size.alloc(ctx->pool, B));
+    BT_CHECK(st->dfs_rank.alloc(ctx->pool, B));
+    BT_CHECK(st->box_of_rank.alloc(ctx->pool, B));
+    BT_CHECK(st->slot_of.alloc(ctx->pool, B));
+    BT_CHECK(st->cells.alloc(ctx->pool, B * (int64_t) sizeof(ICell)));
+    ICell *cells = (ICell *) st->cells.get();
+    for (int lev = nlevels - 1; lev >= 0; --lev)
+        subtree_size_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
+            ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
+            st->subtree_size.get());
+    for (int lev = 0; lev < nlevels; ++lev)
+        dfs_rank_cells_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
+            ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
+            st->subtree_size.get(), p.box_levels, p.box_flags, st->dfs_rank.get(),
+            st->box_of_rank.get(), st->slot_of.get(), cells);
+    if (with_blocks) {
+        // source boxes in depth-first order (+ prefix counts over ranks): own-subtree blocks
+        BT_CHECK(st->src_rank_prefix.alloc(ctx->pool, B + 1));
+        SourceRankFlag<T, D> f{a.nodes, st->box_of_rank.get()};
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, f, B, st->src_rank_prefix.get(),
+                                                          (int32_t *) nullptr, true)));
+        BT_CHECK(st->src_by_rank.alloc(ctx->pool, B + 1));
+        compact_sources_by_rank_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
+            f, (int32_t) B, st->src_rank_prefix.get(), st->src_by_rank.get());
+    }
+    a.dfs_rank = st->dfs_rank.get();
+    FastTree ft{st->dfs_rank.get(), st->box_of_rank.get(), st->subtree_size.get(),
+                st->src_rank_prefix.get(), st->src_by_rank.get()};
+
+    // ---- colleague rows, level by level ----------------------------------------------
+    Buf<int32_t> coll_rows, coll_cnt, coll_ins, l2_cnt;
+    Buf<int32_t> &srccoll_rows = st->srccoll_rows, &srccoll_cnt = st->srccoll_cnt;
+    BT_CHECK(coll_rows.alloc(ctx->pool, B * P));
+    BT_CHECK(srccoll_rows.alloc(ctx->pool, B * P));
+    // coll_cnt | coll_ins | srccoll_cnt | l2_cnt are zeroed together
+    Buf<int32_t> zeroed;
+    BT_CHECK(zeroed.alloc(ctx->pool, 3 * B));
+    BT_CHECK(srccoll_cnt.alloc(ctx->pool, B));
+    BT_HIP_CHECK(hipMemsetAsync(zeroed.get(), 0, (size_t) (3 * B) * 4, ctx->stream));
+    BT_HIP_CHECK(hipMemsetAsync(srccoll_cnt.get(), 0, (size_t) B * 4, ctx->stream));
+    int32_t *d_coll_cnt = zeroed.get(), *d_coll_ins = zeroed.get() + B, *d_l2_cnt = zeroed.get() + 2 * B;
+    V2Rows<D> rows{};
+    rows.child_t = st->child_t.get();
+    rows.parent = p.box_parent_ids;
+    rows.flags = p.box_flags;
+    rows.slot_of = st->slot_of.get();
+    rows.target_mask = p.target_boxes_mask;
+    rows.coll_rows = coll_rows.get(); rows.coll_cnt = d_coll_cnt; rows.coll_ins = d_coll_ins;
+    rows.srccoll_rows = srccoll_rows.get(); rows.srccoll_cnt = srccoll_cnt.get();
+    rows.l2_cnt = d_l2_cnt;
+    for (int lev = 1; lev < nlevels; ++lev) {
+        int32_t b0 = ls[lev], nb = ls[lev + 1] - ls[lev];
+        if (p.active_level_ranges) {        // sharded traversal: this rank's boxes only
+            b0 = p.active_level_ranges[2 * lev];
+            nb = p.active_level_ranges[2 * lev + 1] - b0;
+        }
+        if (nb > 0)
+            coll_rows_v2_kernel<D, false><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(rows, b0, nb);
+    }
+    a.srccoll_rows = srccoll_rows.get();       // list 4 walks the same rows
+    a.srccoll_cnt = srccoll_cnt.get();
+    a.srccoll_stride = P;
+    a.srccoll_id_mask = V2_ID_MASK;
+    BT_CHECK(tmark(ctx, st, "trav:colleague rows"));
+
+    // ---- work items -----------------------------------------------------------------------
+    static const int heavy_margin = [] {
+        const char *e = getenv("BT_HEAVY_MARGIN");      // tuning aid
+        return e ? atoi(e) : 3;
+    }();
+    const int heavy_max_level = nlevels - heavy_margin;
+    int64_t nheavy_max = 0;
+    if (heavy_max_level >= 0) nheavy_max = std::min<int64_t>(ntb, ls[std::min(heavy_max_level + 1, nlevels)]);
+    const int64_t items_cap = std::max<int64_t>(64, div_up(ntb + (int64_t) P * nheavy_max, 64) * 64);
+    const int64_t nflat = (int64_t) nlevels * items_cap;
+    if (nflat >= ((int64_t) 1 << 31)) {
+        set_error("list 3 bookkeeping exceeds int32 range");
+        return BT_ERR_UNSUPPORTED;
+    }
+    Buf<int32_t> item_cnt, first_item, item_tbn, item_slot;
+    Buf<int64_t> totals;            // device: nitems, coll, l2, l1, l3, close
+    enum { T_NITEMS = 0, T_COLL, T_L2, T_L1, T_L3, T_CLOSE, T_OVF, T_COUNT };
+    BT_CHECK(totals.alloc(ctx->pool, T_COUNT));
+    BT_HIP_CHECK(hipMemsetAsync(totals.get(), 0, T_COUNT * 8, ctx->stream));
+    BT_CHECK(item_cnt.alloc(ctx->pool, ntb));
+    BT_CHECK(first_item.alloc(ctx->pool, ntb + 1));
+    BT_CHECK(item_tbn.alloc(ctx->pool, items_cap));
+    BT_CHECK(item_slot.alloc(ctx->pool, items_cap));
+    make_items_v2_kernel<false><<<nblk(ntb), 256, 0, ctx->stream>>>(
+        (int32_t) ntb, st->target_boxes, cells, d_coll_cnt, heavy_max_level, item_cnt.get(),
+        nullptr, nullptr);
+    BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{item_cnt.get()}, ntb,
+                                                      first_item.get(), totals.get() + T_NITEMS, true)));
+    make_items_v2_kernel<true><<<nblk(ntb), 256, 0, ctx->stream>>>(
+        (int32_t) ntb, st->target_boxes, cells, d_coll_cnt, heavy_max_level, first_item.get(),
+        item_tbn.get(), item_slot.get());
+    // the item count as int32 for the kernels: the low word of the little-endian total
+    const int32_t *d_nitems = (const int32_t *) (totals.get() + T_NITEMS);
+
+    // ---- the walk: lists 1 and 3 (+ close) into rows ------------------------------------------
+    static const int k1_env = [] { const char *e = getenv("BT_V2_K1"); return e ? atoi(e) : 0; }();
+    static const int k3_env = [] { const char *e = getenv("BT_V2_K3"); return e ? atoi(e) : 0; }();
+    const int K1 = k1_env > 0 ? k1_env : (D == 3 ? 64 : D == 2 ? 24 : 8);
+    const int K3 = k3_env > 0 ? k3_env : (D == 3 ? 32 : D == 2 ? 16 : 8);
+    const int Kc = st->with_extent ? K3 : 0;
+    Buf<int32_t> row1, row3, rowc, l1_item, l3_item, close_item, ovf_list;
+    Buf<uint8_t> row3lev, overflow;
+    BT_CHECK(row1.alloc(ctx->pool, items_cap * K1));
+    BT_CHECK(row3.alloc(ctx->pool, items_cap * K3));
+    BT_CHECK(row3lev.alloc(ctx->pool, items_cap * K3));
+    if (Kc) BT_CHECK(rowc.alloc(ctx->pool, items_cap * Kc));
+    BT_CHECK(l1_item.alloc(ctx->pool, items_cap + 1));
+    BT_CHECK(l3_item.alloc(ctx->pool, nflat + 1));
+    if (st->with_extent) BT_CHECK(close_item.alloc(ctx->pool, items_cap + 1));
+    BT_CHECK(overflow.alloc(ctx->pool, items_cap));
+    BT_CHECK(ovf_list.alloc(ctx->pool, items_cap));
+    Buf<int32_t> l1_cnt, l3_cnt, close_cnt;
+    BT_CHECK(l1_cnt.alloc(ctx->pool, items_cap));
+    BT_CHECK(l3_cnt.alloc(ctx->pool, nflat));
+    if (st->with_extent) BT_CHECK(close_cnt.alloc(ctx->pool, items_cap));
+
+    V2Walk w{};
+    w.cells = cells;
+    w.flags = p.box_flags;
+    w.child_t = st->child_t.get();
+    w.coll_rows = coll_rows.get(); w.coll_cnt = d_coll_cnt;
+    w.srccoll_rows = srccoll_rows.get(); w.srccoll_cnt = srccoll_cnt.get();
+    w.item_tbn = item_tbn.get(); w.item_slot = item_slot.get();
+    w.d_nitems = d_nitems;
+    w.items_cap = (int32_t) items_cap;
+    w.nlevels = nlevels; w.walk_cap = walk_cap;
+    w.with_blocks = with_blocks ? 1 : 0;
+    w.row1 = row1.get(); w.row3 = row3.get(); w.rowc = Kc ? rowc.get() : nullptr;
+    w.row3lev = row3lev.get();
+    w.K1 = K1; w.K3 = K3; w.Kc = Kc;
+    w.l1_cs = l1_cnt.get(); w.l3_cs = l3_cnt.get();
+    w.close_cs = st->with_extent ? close_cnt.get() : nullptr;
+    w.overflow = overflow.get();
+    w.ovf_count = (int32_t *) (totals.get() + T_OVF);
+    w.ovf_list = ovf_list.get();
+    walk13_v2_kernel<T, D, true><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
+    BT_CHECK(tmark(ctx, st, "trav:walk (rows)"));
+
+    // ---- starts of everything, totals in one transfer -------------------------------------------
+    CsrList &coll = st->coll;
+    coll.n = B;
+    Buf<int32_t> l2_by_box;
+    BT_CHECK(coll.starts.alloc(ctx->pool, B + 1));
+    BT_CHECK(l2_by_box.alloc(ctx->pool, B + 1));
+    BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{d_coll_cnt}, B, coll.starts.get(),
+                                                      totals.get() + T_COLL, true)));
+    BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{d_l2_cnt}, B, l2_by_box.get(),
+                                                      totals.get() + T_L2, true)));
+    BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{l1_cnt.get()}, items_cap,
+                                                      l1_item.get(), totals.get() + T_L1, true)));
+    BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{l3_cnt.get()}, nflat,
+                                                      l3_item.get(), totals.get() + T_L3, true)));
+    if (st->with_extent)
+        BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{close_cnt.get()}, items_cap,
+                                                          close_item.get(), totals.get() + T_CLOSE, true)));
+    int64_t h_tot[T_COUNT];
+    BT_HIP_CHECK(hipMemcpyAsync(h_tot, totals.get(), sizeof(h_tot), hipMemcpyDeviceToHost, ctx->stream));
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->n_host_syncs++;
+    for (int k = T_COLL; k <= T_CLOSE; ++k)
+        if (h_tot[k] >= ((int64_t) 1 << 31)) {
+            set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference): "
+                      "%lld", (long long) h_tot[k]);
+            return BT_ERR_UNSUPPORTED;
+        }
+    const int64_t novf = h_tot[T_OVF] & 0xffffffffll;
+
+    // ---- final places ------------------------------------------------------------------------------
+    coll.total = h_tot[T_COLL];
+    BT_CHECK(coll.lists.alloc(ctx->pool, coll.total));
+    compact_coll_rows_v2_kernel<8><<<nblk(B * 8), 256, 0, ctx->stream>>>(
+        B, P, coll_rows.get(), coll.starts.get(), coll.lists.get());
+    a.coll_starts = coll.starts.get();
+    a.coll_lists = coll.lists.get();
+    {
+        CsrList &c = st->l2;
+        c.n = st->nttp;
+        c.total = h_tot[T_L2];
+        BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
+        BT_CHECK(c.lists.alloc(ctx->pool, c.total));
+        gather_starts_dev_kernel<<<nblk(c.n + 1), 256, 0, ctx->stream>>>(
+            (int32_t) c.n, st->ttp_boxes.get(), l2_by_box.get(), (int32_t) B, c.starts.get());
+        rows.l2_starts = l2_by_box.get();
+        rows.l2_lists = c.lists.get();
+        if (B > 1 && c.total > 0)
+            coll_rows_v2_kernel<D, true><<<nblk((B - 1) * C), 256, 0, ctx->stream>>>(
+                rows, 1, (int32_t) (B - 1));
+    }
+    BT_CHECK(tmark(ctx, st, "trav:colleagues+list2"));
+
+    CsrList &c1 = st->l1;
+    c1.n = ntb;
+    c1.total = h_tot[T_L1];
+    CsrList &cs = st->close_smaller;
+    cs.n = ntb;
+    const int64_t total3 = h_tot[T_L3];
+    BT_CHECK(c1.lists.alloc(ctx->pool, c1.total));
+    BT_CHECK(st->l3_lists.alloc(ctx->pool, total3));
+    rows_to_csr_v2_kernel<<<nblk(items_cap), 256, 0, ctx->stream>>>(
+        d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, c1.lists.get());
+    if (total3 > 0)
+        l3_scatter_v2_kernel<<<nblk(items_cap), 256, lvl_lds, ctx->stream>>>(
+            d_nitems, (int32_t) items_cap, nlevels, overflow.get(), row3.get(), row3lev.get(), K3,
+            l3_item.get(), st->l3_lists.get());
+    if (st->with_extent) {
+        cs.total = h_tot[T_CLOSE];
+        BT_CHECK(cs.lists.alloc(ctx->pool, cs.total));
+        if (cs.total > 0)
+            rows_to_csr_v2_kernel<<<nblk(items_cap), 256, 0, ctx->stream>>>(
+                d_nitems, overflow.get(), rowc.get(), Kc, close_item.get(), nullptr, cs.lists.get());
+    }
+    if (novf > 0) {
+        // items whose lists did not fit their rows: walk again, straight to the final places
+        V2Walk wf = w;
+        wf.l1_cs = l1_item.get(); wf.l3_cs = l3_item.get();
+        wf.close_cs = st->with_extent ? close_item.get() : nullptr;
+        wf.l1_lists = c1.lists.get(); wf.l3_lists = st->l3_lists.get();
+        wf.close_lists = st->with_extent ? cs.lists.get() : nullptr;
+        walk13_v2_kernel<T, D, false><<<nblk(novf), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, wf);
+    }
+    BT_CHECK(tmark(ctx, st, "trav:lists 1+3 (final)"));
+
+    // per-box starts from the per-item starts (items of a box are consecutive)
+    BT_CHECK(c1.starts.alloc(ctx->pool, ntb + 1));
+    gather_i32_kernel<<<nblk(ntb + 1), 256, 0, ctx->stream>>>(
+        (int32_t) (ntb + 1), first_item.get(), l1_item.get(), c1.starts.get());
+    if (st->with_extent) {
+        BT_CHECK(cs.starts.alloc(ctx->pool, ntb + 1));
+        gather_i32_kernel<<<nblk(ntb + 1), 256, 0, ctx->stream>>>(
+            (int32_t) (ntb + 1), first_item.get(), close_item.get(), cs.starts.get());
+    }
+    const int64_t nflat_box = (int64_t) nlevels * ntb;
+    BT_CHECK(st->l3_starts.alloc(ctx->pool, nflat_box + 1));
+    l3_box_starts_kernel<<<nblk(nflat_box + 1), 256, 0, ctx->stream>>>(
+        nflat_box, (int32_t) ntb, (int32_t) items_cap, nlevels, first_item.get(), l3_item.get(),
+        st->l3_starts.get());
+
+    // list 1: order by depth-first rank, insert the own-subtree blocks
+    {
+        Buf<int32_t> jobbuf;
+        BT_CHECK(jobbuf.alloc(ctx->pool, 3 * ntb + 1));
+        BlockJobs jobs{jobbuf.get(), jobbuf.get() + 1, jobbuf.get() + 1 + ntb,
+                       jobbuf.get() + 1 + 2 * ntb};
+        BT_HIP_CHECK(hipMemsetAsync(jobbuf.get(), 0, 4, ctx->stream));
+        Buf<uint8_t> tier;
+        Buf<int32_t> tier_present;
+        BT_CHECK(tier.alloc(ctx->pool, ntb));
+        BT_CHECK(tier_present.alloc(ctx->pool, 2));
+        BT_HIP_CHECK(hipMemsetAsync(tier.get(), 0, (size_t) ntb, ctx->stream));
+        BT_HIP_CHECK(hipMemsetAsync(tier_present.get(), 0, 8, ctx->stream));
+        l1_finalize32_kernel<T, D><<<nblk(ntb * 16), 256, 0, ctx->stream>>>(
+            a, ft, (int32_t) ntb, c1.starts.get(), c1.lists.get(), jobs, tier.get(),
+            tier_present.get());
+        // lists longer than 32 entries: counts stay on the device, fixed grids
+        Buf<int32_t> pos[2], list[2];
+        for (int which = 1; which <= 2; ++which) {
+            TierIs pr{tier.get(), (uint8_t) which};
+            BT_CHECK(pos[which - 1].alloc(ctx->pool, ntb + 1));
+            BT_CHECK(list[which - 1].alloc(ctx->pool, ntb));
+            BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, pr, ntb, pos[which - 1].get(),
+                                                              (int32_t *) nullptr, true)));
+            compact_tier_kernel<<<nblk(ntb), 256, 0, ctx->stream>>>((int32_t) ntb, pr,
+                                                                   pos[which - 1].get(),
+                                                                   list[which - 1].get());
+            const unsigned grid = (unsigned) std::min<int64_t>(ctx->num_cus * 8, std::max<int64_t>(1, ntb));
+            if (which == 1)
+                l1_finalize_wave_kernel<T, D><<<grid, 256, 0, ctx->stream>>>(
+                    a, ft, list[0].get(), pos[0].get() + ntb, c1.starts.get(), c1.lists.get(), jobs);
+            else
+                l1_finalize_block_kernel<T, D><<<grid, 256, 0, ctx->stream>>>(
+                    a, ft, list[1].get(), pos[1].get() + ntb, c1.starts.get(), c1.lists.get(), jobs);
+        }
+        if (with_blocks)
+            copy_rank_blocks_kernel<<<(unsigned) std::min<int64_t>(ctx->num_cus * 8, ntb), 256, 0,
+                                      ctx->stream>>>(
+                jobs.count, jobs.dst, jobs.src, jobs.len, st->src_by_rank.get(), c1.lists.get());
+        // the scratch buffers above return to the pool at scope exit: all work that uses
+        // them is already queued on this stream, and so is whatever reuses them
     }
     BT_CHECK(tmark(ctx, st, "trav:list1+list3"));
     BT_HIP_CHECK(hipGetLastError());
@@ -1223,7 +1558,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
 
     BT_CHECK(st->nodes.alloc(ctx->pool, B * (int64_t) sizeof(Node<T, D>)));
     BT_CHECK(st->child_t.alloc(ctx->pool, B * (1 << D)));
-    pack_nodes_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
+    pack_nodes_kernel<T, D, true><<<nblk(B), 256, 0, ctx->stream>>>(
         (int32_t) B, p.aligned_nboxes, (const T *) p.box_centers, p.box_levels, p.box_flags,
         p.box_child_ids, (Node<T, D> *) st->nodes.get(), st->child_t.get());
 
@@ -1253,18 +1588,40 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     st->fast = false;
     if (!p.force_generic) {
         Buf<int> bad;
-        BT_CHECK(bad.alloc(ctx->pool, 1));
-        BT_HIP_CHECK(hipMemsetAsync(bad.get(), 0, sizeof(int), ctx->stream));
-        check_structure_kernel<D><<<nblk(B), 256, 0, ctx->stream>>>(
+        BT_CHECK(bad.alloc(ctx->pool, 4));
+        BT_HIP_CHECK(hipMemsetAsync(bad.get(), 0, 4 * sizeof(int), ctx->stream));
+        check_structure_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
             (int32_t) B, p.aligned_nboxes, p.box_parent_ids, p.box_child_ids, p.box_levels,
-            p.box_flags, bad.get());
-        int32_t hb = 1;
-        BT_CHECK(read_i32(ctx, (const int32_t *) bad.get(), &hb));
-        st->fast = hb == 0;
+            p.box_flags, (const T *) p.box_centers, (T) p.root_extent, bad.get());
+        int32_t hb[4] = {1, 1, 1, 0};
+        T root_center[D];
+        BT_HIP_CHECK(hipMemcpyAsync(hb, bad.get(), 16, hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipMemcpy2DAsync(root_center, sizeof(T), p.box_centers,
+                                      (size_t) p.aligned_nboxes * sizeof(T), sizeof(T), D,
+                                      hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        st->fast = hb[0] == 0;
+        st->has_blocks = hb[2] != 0;
+        // lattice kernels: exact lattice centres, and the deepest box many ulps wide
+        // (bt_trav_v2.hpp header)
+        double mag = std::fabs(p.root_extent);
+        for (int ax = 0; ax < D; ++ax)
+            mag = std::max(mag, std::fabs((double) root_center[ax]) + 0.5 * std::fabs(p.root_extent));
+        const double eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
+        const double rmin = p.root_extent / std::ldexp(1.0, nlevels);     // radius of the deepest level
+        const bool levels_ok = rmin > 16.0 * (nlevels + 2) * eps * mag;
+        static const bool v2_off_env = [] {
+            const char *e = getenv("BT_TRAV_V1");            // debugging aid: the float kernels
+            return e && atoi(e);
+        }();
+        st->lattice = st->fast && hb[1] == 0 && levels_ok && p.well_sep_is_n_away == 1
+            && B < ((int64_t) 1 << 26) && nlevels <= 29 && !v2_off_env;
     }
     a.fast = st->fast ? 1 : 0;
 
-    if (st->fast) {
+    if (st->lattice) {
+        BT_CHECK((fast_lists_v2<T, D>(ctx, st, a)));
+    } else if (st->fast) {
         BT_CHECK((fast_lists<T, D>(ctx, st, a)));
     } else {
         // T3 colleagues

@@ -55,15 +55,18 @@ __global__ __launch_bounds__(256) void compact_sources_by_rank_kernel(SourceRank
     if (f(r)) src_by_rank[prefix[r]] = f.box_of_rank[r];
 }
 
-// one workgroup per job (the largest job, the root's, is a 12 MB copy at 1e8 points)
-__global__ __launch_bounds__(256) void copy_rank_blocks_kernel(const int32_t *dst,
+// one workgroup per job at a time (the largest job, the root's, is a 12 MB copy at 1e8
+// points); the job count stays on the device
+__global__ __launch_bounds__(256) void copy_rank_blocks_kernel(const int32_t *njobs, const int32_t *dst,
         const int32_t *src, const int32_t *len, const int32_t *src_by_rank, int32_t *lists)
 {
-    const int32_t j = blockIdx.x;
-    const int32_t n = len[j];
-    const int32_t *in = src_by_rank + src[j];
-    int32_t *out = lists + dst[j];
-    for (int32_t i = threadIdx.x; i < n; i += 256) out[i] = in[i];
+    const int32_t nj = *njobs;
+    for (int32_t j = blockIdx.x; j < nj; j += gridDim.x) {
+        const int32_t n = len[j];
+        const int32_t *in = src_by_rank + src[j];
+        int32_t *out = lists + dst[j];
+        for (int32_t i = threadIdx.x; i < n; i += 256) out[i] = in[i];
+    }
 }
 
 // ---- structure check --------------------------------------------------------------
@@ -79,15 +82,19 @@ __device__ __forceinline__ int find_slot(const int32_t *child, int64_t aligned, 
     return -1;
 }
 
-template <int D>
+// bad[0]: numbering / flags not as the fast kernels need them.
+// bad[2]: (information) some target box has source boxes below it.
+// bad[1]: some box centre is not exactly "parent centre +/- root_extent / 2^(level+1)"
+//         (the lattice kernels of bt_trav_v2.hpp then must not be used).
+template <class T, int D>
 __global__ __launch_bounds__(256) void check_structure_kernel(int32_t nboxes, int64_t aligned,
         const int32_t *parent, const int32_t *child, const uint8_t *levels, const uint8_t *flags,
-        int *bad)
+        const T *centers, T root_extent, int *bad)
 {
     constexpr int C = 1 << D;
     const int32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nboxes) return;
-    bool ok = true;
+    bool ok = true, geom_ok = true;
     for (int m = 0; m < C; ++m) {
         const int32_t c = child[(int64_t) m * aligned + b];
         if (c != 0) ok = ok && c > b && c < nboxes && parent[c] == b;
@@ -108,9 +115,27 @@ __global__ __launch_bounds__(256) void check_structure_kernel(int32_t nboxes, in
             // flag consistency: anything with sources below must be reachable
             if (flags[b] & (BT_BOX_IS_SOURCE_BOX | BT_BOX_HAS_SOURCE_CHILD_BOXES))
                 ok = ok && (flags[p] & BT_BOX_HAS_SOURCE_CHILD_BOXES);
+            if (ok && levels[b] < 63) {
+                // tree_build_kernels.py:698-705, as the builder evaluates it
+                const T radius = (root_extent * 1 / (T) (1ull << (1 + (int) levels[b])));
+#pragma unroll
+                for (int ax = 0; ax < D; ++ax) {
+                    const bool has_bit = (slot >> (D - 1 - ax)) & 1;
+                    const T pc = centers[(int64_t) ax * aligned + p];
+                    const T want = has_bit ? pc + radius : pc - radius;
+                    geom_ok = geom_ok && want == centers[(int64_t) ax * aligned + b];
+                }
+            } else {
+                geom_ok = false;
+            }
         }
     }
     if (!ok) atomicExch(bad, 1);
+    if (!geom_ok) atomicExch(bad + 1, 1);
+    // a target box with sources below it (extents, or a TreeOfBoxes): list 1 then holds
+    // a whole block of depth-first ranks (BlockJobs)
+    if ((flags[b] & BT_BOX_IS_TARGET_BOX) && (flags[b] & BT_BOX_HAS_SOURCE_CHILD_BOXES))
+        atomicExch(bad + 2, 1);
 }
 
 // ---- depth-first preorder rank ---------------------------------------------------
@@ -861,14 +886,14 @@ __global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, Fa
 // counting the smaller ones (ranks are distinct)
 template <class T, int D>
 __global__ __launch_bounds__(256) void l1_finalize_wave_kernel(TravArgs<T, D> a, FastTree ft,
-        const int32_t *mid_list, int32_t nmid, const int32_t *l1_starts, int32_t *l1_lists,
+        const int32_t *mid_list, const int32_t *d_nmid, const int32_t *l1_starts, int32_t *l1_lists,
         BlockJobs jobs)
 {
     __shared__ int32_t s_all[4][L1_WAVE_MAX];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int32_t idx = blockIdx.x * 4 + w;
-    if (idx >= nmid) return;
     int32_t *s_v = s_all[w];
+    const int32_t nmid = *d_nmid;
+  for (int32_t idx = blockIdx.x * 4 + w; idx < nmid; idx += gridDim.x * 4) {
     const int32_t tbn = mid_list[idx];
     const int32_t b = a.target_boxes[tbn];
     int32_t *out = l1_lists + l1_starts[tbn];
@@ -898,16 +923,23 @@ __global__ __launch_bounds__(256) void l1_finalize_wave_kernel(TravArgs<T, D> a,
         jobs.src[j] = blk_src;
         jobs.len[j] = blk_len;
     }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+  }
 }
 
 // list 1 of one listed target box (32 < entries <= L1_BLOCK_MAX): bitonic sort of the
 // ranks in LDS by one workgroup, then the same placement as above
 template <class T, int D>
 __global__ __launch_bounds__(256) void l1_finalize_block_kernel(TravArgs<T, D> a, FastTree ft,
-        const int32_t *big_list, const int32_t *l1_starts, int32_t *l1_lists, BlockJobs jobs)
+        const int32_t *big_list, const int32_t *d_nbig, const int32_t *l1_starts,
+        int32_t *l1_lists, BlockJobs jobs)
 {
     __shared__ int32_t s_v[L1_BLOCK_MAX];
-    const int32_t tbn = big_list[blockIdx.x];
+    const int32_t nbig = *d_nbig;
+  for (int32_t jb = blockIdx.x; jb < nbig; jb += gridDim.x) {
+    __syncthreads();
+    const int32_t tbn = big_list[jb];
     const int32_t b = a.target_boxes[tbn];
     int32_t *out = l1_lists + l1_starts[tbn];
     const int32_t n_all = l1_starts[tbn + 1] - l1_starts[tbn];
@@ -950,6 +982,7 @@ __global__ __launch_bounds__(256) void l1_finalize_block_kernel(TravArgs<T, D> a
         jobs.src[j] = blk_src;
         jobs.len[j] = blk_len;
     }
+  }
 }
 
 // l3 bookkeeping per (level, target box) from the per-(level, item) starts
