@@ -187,12 +187,17 @@ __device__ __forceinline__ uint64_t sp_add_sat(uint64_t a, uint64_t b)
     return r > SP_VAL_MASK ? SP_VAL_MASK : r;
 }
 
-template <class AccT, class OutT, class F>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_single_pass_kernel(F f, int64_t n, OutT *out,
+// THREADS = 256 for small inputs; 1024 (tiles of 16384 elements) for large ones: the
+// look-back chain advances by about 64 tiles per poll round trip (~1.5 us under load),
+// i.e. some 40 tiles/us -- 4096-element tiles cap a 32-bit scan at ~1.3 TB/s (measured:
+// 1.6*10^8 elements in 2.2 ms), four times larger tiles leave the chain idle.
+template <class AccT, class OutT, class F, int THREADS>
+__global__ __launch_bounds__(THREADS) void scan_single_pass_kernel(F f, int64_t n, OutT *out,
         AccT *d_total, bool write_total_at_n, uint64_t *desc, uint32_t *ticket_counter,
         uint32_t ticket_base, uint32_t gen, DeviceStatus *status)
 {
-    constexpr int NW = SCAN_THREADS / 64;
+    constexpr int NW = THREADS / 64;
+    constexpr int64_t TILE = (int64_t) THREADS * SCAN_ITEMS;
     using W = uint32_t;
     __shared__ uint32_t s_tile;
     __shared__ W s_wave[NW];
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_single_pass_kernel(F f, int
     __syncthreads();
     const uint32_t tile = s_tile;
     const int w = threadIdx.x >> 6, lane = lane_id();
-    const int64_t wave_base = (int64_t) tile * SCAN_TILE + (int64_t) w * (64 * SCAN_ITEMS);
+    const int64_t wave_base = (int64_t) tile * TILE + (int64_t) w * (64 * SCAN_ITEMS);
     W v[SCAN_ITEMS], ex[SCAN_ITEMS];
     uint64_t mine = 0;                 // exact (64-bit) sum of this lane's items
 #pragma unroll
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_single_pass_kernel(F f, int
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (lane == 0) s_excl = excl;
-        const int64_t ntiles = (n + SCAN_TILE - 1) / SCAN_TILE;
+        const int64_t ntiles = (n + TILE - 1) / TILE;
         if (lane == 0 && (int64_t) tile == ntiles - 1) {
             const uint64_t tot = sp_add_sat(excl, agg);
             if (d_total) *d_total = (AccT) tot;
@@ -302,10 +307,19 @@ int device_exclusive_scan(bt_context *ctx, F f, int64_t n, OutT *out, AccT *d_to
     const int64_t ntiles = div_up(n, SCAN_TILE);
     if constexpr (std::is_integral<AccT>::value && sizeof(OutT) == 4) {
         uint32_t gen = 0, base = 0;
-        BT_CHECK(scan_prepare(ctx, ntiles, &gen, &base));
-        scan_single_pass_kernel<AccT, OutT, F><<<(unsigned) ntiles, SCAN_THREADS, 0, ctx->stream>>>(
-            f, n, out, d_total, write_total_at_n, ctx->scan_desc, ctx->scan_ticket, base, gen,
-            ctx->d_status);
+        if (ntiles > 2048) {
+            const int64_t nbig = div_up(n, (int64_t) 1024 * SCAN_ITEMS);
+            BT_CHECK(scan_prepare(ctx, nbig, &gen, &base));
+            scan_single_pass_kernel<AccT, OutT, F, 1024><<<(unsigned) nbig, 1024, 0, ctx->stream>>>(
+                f, n, out, d_total, write_total_at_n, ctx->scan_desc, ctx->scan_ticket, base, gen,
+                ctx->d_status);
+        } else {
+            BT_CHECK(scan_prepare(ctx, ntiles, &gen, &base));
+            scan_single_pass_kernel<AccT, OutT, F, SCAN_THREADS>
+                <<<(unsigned) ntiles, SCAN_THREADS, 0, ctx->stream>>>(
+                    f, n, out, d_total, write_total_at_n, ctx->scan_desc, ctx->scan_ticket, base,
+                    gen, ctx->d_status);
+        }
         BT_HIP_CHECK(hipGetLastError());
         return BT_OK;
     } else {

@@ -622,6 +622,7 @@ struct TravState {
     int64_t nsb = 0, ntb = 0, nspb = 0, nttp = 0;
     const int32_t *target_boxes = nullptr;
     Buf<int32_t> lev_starts;           // [4][nlevels+1]
+    std::vector<int32_t> h_lev_starts; // host copy
     Buf<int32_t> d_level_start_box_nrs;
     CsrList coll, l1, l2, l4, close_smaller, close_bigger;
     // list 3: flat level-major
@@ -1295,11 +1296,23 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         return e ? atoi(e) : 3;
     }();
     const int heavy_max_level = nlevels - heavy_margin;
-    int64_t nheavy_max = 0;
-    if (heavy_max_level >= 0) nheavy_max = std::min<int64_t>(ntb, ls[std::min(heavy_max_level + 1, nlevels)]);
-    const int64_t items_cap = std::max<int64_t>(64, div_up(ntb + (int64_t) P * nheavy_max, 64) * 64);
-    const int64_t nflat = (int64_t) nlevels * items_cap;
-    if (nflat >= ((int64_t) 1 << 31)) {
+    // columns: the target boxes of level tl make at most cap(tl) items
+    L3Layout lay{};
+    int64_t items_cap = 0, nflat = 0;
+    {
+        const int32_t *tls = st->h_lev_starts.data() + (nlevels + 1);     // target boxes per level
+        for (int l = 0; l <= nlevels; ++l) {
+            lay.ecap[l] = (int32_t) std::min<int64_t>(items_cap, INT_MAX);
+            lay.base[l] = (int32_t) std::min<int64_t>(nflat, INT_MAX);
+            nflat += items_cap;
+            if (l < nlevels)
+                items_cap += (int64_t) (tls[l + 1] - tls[l]) * (l <= heavy_max_level ? P + 1 : 1);
+        }
+        nflat -= items_cap;            // rows 0 .. nlevels-1 only
+        lay.base[nlevels] = (int32_t) std::min<int64_t>(nflat, INT_MAX);
+    }
+    items_cap = std::max<int64_t>(64, div_up(items_cap, 64) * 64);
+    if (nflat >= ((int64_t) 1 << 31) || items_cap >= ((int64_t) 1 << 31)) {
         set_error("list 3 bookkeeping exceeds int32 range");
         return BT_ERR_UNSUPPORTED;
     }
@@ -1338,6 +1351,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     BT_CHECK(l1_item.alloc(ctx->pool, items_cap + 1));
     BT_CHECK(l3_item.alloc(ctx->pool, nflat + 1));
     if (st->with_extent) BT_CHECK(close_item.alloc(ctx->pool, items_cap + 1));
+    (void) sizeof(nflat);
     BT_CHECK(overflow.alloc(ctx->pool, items_cap));
     BT_CHECK(ovf_list.alloc(ctx->pool, items_cap));
     Buf<int32_t> l1_cnt, l3_cnt, close_cnt;
@@ -1354,6 +1368,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     w.item_tbn = item_tbn.get(); w.item_slot = item_slot.get();
     w.d_nitems = d_nitems;
     w.items_cap = (int32_t) items_cap;
+    w.lay = lay;
     w.nlevels = nlevels; w.walk_cap = walk_cap;
     w.with_blocks = with_blocks ? 1 : 0;
     w.row1 = row1.get(); w.row3 = row3.get(); w.rowc = Kc ? rowc.get() : nullptr;
@@ -1431,7 +1446,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, c1.lists.get());
     if (total3 > 0)
         l3_scatter_v2_kernel<<<nblk(items_cap), 256, lvl_lds, ctx->stream>>>(
-            d_nitems, (int32_t) items_cap, nlevels, overflow.get(), row3.get(), row3lev.get(), K3,
+            d_nitems, lay, nlevels, overflow.get(), row3.get(), row3lev.get(), K3,
             l3_item.get(), st->l3_lists.get());
     if (st->with_extent) {
         cs.total = h_tot[T_CLOSE];
@@ -1462,8 +1477,8 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     }
     const int64_t nflat_box = (int64_t) nlevels * ntb;
     BT_CHECK(st->l3_starts.alloc(ctx->pool, nflat_box + 1));
-    l3_box_starts_kernel<<<nblk(nflat_box + 1), 256, 0, ctx->stream>>>(
-        nflat_box, (int32_t) ntb, (int32_t) items_cap, nlevels, first_item.get(), l3_item.get(),
+    l3_box_starts_v2_kernel<<<nblk(nflat_box + 1), 256, 0, ctx->stream>>>(
+        nflat_box, (int32_t) ntb, lay, nlevels, first_item.get(), l3_item.get(),
         st->l3_starts.get());
 
     // list 1: order by depth-first rank, insert the own-subtree blocks
@@ -1526,34 +1541,66 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     const size_t lvl_lds = (size_t) nlevels * WALK_THREADS * 4;
 
     BT_CHECK(tmark(ctx, st, "trav:start"));
-    // T1
-    BT_CHECK(compact_boxes(ctx, p, BT_BOX_IS_SOURCE_BOX, p.source_boxes_mask, st->source_boxes, &st->nsb));
-    BT_CHECK(compact_boxes(ctx, p, BT_BOX_HAS_SOURCE_CHILD_BOXES, p.source_parent_boxes_mask,
-                           st->source_parent_boxes, &st->nspb));
-    BT_CHECK(compact_boxes(ctx, p, BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX,
-                           p.target_boxes_mask, st->ttp_boxes, &st->nttp));
-    if (sat && !p.target_boxes_mask) {
-        st->target_boxes = st->source_boxes.get();
-        st->ntb = st->nsb;
-    } else {
-        BT_CHECK(compact_boxes(ctx, p, BT_BOX_IS_TARGET_BOX, p.target_boxes_mask,
-                               st->target_boxes_buf, &st->ntb));
-        st->target_boxes = st->target_boxes_buf.get();
-    }
-
-    // T2
+    // T1 + T2 + structure check, with ONE host synchronisation: the four flag scans
+    // give the list sizes (pos[B]) and the level starts (pos[level_start_box_nrs[l]]:
+    // the number of listed boxes before the level's first box, which is what
+    // traversal.py:361-392 + 2093-2096 compute).
     BT_CHECK(st->d_level_start_box_nrs.alloc(ctx->pool, nlevels + 1));
     BT_HIP_CHECK(hipMemcpyAsync(st->d_level_start_box_nrs.get(), p.level_start_box_nrs,
                                 (size_t) (nlevels + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     BT_CHECK(st->lev_starts.alloc(ctx->pool, 4 * (nlevels + 1)));
+    const bool shared_tb = sat && !p.target_boxes_mask;     // target_boxes is source_boxes
+    FlagPred preds[4] = {
+        {p.box_flags, p.source_boxes_mask, BT_BOX_IS_SOURCE_BOX},
+        {p.box_flags, p.target_boxes_mask, BT_BOX_IS_TARGET_BOX},
+        {p.box_flags, p.source_parent_boxes_mask, BT_BOX_HAS_SOURCE_CHILD_BOXES},
+        {p.box_flags, p.target_boxes_mask, BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX}};
+    Buf<int32_t> pos[4];
+    for (int k = 0; k < 4; ++k) {
+        if (k == 1 && shared_tb) continue;
+        BT_CHECK(pos[k].alloc(ctx->pool, B + 1));
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, preds[k], B, pos[k].get(),
+                                                          (int32_t *) nullptr, true)));
+        gather_i32_kernel<<<1, 64, 0, ctx->stream>>>(nlevels + 1, st->d_level_start_box_nrs.get(),
+                                                     pos[k].get(), st->lev_starts.get() + k * (nlevels + 1));
+    }
+    if (shared_tb)
+        BT_HIP_CHECK(hipMemcpyAsync(st->lev_starts.get() + (nlevels + 1), st->lev_starts.get(),
+                                    (size_t) (nlevels + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    Buf<int> bad;
+    BT_CHECK(bad.alloc(ctx->pool, 4));
+    BT_HIP_CHECK(hipMemsetAsync(bad.get(), 0, 4 * sizeof(int), ctx->stream));
+    if (!p.force_generic)
+        check_structure_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
+            (int32_t) B, p.aligned_nboxes, p.box_parent_ids, p.box_child_ids, p.box_levels,
+            p.box_flags, (const T *) p.box_centers, (T) p.root_extent, bad.get());
+    int32_t hb[4] = {1, 1, 1, 0};
+    T root_center[D];
+    st->h_lev_starts.assign((size_t) 4 * (nlevels + 1), 0);
+    BT_HIP_CHECK(hipMemcpyAsync(st->h_lev_starts.data(), st->lev_starts.get(),
+                                st->h_lev_starts.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    BT_HIP_CHECK(hipMemcpyAsync(hb, bad.get(), 16, hipMemcpyDeviceToHost, ctx->stream));
+    BT_HIP_CHECK(hipMemcpy2DAsync(root_center, sizeof(T), p.box_centers,
+                                  (size_t) p.aligned_nboxes * sizeof(T), sizeof(T), D,
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->n_host_syncs++;
     {
-        const int32_t *lists[4] = {st->source_boxes.get(), st->target_boxes,
-                                   st->source_parent_boxes.get(), st->ttp_boxes.get()};
+        const int32_t *h = st->h_lev_starts.data();
+        st->nsb = h[0 * (nlevels + 1) + nlevels];
+        st->ntb = h[1 * (nlevels + 1) + nlevels];
+        st->nspb = h[2 * (nlevels + 1) + nlevels];
+        st->nttp = h[3 * (nlevels + 1) + nlevels];
+        Buf<int32_t> *lists[4] = {&st->source_boxes, &st->target_boxes_buf,
+                                  &st->source_parent_boxes, &st->ttp_boxes};
         const int64_t ns[4] = {st->nsb, st->ntb, st->nspb, st->nttp};
-        for (int k = 0; k < 4; ++k)
-            level_starts_kernel<<<1, 64, 0, ctx->stream>>>(lists[k], (int32_t) ns[k],
-                    st->d_level_start_box_nrs.get(), nlevels,
-                    st->lev_starts.get() + k * (nlevels + 1));
+        for (int k = 0; k < 4; ++k) {
+            if (k == 1 && shared_tb) continue;
+            BT_CHECK(lists[k]->alloc(ctx->pool, ns[k]));
+            compact_kernel<<<nblk(B), 256, 0, ctx->stream>>>(preds[k], (int32_t) B, pos[k].get(),
+                                                            lists[k]->get());
+        }
+        st->target_boxes = shared_tb ? st->source_boxes.get() : st->target_boxes_buf.get();
     }
 
     BT_CHECK(st->nodes.alloc(ctx->pool, B * (int64_t) sizeof(Node<T, D>)));
@@ -1586,20 +1633,8 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
 
     // ---- which path? ---------------------------------------------------------------
     st->fast = false;
+    st->lattice = false;
     if (!p.force_generic) {
-        Buf<int> bad;
-        BT_CHECK(bad.alloc(ctx->pool, 4));
-        BT_HIP_CHECK(hipMemsetAsync(bad.get(), 0, 4 * sizeof(int), ctx->stream));
-        check_structure_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
-            (int32_t) B, p.aligned_nboxes, p.box_parent_ids, p.box_child_ids, p.box_levels,
-            p.box_flags, (const T *) p.box_centers, (T) p.root_extent, bad.get());
-        int32_t hb[4] = {1, 1, 1, 0};
-        T root_center[D];
-        BT_HIP_CHECK(hipMemcpyAsync(hb, bad.get(), 16, hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipMemcpy2DAsync(root_center, sizeof(T), p.box_centers,
-                                      (size_t) p.aligned_nboxes * sizeof(T), sizeof(T), D,
-                                      hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         st->fast = hb[0] == 0;
         st->has_blocks = hb[2] != 0;
         // lattice kernels: exact lattice centres, and the deepest box many ulps wide

@@ -134,8 +134,11 @@ __global__ __launch_bounds__(256) void check_structure_kernel(int32_t nboxes, in
     if (!geom_ok) atomicExch(bad + 1, 1);
     // a target box with sources below it (extents, or a TreeOfBoxes): list 1 then holds
     // a whole block of depth-first ranks (BlockJobs)
-    if ((flags[b] & BT_BOX_IS_TARGET_BOX) && (flags[b] & BT_BOX_HAS_SOURCE_CHILD_BOXES))
-        atomicExch(bad + 2, 1);
+    // (one idempotent store at most per box and none once the flag is up: millions of
+    // same-address atomics serialise in L2 -- 3.9 ms on the 3.4*10^6 boxes of c4)
+    if ((flags[b] & BT_BOX_IS_TARGET_BOX) && (flags[b] & BT_BOX_HAS_SOURCE_CHILD_BOXES)
+            && __hip_atomic_load(bad + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        __hip_atomic_store(bad + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- depth-first preorder rank ---------------------------------------------------

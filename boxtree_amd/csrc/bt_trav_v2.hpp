@@ -245,6 +245,15 @@ __global__ __launch_bounds__(256) void make_items_v2_kernel(int32_t ntb, const i
 // ROWS = false: the items of the overflow list are walked again and write straight to
 //   their final places.
 
+// Per-level list-3 counts of the items, "staircase" layout: an item of a target box at
+// level tl can only have entries at source levels > tl, and items are numbered in
+// target-box (= level) order, so row l needs columns for the items of levels < l only:
+// ecap[l] = an upper bound of their number, base[l] = sum of ecap[l'] for l' < l.
+struct L3Layout {
+    int32_t base[BT_MAX_LEVELS + 1];
+    int32_t ecap[BT_MAX_LEVELS + 1];
+};
+
 struct V2Walk {
     const ICell *cells;
     const uint8_t *flags;
@@ -252,7 +261,8 @@ struct V2Walk {
     const int32_t *coll_rows, *coll_cnt, *srccoll_rows, *srccoll_cnt;
     const int32_t *item_tbn, *item_slot;
     const int32_t *d_nitems;           // actual item count (device)
-    int32_t items_cap;                 // stride of the per-level count array
+    int32_t items_cap;                 // columns of the item arrays (>= the item count)
+    L3Layout lay;
     int nlevels, walk_cap;
     int with_blocks;                   // own-subtree blocks exist (extents)
     // rows
@@ -287,8 +297,9 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         item = blockIdx.x * 256 + threadIdx.x;
         if (item >= *w.d_nitems) {
             if (item < w.items_cap) {
-                // the flat per-level count array is scanned over items_cap columns
-                for (int l = 0; l < w.nlevels; ++l) w.l3_cs[(int64_t) l * w.items_cap + item] = 0;
+                // the count arrays are scanned over all their columns
+                for (int l = 0; l < w.nlevels; ++l)
+                    if (item < w.lay.ecap[l]) w.l3_cs[w.lay.base[l] + item] = 0;
                 w.l1_cs[item] = 0;
                 if (w.close_cs) w.close_cs[item] = 0;
                 w.overflow[item] = 0;
@@ -325,7 +336,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         for (int l = 0; l < w.nlevels; ++l) lvl[l * WALK_THREADS] = 0;
     } else {
         for (int l = 0; l < w.nlevels; ++l)
-            lvl[l * WALK_THREADS] = w.l3_cs[(int64_t) l * w.items_cap + item];
+            lvl[l * WALK_THREADS] = item < w.lay.ecap[l] ? w.l3_cs[w.lay.base[l] + item] : 0;
     }
     auto emit3 = [&](int lev, int32_t box) {
         if (ROWS) {
@@ -506,7 +517,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
 
     if (ROWS) {
         for (int l = 0; l < w.nlevels; ++l)
-            w.l3_cs[(int64_t) l * w.items_cap + item] = lvl[l * WALK_THREADS];
+            if (item < w.lay.ecap[l]) w.l3_cs[w.lay.base[l] + item] = lvl[l * WALK_THREADS];
         w.l1_cs[item] = e1.n + blk_len;
         if (w.close_cs) w.close_cs[item] = ec.n;
         const bool ovf = e1.n > w.K1 || n3 > w.K3 || (w.close_cs && ec.n > w.Kc);
@@ -538,25 +549,43 @@ __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_ni
 }
 
 // list 3: rows -> per-level lists (cursors start at the item's per-level starts)
-__global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nitems,
-        int32_t items_cap, int nlevels, const uint8_t *overflow, const int32_t *row3,
-        const uint8_t *row3lev, int K3, const int32_t *l3_item_starts, int32_t *l3_lists)
+__global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nitems, L3Layout lay,
+        int nlevels, const uint8_t *overflow, const int32_t *row3, const uint8_t *row3lev, int K3,
+        const int32_t *l3_item_starts, int32_t *l3_lists)
 {
     const int32_t item = blockIdx.x * 256 + threadIdx.x;
     if (item >= *d_nitems || overflow[item]) return;
     int32_t *cur = s_walk_lds + threadIdx.x;
     int n = 0;
     for (int l = 0; l < nlevels; ++l) {
-        const int32_t s = l3_item_starts[(int64_t) l * items_cap + item];
+        int32_t s = 0;
+        if (item < lay.ecap[l]) {
+            s = l3_item_starts[lay.base[l] + item];
+            n += l3_item_starts[lay.base[l] + item + 1] - s;
+        }
         cur[l * WALK_THREADS] = s;
-        n += l3_item_starts[(int64_t) l * items_cap + item + 1] - s;   // next column, same level
     }
-    // (the count of the last column of a level runs into the next level's first start,
-    // which is what the flat scan makes it)
     const int32_t *row = row3 + (int64_t) (item >> 6) * 64 * K3 + (item & 63);
     const uint8_t *rl = row3lev + (int64_t) (item >> 6) * 64 * K3 + (item & 63);
     for (int j = 0; j < n; ++j) {
         const int lev = rl[(int64_t) j * 64];
         l3_lists[cur[lev * WALK_THREADS]++] = row[(int64_t) j * 64];
     }
+}
+
+// list-3 starts per (level, target box) from the per-(level, item) starts: a box whose
+// first item lies beyond the level's columns has no entries there and starts where
+// the level ends
+__global__ __launch_bounds__(256) void l3_box_starts_v2_kernel(int64_t nflat_box, int32_t ntb,
+        L3Layout lay, int nlevels, const int32_t *first_item, const int32_t *item_starts,
+        int32_t *box_starts)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i > nflat_box) return;
+    if (i == nflat_box) { box_starts[i] = item_starts[lay.base[nlevels]]; return; }
+    const int lev = (int) (i / ntb);
+    const int32_t tbn = (int32_t) (i % ntb);
+    const int32_t item = first_item[tbn];
+    const int32_t col = item < lay.ecap[lev] ? item : lay.ecap[lev];
+    box_starts[i] = item_starts[lay.base[lev] + col];
 }
