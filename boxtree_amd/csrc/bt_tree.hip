@@ -250,6 +250,166 @@ __global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_
 }
 
 // ---------------------------------------------------------------------------
+// Continuation keys.  The 64-bit key addresses L1 levels (21 in 3D); the reference
+// is defined down to level 31 (`1U << (1 + level)`, tbk:329, 374-376).  Boxes of
+// level L1 that still have to split get their particles re-keyed for the levels
+// L1+1 .. 31 and re-sorted inside the box:
+//     K2 = (segment << (D*L2 + capbits)) | (Kt2 << capbits) | cap2,
+// segment = rank of the box among the re-keyed ones (keeps boxes apart in one
+// global stable sort), Kt2 = Morton path below level L1, cap2 = (deepest level the
+// particle may descend to) - L1.  The per-axis cell index at level 31 is the same
+// expression as keygen_kernel's, evaluated with 2^31.
+// ---------------------------------------------------------------------------
+
+constexpr int KEY_AXIS_BITS = 31;
+
+template <class T, int D>
+struct Keygen2Args {
+    const T *packed;            // [n][PackStride<D>] interleaved coordinates (srcntgt order)
+    const T *src_radii, *tgt_radii;
+    int64_t nsources;
+    T bbox_min[D], bbox_max[D];
+    T stick_out_factor;
+    int L1, L2, capbits, norm, point_skip_levels;
+    const uint32_t *ids;        // tree order -> srcntgt id
+    const int32_t *box_start;
+    const int32_t *seg_box;     // [nseg] re-keyed boxes, ascending
+    const int32_t *seg_start;   // [nseg + 1] offsets into the compact arrays
+    int32_t nseg;
+    int64_t m;                  // particles to re-key
+};
+
+template <class T, int D, bool EXT>
+__global__ __launch_bounds__(256) void keygen2_kernel(Keygen2Args<T, D> a, uint64_t *keys2,
+                                                      uint32_t *ids2, int32_t *positions)
+{
+    const int64_t j = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (j >= a.m) return;
+    int lo = 0, hi = a.nseg;                    // last segment with seg_start <= j
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t) a.seg_start[mid] <= j) lo = mid; else hi = mid;
+    }
+    const int seg = lo;
+    const int32_t p = a.box_start[a.seg_box[seg]] + (int32_t) (j - a.seg_start[seg]);
+    const uint32_t id = a.ids[p];
+    constexpr int PS = PackStride<D>::value;
+    T x[D], gmin[D], gext[D];
+    uint32_t v[D];
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        x[ax] = a.packed[(int64_t) id * PS + ax];
+        gmin[ax] = a.bbox_min[ax];
+        gext[ax] = a.bbox_max[ax] - gmin[ax];
+        v[ax] = (uint32_t) (((x[ax] - gmin[ax]) / gext[ax]) * (T) (1u << KEY_AXIS_BITS));
+    }
+    const int Ltot = a.L1 + a.L2;               // == KEY_AXIS_BITS
+    int cap = Ltot;
+    if (EXT) {
+        T radius = (T) 0;
+        if ((int64_t) id < a.nsources) { if (a.src_radii) radius = a.src_radii[id]; }
+        else                           { if (a.tgt_radii) radius = a.tgt_radii[id - a.nsources]; }
+        const T one_half = ((T) 1) / 2;
+        const T brf = (T) ((1. + (double) a.stick_out_factor) * (double) one_half);   // tbk:342-346
+        int lfirst = a.L1 + 1;
+        if (radius == (T) 0 && a.point_skip_levels + 1 > lfirst) lfirst = a.point_skip_levels + 1;
+        for (int l = lfirst; l <= Ltot; ++l) {
+            const T size_factor = ((T) 1) / ((T) (1u << l));    // tbk:328-329
+            bool stop = false;
+            T center[D];
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) {
+                const uint32_t bits = v[ax] >> (Ltot - l);
+                center[ax] = gmin[ax] + gext[ax] * ((T) bits + one_half) * size_factor;  // tbk:380-384
+            }
+            if (a.norm == BT_NORM_LINF) {
+#pragma unroll
+                for (int ax = 0; ax < D; ++ax) {
+                    const T sor = brf * gext[ax] * size_factor;                // tbk:390-393
+                    stop = stop || (x[ax] + radius >= center[ax] + sor);       // tbk:396-399
+                    stop = stop || (x[ax] - radius < center[ax] - sor);        // tbk:400-403
+                }
+            } else {
+                const T sor = brf * gext[0] * size_factor;                     // tbk:408-411
+                T sumsq = (T) 0;
+#pragma unroll
+                for (int ax = 0; ax < D; ++ax) {
+                    const T t = (x[ax] - center[ax]) * (x[ax] - center[ax]);
+                    sumsq = (ax == 0) ? t : sumsq + t;
+                }
+                const T dist = sqrt(sumsq) + radius;                           // tbk:413-419
+                stop = stop || (dist * dist >= D * sor * sor);                 // tbk:422-428
+            }
+            if (stop) { cap = l - 1; break; }
+        }
+    }
+    uint64_t kt = 0;
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        const uint32_t mlow = v[ax] & ((1u << a.L2) - 1u);
+        kt |= spread_bits<D>(mlow) << (D - 1 - ax);                               // tbk:441-445
+    }
+    const int cap2 = cap - a.L1;
+    if (EXT) {
+        const int drop = D * (a.L2 - cap2);
+        if (drop > 0) kt = (drop >= 64) ? 0 : (kt >> drop) << drop;
+    }
+    const int keybits2 = D * a.L2 + a.capbits;
+    keys2[j] = ((uint64_t) seg << keybits2) | (kt << a.capbits) | (EXT ? (uint64_t) cap2 : 0ull);
+    ids2[j] = id;
+    positions[j] = p;
+}
+
+__global__ __launch_bounds__(256) void scatter_rekeyed_kernel(int64_t m, const int32_t *positions,
+        const uint64_t *keys2, const uint32_t *ids2, uint64_t *keys_full, uint32_t *ids)
+{
+    const int64_t j = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const int32_t p = positions[j];
+    keys_full[p] = keys2[j];
+    ids[p] = ids2[j];
+}
+
+// boxes of one level that may have to split below the key's reach
+struct RekeyPred {
+    const int32_t *box_count;
+    const int64_t *wprefix;
+    const int32_t *box_start;
+    int32_t b0, max_weight;
+    int adaptive;
+    __device__ bool cand(int64_t i) const
+    {
+        const int32_t b = b0 + (int32_t) i;
+        const int32_t n = box_count[b];
+        if (n <= 0) return false;
+        if (!adaptive) return true;
+        int64_t w = n;
+        if (wprefix) { const int32_t s = box_start[b]; w = wprefix[s + n] - wprefix[s]; }
+        return w > (int64_t) max_weight;
+    }
+};
+struct RekeyFlag {
+    RekeyPred p;
+    __device__ int32_t operator()(int64_t i) const { return p.cand(i) ? 1 : 0; }
+};
+struct RekeyCount {
+    RekeyPred p;
+    __device__ int32_t operator()(int64_t i) const { return p.cand(i) ? p.box_count[p.b0 + (int32_t) i] : 0; }
+};
+
+__global__ __launch_bounds__(256) void rekey_segments_kernel(int32_t nb, RekeyPred pr,
+        const int32_t *seg_rank, const int32_t *seg_off, uint8_t *cand, int32_t *seg_box,
+        int32_t *seg_start)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i > nb) return;
+    if (i == nb) { seg_start[seg_rank[nb]] = seg_off[nb]; return; }
+    const bool c = pr.cand(i);
+    cand[i] = c ? 1 : 0;
+    if (c) { seg_box[seg_rank[i]] = pr.b0 + i; seg_start[seg_rank[i]] = seg_off[i]; }
+}
+
+// ---------------------------------------------------------------------------
 // box construction from the sorted keys
 // ---------------------------------------------------------------------------
 
@@ -274,6 +434,8 @@ __device__ __forceinline__ int upper_bound_key(const uint64_t *k, int lo, int hi
 struct LevelFlags {
     int32_t total_new;      // written by the scan
     int32_t have_oversize;  // tbk:600-610
+    int32_t need_more;      // a box at the key's deepest level must split: continuation
+    int32_t pad;
 };
 
 struct BuildArgs {
@@ -296,6 +458,9 @@ struct BuildArgs {
     const int32_t *parent_list; // level restriction: force-split these boxes (any level)
     int top_level;              // sharded builds: levels above it use global counts
     const int64_t *top_prefix;  // [C^top_level + 1] or null
+    int loff;                   // the key addresses levels loff+1 .. loff+L (continuation keys)
+    int can_continue;           // a continuation key exists below level loff+L
+    const uint8_t *cand;        // continuation: which boxes of level loff were re-keyed
 };
 
 // global particle count of the box with Morton path `path` at `level` <= top_level
@@ -328,17 +493,20 @@ __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
 
     int lo = 0, e = 0, s = 0;
     uint64_t prefix = 0;
+    const int lr = l - a.loff;          // level relative to the key
+    // continuation: boxes of level loff that were not re-keyed have nothing to split
+    const bool skipped = a.cand != nullptr && !forced && active && !a.cand[bl];
     if (active) {
         s = a.box_start[b];
         e = s + a.box_count[b];
-        if (l - 1 < a.L && e > s) {
-            const int pshift = a.capbits + D * (a.L - (l - 1));
+        if (lr - 1 < a.L && e > s && !skipped) {
+            const int pshift = a.capbits + D * (a.L - (lr - 1));
             prefix = (pshift >= 64) ? 0 : (a.keys[s] >> pshift);
-            const int cshift = a.capbits + D * (a.L - l);
+            const int cshift = a.capbits + D * (a.L - lr);
             if (m == 0) {
                 if (EXT) {
-                    // own (stuck) particles: Kt == prefix000.., cap == l-1
-                    const uint64_t stuck = ((prefix << D) << cshift) | (uint64_t) (l - 1);
+                    // own (stuck) particles: Kt == prefix000.., cap == lr-1
+                    const uint64_t stuck = ((prefix << D) << cshift) | (uint64_t) (lr - 1);
                     lo = upper_bound_key(a.keys, s, e, stuck);
                 } else {
                     lo = s;
@@ -358,15 +526,24 @@ __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
     if (!active) return;
 
     int32_t W = range_weight(a, first, e);                       // tbk:569-573
-    const bool top = a.top_prefix && l - 1 < a.top_level && e > s;
+    const bool top = a.top_prefix && a.loff == 0 && l - 1 < a.top_level && e > s;
     if (top) W = top_weight<D>(a, prefix, l - 1);
     bool split;
     if (forced) split = true;                                    // tbk:593-595
     else if (a.adaptive) split = W > a.max_weight;               // tbk:577-591
     else split = true;
-    if (l - 1 >= a.L) {
+    if (skipped) split = false;
+    if (lr - 1 >= a.L) {
         if (split && e > s && (a.adaptive || W > a.max_weight)) {
-            if (m == 0) atomicExch(&a.status->max_levels, 1);
+            // deeper than this key reaches: re-key the box's particles for the levels
+            // below (tree_build_impl), or give up where the coordinate bits end
+            if (m == 0) {
+                if (a.can_continue)
+                    __hip_atomic_store(&a.flags->need_more, 1, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                else
+                    atomicExch(&a.status->max_levels, 1);
+            }
         }
         split = false;
     }
@@ -1391,6 +1568,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     const bool EXT = st->have_extent;
 
     BT_CHECK(mark(ctx, st, "start"));
+    int point_skip_raw = 0;
 
     // ---- keys ----------------------------------------------------------------
     BT_CHECK(st->keys_a.alloc(ctx->pool, N));
@@ -1425,6 +1603,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
             const double ratio = p.stick_out_factor * p.root_extent / (256.0 * eps * scale);
             int skip = 0;
             if (ratio > 1.0) skip = (int) std::floor(std::log2(ratio));
+            point_skip_raw = std::max(0, skip);
             ka.point_skip_levels = std::max(0, std::min(skip, st->L));
         }
         const unsigned blocks = (unsigned) div_up(N, 256);
@@ -1538,71 +1717,173 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         }
         if (total <= (int64_t) p.max_leaf_refine_weight) enter_loop = false;
     }
-    while (enter_loop) {
-        if (D * level > sorted_high_bits) {
-            // deeper than the sorted key bits reach: order all bits now.  Box ranges
-            // stay valid (the order of the top bits does not change); ties keep
-            // whatever order they have, the fix-up sorts leaves by user id anyway.
-            bool in_b = false;
-            BT_CHECK(radix_sort_pairs<uint64_t>(ctx, keys_cur, ids, keys_oth, ids_other, N, 0,
-                                                keybits, false, &in_b));
-            if (in_b) { std::swap(keys_cur, keys_oth); std::swap(ids, ids_other); }
-            keys = keys_cur;
-            sorted_high_bits = keybits;
+    // one pass of the level loop on one key array: `kkeys` addresses the levels
+    // loff+1 .. loff+Lkey; *need_more comes back set when a box of level loff+Lkey
+    // must split (and a continuation key exists)
+    auto level_loop = [&](const uint64_t *&kkeys, int Lkey, int loff, const uint8_t *cand,
+                          bool can_continue, bool *need_more) -> int {
+        while (true) {
+            if (loff == 0 && D * level > sorted_high_bits) {
+                // deeper than the sorted key bits reach: order all bits now.  Box ranges
+                // stay valid (the order of the top bits does not change); ties keep
+                // whatever order they have, the fix-up sorts leaves by user id anyway.
+                bool in_b = false;
+                BT_CHECK(radix_sort_pairs<uint64_t>(ctx, keys_cur, ids, keys_oth, ids_other, N, 0,
+                                                    keybits, false, &in_b));
+                if (in_b) { std::swap(keys_cur, keys_oth); std::swap(ids, ids_other); }
+                kkeys = keys_cur;
+                sorted_high_bits = keybits;
+            }
+            const int b0 = st->level_start[level - 1];
+            const int nprev = st->level_start[level] - b0;
+            Buf<int32_t> bounds, nnew, offsets;
+            BT_CHECK(bounds.alloc(ctx->pool, (int64_t) nprev * (C + 1)));
+            BT_CHECK(nnew.alloc(ctx->pool, nprev));
+            BT_CHECK(offsets.alloc(ctx->pool, nprev));
+            BT_HIP_CHECK(hipMemsetAsync(d_flags.get(), 0, sizeof(LevelFlags), ctx->stream));
+
+            BuildArgs a{};
+            a.keys = kkeys;
+            a.wprefix = st->wprefix.get();
+            a.box_start = st->box_start.get(); a.box_count = st->box_count.get();
+            a.box_parent = st->box_parent.get(); a.box_nonchild = st->box_nonchild.get();
+            a.box_child = st->box_child.get();
+            a.box_level = st->box_level.get(); a.box_haschild = st->box_haschild.get();
+            a.bounds = bounds.get(); a.nnew = nnew.get(); a.offsets = offsets.get();
+            a.flags = d_flags.get(); a.status = ctx->d_status;
+            a.max_weight = p.max_leaf_refine_weight;
+            a.level = level; a.L = Lkey; a.capbits = st->capbits;
+            a.b0 = b0; a.nprev = nprev;
+            a.adaptive = p.kind != BT_KIND_NON_ADAPTIVE;
+            a.top_level = p.top_level;
+            a.top_prefix = p.top_cell_prefix;
+            a.keep_empty = p.skip_prune ? 1 : 0;
+            a.loff = loff;
+            a.can_continue = can_continue ? 1 : 0;
+            a.cand = (level == loff + 1) ? cand : nullptr;
+
+            const unsigned blocks = (unsigned) div_up((int64_t) nprev * C, 256);
+            if (EXT) count_children_kernel<D, true><<<blocks, 256, 0, ctx->stream>>>(a);
+            else count_children_kernel<D, false><<<blocks, 256, 0, ctx->stream>>>(a);
+            ScanNnew sn{nnew.get()};
+            BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, sn, nprev, offsets.get(),
+                                                              &d_flags.get()->total_new)));
+            BT_HIP_CHECK(hipMemcpyAsync(h_flags, d_flags.get(), sizeof(LevelFlags),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            ctx->n_host_syncs++;
+            if (h_flags->need_more) *need_more = true;
+            const int total_new = h_flags->total_new;
+            if (total_new == 0) break;                 // tree_build.py:1016-1025 / no split
+
+            const int64_t new_start = st->level_start[level];
+            BT_CHECK(ensure_box_capacity(ctx, st, new_start + total_new, sizeof(T)));
+            // pointers may have moved
+            a.box_start = st->box_start.get(); a.box_count = st->box_count.get();
+            a.box_parent = st->box_parent.get(); a.box_nonchild = st->box_nonchild.get();
+            a.box_child = st->box_child.get();
+            a.box_level = st->box_level.get(); a.box_haschild = st->box_haschild.get();
+            a.new_level_start = (int) new_start;
+            write_children_kernel<T, D><<<blocks, 256, 0, ctx->stream>>>(
+                a, (T *) st->centers.get(), (T) p.root_extent);
+            BT_HIP_CHECK(hipGetLastError());
+            st->nboxes = new_start + total_new;
+            st->level_start.push_back((int32_t) st->nboxes);
+            if (!h_flags->have_oversize) break;        // tree_build.py:1228-1230
+            level += 1;
+            if (level - loff > Lkey + 1) break;        // defensive; the device flags the depth
         }
-        const int b0 = st->level_start[level - 1];
-        const int nprev = st->level_start[level] - b0;
-        Buf<int32_t> bounds, nnew, offsets;
-        BT_CHECK(bounds.alloc(ctx->pool, (int64_t) nprev * (C + 1)));
-        BT_CHECK(nnew.alloc(ctx->pool, nprev));
-        BT_CHECK(offsets.alloc(ctx->pool, nprev));
-        BT_HIP_CHECK(hipMemsetAsync(d_flags.get(), 0, sizeof(LevelFlags), ctx->stream));
+        return BT_OK;
+    };
 
-        BuildArgs a{};
-        a.keys = keys;
-        a.wprefix = st->wprefix.get();
-        a.box_start = st->box_start.get(); a.box_count = st->box_count.get();
-        a.box_parent = st->box_parent.get(); a.box_nonchild = st->box_nonchild.get();
-        a.box_child = st->box_child.get();
-        a.box_level = st->box_level.get(); a.box_haschild = st->box_haschild.get();
-        a.bounds = bounds.get(); a.nnew = nnew.get(); a.offsets = offsets.get();
-        a.flags = d_flags.get(); a.status = ctx->d_status;
-        a.max_weight = p.max_leaf_refine_weight;
-        a.level = level; a.L = st->L; a.capbits = st->capbits;
-        a.b0 = b0; a.nprev = nprev;
-        a.adaptive = p.kind != BT_KIND_NON_ADAPTIVE;
-        a.top_level = p.top_level;
-        a.top_prefix = p.top_cell_prefix;
-        a.keep_empty = p.skip_prune ? 1 : 0;
-
-        const unsigned blocks = (unsigned) div_up((int64_t) nprev * C, 256);
-        if (EXT) count_children_kernel<D, true><<<blocks, 256, 0, ctx->stream>>>(a);
-        else count_children_kernel<D, false><<<blocks, 256, 0, ctx->stream>>>(a);
-        ScanNnew sn{nnew.get()};
-        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, sn, nprev, offsets.get(),
-                                                          &d_flags.get()->total_new)));
-        BT_HIP_CHECK(hipMemcpyAsync(h_flags, d_flags.get(), sizeof(LevelFlags),
-                                    hipMemcpyDeviceToHost, ctx->stream));
+    // levels addressable below the first key (the per-axis cell index has 31 bits)
+    const int L2 = KEY_AXIS_BITS - st->L;
+    bool need_more = false;
+    if (enter_loop) BT_CHECK(level_loop(keys, st->L, 0, nullptr, L2 > 0, &need_more));
+    if (need_more) {
+        // ---- continuation below level L1 = st->L (keygen2_kernel) ---------------------
+        const int L1 = st->L;
+        const int keybits2 = D * L2 + st->capbits;
+        const int b0 = st->level_start[L1];
+        const int nb = st->level_start[L1 + 1] - b0;
+        RekeyPred pr{st->box_count.get(), st->wprefix.get(), st->box_start.get(), b0,
+                     p.max_leaf_refine_weight, p.kind != BT_KIND_NON_ADAPTIVE};
+        Buf<int32_t> seg_rank, seg_off, seg_box, seg_start;
+        Buf<uint8_t> cand;
+        BT_CHECK(seg_rank.alloc(ctx->pool, nb + 1));
+        BT_CHECK(seg_off.alloc(ctx->pool, nb + 1));
+        BT_CHECK(cand.alloc(ctx->pool, nb));
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, RekeyFlag{pr}, nb, seg_rank.get(),
+                                                          (int32_t *) nullptr, true)));
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, RekeyCount{pr}, nb, seg_off.get(),
+                                                          (int32_t *) nullptr, true)));
+        int32_t h_tot[2] = {0, 0};
+        BT_HIP_CHECK(hipMemcpyAsync(&h_tot[0], seg_rank.get() + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipMemcpyAsync(&h_tot[1], seg_off.get() + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
         BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        const int total_new = h_flags->total_new;
-        if (total_new == 0) break;                 // tree_build.py:1016-1025 / no split
-
-        const int64_t new_start = st->level_start[level];
-        BT_CHECK(ensure_box_capacity(ctx, st, new_start + total_new, sizeof(T)));
-        // pointers may have moved
-        a.box_start = st->box_start.get(); a.box_count = st->box_count.get();
-        a.box_parent = st->box_parent.get(); a.box_nonchild = st->box_nonchild.get();
-        a.box_child = st->box_child.get();
-        a.box_level = st->box_level.get(); a.box_haschild = st->box_haschild.get();
-        a.new_level_start = (int) new_start;
-        write_children_kernel<T, D><<<blocks, 256, 0, ctx->stream>>>(
-            a, (T *) st->centers.get(), (T) p.root_extent);
+        ctx->n_host_syncs++;
+        const int32_t nseg = h_tot[0];
+        const int64_t M = h_tot[1];
+        int segbits = 1;
+        while (((int64_t) 1 << segbits) < nseg) ++segbits;
+        if (keybits2 + segbits > 64) {
+            set_error("%d boxes of level %d have to be refined below the reach of the 64-bit "
+                      "Morton key: more than its continuation can tell apart", nseg, L1);
+            return BT_ERR_UNSUPPORTED;
+        }
+        BT_CHECK(seg_box.alloc(ctx->pool, nseg));
+        BT_CHECK(seg_start.alloc(ctx->pool, nseg + 1));
+        rekey_segments_kernel<<<(unsigned) div_up(nb + 1, 256), 256, 0, ctx->stream>>>(
+            nb, pr, seg_rank.get(), seg_off.get(), cand.get(), seg_box.get(), seg_start.get());
+        Buf<uint64_t> k2a, k2b;
+        Buf<uint32_t> i2a, i2b;
+        Buf<int32_t> positions;
+        BT_CHECK(k2a.alloc(ctx->pool, M));
+        BT_CHECK(k2b.alloc(ctx->pool, M));
+        BT_CHECK(i2a.alloc(ctx->pool, M));
+        BT_CHECK(i2b.alloc(ctx->pool, M));
+        BT_CHECK(positions.alloc(ctx->pool, M));
+        Keygen2Args<T, D> ka{};
+        ka.packed = (const T *) st->packed.get();
+        ka.src_radii = (const T *) p.source_radii;
+        ka.tgt_radii = (const T *) p.target_radii;
+        ka.nsources = st->nsources;
+        for (int ax = 0; ax < D; ++ax) {
+            ka.bbox_min[ax] = (T) p.bbox_min[ax];
+            ka.bbox_max[ax] = (T) p.bbox_max[ax];
+        }
+        ka.stick_out_factor = (T) p.stick_out_factor;
+        ka.L1 = L1; ka.L2 = L2; ka.capbits = st->capbits; ka.norm = p.extent_norm;
+        ka.point_skip_levels = std::min(point_skip_raw, KEY_AXIS_BITS);
+        ka.ids = ids;
+        ka.box_start = st->box_start.get();
+        ka.seg_box = seg_box.get(); ka.seg_start = seg_start.get();
+        ka.nseg = nseg; ka.m = M;
+        const unsigned kblocks = (unsigned) div_up(M, 256);
+        if (EXT) keygen2_kernel<T, D, true><<<kblocks, 256, 0, ctx->stream>>>(ka, k2a.get(), i2a.get(), positions.get());
+        else keygen2_kernel<T, D, false><<<kblocks, 256, 0, ctx->stream>>>(ka, k2a.get(), i2a.get(), positions.get());
+        bool in_b = false;
+        BT_CHECK(radix_sort_pairs<uint64_t>(ctx, k2a.get(), i2a.get(), k2b.get(), i2b.get(), M, 0,
+                                            keybits2 + segbits, false, &in_b));
+        // the re-keyed boxes keep their ranges: compact index j <-> position positions[j]
+        // (ascending), so the sorted pairs go back in order; keys_oth is free after the
+        // full sort and becomes the key array of the deeper levels
+        scatter_rekeyed_kernel<<<kblocks, 256, 0, ctx->stream>>>(
+            M, positions.get(), in_b ? k2b.get() : k2a.get(), in_b ? i2b.get() : i2a.get(),
+            keys_oth, ids);
+        if (p.refine_weights) {
+            // positions inside the re-keyed boxes changed: weight prefix sums again
+            GatherWeight gw{p.refine_weights, ids};
+            BT_CHECK((device_exclusive_scan<int64_t, int64_t>(ctx, gw, N, st->wprefix.get(),
+                                                              (int64_t *) nullptr, true)));
+        }
         BT_HIP_CHECK(hipGetLastError());
-        st->nboxes = new_start + total_new;
-        st->level_start.push_back((int32_t) st->nboxes);
-        if (!h_flags->have_oversize) break;        // tree_build.py:1228-1230
-        level += 1;
-        if (level > st->L + 1) break;              // defensive; max_levels flag is set on device
+        const uint64_t *keys2 = keys_oth;
+        bool dummy = false;
+        level = L1 + 1;
+        BT_CHECK(level_loop(keys2, L2, L1, cand.get(), false, &dummy));
+        // (the scratch buffers of this block are released after the work that reads them
+        // has been queued on the stream; the pool hands memory to this stream only)
     }
     BT_CHECK(check_status(ctx));
     BT_CHECK(mark(ctx, st, "boxes"));

@@ -184,6 +184,55 @@ def test_user_bbox(actx, oracle):
                trav_kw={})
 
 
+def clustered_points(dims, n_bg, n_cl, scale, seed):
+    """Uniform background plus a cluster of width `scale` around an interior point."""
+    rng = np.random.default_rng(seed)
+    bg = [rng.random(n_bg) for _ in range(dims)]
+    c = rng.random(dims) * 0.5 + 0.25
+    cl = [c[d] + scale * rng.random(n_cl) for d in range(dims)]
+    return [np.concatenate([bg[d], cl[d]]) for d in range(dims)]
+
+
+@pytest.mark.parametrize("log2_scale,n_cl", [(-20, 400), (-22, 3000), (-24, 800)])
+def test_deep_tree_below_the_key(actx, oracle, log2_scale, n_cl):
+    """3D trees deeper than the 21 levels of the 64-bit Morton key: the boxes of level
+    21 that still have to split are re-keyed for the levels below (the reference
+    keeps splitting, tree_build.py:622, 705-709)."""
+    p = clustered_points(3, 20000, n_cl, 2.0 ** log2_scale, seed=7 - log2_scale)
+    htree, otree, htrav, _ = build_both(actx, oracle, p, max_particles_in_box=8, trav_kw={})
+    assert 23 <= htree.nlevels <= 30          # (level 30 and below: DESIGN.md, int-shift deviation)
+    check_tree(htree, p, max_particles_in_box=8)
+    check_traversal(htree, htrav)
+
+
+def test_deep_tree_below_the_key_two_clusters_weights(actx, oracle):
+    """Several re-keyed boxes at once, explicit refine weights (the weight prefix sums
+    are rebuilt after the re-sort)."""
+    rng = np.random.default_rng(5)
+    a = clustered_points(3, 5000, 500, 2.0 ** -22, seed=1)
+    b = clustered_points(3, 5000, 700, 2.0 ** -23, seed=2)
+    p = [np.concatenate([a[d], b[d]]) for d in range(3)]
+    rw = rng.integers(1, 5, len(p[0]), dtype=np.int32)
+    htree, _, _, _ = build_both(actx, oracle, p, refine_weights=rw, max_leaf_refine_weight=20)
+    assert htree.nlevels >= 24
+    check_tree(htree, p, refine_weights=rw, max_leaf_refine_weight=20)
+
+
+def test_deep_tree_below_the_key_with_extents(actx, oracle):
+    """Target radii: the key has 19 levels, the continuation key carries the stop
+    level of every re-keyed particle (tbk:388-428 evaluated below level 19)."""
+    src = clustered_points(3, 8000, 600, 2.0 ** -22, seed=3)
+    rng = np.random.default_rng(9)
+    c = [float(np.median(src[d][-600:])) for d in range(3)]
+    tgt = [np.concatenate([rng.random(2000), c[d] + 2.0 ** -22 * rng.random(300)])
+           for d in range(3)]
+    radii = np.concatenate([2.0 ** rng.uniform(-12, -6, 2000), 2.0 ** rng.uniform(-30, -20, 300)])
+    htree, _, htrav, _ = build_both(actx, oracle, src, targets=tgt, target_radii=radii,
+                                    stick_out_factor=0.25, max_particles_in_box=8, trav_kw={})
+    assert htree.nlevels >= 21
+    check_traversal(htree, htrav)
+
+
 def test_max_levels_exceeded(actx):
     from boxtree_amd import MaxLevelsExceeded, TreeBuilder
     p = [np.zeros(100), np.zeros(100)]

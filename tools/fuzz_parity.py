@@ -237,10 +237,13 @@ def run(ncases, first_seed, verbose=True, aux=True):
                   flush=True)
             raise
         if oerr is None and derr is not None:
-            # documented deviation: the 64-bit key addresses min(31, 63 // d) levels
-            # (min(31, 57 // d) with extents); deeper trees raise instead of differing
+            # the per-axis cell index has 31 bits (the reference's `1U << (1 + level)`
+            # is undefined beyond): deeper trees raise instead of differing.  Level-
+            # restricted builds stop where the first 64-bit key ends.
             dims_ = len(particles)
-            key_levels = min(31, (57 if "target_radii" in kw else 63) // dims_)
+            key_levels = 31
+            if kw.get("kind") == "adaptive-level-restricted":
+                key_levels = min(31, (57 if "target_radii" in kw else 63) // dims_)
             assert otree.nlevels - 1 > key_levels, (seed, otree.nlevels, key_levels)
             stats["beyond_key_depth"] = stats.get("beyond_key_depth", 0) + 1
             continue
