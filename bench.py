@@ -132,22 +132,44 @@ WORKLOAD_MPB = {"c1": 30}      # max_particles_in_box of a workload (64 unless l
 # }}}
 
 
-def cpu_baseline(workload, n_sample, mpb):
-    """The CPU oracle ("port" of the reference algorithm, 1 thread) timed on a
-    bounded sample of the same workload.  Reported, never the target."""
+def cpu_baseline(workload, n_sample, mpb, reps=3):
+    """The CPU oracle ("port" of the reference's level-loop algorithm) timed on bounded
+    samples of the same workload: once with one thread, once with all host cores (the
+    same source built with -fopenmp, identical results), best of `reps` runs each.
+    Reported, never the target."""
     from oracle import oracle
-    oracle.build_lib()
-    w = make_workload_numpy(workload, n_sample, 15)
-    nn = len(w["particles"][0]) + (len(w["targets"][0]) if w["targets"] else 0)
-    t0 = time.perf_counter()
-    tree = oracle.build_tree(w["particles"], targets=w["targets"],
-                             max_particles_in_box=mpb, **w["kw"])
-    oracle.build_traversal(tree)
-    dt = time.perf_counter() - t0
+
+    def run(variant, threads, n):
+        nthreads = oracle.set_variant(variant, threads)
+        w = make_workload_numpy(workload, n, 15)
+        nn = len(w["particles"][0]) + (len(w["targets"][0]) if w["targets"] else 0)
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            tree = oracle.build_tree(w["particles"], targets=w["targets"],
+                                     max_particles_in_box=mpb, **w["kw"])
+            oracle.build_traversal(tree)
+            times.append(time.perf_counter() - t0)
+        return nn, nthreads, times
+
+    ncores = os.cpu_count() or 1
+    try:
+        # one thread: a quarter of the sample keeps three repetitions within ~20 s
+        n1, _, t1 = run("seq", None, max(n_sample // 4, 1))
+        nall, nthreads, tall = run("omp", ncores, n_sample)
+    finally:
+        oracle.set_variant("seq")
+    fmt = lambda ts: "/".join(f"{t:.2f}" for t in ts)  # noqa: E731
     return {
-        "value": nn / dt, "unit": "particles/s", "cores": 1, "kind": "port",
-        "sample": f"{workload} recipe at {nn} particles (tree build + traversal, "
-                  f"oracle/boxtree_oracle.c, {dt:.2f} s, {os.cpu_count()} host cores present)",
+        "value": nall / min(tall), "unit": "particles/s", "cores": nthreads, "kind": "port",
+        "sample": f"{workload} recipe at {nall} particles, tree build + traversal, "
+                  f"oracle/boxtree_oracle.c built with -fopenmp on {nthreads} threads "
+                  f"({ncores} host cores present), best of {reps} runs ({fmt(tall)} s)",
+        "single_thread": {
+            "value": n1 / min(t1), "unit": "particles/s", "cores": 1,
+            "sample": f"{workload} recipe at {n1} particles, sequential build of the same "
+                      f"source, best of {reps} runs ({fmt(t1)} s)",
+        },
     }
 
 
@@ -255,7 +277,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         st, times = step()
-        sort_ms.append((st.pass_ms_avg, st.passes, st.n))
+        sort_ms.append((st.full_pass_ms_avg, st.passes, st.n, st.first_pass_ms,
+                        st.first_pass_identity, st.full_passes))
         for k, v in times.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
@@ -284,10 +307,12 @@ def main():
         n_sorted = sort_ms[-1][2]
         achieved = 24.0 * n_sorted / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
         # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes,
-        # corrected as MI355X_MICROARCH.md prescribes; see profiles/r01_pmc_onesweep.json)
+        # corrected as MI355X_MICROARCH.md prescribes; see profiles/*_pmc_onesweep.json)
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_onesweep.json")))
+            pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                               if f.endswith("_pmc_onesweep.json"))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_files[-1])))
             if int(pmc["n_pairs"]) == int(n_sorted):
                 traffic = pmc["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
@@ -315,8 +340,10 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "bt::onesweep_kernel<unsigned long, 512, 16, 4, *> "
-                          "(one 8-bit digit pass of the 64-bit Morton-key sort)",
+                "kernel": "bt::onesweep_kernel<unsigned long, ..., false> (one 8-bit digit pass of "
+                          "the 64-bit Morton-key sort that reads and writes keys and values: "
+                          "24 bytes per pair; the first pass synthesises its values, moves "
+                          "20 bytes per pair and is reported apart)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -325,6 +352,12 @@ def main():
                 "algorithmic_bytes_per_launch": 24.0 * n_sorted,
                 "avg_launch_ms": pass_ms,
                 "passes_per_sort": sort_ms[-1][1],
+                "launches_averaged_per_sort": sort_ms[-1][5],
+                "first_pass": {
+                    "synthesised_values": bool(sort_ms[-1][4]),
+                    "avg_launch_ms": float(np.mean([s[3] for s in sort_ms])),
+                    "algorithmic_bytes_per_launch": (20.0 if sort_ms[-1][4] else 24.0) * n_sorted,
+                },
             },
             "stages_ms": {k: v / args.steps for k, v in stage_acc.items()},
         }

@@ -30,9 +30,14 @@ P3 = vp * BT_MAX_DIMS
 PL = vp * BT_MAX_LEVELS
 
 
+ABI_VERSION = 2      # BT_ABI_VERSION of include/boxtree_hip.h
+
+
 class SortStats(ct.Structure):
     _fields_ = [("n", ct.c_int64), ("passes", ct.c_int32), ("pass_ms_avg", ct.c_float),
-                ("hist_ms", ct.c_float), ("total_ms", ct.c_float)]
+                ("hist_ms", ct.c_float), ("total_ms", ct.c_float),
+                ("first_pass_ms", ct.c_float), ("first_pass_identity", ct.c_int32),
+                ("full_pass_ms_avg", ct.c_float), ("full_passes", ct.c_int32)]
 
 
 class TreeParams(ct.Structure):
@@ -256,7 +261,7 @@ def load():
     lib.bt_gather.argtypes = [vp, ct.c_int, vp, vp, ct.c_int64, vp]
     lib.bt_gather_pack.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), vp, ct.c_int64, vp]
     lib.bt_unpack.argtypes = [vp, ct.c_int, ct.c_int, vp, ct.c_int64, ct.POINTER(vp)]
-    if lib.bt_abi_version() != 1:
+    if lib.bt_abi_version() != ABI_VERSION:
         raise RuntimeError("libboxtree_hip.so ABI version mismatch")
     _lib = lib
     return lib

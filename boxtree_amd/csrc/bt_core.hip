@@ -212,6 +212,8 @@ void bt_destroy(bt_context *ctx)
     bt_free_aq_state(ctx);
     ctx->pool.release_all();
     if (ctx->d_status) (void) hipFree(ctx->d_status);
+    for (void *&e : ctx->sort_ev)
+        if (e) { (void) hipEventDestroy((hipEvent_t) e); e = nullptr; }
     if (ctx->scan_desc) (void) hipFree(ctx->scan_desc);
     if (ctx->scan_ticket) (void) hipFree(ctx->scan_ticket);
     if (ctx->h_status) (void) hipHostFree(ctx->h_status);

@@ -625,6 +625,255 @@ __global__ __launch_bounds__(256) void write_children_kernel(BuildArgs a, T *cen
     a.box_child[(int64_t) b * C + m] = child_id;
 }
 
+// ---------------------------------------------------------------------------
+// One level in ONE launch, no host round trip: count_children + scan + write_children
+// fused.  A workgroup takes tiles of 256 / C parent boxes in ticket order; a tile
+// counts its children (boundaries stay in registers), learns the number of children
+// created before it by decoupled look-back over the preceding tiles (the chained scan
+// of bt_prims.hpp with a second field: "some child is still overfull") and writes its
+// children at their final numbers.  The last tile records where the next level starts
+// and whether any child must split again; the launch of the next level reads that
+// from device memory, so the host can queue several levels blindly and look at the
+// state once (tree_build.py:762-1060 spends a dozen host round trips per level here).
+// ---------------------------------------------------------------------------
+
+struct LoopState {
+    int32_t level_start[BT_MAX_LEVELS + 3];
+    int32_t oversize[BT_MAX_LEVELS + 3];    // level l was created with an overfull child
+    int32_t done;                           // no further level is needed
+    int32_t last_level;                     // deepest level created
+    int32_t overflow;                       // box arrays too small: nothing was written
+    int32_t need_more;                      // continuation keys needed
+};
+
+// descriptor: generation:16 | flag:2 | overfull tiles:14 (saturating) | children:32
+__device__ __forceinline__ uint64_t sl_pack(uint32_t gen, uint32_t flag, uint32_t os, uint32_t sum)
+{
+    if (os > 0x3fffu) os = 0x3fffu;
+    return ((uint64_t) (gen & 0xffffu) << 48) | ((uint64_t) flag << 46) | ((uint64_t) os << 32) | sum;
+}
+
+template <class T, int D, bool EXT>
+__global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState *ls,
+        T *centers /* [cap][D] */, T root_extent, int32_t box_cap, int first_level,
+        uint64_t *desc, uint32_t gen, uint32_t *ticket)
+{
+    constexpr int C = 1 << D;
+    constexpr int PPT = 256 / C;            // parents per tile
+    __shared__ uint32_t s_tile;
+    __shared__ int32_t s_scan[256 / 64 + 1];
+    __shared__ int32_t s_excl;
+    __shared__ int32_t s_os;
+
+    if (ls->done || ls->overflow) return;
+    const int level = a.level;
+    const int b0 = ls->level_start[level - 1];
+    const int nprev = ls->level_start[level] - b0;
+    const int new_level_start = ls->level_start[level];
+    // every workgroup takes the same decision from what earlier launches wrote
+    if (level > first_level && (nprev == 0 || !ls->oversize[level - 1])) {   // tree_build.py:1228-1230
+        if (blockIdx.x == 0 && threadIdx.x == 0) ls->done = 1;
+        return;
+    }
+    const int ntiles = (nprev + PPT - 1) / PPT;
+    const int lane = threadIdx.x & 63;
+    const int m = threadIdx.x % C;
+    const int lr = level - a.loff;          // level relative to the key
+
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) { s_tile = atomicAdd(ticket, 1u); s_os = 0; }
+        __syncthreads();
+        const int tile = (int) s_tile;
+        if (tile >= ntiles) break;
+        const int bl = tile * PPT + threadIdx.x / C;
+        const bool active = bl < nprev;
+        const int b = b0 + (active ? bl : 0);
+
+        // ---- children boundaries (count_children_kernel) ------------------------------
+        int lo = 0, e = 0, s = 0;
+        uint64_t prefix = 0;
+        const bool skipped = a.cand != nullptr && active && !a.cand[bl];
+        if (active) {
+            s = a.box_start[b];
+            e = s + a.box_count[b];
+            if (lr - 1 < a.L && e > s && !skipped) {
+                const int pshift = a.capbits + D * (a.L - (lr - 1));
+                prefix = (pshift >= 64) ? 0 : (a.keys[s] >> pshift);
+                const int cshift = a.capbits + D * (a.L - lr);
+                if (m == 0) {
+                    if (EXT) {
+                        const uint64_t stuck = ((prefix << D) << cshift) | (uint64_t) (lr - 1);
+                        lo = upper_bound_key(a.keys, s, e, stuck);
+                    } else {
+                        lo = s;
+                    }
+                } else {
+                    const uint64_t ck = ((prefix << D) | (uint64_t) m) << cshift;
+                    lo = lower_bound_key(a.keys, s, e, ck);
+                }
+            } else {
+                lo = (m == 0) ? s : e;
+            }
+        }
+        int hi = __shfl_down(lo, 1, C);
+        if (m == C - 1) hi = e;
+        const int first = __shfl(lo, 0, C);     // start of the child-bound range
+
+        bool split = false, oversize = false;
+        int cnt = 0;
+        if (active) {
+            int32_t W = range_weight(a, first, e);                       // tbk:569-573
+            const bool top = a.top_prefix && a.loff == 0 && level - 1 < a.top_level && e > s;
+            if (top) W = top_weight<D>(a, prefix, level - 1);
+            split = a.adaptive ? W > a.max_weight : true;                // tbk:577-597
+            if (skipped) split = false;
+            if (lr - 1 >= a.L) {
+                if (split && e > s && (a.adaptive || W > a.max_weight) && m == 0) {
+                    if (a.can_continue)
+                        __hip_atomic_store(&ls->need_more, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    else
+                        atomicExch(&a.status->max_levels, 1);
+                }
+                split = false;
+            }
+            if (e == s && (a.adaptive || !a.keep_empty)) split = false;
+            cnt = hi - lo;
+            const int32_t Wc = top ? top_weight<D>(a, (prefix << D) | (uint64_t) m, level)
+                                   : range_weight(a, lo, hi);
+            oversize = split && cnt > 0 && Wc > a.max_weight;            // tbk:600-610
+        }
+        const bool nonempty = split && (cnt > 0 || a.keep_empty);
+        const uint64_t bal = __ballot(nonempty);
+        const int gshift = lane / C * C;
+        const uint32_t gmask = (uint32_t) ((bal >> gshift) & ((1ull << C) - 1));
+        const int rank = __popc(gmask & ((1u << m) - 1u));
+        const int nnew = (active && split && m == 0) ? __popc(gmask) : 0;
+        if (__ballot(oversize) != 0ull && lane == 0) s_os = 1;           // (benign race: same value)
+
+        // ---- exclusive offsets of the tile's parents; tile aggregate -----------------------
+        int32_t tile_total = 0;
+        const int32_t in_tile = block_exclusive_scan<int32_t, 256>(nnew, s_scan, &tile_total);
+        const int32_t group_off = __shfl(in_tile, 0, C);     // the group's m == 0 lane
+        const uint32_t tile_os = (uint32_t) s_os;            // written before the scan's barriers
+
+        // ---- look-back over the preceding tiles (wave 0) ---------------------------------
+        if (threadIdx.x < 64) {
+            uint32_t ex_sum = 0, ex_os = 0;
+            if (tile > 0) {
+                if (lane == 0)
+                    __hip_atomic_store(desc + tile, sl_pack(gen, SP_AGG, tile_os, (uint32_t) tile_total),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int64_t look = (int64_t) tile - 1;
+                uint32_t spins = 0;
+                while (true) {
+                    const int64_t idx = look - lane;
+                    uint64_t word = sl_pack(gen, SP_PREFIX, 0, 0);       // before tile 0
+                    if (idx >= 0)
+                        word = __hip_atomic_load(desc + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t flag = (uint32_t) (word >> 46) & 3u;
+                    const bool valid = (uint32_t) (word >> 48) == (gen & 0xffffu) && flag != 0;
+                    const uint64_t is_prefix = __ballot(valid && flag == SP_PREFIX);
+                    const uint64_t invalid = __ballot(!valid);
+                    const int first_prefix = is_prefix ? __builtin_ctzll(is_prefix) : 64;
+                    const int first_invalid = invalid ? __builtin_ctzll(invalid) : 64;
+                    if (first_invalid <= first_prefix && first_invalid < 64) {
+                        if (++spins > SP_SPIN_LIMIT) {
+                            if (lane == 0) atomicExch(&a.status->internal, 78);
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(1);
+                        continue;
+                    }
+                    const bool use = lane <= first_prefix;
+                    ex_sum += wave_reduce_sum(use ? (uint32_t) word : 0u);
+                    ex_os += wave_reduce_sum(use ? (uint32_t) (word >> 32) & 0x3fffu : 0u);
+                    if (first_prefix < 64) break;
+                    look -= 64;
+                }
+            }
+            if (lane == 0) {
+                __hip_atomic_store(desc + tile,
+                                   sl_pack(gen, SP_PREFIX, ex_os + tile_os, ex_sum + (uint32_t) tile_total),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_excl = (int32_t) ex_sum;
+                if (tile == ntiles - 1) {
+                    // the level is complete as far as the counts go
+                    const int64_t end = (int64_t) new_level_start + ex_sum + (uint32_t) tile_total;
+                    if (end > (int64_t) box_cap) {
+                        ls->overflow = level;
+                        ls->level_start[level + 1] = new_level_start;
+                    } else {
+                        ls->level_start[level + 1] = (int32_t) end;
+                        ls->oversize[level] = (ex_os + tile_os) > 0 ? 1 : 0;
+                        if (end > new_level_start) ls->last_level = level;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!active) continue;
+
+        // ---- children (write_children_kernel) -------------------------------------------------
+        int32_t child_id = 0;
+        const int64_t cid = (int64_t) new_level_start + s_excl + group_off + rank;
+        const bool fits = cid < (int64_t) box_cap;
+        if (nonempty && fits) {
+            child_id = (int32_t) cid;                                  // tbk:667 (after pruning)
+            a.box_start[child_id] = hi > lo ? lo : 0;
+            a.box_count[child_id] = hi - lo;
+            a.box_parent[child_id] = b;
+            a.box_level[child_id] = (uint8_t) level;
+            a.box_haschild[child_id] = 0;
+            a.box_nonchild[child_id] = 0;
+            // tbk:698-705: centre = parent centre +/- root_extent / 2^(1+level)
+            const T radius = (root_extent * 1 / (T) (1ull << (1 + level)));
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) {
+                const bool has_bit = (m >> (D - 1 - ax)) & 1;
+                const T pc = centers[(int64_t) b * D + ax];
+                centers[(int64_t) child_id * D + ax] = has_bit ? pc + radius : pc - radius;
+            }
+#pragma unroll
+            for (int mm = 0; mm < C; ++mm) a.box_child[(int64_t) child_id * C + mm] = 0;
+        }
+        a.box_child[(int64_t) b * C + m] = child_id;
+        if (m == 0) {
+            a.box_haschild[b] = split ? 1 : 0;
+            a.box_nonchild[b] = split ? (first - s) : 0;
+        }
+    }
+}
+
+template <class T, int D>
+__global__ void init_root_kernel(BuildArgs a, LoopState *ls, T *centers, int32_t n, T bbox_min0,
+        T bbox_min1, T bbox_min2, T bbox_max0, T bbox_max1, T bbox_max2, uint32_t *tickets)
+{
+    constexpr int C = 1 << D;
+    const int t = threadIdx.x;
+    if (t == 0) {
+        // root box: tree_build.py:585-618
+        a.box_start[0] = 0; a.box_count[0] = n; a.box_parent[0] = 0;
+        a.box_level[0] = 0; a.box_haschild[0] = 0; a.box_nonchild[0] = 0;
+        const T mn[3] = {bbox_min0, bbox_min1, bbox_min2}, mx[3] = {bbox_max0, bbox_max1, bbox_max2};
+        for (int ax = 0; ax < D; ++ax) centers[ax] = mn[ax] + (mx[ax] - mn[ax]) / 2;
+        for (int m = 0; m < C; ++m) a.box_child[m] = 0;
+        ls->level_start[0] = 0; ls->level_start[1] = 1;
+        ls->done = 0; ls->last_level = 0; ls->overflow = 0; ls->need_more = 0;
+    }
+    if (t < BT_MAX_LEVELS + 3) { ls->oversize[t] = 0; tickets[t] = 0; }
+    if (t >= 2 && t < BT_MAX_LEVELS + 3) ls->level_start[t] = 1;
+}
+
+// after a capacity overflow at level `from`: forget what the launches from that level on did
+__global__ void reset_loop_kernel(LoopState *ls, uint32_t *tickets, int from)
+{
+    const int t = threadIdx.x;
+    if (t == 0) { ls->done = 0; ls->overflow = 0; }
+    if (t >= from && t < BT_MAX_LEVELS + 3) { ls->oversize[t] = 0; tickets[t] = 0; }
+    if (t > from && t < BT_MAX_LEVELS + 3) ls->level_start[t] = ls->level_start[from];
+}
+
 struct ScanNnew {
     const int32_t *nnew;
     __device__ int32_t operator()(int64_t i) const { return nnew[i]; }
@@ -1057,10 +1306,11 @@ int ensure_box_capacity(bt_context *ctx, TreeState *st, int64_t need, size_t coo
     BT_CHECK(grow(ctx, st->box_start, old, nc, false));
     BT_CHECK(grow(ctx, st->box_count, old, nc, false));
     BT_CHECK(grow(ctx, st->box_parent, old, nc, false));
-    BT_CHECK(grow(ctx, st->box_nonchild, old, nc, true));
-    BT_CHECK(grow(ctx, st->box_child, old * st->C, nc * st->C, true));
+    // (every field of a box is written when the box is created: no zero fill)
+    BT_CHECK(grow(ctx, st->box_nonchild, old, nc, false));
+    BT_CHECK(grow(ctx, st->box_child, old * st->C, nc * st->C, false));
     BT_CHECK(grow(ctx, st->box_level, old, nc, false));
-    BT_CHECK(grow(ctx, st->box_haschild, old, nc, true));
+    BT_CHECK(grow(ctx, st->box_haschild, old, nc, false));
     BT_CHECK(grow(ctx, st->centers, old * st->D * (int64_t) coord_size,
                   nc * st->D * (int64_t) coord_size, false));
     st->cap = nc;
@@ -1673,35 +1923,50 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     }
 
     // ---- boxes, level by level -------------------------------------------------
+    // Capacity up front (twice the number of boxes a tree with full leaves would have,
+    // times the fan-out; measured trees need 2-3.5 N/mpb): the level kernels check it,
+    // and an overflow grows the arrays and repeats the level.
     st->nboxes = 0;
     st->cap = 0;
-    BT_CHECK(ensure_box_capacity(ctx, st, 1024, sizeof(T)));
     {
-        // root box: tree_build.py:585-618
-        int32_t zero = 0, n32 = (int32_t) N;
-        T center[D];
-        for (int ax = 0; ax < D; ++ax) {
-            const T mn = (T) p.bbox_min[ax], mx = (T) p.bbox_max[ax];
-            center[ax] = mn + (mx - mn) / 2;
-        }
-        BT_HIP_CHECK(hipMemcpyAsync(st->box_start.get(), &zero, 4, hipMemcpyHostToDevice, ctx->stream));
-        BT_HIP_CHECK(hipMemcpyAsync(st->box_count.get(), &n32, 4, hipMemcpyHostToDevice, ctx->stream));
-        BT_HIP_CHECK(hipMemcpyAsync(st->box_parent.get(), &zero, 4, hipMemcpyHostToDevice, ctx->stream));
-        BT_HIP_CHECK(hipMemsetAsync(st->box_level.get(), 0, 1, ctx->stream));
-        BT_HIP_CHECK(hipMemcpyAsync(st->centers.get(), center, sizeof(T) * D, hipMemcpyHostToDevice,
-                                    ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // host temporaries go out of scope
+        const double per_leaf = (double) N / std::max(1, p.max_leaf_refine_weight);
+        const int64_t guess = (int64_t) std::min(2.0 * C * per_leaf + 4096.0, 2.0e9);
+        BT_CHECK(ensure_box_capacity(ctx, st, std::max<int64_t>(guess, 1024), sizeof(T)));
+    }
+    Buf<LoopState> d_ls;
+    Buf<uint32_t> tickets;
+    BT_CHECK(d_ls.alloc(ctx->pool, 1));
+    BT_CHECK(tickets.alloc(ctx->pool, BT_MAX_LEVELS + 3));
+    LoopState *h_ls = nullptr;
+    BT_HIP_CHECK(hipHostMalloc((void **) &h_ls, sizeof(LoopState), hipHostMallocDefault));
+    struct HostFree { LoopState *p; ~HostFree() { (void) hipHostFree(p); } } host_free{h_ls};
+
+    auto base_args = [&](BuildArgs &a) {
+        a = BuildArgs{};
+        a.wprefix = st->wprefix.get();
+        a.box_start = st->box_start.get(); a.box_count = st->box_count.get();
+        a.box_parent = st->box_parent.get(); a.box_nonchild = st->box_nonchild.get();
+        a.box_child = st->box_child.get();
+        a.box_level = st->box_level.get(); a.box_haschild = st->box_haschild.get();
+        a.status = ctx->d_status;
+        a.max_weight = p.max_leaf_refine_weight;
+        a.capbits = st->capbits;
+        a.adaptive = p.kind != BT_KIND_NON_ADAPTIVE;
+        a.top_level = p.top_level;
+        a.top_prefix = p.top_cell_prefix;
+        a.keep_empty = p.skip_prune ? 1 : 0;
+    };
+    {
+        BuildArgs a;
+        base_args(a);
+        T mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+        for (int ax = 0; ax < D; ++ax) { mn[ax] = (T) p.bbox_min[ax]; mx[ax] = (T) p.bbox_max[ax]; }
+        init_root_kernel<T, D><<<1, 128, 0, ctx->stream>>>(a, d_ls.get(), (T *) st->centers.get(),
+                (int32_t) N, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], tickets.get());
     }
     st->nboxes = 1;
     st->level_start = {0, 1};
 
-    Buf<LevelFlags> d_flags;
-    BT_CHECK(d_flags.alloc(ctx->pool, 1));
-    LevelFlags *h_flags = nullptr;
-    BT_HIP_CHECK(hipHostMalloc((void **) &h_flags, sizeof(LevelFlags), hipHostMallocDefault));
-    struct HostFree { LevelFlags *p; ~HostFree() { (void) hipHostFree(p); } } host_free{h_flags};
-
-    int level = 1;
     const bool level_restricted = p.kind == BT_KIND_ADAPTIVE_LEVEL_RESTRICTED;
     if (level_restricted && N > 0) BT_CHECK((lr_build_boxes<T, D>(ctx, st, keys)));
     // tree_build.py:676: the level loop is not entered at all when the root is not
@@ -1717,13 +1982,38 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         }
         if (total <= (int64_t) p.max_leaf_refine_weight) enter_loop = false;
     }
-    // one pass of the level loop on one key array: `kkeys` addresses the levels
-    // loff+1 .. loff+Lkey; *need_more comes back set when a box of level loff+Lkey
-    // must split (and a continuation key exists)
+
+    // descriptors of the level kernels' look-back (generation-tagged, never cleared
+    // between launches; cleared when the 16-bit tag wraps)
+    Buf<uint64_t> sl_desc;
+    auto ensure_desc = [&]() -> int {
+        const int64_t need = st->cap / (256 / C) + 2;
+        if (sl_desc.size() < need) {
+            BT_CHECK(sl_desc.alloc(ctx->pool, need));
+            BT_HIP_CHECK(hipMemsetAsync(sl_desc.get(), 0, (size_t) need * 8, ctx->stream));
+        }
+        return BT_OK;
+    };
+    uint32_t sl_gen = 0;
+
+    // Levels first_level .. on one key array (`kkeys` addresses the levels loff+1 ..
+    // loff+Lkey).  Launches are queued in batches without looking at the result; the
+    // state comes back once per batch.  *need_more: a box of level loff+Lkey must split
+    // (and a continuation key exists).
     auto level_loop = [&](const uint64_t *&kkeys, int Lkey, int loff, const uint8_t *cand,
-                          bool can_continue, bool *need_more) -> int {
+                          bool can_continue, int first_level, bool *need_more) -> int {
+        int next = first_level;
+        const int deepest = loff + Lkey + 1;         // its launch only reports "too deep"
+        // depth estimate for the first batch: points on a (D-1)-dimensional set fill
+        // 2^(D-1) children per split
+        int batch = 4;
+        if (loff == 0) {
+            const double per_leaf = std::max(1.0, (double) N / std::max(1, p.max_leaf_refine_weight));
+            const int fan = D > 1 ? D - 1 : 1;
+            batch = std::max(4, (int) std::ceil(std::log2(per_leaf) / fan) + 2);
+        }
         while (true) {
-            if (loff == 0 && D * level > sorted_high_bits) {
+            if (loff == 0 && D * next > sorted_high_bits) {
                 // deeper than the sorted key bits reach: order all bits now.  Box ranges
                 // stay valid (the order of the top bits does not change); ties keep
                 // whatever order they have, the fix-up sorts leaves by user id anyway.
@@ -1734,72 +2024,73 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
                 kkeys = keys_cur;
                 sorted_high_bits = keybits;
             }
-            const int b0 = st->level_start[level - 1];
-            const int nprev = st->level_start[level] - b0;
-            Buf<int32_t> bounds, nnew, offsets;
-            BT_CHECK(bounds.alloc(ctx->pool, (int64_t) nprev * (C + 1)));
-            BT_CHECK(nnew.alloc(ctx->pool, nprev));
-            BT_CHECK(offsets.alloc(ctx->pool, nprev));
-            BT_HIP_CHECK(hipMemsetAsync(d_flags.get(), 0, sizeof(LevelFlags), ctx->stream));
-
-            BuildArgs a{};
-            a.keys = kkeys;
-            a.wprefix = st->wprefix.get();
-            a.box_start = st->box_start.get(); a.box_count = st->box_count.get();
-            a.box_parent = st->box_parent.get(); a.box_nonchild = st->box_nonchild.get();
-            a.box_child = st->box_child.get();
-            a.box_level = st->box_level.get(); a.box_haschild = st->box_haschild.get();
-            a.bounds = bounds.get(); a.nnew = nnew.get(); a.offsets = offsets.get();
-            a.flags = d_flags.get(); a.status = ctx->d_status;
-            a.max_weight = p.max_leaf_refine_weight;
-            a.level = level; a.L = Lkey; a.capbits = st->capbits;
-            a.b0 = b0; a.nprev = nprev;
-            a.adaptive = p.kind != BT_KIND_NON_ADAPTIVE;
-            a.top_level = p.top_level;
-            a.top_prefix = p.top_cell_prefix;
-            a.keep_empty = p.skip_prune ? 1 : 0;
-            a.loff = loff;
-            a.can_continue = can_continue ? 1 : 0;
-            a.cand = (level == loff + 1) ? cand : nullptr;
-
-            const unsigned blocks = (unsigned) div_up((int64_t) nprev * C, 256);
-            if (EXT) count_children_kernel<D, true><<<blocks, 256, 0, ctx->stream>>>(a);
-            else count_children_kernel<D, false><<<blocks, 256, 0, ctx->stream>>>(a);
-            ScanNnew sn{nnew.get()};
-            BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, sn, nprev, offsets.get(),
-                                                              &d_flags.get()->total_new)));
-            BT_HIP_CHECK(hipMemcpyAsync(h_flags, d_flags.get(), sizeof(LevelFlags),
-                                        hipMemcpyDeviceToHost, ctx->stream));
+            int last = std::min(deepest, next + batch - 1);
+            if (loff == 0) last = std::min(last, std::max(next, sorted_high_bits / D));
+            BT_CHECK(ensure_desc());
+            for (int l = next; l <= last; ++l) {
+                BuildArgs a;
+                base_args(a);
+                a.keys = kkeys;
+                a.level = l; a.L = Lkey; a.loff = loff;
+                a.can_continue = can_continue ? 1 : 0;
+                a.cand = (l == loff + 1) ? cand : nullptr;
+                sl_gen += 1;
+                if ((sl_gen & 0xffffu) == 0) {       // tag wrapped: no stale word may survive
+                    BT_HIP_CHECK(hipMemsetAsync(sl_desc.get(), 0, (size_t) sl_desc.size() * 8, ctx->stream));
+                    sl_gen += 1;
+                }
+                // parents of level l-1: at most C^(l-1) (first key) and at most the capacity
+                double bound = loff == 0 ? std::pow((double) C, l - 1) : (double) st->cap;
+                bound = std::min(bound, (double) st->cap);
+                const int64_t tiles = (int64_t) std::ceil(bound / (256 / C));
+                const unsigned grid = (unsigned) std::max<int64_t>(
+                    1, std::min<int64_t>(tiles, (int64_t) ctx->num_cus * 8));
+                if (EXT)
+                    split_level_kernel<T, D, true><<<grid, 256, 0, ctx->stream>>>(
+                        a, d_ls.get(), (T *) st->centers.get(), (T) p.root_extent, (int32_t) st->cap,
+                        first_level, sl_desc.get(), sl_gen, tickets.get() + l);
+                else
+                    split_level_kernel<T, D, false><<<grid, 256, 0, ctx->stream>>>(
+                        a, d_ls.get(), (T *) st->centers.get(), (T) p.root_extent, (int32_t) st->cap,
+                        first_level, sl_desc.get(), sl_gen, tickets.get() + l);
+            }
+            BT_HIP_CHECK(hipGetLastError());
+            BT_HIP_CHECK(hipMemcpyAsync(h_ls, d_ls.get(), sizeof(LoopState), hipMemcpyDeviceToHost,
+                                        ctx->stream));
             BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
             ctx->n_host_syncs++;
-            if (h_flags->need_more) *need_more = true;
-            const int total_new = h_flags->total_new;
-            if (total_new == 0) break;                 // tree_build.py:1016-1025 / no split
-
-            const int64_t new_start = st->level_start[level];
-            BT_CHECK(ensure_box_capacity(ctx, st, new_start + total_new, sizeof(T)));
-            // pointers may have moved
-            a.box_start = st->box_start.get(); a.box_count = st->box_count.get();
-            a.box_parent = st->box_parent.get(); a.box_nonchild = st->box_nonchild.get();
-            a.box_child = st->box_child.get();
-            a.box_level = st->box_level.get(); a.box_haschild = st->box_haschild.get();
-            a.new_level_start = (int) new_start;
-            write_children_kernel<T, D><<<blocks, 256, 0, ctx->stream>>>(
-                a, (T *) st->centers.get(), (T) p.root_extent);
-            BT_HIP_CHECK(hipGetLastError());
-            st->nboxes = new_start + total_new;
-            st->level_start.push_back((int32_t) st->nboxes);
-            if (!h_flags->have_oversize) break;        // tree_build.py:1228-1230
-            level += 1;
-            if (level - loff > Lkey + 1) break;        // defensive; the device flags the depth
+            if (h_ls->overflow) {
+                // the children of level `lv` did not fit: grow (keeping the boxes of the
+                // levels above) and repeat from that level
+                const int lv = h_ls->overflow;
+                st->nboxes = h_ls->level_start[lv];
+                BT_CHECK(ensure_box_capacity(ctx, st, std::max<int64_t>(st->cap * 2, st->nboxes + 1024),
+                                             sizeof(T)));
+                reset_loop_kernel<<<1, 128, 0, ctx->stream>>>(d_ls.get(), tickets.get(), lv);
+                next = lv;
+                continue;
+            }
+            if (h_ls->need_more) *need_more = true;
+            // the loop goes on iff the last queued level was created with an overfull
+            // child (tree_build.py:1228-1230)
+            const bool created_last = h_ls->level_start[last + 1] > h_ls->level_start[last];
+            if (h_ls->done || !created_last || !h_ls->oversize[last] || last >= deepest) break;
+            next = last + 1;
+            batch = 4;
         }
+        // host copy of the level starts: levels [0, nl) exist
+        int nl = first_level;
+        while (nl <= BT_MAX_LEVELS && h_ls->level_start[nl + 1] > h_ls->level_start[nl]) ++nl;
+        st->level_start.resize((size_t) first_level + 1);
+        for (int l = first_level; l < nl; ++l) st->level_start.push_back(h_ls->level_start[l + 1]);
+        st->nboxes = st->level_start.back();
         return BT_OK;
     };
 
     // levels addressable below the first key (the per-axis cell index has 31 bits)
     const int L2 = KEY_AXIS_BITS - st->L;
     bool need_more = false;
-    if (enter_loop) BT_CHECK(level_loop(keys, st->L, 0, nullptr, L2 > 0, &need_more));
+    if (enter_loop) BT_CHECK(level_loop(keys, st->L, 0, nullptr, L2 > 0, 1, &need_more));
     if (need_more) {
         // ---- continuation below level L1 = st->L (keygen2_kernel) ---------------------
         const int L1 = st->L;
@@ -1880,8 +2171,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         BT_HIP_CHECK(hipGetLastError());
         const uint64_t *keys2 = keys_oth;
         bool dummy = false;
-        level = L1 + 1;
-        BT_CHECK(level_loop(keys2, L2, L1, cand.get(), false, &dummy));
+        BT_CHECK(level_loop(keys2, L2, L1, cand.get(), false, L1 + 1, &dummy));
         // (the scratch buffers of this block are released after the work that reads them
         // has been queued on the stream; the pool hands memory to this stream only)
     }

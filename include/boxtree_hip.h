@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BT_ABI_VERSION 1
+#define BT_ABI_VERSION 2
 #define BT_MAX_DIMS 3
 #define BT_MAX_LEVELS 64       /* capacity of per-level arrays in the structs */
 
@@ -106,6 +106,12 @@ typedef struct {
     float pass_ms_avg;         /* HIP-event time of the onesweep kernels / passes */
     float hist_ms;             /* up-front histogram kernel                      */
     float total_ms;
+    /* the first pass apart: with synthesised values (the tree build's sort starts   */
+    /* from 0..n-1) it reads no value array, 20 instead of 24 bytes per pair          */
+    float first_pass_ms;
+    int32_t first_pass_identity;
+    float full_pass_ms_avg;    /* passes that read and write keys and values      */
+    int32_t full_passes;
 } bt_sort_stats;
 int bt_get_sort_stats(bt_context *ctx, bt_sort_stats *out);
 

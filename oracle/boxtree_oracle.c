@@ -40,3 +40,14 @@
 void orc_free(void *p) { free(p); }
 
 int orc_abi_version(void) { return 1; }
+
+/* threads used by the loops (1 in the sequential build) */
+int orc_max_threads(void) { return ORC_NTHREADS(); }
+void orc_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void) n;
+#endif
+}

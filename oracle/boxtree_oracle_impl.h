@@ -1,7 +1,7 @@
 /*
  * TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
  *
- * CPU oracle: a sequential, literal restatement of inducer/boxtree's tree-build
+ * CPU oracle: a literal restatement of inducer/boxtree's tree-build
  * and traversal kernels (reference = /root/reference, version 2024.10).  Only
  * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  *
@@ -39,6 +39,25 @@
 
 #define ORC_MAXDIM 3
 #define ORC_MAXC 8
+
+/* The same source builds the sequential oracle (liboracle.so) and, with -fopenmp,
+ * the all-core CPU baseline (liboracle_omp.so).  Loops over particles / boxes /
+ * list objects are split into one contiguous chunk per thread; chunk results are
+ * combined in chunk order, so both builds produce identical arrays
+ * (tests/test_oracle_openmp.py). */
+#ifdef _OPENMP
+#include <omp.h>
+#define ORC_NTHREADS() omp_get_max_threads()
+#define ORC_TID() omp_get_thread_num()
+#define ORC_PRAGMA(x) _Pragma(#x)
+#else
+#define ORC_NTHREADS() 1
+#define ORC_TID() 0
+#define ORC_PRAGMA(x)
+#endif
+/* chunk [lo_, hi_) of [0, n) of thread t out of nth */
+#define ORC_CHUNK(n, t, nth, lo_, hi_) \
+    const int64_t lo_ = (int64_t) (n) * (t) / (nth), hi_ = (int64_t) (n) * ((t) + 1) / (nth)
 
 enum { ORC_OK = 0, ORC_ERR_MAX_LEVELS = 1, ORC_ERR_ALLOC = 2, ORC_ERR_INTERNAL = 3 };
 enum { ORC_NORM_NONE = 0, ORC_NORM_LINF = 1, ORC_NORM_L2 = 2 };
@@ -156,11 +175,18 @@ void SFX(orc_bbox)(int dims, int64_t n, const COORD_T *const *coords,
 {
     for (int d = 0; d < dims; ++d) {
         COORD_T mn = COORD_MAX, mx = -COORD_MAX;   /* bbox_neutral() :66-75 */
-        for (int64_t i = 0; i < n; ++i) {
-            COORD_T r = radii ? radii[i] : 0;
-            COORD_T lo = coords[d][i] - r, hi = coords[d][i] + r;  /* :77-90 */
-            mn = (lo < mn) ? lo : mn;                              /* :92-99 */
-            mx = (hi > mx) ? hi : mx;
+        ORC_PRAGMA(omp parallel)
+        {
+            COORD_T tmn = COORD_MAX, tmx = -COORD_MAX;
+            ORC_CHUNK(n, ORC_TID(), ORC_NTHREADS(), lo_, hi_);
+            for (int64_t i = lo_; i < hi_; ++i) {
+                COORD_T r = radii ? radii[i] : 0;
+                COORD_T lo = coords[d][i] - r, hi = coords[d][i] + r;  /* :77-90 */
+                tmn = (lo < tmn) ? lo : tmn;                           /* :92-99 */
+                tmx = (hi > tmx) ? hi : tmx;
+            }
+            ORC_PRAGMA(omp critical)
+            { mn = (tmn < mn) ? tmn : mn; mx = (tmx > mx) ? tmx : mx; }
         }
         out_min[d] = mn; out_max[d] = mx;
     }
@@ -401,24 +427,54 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
         }
 
         /* K3 morton_count_scan over all particles (:732, tbk:1555-1572),
-         * segmented by box_start_flags, sequential evaluation */
+         * segmented by box_start_flags.  One chunk per thread: a local scan from the
+         * chunk's start, then the carry of the preceding chunks is added to the items
+         * before the chunk's first segment boundary (scan_t_add is associative). */
         {
-            orc_mc_t acc; memset(&acc, 0, sizeof(acc));
-            for (int64_t i = 0; i < N; ++i) {
-                orc_mc_t item = SFX(orc_scan_t_from_particle)(
-                    in, i, box_levels[srcntgt_box_ids[i]], morton_nrs, user_srcntgt_ids);
-                int seg_start = (i == 0) || box_start_flags[i];
-                acc = SFX(orc_scan_t_add)(acc, item, seg_start, C);
-
+            const int nth = ORC_NTHREADS();
+            orc_mc_t *chunk_end = (orc_mc_t *) calloc((size_t) nth, sizeof(orc_mc_t));
+            int64_t *first_boundary = (int64_t *) calloc((size_t) nth, sizeof(int64_t));
+            if (!chunk_end || !first_boundary) { status = ORC_ERR_ALLOC; goto done; }
+            ORC_PRAGMA(omp parallel num_threads(nth))
+            {
+                const int t = ORC_TID();
+                ORC_CHUNK(N, t, nth, lo_, hi_);
+                orc_mc_t acc; memset(&acc, 0, sizeof(acc));
+                int64_t fb = hi_;                      /* first boundary in the chunk */
+                for (int64_t i = lo_; i < hi_; ++i) {
+                    orc_mc_t item = SFX(orc_scan_t_from_particle)(
+                        in, i, box_levels[srcntgt_box_ids[i]], morton_nrs, user_srcntgt_ids);
+                    int seg_start = (i == 0) || box_start_flags[i];
+                    if (seg_start && fb == hi_) fb = i;
+                    acc = SFX(orc_scan_t_add)(acc, item, seg_start, C);
+                    morton_bin_counts[i] = acc;
+                }
+                chunk_end[t] = acc;
+                first_boundary[t] = fb;
+                ORC_PRAGMA(omp barrier)
+                /* carry into this chunk: the running value at the end of chunk t-1 */
+                orc_mc_t carry; memset(&carry, 0, sizeof(carry));
+                for (int u = 0; u < t; ++u) {
+                    ORC_CHUNK(N, u, nth, ulo, uhi);
+                    int had_boundary = first_boundary[u] < uhi;
+                    (void) ulo;
+                    carry = SFX(orc_scan_t_add)(carry, chunk_end[u], had_boundary, C);
+                }
+                for (int64_t i = lo_; i < fb; ++i)
+                    morton_bin_counts[i] = SFX(orc_scan_t_add)(carry, morton_bin_counts[i], 0, C);
+                ORC_PRAGMA(omp barrier)
                 /* output statement, tbk:480-508 */
-                int32_t my_id_in_my_box = -1 + acc.nonchild_srcntgts;
-                for (int m = 0; m < C; ++m) my_id_in_my_box += acc.pcnt[m];
-                morton_bin_counts[i] = acc;
-                int32_t current_box_id = srcntgt_box_ids[i];
-                int32_t box_srcntgt_count = box_srcntgt_counts_cumul[current_box_id];
-                if (my_id_in_my_box + 1 == box_srcntgt_count)
-                    box_morton_bin_counts[current_box_id] = acc;
+                for (int64_t i = lo_; i < hi_; ++i) {
+                    const orc_mc_t a2 = morton_bin_counts[i];
+                    int32_t my_id_in_my_box = -1 + a2.nonchild_srcntgts;
+                    for (int m = 0; m < C; ++m) my_id_in_my_box += a2.pcnt[m];
+                    int32_t current_box_id = srcntgt_box_ids[i];
+                    int32_t box_srcntgt_count = box_srcntgt_counts_cumul[current_box_id];
+                    if (my_id_in_my_box + 1 == box_srcntgt_count)
+                        box_morton_bin_counts[current_box_id] = a2;
+                }
             }
+            free(chunk_end); free(first_boundary);
         }
 
         /* K4 split_box_id_scan over boxes above the new level (:740-759,
@@ -556,6 +612,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
         nlev_used = level + 1;
 
         /* K5 box_splitter over all boxes (:1072, tbk:646-711) */
+        ORC_PRAGMA(omp parallel for schedule(static))
         for (int64_t ibox = 0; ibox < nboxes_new; ++ibox) {
             int do_split_box = box_has_children[ibox] && (box_levels[ibox] + 1 == level);
             if (level_restrict) do_split_box = do_split_box || force_split_box[ibox];  /* tbk:651-653 */
@@ -588,6 +645,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
         }
 
         /* K6 renumber_particles (:1111, tbk:744-819) */
+        ORC_PRAGMA(omp parallel for schedule(static))
         for (int64_t i = 0; i < N; ++i) {
             int32_t ibox = srcntgt_box_ids[i];
             int do_split_box = box_has_children[ibox] && (box_levels[ibox] + 1 == level);
@@ -745,6 +803,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
             free(arr); arr = na_; } while (0)
         ORC_PRUNE(box_srcntgt_starts, int32_t, 0);
         ORC_PRUNE(box_srcntgt_counts_cumul, int32_t, 0);
+        ORC_PRAGMA(omp parallel for schedule(static))
         for (int64_t i = 0; i < N; ++i)                     /* :1406 map_values */
             srcntgt_box_ids[i] = dst_box_id[srcntgt_box_ids[i]];
         ORC_PRUNE(box_parent_ids, int32_t, 1);
@@ -795,6 +854,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
         out->user_source_ids = (int32_t *) malloc((size_t) (N ? N : 1) * 4);
         out->sorted_target_ids = (int32_t *) calloc((size_t) (N ? N : 1), 4);
         memcpy(out->user_source_ids, user_srcntgt_ids, (size_t) N * 4);
+        ORC_PRAGMA(omp parallel for schedule(static))
         for (int64_t i = 0; i < N; ++i)                  /* K17 tools.py:81-109 */
             out->sorted_target_ids[user_srcntgt_ids[i]] = (int32_t) i;
         /* :1469-1474 */
@@ -826,6 +886,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
             }
         }
         /* K13 find_source_and_target_indices, tbk:1013-1164 */
+        ORC_PRAGMA(omp parallel for schedule(static))
         for (int64_t i = 0; i < N; ++i) {
             int32_t sorted_srcntgt_id = (int32_t) i;
             int32_t source_nr = source_numbers[i];
@@ -883,14 +944,17 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
     for (int d = 0; d < dims; ++d) {
         if (in->sources_are_targets) {
             out->sources[d] = (COORD_T *) malloc((size_t) (N ? N : 1) * sizeof(COORD_T));
+            ORC_PRAGMA(omp parallel for schedule(static))
             for (int64_t i = 0; i < N; ++i)
                 out->sources[d][i] = in->srcntgts[d][user_srcntgt_ids[i]];
             out->targets[d] = out->sources[d];
         } else {
             out->sources[d] = (COORD_T *) malloc((size_t) (nsources ? nsources : 1) * sizeof(COORD_T));
             out->targets[d] = (COORD_T *) malloc((size_t) (ntargets ? ntargets : 1) * sizeof(COORD_T));
+            ORC_PRAGMA(omp parallel for schedule(static))
             for (int64_t i = 0; i < nsources; ++i)
                 out->sources[d][i] = in->srcntgts[d][out->user_source_ids[i]];
+            ORC_PRAGMA(omp parallel for schedule(static))
             for (int64_t i = 0; i < ntargets; ++i)
                 out->targets[d][i] = in->srcntgts[d][srcntgt_target_ids[i]];
         }
@@ -920,6 +984,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
         if (in->sources_are_targets) box_target_counts_nonchild = box_source_counts_nonchild;
         else nonchild_alloc_t = box_target_counts_nonchild = (int32_t *) calloc((size_t) B + 1, 4);
     }
+    ORC_PRAGMA(omp parallel for schedule(static))
     for (int64_t box_id = 0; box_id < B; ++box_id) {
         int32_t particle_count = box_srcntgt_counts_cumul[box_id];
         int32_t nonchild_source_count = have_extent ? box_source_counts_nonchild[box_id] : 0;
@@ -985,6 +1050,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
                                                     : box_target_counts_nonchild;
                 COORD_T *const *particles = round == 0 ? out->sources : out->targets;
                 const COORD_T *pradii = round == 0 ? out->source_radii : out->target_radii;
+                ORC_PRAGMA(omp parallel for schedule(dynamic, 256))
                 for (int64_t ibox = start; ibox < stop; ++ibox) {
                     COORD_T mn[ORC_MAXDIM], mx[ORC_MAXDIM];
                     for (int d = 0; d < dims; ++d)

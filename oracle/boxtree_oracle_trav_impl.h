@@ -1,7 +1,9 @@
 /*
  * TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  See boxtree_oracle_impl.h header.
  *
- * Sequential literal restatement of boxtree/traversal.py (FMMTraversalBuilder).
+ * Literal restatement of boxtree/traversal.py (FMMTraversalBuilder).  The list
+ * generators run over contiguous chunks of their objects, one chunk per thread when
+ * built with -fopenmp; the chunks' lists are concatenated in order.
  * PARITY UNPINNED (see boxtree_oracle_impl.h).
  * Included once per coordinate type (COORD_T / SFX / COORD_SQRT / COORD_EPS).
  */
@@ -109,6 +111,24 @@ static inline int SFX(orc_is_adj)(int dims, COORD_T root_extent,
     walk_morton_nr_stack[walk_stack_size] = walk_morton_nr; \
     ++walk_stack_size; \
     walk_parent_box_id = (new_box); walk_morton_nr = 0
+
+/* per-thread list pieces -> one list (in chunk order) */
+#ifndef ORC_CONCAT_DEFINED
+#define ORC_CONCAT_DEFINED
+static void orc_concat_parts(orc_ivec *dst, orc_ivec *parts, int nparts)
+{
+    int64_t total = 0;
+    for (int t = 0; t < nparts; ++t) total += parts[t].n;
+    dst->data = (int32_t *) malloc((size_t) (total ? total : 1) * sizeof(int32_t));
+    dst->n = 0; dst->cap = total ? total : 1;
+    for (int t = 0; t < nparts; ++t) {
+        if (parts[t].n) memcpy(dst->data + dst->n, parts[t].data, (size_t) parts[t].n * 4);
+        dst->n += parts[t].n;
+        free(parts[t].data);
+    }
+    free(parts);
+}
+#endif
 
 /* finish a CSR list built object-by-object */
 static int SFX(orc_finish_list)(orc_built_list *bl, int64_t n_objects,
@@ -321,7 +341,6 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
     const COORD_T root_extent = in->root_extent;
     const int nway = in->well_sep_is_n_away;
     const int with_extent = in->sources_have_extent || in->targets_have_extent;
-    ORC_WALK_DECL;
     memset(out, 0, sizeof(*out));
 
     /* T1 sources_parents_and_targets: traversal.py:326-355, 2043-2067 */
@@ -368,8 +387,15 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
     {
         orc_ivec l = {0};
         int32_t *counts = (int32_t *) calloc((size_t) B + 1, 4);
-        for (int64_t box_id = 0; box_id < B; ++box_id) {
-            int64_t n0 = l.n;
+        const int nth = ORC_NTHREADS();
+        orc_ivec *parts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
+        ORC_PRAGMA(omp parallel num_threads(nth))
+        {
+        ORC_WALK_DECL;
+        orc_ivec *pl = &parts[ORC_TID()];
+        ORC_CHUNK(B, ORC_TID(), nth, lo_, hi_);
+        for (int64_t box_id = lo_; box_id < hi_; ++box_id) {
+            int64_t n0 = pl->n;
             ORC_LOAD_CENTER(center, box_id);
             if (box_id != 0) {
                 int level = in->box_levels[box_id];
@@ -383,7 +409,7 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
                                 walk_center, in->box_levels[walk_box_id]);
                         if (a_or_o) {
                             if (walk_stack_size + 1 == level && walk_box_id != box_id) {
-                                orc_ivec_push(&l, walk_box_id);
+                                orc_ivec_push(pl, walk_box_id);
                             } else {
                                 ORC_WALK_PUSH(walk_box_id);
                                 continue;
@@ -393,8 +419,10 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
                     ORC_WALK_ADVANCE
                 }
             }
-            counts[box_id] = (int32_t) (l.n - n0);
+            counts[box_id] = (int32_t) (pl->n - n0);
         }
+        }
+        orc_concat_parts(&l, parts, nth);
         SFX(orc_finish_list)(&out->same_level_non_well_sep_boxes, B, counts, &l, 0);
         free(counts);
     }
@@ -404,12 +432,19 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
     {
         orc_ivec l = {0};
         int32_t *counts = (int32_t *) calloc((size_t) ntarget_boxes + 1, 4);
-        for (int64_t tbn = 0; tbn < ntarget_boxes; ++tbn) {
-            int64_t n0 = l.n;
+        const int nth = ORC_NTHREADS();
+        orc_ivec *parts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
+        ORC_PRAGMA(omp parallel num_threads(nth))
+        {
+        ORC_WALK_DECL;
+        orc_ivec *pl = &parts[ORC_TID()];
+        ORC_CHUNK(ntarget_boxes, ORC_TID(), nth, lo_, hi_);
+        for (int64_t tbn = lo_; tbn < hi_; ++tbn) {
+            int64_t n0 = pl->n;
             int32_t box_id = target_boxes[tbn];
             ORC_LOAD_CENTER(center, box_id);
             int level = in->box_levels[box_id];
-            if (in->box_flags[0] & BOX_IS_SOURCE_BOX) orc_ivec_push(&l, 0);
+            if (in->box_flags[0] & BOX_IS_SOURCE_BOX) orc_ivec_push(pl, 0);
             ORC_WALK_INIT(0);
             while (continue_walk) {
                 ORC_WALK_GET_BOX_ID;
@@ -419,7 +454,7 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
                             walk_center, in->box_levels[walk_box_id]);
                     if (a_or_o) {
                         uint8_t flags = in->box_flags[walk_box_id];
-                        if (flags & BOX_IS_SOURCE_BOX) orc_ivec_push(&l, walk_box_id);
+                        if (flags & BOX_IS_SOURCE_BOX) orc_ivec_push(pl, walk_box_id);
                         if (flags & BOX_HAS_SOURCE_CHILD_BOXES) {
                             ORC_WALK_PUSH(walk_box_id);
                             continue;
@@ -428,8 +463,10 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
                 }
                 ORC_WALK_ADVANCE
             }
-            counts[tbn] = (int32_t) (l.n - n0);
+            counts[tbn] = (int32_t) (pl->n - n0);
         }
+        }
+        orc_concat_parts(&l, parts, nth);
         SFX(orc_finish_list)(&out->neighbor_source_boxes, ntarget_boxes, counts, &l, 0);
         free(counts);
     }
@@ -438,8 +475,14 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
     {
         orc_ivec l = {0};
         int32_t *counts = (int32_t *) calloc((size_t) nttp + 1, 4);
-        for (int64_t it = 0; it < nttp; ++it) {
-            int64_t n0 = l.n;
+        const int nth = ORC_NTHREADS();
+        orc_ivec *parts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
+        ORC_PRAGMA(omp parallel num_threads(nth))
+        {
+        orc_ivec *pl = &parts[ORC_TID()];
+        ORC_CHUNK(nttp, ORC_TID(), nth, lo_, hi_);
+        for (int64_t it = lo_; it < hi_; ++it) {
+            int64_t n0 = pl->n;
             int32_t box_id = ttp_boxes[it];
             ORC_LOAD_CENTER(center, box_id);
             int level = in->box_levels[box_id];
@@ -454,12 +497,14 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
                         ORC_LOAD_CENTER(sib_center, sib_box_id);
                         int sep = !SFX(orc_is_adj_nbhd)(dims, root_extent, center, level,
                                 (COORD_T) nway, sib_center, in->box_levels[sib_box_id]);
-                        if (sep) orc_ivec_push(&l, sib_box_id);
+                        if (sep) orc_ivec_push(pl, sib_box_id);
                     }
                 }
             }
-            counts[it] = (int32_t) (l.n - n0);
+            counts[it] = (int32_t) (pl->n - n0);
         }
+        }
+        orc_concat_parts(&l, parts, nth);
         SFX(orc_finish_list)(&out->from_sep_siblings, nttp, counts, &l, 0);
         free(counts);
     }
@@ -470,26 +515,44 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
                 (size_t) in->nlevels + 1, sizeof(orc_built_list));
         int32_t *counts = (int32_t *) calloc((size_t) ntarget_boxes + 1, 4);
         for (int ilevel = 0; ilevel < in->nlevels; ++ilevel) {
-            orc_ivec l = {0}, dummy = {0};
-            for (int64_t tbn = 0; tbn < ntarget_boxes; ++tbn) {
-                int64_t n0 = l.n;
-                SFX(orc_gen_from_sep_smaller)(in, target_boxes, slnws, (int32_t) tbn,
-                        ilevel, &l, &dummy);
-                counts[tbn] = (int32_t) (l.n - n0);
+            orc_ivec l = {0};
+            const int nth = ORC_NTHREADS();
+            orc_ivec *parts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
+            ORC_PRAGMA(omp parallel num_threads(nth))
+            {
+                orc_ivec *pl = &parts[ORC_TID()];
+                orc_ivec dummy = {0};
+                ORC_CHUNK(ntarget_boxes, ORC_TID(), nth, lo_, hi_);
+                for (int64_t tbn = lo_; tbn < hi_; ++tbn) {
+                    int64_t n0 = pl->n;
+                    SFX(orc_gen_from_sep_smaller)(in, target_boxes, slnws, (int32_t) tbn,
+                            ilevel, pl, &dummy);
+                    counts[tbn] = (int32_t) (pl->n - n0);
+                }
+                free(dummy.data);
             }
-            free(dummy.data);
+            orc_concat_parts(&l, parts, nth);
             SFX(orc_finish_list)(&out->from_sep_smaller_by_level[ilevel],
                     ntarget_boxes, counts, &l, 1);
         }
         if (with_extent) {
-            orc_ivec l = {0}, dummy = {0};
-            for (int64_t tbn = 0; tbn < ntarget_boxes; ++tbn) {
-                int64_t n0 = l.n;
-                SFX(orc_gen_from_sep_smaller)(in, target_boxes, slnws, (int32_t) tbn,
-                        -1, &dummy, &l);
-                counts[tbn] = (int32_t) (l.n - n0);
+            orc_ivec l = {0};
+            const int nth = ORC_NTHREADS();
+            orc_ivec *parts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
+            ORC_PRAGMA(omp parallel num_threads(nth))
+            {
+                orc_ivec *pl = &parts[ORC_TID()];
+                orc_ivec dummy = {0};
+                ORC_CHUNK(ntarget_boxes, ORC_TID(), nth, lo_, hi_);
+                for (int64_t tbn = lo_; tbn < hi_; ++tbn) {
+                    int64_t n0 = pl->n;
+                    SFX(orc_gen_from_sep_smaller)(in, target_boxes, slnws, (int32_t) tbn,
+                            -1, &dummy, pl);
+                    counts[tbn] = (int32_t) (pl->n - n0);
+                }
+                free(dummy.data);
             }
-            free(dummy.data);
+            orc_concat_parts(&l, parts, nth);
             SFX(orc_finish_list)(&out->from_sep_close_smaller, ntarget_boxes, counts, &l, 0);
         }
         free(counts);
@@ -500,8 +563,15 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
         orc_ivec l = {0}, lc = {0};
         int32_t *counts = (int32_t *) calloc((size_t) nttp + 1, 4);
         int32_t *ccounts = (int32_t *) calloc((size_t) nttp + 1, 4);
-        for (int64_t it = 0; it < nttp; ++it) {
-            int64_t n0 = l.n, nc0 = lc.n;
+        const int nth = ORC_NTHREADS();
+        orc_ivec *parts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
+        orc_ivec *cparts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
+        ORC_PRAGMA(omp parallel num_threads(nth))
+        {
+        orc_ivec *pl = &parts[ORC_TID()], *plc = &cparts[ORC_TID()];
+        ORC_CHUNK(nttp, ORC_TID(), nth, lo_, hi_);
+        for (int64_t it = lo_; it < hi_; ++it) {
+            int64_t n0 = pl->n, nc0 = plc->n;
             int32_t tgt_ibox = ttp_boxes[it];
             ORC_LOAD_CENTER(tgt_box_center, tgt_ibox);
             int tgt_box_level = in->box_levels[tgt_ibox];
@@ -528,7 +598,7 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
                                     in->stick_out_factor);
                             if (!tgt_meets) {
                                 if (tgt_box_flags & BOX_IS_TARGET_BOX)
-                                    orc_ivec_push(&lc, slnws_box_id);
+                                    orc_ivec_push(plc, slnws_box_id);
                                 continue;
                             }
                         }
@@ -543,17 +613,20 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
                                 int parent_meets = SFX(orc_meets_sep_bigger)(dims, root_extent,
                                         parent_center, tgt_parent_level, slnws_center,
                                         walk_level, in->stick_out_factor);
-                                if (!parent_meets) orc_ivec_push(&l, slnws_box_id);
+                                if (!parent_meets) orc_ivec_push(pl, slnws_box_id);
                             }
                         } else {
-                            orc_ivec_push(&l, slnws_box_id);
+                            orc_ivec_push(pl, slnws_box_id);
                         }
                     }
                 }
             }
-            counts[it] = (int32_t) (l.n - n0);
-            ccounts[it] = (int32_t) (lc.n - nc0);
+            counts[it] = (int32_t) (pl->n - n0);
+            ccounts[it] = (int32_t) (plc->n - nc0);
         }
+        }
+        orc_concat_parts(&l, parts, nth);
+        orc_concat_parts(&lc, cparts, nth);
         SFX(orc_finish_list)(&out->from_sep_bigger, nttp, counts, &l, 0);
         if (with_extent) {
             /* re-index close-bigger from target-or-target-parent to target

@@ -40,14 +40,33 @@ class MaxLevelsExceeded(RuntimeError):   # tree_build.py:79
     pass
 
 
+_VARIANT = "seq"      # "seq": liboracle.so, "omp": liboracle_omp.so (same source, -fopenmp)
+
+
+def set_variant(variant, num_threads=None):
+    """Choose the sequential oracle or its OpenMP build (bench.py's all-core CPU
+    baseline; identical results, tests/test_oracle_openmp.py).  Returns the number of
+    threads the loops will use."""
+    global _VARIANT, _LIB
+    assert variant in ("seq", "omp")
+    if variant != _VARIANT:
+        _VARIANT = variant
+        _LIB = None
+    lib = _lib()
+    lib.orc_set_num_threads(int(num_threads or 0))
+    return int(lib.orc_max_threads())
+
+
 def build_lib(force=False):
-    """Compile liboracle.so with gcc (a few seconds)."""
-    so = os.path.join(_HERE, "liboracle.so")
+    """Compile liboracle.so / liboracle_omp.so with gcc (a few seconds)."""
+    name = "liboracle.so" if _VARIANT == "seq" else "liboracle_omp.so"
+    so = os.path.join(_HERE, name)
     srcs = [os.path.join(_HERE, f) for f in (
-        "boxtree_oracle.c", "boxtree_oracle_impl.h", "boxtree_oracle_trav_impl.h")]
+        "boxtree_oracle.c", "boxtree_oracle_impl.h", "boxtree_oracle_trav_impl.h",
+        "boxtree_oracle_aq_impl.h")]
     if (force or not os.path.exists(so)
             or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "liboracle.so", "-B"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", name, "-B"])
     return so
 
 
@@ -57,6 +76,8 @@ def _lib():
         _LIB = ct.CDLL(build_lib())
         _LIB.orc_free.argtypes = [ct.c_void_p]
         _LIB.orc_free.restype = None
+        _LIB.orc_set_num_threads.argtypes = [ct.c_int]
+        _LIB.orc_max_threads.restype = ct.c_int
     return _LIB
 
 

@@ -19,7 +19,7 @@ def test_header_symbols_exported():
     assert declared == set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.bt_abi_version() == 1
+    assert lib.bt_abi_version() == _lib.ABI_VERSION
 
 
 def test_no_gpu_fails_loudly():
