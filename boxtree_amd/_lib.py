@@ -157,11 +157,43 @@ class AqTree(ct.Structure):
     ]
 
 
+class Span(ct.Structure):
+    _fields_ = [("offset", ct.c_int64), ("count", ct.c_int64)]
+
+
+SpanL = Span * BT_MAX_LEVELS
+LevelStarts = ct.c_int32 * (BT_MAX_LEVELS + 1)
+ALLOC_FN = ct.CFUNCTYPE(ct.c_void_p, ct.c_void_p, ct.c_int64)
+
+
+class TravPacked(ct.Structure):
+    _fields_ = [
+        ("base", vp), ("total", ct.c_int64), ("nlevels", ct.c_int32),
+        ("lattice_path", ct.c_int32), ("sizes", TravSizes),
+        ("level_start_source_box_nrs", LevelStarts),
+        ("level_start_target_box_nrs", LevelStarts),
+        ("level_start_source_parent_box_nrs", LevelStarts),
+        ("level_start_target_or_target_parent_box_nrs", LevelStarts),
+        ("source_boxes", Span), ("target_boxes", Span), ("source_parent_boxes", Span),
+        ("target_or_target_parent_boxes", Span),
+        ("same_level_non_well_sep_boxes_starts", Span), ("same_level_non_well_sep_boxes_lists", Span),
+        ("neighbor_source_boxes_starts", Span), ("neighbor_source_boxes_lists", Span),
+        ("from_sep_siblings_starts", Span), ("from_sep_siblings_lists", Span),
+        ("from_sep_bigger_starts", Span), ("from_sep_bigger_lists", Span),
+        ("from_sep_close_smaller_starts", Span), ("from_sep_close_smaller_lists", Span),
+        ("from_sep_close_bigger_starts", Span), ("from_sep_close_bigger_lists", Span),
+        ("from_sep_smaller_starts", SpanL), ("from_sep_smaller_lists", SpanL),
+        ("from_sep_smaller_nonempty_indices", SpanL),
+        ("from_sep_smaller_compressed_indices", SpanL),
+        ("target_boxes_sep_smaller", SpanL),
+    ]
+
+
 EXPORTED_SYMBOLS = [
     "bt_abi_version", "bt_create", "bt_destroy", "bt_trim", "bt_last_error_string",
     "bt_bbox", "bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32", "bt_get_sort_stats",
     "bt_tree_build", "bt_tree_export", "bt_get_stage_times",
-    "bt_traversal_build", "bt_traversal_export", "bt_merge_csr_lists",
+    "bt_traversal_build", "bt_traversal_export", "bt_traversal_build_packed", "bt_merge_csr_lists",
     "bt_peer_lists_build", "bt_area_query_build", "bt_csr_export", "bt_leaves_to_balls",
     "bt_space_invader_query",
     "bt_fmm_box_particle_sums", "bt_fmm_csr_sum", "bt_fmm_box_to_particles", "bt_fmm_tree_sweep",
@@ -217,6 +249,8 @@ def load():
     lib.bt_get_stage_times.argtypes = [vp, ct.POINTER(StageTimes)]
     lib.bt_traversal_build.argtypes = [vp, ct.POINTER(TravParams), ct.POINTER(TravSizes)]
     lib.bt_traversal_export.argtypes = [vp, ct.POINTER(TravArrays)]
+    lib.bt_traversal_build_packed.argtypes = [vp, ct.POINTER(TravParams), ALLOC_FN, vp,
+                                              ct.POINTER(TravPacked)]
     lib.bt_merge_csr_lists.argtypes = [vp, ct.c_int, ct.POINTER(vp), ct.POINTER(vp),
                                        ct.c_int64, vp, vp]
     lib.bt_peer_lists_build.argtypes = [vp, ct.POINTER(AqTree), ct.POINTER(ct.c_int64)]

@@ -91,6 +91,11 @@ public:
         if (p_ && pool_) pool_->free(p_);
         p_ = nullptr; n_ = 0;
     }
+    // memory owned by someone else (the caller's output block): never freed here
+    void set_external(T *p, int64_t n) {
+        reset();
+        pool_ = nullptr; p_ = p; n_ = n;
+    }
     T *get() const { return p_; }
     int64_t size() const { return n_; }
     void swap(Buf &o) { std::swap(pool_, o.pool_); std::swap(p_, o.p_); std::swap(n_, o.n_); }

@@ -40,6 +40,9 @@ struct Cfg8 { static constexpr int THREADS = 768, ITEMS = 8, MINW = 6; };
 struct Cfg9 { static constexpr int THREADS = 384, ITEMS = 16, MINW = 3; };
 struct Cfg10 { static constexpr int THREADS = 512, ITEMS = 12, MINW = 2; };
 struct Cfg11 { static constexpr int THREADS = 256, ITEMS = 20, MINW = 2; };
+// 16384-key tiles: one workgroup per CU (128 KiB reorder buffer), digit runs twice as
+// long (fewer partial lines), half as many look-back rows
+struct Cfg12 { static constexpr int THREADS = 1024, ITEMS = 16, MINW = 4; };
 
 static int sort_dbg()
 {
@@ -54,22 +57,43 @@ static int sort_cfg_index()
     if (idx < 0) {
         const char *e = getenv("BT_SORT_CFG");
         idx = e ? atoi(e) : 0;
-        if (idx < 0 || idx > 11) idx = 0;
+        if (idx < 0 || idx > 12) idx = 0;
     }
     return idx;
 }
 
-__device__ __forceinline__ uint64_t lb_pack(uint32_t gen, uint32_t flag, uint32_t v)
-{
-    return ((uint64_t) ((gen << 2) | flag) << 32) | v;
-}
+// Look-back words.  64-bit: {generation | flag, count}, one array shared by all passes
+// (the generation tells them apart).  32-bit (n < 2^30): {flag:2 | count:30}, one
+// zeroed array per pass -- half the bytes every poll of a predecessor row moves (the
+// polls were ~0.25 GB of the 2.89 GB a pass over 10^8 pairs moved).
+template <class W> struct Lb;
+template <> struct Lb<uint64_t> {
+    static __device__ __forceinline__ uint64_t pack(uint32_t gen, uint32_t flag, uint32_t v)
+    {
+        return ((uint64_t) ((gen << 2) | flag) << 32) | v;
+    }
+    static __device__ __forceinline__ uint32_t tag(uint64_t w) { return (uint32_t) (w >> 32); }
+    static __device__ __forceinline__ uint32_t want(uint32_t gen, uint32_t flag) { return (gen << 2) | flag; }
+    static __device__ __forceinline__ uint32_t value(uint64_t w) { return (uint32_t) w; }
+};
+template <> struct Lb<uint32_t> {
+    static __device__ __forceinline__ uint32_t pack(uint32_t, uint32_t flag, uint32_t v)
+    {
+        return (flag << 30) | v;
+    }
+    static __device__ __forceinline__ uint32_t tag(uint32_t w) { return w >> 30; }
+    static __device__ __forceinline__ uint32_t want(uint32_t, uint32_t flag) { return flag; }
+    static __device__ __forceinline__ uint32_t value(uint32_t w) { return w & 0x3fffffffu; }
+};
 
-__device__ __forceinline__ void lb_store(uint64_t *p, uint64_t v)
+template <class W>
+__device__ __forceinline__ void lb_store(W *p, W v)
 {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ uint64_t lb_load(const uint64_t *p)
+template <class W>
+__device__ __forceinline__ W lb_load(const W *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -137,24 +161,25 @@ __global__ __launch_bounds__(256) void seed_hist_kernel(const KeyT *__restrict__
 constexpr int MAX_SEED = 1024;
 
 // one workgroup per digit scans that digit's counts over the seeded tiles
+template <class W>
 __global__ __launch_bounds__(MAX_SEED) void seed_scan_kernel(const uint32_t *tile_hist,
-        uint32_t nseed, uint64_t *lookback, uint32_t gen)
+        uint32_t nseed, W *lookback, uint32_t gen)
 {
     __shared__ uint32_t s_tmp[MAX_SEED / 64 + 1];
     const uint32_t d = blockIdx.x, t = threadIdx.x;
     const uint32_t c = (t < nseed) ? tile_hist[t * RADIX + d] : 0u;
     const uint32_t ex = block_exclusive_scan<uint32_t, MAX_SEED>(c, s_tmp, (uint32_t *) nullptr);
-    if (t < nseed) lookback[(uint64_t) t * RADIX + d] = lb_pack(gen, LB_PREFIX, ex + c);
+    if (t < nseed) lookback[(uint64_t) t * RADIX + d] = Lb<W>::pack(gen, LB_PREFIX, ex + c);
 }
 
 // ---- one digit pass ---------------------------------------------------------
 
-template <class KeyT, int THREADS, int ITEMS, int MINW, bool IDENTITY_VALS>
+template <class KeyT, class W, int THREADS, int ITEMS, int MINW, bool IDENTITY_VALS>
 __global__ __launch_bounds__(THREADS, MINW) void onesweep_kernel(
         const KeyT *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
         KeyT *__restrict__ keys_out, uint32_t *__restrict__ vals_out,
         uint32_t n, int shift, const uint32_t *__restrict__ digit_start,
-        uint64_t *lookback, uint32_t *tile_counter, uint32_t gen, DeviceStatus *status, int dbg,
+        W *lookback, uint32_t *tile_counter, uint32_t gen, DeviceStatus *status, int dbg,
         uint32_t nseed)
 {
     constexpr int NW = THREADS / 64;
@@ -226,9 +251,9 @@ __global__ __launch_bounds__(THREADS, MINW) void onesweep_kernel(
     }
     uint32_t count = tot;
     if (tid == RADIX - 1) count -= ((uint32_t) TILE - valid);   // padding keys
-    uint64_t *lb = lookback + (uint64_t) tile * RADIX + tid;
+    W *lb = lookback + (uint64_t) tile * RADIX + tid;
     if (tid < RADIX && tile >= nseed)
-        lb_store(lb, lb_pack(gen, tile == 0 ? LB_PREFIX : LB_AGG, count));
+        lb_store<W>(lb, Lb<W>::pack(gen, tile == 0 ? LB_PREFIX : LB_AGG, count));
 
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -266,26 +291,26 @@ __global__ __launch_bounds__(THREADS, MINW) void onesweep_kernel(
         uint32_t excl = 0;
         if (tile < nseed) {
             // inclusive prefix was published before the pass started
-            excl = (uint32_t) lb_load(lb) - count;
+            excl = Lb<W>::value(lb_load<W>(lb)) - count;
         } else if (tile > 0 && !(dbg & 2)) {
             // serial walk back over the predecessors (issuing several polls at once
             // was measured slower: the polls themselves are the scarce resource)
             int64_t t = (int64_t) tile - 1;
             uint32_t spins = 0;
-            const uint32_t want_p = (gen << 2) | LB_PREFIX;
-            const uint32_t want_a = (gen << 2) | LB_AGG;
+            const uint32_t want_p = Lb<W>::want(gen, LB_PREFIX);
+            const uint32_t want_a = Lb<W>::want(gen, LB_AGG);
             while (true) {
-                const uint64_t w = lb_load(lookback + (uint64_t) t * RADIX + tid);
-                const uint32_t hi = (uint32_t) (w >> 32);
-                if (hi == want_p) { excl += (uint32_t) w; break; }
-                if (hi == want_a) { excl += (uint32_t) w; --t; continue; }
+                const W w = lb_load<W>(lookback + (uint64_t) t * RADIX + tid);
+                const uint32_t hi = Lb<W>::tag(w);
+                if (hi == want_p) { excl += Lb<W>::value(w); break; }
+                if (hi == want_a) { excl += Lb<W>::value(w); --t; continue; }
                 if (++spins > LOOKBACK_SPIN_LIMIT) {
                     atomicExch(&status->lookback_timeout, 1);
                     break;
                 }
                 __builtin_amdgcn_s_sleep(2);
             }
-            lb_store(lb, lb_pack(gen, LB_PREFIX, excl + count));
+            lb_store<W>(lb, Lb<W>::pack(gen, LB_PREFIX, excl + count));
         }
         s_global_base[tid] = (dbg & 1) ? base : digit_start[tid] + excl - dbase;
     }
@@ -313,10 +338,13 @@ __global__ __launch_bounds__(THREADS, MINW) void onesweep_kernel(
     }
 }
 
-template <class KeyT, class Tr>
-int radix_sort_pairs_cfg(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t *vb,
-                         int64_t n, int begin_bit, int end_bit, bool identity_vals, bool *in_b)
+template <class KeyT, class Tr, class W>
+int radix_sort_pairs_w(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t *vb,
+                       int64_t n, int begin_bit, int end_bit, bool identity_vals, bool *in_b)
 {
+    // W = uint32_t: one zeroed look-back array per pass; uint64_t: one array, passes
+    // told apart by the generation in the word
+    constexpr bool PER_PASS = sizeof(W) == 4;
     constexpr int TILE = Tr::THREADS * Tr::ITEMS;
     constexpr int MAXP = (int) sizeof(KeyT);   // at most one pass per key byte
 
@@ -343,9 +371,10 @@ int radix_sort_pairs_cfg(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint
 
     const uint32_t ntiles = (uint32_t) div_up(n, TILE);
     Buf<uint32_t> hist;      // [npasses][RADIX] then tile counters [npasses]
-    Buf<uint64_t> lookback;  // [ntiles][RADIX]
+    Buf<W> lookback;         // [ntiles][RADIX] (x npasses for 32-bit words)
+    const int64_t lb_per_pass = (int64_t) ntiles * RADIX;
     BT_CHECK(hist.alloc(ctx->pool, (int64_t) npasses * RADIX + MAXP));
-    BT_CHECK(lookback.alloc(ctx->pool, (int64_t) ntiles * RADIX));
+    BT_CHECK(lookback.alloc(ctx->pool, lb_per_pass * (PER_PASS ? npasses : 1)));
     uint32_t *tile_counters = hist.get() + (int64_t) npasses * RADIX;
 
     // timing of the 64-bit-key sorts (the roofline figure is quoted on them): four
@@ -355,6 +384,10 @@ int radix_sort_pairs_cfg(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint
     hipEvent_t *ev = (hipEvent_t *) ctx->sort_ev;
     if (timed && !ev[0])
         for (int i = 0; i < 4; ++i) BT_HIP_CHECK(hipEventCreate(&ev[i]));
+
+    BT_HIP_CHECK(hipMemsetAsync(hist.get(), 0, ((size_t) npasses * RADIX + MAXP) * 4, ctx->stream));
+    BT_HIP_CHECK(hipMemsetAsync(lookback.get(), 0,
+                                (size_t) lb_per_pass * (PER_PASS ? npasses : 1) * sizeof(W), ctx->stream));
 
     if (timed) BT_HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
     {
@@ -376,22 +409,23 @@ int radix_sort_pairs_cfg(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint
     uint32_t *vin = va, *vout = vb;
     for (int p = 0; p < npasses; ++p) {
         const int shift = begin_bit + p * RADIX_BITS;
+        W *lbp = lookback.get() + (PER_PASS ? lb_per_pass * p : 0);
         if (nseed > 0) {
             seed_hist_kernel<KeyT, TILE><<<nseed, 256, 0, ctx->stream>>>(
                 kin, (uint32_t) n, shift, tile_hist.get());
-            seed_scan_kernel<<<RADIX, MAX_SEED, 0, ctx->stream>>>(tile_hist.get(), nseed, lookback.get(),
-                                                         (uint32_t) (p + 1));
+            seed_scan_kernel<W><<<RADIX, MAX_SEED, 0, ctx->stream>>>(tile_hist.get(), nseed, lbp,
+                                                                    (uint32_t) (p + 1));
         }
         if (p == 0 && identity_vals) {
-            onesweep_kernel<KeyT, Tr::THREADS, Tr::ITEMS, Tr::MINW, true>
+            onesweep_kernel<KeyT, W, Tr::THREADS, Tr::ITEMS, Tr::MINW, true>
                 <<<ntiles, Tr::THREADS, 0, ctx->stream>>>(
                     kin, vin, kout, vout, (uint32_t) n, shift, hist.get() + p * RADIX,
-                    lookback.get(), tile_counters + p, (uint32_t) (p + 1), ctx->d_status, sort_dbg(), nseed);
+                    lbp, tile_counters + p, (uint32_t) (p + 1), ctx->d_status, sort_dbg(), nseed);
         } else {
-            onesweep_kernel<KeyT, Tr::THREADS, Tr::ITEMS, Tr::MINW, false>
+            onesweep_kernel<KeyT, W, Tr::THREADS, Tr::ITEMS, Tr::MINW, false>
                 <<<ntiles, Tr::THREADS, 0, ctx->stream>>>(
                     kin, vin, kout, vout, (uint32_t) n, shift, hist.get() + p * RADIX,
-                    lookback.get(), tile_counters + p, (uint32_t) (p + 1), ctx->d_status, sort_dbg(), nseed);
+                    lbp, tile_counters + p, (uint32_t) (p + 1), ctx->d_status, sort_dbg(), nseed);
         }
         KeyT *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
@@ -411,6 +445,18 @@ int radix_sort_pairs_cfg(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint
     return BT_OK;
 }
 
+template <class KeyT, class Tr>
+int radix_sort_pairs_cfg(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t *vb,
+                         int64_t n, int begin_bit, int end_bit, bool identity_vals, bool *in_b)
+{
+    // 32-bit look-back words hold counts below 2^30 (BT_SORT_DBG & 16: always 64-bit)
+    if (n < ((int64_t) 1 << 30) && !(sort_dbg() & 16))
+        return radix_sort_pairs_w<KeyT, Tr, uint32_t>(ctx, ka, va, kb, vb, n, begin_bit, end_bit,
+                                                      identity_vals, in_b);
+    return radix_sort_pairs_w<KeyT, Tr, uint64_t>(ctx, ka, va, kb, vb, n, begin_bit, end_bit,
+                                                  identity_vals, in_b);
+}
+
 template <class KeyT>
 int radix_sort_pairs(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t *vb,
                      int64_t n, int begin_bit, int end_bit, bool identity_vals, bool *in_b)
@@ -427,6 +473,7 @@ int radix_sort_pairs(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t
     case 9: return radix_sort_pairs_cfg<KeyT, Cfg9>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
     case 10: return radix_sort_pairs_cfg<KeyT, Cfg10>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
     case 11: return radix_sort_pairs_cfg<KeyT, Cfg11>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
+    case 12: return radix_sort_pairs_cfg<KeyT, Cfg12>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
     default: return radix_sort_pairs_cfg<KeyT, Cfg0>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
     }
 }

@@ -533,6 +533,36 @@ __global__ __launch_bounds__(256) void l3_compress_kernel(int32_t ntb, const int
     }
 }
 
+// all source levels in one launch (thread = (level, target box number))
+struct L3CompressAll {
+    int32_t *starts[BT_MAX_LEVELS], *nonempty[BT_MAX_LEVELS], *cidx[BT_MAX_LEVELS],
+            *tboxes[BT_MAX_LEVELS];
+    int32_t lev_base[BT_MAX_LEVELS], cidx_base[BT_MAX_LEVELS], lev_count[BT_MAX_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void l3_compress_all_kernel(int32_t ntb, int nlevels,
+        const int32_t *l3_starts /* [nlevels*ntb + 1] */, const int32_t *l3_cidx,
+        const int32_t *target_boxes, L3CompressAll o)
+{
+    const int64_t gid = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const int l = (int) (gid / (ntb + 1));
+    const int32_t i = (int32_t) (gid % (ntb + 1));
+    if (l >= nlevels) return;
+    const int32_t *lev_starts = l3_starts + (int64_t) l * ntb;
+    const int32_t *cidx = l3_cidx + (int64_t) l * ntb;
+    if (o.cidx[l]) o.cidx[l][i] = cidx[i] - o.cidx_base[l];
+    if (i == ntb) {
+        o.starts[l][cidx[ntb] - o.cidx_base[l]] = o.lev_count[l];
+        return;
+    }
+    if (lev_starts[i + 1] > lev_starts[i]) {
+        const int32_t k = cidx[i] - o.cidx_base[l];
+        o.starts[l][k] = lev_starts[i] - o.lev_base[l];
+        o.nonempty[l][k] = i;
+        o.tboxes[l][k] = target_boxes[i];
+    }
+}
+
 // ---- close-bigger re-indexing (_ListMerger, traversal.py:1259-1344) --------------------------
 
 __global__ __launch_bounds__(256) void reverse_index_kernel(const int32_t *list, int32_t n, int32_t *out)
@@ -633,6 +663,12 @@ struct TravState {
     Buf<int32_t> subtree_size, dfs_rank, box_of_rank, src_rank_prefix, src_by_rank;
     Buf<unsigned char> nodes;          // packed Node<T, D>[nboxes]
     Buf<int32_t> child_t;              // [nboxes][C]
+    // one-block output (bt_traversal_build_packed)
+    bt_alloc_fn packed_alloc = nullptr;
+    void *packed_user = nullptr;
+    bt_trav_packed *packed = nullptr;
+    int32_t *arena = nullptr;          // the caller's block once it exists
+    bt_trav_sizes sizes{};
     bool fast = false;
     bool lattice = false;              // bt_trav_v2.hpp kernels apply
     bool has_blocks = true;            // some target box has source boxes below it
@@ -1188,6 +1224,110 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     return BT_OK;
 }
 
+// ---- one-block output ---------------------------------------------------------------------
+
+void fill_sizes(TravState *st, bt_trav_sizes *out)
+{
+    const int nlevels = st->nlevels;
+    memset(out, 0, sizeof(*out));
+    out->nsource_boxes = st->nsb; out->ntarget_boxes = st->ntb;
+    out->nsource_parent_boxes = st->nspb;
+    out->ntarget_or_target_parent_boxes = st->nttp;
+    out->n_same_level_non_well_sep = st->coll.total;
+    out->n_neighbor_source = st->l1.total;
+    out->n_from_sep_siblings = st->l2.total;
+    out->n_from_sep_bigger = st->l4.total;
+    out->n_from_sep_close_smaller = st->with_extent ? st->close_smaller.total : -1;
+    out->n_from_sep_close_bigger = st->with_extent ? st->close_bigger.total : -1;
+    for (int l = 0; l < nlevels; ++l) {
+        out->n_from_sep_smaller[l] = st->l3_level_count[l];
+        out->n_from_sep_smaller_nonempty[l] = st->l3_nonempty[l];
+    }
+}
+
+// spans of all outputs in the caller's block (the list-3 lists of the levels are
+// consecutive, like st->l3_lists); asks the caller for the block
+int make_arena(bt_context *ctx, TravState *st)
+{
+    bt_trav_packed *pk = st->packed;
+    const bt_trav_sizes &z = st->sizes;
+    const int nl = st->nlevels;
+    const int64_t B = st->p.nboxes;
+    int64_t off = 0;
+    auto take = [&](bt_span &sp, int64_t count) {
+        sp.offset = off; sp.count = count;
+        off += (std::max<int64_t>(count, 0) + 63) / 64 * 64;      // 256-byte steps
+    };
+    const bool shared_tb = st->p.sources_are_targets && !st->p.target_boxes_mask;
+    take(pk->source_boxes, z.nsource_boxes);
+    if (shared_tb) pk->target_boxes = pk->source_boxes;
+    else take(pk->target_boxes, z.ntarget_boxes);
+    take(pk->source_parent_boxes, z.nsource_parent_boxes);
+    take(pk->target_or_target_parent_boxes, z.ntarget_or_target_parent_boxes);
+    take(pk->same_level_non_well_sep_boxes_starts, B + 1);
+    take(pk->same_level_non_well_sep_boxes_lists, z.n_same_level_non_well_sep);
+    take(pk->neighbor_source_boxes_starts, z.ntarget_boxes + 1);
+    take(pk->neighbor_source_boxes_lists, z.n_neighbor_source);
+    take(pk->from_sep_siblings_starts, z.ntarget_or_target_parent_boxes + 1);
+    take(pk->from_sep_siblings_lists, z.n_from_sep_siblings);
+    take(pk->from_sep_bigger_starts, z.ntarget_or_target_parent_boxes + 1);
+    take(pk->from_sep_bigger_lists, z.n_from_sep_bigger);
+    if (st->with_extent) {
+        take(pk->from_sep_close_smaller_starts, z.ntarget_boxes + 1);
+        take(pk->from_sep_close_smaller_lists, z.n_from_sep_close_smaller);
+        take(pk->from_sep_close_bigger_starts, z.ntarget_boxes + 1);
+        take(pk->from_sep_close_bigger_lists, z.n_from_sep_close_bigger);
+    } else {
+        pk->from_sep_close_smaller_starts = pk->from_sep_close_smaller_lists = bt_span{0, -1};
+        pk->from_sep_close_bigger_starts = pk->from_sep_close_bigger_lists = bt_span{0, -1};
+    }
+    // list 3: all levels' lists back to back, then the small per-level arrays
+    for (int l = 0; l < nl; ++l) {
+        pk->from_sep_smaller_lists[l].offset = off;
+        pk->from_sep_smaller_lists[l].count = z.n_from_sep_smaller[l];
+        off += z.n_from_sep_smaller[l];
+    }
+    off = (off + 63) / 64 * 64;
+    for (int l = 0; l < nl; ++l) {
+        take(pk->from_sep_smaller_starts[l], z.n_from_sep_smaller_nonempty[l] + 1);
+        take(pk->from_sep_smaller_nonempty_indices[l], z.n_from_sep_smaller_nonempty[l]);
+        take(pk->from_sep_smaller_compressed_indices[l], z.ntarget_boxes + 1);
+        take(pk->target_boxes_sep_smaller[l], z.n_from_sep_smaller_nonempty[l]);
+    }
+    pk->total = off;
+    pk->nlevels = nl;
+    pk->sizes = z;
+    pk->lattice_path = st->lattice ? 1 : 0;
+    const int32_t *h = st->h_lev_starts.data();
+    for (int l = 0; l <= nl; ++l) {
+        pk->level_start_source_box_nrs[l] = h[0 * (nl + 1) + l];
+        pk->level_start_target_box_nrs[l] = h[1 * (nl + 1) + l];
+        pk->level_start_source_parent_box_nrs[l] = h[2 * (nl + 1) + l];
+        pk->level_start_target_or_target_parent_box_nrs[l] = h[3 * (nl + 1) + l];
+    }
+    void *base = st->packed_alloc(st->packed_user, std::max<int64_t>(off, 64) * 4);
+    if (!base) {
+        set_error("bt_traversal_build_packed: the allocation callback returned NULL "
+                  "(%lld bytes)", (long long) off * 4);
+        return BT_ERR_ALLOC;
+    }
+    pk->base = base;
+    st->arena = (int32_t *) base;
+    return BT_OK;
+}
+
+inline int32_t *span_ptr(TravState *st, const bt_span &sp)
+{
+    return (st->arena && sp.count >= 0) ? st->arena + sp.offset : nullptr;
+}
+
+// a list's final storage: the span in the caller's block if there is one, the pool else
+int place_list(bt_context *ctx, TravState *st, Buf<int32_t> &buf, int64_t count, const bt_span *sp)
+{
+    if (st->arena && sp) { buf.set_external(st->arena + sp->offset, count); return BT_OK; }
+    return buf.alloc(ctx->pool, count);
+}
+
 // ---- lattice kernels (bt_trav_v2.hpp): colleagues, lists 1-3, close-smaller -------------
 //
 // Everything is counted first (rows with exact counts), the totals of all lists come
@@ -1318,7 +1458,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     }
     Buf<int32_t> item_cnt, first_item, item_tbn, item_slot;
     Buf<int64_t> totals;            // device: nitems, coll, l2, l1, l3, close
-    enum { T_NITEMS = 0, T_COLL, T_L2, T_L1, T_L3, T_CLOSE, T_OVF, T_COUNT };
+    enum { T_NITEMS = 0, T_COLL, T_L2, T_L1, T_L3, T_CLOSE, T_L4, T_L4RAW, T_OVF, T_COUNT };
     BT_CHECK(totals.alloc(ctx->pool, T_COUNT));
     BT_HIP_CHECK(hipMemsetAsync(totals.get(), 0, T_COUNT * 8, ctx->stream));
     BT_CHECK(item_cnt.alloc(ctx->pool, ntb));
@@ -1399,31 +1539,94 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     if (st->with_extent)
         BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{close_cnt.get()}, items_cap,
                                                           close_item.get(), totals.get() + T_CLOSE, true)));
+    // list 3 per (level, target box): starts, and the compressed (non-empty) numbering
+    const int64_t nflat_box = (int64_t) nlevels * ntb;
+    BT_CHECK(st->l3_starts.alloc(ctx->pool, nflat_box + 1));
+    l3_box_starts_v2_kernel<<<nblk(nflat_box + 1), 256, 0, ctx->stream>>>(
+        nflat_box, (int32_t) ntb, lay, nlevels, first_item.get(), l3_item.get(),
+        st->l3_starts.get());
+    BT_CHECK(st->l3_cidx.alloc(ctx->pool, nflat_box + 1));
+    BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, NonEmptyPred{st->l3_starts.get()}, nflat_box,
+                                                      st->l3_cidx.get(), (int32_t *) nullptr, true)));
+    Buf<int32_t> marks;
+    BT_CHECK(marks.alloc(ctx->pool, 2 * (nlevels + 1)));
+    l3_level_marks_kernel<<<1, 128, 0, ctx->stream>>>(nlevels, ntb, st->l3_starts.get(),
+                                                     st->l3_cidx.get(), marks.get());
+    // list 4 (+ close): counts now, lists after the totals are known
+    CsrList &c4 = st->l4;
+    c4.n = st->nttp;
+    CsrList raw4;
+    raw4.n = st->nttp;
+    Buf<int32_t> l4_cnt, raw4_cnt;
+    BT_CHECK(l4_cnt.alloc(ctx->pool, c4.n));
+    if (st->with_extent) BT_CHECK(raw4_cnt.alloc(ctx->pool, raw4.n));
+    list4_kernel<T, D, false><<<nblk(c4.n), 256, 0, ctx->stream>>>(
+        a, (int32_t) c4.n, l4_cnt.get(), nullptr, st->with_extent ? raw4_cnt.get() : nullptr, nullptr);
+    BT_CHECK(c4.starts.alloc(ctx->pool, c4.n + 1));
+    BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{l4_cnt.get()}, c4.n, c4.starts.get(),
+                                                      totals.get() + T_L4, true)));
+    if (st->with_extent) {
+        BT_CHECK(raw4.starts.alloc(ctx->pool, raw4.n + 1));
+        BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{raw4_cnt.get()}, raw4.n,
+                                                          raw4.starts.get(), totals.get() + T_L4RAW, true)));
+    }
+
     int64_t h_tot[T_COUNT];
+    std::vector<int32_t> h_marks((size_t) 2 * (nlevels + 1));
     BT_HIP_CHECK(hipMemcpyAsync(h_tot, totals.get(), sizeof(h_tot), hipMemcpyDeviceToHost, ctx->stream));
+    BT_HIP_CHECK(hipMemcpyAsync(h_marks.data(), marks.get(), h_marks.size() * 4, hipMemcpyDeviceToHost,
+                                ctx->stream));
     BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->n_host_syncs++;
-    for (int k = T_COLL; k <= T_CLOSE; ++k)
+    for (int k = T_COLL; k <= T_L4RAW; ++k)
         if (h_tot[k] >= ((int64_t) 1 << 31)) {
             set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference): "
                       "%lld", (long long) h_tot[k]);
             return BT_ERR_UNSUPPORTED;
         }
     const int64_t novf = h_tot[T_OVF] & 0xffffffffll;
-
-    // ---- final places ------------------------------------------------------------------------------
+    st->l3_level_base.assign((size_t) nlevels, 0);
+    st->l3_level_count.assign((size_t) nlevels, 0);
+    st->l3_nonempty.assign((size_t) nlevels, 0);
+    st->l3_cidx_base.assign((size_t) nlevels, 0);
+    for (int l = 0; l < nlevels; ++l) {
+        st->l3_level_base[l] = h_marks[l];
+        st->l3_level_count[l] = h_marks[l + 1] - h_marks[l];
+        st->l3_cidx_base[l] = h_marks[nlevels + 1 + l];
+        st->l3_nonempty[l] = h_marks[nlevels + 1 + l + 1] - h_marks[nlevels + 1 + l];
+    }
+    CsrList &c1 = st->l1;
+    c1.n = ntb;
+    CsrList &cs = st->close_smaller;
+    cs.n = ntb;
+    CsrList &cb = st->close_bigger;
+    cb.n = ntb;
     coll.total = h_tot[T_COLL];
-    BT_CHECK(coll.lists.alloc(ctx->pool, coll.total));
+    st->l2.n = st->nttp;
+    st->l2.total = h_tot[T_L2];
+    c1.total = h_tot[T_L1];
+    const int64_t total3 = h_tot[T_L3];
+    cs.total = st->with_extent ? h_tot[T_CLOSE] : 0;
+    c4.total = h_tot[T_L4];
+    raw4.total = st->with_extent ? h_tot[T_L4RAW] : 0;
+    cb.total = raw4.total;       // close lists are only made for target boxes (traversal.py:1003)
+
+    // ---- final places: the caller's block if this is a one-block build ------------------------------
+    fill_sizes(st, &st->sizes);
+    const bt_trav_packed *pk = nullptr;
+    if (st->packed_alloc) {
+        BT_CHECK(make_arena(ctx, st));
+        pk = st->packed;
+    }
+    BT_CHECK(place_list(ctx, st, coll.lists, coll.total, pk ? &pk->same_level_non_well_sep_boxes_lists : nullptr));
     compact_coll_rows_v2_kernel<8><<<nblk(B * 8), 256, 0, ctx->stream>>>(
         B, P, coll_rows.get(), coll.starts.get(), coll.lists.get());
     a.coll_starts = coll.starts.get();
     a.coll_lists = coll.lists.get();
     {
         CsrList &c = st->l2;
-        c.n = st->nttp;
-        c.total = h_tot[T_L2];
         BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
-        BT_CHECK(c.lists.alloc(ctx->pool, c.total));
+        BT_CHECK(place_list(ctx, st, c.lists, c.total, pk ? &pk->from_sep_siblings_lists : nullptr));
         gather_starts_dev_kernel<<<nblk(c.n + 1), 256, 0, ctx->stream>>>(
             (int32_t) c.n, st->ttp_boxes.get(), l2_by_box.get(), (int32_t) B, c.starts.get());
         rows.l2_starts = l2_by_box.get();
@@ -1434,14 +1637,8 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     }
     BT_CHECK(tmark(ctx, st, "trav:colleagues+list2"));
 
-    CsrList &c1 = st->l1;
-    c1.n = ntb;
-    c1.total = h_tot[T_L1];
-    CsrList &cs = st->close_smaller;
-    cs.n = ntb;
-    const int64_t total3 = h_tot[T_L3];
-    BT_CHECK(c1.lists.alloc(ctx->pool, c1.total));
-    BT_CHECK(st->l3_lists.alloc(ctx->pool, total3));
+    BT_CHECK(place_list(ctx, st, c1.lists, c1.total, pk ? &pk->neighbor_source_boxes_lists : nullptr));
+    BT_CHECK(place_list(ctx, st, st->l3_lists, total3, pk ? &pk->from_sep_smaller_lists[0] : nullptr));
     rows_to_csr_v2_kernel<<<nblk(items_cap), 256, 0, ctx->stream>>>(
         d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, c1.lists.get());
     if (total3 > 0)
@@ -1449,8 +1646,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             d_nitems, lay, nlevels, overflow.get(), row3.get(), row3lev.get(), K3,
             l3_item.get(), st->l3_lists.get());
     if (st->with_extent) {
-        cs.total = h_tot[T_CLOSE];
-        BT_CHECK(cs.lists.alloc(ctx->pool, cs.total));
+        BT_CHECK(place_list(ctx, st, cs.lists, cs.total, pk ? &pk->from_sep_close_smaller_lists : nullptr));
         if (cs.total > 0)
             rows_to_csr_v2_kernel<<<nblk(items_cap), 256, 0, ctx->stream>>>(
                 d_nitems, overflow.get(), rowc.get(), Kc, close_item.get(), nullptr, cs.lists.get());
@@ -1475,11 +1671,27 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         gather_i32_kernel<<<nblk(ntb + 1), 256, 0, ctx->stream>>>(
             (int32_t) (ntb + 1), first_item.get(), close_item.get(), cs.starts.get());
     }
-    const int64_t nflat_box = (int64_t) nlevels * ntb;
-    BT_CHECK(st->l3_starts.alloc(ctx->pool, nflat_box + 1));
-    l3_box_starts_v2_kernel<<<nblk(nflat_box + 1), 256, 0, ctx->stream>>>(
-        nflat_box, (int32_t) ntb, lay, nlevels, first_item.get(), l3_item.get(),
-        st->l3_starts.get());
+
+    // list 4 (+ close, re-indexed to target boxes: _ListMerger, traversal.py:1259-1344)
+    BT_CHECK(place_list(ctx, st, c4.lists, c4.total, pk ? &pk->from_sep_bigger_lists : nullptr));
+    if (st->with_extent) BT_CHECK(raw4.lists.alloc(ctx->pool, raw4.total));
+    list4_kernel<T, D, true><<<nblk(c4.n), 256, 0, ctx->stream>>>(
+        a, (int32_t) c4.n, c4.starts.get(), c4.lists.get(),
+        st->with_extent ? raw4.starts.get() : nullptr, st->with_extent ? raw4.lists.get() : nullptr);
+    if (st->with_extent) {
+        Buf<int32_t> ttp_from_all;
+        BT_CHECK(ttp_from_all.alloc(ctx->pool, B));
+        BT_HIP_CHECK(hipMemsetAsync(ttp_from_all.get(), 0, (size_t) B * 4, ctx->stream));
+        reverse_index_kernel<<<nblk(st->nttp), 256, 0, ctx->stream>>>(
+            st->ttp_boxes.get(), (int32_t) st->nttp, ttp_from_all.get());
+        BT_CHECK(cb.starts.alloc(ctx->pool, cb.n + 1));
+        MergeCount mc{st->target_boxes, ttp_from_all.get(), raw4.starts.get()};
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, mc, cb.n, cb.starts.get(),
+                                                          (int32_t *) nullptr, true)));
+        BT_CHECK(place_list(ctx, st, cb.lists, cb.total, pk ? &pk->from_sep_close_bigger_lists : nullptr));
+        merge_copy_kernel<<<nblk(cb.n), 256, 0, ctx->stream>>>(
+            (int32_t) cb.n, mc, raw4.lists.get(), cb.starts.get(), cb.lists.get());
+    }
 
     // list 1: order by depth-first rank, insert the own-subtree blocks
     {
@@ -1523,7 +1735,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         // the scratch buffers above return to the pool at scope exit: all work that uses
         // them is already queued on this stream, and so is whatever reuses them
     }
-    BT_CHECK(tmark(ctx, st, "trav:list1+list3"));
+    BT_CHECK(tmark(ctx, st, "trav:list1 order + list4"));
     BT_HIP_CHECK(hipGetLastError());
     return BT_OK;
 }
@@ -1726,10 +1938,10 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
             st->with_extent ? cs.lists.get() : nullptr);
 
     }
-    BT_CHECK(l3_postprocess(ctx, st));
+    if (!st->lattice) BT_CHECK(l3_postprocess(ctx, st));
     BT_CHECK(tmark(ctx, st, "trav:list3"));
     // T7 list 4 (+ close, re-indexed to target boxes)
-    {
+    if (!st->lattice) {
         CsrList &c = st->l4;
         c.n = st->nttp;
         BT_CHECK(c.starts.alloc(ctx->pool, c.n + 1));
@@ -1772,28 +1984,18 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     }
     BT_HIP_CHECK(hipGetLastError());
     BT_CHECK(tmark(ctx, st, "trav:list4"));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // (no wait here: the export that follows is queued on the same stream)
 
-    out->nsource_boxes = st->nsb; out->ntarget_boxes = st->ntb;
-    out->nsource_parent_boxes = st->nspb;
-    out->ntarget_or_target_parent_boxes = st->nttp;
-    out->n_same_level_non_well_sep = st->coll.total;
-    out->n_neighbor_source = st->l1.total;
-    out->n_from_sep_siblings = st->l2.total;
-    out->n_from_sep_bigger = st->l4.total;
-    out->n_from_sep_close_smaller = st->with_extent ? st->close_smaller.total : -1;
-    out->n_from_sep_close_bigger = st->with_extent ? st->close_bigger.total : -1;
-    for (int l = 0; l < nlevels; ++l) {
-        out->n_from_sep_smaller[l] = st->l3_level_count[l];
-        out->n_from_sep_smaller_nonempty[l] = st->l3_nonempty[l];
-    }
+    fill_sizes(st, out);
+    st->sizes = *out;
     st->built = true;
     return BT_OK;
 }
 
 int copy_i32(bt_context *ctx, int32_t *dst, const int32_t *src, int64_t n)
 {
-    if (n > 0 && dst)
+    // (dst == src: the list was built in the caller's block, nothing to move)
+    if (n > 0 && dst && dst != src)
         BT_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t) n * 4, hipMemcpyDeviceToDevice, ctx->stream));
     return BT_OK;
 }
@@ -1802,7 +2004,8 @@ int copy_i32(bt_context *ctx, int32_t *dst, const int32_t *src, int64_t n)
 
 extern "C" {
 
-int bt_traversal_build(bt_context *ctx, const bt_trav_params *p, bt_trav_sizes *out)
+static int trav_build_entry(bt_context *ctx, const bt_trav_params *p, bt_trav_sizes *out,
+                            bt_alloc_fn alloc, void *user, bt_trav_packed *packed)
 {
     if (!ctx || !p || !out) { set_error("bt_traversal_build: NULL argument"); return BT_ERR_INVALID; }
     BT_HIP_CHECK(hipSetDevice(ctx->device));
@@ -1842,6 +2045,8 @@ int bt_traversal_build(bt_context *ctx, const bt_trav_params *p, bt_trav_sizes *
     ctx->trav = st;
     st->p = *p;
     st->nlevels = p->nlevels;
+    st->packed_alloc = alloc; st->packed_user = user; st->packed = packed;
+    BT_CHECK(reset_status(ctx));
     int s = BT_ERR_INVALID;
     const bool f64 = p->coord_kind == BT_F64;
     switch (p->dims) {
@@ -1853,15 +2058,8 @@ int bt_traversal_build(bt_context *ctx, const bt_trav_params *p, bt_trav_sizes *
     return s;
 }
 
-int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
+static int export_impl(bt_context *ctx, TravState *st, const bt_trav_arrays *o)
 {
-    if (!ctx || !o) { set_error("bt_traversal_export: NULL argument"); return BT_ERR_INVALID; }
-    TravState *st = ctx->trav;
-    if (!st || !st->built) {
-        set_error("bt_traversal_export: no traversal has been built on this context");
-        return BT_ERR_INVALID;
-    }
-    BT_HIP_CHECK(hipSetDevice(ctx->device));
     const int nl = st->nlevels;
     BT_CHECK(copy_i32(ctx, o->source_boxes, st->source_boxes.get(), st->nsb));
     if (!st->p.sources_are_targets || st->p.target_boxes_mask)
@@ -1896,6 +2094,7 @@ int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
         BT_CHECK(put(st->close_bigger, o->from_sep_close_bigger_starts, o->from_sep_close_bigger_lists));
     }
     const int64_t ntb = st->ntb;
+    L3CompressAll ca{};
     for (int l = 0; l < nl; ++l) {
         if (!o->from_sep_smaller_starts[l]) {
             set_error("bt_traversal_export: NULL list-3 output for level %d", l);
@@ -1903,17 +2102,73 @@ int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
         }
         BT_CHECK(copy_i32(ctx, o->from_sep_smaller_lists[l],
                           st->l3_lists.get() + st->l3_level_base[l], st->l3_level_count[l]));
-        l3_compress_kernel<<<nblk(ntb + 1), 256, 0, ctx->stream>>>(
-            (int32_t) ntb, st->l3_starts.get() + (int64_t) l * ntb, (int32_t) st->l3_level_base[l],
-            st->l3_cidx.get() + (int64_t) l * ntb, (int32_t) st->l3_cidx_base[l], st->target_boxes,
-            o->from_sep_smaller_starts[l], o->from_sep_smaller_nonempty_indices[l],
-            o->from_sep_smaller_compressed_indices[l], o->target_boxes_sep_smaller[l],
-            (int32_t) st->l3_level_count[l]);
+        ca.starts[l] = o->from_sep_smaller_starts[l];
+        ca.nonempty[l] = o->from_sep_smaller_nonempty_indices[l];
+        ca.cidx[l] = o->from_sep_smaller_compressed_indices[l];
+        ca.tboxes[l] = o->target_boxes_sep_smaller[l];
+        ca.lev_base[l] = (int32_t) st->l3_level_base[l];
+        ca.cidx_base[l] = (int32_t) st->l3_cidx_base[l];
+        ca.lev_count[l] = (int32_t) st->l3_level_count[l];
     }
+    l3_compress_all_kernel<<<nblk((int64_t) nl * (ntb + 1)), 256, 0, ctx->stream>>>(
+        (int32_t) ntb, nl, st->l3_starts.get(), st->l3_cidx.get(), st->target_boxes, ca);
     BT_HIP_CHECK(hipGetLastError());
     BT_CHECK(tmark(ctx, st, "trav:export"));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return BT_OK;
+    ctx->n_host_syncs++;
+    return check_status(ctx);       // waits for the stream; reports device-side failures
+}
+
+int bt_traversal_build(bt_context *ctx, const bt_trav_params *p, bt_trav_sizes *out)
+{
+    return trav_build_entry(ctx, p, out, nullptr, nullptr, nullptr);
+}
+
+int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
+{
+    if (!ctx || !o) { set_error("bt_traversal_export: NULL argument"); return BT_ERR_INVALID; }
+    TravState *st = ctx->trav;
+    if (!st || !st->built) {
+        set_error("bt_traversal_export: no traversal has been built on this context");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    return export_impl(ctx, st, o);
+}
+
+int bt_traversal_build_packed(bt_context *ctx, const bt_trav_params *p, bt_alloc_fn alloc,
+                              void *user, bt_trav_packed *out)
+{
+    if (!alloc || !out) { set_error("bt_traversal_build_packed: NULL argument"); return BT_ERR_INVALID; }
+    memset(out, 0, sizeof(*out));
+    bt_trav_sizes sizes;
+    BT_CHECK(trav_build_entry(ctx, p, &sizes, alloc, user, out));
+    TravState *st = ctx->trav;
+    if (!st->arena) BT_CHECK(make_arena(ctx, st));      // the general paths: sizes known only now
+    bt_trav_arrays o{};
+    o.source_boxes = span_ptr(st, out->source_boxes);
+    o.target_boxes = span_ptr(st, out->target_boxes);
+    o.source_parent_boxes = span_ptr(st, out->source_parent_boxes);
+    o.target_or_target_parent_boxes = span_ptr(st, out->target_or_target_parent_boxes);
+    o.same_level_non_well_sep_boxes_starts = span_ptr(st, out->same_level_non_well_sep_boxes_starts);
+    o.same_level_non_well_sep_boxes_lists = span_ptr(st, out->same_level_non_well_sep_boxes_lists);
+    o.neighbor_source_boxes_starts = span_ptr(st, out->neighbor_source_boxes_starts);
+    o.neighbor_source_boxes_lists = span_ptr(st, out->neighbor_source_boxes_lists);
+    o.from_sep_siblings_starts = span_ptr(st, out->from_sep_siblings_starts);
+    o.from_sep_siblings_lists = span_ptr(st, out->from_sep_siblings_lists);
+    o.from_sep_bigger_starts = span_ptr(st, out->from_sep_bigger_starts);
+    o.from_sep_bigger_lists = span_ptr(st, out->from_sep_bigger_lists);
+    o.from_sep_close_smaller_starts = span_ptr(st, out->from_sep_close_smaller_starts);
+    o.from_sep_close_smaller_lists = span_ptr(st, out->from_sep_close_smaller_lists);
+    o.from_sep_close_bigger_starts = span_ptr(st, out->from_sep_close_bigger_starts);
+    o.from_sep_close_bigger_lists = span_ptr(st, out->from_sep_close_bigger_lists);
+    for (int l = 0; l < st->nlevels; ++l) {
+        o.from_sep_smaller_starts[l] = span_ptr(st, out->from_sep_smaller_starts[l]);
+        o.from_sep_smaller_lists[l] = span_ptr(st, out->from_sep_smaller_lists[l]);
+        o.from_sep_smaller_nonempty_indices[l] = span_ptr(st, out->from_sep_smaller_nonempty_indices[l]);
+        o.from_sep_smaller_compressed_indices[l] = span_ptr(st, out->from_sep_smaller_compressed_indices[l]);
+        o.target_boxes_sep_smaller[l] = span_ptr(st, out->target_boxes_sep_smaller[l]);
+    }
+    return export_impl(ctx, st, &o);
 }
 
 

@@ -142,15 +142,25 @@ __global__ __launch_bounds__(256) void coll_rows_v2_kernel(V2Rows<D> t, int32_t 
     int32_t *crow = t.coll_rows + (int64_t) b * P;
     int32_t *srow = t.srccoll_rows + (int64_t) b * P;
     int32_t ccur = 0, scur = 0, lcnt = 0;
-    constexpr int UNR = 4;
+    // the parent's row is read once, spread over the group's lanes (entry i sits in
+    // register i / C of lane i % C): the loop below then depends on ONE load per
+    // candidate (its child slot), not on a chain row entry -> child slot
+    constexpr int NREG = (P + C - 1) / C;
+    uint32_t preg[NREG];
+#pragma unroll
+    for (int j = 0; j < NREG; ++j) preg[j] = (m + C * j < n) ? (uint32_t) prow[m + C * j] : 0u;
+    constexpr int UNR = 8;
     for (int i0 = 0; i0 <= n; i0 += UNR) {
         uint32_t es[UNR], chs[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int i = i0 + u;
-            es[u] = (i > n) ? 0u : (i < ins) ? (uint32_t) prow[i]
-                  : (i == ins ? ((uint32_t) p | (V2_CODE_SELF << V2_CODE_SHIFT))
-                              : (uint32_t) prow[i - 1]);
+            const int ii = (i < ins) ? i : i - 1;        // index into the parent's row
+            uint32_t sel = preg[0];
+#pragma unroll
+            for (int j = 1; j < NREG; ++j) sel = (ii / C == j) ? preg[j] : sel;
+            const uint32_t e = (uint32_t) __shfl((int) sel, (ii < 0 ? 0 : ii) % C, C);
+            es[u] = (i > n) ? 0u : (i == ins ? ((uint32_t) p | (V2_CODE_SELF << V2_CODE_SHIFT)) : e);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u)

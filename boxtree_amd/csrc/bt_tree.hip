@@ -653,13 +653,19 @@ __device__ __forceinline__ uint64_t sl_pack(uint32_t gen, uint32_t flag, uint32_
     return ((uint64_t) (gen & 0xffffu) << 48) | ((uint64_t) flag << 46) | ((uint64_t) os << 32) | sum;
 }
 
+// sub-tiles per ticket: the look-back chain advances by some 40 tiles per microsecond
+// (bt_prims.hpp), so a tile must hold enough parents -- 256 in 3D -- for the chain to
+// keep up with the counting (32-parent tiles: 1.5 ms for the 10^6 parents of one level)
+constexpr int SL_SUB = 8;
+
 template <class T, int D, bool EXT>
 __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState *ls,
         T *centers /* [cap][D] */, T root_extent, int32_t box_cap, int first_level,
         uint64_t *desc, uint32_t gen, uint32_t *ticket)
 {
     constexpr int C = 1 << D;
-    constexpr int PPT = 256 / C;            // parents per tile
+    constexpr int PPS = 256 / C;            // parents per sub-tile
+    constexpr int PPT = PPS * SL_SUB;       // parents per tile
     __shared__ uint32_t s_tile;
     __shared__ int32_t s_scan[256 / 64 + 1];
     __shared__ int32_t s_excl;
@@ -678,6 +684,7 @@ __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState
     const int ntiles = (nprev + PPT - 1) / PPT;
     const int lane = threadIdx.x & 63;
     const int m = threadIdx.x % C;
+    const int gshift = lane / C * C;
     const int lr = level - a.loff;          // level relative to the key
 
     while (true) {
@@ -686,76 +693,127 @@ __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState
         __syncthreads();
         const int tile = (int) s_tile;
         if (tile >= ntiles) break;
-        const int bl = tile * PPT + threadIdx.x / C;
-        const bool active = bl < nprev;
-        const int b = b0 + (active ? bl : 0);
 
-        // ---- children boundaries (count_children_kernel) ------------------------------
-        int lo = 0, e = 0, s = 0;
-        uint64_t prefix = 0;
-        const bool skipped = a.cand != nullptr && active && !a.cand[bl];
-        if (active) {
-            s = a.box_start[b];
-            e = s + a.box_count[b];
-            if (lr - 1 < a.L && e > s && !skipped) {
-                const int pshift = a.capbits + D * (a.L - (lr - 1));
-                prefix = (pshift >= 64) ? 0 : (a.keys[s] >> pshift);
-                const int cshift = a.capbits + D * (a.L - lr);
-                if (m == 0) {
-                    if (EXT) {
-                        const uint64_t stuck = ((prefix << D) << cshift) | (uint64_t) (lr - 1);
-                        lo = upper_bound_key(a.keys, s, e, stuck);
+        // ---- children boundaries of SL_SUB sub-tiles (count_children_kernel) -------------
+        // The binary searches of the sub-tiles advance in lockstep: every step issues
+        // SL_SUB independent loads (one search at a time is a chain of ~17 dependent
+        // loads per thread, and the kernel holds few waves per SIMD).
+        int lo_[SL_SUB], hi_[SL_SUB], first_[SL_SUB], s_[SL_SUB], off_[SL_SUB];
+        uint32_t bits_[SL_SUB];             // 1: split, 2: nonempty, 8: active, rank << 4
+        int e_[SL_SUB];
+        uint64_t pre_[SL_SUB], tgt_[SL_SUB];
+        uint32_t act_[SL_SUB];              // 1: active, 2: skipped
+        {
+            int shi[SL_SUB];
+#pragma unroll
+            for (int k = 0; k < SL_SUB; ++k) {
+                const int bl = tile * PPT + k * PPS + threadIdx.x / C;
+                const bool active = bl < nprev;
+                const int b = b0 + (active ? bl : 0);
+                int lo = 0, hi = 0, e = 0, s = 0;       // search range [lo, hi)
+                uint64_t prefix = 0, tgt = 0;
+                const bool skipped = a.cand != nullptr && active && !a.cand[bl];
+                if (active) {
+                    s = a.box_start[b];
+                    e = s + a.box_count[b];
+                    // without extents the split decision needs no child boundary (all of
+                    // the box's particles are child-bound): a box that stays a leaf -- most
+                    // boxes of the deepest levels -- is not searched at all
+                    bool will_split = true;
+                    if (!EXT && a.adaptive && !(a.top_prefix && a.loff == 0 && level - 1 < a.top_level))
+                        will_split = range_weight(a, s, e) > a.max_weight;
+                    if (lr - 1 < a.L && e > s && !skipped && will_split) {
+                        const int pshift = a.capbits + D * (a.L - (lr - 1));
+                        prefix = (pshift >= 64) ? 0 : (a.keys[s] >> pshift);
+                        const int cshift = a.capbits + D * (a.L - lr);
+                        // first position whose key is > tgt (upper bound); a lower bound
+                        // of ck is the upper bound of ck - 1
+                        if (m == 0) {
+                            if (EXT) {
+                                // own (stuck) particles: Kt == prefix000.., cap == lr-1
+                                tgt = ((prefix << D) << cshift) | (uint64_t) (lr - 1);
+                                lo = s; hi = e;
+                            } else {
+                                lo = hi = s;
+                            }
+                        } else {
+                            const uint64_t ck = ((prefix << D) | (uint64_t) m) << cshift;
+                            if (ck == 0) { lo = hi = s; }
+                            else { tgt = ck - 1; lo = s; hi = e; }
+                        }
                     } else {
-                        lo = s;
+                        lo = hi = (m == 0) ? s : e;
                     }
-                } else {
-                    const uint64_t ck = ((prefix << D) | (uint64_t) m) << cshift;
-                    lo = lower_bound_key(a.keys, s, e, ck);
                 }
-            } else {
-                lo = (m == 0) ? s : e;
+                lo_[k] = lo; shi[k] = hi; s_[k] = s; e_[k] = e; pre_[k] = prefix; tgt_[k] = tgt;
+                act_[k] = (active ? 1u : 0u) | (skipped ? 2u : 0u);
+            }
+            bool any = true;
+            while (any) {
+                any = false;
+#pragma unroll
+                for (int k = 0; k < SL_SUB; ++k) {
+                    if (lo_[k] < shi[k]) {
+                        const int mid = lo_[k] + ((shi[k] - lo_[k]) >> 1);
+                        if (a.keys[mid] <= tgt_[k]) lo_[k] = mid + 1; else shi[k] = mid;
+                        any = true;
+                    }
+                }
             }
         }
-        int hi = __shfl_down(lo, 1, C);
-        if (m == C - 1) hi = e;
-        const int first = __shfl(lo, 0, C);     // start of the child-bound range
+        int32_t run = 0;                    // children of the tile's earlier sub-tiles
+        bool any_os = false;
+#pragma unroll
+        for (int k = 0; k < SL_SUB; ++k) {
+            const bool active = act_[k] & 1u, skipped = act_[k] & 2u;
+            const int lo = lo_[k], e = e_[k], s = s_[k];
+            const uint64_t prefix = pre_[k];
+            int hi = __shfl_down(lo, 1, C);
+            if (m == C - 1) hi = e;
+            const int first = __shfl(lo, 0, C);     // start of the child-bound range
 
-        bool split = false, oversize = false;
-        int cnt = 0;
-        if (active) {
-            int32_t W = range_weight(a, first, e);                       // tbk:569-573
-            const bool top = a.top_prefix && a.loff == 0 && level - 1 < a.top_level && e > s;
-            if (top) W = top_weight<D>(a, prefix, level - 1);
-            split = a.adaptive ? W > a.max_weight : true;                // tbk:577-597
-            if (skipped) split = false;
-            if (lr - 1 >= a.L) {
-                if (split && e > s && (a.adaptive || W > a.max_weight) && m == 0) {
-                    if (a.can_continue)
-                        __hip_atomic_store(&ls->need_more, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else
-                        atomicExch(&a.status->max_levels, 1);
+            bool split = false, oversize = false;
+            int cnt = 0;
+            if (active) {
+                int32_t W = range_weight(a, first, e);                       // tbk:569-573
+                const bool top = a.top_prefix && a.loff == 0 && level - 1 < a.top_level && e > s;
+                if (top) W = top_weight<D>(a, prefix, level - 1);
+                split = a.adaptive ? W > a.max_weight : true;                // tbk:577-597
+                if (skipped) split = false;
+                if (lr - 1 >= a.L) {
+                    if (split && e > s && (a.adaptive || W > a.max_weight) && m == 0) {
+                        if (a.can_continue)
+                            __hip_atomic_store(&ls->need_more, 1, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        else
+                            atomicExch(&a.status->max_levels, 1);
+                    }
+                    split = false;
                 }
-                split = false;
+                if (e == s && (a.adaptive || !a.keep_empty)) split = false;
+                cnt = hi - lo;
+                const int32_t Wc = top ? top_weight<D>(a, (prefix << D) | (uint64_t) m, level)
+                                       : range_weight(a, lo, hi);
+                oversize = split && cnt > 0 && Wc > a.max_weight;            // tbk:600-610
             }
-            if (e == s && (a.adaptive || !a.keep_empty)) split = false;
-            cnt = hi - lo;
-            const int32_t Wc = top ? top_weight<D>(a, (prefix << D) | (uint64_t) m, level)
-                                   : range_weight(a, lo, hi);
-            oversize = split && cnt > 0 && Wc > a.max_weight;            // tbk:600-610
-        }
-        const bool nonempty = split && (cnt > 0 || a.keep_empty);
-        const uint64_t bal = __ballot(nonempty);
-        const int gshift = lane / C * C;
-        const uint32_t gmask = (uint32_t) ((bal >> gshift) & ((1ull << C) - 1));
-        const int rank = __popc(gmask & ((1u << m) - 1u));
-        const int nnew = (active && split && m == 0) ? __popc(gmask) : 0;
-        if (__ballot(oversize) != 0ull && lane == 0) s_os = 1;           // (benign race: same value)
+            const bool nonempty = split && (cnt > 0 || a.keep_empty);
+            const uint64_t bal = __ballot(nonempty);
+            const uint32_t gmask = (uint32_t) ((bal >> gshift) & ((1ull << C) - 1));
+            const int rank = __popc(gmask & ((1u << m) - 1u));
+            const int nnew = (active && split && m == 0) ? __popc(gmask) : 0;
+            any_os = any_os || (__ballot(oversize) != 0ull);
 
-        // ---- exclusive offsets of the tile's parents; tile aggregate -----------------------
-        int32_t tile_total = 0;
-        const int32_t in_tile = block_exclusive_scan<int32_t, 256>(nnew, s_scan, &tile_total);
-        const int32_t group_off = __shfl(in_tile, 0, C);     // the group's m == 0 lane
-        const uint32_t tile_os = (uint32_t) s_os;            // written before the scan's barriers
+            int32_t sub_total = 0;
+            const int32_t in_sub = block_exclusive_scan<int32_t, 256>(nnew, s_scan, &sub_total);
+            hi_[k] = hi; first_[k] = first;
+            off_[k] = run + __shfl(in_sub, 0, C);       // the group's m == 0 lane
+            bits_[k] = (active ? 8u : 0u) | (split ? 1u : 0u) | (nonempty ? 2u : 0u) | ((uint32_t) rank << 4);
+            run += sub_total;
+        }
+        const int32_t tile_total = run;
+        if (any_os && lane == 0) s_os = 1;              // (benign race: same value)
+        __syncthreads();
+        const uint32_t tile_os = (uint32_t) s_os;
 
         // ---- look-back over the preceding tiles (wave 0) ---------------------------------
         if (threadIdx.x < 64) {
@@ -812,35 +870,44 @@ __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState
             }
         }
         __syncthreads();
-        if (!active) continue;
+        const int32_t tile_excl = s_excl;
 
         // ---- children (write_children_kernel) -------------------------------------------------
-        int32_t child_id = 0;
-        const int64_t cid = (int64_t) new_level_start + s_excl + group_off + rank;
-        const bool fits = cid < (int64_t) box_cap;
-        if (nonempty && fits) {
-            child_id = (int32_t) cid;                                  // tbk:667 (after pruning)
-            a.box_start[child_id] = hi > lo ? lo : 0;
-            a.box_count[child_id] = hi - lo;
-            a.box_parent[child_id] = b;
-            a.box_level[child_id] = (uint8_t) level;
-            a.box_haschild[child_id] = 0;
-            a.box_nonchild[child_id] = 0;
-            // tbk:698-705: centre = parent centre +/- root_extent / 2^(1+level)
-            const T radius = (root_extent * 1 / (T) (1ull << (1 + level)));
+        // tbk:698-705: centre = parent centre +/- root_extent / 2^(1+level)
+        const T radius = (root_extent * 1 / (T) (1ull << (1 + level)));
 #pragma unroll
-            for (int ax = 0; ax < D; ++ax) {
-                const bool has_bit = (m >> (D - 1 - ax)) & 1;
-                const T pc = centers[(int64_t) b * D + ax];
-                centers[(int64_t) child_id * D + ax] = has_bit ? pc + radius : pc - radius;
+        for (int k = 0; k < SL_SUB; ++k) {
+            if (!(bits_[k] & 8u)) continue;
+            const int bl = tile * PPT + k * PPS + threadIdx.x / C;
+            const int b = b0 + bl;
+            const bool split = bits_[k] & 1u, nonempty = bits_[k] & 2u;
+            const int rank = (int) (bits_[k] >> 4);
+            int32_t child_id = 0;
+            const int64_t cid = (int64_t) new_level_start + tile_excl + off_[k] + rank;
+            if (nonempty && cid < (int64_t) box_cap) {
+                child_id = (int32_t) cid;                                  // tbk:667 (after pruning)
+                // an empty child (skip_prune) keeps start 0: tbk:680-695 only sets the start
+                // "if the new box has particles to begin with"
+                a.box_start[child_id] = hi_[k] > lo_[k] ? lo_[k] : 0;
+                a.box_count[child_id] = hi_[k] - lo_[k];
+                a.box_parent[child_id] = b;
+                a.box_level[child_id] = (uint8_t) level;
+                a.box_haschild[child_id] = 0;
+                a.box_nonchild[child_id] = 0;
+#pragma unroll
+                for (int ax = 0; ax < D; ++ax) {
+                    const bool has_bit = (m >> (D - 1 - ax)) & 1;
+                    const T pc = centers[(int64_t) b * D + ax];
+                    centers[(int64_t) child_id * D + ax] = has_bit ? pc + radius : pc - radius;
+                }
+#pragma unroll
+                for (int mm = 0; mm < C; ++mm) a.box_child[(int64_t) child_id * C + mm] = 0;
             }
-#pragma unroll
-            for (int mm = 0; mm < C; ++mm) a.box_child[(int64_t) child_id * C + mm] = 0;
-        }
-        a.box_child[(int64_t) b * C + m] = child_id;
-        if (m == 0) {
-            a.box_haschild[b] = split ? 1 : 0;
-            a.box_nonchild[b] = split ? (first - s) : 0;
+            a.box_child[(int64_t) b * C + m] = child_id;
+            if (m == 0) {
+                a.box_haschild[b] = split ? 1 : 0;
+                a.box_nonchild[b] = split ? (first_[k] - s_[k]) : 0;
+            }
         }
     }
 }
@@ -1987,7 +2054,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     // between launches; cleared when the 16-bit tag wraps)
     Buf<uint64_t> sl_desc;
     auto ensure_desc = [&]() -> int {
-        const int64_t need = st->cap / (256 / C) + 2;
+        const int64_t need = st->cap / (256 / C * SL_SUB) + 2;
         if (sl_desc.size() < need) {
             BT_CHECK(sl_desc.alloc(ctx->pool, need));
             BT_HIP_CHECK(hipMemsetAsync(sl_desc.get(), 0, (size_t) need * 8, ctx->stream));
@@ -2042,7 +2109,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
                 // parents of level l-1: at most C^(l-1) (first key) and at most the capacity
                 double bound = loff == 0 ? std::pow((double) C, l - 1) : (double) st->cap;
                 bound = std::min(bound, (double) st->cap);
-                const int64_t tiles = (int64_t) std::ceil(bound / (256 / C));
+                const int64_t tiles = (int64_t) std::ceil(bound / (256 / C * SL_SUB));
                 const unsigned grid = (unsigned) std::max<int64_t>(
                     1, std::min<int64_t>(tiles, (int64_t) ctx->num_cus * 8));
                 if (EXT)
@@ -2171,6 +2238,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         BT_HIP_CHECK(hipGetLastError());
         const uint64_t *keys2 = keys_oth;
         bool dummy = false;
+        // the launch of level L1+1 on the first key took that level's tickets
+        reset_loop_kernel<<<1, 128, 0, ctx->stream>>>(d_ls.get(), tickets.get(), L1 + 1);
         BT_CHECK(level_loop(keys2, L2, L1, cand.get(), false, L1 + 1, &dummy));
         // (the scratch buffers of this block are released after the work that reads them
         // has been queued on the stream; the pool hands memory to this stream only)

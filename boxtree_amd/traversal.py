@@ -250,75 +250,69 @@ class FMMTraversalBuilder:
             tp.active_level_ranges = alr.ctypes.data_as(ct.POINTER(ct.c_int32))
 
         lib = actx.lib
-        sizes = _lib.TravSizes()
+        # One int32 block for every output array: the library asks for it once all list
+        # sizes are known (one allocation instead of ~70), builds the large lists in
+        # place, and reports where each array lives (bt_trav_packed).
+        block = []
+
+        def alloc(_user, nbytes):
+            block.append(actx.empty(int(nbytes) // 4, np.int32))
+            return block[0].data_ptr()
+
+        packed = _lib.TravPacked()
         actx.sync_in()
-        code = lib.bt_traversal_build(actx.handle, ct.byref(tp), ct.byref(sizes))
+        code = lib.bt_traversal_build_packed(actx.handle, ct.byref(tp), _lib.ALLOC_FN(alloc), None,
+                                             ct.byref(packed))
         if code == _lib.BT_ERR_UNSUPPORTED:
             raise NotImplementedError(lib.bt_last_error_string().decode())
         if code == _lib.BT_ERR_INVALID:
             raise ValueError(lib.bt_last_error_string().decode())
         _lib.check(code)
+        buf = block[0]
 
-        e = actx.empty
-        i32 = np.int32
-        out = _lib.TravArrays()
-        ntb = int(sizes.ntarget_boxes)
-        nttp = int(sizes.ntarget_or_target_parent_boxes)
+        def view(span):
+            return buf[span.offset:span.offset + span.count]
+
+        def level_starts(name):
+            # host arrays, as in the reference (traversal.py:2091 actx.to_numpy(result))
+            return np.array(getattr(packed, name)[:nlevels + 1], dtype=np.int32)
+
         with_extent = tree.sources_have_extent or tree.targets_have_extent
-
-        source_boxes = e(int(sizes.nsource_boxes), i32)
-        source_parent_boxes = e(int(sizes.nsource_parent_boxes), i32)
-        target_or_target_parent_boxes = e(nttp, i32)
+        source_boxes = view(packed.source_boxes)
         target_boxes = (source_boxes if sources_are_targets and tbm is None
-                        else e(ntb, i32))
-        out.source_boxes = ptr(source_boxes)
-        out.target_boxes = ptr(target_boxes)
-        out.source_parent_boxes = ptr(source_parent_boxes)
-        out.target_or_target_parent_boxes = ptr(target_or_target_parent_boxes)
+                        else view(packed.target_boxes))
+        source_parent_boxes = view(packed.source_parent_boxes)
+        target_or_target_parent_boxes = view(packed.target_or_target_parent_boxes)
+        lev = {name: level_starts(name) for name in (
+            "level_start_source_box_nrs", "level_start_target_box_nrs",
+            "level_start_source_parent_box_nrs",
+            "level_start_target_or_target_parent_box_nrs")}
 
-        # the four level-start arrays are host arrays in the reference
-        # (traversal.py:2091 actx.to_numpy(result)): one device block, one transfer
-        lev_names = ("level_start_source_box_nrs", "level_start_target_box_nrs",
-                     "level_start_source_parent_box_nrs",
-                     "level_start_target_or_target_parent_box_nrs")
-        lev_block = e(4 * (nlevels + 1), i32)
-        for k, name in enumerate(lev_names):
-            setattr(out, name, ct.c_void_p(lev_block.data_ptr() + 4 * k * (nlevels + 1)))
+        def csr(prefix):
+            return (view(getattr(packed, prefix + "_starts")),
+                    view(getattr(packed, prefix + "_lists")))
 
-        def csr(prefix, n, total):
-            starts = e(n + 1, i32)
-            lists = e(int(total), i32)
-            setattr(out, prefix + "_starts", ptr(starts))
-            setattr(out, prefix + "_lists", ptr(lists))
-            return starts, lists
-
-        slnws = csr("same_level_non_well_sep_boxes", nboxes, sizes.n_same_level_non_well_sep)
-        l1 = csr("neighbor_source_boxes", ntb, sizes.n_neighbor_source)
-        l2 = csr("from_sep_siblings", nttp, sizes.n_from_sep_siblings)
-        l4 = csr("from_sep_bigger", nttp, sizes.n_from_sep_bigger)
+        slnws = csr("same_level_non_well_sep_boxes")
+        l1 = csr("neighbor_source_boxes")
+        l2 = csr("from_sep_siblings")
+        l4 = csr("from_sep_bigger")
         if with_extent:
-            cs = csr("from_sep_close_smaller", ntb, sizes.n_from_sep_close_smaller)
-            cb = csr("from_sep_close_bigger", ntb, sizes.n_from_sep_close_bigger)
+            cs = csr("from_sep_close_smaller")
+            cb = csr("from_sep_close_bigger")
         else:
             cs = cb = (None, None)
 
         l3 = []
         for ilev in range(nlevels):
-            nne = int(sizes.n_from_sep_smaller_nonempty[ilev])
-            cnt = int(sizes.n_from_sep_smaller[ilev])
-            arrs = dict(starts=e(nne + 1, i32), lists=e(cnt, i32),
-                        nonempty_indices=e(nne, i32),
-                        compressed_indices=e(ntb + 1, i32), tboxes=e(nne, i32))
-            out.from_sep_smaller_starts[ilev] = ptr(arrs["starts"]).value
-            out.from_sep_smaller_lists[ilev] = ptr(arrs["lists"]).value
-            out.from_sep_smaller_nonempty_indices[ilev] = ptr(arrs["nonempty_indices"]).value
-            out.from_sep_smaller_compressed_indices[ilev] = ptr(arrs["compressed_indices"]).value
-            out.target_boxes_sep_smaller[ilev] = ptr(arrs["tboxes"]).value
+            nne = int(packed.sizes.n_from_sep_smaller_nonempty[ilev])
+            cnt = int(packed.sizes.n_from_sep_smaller[ilev])
+            arrs = dict(
+                starts=view(packed.from_sep_smaller_starts[ilev]),
+                lists=view(packed.from_sep_smaller_lists[ilev]),
+                nonempty_indices=view(packed.from_sep_smaller_nonempty_indices[ilev]),
+                compressed_indices=view(packed.from_sep_smaller_compressed_indices[ilev]),
+                tboxes=view(packed.target_boxes_sep_smaller[ilev]))
             l3.append((nne, cnt, arrs))
-
-        _lib.check(lib.bt_traversal_export(actx.handle, ct.byref(out)))
-        lev_host = lev_block.cpu().numpy().reshape(4, nlevels + 1)
-        lev = {name: np.ascontiguousarray(lev_host[k]) for k, name in enumerate(lev_names)}
 
         from_sep_smaller_by_level = make_obj_array([
             BuiltList(count=cnt, starts=a["starts"], lists=a["lists"],

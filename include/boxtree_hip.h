@@ -267,6 +267,41 @@ typedef struct {
 
 int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *out);
 
+/* One-call variant: every output array is a span of ONE int32 block that the caller
+ * allocates through a callback once all sizes are known (device memory, 256-byte
+ * aligned, `nbytes` long; return NULL to fail).  The library writes the large lists
+ * straight into the block -- no export copy -- and returns the spans (offsets and
+ * counts in int32 elements from `base`) plus host copies of the four level-start
+ * arrays, which the reference hands out as host arrays (traversal.py:2091).
+ * target_boxes is the span of source_boxes when the tree's sources are its targets. */
+typedef void *(*bt_alloc_fn)(void *user, int64_t nbytes);
+typedef struct { int64_t offset, count; } bt_span;
+typedef struct {
+    void *base;
+    int64_t total;                         /* int32 elements in the block */
+    int32_t nlevels;
+    int32_t lattice_path;                  /* information: the integer-lattice kernels ran */
+    bt_trav_sizes sizes;
+    int32_t level_start_source_box_nrs[BT_MAX_LEVELS + 1];
+    int32_t level_start_target_box_nrs[BT_MAX_LEVELS + 1];
+    int32_t level_start_source_parent_box_nrs[BT_MAX_LEVELS + 1];
+    int32_t level_start_target_or_target_parent_box_nrs[BT_MAX_LEVELS + 1];
+    bt_span source_boxes, target_boxes, source_parent_boxes, target_or_target_parent_boxes;
+    bt_span same_level_non_well_sep_boxes_starts, same_level_non_well_sep_boxes_lists;
+    bt_span neighbor_source_boxes_starts, neighbor_source_boxes_lists;
+    bt_span from_sep_siblings_starts, from_sep_siblings_lists;
+    bt_span from_sep_bigger_starts, from_sep_bigger_lists;
+    bt_span from_sep_close_smaller_starts, from_sep_close_smaller_lists;   /* count -1: absent */
+    bt_span from_sep_close_bigger_starts, from_sep_close_bigger_lists;
+    bt_span from_sep_smaller_starts[BT_MAX_LEVELS];
+    bt_span from_sep_smaller_lists[BT_MAX_LEVELS];
+    bt_span from_sep_smaller_nonempty_indices[BT_MAX_LEVELS];
+    bt_span from_sep_smaller_compressed_indices[BT_MAX_LEVELS];
+    bt_span target_boxes_sep_smaller[BT_MAX_LEVELS];
+} bt_trav_packed;
+int bt_traversal_build_packed(bt_context *ctx, const bt_trav_params *params, bt_alloc_fn alloc,
+                              void *user, bt_trav_packed *out);
+
 /* Row-wise concatenation of up to 4 CSR lists with equal row count
  * (FMMTraversalInfo.merge_close_lists, traversal.py:1650-1693 / _ListMerger
  * :1222-1344): out row i = lists[0] row i ++ lists[1] row i ++ ...  out_starts has
