@@ -48,7 +48,7 @@ int main(int argc, char **argv)
         CHECK_HIP(hipMemcpy(dev[ax], host[ax], (size_t) n * sizeof(double), hipMemcpyHostToDevice));
     }
 
-    if (bt_abi_version() != 1) { fprintf(stderr, "ABI version mismatch\n"); return 4; }
+    if (bt_abi_version() != BT_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 4; }
     bt_context *ctx = NULL;
     CHECK_BT(bt_create(0, NULL, &ctx));
 
