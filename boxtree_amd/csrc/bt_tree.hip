@@ -1064,6 +1064,184 @@ __global__ __launch_bounds__(256) void segment_sort_block_kernel(const int32_t *
 }
 
 // ---------------------------------------------------------------------------
+// Leaves in one pass (sources == targets, no extents): order the leaf's ids
+// (fix-up), write them out, gather the coordinates of its particles and reduce
+// the leaf's bounding box while they are in registers.  Replaces the in-place id
+// sort, the id copy, the gather's re-read of the ids and the extent kernel's
+// re-read of all gathered coordinates (tbk:776-790, 1170-1186, 1311-1399).
+// ---------------------------------------------------------------------------
+
+template <class T, int D>
+struct LeafOut {
+    int32_t *user_source_ids;
+    T *out[D];
+    T *bmin, *bmax;             // [D][aligned]
+    int64_t aligned;
+};
+
+template <class T, int D>
+__global__ __launch_bounds__(256) void leaf_gather_wave_kernel(int nboxes, const int32_t *box_start,
+        const int32_t *box_count, const uint8_t *box_haschild, const uint32_t *ids,
+        const T *__restrict__ packed, const T *centers /* [box][D] */, LeafOut<T, D> o,
+        int32_t *large_list, SegSortFlags *flags)
+{
+    const int b = (blockIdx.x * 256 + threadIdx.x) >> 5;
+    const int lane = threadIdx.x & 31;
+    if (b >= nboxes) return;
+    if (box_haschild[b]) return;            // no own particles without extents
+    const int n = box_count[b];
+    const int s = box_start[b];
+    if (n > 64) {
+        if (lane == 0) {
+            if (n <= SEG_BLOCK_MAX) large_list[atomicAdd(&flags->n_large, 1)] = b;
+            else atomicExch(&flags->has_huge, 1);
+        }
+        return;
+    }
+    uint32_t v0 = (lane < n) ? ids[s + lane] : 0xFFFFFFFFu;
+    uint32_t v1 = (lane + 32 < n) ? ids[s + lane + 32] : 0xFFFFFFFFu;
+    auto cmpx = [&](uint32_t v, int idx, int k, int j) {
+        const uint32_t other = __shfl_xor(v, j, 32);
+        const bool up = (idx & k) == 0;
+        const bool lower = (idx & j) == 0;
+        const uint32_t mn = v < other ? v : other, mx = v < other ? other : v;
+        return (lower == up) ? mn : mx;
+    };
+    if (n > 1) {
+#pragma unroll
+        for (int k = 2; k <= 32; k <<= 1) {
+#pragma unroll
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                v0 = cmpx(v0, lane, k, j);
+                if (n > 32) v1 = cmpx(v1, lane + 32, k, j);
+            }
+        }
+        if (n > 32) {
+            {
+                const uint32_t mn = v0 < v1 ? v0 : v1, mx = v0 < v1 ? v1 : v0;
+                v0 = mn; v1 = mx;
+            }
+#pragma unroll
+            for (int j = 16; j > 0; j >>= 1) {
+                v0 = cmpx(v0, lane, 64, j);
+                v1 = cmpx(v1, lane + 32, 64, j);
+            }
+        }
+    }
+    constexpr int PS = PackStride<D>::value;
+    T c0[D], c1[D], mn[D], mx[D];
+    const bool h0 = lane < n, h1 = lane + 32 < n;
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        c0[ax] = h0 ? packed[(int64_t) v0 * PS + ax] : (T) 0;      // tbk:1170-1186
+        c1[ax] = h1 ? packed[(int64_t) v1 * PS + ax] : (T) 0;
+    }
+    if (h0) o.user_source_ids[s + lane] = (int32_t) v0;
+    if (h1) o.user_source_ids[s + lane + 32] = (int32_t) v1;
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        if (h0) __builtin_nontemporal_store(c0[ax], &o.out[ax][s + lane]);
+        if (h1) __builtin_nontemporal_store(c1[ax], &o.out[ax][s + lane + 32]);
+        // tbk:1311-1399: the extent starts from the box centre
+        const T cen = centers[(int64_t) b * D + ax];
+        T lo = cen, hi = cen;
+        if (h0) { lo = c0[ax] < lo ? c0[ax] : lo; hi = c0[ax] > hi ? c0[ax] : hi; }
+        if (h1) { lo = c1[ax] < lo ? c1[ax] : lo; hi = c1[ax] > hi ? c1[ax] : hi; }
+        mn[ax] = lo; mx[ax] = hi;
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) {
+            const T omn = __shfl_xor(mn[ax], off, 32), omx = __shfl_xor(mx[ax], off, 32);
+            mn[ax] = (omn < mn[ax]) ? omn : mn[ax];
+            mx[ax] = (omx > mx[ax]) ? omx : mx[ax];
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) {
+            o.bmin[(int64_t) ax * o.aligned + b] = mn[ax];
+            o.bmax[(int64_t) ax * o.aligned + b] = mx[ax];
+        }
+    }
+}
+
+// leaves of 65 .. SEG_BLOCK_MAX particles: one workgroup at a time per listed leaf
+template <class T, int D>
+__global__ __launch_bounds__(256) void leaf_gather_block_kernel(const int32_t *large_list,
+        const SegSortFlags *flags, const int32_t *box_start, const int32_t *box_count,
+        const uint32_t *ids, const T *__restrict__ packed, const T *centers, LeafOut<T, D> o)
+{
+    __shared__ uint32_t s_v[SEG_BLOCK_MAX];
+    __shared__ T s_mn[256 / 64][D], s_mx[256 / 64][D];
+    const int nl = flags->n_large;
+    constexpr int PS = PackStride<D>::value;
+    for (int jb = blockIdx.x; jb < nl; jb += gridDim.x) {
+        __syncthreads();
+        const int b = large_list[jb];
+        const int s = box_start[b], n = box_count[b];
+        int m = 128;
+        while (m < n) m <<= 1;
+        for (int i = threadIdx.x; i < m; i += 256) s_v[i] = (i < n) ? ids[s + i] : 0xFFFFFFFFu;
+        __syncthreads();
+        for (int k = 2; k <= m; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = threadIdx.x; i < m; i += 256) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const uint32_t a = s_v[i], c = s_v[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > c) == up) { s_v[i] = c; s_v[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        T mn[D], mx[D];
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) mn[ax] = mx[ax] = centers[(int64_t) b * D + ax];
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const uint32_t id = s_v[i];
+            o.user_source_ids[s + i] = (int32_t) id;
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) {
+                const T c = packed[(int64_t) id * PS + ax];
+                o.out[ax][s + i] = c;
+                mn[ax] = c < mn[ax] ? c : mn[ax];
+                mx[ax] = c > mx[ax] ? c : mx[ax];
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) {
+                const T omn = __shfl_xor(mn[ax], off, 64), omx = __shfl_xor(mx[ax], off, 64);
+                mn[ax] = (omn < mn[ax]) ? omn : mn[ax];
+                mx[ax] = (omx > mx[ax]) ? omx : mx[ax];
+            }
+        }
+        if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) { s_mn[threadIdx.x >> 6][ax] = mn[ax]; s_mx[threadIdx.x >> 6][ax] = mx[ax]; }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) {
+                T a = s_mn[0][ax], c = s_mx[0][ax];
+                for (int w = 1; w < 256 / 64; ++w) {
+                    a = s_mn[w][ax] < a ? s_mn[w][ax] : a;
+                    c = s_mx[w][ax] > c ? s_mx[w][ax] : c;
+                }
+                o.bmin[(int64_t) ax * o.aligned + b] = a;
+                o.bmax[(int64_t) ax * o.aligned + b] = c;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // sources / targets (tbk:1013-1164, 1770-1782; tools.py:81-109)
 // ---------------------------------------------------------------------------
 
@@ -1100,7 +1278,7 @@ __global__ __launch_bounds__(256) void same_ids_kernel(int64_t n, const uint32_t
     if (p >= n) return;
     const uint32_t id = ids[p];
     user_source_ids[p] = (int32_t) id;
-    sorted_target_ids[id] = (int32_t) p;       // reverse_index_array, tools.py:81-109
+    if ((int64_t) id < n) sorted_target_ids[id] = (int32_t) p;   // reverse_index_array, tools.py:81-109
 }
 
 // The scatter half of same_ids_kernel restricted to destinations [lo, hi): run
@@ -1112,7 +1290,7 @@ __global__ __launch_bounds__(256) void inverse_ids_window_kernel(int64_t n, cons
     const int64_t p = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     const uint32_t id = ids[p];
-    if (id >= lo && id < hi) sorted_target_ids[id] = (int32_t) p;
+    if (id >= lo && id < hi && (int64_t) id < n) sorted_target_ids[id] = (int32_t) p;
 }
 
 // inverse permutation from (id, position) pairs that one radix pass has grouped by
@@ -1128,7 +1306,8 @@ __global__ __launch_bounds__(256) void scatter_inverse_kernel(int64_t n, const u
     const int64_t logical = (int64_t) (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     const int64_t j = logical * 256 + threadIdx.x;
     if (j >= n) return;
-    sorted_target_ids[ids[j]] = (int32_t) positions[j];
+    const uint32_t id = ids[j];
+    if ((int64_t) id < n) sorted_target_ids[id] = (int32_t) positions[j];
 }
 
 __global__ __launch_bounds__(256) void copy_ids_kernel(int64_t n, const uint32_t *ids,
@@ -1245,6 +1424,7 @@ struct ExtentArgs {
     const T *part[D];
     const T *radii;          // null if disabled
     T *bmin, *bmax;          // [D][aligned]
+    int leaves_done;         // leaf_gather_*_kernel wrote the extents of the leaves
 };
 
 template <class T, int D>
@@ -1253,8 +1433,14 @@ __global__ __launch_bounds__(256) void box_extent_kernel(ExtentArgs<T, D> a)
     constexpr int C = 1 << D;
     const int g = (blockIdx.x * 256 + threadIdx.x) >> 4;
     const int l16 = threadIdx.x & 15;
-    const bool active = g < a.nb;
+    bool active = g < a.nb;
     const int b = a.b0 + (active ? g : 0);
+    if (active && a.leaves_done) {
+        // only boxes with children are left to do (whole 16-lane groups drop out)
+        bool any_child = false;
+        for (int m = 0; m < C; ++m) any_child = any_child || a.child[(int64_t) m * a.aligned + b] != 0;
+        if (!any_child) return;
+    }
     T mn[D], mx[D];
 #pragma unroll
     for (int ax = 0; ax < D; ++ax) mn[ax] = mx[ax] = a.centers[(int64_t) ax * a.aligned + b];
@@ -1318,6 +1504,8 @@ struct TreeState {
     Buf<uint64_t> keys_a, keys_b;
     Buf<uint32_t> ids_a, ids_b;
     uint32_t *ids = nullptr;           // final tree order -> user srcntgt id
+    uint32_t *ids_other = nullptr;     // the other id buffer (scratch of the global fix-up)
+    bool fixup_done = false;           // ids are in the reference's within-box order
     Buf<int64_t> wprefix;
     Buf<int32_t> src_prefix;           // [N+1] (separate targets only)
     Buf<int32_t> srcntgt_target_ids;   // [ntargets]
@@ -1876,6 +2064,56 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
     return BT_OK;
 }
 
+// within-box order fix-up (see the header): every leaf's ids, and every box's run of own
+// particles, ascending
+int run_fixup(bt_context *ctx, TreeState *st)
+{
+    const int64_t N = st->N;
+    uint32_t *ids = st->ids, *ids_other = st->ids_other;
+    bool need_global_fixup = N > 1;
+    if (N > 1) {
+        Buf<int32_t> large_list;
+        Buf<SegSortFlags> sflags;
+        BT_CHECK(large_list.alloc(ctx->pool, N / 64 + 1));
+        BT_CHECK(sflags.alloc(ctx->pool, 1));
+        BT_HIP_CHECK(hipMemsetAsync(sflags.get(), 0, sizeof(SegSortFlags), ctx->stream));
+        segment_sort_wave_kernel<<<(unsigned) div_up(st->nboxes * 32, 256), 256, 0, ctx->stream>>>(
+            (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_haschild.get(),
+            ids, large_list.get(), sflags.get());
+        SegSortFlags hf;
+        BT_HIP_CHECK(hipMemcpyAsync(&hf, sflags.get(), sizeof(hf), hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->n_host_syncs++;
+        if (!hf.has_huge) {
+            if (hf.n_large > 0)
+                segment_sort_block_kernel<<<hf.n_large, 256, 0, ctx->stream>>>(
+                    large_list.get(), st->box_start.get(), st->box_count.get(), ids);
+            need_global_fixup = false;
+        }
+    }
+    if (need_global_fixup) {
+        Buf<uint32_t> fk_a, fk_b;
+        BT_CHECK(fk_a.alloc(ctx->pool, N));
+        BT_CHECK(fk_b.alloc(ctx->pool, N));
+        segment_key_kernel<<<(unsigned) div_up(st->nboxes * 16, 256), 256, 0, ctx->stream>>>(
+            (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_nonchild.get(),
+            st->box_haschild.get(), ids, fk_a.get());
+        int bits = 1;
+        while (((int64_t) 1 << bits) < N) ++bits;
+        bool in_b = false;
+        // values: reuse the two id buffers; `ids` is consumed by segment_key_kernel
+        // (stream order) before the sort overwrites it.
+        uint32_t *va = ids_other, *vb = ids;
+        BT_CHECK(radix_sort_pairs<uint32_t>(ctx, fk_a.get(), va, fk_b.get(), vb, N, 0, bits,
+                                            true, &in_b));
+        st->ids = in_b ? vb : va;
+        st->ids_other = in_b ? va : vb;
+        BT_CHECK(check_status(ctx));
+    }
+    st->fixup_done = true;
+    return BT_OK;
+}
+
 template <class T, int D>
 int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
 {
@@ -2249,44 +2487,19 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
 
     // ---- within-box order fix-up ----------------------------------------------
     st->ids = ids;
-    bool need_global_fixup = N > 1;
-    if (N > 1) {
-        Buf<int32_t> large_list;
-        Buf<SegSortFlags> sflags;
-        BT_CHECK(large_list.alloc(ctx->pool, N / 64 + 1));
-        BT_CHECK(sflags.alloc(ctx->pool, 1));
-        BT_HIP_CHECK(hipMemsetAsync(sflags.get(), 0, sizeof(SegSortFlags), ctx->stream));
-        segment_sort_wave_kernel<<<(unsigned) div_up(st->nboxes * 32, 256), 256, 0, ctx->stream>>>(
-            (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_haschild.get(),
-            ids, large_list.get(), sflags.get());
-        SegSortFlags hf;
-        BT_HIP_CHECK(hipMemcpyAsync(&hf, sflags.get(), sizeof(hf), hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        if (!hf.has_huge) {
-            if (hf.n_large > 0)
-                segment_sort_block_kernel<<<hf.n_large, 256, 0, ctx->stream>>>(
-                    large_list.get(), st->box_start.get(), st->box_count.get(), ids);
-            need_global_fixup = false;
-        }
-    }
-    if (need_global_fixup) {
-        Buf<uint32_t> fk_a, fk_b;
-        BT_CHECK(fk_a.alloc(ctx->pool, N));
-        BT_CHECK(fk_b.alloc(ctx->pool, N));
-        segment_key_kernel<<<(unsigned) div_up(st->nboxes * 16, 256), 256, 0, ctx->stream>>>(
-            (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_nonchild.get(),
-            st->box_haschild.get(), ids, fk_a.get());
-        int bits = 1;
-        while (((int64_t) 1 << bits) < N) ++bits;
-        bool in_b = false;
-        // values: reuse the two id buffers; `ids` is consumed by segment_key_kernel
-        // (stream order) before the sort overwrites it.
-        uint32_t *va = ids_other, *vb = ids;
-        BT_CHECK(radix_sort_pairs<uint32_t>(ctx, fk_a.get(), va, fk_b.get(), vb, N, 0, bits,
-                                            true, &in_b));
-        st->ids = in_b ? vb : va;
-        BT_CHECK(check_status(ctx));
-    }
+    st->ids_other = ids_other;
+    // sources == targets without extents: the leaves CAN be ordered, gathered and
+    // measured in one pass at export time (leaf_gather_wave_kernel, BT_FUSED_LEAVES=1).
+    // Measured at 10^8 sphere points: 4.5 ms against 0.9 + 2.6 + 0.4 ms for the separate
+    // id sort, gather and leaf extents -- a half-wave per leaf of ~25 particles keeps
+    // 40 % of the lanes busy during the random 32-byte gathers, the thread-per-particle
+    // gather keeps all of them busy -- so it is off by default (3 % faster at 10^7).
+    static const bool fused_env = [] {
+        const char *e = getenv("BT_FUSED_LEAVES");
+        return e && atoi(e);
+    }();
+    st->fixup_done = false;
+    if (!(fused_env && st->sat && !EXT)) BT_CHECK(run_fixup(ctx, st));
     BT_CHECK(mark(ctx, st, "fixup"));
 
     // keys are no longer needed
@@ -2325,6 +2538,34 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
     auto blocks = [](int64_t n) { return (unsigned) std::max<int64_t>(1, div_up(n, 256)); };
 
     BT_CHECK(mark(ctx, st, "(host gap)"));
+    // ---- leaves in one pass (sources == targets, no extents): ids in their final order,
+    // coordinates, leaf extents -------------------------------------------------------------
+    const bool fused = !st->fixup_done && N > 1;
+    Buf<int32_t> large_list;
+    Buf<SegSortFlags> sflags;
+    if (fused) {
+        T *bmin = (T *) o->box_source_bounding_box_min, *bmax = (T *) o->box_source_bounding_box_max;
+        BT_HIP_CHECK(hipMemsetAsync(bmin, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
+        BT_HIP_CHECK(hipMemsetAsync(bmax, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
+        BT_CHECK(large_list.alloc(ctx->pool, N / 64 + 1));
+        BT_CHECK(sflags.alloc(ctx->pool, 1));
+        BT_HIP_CHECK(hipMemsetAsync(sflags.get(), 0, sizeof(SegSortFlags), ctx->stream));
+        LeafOut<T, D> lo{};
+        lo.user_source_ids = o->user_source_ids;
+        for (int ax = 0; ax < D; ++ax) lo.out[ax] = (T *) o->sources[ax];
+        lo.bmin = bmin; lo.bmax = bmax; lo.aligned = aligned;
+        leaf_gather_wave_kernel<T, D><<<blocks(B * 32), 256, 0, ctx->stream>>>(
+            (int) B, st->box_start.get(), st->box_count.get(), st->box_haschild.get(), st->ids,
+            (const T *) st->packed.get(), (const T *) st->centers.get(), lo, large_list.get(),
+            sflags.get());
+        leaf_gather_block_kernel<T, D><<<(unsigned) std::min<int64_t>(ctx->num_cus * 2, N / 64 + 1), 256, 0,
+                                         ctx->stream>>>(
+            large_list.get(), sflags.get(), st->box_start.get(), st->box_count.get(), st->ids,
+            (const T *) st->packed.get(), (const T *) st->centers.get(), lo);
+        BT_HIP_CHECK(hipGetLastError());
+    }
+    BT_CHECK(mark(ctx, st, "leaves"));
+    const uint32_t *final_ids = fused ? (const uint32_t *) o->user_source_ids : st->ids;
     // ---- ids -------------------------------------------------------------------
     if (N > 0) {
         static const int id_windows_env = [] {
@@ -2341,15 +2582,16 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
             // windows 1.86 ms; grouping the (id, position) pairs by the id's top byte
             // first (one 32-bit onesweep pass that synthesises the positions) makes
             // the scatter local.
-            copy_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(N, st->ids, o->user_source_ids);
+            if (!fused) copy_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(N, st->ids, o->user_source_ids);
             int bits = 0;
             while (((int64_t) 1 << bits) < N) ++bits;
             Buf<uint32_t> grouped_ids, positions;
             BT_CHECK(grouped_ids.alloc(ctx->pool, N));
             BT_CHECK(positions.alloc(ctx->pool, N));
             bool in_b = false;
-            BT_CHECK(radix_sort_pairs<uint32_t>(ctx, st->ids, nullptr, grouped_ids.get(),
-                                                positions.get(), N, bits - 8, bits, true, &in_b));
+            BT_CHECK(radix_sort_pairs<uint32_t>(ctx, const_cast<uint32_t *>(final_ids), nullptr,
+                                                grouped_ids.get(), positions.get(), N, bits - 8, bits,
+                                                true, &in_b));
             // blocks rounded up to a multiple of 8 so that every XCD gets whole stretches
             // (measured at 10^8: 1.53 ms for the stage, 1.72 without the XCD mapping,
             // 1.95 with a second pass, 1.95 for the four-window scatter)
@@ -2357,15 +2599,15 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
             scatter_inverse_kernel<<<nb, 256, 0, ctx->stream>>>(
                 N, grouped_ids.get(), positions.get(), o->sorted_target_ids);
         } else if (sat && id_windows > 1) {
-            copy_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(N, st->ids, o->user_source_ids);
+            if (!fused) copy_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(N, st->ids, o->user_source_ids);
             for (int w = 0; w < id_windows; ++w) {
                 const uint32_t lo = (uint32_t) (N * w / id_windows);
                 const uint32_t hi = (uint32_t) (N * (w + 1) / id_windows);
                 inverse_ids_window_kernel<<<blocks(N), 256, 0, ctx->stream>>>(
-                    N, st->ids, lo, hi, o->sorted_target_ids);
+                    N, final_ids, lo, hi, o->sorted_target_ids);
             }
         } else if (sat) {
-            same_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(N, st->ids, o->user_source_ids,
+            same_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(N, final_ids, o->user_source_ids,
                                                               o->sorted_target_ids);
         } else {
             BT_CHECK(st->srcntgt_target_ids.alloc(ctx->pool, st->ntargets));
@@ -2384,7 +2626,7 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
             gs.out[ax] = (T *) o->sources[ax];
             gt.out[ax] = sat ? nullptr : (T *) o->targets[ax];
         }
-        if (st->nsources > 0)
+        if (st->nsources > 0 && !fused)
             gather_packed_kernel<T, D><<<blocks(st->nsources), 256, 0, ctx->stream>>>(
                 st->nsources, o->user_source_ids, packed, gs);
         if (!sat && st->ntargets > 0)
@@ -2430,10 +2672,14 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
         if (round == 1 && sat) continue;
         T *bmin = (T *) (round == 0 ? o->box_source_bounding_box_min : o->box_target_bounding_box_min);
         T *bmax = (T *) (round == 0 ? o->box_source_bounding_box_max : o->box_target_bounding_box_max);
-        BT_HIP_CHECK(hipMemsetAsync(bmin, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
-        BT_HIP_CHECK(hipMemsetAsync(bmax, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
-        for (int lev = nlevels - 1; lev >= 0; --lev) {
+        if (!fused) {
+            BT_HIP_CHECK(hipMemsetAsync(bmin, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
+            BT_HIP_CHECK(hipMemsetAsync(bmax, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
+        }
+        // (with the leaves done the deepest level has nothing left)
+        for (int lev = nlevels - 1 - (fused ? 1 : 0); lev >= 0; --lev) {
             ExtentArgs<T, D> a;
+            a.leaves_done = fused ? 1 : 0;
             a.b0 = st->level_start[lev];
             a.nb = st->level_start[lev + 1] - a.b0;
             a.aligned = aligned;
@@ -2452,7 +2698,21 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
     }
     BT_HIP_CHECK(hipGetLastError());
     BT_CHECK(mark(ctx, st, "extents"));
+    if (fused) {
+        SegSortFlags hf;
+        BT_HIP_CHECK(hipMemcpyAsync(&hf, sflags.get(), sizeof(hf), hipMemcpyDeviceToHost, ctx->stream));
+        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        ctx->n_host_syncs++;
+        if (hf.has_huge) {
+            // a leaf beyond the workgroup sort (zero refine weights): order the ids with
+            // the global fix-up and take the general path
+            BT_CHECK(run_fixup(ctx, st));
+            return tree_export_impl<T, D>(ctx, st, o);
+        }
+        return BT_OK;
+    }
     BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->n_host_syncs++;
     return BT_OK;
 }
 
