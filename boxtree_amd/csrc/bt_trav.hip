@@ -1480,7 +1480,9 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     static const int k1_env = [] { const char *e = getenv("BT_V2_K1"); return e ? atoi(e) : 0; }();
     static const int k3_env = [] { const char *e = getenv("BT_V2_K3"); return e ? atoi(e) : 0; }();
     const int K1 = k1_env > 0 ? k1_env : (D == 3 ? 64 : D == 2 ? 24 : 8);
-    const int K3 = k3_env > 0 ? k3_env : (D == 3 ? 32 : D == 2 ? 16 : 8);
+    // (with extents the lists 3 of the per-colleague items are long: at 10^8 + 10^7
+    // particles 8 % of the items overflow 32 entries, 1 % overflow 64)
+    const int K3 = k3_env > 0 ? k3_env : (D == 3 ? (st->with_extent ? 64 : 32) : D == 2 ? 16 : 8);
     const int Kc = st->with_extent ? K3 : 0;
     Buf<int32_t> row1, row3, rowc, l1_item, l3_item, close_item, ovf_list;
     Buf<uint8_t> row3lev, overflow;
@@ -1519,6 +1521,13 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     w.overflow = overflow.get();
     w.ovf_count = (int32_t *) (totals.get() + T_OVF);
     w.ovf_list = ovf_list.get();
+    static const bool trav_stats = [] { const char *e = getenv("BT_TRAV_STATS"); return e && atoi(e); }();
+    Buf<int32_t> dbg_counts;
+    if (trav_stats) {
+        BT_CHECK(dbg_counts.alloc(ctx->pool, 4));
+        BT_HIP_CHECK(hipMemsetAsync(dbg_counts.get(), 0, 16, ctx->stream));
+        w.dbg_counts = dbg_counts.get();
+    }
     walk13_v2_kernel<T, D, true><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
     BT_CHECK(tmark(ctx, st, "trav:walk (rows)"));
 
@@ -1585,6 +1594,17 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             return BT_ERR_UNSUPPORTED;
         }
     const int64_t novf = h_tot[T_OVF] & 0xffffffffll;
+    if (trav_stats) {
+        int32_t hc[4];
+        BT_HIP_CHECK(hipMemcpy(hc, dbg_counts.get(), 16, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[bt trav] boxes %lld target boxes %lld items %lld (cap %lld) K1 %d K3 %d Kc %d | "
+                "overflow items %lld (list1 %d, list3 %d, close %d; per-colleague items %d) | entries: "
+                "coll %lld l2 %lld l1 %lld l3 %lld close %lld l4 %lld\n", (long long) B, (long long) ntb,
+                (long long) (h_tot[T_NITEMS] & 0xffffffffll), (long long) items_cap, K1, K3, Kc,
+                (long long) novf, hc[0], hc[1], hc[2], hc[3], (long long) h_tot[T_COLL],
+                (long long) h_tot[T_L2], (long long) h_tot[T_L1], (long long) h_tot[T_L3],
+                (long long) h_tot[T_CLOSE], (long long) h_tot[T_L4]);
+    }
     st->l3_level_base.assign((size_t) nlevels, 0);
     st->l3_level_count.assign((size_t) nlevels, 0);
     st->l3_nonempty.assign((size_t) nlevels, 0);

@@ -801,8 +801,9 @@ __global__ __launch_bounds__(256) void l1_finalize_kernel(TravArgs<T, D> a, Fast
     for (int32_t i = 0; i < k; ++i) out[i] = ft.box_of_rank[out[i]];
 }
 
-// Same as l1_finalize_kernel with 32 lanes per target box: lists of up to 32 ranks
-// (nearly all of them) are ordered by counting in registers; longer ones by lane 0.
+// Same as l1_finalize_kernel with 16 lanes per target box: lists of up to 64 ranks
+// (nearly all of them) are ordered by counting in registers; longer ones go to a wave
+// or a workgroup.
 constexpr int L1_BLOCK_MAX = 8192;
 constexpr int L1_WAVE_MAX = 1024;
 
@@ -841,21 +842,38 @@ __global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, Fa
         blk_len = ft.src_prefix[my_rank + ft.subtree_size[b]] - blk_src;
     }
     const int32_t n = n_all - blk_len;
-    if (n <= 32) {
+    if (n <= 64) {
+        // up to four entries per lane; the upper two only where a list has more than 32
+        // (a 16-lane group takes one branch together)
+        const bool big = n > 32;
         const int32_t v0 = lane < n ? out[lane] : INT32_MAX;
         const int32_t v1 = lane + 16 < n ? out[lane + 16] : INT32_MAX;
-        int r0 = 0, r1 = 0, k = 0;
+        const int32_t v2 = (big && lane + 32 < n) ? out[lane + 32] : INT32_MAX;
+        const int32_t v3 = (big && lane + 48 < n) ? out[lane + 48] : INT32_MAX;
+        int r0 = 0, r1 = 0, r2 = 0, r3 = 0, k = 0;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             const int32_t o0 = __shfl(v0, j, 16), o1 = __shfl(v1, j, 16);
             r0 += ((o0 < v0) ? 1 : 0) + ((o1 < v0) ? 1 : 0);     // ranks are distinct
             r1 += ((o0 < v1) ? 1 : 0) + ((o1 < v1) ? 1 : 0);
             k += ((o0 <= my_rank) ? 1 : 0) + ((o1 <= my_rank) ? 1 : 0);   // before the own block
+            if (big) {
+                const int32_t o2 = __shfl(v2, j, 16), o3 = __shfl(v3, j, 16);
+                r0 += ((o2 < v0) ? 1 : 0) + ((o3 < v0) ? 1 : 0);
+                r1 += ((o2 < v1) ? 1 : 0) + ((o3 < v1) ? 1 : 0);
+                r2 += ((o0 < v2) ? 1 : 0) + ((o1 < v2) ? 1 : 0) + ((o2 < v2) ? 1 : 0) + ((o3 < v2) ? 1 : 0);
+                r3 += ((o0 < v3) ? 1 : 0) + ((o1 < v3) ? 1 : 0) + ((o2 < v3) ? 1 : 0) + ((o3 < v3) ? 1 : 0);
+                k += ((o2 <= my_rank) ? 1 : 0) + ((o3 <= my_rank) ? 1 : 0);
+            }
         }
         const int32_t w0 = lane < n ? ft.box_of_rank[v0] : 0;
         const int32_t w1 = lane + 16 < n ? ft.box_of_rank[v1] : 0;
+        const int32_t w2 = (big && lane + 32 < n) ? ft.box_of_rank[v2] : 0;
+        const int32_t w3 = (big && lane + 48 < n) ? ft.box_of_rank[v3] : 0;
         if (lane < n) out[r0 < k ? r0 : r0 + blk_len] = w0;
         if (lane + 16 < n) out[r1 < k ? r1 : r1 + blk_len] = w1;
+        if (big && lane + 32 < n) out[r2 < k ? r2 : r2 + blk_len] = w2;
+        if (big && lane + 48 < n) out[r3 < k ? r3 : r3 + blk_len] = w3;
         if (blk_len > 0 && lane == 0) {
             const int32_t j = atomicAdd(jobs.count, 1);
             jobs.dst[j] = l1_starts[tbn] + k;
@@ -908,18 +926,33 @@ __global__ __launch_bounds__(256) void l1_finalize_wave_kernel(TravArgs<T, D> a,
         blk_len = ft.src_prefix[my_rank + ft.subtree_size[b]] - blk_src;
     }
     const int32_t n = n_all - blk_len;
-    for (int i = lane; i < n; i += 64) s_v[i] = out[i];
+    // bitonic sort of the (distinct) ranks in LDS by the wave: O(n log^2 n / 64) steps
+    // (ranking every entry against all others took 3.4 ms on the 10^5 mid-size lists of
+    // the 10^8 + 10^7 extent workload)
+    int m = 64;
+    while (m < n) m <<= 1;
+    for (int i = lane; i < m; i += 64) s_v[i] = (i < n) ? out[i] : INT32_MAX;
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
+    for (int k = 2; k <= m; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = lane; i < m; i += 64) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const int32_t x = s_v[i], y = s_v[l];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { s_v[i] = y; s_v[l] = x; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+        }
+    }
     int32_t k0 = 0;                                  // entries before the own-subtree block
     for (int base = 0; base < n; base += 64)
         k0 += __popcll(__ballot(base + lane < n && s_v[base + lane] <= my_rank));
-    for (int i = lane; i < n; i += 64) {
-        const int32_t v = s_v[i];
-        int32_t r = 0;
-        for (int j = 0; j < n; ++j) r += (s_v[j] < v) ? 1 : 0;      // broadcast LDS reads
-        out[r < k0 ? r : r + blk_len] = ft.box_of_rank[v];
-    }
+    for (int i = lane; i < n; i += 64)
+        out[i < k0 ? i : i + blk_len] = ft.box_of_rank[s_v[i]];
     if (blk_len > 0 && lane == 0) {
         const int32_t j = atomicAdd(jobs.count, 1);
         jobs.dst[j] = l1_starts[tbn] + k0;

@@ -282,6 +282,7 @@ struct V2Walk {
     int32_t *l1_cs, *l3_cs, *close_cs; // counts (ROWS) / starts (!ROWS)
     uint8_t *overflow;                 // [items_cap]
     int32_t *ovf_count, *ovf_list;
+    int32_t *dbg_counts;               // optional [4]
     // final places (!ROWS)
     int32_t *l1_lists, *l3_lists, *close_lists;
 };
@@ -492,7 +493,9 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                             meets = ((2 - 8 * Eps<T>::v) * source_rad <= rhs);
                         }
                     }
-                    const bool force_close = a.close_lists_exist
+                    // (counts are >= 0: without a threshold nothing is forced and the
+                    // random load of the count is saved)
+                    const bool force_close = a.close_lists_exist && a.min_nsources_cumul > 0
                         && (a.src_counts_cumul[wb] < a.min_nsources_cumul);
                     if (meets && !force_close) {
                         emit3(wl, wb);
@@ -533,6 +536,12 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         const bool ovf = e1.n > w.K1 || n3 > w.K3 || (w.close_cs && ec.n > w.Kc);
         w.overflow[item] = ovf ? 1 : 0;
         if (ovf) w.ovf_list[atomicAdd(w.ovf_count, 1)] = item;
+        if (ovf && w.dbg_counts) {          // BT_TRAV_STATS: why items overflow
+            if (e1.n > w.K1) atomicAdd(w.dbg_counts + 0, 1);
+            if (n3 > w.K3) atomicAdd(w.dbg_counts + 1, 1);
+            if (w.close_cs && ec.n > w.Kc) atomicAdd(w.dbg_counts + 2, 1);
+            if (slot >= 0) atomicAdd(w.dbg_counts + 3, 1);
+        }
     }
 }
 
