@@ -10,6 +10,7 @@ enqueues on its command queue happens inside ``bt_tree_build``/``bt_tree_export`
 from __future__ import annotations
 
 import ctypes as ct
+import dataclasses
 import logging
 from typing import Any, Literal
 
@@ -32,6 +33,208 @@ class MaxLevelsExceeded(RuntimeError):   # tree_build.py:79
 # tree_build.py:83-88
 TreeKind = Literal["adaptive", "adaptive-level-restricted", "non-adaptive"]
 ExtentNorm = Literal["l2", "linf"]
+
+
+
+# {{{ host side of TreeBuilder.__call__
+#
+# What the reference does on the host before it enqueues anything
+# (boxtree/tree_build.py:223-295 argument contract, :405-454 refine weights, :456-510
+# root box).  The exception types and messages are part of the call surface and the
+# root-box arithmetic fixes every later rounding, so both are kept; the organisation is
+# this package's own: one record of normalised inputs, the bounding box as a pair of
+# coordinate vectors instead of a structured scalar.
+
+@dataclasses.dataclass
+class _Inputs:
+    particles: list
+    targets: list | None
+    source_radii: Any
+    target_radii: Any
+    coord_dtype: np.dtype
+    extent_norm: str | None         # None without extents
+    stick_out_factor: Any
+    point_stride: int
+
+    @property
+    def dimensions(self):
+        return len(self.particles)
+
+    @property
+    def axis_names(self):
+        return AXIS_NAMES[:self.dimensions]
+
+    @property
+    def nsources(self):
+        return len(self.particles[0])
+
+    @property
+    def ntargets(self):
+        return self.nsources if self.targets is None else len(self.targets[0])
+
+    @property
+    def nsrcntgts(self):
+        return self.nsources if self.targets is None else self.nsources + self.ntargets
+
+
+@dataclasses.dataclass
+class _RootBox:
+    lo: np.ndarray                  # coord dtype, [dimensions]
+    hi: np.ndarray
+    root_extent: Any                # coord-dtype scalar
+
+
+def _on_device(actx, a):
+    if a is None:
+        return None
+    from boxtree_amd.array_context import as_device_array
+    return as_device_array(actx, a).contiguous()
+
+
+def _equal_lengths(arrays, message):
+    if len({len(a) for a in arrays}) != 1:
+        raise ValueError(message)
+
+
+def _check_radii(name, radii, count, coord_dtype):
+    if radii is None:
+        return
+    if tuple(radii.shape) != (count,):
+        raise ValueError(f"'{name}' has an invalid shape: "
+                         f"{tuple(radii.shape)} (expected ({count},))")
+    if np_dtype_of(radii) != coord_dtype:
+        raise TypeError(
+            f"dtypes of coordinate array 'particles' and '{name}' "
+            f"must agree: got {coord_dtype} and {np_dtype_of(radii)}")
+
+
+def _normalise_inputs(actx, kind, particles, targets, source_radii, target_radii,
+                      extent_norm, stick_out_factor, point_stride) -> _Inputs:
+    if kind not in ("adaptive", "adaptive-level-restricted", "non-adaptive"):
+        raise ValueError(f"unknown tree kind: '{kind}'")
+    if extent_norm is None:
+        extent_norm = "linf"
+    if extent_norm not in ("linf", "l2"):
+        raise ValueError(f"unexpected value of 'extent_norm': {extent_norm}")
+    have_extent = source_radii is not None or target_radii is not None
+    if have_extent and targets is None:
+        raise ValueError("must specify targets when specifying any kind of radii")
+
+    if point_stride > 1:
+        # the coordinate arrays are views into one interleaved buffer (x0 y0 z0 x1 ...),
+        # as the exchange of a sharded build delivers them; the key kernel reads them in
+        # place (bt_tree_params.source_stride)
+        particles = list(particles)
+        assert all(p.stride(0) == point_stride for p in particles)
+        assert source_radii is None and targets is None
+    else:
+        particles = [_on_device(actx, p) for p in particles]
+    dtypes = {np_dtype_of(p) for p in particles}
+    if len(dtypes) != 1:
+        raise ValueError("coordinate arrays must share one dtype")
+    coord_dtype, = dtypes
+    if coord_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise TypeError(f"unsupported coordinate dtype {coord_dtype}")
+    _equal_lengths(particles, "coordinate arrays must have equal length")
+
+    if targets is not None:
+        targets = [_on_device(actx, t) for t in targets]
+        _equal_lengths(targets, "target coordinate arrays must have equal length")
+    inp = _Inputs(particles=particles, targets=targets,
+                  source_radii=_on_device(actx, source_radii),
+                  target_radii=_on_device(actx, target_radii), coord_dtype=coord_dtype,
+                  extent_norm=extent_norm if have_extent else None,
+                  stick_out_factor=stick_out_factor, point_stride=point_stride)
+    _check_radii("source_radii", inp.source_radii, inp.nsources, coord_dtype)
+    _check_radii("target_radii", inp.target_radii, inp.ntargets, coord_dtype)
+    if have_extent:
+        if stick_out_factor is None:
+            raise ValueError("if sources or targets have extent, "
+                             "'stick_out_factor' must be explicitly specified")
+    else:
+        inp.stick_out_factor = 0
+    if targets is not None:
+        target_dtypes = {np_dtype_of(t) for t in targets}
+        if target_dtypes != {coord_dtype}:
+            raise TypeError(
+                "sources and targets coordinates must have same dtype: "
+                f"got {coord_dtype} and {target_dtypes}")
+    return inp
+
+
+def _refine_weight_spec(actx, inp, max_particles_in_box, refine_weights, max_leaf_refine_weight):
+    """``(weights on the device or None for unit weights, leaf capacity)``."""
+    by_count = max_particles_in_box is not None
+    by_weight = refine_weights is not None and max_leaf_refine_weight is not None
+    if by_count and by_weight:
+        raise ValueError("may only specify one of 'max_particles_in_box' and "
+                         "'refine_weights'/'max_leaf_refine_weight")
+    if not by_count and not by_weight:
+        raise ValueError("must specify either 'max_particles_in_box' or "
+                         "'refine_weights'/'max_leaf_refine_weight'")
+    if by_count:
+        weights, capacity = None, max_particles_in_box     # unit weights stay implicit
+    else:
+        weights, capacity = _on_device(actx, refine_weights), max_leaf_refine_weight
+        if np_dtype_of(weights) != np.int32:
+            raise TypeError("'refine_weights' must have dtype 'int32' "
+                            f"(got {np_dtype_of(weights)})")
+        if tuple(weights.shape) != (inp.nsrcntgts,):
+            raise ValueError("'refine_weights' has an invalid shape")
+    if capacity <= 0:
+        raise ValueError(f"'max_leaf_refine_weight' must be positive: {capacity}")
+    heaviest = int(weights.max()) if weights is not None and inp.nsrcntgts else 1
+    if capacity < heaviest:
+        raise ValueError(
+            "entries of 'refine_weights' cannot exceed 'max_leaf_refine_weight'")
+    if weights is not None and inp.nsrcntgts and int(weights.min()) < 0:
+        raise ValueError("all entries of 'refine_weights' must be nonnegative")
+    return weights, capacity
+
+
+def _root_box(actx, bbox_finder, inp, user_bbox, agreed_root_box, stretch) -> _RootBox:
+    dims, dt = inp.dimensions, inp.coord_dtype
+    if agreed_root_box is not None:
+        # (lo, hi, root_extent) agreed on by all ranks of a sharded build
+        # (boxtree_amd/distributed/__init__.py): the result of the arithmetic below on the
+        # GLOBAL bounding box, used verbatim
+        return _RootBox(np.array(agreed_root_box[0], dtype=dt),
+                        np.array(agreed_root_box[1], dtype=dt), dt.type(agreed_root_box[2]))
+
+    # bounding box of the particles (x -+ r), sources and targets together
+    found, _ = bbox_finder(actx, inp.particles, inp.source_radii)
+    lo = np.array([found[f"min_{ax}"] for ax in inp.axis_names], dtype=dt)
+    hi = np.array([found[f"max_{ax}"] for ax in inp.axis_names], dtype=dt)
+    if inp.targets is not None:
+        found_t, _ = bbox_finder(actx, inp.targets, inp.target_radii)
+        lo = np.minimum(lo, np.array([found_t[f"min_{ax}"] for ax in inp.axis_names], dtype=dt))
+        hi = np.maximum(hi, np.array([found_t[f"max_{ax}"] for ax in inp.axis_names], dtype=dt))
+
+    if user_bbox is None:
+        # square, and slightly larger at the top so that scaled coordinates stay < 1
+        # (tree_build.py:462-476): the widest axis, stretched, in the coordinate type;
+        # the upper corner is the lower one plus that extent
+        root_extent = (hi - lo).max() * (1 + stretch)
+        return _RootBox(lo, lo + root_extent, root_extent)
+
+    # a bounding box given by the caller: dims x 2 array (or the reference's structured
+    # scalar); it must be square and cover the particles (tree_build.py:477-508)
+    if not isinstance(user_bbox, np.ndarray):
+        raise NotImplementedError(f"unsupported bounding box type: {type(user_bbox)}")
+    if user_bbox.dtype.names is None and user_bbox.ndim >= 1 and len(user_bbox) == dims:
+        ulo = np.array([user_bbox[i][0] for i in range(dims)], dtype=dt)
+        uhi = np.array([user_bbox[i][1] for i in range(dims)], dtype=dt)
+    else:
+        assert user_bbox.size == 1
+        rec = user_bbox.reshape(())
+        ulo = np.array([rec[f"min_{ax}"] for ax in inp.axis_names], dtype=dt)
+        uhi = np.array([rec[f"max_{ax}"] for ax in inp.axis_names], dtype=dt)
+    assert np.all(ulo < uhi) and np.all(ulo <= lo) and np.all(uhi >= hi)
+    extents = uhi - ulo
+    assert np.all(np.abs(extents - extents[0]) < 1e-15)
+    return _RootBox(ulo, uhi, extents[0])
+
+# }}}
 
 
 class TreeBuilder:
@@ -68,212 +271,29 @@ class TreeBuilder:
                  "array context 'actx' is used throughout.",
                  DeprecationWarning, stacklevel=2)
 
-        # {{{ input processing (tree_build.py:223-295)
-
-        if kind not in ["adaptive", "adaptive-level-restricted", "non-adaptive"]:
-            raise ValueError(f"unknown tree kind: '{kind}'")
-
-        dimensions = len(particles)
-        axis_names = AXIS_NAMES[:dimensions]
-
-        sources_are_targets = targets is None
-        sources_have_extent = source_radii is not None
-        targets_have_extent = target_radii is not None
-
-        if extent_norm is None:
-            extent_norm = "linf"
-        if extent_norm not in ["linf", "l2"]:
-            raise ValueError(f"unexpected value of 'extent_norm': {extent_norm}")
-
-        srcntgts_extent_norm = extent_norm
-        srcntgts_have_extent = sources_have_extent or targets_have_extent
-        if not srcntgts_have_extent:
-            srcntgts_extent_norm = None
-        del extent_norm
-
-        if srcntgts_extent_norm and targets is None:
-            raise ValueError("must specify targets when specifying any kind of radii")
-
-        def dev(a):
-            if a is None:
-                return None
-            from boxtree_amd.array_context import as_device_array
-            return as_device_array(actx, a).contiguous()
-
-        # ``_point_stride``: the coordinate arrays are views into one interleaved
-        # buffer (x0 y0 z0 x1 ...), as the exchange of a sharded build delivers them;
-        # the key kernel reads them in place (bt_tree_params.source_stride)
+        # host side of the call: argument contract, weights, root box (helpers below)
         point_stride = int(kwargs.get("_point_stride") or 0)
-        if point_stride > 1:
-            particles = list(particles)
-            assert all(p.stride(0) == point_stride for p in particles)
-            assert source_radii is None and targets is None
-        else:
-            particles = [dev(p) for p in particles]
-        coord_dtypes = {np_dtype_of(p) for p in particles}
-        if len(coord_dtypes) != 1:
-            raise ValueError("coordinate arrays must share one dtype")
-        coord_dtype, = coord_dtypes
-        if coord_dtype not in (np.dtype(np.float32), np.dtype(np.float64)):
-            raise TypeError(f"unsupported coordinate dtype {coord_dtype}")
+        inp = _normalise_inputs(actx, kind, particles, targets, source_radii, target_radii,
+                                extent_norm, stick_out_factor, point_stride)
+        refine_weights, max_leaf_refine_weight = _refine_weight_spec(
+            actx, inp, max_particles_in_box, refine_weights, max_leaf_refine_weight)
+        box = _root_box(actx, self.bbox_finder, inp, bbox, kwargs.get("_root_box"),
+                        TreeBuilder.ROOT_EXTENT_STRETCH_FACTOR)
+
+        # names used by the rest of the call
+        particles, targets = inp.particles, inp.targets
+        source_radii, target_radii = inp.source_radii, inp.target_radii
+        dimensions, axis_names, coord_dtype = inp.dimensions, inp.axis_names, inp.coord_dtype
+        nsources, ntargets, nsrcntgts = inp.nsources, inp.ntargets, inp.nsrcntgts
+        sources_are_targets = inp.targets is None
+        sources_have_extent = inp.source_radii is not None
+        targets_have_extent = inp.target_radii is not None
+        srcntgts_have_extent = sources_have_extent or targets_have_extent
+        srcntgts_extent_norm = inp.extent_norm
+        stick_out_factor = inp.stick_out_factor
         particle_id_dtype = np.dtype(np.int32)
         box_id_dtype = np.dtype(np.int32)
-
-        if len({len(p) for p in particles}) != 1:
-            raise ValueError("coordinate arrays must have equal length")
-        nsources = len(particles[0])
-        if targets is None:
-            nsrcntgts = nsources
-            ntargets = nsources
-        else:
-            targets = [dev(t) for t in targets]
-            if len({len(t) for t in targets}) != 1:
-                raise ValueError("target coordinate arrays must have equal length")
-            ntargets = len(targets[0])
-            nsrcntgts = nsources + ntargets
-
-        source_radii = dev(source_radii)
-        target_radii = dev(target_radii)
-        if source_radii is not None:
-            if tuple(source_radii.shape) != (nsources,):
-                raise ValueError("'source_radii' has an invalid shape: "
-                                 f"{tuple(source_radii.shape)} (expected ({nsources},))")
-            if np_dtype_of(source_radii) != coord_dtype:
-                raise TypeError(
-                    "dtypes of coordinate array 'particles' and 'source_radii' "
-                    f"must agree: got {coord_dtype} and {np_dtype_of(source_radii)}")
-        if target_radii is not None:
-            if tuple(target_radii.shape) != (ntargets,):
-                raise ValueError("'target_radii' has an invalid shape: "
-                                 f"{tuple(target_radii.shape)} (expected ({ntargets},))")
-            if np_dtype_of(target_radii) != coord_dtype:
-                raise TypeError(
-                    "dtypes of coordinate array 'particles' and 'target_radii' "
-                    f"must agree: got {coord_dtype} and {np_dtype_of(target_radii)}")
-
-        if sources_have_extent or targets_have_extent:
-            if stick_out_factor is None:
-                raise ValueError("if sources or targets have extent, "
-                                 "'stick_out_factor' must be explicitly specified")
-        else:
-            stick_out_factor = 0
-
-        if targets is not None:
-            target_coord_dtypes = {np_dtype_of(t) for t in targets}
-            if target_coord_dtypes != {coord_dtype}:
-                raise TypeError(
-                    "sources and targets coordinates must have same dtype: "
-                    f"got {coord_dtype} and {target_coord_dtypes}")
-
-        # }}}
-
-        # {{{ refine weights (tree_build.py:405-454)
-
-        specified_max_particles_in_box = max_particles_in_box is not None
-        specified_refine_weights = (
-            refine_weights is not None and max_leaf_refine_weight is not None)
-
-        if specified_max_particles_in_box and specified_refine_weights:
-            raise ValueError("may only specify one of 'max_particles_in_box' and "
-                             "'refine_weights'/'max_leaf_refine_weight")
-        elif not specified_max_particles_in_box and not specified_refine_weights:
-            raise ValueError("must specify either 'max_particles_in_box' or "
-                             "'refine_weights'/'max_leaf_refine_weight'")
-        elif specified_max_particles_in_box:
-            refine_weights = None          # unit weights are implicit on the device
-            max_leaf_refine_weight = max_particles_in_box
-        else:
-            refine_weights = dev(refine_weights)
-            if np_dtype_of(refine_weights) != np.int32:
-                raise TypeError("'refine_weights' must have dtype 'int32' "
-                                f"(got {np_dtype_of(refine_weights)})")
-            if tuple(refine_weights.shape) != (nsrcntgts,):
-                raise ValueError("'refine_weights' has an invalid shape")
-
-        if max_leaf_refine_weight <= 0:
-            raise ValueError(
-                f"'max_leaf_refine_weight' must be positive: {max_leaf_refine_weight}")
-        if refine_weights is not None and nsrcntgts:
-            if max_leaf_refine_weight < int(refine_weights.max()):
-                raise ValueError(
-                    "entries of 'refine_weights' cannot exceed 'max_leaf_refine_weight'")
-            if int(refine_weights.min()) < 0:
-                raise ValueError("all entries of 'refine_weights' must be nonnegative")
-        elif max_leaf_refine_weight < 1:
-            raise ValueError(
-                "entries of 'refine_weights' cannot exceed 'max_leaf_refine_weight'")
-
-        # }}}
-
-        # {{{ find and process bounding box (tree_build.py:456-510)
-
-        root_box = kwargs.get("_root_box")
-        if root_box is None:
-            bbox_auto, _ = self.bbox_finder(actx, particles, source_radii)
-            if targets is not None:
-                bbox_t, _ = self.bbox_finder(actx, targets, target_radii)
-                for ax in axis_names:
-                    bbox_auto[f"min_{ax}"] = min(bbox_auto[f"min_{ax}"], bbox_t[f"min_{ax}"])
-                    bbox_auto[f"max_{ax}"] = max(bbox_auto[f"max_{ax}"], bbox_t[f"max_{ax}"])
-
-        if root_box is not None:
-            # (bbox_min, bbox_max, root_extent) agreed on by all ranks of a sharded
-            # build (boxtree_amd/distributed/__init__.py): already the result of the host
-            # arithmetic below on the GLOBAL bounding box (an all-reduce of the
-            # ranks' boxes, so it covers these particles), used verbatim
-            from boxtree_amd.bounding_box import make_bounding_box_dtype
-            bbox_min = np.array(root_box[0], dtype=coord_dtype)
-            bbox_max = np.array(root_box[1], dtype=coord_dtype)
-            root_extent = coord_dtype.type(root_box[2])
-            bbox = np.empty((), make_bounding_box_dtype(dimensions, coord_dtype))
-            for i, ax in enumerate(axis_names):
-                bbox[f"min_{ax}"] = bbox_min[i]
-                bbox[f"max_{ax}"] = bbox_max[i]
-        elif bbox is None:
-            bbox = bbox_auto.copy()
-            root_extent = max(
-                bbox[f"max_{ax}"] - bbox[f"min_{ax}"]
-                for ax in axis_names) * (1 + TreeBuilder.ROOT_EXTENT_STRETCH_FACTOR)
-
-            # make bbox square and slightly larger at the top, to ensure scaled
-            # coordinates are always < 1
-            bbox_min = np.empty(dimensions, coord_dtype)
-            for i, ax in enumerate(axis_names):
-                bbox_min[i] = bbox[f"min_{ax}"]
-
-            bbox_max = bbox_min + root_extent
-            for i, ax in enumerate(axis_names):
-                bbox[f"max_{ax}"] = bbox_max[i]
-        else:
-            if isinstance(bbox, np.ndarray):
-                if len(bbox) == dimensions:
-                    bbox_bak = bbox.copy()
-                    bbox = np.empty((), bbox_auto.dtype)
-                    for i, ax in enumerate(axis_names):
-                        bbox[f"min_{ax}"] = bbox_bak[i][0]
-                        bbox[f"max_{ax}"] = bbox_bak[i][1]
-                else:
-                    assert bbox.size == 1
-                    bbox = bbox.reshape(())
-            else:
-                raise NotImplementedError(
-                    f"unsupported bounding box type: {type(bbox)}")
-
-            bbox_min = np.empty(dimensions, coord_dtype)
-            bbox_max = np.empty(dimensions, coord_dtype)
-            for i, ax in enumerate(axis_names):
-                bbox_min[i] = bbox[f"min_{ax}"]
-                bbox_max[i] = bbox[f"max_{ax}"]
-                assert bbox_min[i] < bbox_max[i]
-                assert bbox_min[i] <= bbox_auto[f"min_{ax}"]
-                assert bbox_max[i] >= bbox_auto[f"max_{ax}"]
-
-            bbox_exts = bbox_max - bbox_min
-            for ext in bbox_exts:
-                assert abs(ext - bbox_exts[0]) < 1e-15
-            root_extent = bbox_exts[0]
-
-        # }}}
+        bbox_min, bbox_max, root_extent = box.lo, box.hi, box.root_extent
 
         # {{{ device build
 
@@ -298,8 +318,8 @@ class TreeBuilder:
         tp.skip_prune = int(bool(kwargs.get("skip_prune")))
         tp.stick_out_factor = float(coord_dtype.type(stick_out_factor))
         for i, ax in enumerate(axis_names):
-            tp.bbox_min[i] = float(bbox[f"min_{ax}"])
-            tp.bbox_max[i] = float(bbox[f"max_{ax}"])
+            tp.bbox_min[i] = float(bbox_min[i])
+            tp.bbox_max[i] = float(bbox_max[i])
         tp.root_extent = float(coord_dtype.type(root_extent))
         top_tree = kwargs.get("_top_tree")
         if top_tree is not None:
