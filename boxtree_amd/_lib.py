@@ -157,6 +157,19 @@ class AqTree(ct.Structure):
     ]
 
 
+class MgpuParams(ct.Structure):
+    _fields_ = [("dims", ct.c_int32), ("coord_kind", ct.c_int32), ("n", ct.c_int64),
+                ("coords", P3), ("top_level", ct.c_int32),
+                ("max_particles_in_box", ct.c_int64)]
+
+
+class MgpuShard(ct.Structure):
+    _fields_ = [("n_owned", ct.c_int64), ("points", vp),
+                ("bbox_min", ct.c_double * 3), ("bbox_max", ct.c_double * 3),
+                ("root_extent", ct.c_double), ("top_level", ct.c_int32),
+                ("top_cell_prefix", vp), ("bytes_sent", ct.c_int64), ("rounds", ct.c_int32)]
+
+
 class Span(ct.Structure):
     _fields_ = [("offset", ct.c_int64), ("count", ct.c_int64)]
 
@@ -199,7 +212,7 @@ EXPORTED_SYMBOLS = [
     "bt_fmm_box_particle_sums", "bt_fmm_csr_sum", "bt_fmm_box_to_particles", "bt_fmm_tree_sweep",
     "bt_translation_classes",
     "bt_filter_targets_user_order", "bt_filter_targets_tree_order", "bt_link_point_sources",
-    "bt_box_morton_paths", "bt_let_build",
+    "bt_box_morton_paths", "bt_let_build", "bt_mgpu_exchange", "bt_mgpu_plan",
     "bt_dfs_order", "bt_partition_work", "bt_ancestor_mask", "bt_mark_list_boxes",
     "bt_local_particles", "bt_modify_target_flags", "bt_box_to_user_ranks",
     "bt_boxes_used_by_ranks",
@@ -249,6 +262,9 @@ def load():
     lib.bt_get_stage_times.argtypes = [vp, ct.POINTER(StageTimes)]
     lib.bt_traversal_build.argtypes = [vp, ct.POINTER(TravParams), ct.POINTER(TravSizes)]
     lib.bt_traversal_export.argtypes = [vp, ct.POINTER(TravArrays)]
+    lib.bt_mgpu_exchange.argtypes = [vp, vp, ct.c_int, ct.c_int, ct.POINTER(MgpuParams),
+                                     ct.POINTER(MgpuShard)]
+    lib.bt_mgpu_plan.argtypes = [ct.c_int, ct.c_int, ct.c_int64, ct.c_int, vp, vp, vp]
     lib.bt_traversal_build_packed.argtypes = [vp, ct.POINTER(TravParams), ALLOC_FN, vp,
                                               ct.POINTER(TravPacked)]
     lib.bt_merge_csr_lists.argtypes = [vp, ct.c_int, ct.POINTER(vp), ct.POINTER(vp),

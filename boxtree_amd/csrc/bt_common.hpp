@@ -111,6 +111,7 @@ private:
 struct TreeState;   // bt_tree.hip
 struct TravState;   // bt_trav.hip
 struct AqState;     // bt_area_query.hip
+struct MgpuState;   // bt_mgpu.hip
 
 struct bt_context {
     int device = 0;
@@ -123,6 +124,7 @@ struct bt_context {
     TreeState *tree = nullptr;
     TravState *trav = nullptr;
     AqState *aq = nullptr;
+    MgpuState *mgpu = nullptr;
     // timing of the last bt_radix_sort call (HIP events on ctx->stream)
     float last_sort_pass_ms = 0.f;
     int last_sort_passes = 0;

@@ -161,6 +161,7 @@ int check_status(bt_context *ctx)
 void bt_free_tree_state(bt_context *ctx);   // bt_tree.hip
 void bt_free_trav_state(bt_context *ctx);   // bt_trav.hip
 void bt_free_aq_state(bt_context *ctx);     // bt_area_query.hip
+void bt_free_mgpu_state(bt_context *ctx);   // bt_mgpu.hip
 
 extern "C" {
 
@@ -210,6 +211,7 @@ void bt_destroy(bt_context *ctx)
     bt_free_tree_state(ctx);
     bt_free_trav_state(ctx);
     bt_free_aq_state(ctx);
+    bt_free_mgpu_state(ctx);
     ctx->pool.release_all();
     if (ctx->d_status) (void) hipFree(ctx->d_status);
     for (void *&e : ctx->sort_ev)
@@ -228,6 +230,7 @@ int bt_trim(bt_context *ctx)
     bt_free_tree_state(ctx);
     bt_free_trav_state(ctx);
     bt_free_aq_state(ctx);
+    bt_free_mgpu_state(ctx);
     ctx->pool.release_all();
     return BT_OK;
 }

@@ -475,6 +475,44 @@ int bt_gather_pack(bt_context *ctx, int dims, int elem_size, const void *const *
 int bt_unpack(bt_context *ctx, int dims, int elem_size, const void *in, int64_t n,
               void *const *out);
 
+/* ---- multi-GPU entry: the particle exchange of a sharded build over an RCCL
+ *      communicator owned by the caller (one process per GPU) ---- */
+
+typedef struct {
+    int32_t dims, coord_kind;
+    int64_t n;                         /* particles of this rank's chunk              */
+    const void *coords[BT_MAX_DIMS];   /* device, [n] each (sources == targets, points) */
+    int32_t top_level;                 /* level of the ownership cells; 0: default (5 in 3D) */
+    int64_t max_particles_in_box;      /* > 0: derive the top of the global tree, keep its  */
+                                       /* leaves on one rank (kind "adaptive", unit weights) */
+} bt_mgpu_params;
+
+typedef struct {
+    int64_t n_owned;                   /* particles this rank owns after the exchange  */
+    void *points;                      /* device, interleaved [n_owned][dims]; owned by the */
+                                       /* context until the next exchange / bt_destroy  */
+    double bbox_min[BT_MAX_DIMS], bbox_max[BT_MAX_DIMS], root_extent;   /* global root box */
+    int32_t top_level;
+    const int64_t *top_cell_prefix;    /* device [2^(dims*top_level) + 1] or NULL        */
+    int64_t bytes_sent;                /* payload bytes that left this GPU              */
+    int32_t rounds;                    /* point-to-point rounds of the all-to-all       */
+} bt_mgpu_shard;
+
+/* rccl_comm: an ncclComm_t of nranks ranks with this process at `rank`, created on the
+ * context's device.  Collectives are enqueued on the context's stream; the call
+ * returns when the shard is complete.  Feed the shard to bt_tree_build with
+ * sources[ax] = (char *) points + ax * sizeof(coord), source_stride = dims, the root
+ * box, top_level and top_cell_prefix. */
+int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
+                     const bt_mgpu_params *params, bt_mgpu_shard *out);
+
+/* The host part of the exchange, a pure function of the all-reduced level-top_level
+ * cell histogram: owner rank of every cell (contiguous Morton ranges balanced by
+ * particle count, leaves of the global top tree kept whole) and the exclusive prefix
+ * sums of the histogram [ncells + 1] (may be NULL). */
+int bt_mgpu_plan(int dims, int top_level, int64_t max_particles_in_box, int nranks,
+                 const int64_t *global_hist, int32_t *owner_of_cell, int64_t *cell_prefix);
+
 /* Morton path (x most significant in every digit, level*dims bits) of every box,
  * from its centre and level. */
 int bt_box_morton_paths(bt_context *ctx, int dims, int coord_kind, int64_t nboxes,

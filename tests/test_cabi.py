@@ -53,7 +53,8 @@ def test_struct_layouts_match_the_header(tmp_path):
         "bt_tree_sizes": _lib.TreeSizes, "bt_tree_arrays": _lib.TreeArrays,
         "bt_stage_times": _lib.StageTimes, "bt_trav_params": _lib.TravParams,
         "bt_trav_sizes": _lib.TravSizes, "bt_trav_arrays": _lib.TravArrays,
-        "bt_aq_tree": _lib.AqTree,
+        "bt_aq_tree": _lib.AqTree, "bt_trav_packed": _lib.TravPacked,
+        "bt_mgpu_params": _lib.MgpuParams, "bt_mgpu_shard": _lib.MgpuShard,
     }
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "boxtree_hip.h"',
              'int main(void) {']
@@ -76,3 +77,39 @@ def test_struct_layouts_match_the_header(tmp_path):
             assert ct.sizeof(cls) == int(value), (cname, ct.sizeof(cls), value)
         else:
             assert getattr(cls, field).offset == int(value), (cname, field)
+
+
+def test_mgpu_plan_matches_the_python_plan():
+    """bt_mgpu_plan (host part of bt_mgpu_exchange: owners of the level-k cells, leaves of
+    the global top tree kept whole) against the numpy statement used by the
+    torch.distributed path (boxtree_amd/distributed: top_tree_plan + partition_cells).
+    Pure host code: runs without a GPU."""
+    import ctypes as ct
+
+    import numpy as np
+
+    from boxtree_amd.distributed import partition_cells, top_tree_plan
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    for dims, k in ((3, 3), (3, 4), (2, 5), (1, 7)):
+        ncells = 1 << (dims * k)
+        for trial in range(4):
+            # clustered counts: a few heavy cells, many empty ones
+            hist = (rng.random(ncells) < 0.3) * rng.integers(0, 200, ncells)
+            hist[rng.integers(0, ncells, 3)] += rng.integers(1000, 100000, 3)
+            hist = hist.astype(np.int64)
+            for world in (1, 2, 5, 8):
+                for mpb in (0, 30, 5000):
+                    owner = np.empty(ncells, np.int32)
+                    prefix = np.empty(ncells + 1, np.int64)
+                    code = lib.bt_mgpu_plan(dims, k, mpb, world, hist.ctypes.data_as(ct.c_void_p),
+                                            owner.ctypes.data_as(ct.c_void_p),
+                                            prefix.ctypes.data_as(ct.c_void_p))
+                    assert code == 0
+                    if mpb > 0:
+                        plan = top_tree_plan(hist, dims, k, mpb)
+                        want = partition_cells(hist, world, plan["unit_start"])
+                        assert np.array_equal(prefix, plan["cell_prefix"])
+                    else:
+                        want = partition_cells(hist, world, None)
+                    assert np.array_equal(owner, want), (dims, k, world, mpb)

@@ -1,0 +1,98 @@
+"""bt_mgpu_exchange (the C-ABI entry of the sharded build) with a one-rank RCCL
+communicator on the one GPU a test box has: root box, ownership cells, the packed
+receive buffer and the top-tree prefix must reproduce what the torch.distributed
+path computes, and the shard must build the same tree as the plain single-GPU call.
+(More ranks need more GPUs; the host part -- who owns which cell -- is compared with
+the Python plan for 1..8 ranks in tests/test_cabi.py.)"""
+
+import ctypes as ct
+import os
+
+import numpy as np
+import pytest
+
+from compare import assert_same_tree
+
+pytestmark = pytest.mark.gpu
+
+
+def one_rank_comm():
+    import torch
+    rccl = ct.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+    class UniqueId(ct.Structure):
+        _fields_ = [("internal", ct.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(ct.byref(uid)) == 0
+    comm = ct.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ct.POINTER(ct.c_void_p), ct.c_int, UniqueId, ct.c_int]
+    assert rccl.ncclCommInitRank(ct.byref(comm), 1, uid, 0) == 0
+    return rccl, comm
+
+
+@pytest.mark.parametrize("dims,dtype", [(3, np.float64), (2, np.float64), (3, np.float32)])
+def test_exchange_one_rank(dims, dtype):
+    import torch
+    from boxtree_amd import HIPArrayContext, TreeBuilder, _lib
+    from boxtree_amd.distributed import morton_cells, top_tree_plan
+    actx = HIPArrayContext(0)
+    torch.cuda.set_device(0)
+    rccl, comm = one_rank_comm()
+    try:
+        n, mpb = 200000, 30
+        rng = np.random.default_rng(dims)
+        pts = [torch.from_numpy(rng.standard_normal(n).astype(dtype)).cuda() for _ in range(dims)]
+        par = _lib.MgpuParams()
+        par.dims = dims
+        par.coord_kind = _lib.BT_F64 if dtype == np.float64 else _lib.BT_F32
+        par.n = n
+        for ax in range(dims):
+            par.coords[ax] = pts[ax].data_ptr()
+        par.top_level = 0
+        par.max_particles_in_box = mpb
+        shard = _lib.MgpuShard()
+        torch.cuda.synchronize()
+        _lib.check(actx.lib.bt_mgpu_exchange(actx.handle, comm, 0, 1, ct.byref(par), ct.byref(shard)))
+        assert shard.n_owned == n and shard.bytes_sent == 0 and shard.rounds == 1
+
+        # the receive buffer: one rank owns everything, in the original order
+        es = np.dtype(dtype).itemsize
+        recv = torch.empty(n * dims, dtype=pts[0].dtype, device="cuda")
+        hip = ct.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(ct.c_void_p(recv.data_ptr()), ct.c_void_p(shard.points),
+                             ct.c_size_t(n * dims * es), 3) == 0
+        for ax in range(dims):
+            assert torch.equal(recv.view(n, dims)[:, ax], pts[ax])
+
+        # root box: tree_build.py:462-476 on the global (= local) bounding box
+        lo = np.array([float(p.min()) for p in pts], dtype=dtype)
+        hi = np.array([float(p.max()) for p in pts], dtype=dtype)
+        root_extent = (hi - lo).max() * (1 + 1e-4)
+        assert np.array_equal(np.array(shard.bbox_min[:dims], dtype=dtype), lo)
+        assert np.array_equal(np.array(shard.bbox_max[:dims], dtype=dtype), lo + root_extent)
+        assert dtype(shard.root_extent) == root_extent
+
+        # ownership cells and their prefix sums
+        k = shard.top_level
+        assert k == (5 if dims == 3 else 7)
+        cells = morton_cells(pts, lo, lo + root_extent, k)
+        hist = torch.bincount(cells, minlength=1 << (dims * k)).cpu().numpy()
+        plan = top_tree_plan(hist, dims, k, mpb)
+        prefix = torch.empty((1 << (dims * k)) + 1, dtype=torch.int64, device="cuda")
+        assert hip.hipMemcpy(ct.c_void_p(prefix.data_ptr()), ct.c_void_p(shard.top_cell_prefix),
+                             ct.c_size_t(prefix.numel() * 8), 3) == 0
+        assert np.array_equal(prefix.cpu().numpy(), plan["cell_prefix"])
+
+        # the shard builds the tree of the plain call
+        views = [recv.view(n, dims)[:, ax] for ax in range(dims)]
+        kw = dict(_root_box=(lo, lo + root_extent, root_extent), _top_tree=(k, prefix))
+        if dims > 1:
+            kw["_point_stride"] = dims
+        else:
+            views = [v.contiguous() for v in views]
+        t_shard, _ = TreeBuilder(actx)(actx, views, max_particles_in_box=mpb, **kw)
+        t_plain, _ = TreeBuilder(actx)(actx, pts, max_particles_in_box=mpb)
+        assert_same_tree(actx.to_numpy(t_shard), actx.to_numpy(t_plain))
+    finally:
+        rccl.ncclCommDestroy(comm)
