@@ -99,6 +99,23 @@ class HIPArrayContext:
     def empty(self, shape, dtype):
         return self.torch.empty(shape, dtype=_torch_dtype(self.torch, dtype), device=self.device)
 
+    def empty_block(self, specs):
+        """Uninitialised arrays ``[(shape, dtype), ...]`` carved out of ONE allocation
+        (256-byte aligned views): the outputs of a call cost one trip to the caching
+        allocator instead of one per array."""
+        torch = self.torch
+        offsets, total = [], 0
+        for shape, dtype in specs:
+            count = int(np.prod(shape)) if isinstance(shape, tuple) else int(shape)
+            offsets.append((total, count * np.dtype(dtype).itemsize))
+            total += -(-count * np.dtype(dtype).itemsize // 256) * 256
+        block = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
+        out = []
+        for (shape, dtype), (off, nbytes) in zip(specs, offsets):
+            v = block[off:off + nbytes].view(_torch_dtype(torch, dtype))
+            out.append(v.view(shape) if isinstance(shape, tuple) else v)
+        return out
+
 
 def _torch_dtype(torch, dtype):
     dtype = np.dtype(dtype)

@@ -358,19 +358,15 @@ class TreeBuilder:
         i32 = np.int32
 
         out = _lib.TreeArrays()
-        user_source_ids = e(nsources, i32)
-        sorted_target_ids = e(ntargets, i32)
-        sources = [e(nsources, coord_dtype) for _ in range(dimensions)]
-        box_source_starts = e(nboxes, i32)
-        box_source_counts_nonchild = e(nboxes, i32)
-        box_source_counts_cumul = e(nboxes, i32)
-        box_parent_ids = e(nboxes, i32)
-        box_child_ids = e((C, aligned_nboxes), i32)
-        box_centers = e((dimensions, aligned_nboxes), coord_dtype)
-        box_levels = e(nboxes, np.uint8)
-        box_flags = e(nboxes, np.uint8)
-        box_source_bounding_box_min = e((dimensions, aligned_nboxes), coord_dtype)
-        box_source_bounding_box_max = e((dimensions, aligned_nboxes), coord_dtype)
+        grid = (dimensions, aligned_nboxes)
+        (user_source_ids, sorted_target_ids, box_source_starts, box_source_counts_nonchild,
+         box_source_counts_cumul, box_parent_ids, box_child_ids, box_centers, box_levels,
+         box_flags, box_source_bounding_box_min, box_source_bounding_box_max,
+         *sources) = actx.empty_block([
+             (nsources, i32), (ntargets, i32), (nboxes, i32), (nboxes, i32), (nboxes, i32),
+             (nboxes, i32), ((C, aligned_nboxes), i32), (grid, coord_dtype), (nboxes, np.uint8),
+             (nboxes, np.uint8), (grid, coord_dtype), (grid, coord_dtype),
+             *[(nsources, coord_dtype) for _ in range(dimensions)]])
 
         out.user_source_ids = ptr(user_source_ids)
         out.sorted_target_ids = ptr(sorted_target_ids)
@@ -397,12 +393,11 @@ class TreeBuilder:
             box_target_bounding_box_max = box_source_bounding_box_max
             sorted_source_radii = sorted_target_radii = None
         else:
-            tgt_arrays = [e(ntargets, coord_dtype) for _ in range(dimensions)]
-            box_target_starts = e(nboxes, i32)
-            box_target_counts_nonchild = e(nboxes, i32)
-            box_target_counts_cumul = e(nboxes, i32)
-            box_target_bounding_box_min = e((dimensions, aligned_nboxes), coord_dtype)
-            box_target_bounding_box_max = e((dimensions, aligned_nboxes), coord_dtype)
+            (box_target_starts, box_target_counts_nonchild, box_target_counts_cumul,
+             box_target_bounding_box_min, box_target_bounding_box_max,
+             *tgt_arrays) = actx.empty_block([
+                 (nboxes, i32), (nboxes, i32), (nboxes, i32), (grid, coord_dtype),
+                 (grid, coord_dtype), *[(ntargets, coord_dtype) for _ in range(dimensions)]])
             sorted_source_radii = e(nsources, coord_dtype) if sources_have_extent else None
             sorted_target_radii = e(ntargets, coord_dtype) if targets_have_extent else None
             for i in range(dimensions):
