@@ -1802,7 +1802,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     Buf<int> bad;
     BT_CHECK(bad.alloc(ctx->pool, 4));
     BT_HIP_CHECK(hipMemsetAsync(bad.get(), 0, 4 * sizeof(int), ctx->stream));
-    if (!p.force_generic)
+    if (p.force_generic != 1)
         check_structure_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
             (int32_t) B, p.aligned_nboxes, p.box_parent_ids, p.box_child_ids, p.box_levels,
             p.box_flags, (const T *) p.box_centers, (T) p.root_extent, bad.get());
@@ -1866,7 +1866,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     // ---- which path? ---------------------------------------------------------------
     st->fast = false;
     st->lattice = false;
-    if (!p.force_generic) {
+    if (p.force_generic != 1) {
         st->fast = hb[0] == 0;
         st->has_blocks = hb[2] != 0;
         // lattice kernels: exact lattice centres, and the deepest box many ulps wide
@@ -1882,7 +1882,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
             return e && atoi(e);
         }();
         st->lattice = st->fast && hb[1] == 0 && levels_ok && p.well_sep_is_n_away == 1
-            && B < ((int64_t) 1 << 26) && nlevels <= 29 && !v2_off_env;
+            && B < ((int64_t) 1 << 26) && nlevels <= 29 && !v2_off_env && p.force_generic != 2;
     }
     a.fast = st->fast ? 1 : 0;
 

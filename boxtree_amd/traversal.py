@@ -238,7 +238,9 @@ class FMMTraversalBuilder:
         if _force_generic is None:
             import os
             _force_generic = os.environ.get("BOXTREE_HIP_FORCE_GENERIC", "0") == "1"
-        tp.force_generic = int(bool(_force_generic))
+        # True: walk-from-root kernels; "float": parent-colleague kernels with the float
+        # predicates; False: the default choice (integer-lattice form where it applies)
+        tp.force_generic = 2 if _force_generic == "float" else int(bool(_force_generic))
         # sharded traversals (boxtree_amd/distributed/__init__.py step 6): lists of a subset
         # of the target boxes of a tree whose box arrays are complete
         tbm = dev(_target_boxes_mask)

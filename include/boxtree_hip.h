@@ -218,7 +218,9 @@ typedef struct {
     const int8_t *source_parent_boxes_mask;    /* device or NULL */
     int32_t force_generic;     /* 1: always use the walk-from-root kernels (any tree);
                                   0: use the parent-colleague kernels when the box
-                                  numbering is verified level-major/depth-first      */
+                                  numbering allows (integer-lattice form when the
+                                  centres are exact lattice centres);
+                                  2: as 0, but never the integer-lattice form */
     /* Sharded traversals only (no counterpart in the reference): build the lists of
      * a subset of the target boxes of a tree whose box arrays are complete.
      * target_boxes_mask[nboxes] (device, or NULL = all) filters target_boxes and

@@ -43,8 +43,9 @@ def build_both(actx, oracle, particles, targets=None, trav_kw=None, **kw):
         call_kw["_from_sep_smaller_min_nsources_cumul"] = tkw.pop(
             "_from_sep_smaller_min_nsources_cumul")
     otrav = oracle.build_traversal(otree, **trav_kw)
-    # both device paths (parent-colleague kernels and walk-from-root kernels)
-    for force_generic in (True, False):
+    # all device paths: walk-from-root kernels, parent-colleague kernels with float
+    # predicates, and the default (the integer-lattice form where it applies)
+    for force_generic in (True, "float", False):
         trav, _ = FMMTraversalBuilder(actx, **tkw)(actx, tree, _force_generic=force_generic,
                                                    **call_kw)
         htrav = actx.to_numpy(trav)
