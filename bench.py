@@ -262,7 +262,12 @@ def main():
         info.update(nboxes=nboxes, nlevels=nlevels,
                     n_list1=int(trav.neighbor_source_boxes_lists.shape[0]),
                     n_list2=int(trav.from_sep_siblings_lists.shape[0]),
-                    n_colleagues=int(trav.same_level_non_well_sep_boxes_lists.shape[0]))
+                    n_colleagues=int(trav.same_level_non_well_sep_boxes_lists.shape[0]),
+                    n_list3=int(sum(int(b.count) for b in trav.from_sep_smaller_by_level)),
+                    n_list4=int(trav.from_sep_bigger_lists.shape[0]),
+                    n_close=(0 if trav.from_sep_close_smaller_lists is None else
+                             int(trav.from_sep_close_smaller_lists.shape[0])
+                             + int(trav.from_sep_close_bigger_lists.shape[0])))
         return st, times
 
     for _ in range(args.warmup):
@@ -317,6 +322,24 @@ def main():
                 traffic = pmc["traffic_bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
+        # what a plain device-to-device copy of the same byte count reaches on this GPU,
+        # measured here: the practical ceiling the sort pass is to be read against
+        copy_gbps = None
+        try:
+            nbytes = int(12 * n_sorted)
+            src_b = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            dst_b = torch.empty_like(src_b)
+            dst_b.copy_(src_b)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                dst_b.copy_(src_b)
+            e1.record()
+            torch.cuda.synchronize()
+            copy_gbps = 2.0 * nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+            del src_b, dst_b
+        except RuntimeError:
+            pass
         out = {
             "metric": "particles/sec tree build+traversal, 3D 10^8 pts; radix-sort HBM GB/s vs peak",
             "value": value,
@@ -350,6 +373,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "algorithmic_bytes_per_launch": 24.0 * n_sorted,
+                "device_copy_GBps_same_bytes": copy_gbps,
                 "avg_launch_ms": pass_ms,
                 "passes_per_sort": sort_ms[-1][1],
                 "launches_averaged_per_sort": sort_ms[-1][5],
@@ -360,6 +384,29 @@ def main():
                 },
             },
             "stages_ms": {k: v / args.steps for k, v in stage_acc.items()},
+        }
+        # list output rate of the traversal stages (the walks are latency /
+        # L2 bound; what they deliver is 4 bytes per list entry)
+        st_ms = out["stages_ms"]
+
+        def rate(entries, *stages):
+            ms = sum(st_ms.get(k, 0.0) for k in stages)
+            return {"entries": int(entries), "ms": ms,
+                    "output_GBps": (4.0 * entries / (ms * 1e-3) / 1e9) if ms > 0 else None}
+
+        trav_stages = [k for k in st_ms if k.startswith("trav:")]
+        out["traversal_output"] = {
+            "colleagues+list2": rate(info.get("n_colleagues", 0) + info.get("n_list2", 0),
+                                     "trav:colleague rows", "trav:colleagues+list2",
+                                     "trav:colleagues", "trav:list2"),
+            "lists 1, 3, 4 (+ close)": rate(
+                info.get("n_list1", 0) + info.get("n_list3", 0) + info.get("n_list4", 0)
+                + info.get("n_close", 0),
+                "trav:walk (rows)", "trav:lists 1+3 (final)", "trav:list1 order + list4",
+                "trav:list1+list3", "trav:list1", "trav:list3", "trav:list4"),
+            "all lists": rate(sum(info.get(k, 0) for k in (
+                "n_colleagues", "n_list1", "n_list2", "n_list3", "n_list4", "n_close")),
+                *trav_stages),
         }
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, args.mpb)
