@@ -132,6 +132,26 @@ WORKLOAD_MPB = {"c1": 30}      # max_particles_in_box of a workload (64 unless l
 # }}}
 
 
+def usable_cores():
+    """Host cores this process may actually use: the affinity mask, capped by the
+    container's CPU quota (cgroup cpu.max) -- a GPU box of the pool shows 256 cores and
+    grants 16; 256 threads on 16 cores run the OpenMP oracle ten times slower than 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(workload, n_sample, mpb, reps=3):
     """The CPU oracle ("port" of the reference's level-loop algorithm) timed on bounded
     samples of the same workload: once with one thread, once with all host cores (the
@@ -152,7 +172,7 @@ def cpu_baseline(workload, n_sample, mpb, reps=3):
             times.append(time.perf_counter() - t0)
         return nn, nthreads, times
 
-    ncores = os.cpu_count() or 1
+    ncores = usable_cores()
     try:
         # one thread: a quarter of the sample keeps three repetitions within ~20 s
         n1, _, t1 = run("seq", None, max(n_sample // 4, 1))
@@ -164,7 +184,8 @@ def cpu_baseline(workload, n_sample, mpb, reps=3):
         "value": nall / min(tall), "unit": "particles/s", "cores": nthreads, "kind": "port",
         "sample": f"{workload} recipe at {nall} particles, tree build + traversal, "
                   f"oracle/boxtree_oracle.c built with -fopenmp on {nthreads} threads "
-                  f"({ncores} host cores present), best of {reps} runs ({fmt(tall)} s)",
+                  f"(all cores this process may use: {os.cpu_count()} present, CPU quota "
+                  f"{ncores}), best of {reps} runs ({fmt(tall)} s)",
         "single_thread": {
             "value": n1 / min(t1), "unit": "particles/s", "cores": 1,
             "sample": f"{workload} recipe at {n1} particles, sequential build of the same "
