@@ -78,6 +78,7 @@ class TreeArrays(ct.Structure):
         ("box_levels", vp), ("box_flags", vp),
         ("box_source_bounding_box_min", vp), ("box_source_bounding_box_max", vp),
         ("box_target_bounding_box_min", vp), ("box_target_bounding_box_max", vp),
+        ("level_start_box_nrs", vp),
     ]
 
 
@@ -204,6 +205,7 @@ class TravPacked(ct.Structure):
 
 EXPORTED_SYMBOLS = [
     "bt_abi_version", "bt_create", "bt_destroy", "bt_trim", "bt_last_error_string",
+    "bt_set_stream", "bt_set_stream_ordered", "bt_synchronize",
     "bt_bbox", "bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32", "bt_get_sort_stats",
     "bt_tree_build", "bt_tree_export", "bt_get_stage_times",
     "bt_traversal_build", "bt_traversal_export", "bt_traversal_build_packed", "bt_merge_csr_lists",
@@ -252,6 +254,9 @@ def load():
     lib.bt_destroy.argtypes = [vp]
     lib.bt_destroy.restype = None
     lib.bt_trim.argtypes = [vp]
+    lib.bt_set_stream.argtypes = [vp, vp]
+    lib.bt_set_stream_ordered.argtypes = [vp, ct.c_int]
+    lib.bt_synchronize.argtypes = [vp]
     lib.bt_bbox.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), vp, ct.c_int64,
                             ct.POINTER(ct.c_double), ct.POINTER(ct.c_double)]
     for name in ("bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32"):
@@ -321,3 +326,15 @@ def check(code):
     if code != BT_OK:
         msg = load().bt_last_error_string().decode("utf-8", "replace")
         raise BoxtreeHipError(code, msg)
+
+
+# BT_HOST_TRACE=1: stamps of the Python layer on the clock the library's own stage marks
+# use (CLOCK_MONOTONIC, microseconds); tools/host_trace.py puts them on one timeline.
+_HOST_TRACE = os.environ.get("BT_HOST_TRACE", "0") not in ("", "0")
+
+
+def host_trace(name):
+    if _HOST_TRACE:
+        import sys
+        import time
+        sys.stderr.write(f"[py]      {name:<14s} {time.monotonic_ns() * 1e-3:.1f}\n")

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as ct
 import dataclasses
+import os
 
 import numpy as np
 
@@ -36,12 +37,22 @@ class HIPArrayContext:
         self.device_index = int(device)
         self.device = torch.device("cuda", self.device_index)
         self.lib = _lib.load()
-        self.stream = torch.cuda.Stream(self.device)
         handle = ct.c_void_p()
-        _lib.check(self.lib.bt_create(self.device_index,
-                                      ct.c_void_p(self.stream.cuda_stream),
+        cur = torch.cuda.current_stream(self.device)
+        _lib.check(self.lib.bt_create(self.device_index, ct.c_void_p(cur.cuda_stream),
                                       ct.byref(handle)))
         self.handle = handle
+        # The library runs on torch's current stream (bt_create takes NULL as "make your
+        # own", so the legacy default stream, handle 0, is set explicitly): inputs made by
+        # torch ops, the library's kernels, torch ops on the outputs and the caching
+        # allocator's reuse of freed blocks are all ordered by that one stream.
+        self._stream_handle = None
+        self.sync_in()
+        # Results are stream-ordered, like every torch op and like the reference, whose
+        # builders return (object, event): the builders return when the host knows the
+        # result's sizes, the last kernels may still be filling the arrays.
+        self.stream_ordered = os.environ.get("BOXTREE_HIP_STREAM_ORDERED", "1") != "0"
+        _lib.check(self.lib.bt_set_stream_ordered(self.handle, int(self.stream_ordered)))
 
     def __del__(self):
         try:
@@ -52,9 +63,23 @@ class HIPArrayContext:
             pass
 
     # -- stream ordering -------------------------------------------------------
+    @property
+    def stream(self):
+        """The torch stream the library's kernels are queued on."""
+        return self.torch.cuda.current_stream(self.device)
+
     def sync_in(self):
-        """Make the library stream wait for work queued on torch's current stream."""
-        self.stream.wait_stream(self.torch.cuda.current_stream(self.device))
+        """Called before every library call: point the library at torch's current stream
+        (a no-op unless the caller switched streams since the last call)."""
+        h = self.torch.cuda.current_stream(self.device).cuda_stream
+        if h != self._stream_handle:
+            _lib.check(self.lib.bt_set_stream(self.handle, ct.c_void_p(h)))
+            self._stream_handle = h
+
+    def synchronize(self):
+        """Wait for everything queued by the library; raises if a call that returned early
+        failed on the device."""
+        _lib.check(self.lib.bt_synchronize(self.handle))
 
     # -- array movement ----------------------------------------------------------
     def from_numpy(self, ary):
@@ -102,29 +127,57 @@ class HIPArrayContext:
     def empty_block(self, specs):
         """Uninitialised arrays ``[(shape, dtype), ...]`` carved out of ONE allocation
         (256-byte aligned views): the outputs of a call cost one trip to the caching
-        allocator instead of one per array."""
+        allocator instead of one per array, and the views of one element type are made by
+        a single ``split_with_sizes`` (a Python-level slice + view per array costs several
+        microseconds; a tree has 15 output arrays, a traversal 50-70)."""
         torch = self.torch
-        offsets, total = [], 0
-        for shape, dtype in specs:
-            count = int(np.prod(shape)) if isinstance(shape, tuple) else int(shape)
-            offsets.append((total, count * np.dtype(dtype).itemsize))
-            total += -(-count * np.dtype(dtype).itemsize // 256) * 256
+        # (index, shape, element count padded to 256 bytes) per element type
+        groups = {}
+        for i, (shape, dtype) in enumerate(specs):
+            if isinstance(shape, tuple):
+                count = 1
+                for extent in shape:
+                    count *= int(extent)
+            else:
+                count = int(shape)
+            tdtype, itemsize = _DTYPES[np.dtype(dtype)]
+            per256 = 256 // itemsize
+            groups.setdefault((tdtype, itemsize), []).append(
+                (i, shape, count, -(-count // per256) * per256 - count))
+        total = sum((c + pad) * key[1] for key, items in groups.items() for _, _, c, pad in items)
         block = torch.empty(max(total, 256), dtype=torch.uint8, device=self.device)
-        out = []
-        for (shape, dtype), (off, nbytes) in zip(specs, offsets):
-            v = block[off:off + nbytes].view(_torch_dtype(torch, dtype))
-            out.append(v.view(shape) if isinstance(shape, tuple) else v)
+        out = [None] * len(specs)
+        off = 0
+        for (tdtype, itemsize), items in groups.items():
+            nbytes = sum(c + pad for _, _, c, pad in items) * itemsize
+            typed = block[off:off + nbytes].view(tdtype)
+            off += nbytes
+            sizes = []
+            for _, _, c, pad in items:
+                sizes.append(c)
+                sizes.append(pad)
+            parts = typed.split_with_sizes(sizes)
+            for k, (i, shape, _, _) in enumerate(items):
+                v = parts[2 * k]
+                out[i] = v.view(shape) if isinstance(shape, tuple) else v
         return out
 
 
-def _torch_dtype(torch, dtype):
-    dtype = np.dtype(dtype)
+def _dtype_table():
+    import torch
     return {
-        np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
-        np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64,
-        np.dtype(np.uint8): torch.uint8, np.dtype(np.int8): torch.int8,
-        np.dtype(np.uint32): torch.int32, np.dtype(np.uint64): torch.int64,
-    }[dtype]
+        np.dtype(np.float32): (torch.float32, 4), np.dtype(np.float64): (torch.float64, 8),
+        np.dtype(np.int32): (torch.int32, 4), np.dtype(np.int64): (torch.int64, 8),
+        np.dtype(np.uint8): (torch.uint8, 1), np.dtype(np.int8): (torch.int8, 1),
+        np.dtype(np.uint32): (torch.int32, 4), np.dtype(np.uint64): (torch.int64, 8),
+    }
+
+
+_DTYPES = _dtype_table()      # numpy dtype -> (torch dtype, item size)
+
+
+def _torch_dtype(torch, dtype):
+    return _DTYPES[np.dtype(dtype)][0]
 
 
 def as_device_array(actx, a):

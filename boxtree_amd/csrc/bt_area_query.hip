@@ -412,7 +412,7 @@ int peer_lists_impl(bt_context *ctx, const bt_aq_tree *p, int64_t *n_entries)
     BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, RowCount{counts.get()}, nboxes,
                                                       st->starts.get(), d_total.get(), true)));
     int64_t total = 0;
-    BT_HIP_CHECK(hipMemcpyAsync(&total, d_total.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
+    BT_CHECK(bt::d2h(ctx, &total, d_total.get(), 8));
     BT_CHECK(check_status(ctx));          // syncs
     if (total > INT32_MAX) { set_error("peer lists: more than 2^31 entries"); return BT_ERR_INVALID; }
     BT_CHECK(st->lists.alloc(ctx->pool, total));
@@ -463,8 +463,8 @@ int area_query_impl(bt_context *ctx, const bt_aq_tree *p, const int32_t *pl_star
     BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, RowCount{counts.get()}, nballs,
                                                       st->starts.get(), d_total.get(), true)));
     int64_t total = 0;
-    BT_HIP_CHECK(hipMemcpyAsync(&total, d_total.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, &total, d_total.get(), 8));
+    BT_CHECK(bt::sync_stream(ctx));
     if (total > INT32_MAX) { set_error("area query: more than 2^31 entries"); return BT_ERR_INVALID; }
     BT_CHECK(st->lists.alloc(ctx->pool, total));
     if (nballs > 0 && total > 0) {
@@ -472,7 +472,7 @@ int area_query_impl(bt_context *ctx, const bt_aq_tree *p, const int32_t *pl_star
                 pk.t, balls, pl_starts, pl_lists, st->starts.get(), st->lists.get());
         BT_HIP_CHECK(hipGetLastError());
     }
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));    // pk's buffers die here
+    BT_CHECK(bt::sync_stream(ctx));    // pk's buffers die here
     st->nrows = nballs;
     st->nentries = total;
     *n_entries = total;
@@ -495,7 +495,7 @@ int space_invader_impl(bt_context *ctx, const bt_aq_tree *p, const int32_t *pl_s
                 pk.t, balls, pl_starts, pl_lists, nullptr, (int32_t *) out);
         BT_HIP_CHECK(hipGetLastError());
     }
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -552,7 +552,7 @@ int bt_csr_export(bt_context *ctx, int32_t *starts, int32_t *lists)
     if (lists && st->nentries > 0)
         BT_HIP_CHECK(hipMemcpyAsync(lists, st->lists.get(), (size_t) st->nentries * 4,
                                     hipMemcpyDeviceToDevice, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     bt_free_aq_state(ctx);
     return BT_OK;
 }
@@ -611,7 +611,7 @@ int bt_leaves_to_balls(bt_context *ctx, int64_t nballs, int64_t nboxes,
     key_starts_kernel<<<(unsigned) div_up(nboxes + 1, 256), 256, 0, ctx->stream>>>(
             sorted_keys, n_entries, nboxes, balls_near_box_starts);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 

@@ -7,6 +7,8 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
+#include <ctime>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -36,6 +38,17 @@ void set_error(const char *fmt, ...);
     } while (0)
 
 inline int64_t div_up(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// BT_HOST_TRACE=1: host-side timestamps (CLOCK_MONOTONIC, microseconds -- the clock of
+// Python's time.monotonic_ns) of the stage marks, to see where the host waits.
+inline void host_trace(const char *name)
+{
+    static const bool on = [] { const char *e = getenv("BT_HOST_TRACE"); return e && atoi(e); }();
+    if (!on) return;
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    fprintf(stderr, "[bt-host] %-14s %.1f\n", name, ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3);
+}
 
 // Device error flags polled by the host at its sync points.
 struct DeviceStatus {
@@ -148,9 +161,28 @@ struct bt_context {
     bool sort_ev_pending = false;
     // statistics of the last build (host-side counters)
     int n_host_syncs = 0;
+    // small device-to-host reads (bt::d2h / bt::sync_stream): a pinned staging block and
+    // the copies waiting for the next synchronisation
+    char *h_ring = nullptr;
+    size_t h_ring_cap = 0, h_ring_used = 0;
+    struct PendingRead { void *dst; const char *src; size_t bytes; };
+    std::vector<PendingRead> pending_reads;
+    // stream-ordered results (bt_set_stream_ordered): calls end with finish_call(), which
+    // queues the status read instead of waiting for it; sync_stream examines it later
+    bool stream_ordered = false;
+    bool status_inflight = false;
 };
 
 namespace bt {
 int check_status(bt_context *ctx);   // sync + read device status flags
 int reset_status(bt_context *ctx);
+// Read `bytes` from device memory into `host_dst`; the value is there after the next
+// sync_stream(ctx).  hipMemcpyAsync into pageable memory blocks the host for a staged copy
+// (30-80 us of idle GPU per read, measured); here the copy goes to pinned memory as a queued
+// command and any number of reads share one wait.
+int d2h(bt_context *ctx, void *host_dst, const void *dev_src, size_t bytes);
+int sync_stream(bt_context *ctx);    // hipStreamSynchronize + delivery of the pending reads
+                                     // + the verdict on a status read queued by finish_call
+int finish_call(bt_context *ctx);    // end of an API call: check_status, or (stream-ordered
+                                     // contexts) queue the status read and return
 }  // namespace bt

@@ -129,17 +129,25 @@ int scan_prepare(bt_context *ctx, int64_t ntiles, uint32_t *gen, uint32_t *ticke
     return BT_OK;
 }
 
-int reset_status(bt_context *ctx)
+int d2h(bt_context *ctx, void *host_dst, const void *dev_src, size_t bytes)
 {
-    BT_HIP_CHECK(hipMemsetAsync(ctx->d_status, 0, sizeof(DeviceStatus), ctx->stream));
+    if (bytes == 0) return BT_OK;
+    const size_t need = (bytes + 15) & ~(size_t) 15;
+    if (ctx->h_ring && need > ctx->h_ring_cap - ctx->h_ring_used && !ctx->pending_reads.empty())
+        BT_CHECK(sync_stream(ctx));
+    if (!ctx->h_ring || need > ctx->h_ring_cap - ctx->h_ring_used) {
+        BT_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return BT_OK;
+    }
+    char *slot = ctx->h_ring + ctx->h_ring_used;
+    ctx->h_ring_used += need;
+    BT_HIP_CHECK(hipMemcpyAsync(slot, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    ctx->pending_reads.push_back({host_dst, slot, bytes});
     return BT_OK;
 }
 
-int check_status(bt_context *ctx)
+static int status_verdict(bt_context *ctx)
 {
-    BT_HIP_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(DeviceStatus),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->h_status->lookback_timeout) {
         set_error("radix sort: decoupled look-back spin bound exceeded");
         return BT_ERR_INTERNAL;
@@ -154,6 +162,43 @@ int check_status(bt_context *ctx)
         return BT_ERR_MAX_LEVELS;
     }
     return BT_OK;
+}
+
+int sync_stream(bt_context *ctx)
+{
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    for (auto &r : ctx->pending_reads) memcpy(r.dst, r.src, r.bytes);
+    ctx->pending_reads.clear();
+    ctx->h_ring_used = 0;
+    BT_HIP_CHECK(e);
+    if (ctx->status_inflight) {
+        ctx->status_inflight = false;
+        return status_verdict(ctx);
+    }
+    return BT_OK;
+}
+
+int finish_call(bt_context *ctx)
+{
+    if (!ctx->stream_ordered) return check_status(ctx);
+    BT_HIP_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(DeviceStatus),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    ctx->status_inflight = true;
+    return BT_OK;
+}
+
+int reset_status(bt_context *ctx)
+{
+    BT_HIP_CHECK(hipMemsetAsync(ctx->d_status, 0, sizeof(DeviceStatus), ctx->stream));
+    return BT_OK;
+}
+
+int check_status(bt_context *ctx)
+{
+    BT_HIP_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(DeviceStatus),
+                                hipMemcpyDeviceToHost, ctx->stream));
+    ctx->status_inflight = true;
+    return sync_stream(ctx);
 }
 
 }  // namespace bt
@@ -195,6 +240,10 @@ int bt_create(int device, void *hip_stream, bt_context **out)
     hipError_t e = hipMalloc((void **) &ctx->d_status, sizeof(bt::DeviceStatus));
     if (e == hipSuccess)
         e = hipHostMalloc((void **) &ctx->h_status, sizeof(bt::DeviceStatus), hipHostMallocDefault);
+    if (e == hipSuccess) {
+        ctx->h_ring_cap = 256 << 10;
+        e = hipHostMalloc((void **) &ctx->h_ring, ctx->h_ring_cap, hipHostMallocDefault);
+    }
     if (e != hipSuccess) { bt_destroy(ctx); BT_HIP_CHECK(e); }
     memset(ctx->h_status, 0, sizeof(bt::DeviceStatus));
     int s = bt::reset_status(ctx);
@@ -207,7 +256,7 @@ void bt_destroy(bt_context *ctx)
 {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
-    if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+    (void) hipStreamSynchronize(ctx->stream);
     bt_free_tree_state(ctx);
     bt_free_trav_state(ctx);
     bt_free_aq_state(ctx);
@@ -219,8 +268,34 @@ void bt_destroy(bt_context *ctx)
     if (ctx->scan_desc) (void) hipFree(ctx->scan_desc);
     if (ctx->scan_ticket) (void) hipFree(ctx->scan_ticket);
     if (ctx->h_status) (void) hipHostFree(ctx->h_status);
+    if (ctx->h_ring) (void) hipHostFree(ctx->h_ring);
     if (ctx->own_stream && ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+int bt_set_stream(bt_context *ctx, void *hip_stream)
+{
+    if (!ctx) return BT_ERR_INVALID;
+    if (ctx->stream == (hipStream_t) hip_stream && !ctx->own_stream) return BT_OK;
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    BT_CHECK(bt::sync_stream(ctx));
+    if (ctx->own_stream && ctx->stream) { (void) hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    ctx->stream = (hipStream_t) hip_stream;
+    return BT_OK;
+}
+
+int bt_set_stream_ordered(bt_context *ctx, int on)
+{
+    if (!ctx) return BT_ERR_INVALID;
+    ctx->stream_ordered = on != 0;
+    return BT_OK;
+}
+
+int bt_synchronize(bt_context *ctx)
+{
+    if (!ctx) return BT_ERR_INVALID;
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    return bt::sync_stream(ctx);
 }
 
 int bt_trim(bt_context *ctx)

@@ -151,7 +151,7 @@ int bt_fmm_box_particle_sums(bt_context *ctx, int64_t n, const int32_t *boxes,
         box_particle_sum_kernel<<<blocks_for(n * WAVE), 256, 0, ctx->stream>>>(
             n, boxes, box_starts, box_counts, values, out, accumulate);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -175,11 +175,11 @@ int bt_fmm_csr_sum(bt_context *ctx, int64_t nrows, const int32_t *starts, const 
                                                                           box_values, rows.get());
             scatter_add_rows_kernel<<<blocks_for(nrows), 256, 0, ctx->stream>>>(nrows, row_boxes,
                                                                                rows.get(), out);
-            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            BT_CHECK(bt::sync_stream(ctx));
         }
     }
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -198,7 +198,7 @@ int bt_fmm_box_to_particles(bt_context *ctx, int64_t nrows, const int32_t *row_b
         box_to_particles_kernel<<<blocks_for(nrows * WAVE), 256, 0, ctx->stream>>>(
             nrows, row_boxes, box_starts, box_counts, row_values, box_values, pot, accumulate);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -220,7 +220,7 @@ int bt_fmm_tree_sweep(bt_context *ctx, int64_t n, const int32_t *boxes, const in
             add_parent_kernel<<<blocks_for(n), 256, 0, ctx->stream>>>(n, boxes, parent_ids, box_values);
     }
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -262,8 +262,8 @@ int bt_translation_classes(bt_context *ctx, int dims, int coord_kind, int64_t n_
 #undef TC_LAUNCH
         BT_HIP_CHECK(hipGetLastError());
     }
-    BT_HIP_CHECK(hipMemcpyAsync(error, d_err.get(), 4, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, error, d_err.get(), 4));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 

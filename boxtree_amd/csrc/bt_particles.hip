@@ -97,8 +97,8 @@ int tree_order_scan(bt_context *ctx, int64_t n, const int8_t *flags,
     BT_CHECK(d_total.alloc(ctx->pool, 1));
     BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, FlagCount{tflags.get()}, n, F.get(),
                                                       d_total.get(), true)));
-    BT_HIP_CHECK(hipMemcpyAsync(nfiltered, d_total.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, nfiltered, d_total.get(), 8));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -185,7 +185,7 @@ int bt_filter_targets_user_order(bt_context *ctx, int64_t nboxes, int64_t ntarge
                 box_target_counts_nonchild, target_starts, target_lists);
         BT_HIP_CHECK(hipGetLastError());
     }
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -219,7 +219,7 @@ int bt_filter_targets_tree_order(bt_context *ctx, int64_t nboxes, int64_t ntarge
             nboxes, ntargets, F.get(), box_target_starts, box_target_counts_nonchild,
             box_target_starts_filtered, box_target_counts_nonchild_filtered);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -253,8 +253,8 @@ int bt_link_point_sources(bt_context *ctx, int64_t nsources, int64_t nboxes,
             nsources, point_source_starts, user_source_ids, tree_order_point_source_counts);
     BT_HIP_CHECK(hipGetLastError());
     int64_t total = 0;
-    BT_HIP_CHECK(hipMemcpyAsync(&total, d_total.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, &total, d_total.get(), 8));
+    BT_CHECK(bt::sync_stream(ctx));
     if (total != npoint_sources) {
         set_error("bt_link_point_sources: point_source_starts describes %lld point sources, "
                   "the caller announced %lld", (long long) total, (long long) npoint_sources);
@@ -273,7 +273,7 @@ int bt_link_point_sources(bt_context *ctx, int64_t nsources, int64_t nboxes,
             tree_order_point_source_counts, box_point_source_starts,
             box_point_source_counts_nonchild, box_point_source_counts_cumul);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 

@@ -233,7 +233,7 @@ int bt_dfs_order(bt_context *ctx, int nchildren, int nlevels, const int32_t *lev
                 dfs_order);
     }
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -257,8 +257,8 @@ int bt_partition_work(bt_context *ctx, int64_t nboxes, const int32_t *dfs_order,
     BT_CHECK((device_exclusive_scan<double, double>(ctx, CostInDfsOrder{cost_per_box, dfs_order},
                                                     nboxes, E.get(), d_total.get(), true)));
     double total = 0;
-    BT_HIP_CHECK(hipMemcpyAsync(&total, d_total.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, &total, d_total.get(), 8));
+    BT_CHECK(bt::sync_stream(ctx));
 
     std::vector<double> thr((size_t) nranks);
     std::vector<int64_t> first((size_t) nranks, nboxes);
@@ -271,9 +271,8 @@ int bt_partition_work(bt_context *ctx, int64_t nboxes, const int32_t *dfs_order,
     first_exceeding_kernel<<<(unsigned) div_up(nranks, 64), 64, 0, ctx->stream>>>(
             nranks, d_thr.get(), E.get(), nboxes, d_first.get());
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipMemcpyAsync(first.data(), d_first.get(), 8 * (size_t) nranks,
-                                hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, first.data(), d_first.get(), 8 * (size_t) nranks));
+    BT_CHECK(bt::sync_stream(ctx));
 
     // the reference's loop (partition.py:99-116) visits the boxes one by one and
     // lets a box end at most one segment; replayed here segment by segment
@@ -306,7 +305,7 @@ int bt_ancestor_mask(bt_context *ctx, int64_t nboxes, const int32_t *box_parent_
     ancestor_mask_kernel<<<(unsigned) div_up(nboxes, 256), 256, 0, ctx->stream>>>(
             nboxes, box_parent_ids, boxes_mask, ancestors);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -323,7 +322,7 @@ int bt_mark_list_boxes(bt_context *ctx, int64_t nrows, const int32_t *box_list,
     mark_list_boxes_kernel<<<(unsigned) div_up(nrows * ROW_LANES, 256), 256, 0, ctx->stream>>>(
             nrows, box_list, mask_a, mask_b, starts, lists, out_mask);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -364,8 +363,8 @@ int bt_local_particles(bt_context *ctx, int64_t nboxes, int64_t nparticles, cons
         particle_idx_kernel<<<(unsigned) div_up(nparticles, 256), 256, 0, ctx->stream>>>(
                 nparticles, F.get(), pmask.get(), particle_idx);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipMemcpyAsync(nlocal, d_total.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, nlocal, d_total.get(), 8));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -380,7 +379,7 @@ int bt_modify_target_flags(bt_context *ctx, int64_t nboxes, const int32_t *count
     modify_target_flags_kernel<<<(unsigned) div_up(nboxes, 256), 256, 0, ctx->stream>>>(
             nboxes, counts_nonchild, counts_cumul, box_flags);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -397,9 +396,8 @@ int bt_box_to_user_ranks(bt_context *ctx, int nranks, int64_t nboxes, const int8
         BT_CHECK(d_total.alloc(ctx->pool, 1));
         BT_CHECK((device_exclusive_scan<int64_t, int32_t>(
                 ctx, UserRankCount{masks, nboxes, nranks}, nboxes, starts, d_total.get(), true)));
-        BT_HIP_CHECK(hipMemcpyAsync(nentries, d_total.get(), 8, hipMemcpyDeviceToHost,
-                                    ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        BT_CHECK(bt::d2h(ctx, nentries, d_total.get(), 8));
+        BT_CHECK(bt::sync_stream(ctx));
         if (*nentries > INT32_MAX) {
             set_error("bt_box_to_user_ranks: list exceeds the int32 CSR limit");
             return BT_ERR_INVALID;
@@ -409,7 +407,7 @@ int bt_box_to_user_ranks(bt_context *ctx, int nranks, int64_t nboxes, const int8
     user_rank_fill_kernel<<<(unsigned) div_up(nboxes, 256), 256, 0, ctx->stream>>>(
             nboxes, nranks, masks, starts, lists);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -436,8 +434,8 @@ int bt_boxes_used_by_ranks(bt_context *ctx, int64_t nboxes, const int8_t *contri
     particle_idx_kernel<<<(unsigned) div_up(nboxes, 256), 256, 0, ctx->stream>>>(
             nboxes, F.get(), flag.get(), boxes);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipMemcpyAsync(n, d_total.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, n, d_total.get(), 8));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 

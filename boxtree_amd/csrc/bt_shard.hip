@@ -159,7 +159,7 @@ int cells_impl(bt_context *ctx, const void *const *coords, int64_t n, const doub
         morton_cells_kernel<T, D><<<(unsigned) div_up(n, 256), 256, 0, ctx->stream>>>(a, cells, hist);
     }
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -230,7 +230,7 @@ int bt_gather(bt_context *ctx, int elem_size, const void *in, const uint32_t *pe
     else
         gather_perm_kernel<uint32_t><<<blocks, 256, 0, ctx->stream>>>(n, perm, (const uint32_t *) in, (uint32_t *) out);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -257,7 +257,7 @@ int bt_gather_pack(bt_context *ctx, int dims, int elem_size, const void *const *
     }
     BT_CHECK(s);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -282,7 +282,7 @@ int bt_unpack(bt_context *ctx, int dims, int elem_size, const void *in, int64_t 
     }
     BT_CHECK(s);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -396,7 +396,7 @@ int let_build_impl(bt_context *ctx, int nlevels, const int32_t *level_starts, co
         BT_HIP_CHECK(hipMemcpyAsync(centers + (int64_t) ax * aligned, &root[ax], sizeof(T),
                                     hipMemcpyHostToDevice, ctx->stream));
     }
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));        // `root` goes out of scope
+    BT_CHECK(bt::sync_stream(ctx));        // `root` goes out of scope
     for (int lev = 1; lev < nlevels; ++lev) {
         const int32_t b0 = level_starts[lev], b1 = level_starts[lev + 1];
         if (b1 <= b0) continue;
@@ -405,8 +405,8 @@ int let_build_impl(bt_context *ctx, int nlevels, const int32_t *level_starts, co
     }
     BT_HIP_CHECK(hipGetLastError());
     int32_t missing = 0;
-    BT_HIP_CHECK(hipMemcpyAsync(&missing, d_missing.get(), 4, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, &missing, d_missing.get(), 4));
+    BT_CHECK(bt::sync_stream(ctx));
     if (missing) {
         set_error("bt_let_build: a box has no parent among the boxes of the level above "
                   "(%d boxes)", nboxes);
@@ -438,7 +438,7 @@ int bt_box_morton_paths(bt_context *ctx, int dims, int coord_kind, int64_t nboxe
     else { if (dims == 1) BP(float, 1); else if (dims == 2) BP(float, 2); else BP(float, 3); }
 #undef BP
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 

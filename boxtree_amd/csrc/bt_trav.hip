@@ -691,6 +691,7 @@ int bt_trav_stage_times(bt_context *ctx, bt_stage_times *out, int n)
 {
     TravState *st = ctx->trav;
     if (!st) return n;
+    if (!st->events.empty()) (void) hipEventSynchronize(st->events.back().second);
     for (size_t i = 1; i < st->events.size() && n < BT_NUM_STAGES; ++i) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, st->events[i - 1].second, st->events[i].second) != hipSuccess) {
@@ -710,6 +711,7 @@ inline unsigned nblk(int64_t n) { return (unsigned) std::max<int64_t>(1, div_up(
 
 int tmark(bt_context *ctx, TravState *st, const char *name)
 {
+    host_trace(name);
     hipEvent_t e;
     BT_HIP_CHECK(hipEventCreate(&e));
     BT_HIP_CHECK(hipEventRecord(e, ctx->stream));
@@ -719,8 +721,8 @@ int tmark(bt_context *ctx, TravState *st, const char *name)
 
 int read_i32(bt_context *ctx, const int32_t *d, int32_t *h)
 {
-    BT_HIP_CHECK(hipMemcpyAsync(h, d, 4, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, h, d, 4));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 
@@ -734,8 +736,8 @@ int scan_list_counts(bt_context *ctx, F f, int64_t n, int32_t *starts, int64_t *
     BT_CHECK(d_total.alloc(ctx->pool, 1));
     BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, f, n, starts, d_total.get(), true)));
     int64_t t = 0;
-    BT_HIP_CHECK(hipMemcpyAsync(&t, d_total.get(), 8, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, &t, d_total.get(), 8));
+    BT_CHECK(bt::sync_stream(ctx));
     if (t >= ((int64_t) 1 << 31)) {
         set_error("interaction list exceeds 2^31-1 entries (int32 CSR limit of the reference): "
                   "%lld", (long long) t);
@@ -789,9 +791,8 @@ int l3_postprocess(bt_context *ctx, TravState *st)
     l3_level_marks_kernel<<<1, 128, 0, ctx->stream>>>(nlevels, ntb, st->l3_starts.get(),
                                                      st->l3_cidx.get(), marks.get());
     std::vector<int32_t> h((size_t) 2 * (nlevels + 1));
-    BT_HIP_CHECK(hipMemcpyAsync(h.data(), marks.get(), h.size() * 4, hipMemcpyDeviceToHost,
-                                ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, h.data(), marks.get(), h.size() * 4));
+    BT_CHECK(bt::sync_stream(ctx));
     st->l3_level_base.assign((size_t) nlevels, 0);
     st->l3_level_count.assign((size_t) nlevels, 0);
     st->l3_nonempty.assign((size_t) nlevels, 0);
@@ -1189,9 +1190,8 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             a, ft, (int32_t) ntb, c1.starts.get(), c1.lists.get(), jobs, tier.get(),
             tier_present.get());
         int32_t h_present[2] = {0, 0};
-        BT_HIP_CHECK(hipMemcpyAsync(h_present, tier_present.get(), 8, hipMemcpyDeviceToHost,
-                                    ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        BT_CHECK(bt::d2h(ctx, h_present, tier_present.get(), 8));
+        BT_CHECK(bt::sync_stream(ctx));
         for (int which = 1; which <= 2; ++which) {
             if (!h_present[which - 1]) continue;
             TierIs pr{tier.get(), (uint8_t) which};
@@ -1211,7 +1211,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             else
                 l1_finalize_block_kernel<T, D><<<cnt, 256, 0, ctx->stream>>>(
                     a, ft, list.get(), pos.get() + ntb, c1.starts.get(), c1.lists.get(), jobs);
-            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));    // `list` is freed on scope exit
+            BT_CHECK(bt::sync_stream(ctx));    // `list` is freed on scope exit
         }
         int32_t njobs = 0;
         BT_CHECK(read_i32(ctx, jobs.count, &njobs));
@@ -1582,10 +1582,9 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
 
     int64_t h_tot[T_COUNT];
     std::vector<int32_t> h_marks((size_t) 2 * (nlevels + 1));
-    BT_HIP_CHECK(hipMemcpyAsync(h_tot, totals.get(), sizeof(h_tot), hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipMemcpyAsync(h_marks.data(), marks.get(), h_marks.size() * 4, hipMemcpyDeviceToHost,
-                                ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, h_tot, totals.get(), sizeof(h_tot)));
+    BT_CHECK(bt::d2h(ctx, h_marks.data(), marks.get(), h_marks.size() * 4));
+    BT_CHECK(bt::sync_stream(ctx));
     ctx->n_host_syncs++;
     for (int k = T_COLL; k <= T_L4RAW; ++k)
         if (h_tot[k] >= ((int64_t) 1 << 31)) {
@@ -1809,13 +1808,12 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     int32_t hb[4] = {1, 1, 1, 0};
     T root_center[D];
     st->h_lev_starts.assign((size_t) 4 * (nlevels + 1), 0);
-    BT_HIP_CHECK(hipMemcpyAsync(st->h_lev_starts.data(), st->lev_starts.get(),
-                                st->h_lev_starts.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipMemcpyAsync(hb, bad.get(), 16, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipMemcpy2DAsync(root_center, sizeof(T), p.box_centers,
-                                  (size_t) p.aligned_nboxes * sizeof(T), sizeof(T), D,
-                                  hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, st->h_lev_starts.data(), st->lev_starts.get(), st->h_lev_starts.size() * 4));
+    BT_CHECK(bt::d2h(ctx, hb, bad.get(), 16));
+    for (int d = 0; d < D; ++d)
+        BT_CHECK(bt::d2h(ctx, &root_center[d], (const T *) p.box_centers + (size_t) d * p.aligned_nboxes,
+                         sizeof(T)));
+    BT_CHECK(bt::sync_stream(ctx));
     ctx->n_host_syncs++;
     {
         const int32_t *h = st->h_lev_starts.data();
@@ -1999,7 +1997,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
             BT_CHECK(cb.lists.alloc(ctx->pool, cb.total));
             merge_copy_kernel<<<nblk(cb.n), 256, 0, ctx->stream>>>(
                 (int32_t) cb.n, mc, raw.lists.get(), cb.starts.get(), cb.lists.get());
-            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            BT_CHECK(bt::sync_stream(ctx));
         }
     }
     BT_HIP_CHECK(hipGetLastError());
@@ -2074,7 +2072,7 @@ static int trav_build_entry(bt_context *ctx, const bt_trav_params *p, bt_trav_si
     case 2: s = f64 ? trav_build_impl<double, 2>(ctx, st, out) : trav_build_impl<float, 2>(ctx, st, out); break;
     case 3: s = f64 ? trav_build_impl<double, 3>(ctx, st, out) : trav_build_impl<float, 3>(ctx, st, out); break;
     }
-    if (s != BT_OK) { (void) hipStreamSynchronize(ctx->stream); bt_free_trav_state(ctx); }
+    if (s != BT_OK) { (void) bt::sync_stream(ctx); bt_free_trav_state(ctx); }
     return s;
 }
 
@@ -2135,7 +2133,8 @@ static int export_impl(bt_context *ctx, TravState *st, const bt_trav_arrays *o)
     BT_HIP_CHECK(hipGetLastError());
     BT_CHECK(tmark(ctx, st, "trav:export"));
     ctx->n_host_syncs++;
-    return check_status(ctx);       // waits for the stream; reports device-side failures
+    return finish_call(ctx);        // waits for the stream and reports device-side failures
+                                    // (stream-ordered contexts: queues the status read)
 }
 
 int bt_traversal_build(bt_context *ctx, const bt_trav_params *p, bt_trav_sizes *out)
@@ -2161,7 +2160,9 @@ int bt_traversal_build_packed(bt_context *ctx, const bt_trav_params *p, bt_alloc
     if (!alloc || !out) { set_error("bt_traversal_build_packed: NULL argument"); return BT_ERR_INVALID; }
     memset(out, 0, sizeof(*out));
     bt_trav_sizes sizes;
+    host_trace("trav:enter");
     BT_CHECK(trav_build_entry(ctx, p, &sizes, alloc, user, out));
+    host_trace("trav:built");
     TravState *st = ctx->trav;
     if (!st->arena) BT_CHECK(make_arena(ctx, st));      // the general paths: sizes known only now
     bt_trav_arrays o{};
@@ -2188,7 +2189,9 @@ int bt_traversal_build_packed(bt_context *ctx, const bt_trav_params *p, bt_alloc
         o.from_sep_smaller_compressed_indices[l] = span_ptr(st, out->from_sep_smaller_compressed_indices[l]);
         o.target_boxes_sep_smaller[l] = span_ptr(st, out->target_boxes_sep_smaller[l]);
     }
-    return export_impl(ctx, st, &o);
+    int s = export_impl(ctx, st, &o);
+    host_trace("trav:leave");
+    return s;
 }
 
 
@@ -2211,7 +2214,7 @@ int bt_merge_csr_lists(bt_context *ctx, int nlists, const int32_t *const *starts
         merge_rows_kernel<<<nblk(nrows), 256, 0, ctx->stream>>>((int32_t) nrows, m, out_starts,
                                                                 out_lists);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
 

@@ -91,9 +91,8 @@ int bbox_impl(bt_context *ctx, int dims, const void *const *coords, const void *
             (const T *) coords[d], (const T *) radii, n, partial.get() + 2 * blocks * d);
     BT_HIP_CHECK(hipGetLastError());
     std::vector<T> h((size_t) (2 * blocks * dims));
-    BT_HIP_CHECK(hipMemcpyAsync(h.data(), partial.get(), h.size() * sizeof(T),
-                                hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, h.data(), partial.get(), h.size() * sizeof(T)));
+    BT_CHECK(bt::sync_stream(ctx));
     for (int d = 0; d < dims; ++d) {
         T mn = CoordTraits<T>::maxval, mx = -CoordTraits<T>::maxval;
         for (int64_t b = 0; b < blocks; ++b) {
@@ -1360,12 +1359,44 @@ struct BoxInfoArgs {
     int32_t *o_tgt_starts, *o_tgt_nonchild, *o_tgt_cumul;
     int32_t *o_parent, *o_child;
     uint8_t *o_levels, *o_flags;
+    const void *centers;           // [nboxes][D], T = float (csize 4) or double (8)
+    void *o_centers;               // [D][aligned]
+    int csize;
+    int32_t *o_level_starts;       // [n_level_starts] or null
+    int n_level_starts;
+    int32_t level_starts[BT_MAX_LEVELS + 1];
 };
 
+// One thread per box of the padded range [0, aligned): exported per-box arrays, centres in
+// the reference's [d][aligned] layout, zeros in the padding columns of the two 2-D arrays,
+// and (first workgroup) the level starts, which travel as kernel arguments.
 __global__ __launch_bounds__(256) void box_info_kernel(BoxInfoArgs a)
 {
     const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= a.nboxes) return;
+    if (blockIdx.x == 0 && a.o_level_starts) {
+        int32_t v = 0;
+#pragma unroll
+        for (int i = 0; i <= BT_MAX_LEVELS; ++i) v = ((int) threadIdx.x == i) ? a.level_starts[i] : v;
+        if ((int) threadIdx.x < a.n_level_starts) a.o_level_starts[threadIdx.x] = v;
+    }
+    if (b >= a.nboxes) {
+        if (b < a.aligned) {
+            for (int m = 0; m < a.C; ++m) a.o_child[(int64_t) m * a.aligned + b] = 0;
+            for (int ax = 0; ax < a.D; ++ax) {
+                if (a.csize == 8) ((double *) a.o_centers)[(int64_t) ax * a.aligned + b] = 0.0;
+                else ((float *) a.o_centers)[(int64_t) ax * a.aligned + b] = 0.f;
+            }
+        }
+        return;
+    }
+    for (int ax = 0; ax < a.D; ++ax) {
+        if (a.csize == 8)
+            ((double *) a.o_centers)[(int64_t) ax * a.aligned + b] =
+                ((const double *) a.centers)[(int64_t) b * a.D + ax];
+        else
+            ((float *) a.o_centers)[(int64_t) ax * a.aligned + b] =
+                ((const float *) a.centers)[(int64_t) b * a.D + ax];
+    }
     const int s = a.box_start[b], cnt = a.box_count[b];
     const int haschild = a.box_haschild[b];
     const int n0 = a.box_nonchild[b];      // own particles of a split box (0 w/o extents)
@@ -1403,15 +1434,6 @@ __global__ __launch_bounds__(256) void box_info_kernel(BoxInfoArgs a)
     a.o_flags[b] = flags;
     for (int m = 0; m < a.C; ++m)
         a.o_child[(int64_t) m * a.aligned + b] = a.box_child[(int64_t) b * a.C + m];
-}
-
-template <class T>
-__global__ __launch_bounds__(256) void repack_centers_kernel(int nboxes, int64_t aligned, int D,
-        const T *centers, T *o_centers)
-{
-    const int b = blockIdx.x * 256 + threadIdx.x;
-    if (b >= nboxes) return;
-    for (int ax = 0; ax < D; ++ax) o_centers[(int64_t) ax * aligned + b] = centers[(int64_t) b * D + ax];
 }
 
 // box extents: tbk:1311-1399, one 16-lane group per box of one level
@@ -1532,6 +1554,7 @@ namespace {
 
 int mark(bt_context *ctx, TreeState *st, const char *name)
 {
+    host_trace(name);
     hipEvent_t e;
     BT_HIP_CHECK(hipEventCreate(&e));
     BT_HIP_CHECK(hipEventRecord(e, ctx->stream));
@@ -1857,8 +1880,8 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
         BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, sn, n, offsets.get(),
                                                           &d_flags.get()->total_new)));
         LevelFlags hf;
-        BT_HIP_CHECK(hipMemcpyAsync(&hf, d_flags.get(), sizeof(hf), hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        BT_CHECK(bt::d2h(ctx, &hf, d_flags.get(), sizeof(hf)));
+        BT_CHECK(bt::sync_stream(ctx));
         *total_new = hf.total_new;
         *oversize = hf.have_oversize;
         if (hf.total_new == 0) return BT_OK;
@@ -1962,8 +1985,8 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
                         (const T *) st->centers.get(), box_path.get(), force.get(), d_have.get());
             }
             int32_t have = 0;
-            BT_HIP_CHECK(hipMemcpyAsync(&have, d_have.get(), 4, hipMemcpyDeviceToHost, ctx->stream));
-            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            BT_CHECK(bt::d2h(ctx, &have, d_have.get(), 4));
+            BT_CHECK(bt::sync_stream(ctx));
             if (!have) break;                   // :1201-1202
             did_upper_level_split = true;
         }
@@ -1975,8 +1998,8 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
             BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, NonZeroI32{force.get()}, nb,
                                                               pos.get(), (int32_t *) nullptr, true)));
             int32_t nf = 0;
-            BT_HIP_CHECK(hipMemcpyAsync(&nf, pos.get() + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
-            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            BT_CHECK(bt::d2h(ctx, &nf, pos.get() + nb, 4));
+            BT_CHECK(bt::sync_stream(ctx));
             BT_CHECK(fl_levels.alloc(ctx->pool, nf));
             BT_CHECK(fl_ids.alloc(ctx->pool, nf));
             BT_CHECK(fl_levels_b.alloc(ctx->pool, nf));
@@ -2027,10 +2050,9 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
                                                                 pos.get(), level_counts.get());
     int32_t h_counts[BT_MAX_LEVELS];
     int32_t nfinal = 0;
-    BT_HIP_CHECK(hipMemcpyAsync(h_counts, level_counts.get(), sizeof(h_counts), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    BT_HIP_CHECK(hipMemcpyAsync(&nfinal, pos.get() + nraw, 4, hipMemcpyDeviceToHost, ctx->stream));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::d2h(ctx, h_counts, level_counts.get(), sizeof(h_counts)));
+    BT_CHECK(bt::d2h(ctx, &nfinal, pos.get() + nraw, 4));
+    BT_CHECK(bt::sync_stream(ctx));
 
     Buf<int32_t> n_start, n_count, n_parent, n_nonchild, n_child;
     Buf<uint8_t> n_level, n_haschild;
@@ -2052,7 +2074,7 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
     lr_renumber_kernel<T, D><<<(unsigned) div_up(nraw, 256), 256, 0, ctx->stream>>>(
         nraw, keep, pos.get(), final_of_raw.get(), in, out);
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
     st->box_start.swap(n_start); st->box_count.swap(n_count); st->box_parent.swap(n_parent);
     st->box_nonchild.swap(n_nonchild); st->box_child.swap(n_child); st->box_level.swap(n_level);
     st->box_haschild.swap(n_haschild); st->centers.swap(n_centers);
@@ -2081,8 +2103,8 @@ int run_fixup(bt_context *ctx, TreeState *st)
             (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_haschild.get(),
             ids, large_list.get(), sflags.get());
         SegSortFlags hf;
-        BT_HIP_CHECK(hipMemcpyAsync(&hf, sflags.get(), sizeof(hf), hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        BT_CHECK(bt::d2h(ctx, &hf, sflags.get(), sizeof(hf)));
+        BT_CHECK(bt::sync_stream(ctx));
         ctx->n_host_syncs++;
         if (!hf.has_huge) {
             if (hf.n_large > 0)
@@ -2194,9 +2216,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         double npts = (double) N;
         if (p.top_cell_prefix) {
             int64_t total = 0;
-            BT_HIP_CHECK(hipMemcpyAsync(&total, p.top_cell_prefix + ((int64_t) 1 << (D * p.top_level)),
-                                        8, hipMemcpyDeviceToHost, ctx->stream));
-            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            BT_CHECK(bt::d2h(ctx, &total, p.top_cell_prefix + ((int64_t) 1 << (D * p.top_level)), 8));
+            BT_CHECK(bt::sync_stream(ctx));
             npts = (double) total;
         }
         const double per_leaf = std::max(1.0, npts / std::max(1, p.max_leaf_refine_weight));
@@ -2242,9 +2263,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     Buf<uint32_t> tickets;
     BT_CHECK(d_ls.alloc(ctx->pool, 1));
     BT_CHECK(tickets.alloc(ctx->pool, BT_MAX_LEVELS + 3));
-    LoopState *h_ls = nullptr;
-    BT_HIP_CHECK(hipHostMalloc((void **) &h_ls, sizeof(LoopState), hipHostMallocDefault));
-    struct HostFree { LoopState *p; ~HostFree() { (void) hipHostFree(p); } } host_free{h_ls};
+    LoopState h_ls_value{};
+    LoopState *h_ls = &h_ls_value;
 
     auto base_args = [&](BuildArgs &a) {
         a = BuildArgs{};
@@ -2281,9 +2301,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     if (enter_loop && p.kind == BT_KIND_NON_ADAPTIVE) {
         int64_t total = N;
         if (st->wprefix.get()) {
-            BT_HIP_CHECK(hipMemcpyAsync(&total, st->wprefix.get() + N, 8, hipMemcpyDeviceToHost,
-                                        ctx->stream));
-            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            BT_CHECK(bt::d2h(ctx, &total, st->wprefix.get() + N, 8));
+            BT_CHECK(bt::sync_stream(ctx));
         }
         if (total <= (int64_t) p.max_leaf_refine_weight) enter_loop = false;
     }
@@ -2360,9 +2379,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
                         first_level, sl_desc.get(), sl_gen, tickets.get() + l);
             }
             BT_HIP_CHECK(hipGetLastError());
-            BT_HIP_CHECK(hipMemcpyAsync(h_ls, d_ls.get(), sizeof(LoopState), hipMemcpyDeviceToHost,
-                                        ctx->stream));
-            BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            BT_CHECK(bt::d2h(ctx, h_ls, d_ls.get(), sizeof(LoopState)));
+            BT_CHECK(bt::sync_stream(ctx));
             ctx->n_host_syncs++;
             if (h_ls->overflow) {
                 // the children of level `lv` did not fit: grow (keeping the boxes of the
@@ -2414,9 +2432,9 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, RekeyCount{pr}, nb, seg_off.get(),
                                                           (int32_t *) nullptr, true)));
         int32_t h_tot[2] = {0, 0};
-        BT_HIP_CHECK(hipMemcpyAsync(&h_tot[0], seg_rank.get() + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipMemcpyAsync(&h_tot[1], seg_off.get() + nb, 4, hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        BT_CHECK(bt::d2h(ctx, &h_tot[0], seg_rank.get() + nb, 4));
+        BT_CHECK(bt::d2h(ctx, &h_tot[1], seg_off.get() + nb, 4));
+        BT_CHECK(bt::sync_stream(ctx));
         ctx->n_host_syncs++;
         const int32_t nseg = h_tot[0];
         const int64_t M = h_tot[1];
@@ -2515,7 +2533,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
                                                           (int32_t *) nullptr, true)));
     }
     BT_CHECK(mark(ctx, st, "srcscan"));
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    BT_CHECK(bt::sync_stream(ctx));
 
     out->nboxes = st->nboxes;
     out->aligned_nboxes = div_up(st->nboxes, 32) * 32;
@@ -2643,8 +2661,6 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
     BT_CHECK(mark(ctx, st, "gather"));
 
     // ---- per-box arrays -----------------------------------------------------------
-    BT_HIP_CHECK(hipMemsetAsync(o->box_child_ids, 0, (size_t) (C * aligned) * 4, ctx->stream));
-    BT_HIP_CHECK(hipMemsetAsync(o->box_centers, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
     {
         BoxInfoArgs a{};
         a.nboxes = (int) B; a.aligned = aligned; a.C = C; a.D = D;
@@ -2660,9 +2676,11 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
         a.o_tgt_cumul = o->box_target_counts_cumul;
         a.o_parent = o->box_parent_ids; a.o_child = o->box_child_ids;
         a.o_levels = o->box_levels; a.o_flags = o->box_flags;
-        box_info_kernel<<<blocks(B), 256, 0, ctx->stream>>>(a);
-        repack_centers_kernel<T><<<blocks(B), 256, 0, ctx->stream>>>(
-            (int) B, aligned, D, (const T *) st->centers.get(), (T *) o->box_centers);
+        a.centers = st->centers.get(); a.o_centers = o->box_centers; a.csize = (int) sizeof(T);
+        a.o_level_starts = o->level_start_box_nrs;
+        a.n_level_starts = (int) std::min<size_t>(st->level_start.size(), BT_MAX_LEVELS + 1);
+        for (int i = 0; i < a.n_level_starts; ++i) a.level_starts[i] = st->level_start[(size_t) i];
+        box_info_kernel<<<blocks(aligned), 256, 0, ctx->stream>>>(a);
     }
     BT_CHECK(mark(ctx, st, "boxinfo"));
 
@@ -2700,8 +2718,8 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
     BT_CHECK(mark(ctx, st, "extents"));
     if (fused) {
         SegSortFlags hf;
-        BT_HIP_CHECK(hipMemcpyAsync(&hf, sflags.get(), sizeof(hf), hipMemcpyDeviceToHost, ctx->stream));
-        BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        BT_CHECK(bt::d2h(ctx, &hf, sflags.get(), sizeof(hf)));
+        BT_CHECK(bt::sync_stream(ctx));
         ctx->n_host_syncs++;
         if (hf.has_huge) {
             // a leaf beyond the workgroup sort (zero refine weights): order the ids with
@@ -2711,9 +2729,10 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
         }
         return BT_OK;
     }
-    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    ctx->n_host_syncs++;
-    return BT_OK;
+    // (a stream-ordered context does not wait here: the caller's arrays are ordered by
+    // the stream, boxtree_hip.h bt_set_stream_ordered)
+    if (!ctx->stream_ordered) ctx->n_host_syncs++;
+    return bt::finish_call(ctx);
 }
 
 template <class T>
@@ -2761,6 +2780,7 @@ int bt_bbox(bt_context *ctx, int dims, int coord_kind, const void *const *coords
 int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
 {
     if (!ctx || !p || !out) { set_error("bt_tree_build: NULL argument"); return BT_ERR_INVALID; }
+    host_trace("build:enter");
     BT_HIP_CHECK(hipSetDevice(ctx->device));
     memset(out, 0, sizeof(*out));
     if (p->dims < 1 || p->dims > BT_MAX_DIMS) {
@@ -2836,7 +2856,8 @@ int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
     BT_CHECK(reset_status(ctx));
     int s = st->f64 ? dispatch_dims_build<double>(ctx, st, out)
                     : dispatch_dims_build<float>(ctx, st, out);
-    if (s != BT_OK) { (void) hipStreamSynchronize(ctx->stream); bt_free_tree_state(ctx); }
+    if (s != BT_OK) { (void) bt::sync_stream(ctx); bt_free_tree_state(ctx); }
+    host_trace("build:leave");
     return s;
 }
 
@@ -2867,8 +2888,10 @@ int bt_tree_export(bt_context *ctx, const bt_tree_arrays *o)
             set_error("bt_tree_export: NULL coordinate output");
             return BT_ERR_INVALID;
         }
+    host_trace("export:enter");
     int s = st->f64 ? dispatch_dims_export<double>(ctx, st, o)
                     : dispatch_dims_export<float>(ctx, st, o);
+    host_trace("export:leave");
     return s;
 }
 
@@ -2879,6 +2902,7 @@ int bt_get_stage_times(bt_context *ctx, bt_stage_times *out)
     TreeState *st = ctx->tree;
     int n = 0;
     if (st) {
+        if (!st->events.empty()) (void) hipEventSynchronize(st->events.back().second);
         for (size_t i = 1; i < st->events.size() && n < BT_NUM_STAGES; ++i) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, st->events[i - 1].second, st->events[i].second)

@@ -8,10 +8,23 @@ AXIS_NAMES = ("x", "y", "z", "w")
 
 
 class DoneEvent:
-    """Stand-in for ``pyopencl.Event``: library calls are host-synchronous, so
-    the returned event is always complete."""
+    """Stand-in for ``pyopencl.Event`` of a call that has completed on the host."""
 
     def wait(self):
+        return None
+
+
+class StreamEvent:
+    """Stand-in for ``pyopencl.Event`` of a builder call on a stream-ordered context
+    (boxtree_hip.h bt_set_stream_ordered): the arrays of the result are valid for work
+    queued on the context's stream; ``wait()`` blocks until they are complete and raises
+    if the device reported a failure after the call had returned."""
+
+    def __init__(self, actx):
+        self._actx = actx
+
+    def wait(self):
+        self._actx.synchronize()
         return None
 
 

@@ -14,7 +14,7 @@ import numpy as np
 
 from boxtree_amd import _lib
 from boxtree_amd.array_context import HIPArrayContext, make_obj_array, np_dtype_of, ptr
-from boxtree_amd.tools import DoneEvent
+from boxtree_amd.tools import DoneEvent, StreamEvent
 from boxtree_amd.tree import _Container
 
 logger = logging.getLogger(__name__)
@@ -122,6 +122,67 @@ class FMMTraversalInfo(_Container):
         return lists[start:stop]
 
 
+_SPAN_NAMES = (
+    "source_boxes", "target_boxes", "source_parent_boxes", "target_or_target_parent_boxes",
+    "same_level_non_well_sep_boxes_starts", "same_level_non_well_sep_boxes_lists",
+    "neighbor_source_boxes_starts", "neighbor_source_boxes_lists",
+    "from_sep_siblings_starts", "from_sep_siblings_lists",
+    "from_sep_bigger_starts", "from_sep_bigger_lists",
+    "from_sep_close_smaller_starts", "from_sep_close_smaller_lists",
+    "from_sep_close_bigger_starts", "from_sep_close_bigger_lists")
+_LEVEL_START_NAMES = (
+    "level_start_source_box_nrs", "level_start_target_box_nrs",
+    "level_start_source_parent_box_nrs", "level_start_target_or_target_parent_box_nrs")
+
+
+def _info_from_packed(tree, well_sep_is_n_away, packed, buf, nlevels, share_target_boxes):
+    """FMMTraversalInfo whose arrays are views into *buf*, the one int32 block the library
+    filled; *packed* (bt_trav_packed) says where each array lives.  The struct is read
+    through numpy in three pieces (ctypes attribute access costs about a microsecond per
+    field and there are some 60 spans)."""
+    P = _lib.TravPacked
+    nspan = len(_SPAN_NAMES)
+    L = _lib.BT_MAX_LEVELS
+    spans = np.frombuffer(packed, dtype=np.int64, count=2 * (nspan + 5 * L),
+                          offset=P.source_boxes.offset).reshape(-1, 2).tolist()
+    lev = np.frombuffer(packed, dtype=np.int32, count=4 * (L + 1),
+                        offset=P.level_start_source_box_nrs.offset).reshape(4, L + 1)
+    S = _lib.TravSizes
+    per_level = np.frombuffer(packed, dtype=np.int64, count=2 * L,
+                              offset=P.sizes.offset + S.n_from_sep_smaller.offset
+                              ).reshape(2, L)[:, :nlevels].tolist()
+
+    def view(i):
+        off, count = spans[i]
+        return buf[off:off + count]
+
+    kw = {name: view(i) for i, name in enumerate(_SPAN_NAMES)}
+    if share_target_boxes:
+        kw["target_boxes"] = kw["source_boxes"]
+    if not (tree.sources_have_extent or tree.targets_have_extent):
+        for name in _SPAN_NAMES[12:]:
+            kw[name] = None
+    # host arrays, as in the reference (traversal.py:2091 actx.to_numpy(result))
+    for i, name in enumerate(_LEVEL_START_NAMES):
+        kw[name] = lev[i, :nlevels + 1].copy()
+
+    base = nspan
+    by_level = np.empty(nlevels, dtype=object)
+    tboxes = np.empty(nlevels, dtype=object)
+    counts, nonempty = per_level
+    for ilev in range(nlevels):
+        by_level[ilev] = BuiltList(
+            count=counts[ilev], starts=view(base + ilev), lists=view(base + L + ilev),
+            num_nonempty_lists=nonempty[ilev], nonempty_indices=view(base + 2 * L + ilev),
+            compressed_indices=view(base + 3 * L + ilev))
+        tboxes[ilev] = view(base + 4 * L + ilev)
+
+    return FMMTraversalInfo(
+        tree=tree, well_sep_is_n_away=well_sep_is_n_away,
+        from_sep_smaller_by_level=by_level,
+        target_boxes_sep_smaller_by_source_level=tboxes, **kw)
+
+
 class FMMTraversalBuilder:
     def __init__(self, array_context, *, well_sep_is_n_away=1,
                  from_sep_smaller_crit=None):
@@ -144,6 +205,7 @@ class FMMTraversalBuilder:
         walk-from-root kernels even for trees whose numbering allows the faster
         parent-colleague kernels; both produce identical lists."""
         assert isinstance(actx, HIPArrayContext)
+        _lib.host_trace("tg:enter")
 
         from_sep_smaller_min_nsources_cumul = _from_sep_smaller_min_nsources_cumul
         if from_sep_smaller_min_nsources_cumul is None:
@@ -192,18 +254,25 @@ class FMMTraversalBuilder:
         # a TreeOfBoxes made by boxtree.tree_of_boxes arrives as numpy arrays with
         # int32 levels and a root whose parent is -1 (tree_of_boxes.py:392-465)
         torch = actx.torch
-        box_centers = dev(tree.box_centers)
-        box_levels = dev(tree.box_levels).to(torch.uint8)
-        box_child_ids = dev(tree.box_child_ids).to(torch.int32)
-        box_flags = dev(tree.box_flags).to(torch.uint8)
-        box_parent_ids = dev(tree.box_parent_ids).to(torch.int32)
-        if int(box_parent_ids[0]) != 0:
-            box_parent_ids = box_parent_ids.clone()
-            box_parent_ids[0] = 0
+        if getattr(tree, "_host_level_starts", None) is not None:
+            # made by TreeBuilder on this device: contiguous arrays of the library's types
+            box_centers, box_levels, box_child_ids = (tree.box_centers, tree.box_levels,
+                                                      tree.box_child_ids)
+            box_flags, box_parent_ids = tree.box_flags, tree.box_parent_ids
+        else:
+            box_centers = dev(tree.box_centers)
+            box_levels = dev(tree.box_levels).to(torch.uint8)
+            box_child_ids = dev(tree.box_child_ids).to(torch.int32)
+            box_flags = dev(tree.box_flags).to(torch.uint8)
+            box_parent_ids = dev(tree.box_parent_ids).to(torch.int32)
+            if int(box_parent_ids[0]) != 0:
+                box_parent_ids = box_parent_ids.clone()
+                box_parent_ids[0] = 0
         assert np_dtype_of(box_centers) == coord_dtype
         from boxtree_amd.tree import level_start_box_nrs_of
         lsb = level_start_box_nrs_of(actx, tree)
 
+        _lib.host_trace("tg:arrays")
         tp = _lib.TravParams()
         tp.dims = dims
         tp.coord_kind = _lib.BT_F64 if coord_dtype == np.float64 else _lib.BT_F32
@@ -270,88 +339,9 @@ class FMMTraversalBuilder:
         if code == _lib.BT_ERR_INVALID:
             raise ValueError(lib.bt_last_error_string().decode())
         _lib.check(code)
-        buf = block[0]
-
-        def view(span):
-            return buf[span.offset:span.offset + span.count]
-
-        def level_starts(name):
-            # host arrays, as in the reference (traversal.py:2091 actx.to_numpy(result))
-            return np.array(getattr(packed, name)[:nlevels + 1], dtype=np.int32)
-
-        with_extent = tree.sources_have_extent or tree.targets_have_extent
-        source_boxes = view(packed.source_boxes)
-        target_boxes = (source_boxes if sources_are_targets and tbm is None
-                        else view(packed.target_boxes))
-        source_parent_boxes = view(packed.source_parent_boxes)
-        target_or_target_parent_boxes = view(packed.target_or_target_parent_boxes)
-        lev = {name: level_starts(name) for name in (
-            "level_start_source_box_nrs", "level_start_target_box_nrs",
-            "level_start_source_parent_box_nrs",
-            "level_start_target_or_target_parent_box_nrs")}
-
-        def csr(prefix):
-            return (view(getattr(packed, prefix + "_starts")),
-                    view(getattr(packed, prefix + "_lists")))
-
-        slnws = csr("same_level_non_well_sep_boxes")
-        l1 = csr("neighbor_source_boxes")
-        l2 = csr("from_sep_siblings")
-        l4 = csr("from_sep_bigger")
-        if with_extent:
-            cs = csr("from_sep_close_smaller")
-            cb = csr("from_sep_close_bigger")
-        else:
-            cs = cb = (None, None)
-
-        l3 = []
-        for ilev in range(nlevels):
-            nne = int(packed.sizes.n_from_sep_smaller_nonempty[ilev])
-            cnt = int(packed.sizes.n_from_sep_smaller[ilev])
-            arrs = dict(
-                starts=view(packed.from_sep_smaller_starts[ilev]),
-                lists=view(packed.from_sep_smaller_lists[ilev]),
-                nonempty_indices=view(packed.from_sep_smaller_nonempty_indices[ilev]),
-                compressed_indices=view(packed.from_sep_smaller_compressed_indices[ilev]),
-                tboxes=view(packed.target_boxes_sep_smaller[ilev]))
-            l3.append((nne, cnt, arrs))
-
-        from_sep_smaller_by_level = make_obj_array([
-            BuiltList(count=cnt, starts=a["starts"], lists=a["lists"],
-                      num_nonempty_lists=nne, nonempty_indices=a["nonempty_indices"],
-                      compressed_indices=a["compressed_indices"])
-            for nne, cnt, a in l3])
-        target_boxes_sep_smaller_by_source_level = make_obj_array(
-            [a["tboxes"] for _, _, a in l3])
-
-        info = FMMTraversalInfo(
-            tree=tree,
-            well_sep_is_n_away=self.well_sep_is_n_away,
-            source_boxes=source_boxes,
-            target_boxes=target_boxes,
-            level_start_source_box_nrs=lev["level_start_source_box_nrs"],
-            level_start_target_box_nrs=lev["level_start_target_box_nrs"],
-            source_parent_boxes=source_parent_boxes,
-            level_start_source_parent_box_nrs=lev["level_start_source_parent_box_nrs"],
-            target_or_target_parent_boxes=target_or_target_parent_boxes,
-            level_start_target_or_target_parent_box_nrs=lev[
-                "level_start_target_or_target_parent_box_nrs"],
-            same_level_non_well_sep_boxes_starts=slnws[0],
-            same_level_non_well_sep_boxes_lists=slnws[1],
-            neighbor_source_boxes_starts=l1[0],
-            neighbor_source_boxes_lists=l1[1],
-            from_sep_siblings_starts=l2[0],
-            from_sep_siblings_lists=l2[1],
-            from_sep_smaller_by_level=from_sep_smaller_by_level,
-            target_boxes_sep_smaller_by_source_level=(
-                target_boxes_sep_smaller_by_source_level),
-            from_sep_close_smaller_starts=cs[0],
-            from_sep_close_smaller_lists=cs[1],
-            from_sep_bigger_starts=l4[0],
-            from_sep_bigger_lists=l4[1],
-            from_sep_close_bigger_starts=cb[0],
-            from_sep_close_bigger_lists=cb[1],
-        )
-        return actx.freeze(info), DoneEvent()
+        _lib.host_trace("tg:built")
+        info = _info_from_packed(tree, self.well_sep_is_n_away, packed, block[0], nlevels,
+                                 share_target_boxes=sources_are_targets and tbm is None)
+        return actx.freeze(info), (StreamEvent(actx) if actx.stream_ordered else DoneEvent())
 
 # vim: fdm=marker

@@ -225,6 +225,9 @@ def level_start_box_nrs_of(actx, tree):
     the tree does not carry them (a :class:`TreeOfBoxes` may have
     ``level_start_box_nrs=None``, boxtree/tree.py:236) -- which needs the boxes to be
     numbered level by level."""
+    cached = getattr(tree, "_host_level_starts", None)
+    if cached is not None:
+        return cached
     if tree.level_start_box_nrs is not None:
         return np.ascontiguousarray(actx.to_numpy(tree.level_start_box_nrs), dtype=np.int32)
     levels = np.asarray(actx.to_numpy(tree.box_levels), dtype=np.int64)

@@ -20,7 +20,7 @@ from boxtree_amd import _lib
 from boxtree_amd.array_context import (
     HIPArrayContext, make_obj_array, np_dtype_of, ptr)
 from boxtree_amd.bounding_box import AXIS_NAMES, BoundingBoxFinder
-from boxtree_amd.tools import DoneEvent
+from boxtree_amd.tools import DoneEvent, StreamEvent
 from boxtree_amd.tree import Tree
 
 logger = logging.getLogger(__name__)
@@ -251,7 +251,18 @@ class TreeBuilder:
         assert isinstance(array_context, HIPArrayContext)
         self._setup_actx = array_context
         self.bbox_finder = BoundingBoxFinder(array_context)
-        self.last_stage_times: dict[str, float] = {}
+        self._stage_times_of = None
+
+    @property
+    def last_stage_times(self):
+        """Milliseconds per stage of the last build and of the last traversal on the same
+        context (HIP events on the library's stream); waits for them to have completed."""
+        actx = self._stage_times_of
+        if actx is None:
+            return {}
+        st = _lib.StageTimes()
+        actx.lib.bt_get_stage_times(actx.handle, ct.byref(st))
+        return {st.name[i].decode(): float(st.ms[i]) for i in range(st.n)}
 
     def __call__(self, actx, particles, kind="adaptive",
                  max_particles_in_box=None, allocator=None, debug=False,
@@ -273,12 +284,15 @@ class TreeBuilder:
 
         # host side of the call: argument contract, weights, root box (helpers below)
         point_stride = int(kwargs.get("_point_stride") or 0)
+        _lib.host_trace("tb:enter")
         inp = _normalise_inputs(actx, kind, particles, targets, source_radii, target_radii,
                                 extent_norm, stick_out_factor, point_stride)
         refine_weights, max_leaf_refine_weight = _refine_weight_spec(
             actx, inp, max_particles_in_box, refine_weights, max_leaf_refine_weight)
+        _lib.host_trace("tb:inputs")
         box = _root_box(actx, self.bbox_finder, inp, bbox, kwargs.get("_root_box"),
                         TreeBuilder.ROOT_EXTENT_STRETCH_FACTOR)
+        _lib.host_trace("tb:rootbox")
 
         # names used by the rest of the call
         particles, targets = inp.particles, inp.targets
@@ -362,11 +376,12 @@ class TreeBuilder:
         (user_source_ids, sorted_target_ids, box_source_starts, box_source_counts_nonchild,
          box_source_counts_cumul, box_parent_ids, box_child_ids, box_centers, box_levels,
          box_flags, box_source_bounding_box_min, box_source_bounding_box_max,
-         *sources) = actx.empty_block([
+         level_start_box_nrs_dev, *sources) = actx.empty_block([
              (nsources, i32), (ntargets, i32), (nboxes, i32), (nboxes, i32), (nboxes, i32),
              (nboxes, i32), ((C, aligned_nboxes), i32), (grid, coord_dtype), (nboxes, np.uint8),
-             (nboxes, np.uint8), (grid, coord_dtype), (grid, coord_dtype),
+             (nboxes, np.uint8), (grid, coord_dtype), (grid, coord_dtype), (nlevels + 1, i32),
              *[(nsources, coord_dtype) for _ in range(dimensions)]])
+        out.level_start_box_nrs = ptr(level_start_box_nrs_dev)
 
         out.user_source_ids = ptr(user_source_ids)
         out.sorted_target_ids = ptr(sorted_target_ids)
@@ -410,12 +425,11 @@ class TreeBuilder:
             out.box_target_bounding_box_min = ptr(box_target_bounding_box_min)
             out.box_target_bounding_box_max = ptr(box_target_bounding_box_max)
 
+        _lib.host_trace("tb:outputs")
         _lib.check(lib.bt_tree_export(actx.handle, ct.byref(out)))
+        _lib.host_trace("tb:exported")
 
-        st = _lib.StageTimes()
-        lib.bt_get_stage_times(actx.handle, ct.byref(st))
-        self.last_stage_times = {
-            st.name[i].decode(): float(st.ms[i]) for i in range(st.n)}
+        self._stage_times_of = actx
 
         # }}}
 
@@ -437,7 +451,7 @@ class TreeBuilder:
             stick_out_factor=stick_out_factor,
             extent_norm=srcntgts_extent_norm,
 
-            level_start_box_nrs=actx.from_numpy(level_start_box_nrs),
+            level_start_box_nrs=level_start_box_nrs_dev,      # written by the export
 
             sources=sources_obj,
             targets=targets_obj,
@@ -467,6 +481,9 @@ class TreeBuilder:
 
             _is_pruned=not kwargs.get("skip_prune"),
         )
+        # host copy of the level starts for the traversal builder (a private attribute,
+        # not a field: copies made field by field fall back to reading the device array)
+        object.__setattr__(tree, "_host_level_starts", level_start_box_nrs.astype(np.int32))
 
         if srcntgts_have_extent and kind == "adaptive-level-restricted":
             # Upstream never tests this combination, and its algorithm -- followed line
@@ -484,6 +501,6 @@ class TreeBuilder:
                     "kind='adaptive-level-restricted' with particle extents left "
                     f"{int(orphaned.sum())} boxes whose particles no leaf owns; this input "
                     "is not supported")
-        return actx.freeze(tree), DoneEvent()
+        return actx.freeze(tree), (StreamEvent(actx) if actx.stream_ordered else DoneEvent())
 
 # vim: foldmethod=marker

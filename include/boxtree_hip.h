@@ -77,6 +77,20 @@ int bt_create(int device, void *hip_stream, bt_context **out);
 void bt_destroy(bt_context *ctx);
 /* release cached device workspace (kept between calls otherwise) */
 int bt_trim(bt_context *ctx);
+/* Run later calls on another stream (NULL: the legacy default stream); waits for the work
+ * queued on the old one first, because the workspace is ordered by the stream. */
+int bt_set_stream(bt_context *ctx, void *hip_stream);
+/* Stream-ordered results (off by default).  When on, bt_tree_export and
+ * bt_traversal_build_packed / bt_traversal_export return as soon as everything the host
+ * needs is known (sizes, level starts, spans): the kernels that fill the caller's arrays
+ * may still be running on the context's stream, so the arrays are valid for work queued on
+ * that stream afterwards -- or after bt_synchronize -- exactly like the (object, event)
+ * pairs the reference returns (tree_build.py:1868, traversal.py:2406).  The device-side
+ * status word of such a call is examined at the next wait on this context: an internal
+ * failure surfaces there (next call, or bt_synchronize). */
+int bt_set_stream_ordered(bt_context *ctx, int on);
+/* wait for the context's stream and report any deferred device-side failure */
+int bt_synchronize(bt_context *ctx);
 const char *bt_last_error_string(void);
 
 /* ---- bounding box (bounding_box.py:54-122, 163-174) --------------------- */
@@ -179,6 +193,7 @@ typedef struct {
     uint8_t *box_flags;                    /* [nboxes] */
     void *box_source_bounding_box_min, *box_source_bounding_box_max;  /* [d, aligned] */
     void *box_target_bounding_box_min, *box_target_bounding_box_max;  /* or NULL */
+    int32_t *level_start_box_nrs;          /* [nlevels+1] device copy of bt_tree_sizes', or NULL */
 } bt_tree_arrays;
 
 int bt_tree_export(bt_context *ctx, const bt_tree_arrays *out);

@@ -1,0 +1,44 @@
+#!/usr/bin/env python
+"""Idle time between kernels of the last bench step in a rocprofv3 rocpd database.
+
+usage: timeline_gaps.py DB [first-kernel-substring] [min-gap-us]
+
+A step starts at the first launch whose name contains the given substring (default
+"bbox_kernel") after a launch that does not; the last complete step is printed as a
+timeline: every gap of at least min-gap-us (default 4) with the kernels either side,
+and the totals (span, busy, idle, launches)."""
+import sqlite3
+import sys
+
+
+def main(path, first="bbox_kernel", min_gap_us="4"):
+    min_gap = float(min_gap_us) * 1e3
+    db = sqlite3.connect(path)
+    rows = db.execute("select name, start, end from kernels order by start").fetchall()
+    starts = [i for i, r in enumerate(rows)
+              if first in r[0] and (i == 0 or first not in rows[i - 1][0])]
+    if len(starts) < 2:
+        print("fewer than two steps found")
+        return
+    lo, hi = starts[-2], starts[-1]
+    step = rows[lo:hi]
+    t0 = step[0][1]
+    busy = sum(e - s for _, s, e in step)
+    span = step[-1][2] - t0
+    print(f"launches {len(step)}  span {span / 1e6:.3f} ms  busy {busy / 1e6:.3f} ms  "
+          f"idle {(span - busy) / 1e6:.3f} ms")
+    gaps = []
+    for (n0, s0, e0), (n1, s1, e1) in zip(step[:-1], step[1:]):
+        g = s1 - e0
+        gaps.append(g)
+        if g >= min_gap:
+            print(f"  t={(e0 - t0) / 1e3:9.1f} us  gap {g / 1e3:7.1f} us   "
+                  f"{n0.split('(')[0][-40:]:>40} -> {n1.split('(')[0][-40:]}")
+    small = sum(g for g in gaps if 0 < g < min_gap)
+    print(f"gaps below {min_gap / 1e3:.0f} us: {small / 1e6:.3f} ms in "
+          f"{sum(1 for g in gaps if 0 < g < min_gap)} places; "
+          f"overlapping launches: {sum(1 for g in gaps if g <= 0)}")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
