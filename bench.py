@@ -293,6 +293,7 @@ def main():
                              + int(trav.from_sep_close_bigger_lists.shape[0])))
         return st, times
 
+    actx.set_stage_timing(False)      # ~30 event records per step; see step()
     for _ in range(args.warmup):
         step()
 
@@ -310,6 +311,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     n_instrumented = 3
+    actx.set_stage_timing(True)
     for _ in range(n_instrumented):
         _, times = step(instrumented=True)
         for k, v in times.items():

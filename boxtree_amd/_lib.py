@@ -205,7 +205,7 @@ class TravPacked(ct.Structure):
 
 EXPORTED_SYMBOLS = [
     "bt_abi_version", "bt_create", "bt_destroy", "bt_trim", "bt_last_error_string",
-    "bt_set_stream", "bt_set_stream_ordered", "bt_synchronize",
+    "bt_set_stream", "bt_set_stream_ordered", "bt_synchronize", "bt_set_stage_timing",
     "bt_bbox", "bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32", "bt_get_sort_stats",
     "bt_tree_build", "bt_tree_export", "bt_get_stage_times",
     "bt_traversal_build", "bt_traversal_export", "bt_traversal_build_packed", "bt_merge_csr_lists",
@@ -257,6 +257,7 @@ def load():
     lib.bt_set_stream.argtypes = [vp, vp]
     lib.bt_set_stream_ordered.argtypes = [vp, ct.c_int]
     lib.bt_synchronize.argtypes = [vp]
+    lib.bt_set_stage_timing.argtypes = [vp, ct.c_int]
     lib.bt_bbox.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), vp, ct.c_int64,
                             ct.POINTER(ct.c_double), ct.POINTER(ct.c_double)]
     for name in ("bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32"):

@@ -76,6 +76,11 @@ class HIPArrayContext:
             _lib.check(self.lib.bt_set_stream(self.handle, ct.c_void_p(h)))
             self._stream_handle = h
 
+    def set_stage_timing(self, on):
+        """Per-stage HIP events of the builders (``TreeBuilder.last_stage_times``); on by
+        default, a few microseconds of stream bubble per stage."""
+        _lib.check(self.lib.bt_set_stage_timing(self.handle, int(bool(on))))
+
     def synchronize(self):
         """Wait for everything queued by the library; raises if a call that returned early
         failed on the device."""

@@ -171,6 +171,8 @@ struct bt_context {
     // queues the status read instead of waiting for it; sync_stream examines it later
     bool stream_ordered = false;
     bool status_inflight = false;
+    bool stage_timing = true;        // record the per-stage events (bt_set_stage_timing)
+    bool pinned_stores_ok = false;   // kernels may store into h_ring / h_status (probed at creation)
 };
 
 namespace bt {

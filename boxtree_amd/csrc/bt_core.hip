@@ -129,6 +129,43 @@ int scan_prepare(bt_context *ctx, int64_t ntiles, uint32_t *gen, uint32_t *ticke
     return BT_OK;
 }
 
+// Device-to-host reads are done by a kernel that stores straight into the pinned block
+// (hipHostMalloc memory is mapped into the device's address space): a hipMemcpyAsync is a
+// runtime blit with ~6 us of pipeline bubble either side, measured in the kernel trace; a
+// kernel queues like any other launch.
+__global__ __launch_bounds__(256) void copy_words_kernel(const uint32_t *src, uint32_t *dst, size_t nwords)
+{
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < nwords; i += (size_t) gridDim.x * 256)
+        dst[i] = src[i];
+}
+
+__global__ void fill_word_kernel(uint32_t *p, uint32_t v) { *p = v; }
+
+__global__ __launch_bounds__(256) void copy_bytes_kernel(const unsigned char *src, unsigned char *dst,
+                                                         size_t n)
+{
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256)
+        dst[i] = src[i];
+}
+
+static int copy_to_pinned(bt_context *ctx, void *pinned_dst, const void *dev_src, size_t bytes)
+{
+    if (!ctx->pinned_stores_ok) {
+        BT_HIP_CHECK(hipMemcpyAsync(pinned_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        return BT_OK;
+    }
+    if (((uintptr_t) dev_src | (uintptr_t) pinned_dst | bytes) % 4 == 0) {
+        const size_t nw = bytes / 4;
+        copy_words_kernel<<<(unsigned) std::min<size_t>(64, (nw + 255) / 256), 256, 0, ctx->stream>>>(
+            (const uint32_t *) dev_src, (uint32_t *) pinned_dst, nw);
+    } else {
+        copy_bytes_kernel<<<(unsigned) std::min<size_t>(64, (bytes + 255) / 256), 256, 0, ctx->stream>>>(
+            (const unsigned char *) dev_src, (unsigned char *) pinned_dst, bytes);
+    }
+    BT_HIP_CHECK(hipGetLastError());
+    return BT_OK;
+}
+
 int d2h(bt_context *ctx, void *host_dst, const void *dev_src, size_t bytes)
 {
     if (bytes == 0) return BT_OK;
@@ -141,7 +178,7 @@ int d2h(bt_context *ctx, void *host_dst, const void *dev_src, size_t bytes)
     }
     char *slot = ctx->h_ring + ctx->h_ring_used;
     ctx->h_ring_used += need;
-    BT_HIP_CHECK(hipMemcpyAsync(slot, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BT_CHECK(copy_to_pinned(ctx, slot, dev_src, bytes));
     ctx->pending_reads.push_back({host_dst, slot, bytes});
     return BT_OK;
 }
@@ -181,8 +218,7 @@ int sync_stream(bt_context *ctx)
 int finish_call(bt_context *ctx)
 {
     if (!ctx->stream_ordered) return check_status(ctx);
-    BT_HIP_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(DeviceStatus),
-                                hipMemcpyDeviceToHost, ctx->stream));
+    BT_CHECK(copy_to_pinned(ctx, ctx->h_status, ctx->d_status, sizeof(DeviceStatus)));
     ctx->status_inflight = true;
     return BT_OK;
 }
@@ -195,8 +231,7 @@ int reset_status(bt_context *ctx)
 
 int check_status(bt_context *ctx)
 {
-    BT_HIP_CHECK(hipMemcpyAsync(ctx->h_status, ctx->d_status, sizeof(DeviceStatus),
-                                hipMemcpyDeviceToHost, ctx->stream));
+    BT_CHECK(copy_to_pinned(ctx, ctx->h_status, ctx->d_status, sizeof(DeviceStatus)));
     ctx->status_inflight = true;
     return sync_stream(ctx);
 }
@@ -248,6 +283,18 @@ int bt_create(int device, void *hip_stream, bt_context **out)
     memset(ctx->h_status, 0, sizeof(bt::DeviceStatus));
     int s = bt::reset_status(ctx);
     if (s != BT_OK) { bt_destroy(ctx); return s; }
+    {
+        // can a kernel store into the pinned block, and does the host see it after a wait?
+        // (otherwise the reads fall back to hipMemcpyAsync)
+        uint32_t *probe = (uint32_t *) ctx->h_ring;
+        probe[0] = 0; probe[1] = 0;
+        bt::copy_words_kernel<<<1, 256, 0, ctx->stream>>>((const uint32_t *) ctx->d_status, probe + 1, 1);
+        bt::fill_word_kernel<<<1, 1, 0, ctx->stream>>>(probe, 0x600DF00Du);
+        const bool ok = hipGetLastError() == hipSuccess
+                        && hipStreamSynchronize(ctx->stream) == hipSuccess && probe[0] == 0x600DF00Du;
+        if (!ok) (void) hipGetLastError();
+        ctx->pinned_stores_ok = ok && !getenv("BT_NO_PINNED_STORES");
+    }
     *out = ctx;
     return BT_OK;
 }
@@ -288,6 +335,13 @@ int bt_set_stream_ordered(bt_context *ctx, int on)
 {
     if (!ctx) return BT_ERR_INVALID;
     ctx->stream_ordered = on != 0;
+    return BT_OK;
+}
+
+int bt_set_stage_timing(bt_context *ctx, int on)
+{
+    if (!ctx) return BT_ERR_INVALID;
+    ctx->stage_timing = on != 0;
     return BT_OK;
 }
 

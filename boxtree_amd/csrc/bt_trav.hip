@@ -712,6 +712,7 @@ inline unsigned nblk(int64_t n) { return (unsigned) std::max<int64_t>(1, div_up(
 int tmark(bt_context *ctx, TravState *st, const char *name)
 {
     host_trace(name);
+    if (!ctx->stage_timing) return BT_OK;
     hipEvent_t e;
     BT_HIP_CHECK(hipEventCreate(&e));
     BT_HIP_CHECK(hipEventRecord(e, ctx->stream));

@@ -1555,6 +1555,7 @@ namespace {
 int mark(bt_context *ctx, TreeState *st, const char *name)
 {
     host_trace(name);
+    if (!ctx->stage_timing) return BT_OK;
     hipEvent_t e;
     BT_HIP_CHECK(hipEventCreate(&e));
     BT_HIP_CHECK(hipEventRecord(e, ctx->stream));

@@ -91,6 +91,10 @@ int bt_set_stream(bt_context *ctx, void *hip_stream);
 int bt_set_stream_ordered(bt_context *ctx, int on);
 /* wait for the context's stream and report any deferred device-side failure */
 int bt_synchronize(bt_context *ctx);
+/* Per-stage HIP events of the builders (bt_get_stage_times); on by default.  An event
+ * record costs a few microseconds of pipeline bubble on the stream, ~30 of them per build +
+ * traversal: switch them off where only the result matters. */
+int bt_set_stage_timing(bt_context *ctx, int on);
 const char *bt_last_error_string(void);
 
 /* ---- bounding box (bounding_box.py:54-122, 163-174) --------------------- */

@@ -24,6 +24,7 @@ g.manual_seed(15)
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10**7
 pts = [torch.rand(n, generator=g, dtype=torch.float64, device="cuda") for _ in range(3)]
 tb, tg = TreeBuilder(actx), FMMTraversalBuilder(actx)
+actx.set_stage_timing(os.environ.get("BT_STAGE_EVENTS", "0") == "1")
 for _ in range(4):
     torch.cuda.synchronize()
     stamp("step")
