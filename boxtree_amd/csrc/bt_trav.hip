@@ -653,6 +653,8 @@ struct TravState {
     const int32_t *target_boxes = nullptr;
     Buf<int32_t> lev_starts;           // [4][nlevels+1]
     std::vector<int32_t> h_lev_starts; // host copy
+    Buf<int32_t> parent_boxes;         // boxes with children, in box order (row 4 of lev_starts)
+    int64_t nparents = 0;
     Buf<int32_t> d_level_start_box_nrs;
     CsrList coll, l1, l2, l4, close_smaller, close_bigger;
     // list 3: flat level-major
@@ -1422,8 +1424,12 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             b0 = p.active_level_ranges[2 * lev];
             nb = p.active_level_ranges[2 * lev + 1] - b0;
         }
-        if (nb > 0)
-            coll_rows_v2_kernel<D, false><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(rows, b0, nb);
+        // a group of lanes per box of the level above that has children
+        const int32_t *pls = st->h_lev_starts.data() + 4 * (nlevels + 1);
+        const int32_t np = pls[lev] - pls[lev - 1];
+        if (nb > 0 && np > 0)
+            coll_rows_v3_kernel<D, false><<<nblk((int64_t) np * V3Lanes<D>::N), 256, 0, ctx->stream>>>(
+                rows, st->parent_boxes.get() + pls[lev - 1], np, b0, b0 + nb);
     }
     a.srccoll_rows = srccoll_rows.get();       // list 4 walks the same rows
     a.srccoll_cnt = srccoll_cnt.get();
@@ -1651,9 +1657,9 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             (int32_t) c.n, st->ttp_boxes.get(), l2_by_box.get(), (int32_t) B, c.starts.get());
         rows.l2_starts = l2_by_box.get();
         rows.l2_lists = c.lists.get();
-        if (B > 1 && c.total > 0)
-            coll_rows_v2_kernel<D, true><<<nblk((B - 1) * C), 256, 0, ctx->stream>>>(
-                rows, 1, (int32_t) (B - 1));
+        if (B > 1 && c.total > 0 && st->nparents > 0)
+            coll_rows_v3_kernel<D, true><<<nblk(st->nparents * V3Lanes<D>::N), 256, 0, ctx->stream>>>(
+                rows, st->parent_boxes.get(), (int32_t) st->nparents, 1, (int32_t) B);
     }
     BT_CHECK(tmark(ctx, st, "trav:colleagues+list2"));
 
@@ -1780,15 +1786,19 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     BT_CHECK(st->d_level_start_box_nrs.alloc(ctx->pool, nlevels + 1));
     BT_HIP_CHECK(hipMemcpyAsync(st->d_level_start_box_nrs.get(), p.level_start_box_nrs,
                                 (size_t) (nlevels + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
-    BT_CHECK(st->lev_starts.alloc(ctx->pool, 4 * (nlevels + 1)));
+    // (a fifth list, not part of the result: the boxes that have children, level by
+    // level -- the colleague-row kernels run one group of lanes per such box)
+    constexpr int NL = 5;
+    BT_CHECK(st->lev_starts.alloc(ctx->pool, NL * (nlevels + 1)));
     const bool shared_tb = sat && !p.target_boxes_mask;     // target_boxes is source_boxes
-    FlagPred preds[4] = {
+    FlagPred preds[NL] = {
         {p.box_flags, p.source_boxes_mask, BT_BOX_IS_SOURCE_BOX},
         {p.box_flags, p.target_boxes_mask, BT_BOX_IS_TARGET_BOX},
         {p.box_flags, p.source_parent_boxes_mask, BT_BOX_HAS_SOURCE_CHILD_BOXES},
-        {p.box_flags, p.target_boxes_mask, BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX}};
-    Buf<int32_t> pos[4];
-    for (int k = 0; k < 4; ++k) {
+        {p.box_flags, p.target_boxes_mask, BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX},
+        {p.box_flags, nullptr, BT_BOX_HAS_SOURCE_CHILD_BOXES | BT_BOX_HAS_TARGET_CHILD_BOXES}};
+    Buf<int32_t> pos[NL];
+    for (int k = 0; k < NL; ++k) {
         if (k == 1 && shared_tb) continue;
         BT_CHECK(pos[k].alloc(ctx->pool, B + 1));
         BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, preds[k], B, pos[k].get(),
@@ -1808,7 +1818,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
             p.box_flags, (const T *) p.box_centers, (T) p.root_extent, bad.get());
     int32_t hb[4] = {1, 1, 1, 0};
     T root_center[D];
-    st->h_lev_starts.assign((size_t) 4 * (nlevels + 1), 0);
+    st->h_lev_starts.assign((size_t) NL * (nlevels + 1), 0);
     BT_CHECK(bt::d2h(ctx, st->h_lev_starts.data(), st->lev_starts.get(), st->h_lev_starts.size() * 4));
     BT_CHECK(bt::d2h(ctx, hb, bad.get(), 16));
     for (int d = 0; d < D; ++d)
@@ -1822,10 +1832,11 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         st->ntb = h[1 * (nlevels + 1) + nlevels];
         st->nspb = h[2 * (nlevels + 1) + nlevels];
         st->nttp = h[3 * (nlevels + 1) + nlevels];
-        Buf<int32_t> *lists[4] = {&st->source_boxes, &st->target_boxes_buf,
-                                  &st->source_parent_boxes, &st->ttp_boxes};
-        const int64_t ns[4] = {st->nsb, st->ntb, st->nspb, st->nttp};
-        for (int k = 0; k < 4; ++k) {
+        st->nparents = h[4 * (nlevels + 1) + nlevels];
+        Buf<int32_t> *lists[NL] = {&st->source_boxes, &st->target_boxes_buf,
+                                   &st->source_parent_boxes, &st->ttp_boxes, &st->parent_boxes};
+        const int64_t ns[NL] = {st->nsb, st->ntb, st->nspb, st->nttp, st->nparents};
+        for (int k = 0; k < NL; ++k) {
             if (k == 1 && shared_tb) continue;
             BT_CHECK(lists[k]->alloc(ctx->pool, ns[k]));
             compact_kernel<<<nblk(B), 256, 0, ctx->stream>>>(preds[k], (int32_t) B, pos[k].get(),

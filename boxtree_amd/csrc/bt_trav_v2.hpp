@@ -103,106 +103,239 @@ struct V2Rows {
     int32_t *l2_lists;
 };
 
-// C lanes per box, lane m looks at child slot m of every candidate parent
-// (colleagues of the box's parent, and the parent itself at its depth-first place).
-// FILL = false: build the box's own row, count its list 2.
-// FILL = true : write list 2 (all levels in one launch; rows are complete by then).
+// One group of lanes per PARENT and one lane per candidate (a colleague of the parent, or
+// the parent itself, at its depth-first place).  FILL = false: build the children's rows,
+// count their lists 2.  FILL = true: write list 2 (all levels in one launch; rows are
+// complete by then).  The children of one parent share
+// their candidates, so the group loads each candidate's 2^d child words once (one or two
+// vector loads per lane) and then serves the parent's children one after the other
+// without another load.  Whether child slot m of a candidate at offset d (per axis -1, 0,
+// +1) is adjacent to the child in slot sb does not depend on the data: per axis
+// rel = 2 d + m_ax - sb_ax must lie in [-1, 1], i.e. d = 0 always, d = -1 only for
+// (m_ax, sb_ax) = (1, 0), d = +1 only for (0, 1) -- so "present", "source" and
+// "adjacent" are bit masks over the child slots, the lanes agree on write positions with
+// one packed prefix sum per child, and each lane writes its (at most 2^d) entries.
+// An earlier form (a group of 2^d lanes per BOX, a lane per child slot, one 4-byte load per
+// candidate and lane, two ballots per candidate) took 10-14 % longer at 10^8 sphere points;
+// both forms are bound by vector-ALU issue (SQ_INSTS_VALU x 4 cycles per wave64
+// instruction / 1024 SIMDs accounts for the whole duration), not by memory: see DESIGN.md
+// section 4.
+template <int D> struct V3Lanes { static constexpr int N = D == 3 ? 32 : D == 2 ? 16 : 4; };
+
+// inclusive prefix sum over aligned groups of LANES (4, 16 or 32) lanes with DPP moves
+// (row_shr within a row of 16 lanes, row_bcast:15 from one row into the next): five
+// dependent adds, where shuffles through ds_bpermute cost an LDS round trip each
+template <int LANES>
+__device__ __forceinline__ uint32_t v3_group_scan(uint32_t v)
+{
+    static_assert(LANES == 16 || LANES == 32, "groups of 4 lanes: see the specialisation");
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);
+    if (LANES == 32)
+        v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);
+    return v;
+}
+
+template <>
+__device__ __forceinline__ uint32_t v3_group_scan<4>(uint32_t v)
+{
+    const int j = threadIdx.x & 3;
+    uint32_t up = (uint32_t) __shfl_up((int) v, 1, 4);
+    if (j >= 1) v += up;
+    up = (uint32_t) __shfl_up((int) v, 2, 4);
+    if (j >= 2) v += up;
+    return v;
+}
+
+// (M(m) - S(sb)) << V2_CODE_SHIFT, modulo 2^32 (see coll_rows_v3_kernel)
+template <int D>
+__device__ __forceinline__ constexpr uint32_t v3_code_delta(int m, int sb)
+{
+    uint32_t r = 0;
+    for (int ax = 0; ax < D; ++ax) {
+        r += (uint32_t) ((m >> (D - 1 - ax)) & 1) << (2 * ax);
+        r -= (uint32_t) ((sb >> (D - 1 - ax)) & 1) << (2 * ax);
+    }
+    return r << V2_CODE_SHIFT;
+}
+
+template <int D>
+__device__ __forceinline__ constexpr uint32_t v3_set_mask(int ax)
+{
+    // child slots m whose bit for axis `ax` is set (v2_mbit)
+    uint32_t r = 0;
+    for (int m = 0; m < (1 << D); ++m) if ((m >> (D - 1 - ax)) & 1) r |= 1u << m;
+    return r;
+}
+
+// parents[0 .. np): boxes that have children; rows / lists are made for their children in
+// [b_lo, b_hi)
 template <int D, bool FILL>
-__global__ __launch_bounds__(256) void coll_rows_v2_kernel(V2Rows<D> t, int32_t b0, int32_t nb)
+__global__ __launch_bounds__(256) void coll_rows_v3_kernel(V2Rows<D> t, const int32_t *parents, int32_t np,
+        int32_t b_lo, int32_t b_hi)
 {
     constexpr int C = 1 << D;
     constexpr int P = V2Dims<D>::P;
+    constexpr int LANES = V3Lanes<D>::N;
+    constexpr uint32_t FULL = (1u << C) - 1u;
     const int32_t tid = blockIdx.x * 256 + threadIdx.x;
-    const int32_t g = tid / C;
-    const int m = tid % C;
-    if (g >= nb) return;                 // whole groups drop out together
-    const int32_t b = b0 + g;
-    const int lane = threadIdx.x & 63;
-    const int gshift = lane / C * C;
-    const uint64_t gmask = (C == 64) ? ~0ull : ((1ull << C) - 1ull);
-    const uint64_t lanes_below = (1ull << m) - 1ull;
+    const int32_t g = tid / LANES;
+    const int j = tid % LANES;
+    if (g >= np) return;                 // whole groups drop out together
+    const int32_t p = parents[g];
 
-    int32_t lcur = 0;
-    if (FILL) {
-        lcur = t.l2_starts[b];
-        if (t.l2_starts[b + 1] == lcur) return;      // group-uniform
+    // the parent's own children (every lane reads the same words)
+    uint32_t kid[C];
+    {
+        const int32_t *src = t.child_t + (int64_t) p * C;
+        if constexpr (C == 8) {
+            const int4 lo = *reinterpret_cast<const int4 *>(src);
+            const int4 hi = *reinterpret_cast<const int4 *>(src + 4);
+            kid[0] = lo.x; kid[1] = lo.y; kid[2] = lo.z; kid[3] = lo.w;
+            kid[4] = hi.x; kid[5] = hi.y; kid[6] = hi.z; kid[7] = hi.w;
+        } else if constexpr (C == 4) {
+            const int4 lo = *reinterpret_cast<const int4 *>(src);
+            kid[0] = lo.x; kid[1] = lo.y; kid[2] = lo.z; kid[3] = lo.w;
+        } else {
+            const int2 lo = *reinterpret_cast<const int2 *>(src);
+            kid[0] = lo.x; kid[1] = lo.y;
+        }
     }
-    const int32_t p = t.parent[b];
-    const int sb = t.slot_of[b];
-    const uint8_t fl = t.flags[b];
-    const bool ttp = (fl & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX))
-        && (!t.target_mask || t.target_mask[b]);    // list 2 only for wanted boxes
-    const int32_t *prow = t.coll_rows + (int64_t) p * P;
+
+    // Everything the children's turns need is loaded here, before the first store: loads
+    // and stores complete in order on this hardware, so a load issued after a turn's stores
+    // would wait for them (a full round trip per child).
     const int n = t.coll_cnt[p];
     const int ins = t.coll_ins[p];
-    int rel0[D];
+    const uint32_t e_at = (uint32_t) t.coll_rows[(int64_t) p * P + (j < P ? j : P - 1)];
+    const uint32_t e_before = (uint32_t) t.coll_rows[(int64_t) p * P + (j >= 1 && j <= P ? j - 1 : 0)];
+    bool want[C];               // FILL: list 2 not empty; else: the box wants a list 2
+    int32_t lstart[C];
 #pragma unroll
-    for (int ax = 0; ax < D; ++ax) rel0[ax] = v2_mbit<D>(m, ax) - v2_mbit<D>(sb, ax);
-
-    int32_t *crow = t.coll_rows + (int64_t) b * P;
-    int32_t *srow = t.srccoll_rows + (int64_t) b * P;
-    int32_t ccur = 0, scur = 0, lcnt = 0;
-    // the parent's row is read once, spread over the group's lanes (entry i sits in
-    // register i / C of lane i % C): the loop below then depends on ONE load per
-    // candidate (its child slot), not on a chain row entry -> child slot
-    constexpr int NREG = (P + C - 1) / C;
-    uint32_t preg[NREG];
-#pragma unroll
-    for (int j = 0; j < NREG; ++j) preg[j] = (m + C * j < n) ? (uint32_t) prow[m + C * j] : 0u;
-    constexpr int UNR = 8;
-    for (int i0 = 0; i0 <= n; i0 += UNR) {
-        uint32_t es[UNR], chs[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const int i = i0 + u;
-            const int ii = (i < ins) ? i : i - 1;        // index into the parent's row
-            uint32_t sel = preg[0];
-#pragma unroll
-            for (int j = 1; j < NREG; ++j) sel = (ii / C == j) ? preg[j] : sel;
-            const uint32_t e = (uint32_t) __shfl((int) sel, (ii < 0 ? 0 : ii) % C, C);
-            es[u] = (i > n) ? 0u : (i == ins ? ((uint32_t) p | (V2_CODE_SELF << V2_CODE_SHIFT)) : e);
-        }
-#pragma unroll
-        for (int u = 0; u < UNR; ++u)
-            chs[u] = (i0 + u <= n)
-                ? (uint32_t) t.child_t[(int64_t) (es[u] & V2_ID_MASK) * C + m] : 0u;
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            if (i0 + u > n) break;                      // uniform within the group
-            const uint32_t ch = chs[u] & CH_ID_MASK;
-            bool adjacent = true;
-            uint32_t code = 0;
-#pragma unroll
-            for (int ax = 0; ax < D; ++ax) {
-                const int rel = 2 * v2_off(es[u], ax) + rel0[ax];
-                adjacent = adjacent && rel >= -1 && rel <= 1;
-                code |= (uint32_t) ((rel + 1) & 3) << (2 * ax);
+    for (int sb = 0; sb < C; ++sb) {
+        const int32_t b = (int32_t) (kid[sb] & CH_ID_MASK);
+        const bool mine = b != 0 && b >= b_lo && b < b_hi;
+        want[sb] = false; lstart[sb] = 0;
+        if (FILL) {
+            if (mine) {
+                lstart[sb] = t.l2_starts[b];
+                want[sb] = t.l2_starts[b + 1] != lstart[sb];
             }
-            const bool is_coll = ch != 0 && ch != (uint32_t) b && adjacent;   // traversal.py:429-442
-            const bool is_l2 = ch != 0 && !adjacent && ttp;                  // traversal.py:588-597
-            if (!FILL) {
-                const bool is_src = is_coll && (chs[u] & CH_SRC);
-                const uint64_t bc = (__ballot(is_coll) >> gshift) & gmask;
-                const uint64_t bs = (__ballot(is_src) >> gshift) & gmask;
-                const uint32_t entry = ch | (code << V2_CODE_SHIFT);
-                // the candidates come in depth-first order; b itself is one of them
-                if (ch == (uint32_t) b) t.coll_ins[b] = ccur + __popcll(bc & lanes_below);
-                if (is_coll) crow[ccur + __popcll(bc & lanes_below)] = (int32_t) entry;
-                if (is_src) srow[scur + __popcll(bs & lanes_below)] = (int32_t) entry;
-                ccur += __popcll(bc);
-                scur += __popcll(bs);
-                lcnt += is_l2 ? 1 : 0;
-            } else {
-                const uint64_t bl = (__ballot(is_l2) >> gshift) & gmask;
-                if (is_l2) t.l2_lists[lcur + __popcll(bl & lanes_below)] = (int32_t) ch;
-                lcur += __popcll(bl);
-            }
+        } else if (mine) {
+            const uint8_t fl = t.flags[b];
+            want[sb] = (fl & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX))
+                && (!t.target_mask || t.target_mask[b]);        // list 2 only for wanted boxes
         }
     }
-    if (!FILL) {
+    // candidate j: the parent's colleagues in depth-first order, the parent itself at
+    // its own place `ins` (n + 1 candidates)
+    const bool valid = j <= n;
+    const bool self = valid && j == ins;
+    uint32_t e = 0;
+    if (valid)
+        e = self ? ((uint32_t) p | (V2_CODE_SELF << V2_CODE_SHIFT)) : (j < ins ? e_at : e_before);
+    const uint32_t q = e & V2_ID_MASK;
+
+    uint32_t ch[C];
 #pragma unroll
-        for (int off = C / 2; off > 0; off >>= 1) lcnt += __shfl_xor(lcnt, off, C);
-        if (m == 0) { t.coll_cnt[b] = ccur; t.srccoll_cnt[b] = scur; t.l2_cnt[b] = lcnt; }
+    for (int m = 0; m < C; ++m) ch[m] = 0;
+    if (valid && !self) {
+        const int32_t *src = t.child_t + (int64_t) q * C;
+        if constexpr (C == 8) {
+            const int4 lo = *reinterpret_cast<const int4 *>(src);
+            const int4 hi = *reinterpret_cast<const int4 *>(src + 4);
+            ch[0] = lo.x; ch[1] = lo.y; ch[2] = lo.z; ch[3] = lo.w;
+            ch[4] = hi.x; ch[5] = hi.y; ch[6] = hi.z; ch[7] = hi.w;
+        } else if constexpr (C == 4) {
+            const int4 lo = *reinterpret_cast<const int4 *>(src);
+            ch[0] = lo.x; ch[1] = lo.y; ch[2] = lo.z; ch[3] = lo.w;
+        } else {
+            const int2 lo = *reinterpret_cast<const int2 *>(src);
+            ch[0] = lo.x; ch[1] = lo.y;
+        }
+    } else if (self) {
+#pragma unroll
+        for (int m = 0; m < C; ++m) ch[m] = kid[m];
+    }
+    uint32_t present = 0, source = 0;
+#pragma unroll
+    for (int m = 0; m < C; ++m) {
+        present |= ((ch[m] & CH_ID_MASK) != 0u ? 1u : 0u) << m;
+        source |= ((ch[m] & CH_SRC) != 0u ? 1u : 0u) << m;
+    }
+    // per axis: the child slots of this candidate adjacent to a child whose own bit on
+    // that axis is 0 (adj0) or 1 (adj1)
+    uint32_t adj0[D], adj1[D];
+    // The code of child slot m of this candidate in the row of the parent's child sb is, per
+    // axis, rel + 1 = (2 d + 1) + m_ax - sb_ax, a value in [0, 2] for adjacent pairs: the
+    // fields never borrow from each other, so the whole code is one integer sum
+    // off + M(m) - S(sb) with compile-time M and S.
+    uint32_t off = 0;
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        const int d = v2_off(e, ax);
+        const uint32_t set = v3_set_mask<D>(ax);
+        adj0[ax] = d == 0 ? FULL : d < 0 ? set : 0u;
+        adj1[ax] = d == 0 ? FULL : d > 0 ? (FULL & ~set) : 0u;
+        off += (uint32_t) (2 * d + 1) << (2 * ax);
+    }
+    off <<= V2_CODE_SHIFT;
+    uint32_t chid[C];
+#pragma unroll
+    for (int m = 0; m < C; ++m) chid[m] = (ch[m] & CH_ID_MASK) + off;
+
+#pragma unroll
+    for (int sb = 0; sb < C; ++sb) {
+        const int32_t b = (int32_t) (kid[sb] & CH_ID_MASK);
+        if (b == 0 || b < b_lo || b >= b_hi) continue;          // group-uniform
+        if (FILL && !want[sb]) continue;                        // group-uniform
+        const int32_t lbase = lstart[sb];
+        const bool ttp = want[sb];
+        uint32_t adjacent = FULL;
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) adjacent &= v2_mbit<D>(sb, ax) ? adj1[ax] : adj0[ax];
+        uint32_t cm = present & adjacent;                       // traversal.py:429-442
+        if (self) cm &= ~(1u << sb);                            // the box itself
+        const uint32_t lm = ttp ? (present & ~adjacent & FULL) : 0u;   // traversal.py:588-597
+        const uint32_t sm = cm & source;
+
+        // positions: an inclusive scan of (colleagues | source colleagues << 10 | list 2 << 20)
+        const uint32_t packed = FILL ? (uint32_t) __popc(lm)
+                                     : ((uint32_t) __popc(cm) | ((uint32_t) __popc(sm) << 10)
+                                        | ((uint32_t) __popc(lm) << 20));
+        const uint32_t incl = v3_group_scan<LANES>(packed);
+        const uint32_t excl = incl - packed;
+
+        // Each lane writes its own entries (at most 2^d stores, a few lanes each).  Putting
+        // a row together in LDS first and writing it with one store was measured slower:
+        // what this kernel spends its time on is the chain of dependent steps per child --
+        // masks, scan, addresses --, and stores are not part of it.
+        if (!FILL) {
+            int32_t *crow = t.coll_rows + (int64_t) b * P;
+            int32_t *srow = t.srccoll_rows + (int64_t) b * P;
+            int pc = (int) (excl & 0x3ffu), ps = (int) ((excl >> 10) & 0x3ffu);
+            if (self) t.coll_ins[b] = pc + __popc(cm & ((1u << sb) - 1u));
+#pragma unroll
+            for (int m = 0; m < C; ++m) {
+                if ((cm >> m) & 1u) {
+                    const int32_t entry = (int32_t) (chid[m] + v3_code_delta<D>(m, sb));
+                    crow[pc++] = entry;
+                    if ((sm >> m) & 1u) srow[ps++] = entry;
+                }
+            }
+            if (j == LANES - 1) {               // the last lane's inclusive sums are the totals
+                t.coll_cnt[b] = (int32_t) (incl & 0x3ffu);
+                t.srccoll_cnt[b] = (int32_t) ((incl >> 10) & 0x3ffu);
+                t.l2_cnt[b] = (int32_t) (incl >> 20);
+            }
+        } else {
+            int32_t pl = lbase + (int32_t) excl;
+#pragma unroll
+            for (int m = 0; m < C; ++m)
+                if ((lm >> m) & 1u) t.l2_lists[pl++] = (int32_t) (ch[m] & CH_ID_MASK);
+        }
     }
 }
 

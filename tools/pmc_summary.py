@@ -12,7 +12,7 @@ def main(path, out=None):
         "order by sum(value) desc").fetchall()
     lines = ["Kernel,Counter,Dispatches,Avg,Min,Max"]
     for name, ctr, n, avg, mn, mx in rows:
-        short = name.split("(")[0][-80:]
+        short = name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-80:]
         lines.append(f"\"{short}\",{ctr},{n},{avg:.3f},{mn:.3f},{mx:.3f}")
     text = "\n".join(lines) + "\n"
     if out:
