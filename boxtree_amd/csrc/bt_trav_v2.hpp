@@ -48,6 +48,25 @@ __device__ __forceinline__ int v2_off(uint32_t e, int ax)
 template <int D>
 __device__ __forceinline__ int v2_mbit(int m, int ax) { return (m >> (D - 1 - ax)) & 1; }
 
+// the 2^d packed child words of a box with one or two vector loads
+template <int C>
+__device__ __forceinline__ void v2_load_children(const int32_t *child_t, int32_t box, uint32_t (&cw)[C])
+{
+    const int32_t *src = child_t + (int64_t) box * C;
+    if constexpr (C == 8) {
+        const int4 lo = *reinterpret_cast<const int4 *>(src);
+        const int4 hi = *reinterpret_cast<const int4 *>(src + 4);
+        cw[0] = lo.x; cw[1] = lo.y; cw[2] = lo.z; cw[3] = lo.w;
+        cw[4] = hi.x; cw[5] = hi.y; cw[6] = hi.z; cw[7] = hi.w;
+    } else if constexpr (C == 4) {
+        const int4 lo = *reinterpret_cast<const int4 *>(src);
+        cw[0] = lo.x; cw[1] = lo.y; cw[2] = lo.z; cw[3] = lo.w;
+    } else {
+        const int2 lo = *reinterpret_cast<const int2 *>(src);
+        cw[0] = lo.x; cw[1] = lo.y;
+    }
+}
+
 // ---- per-tree tables: slot in the parent, integer cells, depth-first ranks ----------
 
 template <int D>
@@ -572,8 +591,15 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         int size = 0, mnr = 0;
         int32_t parent = nws;
         bool go = true;
+        // The 2^d child words of the box being scanned sit in registers (one or two vector
+        // loads when the scan enters or returns to a box) and a step selects among them:
+        // a 4-byte load per step made every step wait for a load of its own.
+        uint32_t cw[C];
+        v2_load_children<C>(w.child_t, parent, cw);
         while (go) {
-            const uint32_t raw = (uint32_t) w.child_t[(int64_t) parent * C + mnr];
+            uint32_t raw = cw[0];
+#pragma unroll
+            for (int m = 1; m < C; ++m) raw = (mnr == m) ? cw[m] : raw;
             const int32_t wb = (int32_t) (raw & CH_ID_MASK);
             bool descend = false;
             int rel[D];
@@ -642,10 +668,12 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                 stk[size * WALK_THREADS] = parent | (mnr << 28);
                 ++size;
                 parent = wb; mnr = 0;
+                v2_load_children<C>(w.child_t, parent, cw);
 #pragma unroll
                 for (int ax = 0; ax < D; ++ax) prel[ax] = rel[ax];
                 continue;
             }
+            bool popped = false;
             while (true) {                              // walk_advance
                 ++mnr;
                 if (mnr < C) break;
@@ -655,9 +683,11 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                 const int32_t e = stk[size * WALK_THREADS];
                 parent = e & 0x0fffffff;
                 mnr = (int) ((uint32_t) e >> 28);
+                popped = true;
 #pragma unroll
                 for (int ax = 0; ax < D; ++ax) prel[ax] >>= 1;
             }
+            if (popped && go) v2_load_children<C>(w.child_t, parent, cw);
         }
     }
 
