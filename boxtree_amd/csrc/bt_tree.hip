@@ -1036,30 +1036,40 @@ __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, cons
     if (lane + 32 < n) ids[s + lane + 32] = v1;
 }
 
+// The number of listed runs is read on the device (flags->n_large): the launch needs no
+// host round trip; a run longer than the workgroup sort on a build that cannot have one
+// is reported through the status word.
 __global__ __launch_bounds__(256) void segment_sort_block_kernel(const int32_t *large_list,
+        const SegSortFlags *flags, int huge_is_error, DeviceStatus *status,
         const int32_t *box_start, const int32_t *box_count, uint32_t *ids)
 {
     __shared__ uint32_t s_v[SEG_BLOCK_MAX];
-    const int b = large_list[blockIdx.x];
-    const int s = box_start[b], n = box_count[b];
-    int m = 128;
-    while (m < n) m <<= 1;
-    for (int i = threadIdx.x; i < m; i += 256) s_v[i] = (i < n) ? ids[s + i] : 0xFFFFFFFFu;
-    __syncthreads();
-    for (int k = 2; k <= m; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < m; i += 256) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const uint32_t a = s_v[i], c = s_v[l];
-                    const bool up = (i & k) == 0;
-                    if ((a > c) == up) { s_v[i] = c; s_v[l] = a; }
+    if (huge_is_error && flags->has_huge && blockIdx.x == 0 && threadIdx.x == 0)
+        atomicExch(&status->internal, 41);
+    const int nl = flags->n_large;
+    for (int r = blockIdx.x; r < nl; r += gridDim.x) {
+        const int b = large_list[r];
+        const int s = box_start[b], n = box_count[b];
+        int m = 128;
+        while (m < n) m <<= 1;
+        for (int i = threadIdx.x; i < m; i += 256) s_v[i] = (i < n) ? ids[s + i] : 0xFFFFFFFFu;
+        __syncthreads();
+        for (int k = 2; k <= m; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = threadIdx.x; i < m; i += 256) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const uint32_t a = s_v[i], c = s_v[l];
+                        const bool up = (i & k) == 0;
+                        if ((a > c) == up) { s_v[i] = c; s_v[l] = a; }
+                    }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
+        for (int i = threadIdx.x; i < n; i += 256) ids[s + i] = s_v[i];
+        __syncthreads();
     }
-    for (int i = threadIdx.x; i < n; i += 256) ids[s + i] = s_v[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -1528,6 +1538,12 @@ struct TreeState {
     uint32_t *ids = nullptr;           // final tree order -> user srcntgt id
     uint32_t *ids_other = nullptr;     // the other id buffer (scratch of the global fix-up)
     bool fixup_done = false;           // ids are in the reference's within-box order
+    // the fix-up is started by the build and finished by the export (fixup_launch /
+    // fixup_finish): the caller allocates its arrays in between, while the kernel runs
+    bool fixup_pending = false;
+    Buf<int32_t> fix_large_list;
+    Buf<SegSortFlags> fix_flags;
+    SegSortFlags h_fix{};
     Buf<int64_t> wprefix;
     Buf<int32_t> src_prefix;           // [N+1] (separate targets only)
     Buf<int32_t> srcntgt_target_ids;   // [ntargets]
@@ -1544,6 +1560,8 @@ struct TreeState {
 void bt_free_tree_state(bt_context *ctx)
 {
     if (ctx->tree) {
+        // a read queued into this state (fixup_launch) must not outlive it
+        if (ctx->tree->fixup_pending) (void) bt::sync_stream(ctx);
         for (auto &e : ctx->tree->events) (void) hipEventDestroy(e.second);
         delete ctx->tree;
         ctx->tree = nullptr;
@@ -2087,34 +2105,62 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
     return BT_OK;
 }
 
-// within-box order fix-up (see the header): every leaf's ids, and every box's run of own
-// particles, ascending
-int run_fixup(bt_context *ctx, TreeState *st)
+// Within-box order fix-up (see the header): every leaf's ids, and every box's run of own
+// particles, ascending -- in two halves.  fixup_launch queues the half-wave sort of the
+// leaves' ids, then the workgroup sort of the runs of 65..SEG_BLOCK_MAX ids (their number is
+// read on the device).  Only a build that can have longer runs -- particle extents (the
+// particles stuck in a split box form one run), refine weights (zero-weight particles),
+// more than SEG_BLOCK_MAX particles per leaf, level restriction -- needs the host to look
+// at the flags: fixup_finish does, at the start of the export (the caller allocates its
+// arrays in between, while the kernel runs), and takes the global route if it must
+// (segment_key_kernel scatters "start of my run" to user order and a 32-bit radix sort of
+// (run start, 0..N-1) yields the permutation).
+int fixup_launch(bt_context *ctx, TreeState *st)
 {
     const int64_t N = st->N;
-    uint32_t *ids = st->ids, *ids_other = st->ids_other;
-    bool need_global_fixup = N > 1;
-    if (N > 1) {
-        Buf<int32_t> large_list;
-        Buf<SegSortFlags> sflags;
-        BT_CHECK(large_list.alloc(ctx->pool, N / 64 + 1));
-        BT_CHECK(sflags.alloc(ctx->pool, 1));
-        BT_HIP_CHECK(hipMemsetAsync(sflags.get(), 0, sizeof(SegSortFlags), ctx->stream));
-        segment_sort_wave_kernel<<<(unsigned) div_up(st->nboxes * 32, 256), 256, 0, ctx->stream>>>(
-            (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_haschild.get(),
-            ids, large_list.get(), sflags.get());
-        SegSortFlags hf;
-        BT_CHECK(bt::d2h(ctx, &hf, sflags.get(), sizeof(hf)));
-        BT_CHECK(bt::sync_stream(ctx));
-        ctx->n_host_syncs++;
-        if (!hf.has_huge) {
-            if (hf.n_large > 0)
-                segment_sort_block_kernel<<<hf.n_large, 256, 0, ctx->stream>>>(
-                    large_list.get(), st->box_start.get(), st->box_count.get(), ids);
-            need_global_fixup = false;
-        }
+    st->fixup_pending = false;
+    if (N <= 1) { st->fixup_done = true; return BT_OK; }
+    const bt_tree_params &p = st->p;
+    const bool can_be_huge = st->have_extent || p.refine_weights != nullptr
+        || p.max_leaf_refine_weight > SEG_BLOCK_MAX || p.kind != BT_KIND_ADAPTIVE;
+    BT_CHECK(st->fix_large_list.alloc(ctx->pool, N / 64 + 1));
+    BT_CHECK(st->fix_flags.alloc(ctx->pool, 1));
+    BT_HIP_CHECK(hipMemsetAsync(st->fix_flags.get(), 0, sizeof(SegSortFlags), ctx->stream));
+    segment_sort_wave_kernel<<<(unsigned) div_up(st->nboxes * 32, 256), 256, 0, ctx->stream>>>(
+        (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_haschild.get(),
+        st->ids, st->fix_large_list.get(), st->fix_flags.get());
+    if (!can_be_huge) {
+        const unsigned grid = (unsigned) std::min<int64_t>(ctx->num_cus * 4, N / 64 + 1);
+        segment_sort_block_kernel<<<grid, 256, 0, ctx->stream>>>(
+            st->fix_large_list.get(), st->fix_flags.get(), 1, ctx->d_status, st->box_start.get(),
+            st->box_count.get(), st->ids);
+        BT_HIP_CHECK(hipGetLastError());
+        st->fix_large_list.reset();
+        st->fix_flags.reset();
+        st->fixup_done = true;
+        return BT_OK;
     }
-    if (need_global_fixup) {
+    BT_CHECK(bt::d2h(ctx, &st->h_fix, st->fix_flags.get(), sizeof(SegSortFlags)));
+    st->fixup_pending = true;
+    return BT_OK;
+}
+
+int fixup_finish(bt_context *ctx, TreeState *st)
+{
+    if (!st->fixup_pending) return BT_OK;
+    const int64_t N = st->N;
+    BT_CHECK(bt::sync_stream(ctx));
+    st->fixup_pending = false;
+    ctx->n_host_syncs++;
+    if (!st->h_fix.has_huge) {
+        if (st->h_fix.n_large > 0)
+            segment_sort_block_kernel<<<(unsigned) std::min<int64_t>(st->h_fix.n_large, ctx->num_cus * 8),
+                                        256, 0, ctx->stream>>>(
+                st->fix_large_list.get(), st->fix_flags.get(), 0, ctx->d_status, st->box_start.get(),
+                st->box_count.get(), st->ids);
+        BT_HIP_CHECK(hipGetLastError());
+    } else {
+        uint32_t *ids = st->ids, *ids_other = st->ids_other;
         Buf<uint32_t> fk_a, fk_b;
         BT_CHECK(fk_a.alloc(ctx->pool, N));
         BT_CHECK(fk_b.alloc(ctx->pool, N));
@@ -2133,8 +2179,16 @@ int run_fixup(bt_context *ctx, TreeState *st)
         st->ids_other = in_b ? va : vb;
         BT_CHECK(check_status(ctx));
     }
+    st->fix_large_list.reset();
+    st->fix_flags.reset();
     st->fixup_done = true;
     return BT_OK;
+}
+
+int run_fixup(bt_context *ctx, TreeState *st)
+{
+    BT_CHECK(fixup_launch(ctx, st));
+    return fixup_finish(ctx, st);
 }
 
 template <class T, int D>
@@ -2518,7 +2572,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         return e && atoi(e);
     }();
     st->fixup_done = false;
-    if (!(fused_env && st->sat && !EXT)) BT_CHECK(run_fixup(ctx, st));
+    if (!(fused_env && st->sat && !EXT)) BT_CHECK(fixup_launch(ctx, st));
     BT_CHECK(mark(ctx, st, "fixup"));
 
     // keys are no longer needed
@@ -2526,15 +2580,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     st->keys_b.reset();
     st->wprefix.reset();
 
-    // ---- source prefix (separate targets) ---------------------------------------
-    if (!st->sat) {
-        BT_CHECK(st->src_prefix.alloc(ctx->pool, N + 1));
-        IsSource is{st->ids, (uint32_t) st->nsources};
-        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, is, N, st->src_prefix.get(),
-                                                          (int32_t *) nullptr, true)));
-    }
-    BT_CHECK(mark(ctx, st, "srcscan"));
-    BT_CHECK(bt::sync_stream(ctx));
+    // (no wait here: the fix-up kernel runs while the caller allocates the output arrays;
+    // everything the sizes below depend on was read in the level loop)
 
     out->nboxes = st->nboxes;
     out->aligned_nboxes = div_up(st->nboxes, 32) * 32;
@@ -2557,6 +2604,15 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
     auto blocks = [](int64_t n) { return (unsigned) std::max<int64_t>(1, div_up(n, 256)); };
 
     BT_CHECK(mark(ctx, st, "(host gap)"));
+    BT_CHECK(fixup_finish(ctx, st));
+    // ---- source prefix (separate targets), over the ids in their final order -------------
+    if (!st->sat && !st->src_prefix.get()) {
+        BT_CHECK(st->src_prefix.alloc(ctx->pool, N + 1));
+        IsSource is{st->ids, (uint32_t) st->nsources};
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, is, N, st->src_prefix.get(),
+                                                          (int32_t *) nullptr, true)));
+    }
+    BT_CHECK(mark(ctx, st, "srcscan"));
     // ---- leaves in one pass (sources == targets, no extents): ids in their final order,
     // coordinates, leaf extents -------------------------------------------------------------
     const bool fused = !st->fixup_done && N > 1;
