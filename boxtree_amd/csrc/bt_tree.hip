@@ -2435,7 +2435,9 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
             }
             BT_HIP_CHECK(hipGetLastError());
             BT_CHECK(bt::d2h(ctx, h_ls, d_ls.get(), sizeof(LoopState)));
-            BT_CHECK(bt::sync_stream(ctx));
+            // (the status word -- look-back timeouts of the sort, depth limit -- comes back
+            // in the same wait)
+            BT_CHECK(check_status(ctx));
             ctx->n_host_syncs++;
             if (h_ls->overflow) {
                 // the children of level `lv` did not fit: grow (keeping the boxes of the
@@ -2468,7 +2470,11 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     // levels addressable below the first key (the per-axis cell index has 31 bits)
     const int L2 = KEY_AXIS_BITS - st->L;
     bool need_more = false;
-    if (enter_loop) BT_CHECK(level_loop(keys, st->L, 0, nullptr, L2 > 0, 1, &need_more));
+    bool status_read = false;      // the level loop's last wait brought the status word
+    if (enter_loop) {
+        BT_CHECK(level_loop(keys, st->L, 0, nullptr, L2 > 0, 1, &need_more));
+        status_read = true;
+    }
     if (need_more) {
         // ---- continuation below level L1 = st->L (keygen2_kernel) ---------------------
         const int L1 = st->L;
@@ -2555,7 +2561,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         // (the scratch buffers of this block are released after the work that reads them
         // has been queued on the stream; the pool hands memory to this stream only)
     }
-    BT_CHECK(check_status(ctx));
+    if (!status_read) BT_CHECK(check_status(ctx));
     BT_CHECK(mark(ctx, st, "boxes"));
 
     // ---- within-box order fix-up ----------------------------------------------
