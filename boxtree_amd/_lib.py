@@ -54,6 +54,7 @@ class TreeParams(ct.Structure):
         ("root_extent", ct.c_double),
         ("top_level", ct.c_int32), ("top_cell_prefix", vp),
         ("source_stride", ct.c_int64), ("target_stride", ct.c_int64),
+        ("compute_root_box", ct.c_int32), ("root_extent_stretch", ct.c_double),
     ]
 
 
@@ -62,6 +63,8 @@ class TreeSizes(ct.Structure):
         ("nboxes", ct.c_int64), ("aligned_nboxes", ct.c_int64),
         ("nlevels", ct.c_int32), ("key_levels", ct.c_int32),
         ("level_start_box_nrs", ct.c_int32 * (BT_MAX_LEVELS + 1)),
+        ("bbox_min", ct.c_double * BT_MAX_DIMS), ("bbox_max", ct.c_double * BT_MAX_DIMS),
+        ("root_extent", ct.c_double),
     ]
 
 

@@ -74,6 +74,53 @@ __global__ __launch_bounds__(BBOX_THREADS) void bbox_kernel(const T *__restrict_
     }
 }
 
+// Root box on the device (tree_build.py:456-476 in the coordinate type): partial[k][ax]
+// are the per-workgroup (min, max) pairs of bbox_kernel for sources (k = 0) and targets
+// (k = 1); out = {min[3], max[3], root_extent}.
+template <class T, int D>
+__global__ __launch_bounds__(256) void root_box_kernel(const T *partial, int nblk_src, int nblk_tgt,
+        T one_plus_stretch, T *out)
+{
+    __shared__ T s_mn[256], s_mx[256];
+    T lo[D], hi[D];
+    for (int ax = 0; ax < D; ++ax) {
+        T mn = CoordTraits<T>::maxval, mx = -CoordTraits<T>::maxval;
+        const T *ps = partial + (int64_t) 2 * nblk_src * ax;
+        for (int b = threadIdx.x; b < nblk_src; b += 256) {
+            mn = (ps[2 * b] < mn) ? ps[2 * b] : mn;
+            mx = (ps[2 * b + 1] > mx) ? ps[2 * b + 1] : mx;
+        }
+        const T *pt = partial + (int64_t) 2 * nblk_src * D + (int64_t) 2 * nblk_tgt * ax;
+        for (int b = threadIdx.x; b < nblk_tgt; b += 256) {
+            mn = (pt[2 * b] < mn) ? pt[2 * b] : mn;
+            mx = (pt[2 * b + 1] > mx) ? pt[2 * b + 1] : mx;
+        }
+        s_mn[threadIdx.x] = mn; s_mx[threadIdx.x] = mx;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int) threadIdx.x < off) {
+                const T a = s_mn[threadIdx.x + off], c = s_mx[threadIdx.x + off];
+                if (a < s_mn[threadIdx.x]) s_mn[threadIdx.x] = a;
+                if (c > s_mx[threadIdx.x]) s_mx[threadIdx.x] = c;
+            }
+            __syncthreads();
+        }
+        lo[ax] = s_mn[0]; hi[ax] = s_mx[0];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        T widest = hi[0] - lo[0];
+        for (int ax = 1; ax < D; ++ax) { const T w = hi[ax] - lo[ax]; widest = (w > widest) ? w : widest; }
+        const T extent = widest * one_plus_stretch;
+        for (int ax = 0; ax < 3; ++ax) {
+            out[ax] = ax < D ? lo[ax] : (T) 0;
+            out[3 + ax] = ax < D ? lo[ax] + extent : (T) 0;
+        }
+        out[6] = extent;
+        out[7] = (T) 0;
+    }
+}
+
 template <class T>
 int bbox_impl(bt_context *ctx, int dims, const void *const *coords, const void *radii,
               int64_t n, double *out_min, double *out_max)
@@ -142,6 +189,7 @@ struct KeygenArgs {
     int64_t nsources, n;
     int64_t src_stride, tgt_stride;     // elements between consecutive points (1 = dense)
     T bbox_min[D], bbox_max[D];
+    const T *rootbox;        // device {min[3], max[3], extent}: overrides bbox_min/max (or null)
     T stick_out_factor;
     int L;          // levels in the key
     int norm;       // BT_NORM_*
@@ -169,8 +217,8 @@ __global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_
 #pragma unroll
     for (int ax = 0; ax < D; ++ax) {
         x[ax] = is_src ? a.src[ax][j * a.src_stride] : a.tgt[ax][j * a.tgt_stride];
-        gmin[ax] = a.bbox_min[ax];                              // tbk:358
-        gext[ax] = a.bbox_max[ax] - gmin[ax];                   // tbk:359
+        gmin[ax] = a.rootbox ? a.rootbox[ax] : a.bbox_min[ax];                    // tbk:358
+        gext[ax] = (a.rootbox ? a.rootbox[3 + ax] : a.bbox_max[ax]) - gmin[ax];   // tbk:359
         // tbk:374-376 evaluated at the deepest level; scaling by 2^k is exact,
         // so (v >> (L-l)) is the reference's level-l value.
         v[ax] = (uint32_t) (((x[ax] - gmin[ax]) / gext[ax]) * (T) (1u << L));
@@ -660,10 +708,11 @@ constexpr int SL_SUB = 8;
 template <class T, int D, bool EXT>
 __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState *ls,
         T *centers /* [cap][D] */, T root_extent, int32_t box_cap, int first_level,
-        uint64_t *desc, uint32_t gen, uint32_t *ticket)
+        uint64_t *desc, uint32_t gen, uint32_t *ticket, const T *rootbox)
 {
     constexpr int C = 1 << D;
     constexpr int PPS = 256 / C;            // parents per sub-tile
+    if (rootbox) root_extent = rootbox[6];  // root box computed on the device
     constexpr int PPT = PPS * SL_SUB;       // parents per tile
     __shared__ uint32_t s_tile;
     __shared__ int32_t s_scan[256 / 64 + 1];
@@ -913,7 +962,8 @@ __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState
 
 template <class T, int D>
 __global__ void init_root_kernel(BuildArgs a, LoopState *ls, T *centers, int32_t n, T bbox_min0,
-        T bbox_min1, T bbox_min2, T bbox_max0, T bbox_max1, T bbox_max2, uint32_t *tickets)
+        T bbox_min1, T bbox_min2, T bbox_max0, T bbox_max1, T bbox_max2, uint32_t *tickets,
+        const T *rootbox)
 {
     constexpr int C = 1 << D;
     const int t = threadIdx.x;
@@ -921,7 +971,9 @@ __global__ void init_root_kernel(BuildArgs a, LoopState *ls, T *centers, int32_t
         // root box: tree_build.py:585-618
         a.box_start[0] = 0; a.box_count[0] = n; a.box_parent[0] = 0;
         a.box_level[0] = 0; a.box_haschild[0] = 0; a.box_nonchild[0] = 0;
-        const T mn[3] = {bbox_min0, bbox_min1, bbox_min2}, mx[3] = {bbox_max0, bbox_max1, bbox_max2};
+        T mn[3] = {bbox_min0, bbox_min1, bbox_min2}, mx[3] = {bbox_max0, bbox_max1, bbox_max2};
+        if (rootbox)
+            for (int ax = 0; ax < 3; ++ax) { mn[ax] = rootbox[ax]; mx[ax] = rootbox[3 + ax]; }
         for (int ax = 0; ax < D; ++ax) centers[ax] = mn[ax] + (mx[ax] - mn[ax]) / 2;
         for (int m = 0; m < C; ++m) a.box_child[m] = 0;
         ls->level_start[0] = 0; ls->level_start[1] = 1;
@@ -1540,6 +1592,9 @@ struct TreeState {
     bool fixup_done = false;           // ids are in the reference's within-box order
     // the fix-up is started by the build and finished by the export (fixup_launch /
     // fixup_finish): the caller allocates its arrays in between, while the kernel runs
+    Buf<unsigned char> rootbox;        // device {min[3], max[3], extent, 0} of the coordinate
+                                       // type when the library computes the root box
+    unsigned char h_rootbox[64] = {0};
     bool fixup_pending = false;
     Buf<int32_t> fix_large_list;
     Buf<SegSortFlags> fix_flags;
@@ -2202,6 +2257,32 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     BT_CHECK(mark(ctx, st, "start"));
     int point_skip_raw = 0;
 
+    // ---- root box on the device (compute_root_box) --------------------------------
+    if (p.compute_root_box) {
+        const int64_t ns = st->nsources, nt = st->sat ? 0 : st->ntargets;
+        auto nblocks = [&](int64_t n) {
+            return n > 0 ? std::min<int64_t>(div_up(n, BBOX_THREADS * 8), (int64_t) ctx->num_cus * 8) : 0;
+        };
+        const int64_t bs = nblocks(ns), bt_ = nblocks(nt);
+        Buf<T> partial;
+        BT_CHECK(partial.alloc(ctx->pool, 2 * (bs + bt_) * D + 2));
+        for (int ax = 0; ax < D; ++ax) {
+            if (bs > 0)
+                bbox_kernel<T><<<(unsigned) bs, BBOX_THREADS, 0, ctx->stream>>>(
+                    (const T *) p.sources[ax], (const T *) nullptr, ns, partial.get() + 2 * bs * ax);
+            if (bt_ > 0)
+                bbox_kernel<T><<<(unsigned) bt_, BBOX_THREADS, 0, ctx->stream>>>(
+                    (const T *) p.targets[ax], (const T *) nullptr, nt,
+                    partial.get() + 2 * bs * D + 2 * bt_ * ax);
+        }
+        BT_CHECK(st->rootbox.alloc(ctx->pool, 8 * sizeof(T)));
+        root_box_kernel<T, D><<<1, 256, 0, ctx->stream>>>(
+            partial.get(), (int) bs, (int) bt_, (T) (1.0 + p.root_extent_stretch), (T *) st->rootbox.get());
+        BT_HIP_CHECK(hipGetLastError());
+        // the host copy arrives with the level loop's first wait
+        BT_CHECK(bt::d2h(ctx, st->h_rootbox, st->rootbox.get(), 8 * sizeof(T)));
+    }
+
     // ---- keys ----------------------------------------------------------------
     BT_CHECK(st->keys_a.alloc(ctx->pool, N));
     BT_CHECK(st->keys_b.alloc(ctx->pool, N));
@@ -2215,6 +2296,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
             ka.bbox_min[ax] = (T) p.bbox_min[ax];
             ka.bbox_max[ax] = (T) p.bbox_max[ax];
         }
+        ka.rootbox = (const T *) st->rootbox.get();
         ka.src_radii = (const T *) p.source_radii;
         ka.tgt_radii = (const T *) p.target_radii;
         ka.nsources = st->nsources;
@@ -2234,7 +2316,9 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
             const double eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
             const double ratio = p.stick_out_factor * p.root_extent / (256.0 * eps * scale);
             int skip = 0;
-            if (ratio > 1.0) skip = (int) std::floor(std::log2(ratio));
+            // (extents only; with compute_root_box there are none and the root box is not
+            // known here)
+            if (EXT && ratio > 1.0) skip = (int) std::floor(std::log2(ratio));
             point_skip_raw = std::max(0, skip);
             ka.point_skip_levels = std::max(0, std::min(skip, st->L));
         }
@@ -2342,7 +2426,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         T mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
         for (int ax = 0; ax < D; ++ax) { mn[ax] = (T) p.bbox_min[ax]; mx[ax] = (T) p.bbox_max[ax]; }
         init_root_kernel<T, D><<<1, 128, 0, ctx->stream>>>(a, d_ls.get(), (T *) st->centers.get(),
-                (int32_t) N, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], tickets.get());
+                (int32_t) N, mn[0], mn[1], mn[2], mx[0], mx[1], mx[2], tickets.get(),
+                (const T *) st->rootbox.get());
     }
     st->nboxes = 1;
     st->level_start = {0, 1};
@@ -2427,11 +2512,13 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
                 if (EXT)
                     split_level_kernel<T, D, true><<<grid, 256, 0, ctx->stream>>>(
                         a, d_ls.get(), (T *) st->centers.get(), (T) p.root_extent, (int32_t) st->cap,
-                        first_level, sl_desc.get(), sl_gen, tickets.get() + l);
+                        first_level, sl_desc.get(), sl_gen, tickets.get() + l,
+                        (const T *) st->rootbox.get());
                 else
                     split_level_kernel<T, D, false><<<grid, 256, 0, ctx->stream>>>(
                         a, d_ls.get(), (T *) st->centers.get(), (T) p.root_extent, (int32_t) st->cap,
-                        first_level, sl_desc.get(), sl_gen, tickets.get() + l);
+                        first_level, sl_desc.get(), sl_gen, tickets.get() + l,
+                        (const T *) st->rootbox.get());
             }
             BT_HIP_CHECK(hipGetLastError());
             BT_CHECK(bt::d2h(ctx, h_ls, d_ls.get(), sizeof(LoopState)));
@@ -2474,6 +2561,16 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     if (enter_loop) {
         BT_CHECK(level_loop(keys, st->L, 0, nullptr, L2 > 0, 1, &need_more));
         status_read = true;
+    }
+    if (p.compute_root_box) {
+        // the root box the device computed, for the host-side uses below and the caller
+        if (!status_read) { BT_CHECK(check_status(ctx)); status_read = true; }
+        const T *h = reinterpret_cast<const T *>(st->h_rootbox);
+        for (int ax = 0; ax < D; ++ax) {
+            st->p.bbox_min[ax] = (double) h[ax];
+            st->p.bbox_max[ax] = (double) h[3 + ax];
+        }
+        st->p.root_extent = (double) h[6];
     }
     if (need_more) {
         // ---- continuation below level L1 = st->L (keygen2_kernel) ---------------------
@@ -2593,6 +2690,11 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     out->aligned_nboxes = div_up(st->nboxes, 32) * 32;
     out->nlevels = (int32_t) st->level_start.size() - 1;
     out->key_levels = st->L;
+    for (int ax = 0; ax < BT_MAX_DIMS; ++ax) {
+        out->bbox_min[ax] = ax < D ? p.bbox_min[ax] : 0.0;
+        out->bbox_max[ax] = ax < D ? p.bbox_max[ax] : 0.0;
+    }
+    out->root_extent = p.root_extent;
     for (size_t i = 0; i < st->level_start.size() && i <= BT_MAX_LEVELS; ++i)
         out->level_start_box_nrs[i] = st->level_start[i];
     st->built = true;
@@ -2897,10 +2999,17 @@ int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
         // max == min on every axis (a single point, or all points coincident) is a
         // tree of one box unless that box would have to split, which no depth can
         // achieve: MaxLevelsExceeded, like the level loop upstream
-        if (!(p->bbox_max[ax] >= p->bbox_min[ax]) && N > 0) {
+        if (!p->compute_root_box && !(p->bbox_max[ax] >= p->bbox_min[ax]) && N > 0) {
             set_error("bt_tree_build: empty bounding box on axis %d", ax);
             return BT_ERR_INVALID;
         }
+    }
+    if (p->compute_root_box
+            && (have_extent || p->top_cell_prefix || p->kind == BT_KIND_ADAPTIVE_LEVEL_RESTRICTED
+                || p->source_stride > 1 || p->target_stride > 1 || N == 0)) {
+        set_error("compute_root_box: point particles in dense arrays, kind 'adaptive' or "
+                  "'non-adaptive', a self-contained build of at least one particle");
+        return BT_ERR_UNSUPPORTED;
     }
 
     bt_free_tree_state(ctx);

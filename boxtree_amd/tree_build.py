@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes as ct
 import dataclasses
 import logging
+import os
 from typing import Any, Literal
 
 import numpy as np
@@ -290,8 +291,17 @@ class TreeBuilder:
         refine_weights, max_leaf_refine_weight = _refine_weight_spec(
             actx, inp, max_particles_in_box, refine_weights, max_leaf_refine_weight)
         _lib.host_trace("tb:inputs")
-        box = _root_box(actx, self.bbox_finder, inp, bbox, kwargs.get("_root_box"),
-                        TreeBuilder.ROOT_EXTENT_STRETCH_FACTOR)
+        # The root box of a plain build (point particles, no box given) is found by the
+        # library on the device, with the arithmetic of _root_box in the coordinate type, and
+        # comes back with the sizes: no wait for the bounding box before the keys are made.
+        device_root_box = (
+            bbox is None and kwargs.get("_root_box") is None and kwargs.get("_top_tree") is None
+            and inp.source_radii is None and inp.target_radii is None
+            and kind in ("adaptive", "non-adaptive") and point_stride <= 1
+            and inp.nsrcntgts > 0 and os.environ.get("BOXTREE_HIP_HOST_ROOT_BOX", "0") != "1")
+        box = None if device_root_box else _root_box(
+            actx, self.bbox_finder, inp, bbox, kwargs.get("_root_box"),
+            TreeBuilder.ROOT_EXTENT_STRETCH_FACTOR)
         _lib.host_trace("tb:rootbox")
 
         # names used by the rest of the call
@@ -307,7 +317,8 @@ class TreeBuilder:
         stick_out_factor = inp.stick_out_factor
         particle_id_dtype = np.dtype(np.int32)
         box_id_dtype = np.dtype(np.int32)
-        bbox_min, bbox_max, root_extent = box.lo, box.hi, box.root_extent
+        if box is not None:
+            bbox_min, bbox_max, root_extent = box.lo, box.hi, box.root_extent
 
         # {{{ device build
 
@@ -331,10 +342,14 @@ class TreeBuilder:
         tp.extent_norm = _lib.NORMS[srcntgts_extent_norm]
         tp.skip_prune = int(bool(kwargs.get("skip_prune")))
         tp.stick_out_factor = float(coord_dtype.type(stick_out_factor))
-        for i, ax in enumerate(axis_names):
-            tp.bbox_min[i] = float(bbox_min[i])
-            tp.bbox_max[i] = float(bbox_max[i])
-        tp.root_extent = float(coord_dtype.type(root_extent))
+        if box is None:
+            tp.compute_root_box = 1
+            tp.root_extent_stretch = TreeBuilder.ROOT_EXTENT_STRETCH_FACTOR
+        else:
+            for i, ax in enumerate(axis_names):
+                tp.bbox_min[i] = float(bbox_min[i])
+                tp.bbox_max[i] = float(bbox_max[i])
+            tp.root_extent = float(coord_dtype.type(root_extent))
         top_tree = kwargs.get("_top_tree")
         if top_tree is not None:
             # (top_level, int64 device tensor [C^top_level + 1]): global cell counts
@@ -360,6 +375,10 @@ class TreeBuilder:
             raise ValueError(lib.bt_last_error_string().decode())
         _lib.check(code)
 
+        if box is None:
+            bbox_min = np.array(sizes.bbox_min[:dimensions], dtype=coord_dtype)
+            bbox_max = np.array(sizes.bbox_max[:dimensions], dtype=coord_dtype)
+            root_extent = coord_dtype.type(sizes.root_extent)
         nboxes = int(sizes.nboxes)
         aligned_nboxes = int(sizes.aligned_nboxes)
         nlevels = int(sizes.nlevels)

@@ -166,6 +166,15 @@ typedef struct {
      * arrays).  Lets the exchange of a sharded build hand over its interleaved
      * receive buffer (x0 y0 z0 x1 ...: stride = dims) without unpacking it. */
     int64_t source_stride, target_stride;
+    /* compute_root_box != 0: bbox_min / bbox_max / root_extent above are ignored; the
+     * library finds the bounding box of sources and targets on the device and derives
+     * the root box there with tree_build.py:456-476's arithmetic in the coordinate type
+     * (root_extent = max_axis(max - min) * (1 + root_extent_stretch), upper corner =
+     * lower corner + root_extent), without a host round trip; the values come back in
+     * bt_tree_sizes.  Point particles (no radii), kind ADAPTIVE or NON_ADAPTIVE, dense
+     * arrays, no top_cell_prefix; BT_ERR_UNSUPPORTED otherwise. */
+    int32_t compute_root_box;
+    double root_extent_stretch;            /* tree_build.py:101: 1e-4 */
 } bt_tree_params;
 
 typedef struct {
@@ -174,6 +183,8 @@ typedef struct {
     int32_t nlevels;
     int32_t key_levels;        /* deepest level the 64-bit key can address */
     int32_t level_start_box_nrs[BT_MAX_LEVELS + 1];   /* [nlevels+1] valid */
+    /* the root box the tree was built in (inputs echoed, or computed: compute_root_box) */
+    double bbox_min[BT_MAX_DIMS], bbox_max[BT_MAX_DIMS], root_extent;
 } bt_tree_sizes;
 
 int bt_tree_build(bt_context *ctx, const bt_tree_params *params, bt_tree_sizes *out);
