@@ -1035,6 +1035,10 @@ struct SegSortFlags {
 // Half a wave per box, up to two ids per lane: the kernel is bound by the latency of
 // its dependent global loads (count, start, ids), so two boxes per wave keep twice as
 // many of them in flight; the 64-element network's j=32 stage is register-local.
+// (The exchanges go through __shfl_xor, i.e. ds_bpermute.  DPP moves for the distances
+// inside a row of 16 lanes -- 1 LDS round trip instead of 15 -- were measured 13 % SLOWER
+// at 10^8 points: the kernel is bound by vector-ALU issue, and the shuffles run on the LDS
+// pipeline beside it.)
 __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, const int32_t *box_start,
         const int32_t *box_count, const uint8_t *box_haschild, uint32_t *ids,
         int32_t *large_list, SegSortFlags *flags)
@@ -1498,6 +1502,23 @@ __global__ __launch_bounds__(256) void box_info_kernel(BoxInfoArgs a)
         a.o_child[(int64_t) m * a.aligned + b] = a.box_child[(int64_t) b * a.C + m];
 }
 
+// value of the lane CTRL names within the same row of 16 lanes (0x100 + n: row_shl:n, lane
+// i reads lane i + n); lanes without a source keep their own value
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_mov(float v)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL,
+                                                      0xf, 0xf, false));
+}
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_mov(double v)
+{
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    return __hiloint2double(__builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false));
+}
+
 // box extents: tbk:1311-1399, one 16-lane group per box of one level
 template <class T, int D>
 struct ExtentArgs {
@@ -1553,14 +1574,19 @@ __global__ __launch_bounds__(256) void box_extent_kernel(ExtentArgs<T, D> a)
             }
         }
     }
+    // reduction over the group's 16 lanes (one DPP row) into lane 0: row_shl:8/4/2/1 moves
+    // instead of shuffles through LDS (48 ds_bpermute per lane in double precision)
 #pragma unroll
-    for (int off = 8; off > 0; off >>= 1) {
-#pragma unroll
-        for (int ax = 0; ax < D; ++ax) {
-            const T omn = __shfl_xor(mn[ax], off, 16), omx = __shfl_xor(mx[ax], off, 16);
-            mn[ax] = (omn < mn[ax]) ? omn : mn[ax];
-            mx[ax] = (omx > mx[ax]) ? omx : mx[ax];
-        }
+    for (int ax = 0; ax < D; ++ax) {
+        T omn, omx;
+        omn = dpp_row_mov<0x108>(mn[ax]); omx = dpp_row_mov<0x108>(mx[ax]);
+        mn[ax] = (omn < mn[ax]) ? omn : mn[ax]; mx[ax] = (omx > mx[ax]) ? omx : mx[ax];
+        omn = dpp_row_mov<0x104>(mn[ax]); omx = dpp_row_mov<0x104>(mx[ax]);
+        mn[ax] = (omn < mn[ax]) ? omn : mn[ax]; mx[ax] = (omx > mx[ax]) ? omx : mx[ax];
+        omn = dpp_row_mov<0x102>(mn[ax]); omx = dpp_row_mov<0x102>(mx[ax]);
+        mn[ax] = (omn < mn[ax]) ? omn : mn[ax]; mx[ax] = (omx > mx[ax]) ? omx : mx[ax];
+        omn = dpp_row_mov<0x101>(mn[ax]); omx = dpp_row_mov<0x101>(mx[ax]);
+        mn[ax] = (omn < mn[ax]) ? omn : mn[ax]; mx[ax] = (omx > mx[ax]) ? omx : mx[ax];
     }
     if (active && l16 == 0) {
 #pragma unroll
