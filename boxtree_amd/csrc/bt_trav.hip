@@ -1666,7 +1666,8 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     BT_CHECK(place_list(ctx, st, c1.lists, c1.total, pk ? &pk->neighbor_source_boxes_lists : nullptr));
     BT_CHECK(place_list(ctx, st, st->l3_lists, total3, pk ? &pk->from_sep_smaller_lists[0] : nullptr));
     rows_to_csr_v2_kernel<<<nblk(items_cap), 256, 0, ctx->stream>>>(
-        d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, c1.lists.get());
+        d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), ft.dfs_rank, (int32_t) B,
+        c1.lists.get());
     if (total3 > 0)
         l3_scatter_v2_kernel<<<nblk(items_cap), 256, lvl_lds, ctx->stream>>>(
             d_nitems, lay, nlevels, overflow.get(), row3.get(), row3lev.get(), K3,
@@ -1675,7 +1676,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         BT_CHECK(place_list(ctx, st, cs.lists, cs.total, pk ? &pk->from_sep_close_smaller_lists : nullptr));
         if (cs.total > 0)
             rows_to_csr_v2_kernel<<<nblk(items_cap), 256, 0, ctx->stream>>>(
-                d_nitems, overflow.get(), rowc.get(), Kc, close_item.get(), nullptr, cs.lists.get());
+                d_nitems, overflow.get(), rowc.get(), Kc, close_item.get(), nullptr, 0, cs.lists.get());
     }
     if (novf > 0) {
         // items whose lists did not fit their rows: walk again, straight to the final places

@@ -491,6 +491,13 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         e1 = V2Emit<ROWS>{w.l1_lists + w.l1_cs[item], 1, INT_MAX, 0};
         ec = V2Emit<ROWS>{w.close_lists ? w.close_lists + w.close_cs[item] : nullptr, 1, INT_MAX, 0};
     }
+    // List 1 holds depth-first ranks until its final ordering.  The single-pass rows take
+    // the box number and rows_to_csr_v2_kernel looks the rank up (eight independent loads
+    // per lane in flight); a lookup here would stall the walk once per entry, the store
+    // having to wait for the load.
+    auto emit1 = [&](int32_t box) {
+        if (ROWS) e1(box); else e1(ft.dfs_rank[box]);
+    };
     int32_t *lvl = s_walk_lds + w.walk_cap * WALK_THREADS + threadIdx.x;
     int n3 = 0;
     int32_t *row3 = ROWS ? w.row3 + tile * w.K3 + tl64 : nullptr;
@@ -512,16 +519,16 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
     };
 
     if (slot < 0) {
-        if (w.flags[0] & BT_BOX_IS_SOURCE_BOX) e1(ft.dfs_rank[0]);       // traversal.py:489-495
+        if (w.flags[0] & BT_BOX_IS_SOURCE_BOX) emit1(0);       // traversal.py:489-495
         // b itself
-        if (tl >= 1 && (bflags & BT_BOX_IS_SOURCE_BOX)) e1(ft.dfs_rank[b]);
+        if (tl >= 1 && (bflags & BT_BOX_IS_SOURCE_BOX)) emit1(b);
         // coarser levels: the ancestors and their source-box colleagues.  A colleague
         // of the ancestor at offset o touches b iff b sits at the matching face of the
         // ancestor along every axis with o != 0.
         if (tl >= 2) {
             int32_t anc = a.parent[b];
             for (int k = tl - 1; k >= 1; --k, anc = a.parent[anc]) {
-                if (w.flags[anc] & BT_BOX_IS_SOURCE_BOX) e1(ft.dfs_rank[anc]);
+                if (w.flags[anc] & BT_BOX_IS_SOURCE_BOX) emit1(anc);
                 const uint32_t mask = (1u << (tl - k)) - 1u;
                 const int32_t *srow = w.srccoll_rows + (int64_t) anc * P;
                 const int ns = w.srccoll_cnt[anc];
@@ -534,7 +541,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                         const uint32_t r = cell.c[ax] & mask;
                         adjacent = adjacent && (o == 0 || (o < 0 ? r == 0u : r == mask));
                     }
-                    if (adjacent) e1(ft.dfs_rank[e & V2_ID_MASK]);
+                    if (adjacent) emit1(e & V2_ID_MASK);
                 }
             }
         }
@@ -583,7 +590,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         const int32_t nws = (int32_t) (ce & V2_ID_MASK);
         const uint8_t cfl = w.flags[nws];
         // a colleague is adjacent (well_sep_is_n_away == 1)
-        if (cfl & BT_BOX_IS_SOURCE_BOX) e1(ft.dfs_rank[nws]);
+        if (cfl & BT_BOX_IS_SOURCE_BOX) emit1(nws);
         if (!(cfl & BT_BOX_HAS_SOURCE_CHILD_BOXES)) continue;
         int prel[D];
 #pragma unroll
@@ -613,7 +620,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                 }
                 const int wl = tl + k;
                 if (in_list_1) {
-                    if (raw & CH_SRC) e1(ft.dfs_rank[wb]);
+                    if (raw & CH_SRC) emit1(wb);
                     descend = (raw & CH_HSC) != 0;
                 } else {
                     bool meets = true;
@@ -712,7 +719,8 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
 // item (the wave reads 256 contiguous bytes) and writes it to the item's CSR segment
 __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_nitems,
         const uint8_t *overflow, const int32_t *rows, int K, const int32_t *starts,
-        const int32_t *blk_reserved /* unused */, int32_t *lists)
+        const int32_t *translate /* entries are indices into this table, or null */,
+        int32_t ntranslate, int32_t *lists)
 {
     const int32_t item = blockIdx.x * 256 + threadIdx.x;
     const int32_t nitems = *d_nitems;
@@ -726,8 +734,24 @@ __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_ni
         nmax = o > nmax ? o : nmax;
     }
     const int32_t *row = rows + (int64_t) (item >> 6) * 64 * K + (item & 63);
-    for (int j = 0; j < nmax; ++j)
-        if (j < n) lists[(int64_t) s + j] = row[(int64_t) j * 64];
+    // eight loads in flight per lane: one load and one store per trip made every trip wait
+    // for its load (the stores may alias the rows as far as the compiler knows)
+    constexpr int UNR = 8;
+    for (int j0 = 0; j0 < nmax; j0 += UNR) {
+        int32_t v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) v[u] = (j0 + u < n) ? row[(int64_t) (j0 + u) * 64] : 0;
+        if (translate) {
+#pragma unroll
+            // (a list's segment may end with space reserved for a block that is copied in
+            // later: the row slots behind the item's entries hold no box numbers)
+            for (int u = 0; u < UNR; ++u)
+                v[u] = (j0 + u < n && (uint32_t) v[u] < (uint32_t) ntranslate) ? translate[v[u]] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (j0 + u < n) lists[(int64_t) s + j0 + u] = v[u];
+    }
 }
 
 // list 3: rows -> per-level lists (cursors start at the item's per-level starts)
@@ -749,9 +773,19 @@ __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nit
     }
     const int32_t *row = row3 + (int64_t) (item >> 6) * 64 * K3 + (item & 63);
     const uint8_t *rl = row3lev + (int64_t) (item >> 6) * 64 * K3 + (item & 63);
-    for (int j = 0; j < n; ++j) {
-        const int lev = rl[(int64_t) j * 64];
-        l3_lists[cur[lev * WALK_THREADS]++] = row[(int64_t) j * 64];
+    constexpr int UNR = 8;                 // loads in flight per lane (see rows_to_csr_v2_kernel)
+    for (int j0 = 0; j0 < n; j0 += UNR) {
+        int32_t v[UNR];
+        int lev[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const bool in = j0 + u < n;
+            v[u] = in ? row[(int64_t) (j0 + u) * 64] : 0;
+            lev[u] = in ? (int) rl[(int64_t) (j0 + u) * 64] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+            if (j0 + u < n) l3_lists[cur[lev[u] * WALK_THREADS]++] = v[u];
     }
 }
 
