@@ -1686,6 +1686,8 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         wf.l1_lists = c1.lists.get(); wf.l3_lists = st->l3_lists.get();
         wf.close_lists = st->with_extent ? cs.lists.get() : nullptr;
         walk13_v2_kernel<T, D, false><<<nblk(novf), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, wf);
+        ranks_of_overflow_kernel<<<nblk(novf * 64), 256, 0, ctx->stream>>>(
+            wf.ovf_count, ovf_list.get(), l1_item.get(), ft.dfs_rank, (int32_t) B, c1.lists.get());
     }
     BT_CHECK(tmark(ctx, st, "trav:lists 1+3 (final)"));
 

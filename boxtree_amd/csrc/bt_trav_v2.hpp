@@ -407,6 +407,31 @@ __global__ __launch_bounds__(256) void make_items_v2_kernel(int32_t ntb, const i
 // ROWS = false: the items of the overflow list are walked again and write straight to
 //   their final places.
 
+// box numbers -> depth-first ranks in the list-1 segments of the items that were walked a
+// second time (one wave per item; the slots reserved behind an item's entries for its own
+// block hold no box numbers yet)
+__global__ __launch_bounds__(256) void ranks_of_overflow_kernel(const int32_t *ovf_count,
+        const int32_t *ovf_list, const int32_t *starts, const int32_t *rank, int32_t nboxes,
+        int32_t *lists)
+{
+    const int32_t idx = (blockIdx.x * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (idx >= *ovf_count) return;
+    const int32_t item = ovf_list[idx];
+    const int32_t s = starts[item], e = starts[item + 1];
+    for (int32_t k0 = s + lane; k0 < e; k0 += 4 * 64) {
+        int32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (k0 + u * 64 < e) ? lists[k0 + u * 64] : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = ((uint32_t) v[u] < (uint32_t) nboxes) ? rank[v[u]] : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k0 + u * 64 < e) lists[k0 + u * 64] = v[u];
+    }
+}
+
 // Per-level list-3 counts of the items, "staircase" layout: an item of a target box at
 // level tl can only have entries at source levels > tl, and items are numbered in
 // target-box (= level) order, so row l needs columns for the items of levels < l only:
@@ -491,13 +516,11 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         e1 = V2Emit<ROWS>{w.l1_lists + w.l1_cs[item], 1, INT_MAX, 0};
         ec = V2Emit<ROWS>{w.close_lists ? w.close_lists + w.close_cs[item] : nullptr, 1, INT_MAX, 0};
     }
-    // List 1 holds depth-first ranks until its final ordering.  The single-pass rows take
-    // the box number and rows_to_csr_v2_kernel looks the rank up (eight independent loads
-    // per lane in flight); a lookup here would stall the walk once per entry, the store
-    // having to wait for the load.
-    auto emit1 = [&](int32_t box) {
-        if (ROWS) e1(box); else e1(ft.dfs_rank[box]);
-    };
+    // List 1 holds depth-first ranks until its final ordering.  The walk writes box numbers
+    // and the ranks are looked up afterwards (rows_to_csr_v2_kernel, ranks_of_overflow_kernel:
+    // independent loads, several per lane in flight); a lookup here would stall the walk once
+    // per entry, the store having to wait for the load.
+    auto emit1 = [&](int32_t box) { e1(box); };
     int32_t *lvl = s_walk_lds + w.walk_cap * WALK_THREADS + threadIdx.x;
     int n3 = 0;
     int32_t *row3 = ROWS ? w.row3 + tile * w.K3 + tl64 : nullptr;
