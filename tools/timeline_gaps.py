@@ -34,6 +34,12 @@ def main(path, first="bbox_kernel", min_gap_us="4"):
         if g >= min_gap:
             print(f"  t={(e0 - t0) / 1e3:9.1f} us  gap {g / 1e3:7.1f} us   "
                   f"{n0.split('(')[0][-40:]:>40} -> {n1.split('(')[0][-40:]}")
+    if "--kernels" in sys.argv:
+        print("kernels of the step in launch order (>= 20 us):")
+        for n_, s_, e_ in step:
+            if e_ - s_ >= 20e3:
+                print(f"  t={(s_ - t0) / 1e3:9.1f} us  {(e_ - s_) / 1e3:8.1f} us  "
+                      f"{n_.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:70]}")
     small = sum(g for g in gaps if 0 < g < min_gap)
     print(f"gaps below {min_gap / 1e3:.0f} us: {small / 1e6:.3f} ms in "
           f"{sum(1 for g in gaps if 0 < g < min_gap)} places; "
@@ -41,4 +47,4 @@ def main(path, first="bbox_kernel", min_gap_us="4"):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:])
+    main(*[a for a in sys.argv[1:] if not a.startswith("--")])
