@@ -1181,8 +1181,8 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         Buf<int32_t> jobbuf;
         BT_CHECK(jobbuf.alloc(ctx->pool, 3 * ntb + 1));
         BlockJobs jobs{jobbuf.get(), jobbuf.get() + 1, jobbuf.get() + 1 + ntb,
-                       jobbuf.get() + 1 + 2 * ntb};
-        BT_HIP_CHECK(hipMemsetAsync(jobbuf.get(), 0, 4, ctx->stream));
+                       jobbuf.get() + 1 + 2 * ntb, nullptr};
+        BT_HIP_CHECK(hipMemsetAsync(jobs.len, 0, (size_t) ntb * 4, ctx->stream));
         Buf<uint8_t> tier;
         Buf<int32_t> tier_present;
         BT_CHECK(tier.alloc(ctx->pool, ntb));
@@ -1191,7 +1191,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         BT_HIP_CHECK(hipMemsetAsync(tier_present.get(), 0, 8, ctx->stream));
         l1_finalize32_kernel<T, D><<<nblk(ntb * 16), 256, 0, ctx->stream>>>(
             a, ft, (int32_t) ntb, c1.starts.get(), c1.lists.get(), jobs, tier.get(),
-            tier_present.get());
+            tier_present.get(), 0);
         int32_t h_present[2] = {0, 0};
         BT_CHECK(bt::d2h(ctx, h_present, tier_present.get(), 8));
         BT_CHECK(bt::sync_stream(ctx));
@@ -1210,17 +1210,16 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
                                                                    list.get());
             if (which == 1)
                 l1_finalize_wave_kernel<T, D><<<(unsigned) div_up(cnt, 4), 256, 0, ctx->stream>>>(
-                    a, ft, list.get(), pos.get() + ntb, c1.starts.get(), c1.lists.get(), jobs);
+                    a, ft, list.get(), pos.get() + ntb, c1.starts.get(), c1.lists.get(), jobs, 0);
             else
                 l1_finalize_block_kernel<T, D><<<cnt, 256, 0, ctx->stream>>>(
-                    a, ft, list.get(), pos.get() + ntb, c1.starts.get(), c1.lists.get(), jobs);
+                    a, ft, list.get(), pos.get() + ntb, c1.starts.get(), c1.lists.get(), jobs, 0);
             BT_CHECK(bt::sync_stream(ctx));    // `list` is freed on scope exit
         }
-        int32_t njobs = 0;
-        BT_CHECK(read_i32(ctx, jobs.count, &njobs));
-        if (njobs > 0)
-            copy_rank_blocks_kernel<<<njobs, 256, 0, ctx->stream>>>(
-                jobs.count, jobs.dst, jobs.src, jobs.len, st->src_by_rank.get(), c1.lists.get());
+        if (st->has_blocks)
+            copy_rank_blocks_kernel<<<(unsigned) std::min<int64_t>(ctx->num_cus * 8, div_up(ntb, 4)), 256, 0,
+                                      ctx->stream>>>(
+                (int32_t) ntb, jobs.dst, jobs.src, jobs.len, st->src_by_rank.get(), c1.lists.get());
     }
     BT_CHECK(tmark(ctx, st, "trav:list1+list3"));
     BT_HIP_CHECK(hipGetLastError());
@@ -1666,8 +1665,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     BT_CHECK(place_list(ctx, st, c1.lists, c1.total, pk ? &pk->neighbor_source_boxes_lists : nullptr));
     BT_CHECK(place_list(ctx, st, st->l3_lists, total3, pk ? &pk->from_sep_smaller_lists[0] : nullptr));
     rows_to_csr_v2_kernel<<<nblk(items_cap), 256, 0, ctx->stream>>>(
-        d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), ft.dfs_rank, (int32_t) B,
-        c1.lists.get());
+        d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, 0, c1.lists.get());
     if (total3 > 0)
         l3_scatter_v2_kernel<<<nblk(items_cap), 256, lvl_lds, ctx->stream>>>(
             d_nitems, lay, nlevels, overflow.get(), row3.get(), row3lev.get(), K3,
@@ -1686,8 +1684,6 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         wf.l1_lists = c1.lists.get(); wf.l3_lists = st->l3_lists.get();
         wf.close_lists = st->with_extent ? cs.lists.get() : nullptr;
         walk13_v2_kernel<T, D, false><<<nblk(novf), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, wf);
-        ranks_of_overflow_kernel<<<nblk(novf * 64), 256, 0, ctx->stream>>>(
-            wf.ovf_count, ovf_list.get(), l1_item.get(), ft.dfs_rank, (int32_t) B, c1.lists.get());
     }
     BT_CHECK(tmark(ctx, st, "trav:lists 1+3 (final)"));
 
@@ -1726,9 +1722,15 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     {
         Buf<int32_t> jobbuf;
         BT_CHECK(jobbuf.alloc(ctx->pool, 3 * ntb + 1));
+        static const bool l1_stats = [] { const char *e = getenv("BT_TRAV_STATS"); return e && atoi(e); }();
+        Buf<int32_t> l1_dbg;
+        if (l1_stats) {
+            BT_CHECK(l1_dbg.alloc(ctx->pool, 16));
+            BT_HIP_CHECK(hipMemsetAsync(l1_dbg.get(), 0, 64, ctx->stream));
+        }
         BlockJobs jobs{jobbuf.get(), jobbuf.get() + 1, jobbuf.get() + 1 + ntb,
-                       jobbuf.get() + 1 + 2 * ntb};
-        BT_HIP_CHECK(hipMemsetAsync(jobbuf.get(), 0, 4, ctx->stream));
+                       jobbuf.get() + 1 + 2 * ntb, l1_dbg.get()};
+        BT_HIP_CHECK(hipMemsetAsync(jobs.len, 0, (size_t) ntb * 4, ctx->stream));
         Buf<uint8_t> tier;
         Buf<int32_t> tier_present;
         BT_CHECK(tier.alloc(ctx->pool, ntb));
@@ -1737,7 +1739,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         BT_HIP_CHECK(hipMemsetAsync(tier_present.get(), 0, 8, ctx->stream));
         l1_finalize32_kernel<T, D><<<nblk(ntb * 16), 256, 0, ctx->stream>>>(
             a, ft, (int32_t) ntb, c1.starts.get(), c1.lists.get(), jobs, tier.get(),
-            tier_present.get());
+            tier_present.get(), 1);
         // lists longer than 32 entries: counts stay on the device, fixed grids
         Buf<int32_t> pos[2], list[2];
         for (int which = 1; which <= 2; ++which) {
@@ -1752,15 +1754,23 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             const unsigned grid = (unsigned) std::min<int64_t>(ctx->num_cus * 8, std::max<int64_t>(1, ntb));
             if (which == 1)
                 l1_finalize_wave_kernel<T, D><<<grid, 256, 0, ctx->stream>>>(
-                    a, ft, list[0].get(), pos[0].get() + ntb, c1.starts.get(), c1.lists.get(), jobs);
+                    a, ft, list[0].get(), pos[0].get() + ntb, c1.starts.get(), c1.lists.get(), jobs, 1);
             else
                 l1_finalize_block_kernel<T, D><<<grid, 256, 0, ctx->stream>>>(
-                    a, ft, list[1].get(), pos[1].get() + ntb, c1.starts.get(), c1.lists.get(), jobs);
+                    a, ft, list[1].get(), pos[1].get() + ntb, c1.starts.get(), c1.lists.get(), jobs, 1);
         }
         if (with_blocks)
-            copy_rank_blocks_kernel<<<(unsigned) std::min<int64_t>(ctx->num_cus * 8, ntb), 256, 0,
+            copy_rank_blocks_kernel<<<(unsigned) std::min<int64_t>(ctx->num_cus * 8, div_up(ntb, 4)), 256, 0,
                                       ctx->stream>>>(
-                jobs.count, jobs.dst, jobs.src, jobs.len, st->src_by_rank.get(), c1.lists.get());
+                (int32_t) ntb, jobs.dst, jobs.src, jobs.len, st->src_by_rank.get(), c1.lists.get());
+        if (l1_stats) {
+            int32_t hd[16];
+            BT_HIP_CHECK(hipMemcpy(hd, l1_dbg.get(), 64, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[bt trav] list-1 ordering: %d lists of <= 64 entries (%d with a head of <= 16; "
+                    "head entries %d of %d), %d for the wave kernel (%d merged, %d sorted), %d for the "
+                    "workgroup kernel, %d serial (longest %d)\n", hd[0], hd[1], hd[8], hd[9], hd[2],
+                    hd[6], hd[7], hd[3], hd[4], hd[5]);
+        }
         // the scratch buffers above return to the pool at scope exit: all work that uses
         // them is already queued on this stream, and so is whatever reuses them
     }

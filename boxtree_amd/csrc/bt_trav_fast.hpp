@@ -34,6 +34,7 @@ struct BlockJobs {
     int32_t *dst;                 // offset into the list-1 array
     int32_t *src;                 // offset into src_by_rank
     int32_t *len;
+    int32_t *dbg;                 // BT_TRAV_STATS: counters of the ordering kernels (or null)
 };
 
 template <class T, int D>
@@ -57,15 +58,20 @@ __global__ __launch_bounds__(256) void compact_sources_by_rank_kernel(SourceRank
 
 // one workgroup per job at a time (the largest job, the root's, is a 12 MB copy at 1e8
 // points); the job count stays on the device
-__global__ __launch_bounds__(256) void copy_rank_blocks_kernel(const int32_t *njobs, const int32_t *dst,
+// own-subtree blocks: slot j belongs to target box j (len 0: none).  The ordering kernels
+// used to append jobs through one atomic counter: 4*10^5 appends to one address took about
+// as long as ordering the lists.
+__global__ __launch_bounds__(256) void copy_rank_blocks_kernel(int32_t nj, const int32_t *dst,
         const int32_t *src, const int32_t *len, const int32_t *src_by_rank, int32_t *lists)
 {
-    const int32_t nj = *njobs;
-    for (int32_t j = blockIdx.x; j < nj; j += gridDim.x) {
+    // a wave per slot: most slots are empty
+    const int lane = threadIdx.x & 63;
+    for (int32_t j = blockIdx.x * 4 + (threadIdx.x >> 6); j < nj; j += gridDim.x * 4) {
         const int32_t n = len[j];
+        if (n <= 0) continue;
         const int32_t *in = src_by_rank + src[j];
         int32_t *out = lists + dst[j];
-        for (int32_t i = threadIdx.x; i < n; i += 256) out[i] = in[i];
+        for (int32_t i = lane; i < n; i += 64) out[i] = in[i];
     }
 }
 
@@ -793,7 +799,7 @@ __global__ __launch_bounds__(256) void l1_finalize_kernel(TravArgs<T, D> a, Fast
         k = 0;
         while (k < n && out[k] <= my_rank) ++k;
         for (int32_t i = n - 1; i >= k; --i) out[i + blk_len] = ft.box_of_rank[out[i]];
-        const int32_t j = atomicAdd(jobs.count, 1);
+        const int32_t j = tbn;                  // one slot per target box: no shared counter
         jobs.dst[j] = l1_starts[tbn] + k;
         jobs.src[j] = blk_src;
         jobs.len[j] = blk_len;
@@ -820,14 +826,38 @@ __global__ __launch_bounds__(256) void compact_tier_kernel(int32_t n, TierIs pr,
     if (i < n && pr(i)) out[pos[i]] = i;
 }
 
+// all-reduce over an aligned group of 16 lanes (one DPP row): quad permutes, then the
+// mirrors of half a row and of the row
+__device__ __forceinline__ int group16_max(int v)
+{
+    int o;
+    o = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false); v = o > v ? o : v;    // quad_perm [1,0,3,2]
+    o = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false); v = o > v ? o : v;    // quad_perm [2,3,0,1]
+    o = __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false); v = o > v ? o : v;   // row_half_mirror
+    o = __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false); v = o > v ? o : v;   // row_mirror
+    return v;
+}
+
+__device__ __forceinline__ int group16_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+    return v;
+}
+
 template <class T, int D>
 __global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, FastTree ft,
         int32_t ntb, const int32_t *l1_starts, int32_t *l1_lists, BlockJobs jobs,
         uint8_t *tier /* [ntb], zeroed: 1 = wave kernel, 2 = workgroup kernel */,
-        int32_t *tier_present /* [2], zeroed */)
+        int32_t *tier_present /* [2], zeroed */,
+        int boxes /* the lists hold box numbers (ordered by their depth-first rank, one lookup
+                     per entry) instead of ranks (ordered, then mapped back: a second lookup) */)
 {
-    // sixteen lanes per box, two entries per lane: four boxes' chains of dependent
+    // sixteen lanes per box, up to four entries per lane: four boxes' chains of dependent
     // loads (box -> rank -> row -> box_of_rank) are in flight per wave
+    __shared__ int32_t s_l1[16 * 64];
     const int32_t gid = blockIdx.x * 256 + threadIdx.x;
     const int32_t tbn = gid >> 4;
     const int lane = gid & 15;
@@ -835,6 +865,15 @@ __global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, Fa
     const int32_t b = a.target_boxes[tbn];
     int32_t *out = l1_lists + l1_starts[tbn];
     const int32_t n_all = l1_starts[tbn + 1] - l1_starts[tbn];
+    // the entries are fetched before the length of the own block is known (three dependent
+    // loads away: box -> rank -> source prefix): slots behind the entries hold junk and are
+    // masked below
+    int32_t x_early[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = lane + 16 * k;
+        x_early[k] = (i < n_all && i < 64) ? out[i] : INT32_MAX;
+    }
     int32_t blk_len = 0, blk_src = 0;
     const int32_t my_rank = ft.dfs_rank[b];
     if (box_flags(a, b) & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
@@ -843,39 +882,60 @@ __global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, Fa
     }
     const int32_t n = n_all - blk_len;
     if (n <= 64) {
-        // up to four entries per lane; the upper two only where a list has more than 32
-        // (a 16-lane group takes one branch together)
-        const bool big = n > 32;
-        const int32_t v0 = lane < n ? out[lane] : INT32_MAX;
-        const int32_t v1 = lane + 16 < n ? out[lane + 16] : INT32_MAX;
-        const int32_t v2 = (big && lane + 32 < n) ? out[lane + 32] : INT32_MAX;
-        const int32_t v3 = (big && lane + 48 < n) ? out[lane + 48] : INT32_MAX;
-        int r0 = 0, r1 = 0, r2 = 0, r3 = 0, k = 0;
+        // The list arrives as a short unordered head (the box itself, coarser boxes) followed
+        // by a run that is already ascending: the colleagues come in depth-first order and
+        // each is walked depth first.  The head is found by looking for the last descent;
+        // every entry counts the head entries below it (c trips instead of n), a run entry
+        // adds its place in the run, a head entry a binary search in the run.  A list that
+        // is not of that form has c = n: plain ranking by counting.
+        int32_t *sv = s_l1 + (threadIdx.x >> 4) * 64;
+        int32_t x[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int32_t o0 = __shfl(v0, j, 16), o1 = __shfl(v1, j, 16);
-            r0 += ((o0 < v0) ? 1 : 0) + ((o1 < v0) ? 1 : 0);     // ranks are distinct
-            r1 += ((o0 < v1) ? 1 : 0) + ((o1 < v1) ? 1 : 0);
-            k += ((o0 <= my_rank) ? 1 : 0) + ((o1 <= my_rank) ? 1 : 0);   // before the own block
-            if (big) {
-                const int32_t o2 = __shfl(v2, j, 16), o3 = __shfl(v3, j, 16);
-                r0 += ((o2 < v0) ? 1 : 0) + ((o3 < v0) ? 1 : 0);
-                r1 += ((o2 < v1) ? 1 : 0) + ((o3 < v1) ? 1 : 0);
-                r2 += ((o0 < v2) ? 1 : 0) + ((o1 < v2) ? 1 : 0) + ((o2 < v2) ? 1 : 0) + ((o3 < v2) ? 1 : 0);
-                r3 += ((o0 < v3) ? 1 : 0) + ((o1 < v3) ? 1 : 0) + ((o2 < v3) ? 1 : 0) + ((o3 < v3) ? 1 : 0);
-                k += ((o2 <= my_rank) ? 1 : 0) + ((o3 <= my_rank) ? 1 : 0);
-            }
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 16 * k;
+            x[k] = i < n ? (boxes ? ft.dfs_rank[x_early[k]] : x_early[k]) : INT32_MAX;
+            sv[i] = x[k];
         }
-        const int32_t w0 = lane < n ? ft.box_of_rank[v0] : 0;
-        const int32_t w1 = lane + 16 < n ? ft.box_of_rank[v1] : 0;
-        const int32_t w2 = (big && lane + 32 < n) ? ft.box_of_rank[v2] : 0;
-        const int32_t w3 = (big && lane + 48 < n) ? ft.box_of_rank[v3] : 0;
-        if (lane < n) out[r0 < k ? r0 : r0 + blk_len] = w0;
-        if (lane + 16 < n) out[r1 < k ? r1 : r1 + blk_len] = w1;
-        if (big && lane + 32 < n) out[r2 < k ? r2 : r2 + blk_len] = w2;
-        if (big && lane + 48 < n) out[r3 < k ? r3 : r3 + blk_len] = w3;
+        __builtin_amdgcn_wave_barrier();
+        int last_desc = 0, below = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = lane + 16 * k;
+            if (i >= 1 && i < n && sv[i - 1] > x[k]) last_desc = i;
+            below += (i < n && x[k] <= my_rank) ? 1 : 0;       // entries before the own block
+        }
+        const int c_found = group16_max(last_desc);
+        const int k = group16_sum(below);
+        const int c = c_found <= 16 ? c_found : n;             // long heads: rank everything
+        if (jobs.dbg && lane == 0) {
+            atomicAdd(jobs.dbg + 0, 1); atomicAdd(jobs.dbg + 8, c); atomicAdd(jobs.dbg + 9, n);
+            if (c_found <= 16) atomicAdd(jobs.dbg + 1, 1);
+        }
+        int cnt[4] = {0, 0, 0, 0};
+        for (int t = 0; t < c; ++t) {
+            const int32_t pv = sv[t];                          // one address: a broadcast read
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cnt[q] += (pv < x[q]) ? 1 : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 16 * q;
+            if (i >= n) continue;
+            int pos;
+            if (i >= c) {
+                pos = (i - c) + cnt[q];
+            } else {
+                int lo = c, hi = n;                            // run entries below x[q]
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (sv[mid] < x[q]) lo = mid + 1; else hi = mid;
+                }
+                pos = cnt[q] + (lo - c);
+            }
+            out[pos < k ? pos : pos + blk_len] = boxes ? x_early[q] : ft.box_of_rank[x[q]];
+        }
         if (blk_len > 0 && lane == 0) {
-            const int32_t j = atomicAdd(jobs.count, 1);
+            const int32_t j = tbn;                  // one slot per target box: no shared counter
             jobs.dst[j] = l1_starts[tbn] + k;
             jobs.src[j] = blk_src;
             jobs.len[j] = blk_len;
@@ -886,15 +946,21 @@ __global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, Fa
     // longer rows are left to a wave (LDS ranking) or a workgroup (LDS sort); they are
     // collected by a scan over `tier`, not by atomic appends (a million appends to one
     // counter serialise)
+    if (jobs.dbg) {
+        atomicAdd(jobs.dbg + (n <= L1_WAVE_MAX ? 2 : n <= L1_BLOCK_MAX ? 3 : 4), 1);
+        if (n > L1_BLOCK_MAX) atomicMax(jobs.dbg + 5, n);
+    }
     if (n <= L1_WAVE_MAX && tier) { tier[tbn] = 1; tier_present[0] = 1; return; }
     if (n <= L1_BLOCK_MAX && tier) { tier[tbn] = 2; tier_present[1] = 1; return; }
+    if (boxes)
+        for (int32_t i = 0; i < n; ++i) out[i] = ft.dfs_rank[out[i]];
     sort_i32_inplace(out, n);
     int32_t k = n;
     if (blk_len > 0) {
         k = 0;
         while (k < n && out[k] <= my_rank) ++k;
         for (int32_t i = n - 1; i >= k; --i) out[i + blk_len] = ft.box_of_rank[out[i]];
-        const int32_t j = atomicAdd(jobs.count, 1);
+        const int32_t j = tbn;                  // one slot per target box: no shared counter
         jobs.dst[j] = l1_starts[tbn] + k;
         jobs.src[j] = blk_src;
         jobs.len[j] = blk_len;
@@ -908,17 +974,25 @@ __global__ __launch_bounds__(256) void l1_finalize32_kernel(TravArgs<T, D> a, Fa
 template <class T, int D>
 __global__ __launch_bounds__(256) void l1_finalize_wave_kernel(TravArgs<T, D> a, FastTree ft,
         const int32_t *mid_list, const int32_t *d_nmid, const int32_t *l1_starts, int32_t *l1_lists,
-        BlockJobs jobs)
+        BlockJobs jobs, int boxes /* see l1_finalize32_kernel */)
 {
     __shared__ int32_t s_all[4][L1_WAVE_MAX];
+    __shared__ int32_t s_box_all[4][L1_WAVE_MAX];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int32_t *s_v = s_all[w];
+    int32_t *s_box = s_box_all[w];
     const int32_t nmid = *d_nmid;
   for (int32_t idx = blockIdx.x * 4 + w; idx < nmid; idx += gridDim.x * 4) {
     const int32_t tbn = mid_list[idx];
     const int32_t b = a.target_boxes[tbn];
     int32_t *out = l1_lists + l1_starts[tbn];
     const int32_t n_all = l1_starts[tbn + 1] - l1_starts[tbn];
+    // (fetched before the length of the own block is known, as in l1_finalize32_kernel)
+    for (int i = lane; i < n_all && i < L1_WAVE_MAX; i += 64) {
+        const int32_t v = out[i];
+        s_box[i] = v;
+        s_v[i] = v;
+    }
     int32_t blk_len = 0, blk_src = 0;
     const int32_t my_rank = ft.dfs_rank[b];
     if (box_flags(a, b) & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
@@ -926,12 +1000,62 @@ __global__ __launch_bounds__(256) void l1_finalize_wave_kernel(TravArgs<T, D> a,
         blk_len = ft.src_prefix[my_rank + ft.subtree_size[b]] - blk_src;
     }
     const int32_t n = n_all - blk_len;
-    // bitonic sort of the (distinct) ranks in LDS by the wave: O(n log^2 n / 64) steps
-    // (ranking every entry against all others took 3.4 ms on the 10^5 mid-size lists of
-    // the 10^8 + 10^7 extent workload)
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    if (boxes) {
+        for (int i = lane; i < n; i += 64) s_v[i] = ft.dfs_rank[s_box[i]];
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+    }
+    // the unordered head of the list (see l1_finalize32_kernel): up to the last descent
+    int c = 0;
+    for (int base = ((n - 1) >> 6) << 6; base >= 0; base -= 64) {
+        const int i = base + lane;
+        const uint64_t bal = __ballot(i >= 1 && i < n && s_v[i - 1] > s_v[i]);
+        if (bal) { c = base + 63 - __clzll(bal); break; }
+    }
+    if (jobs.dbg && lane == 0) atomicAdd(jobs.dbg + (c <= 64 ? 6 : 7), 1);
+    if (c <= 64) {
+        // merge: an entry's place = head entries below it + (run entries below it: its own
+        // index in the run, or a binary search for a head entry)
+        int32_t k0 = 0;                              // entries before the own-subtree block
+        for (int base = 0; base < n; base += 64)
+            k0 += __popcll(__ballot(base + lane < n && s_v[base + lane] <= my_rank));
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            if (i >= n) continue;
+            const int32_t xv = s_v[i];
+            int cnt = 0;
+            for (int t = 0; t < c; ++t) cnt += (s_v[t] < xv) ? 1 : 0;
+            int pos;
+            if (i >= c) {
+                pos = (i - c) + cnt;
+            } else {
+                int lo = c, hi = n;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_v[mid] < xv) lo = mid + 1; else hi = mid;
+                }
+                pos = cnt + (lo - c);
+            }
+            out[pos < k0 ? pos : pos + blk_len] = boxes ? s_box[i] : ft.box_of_rank[xv];
+        }
+        if (blk_len > 0 && lane == 0) {
+            const int32_t j = tbn;                  // one slot per target box: no shared counter
+            jobs.dst[j] = l1_starts[tbn] + k0;
+            jobs.src[j] = blk_src;
+            jobs.len[j] = blk_len;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        continue;
+    }
+    // a long unordered head: bitonic sort of the (distinct) ranks in LDS by the wave,
+    // O(n log^2 n / 64) steps (ranking every entry against all others took 3.4 ms on the
+    // 10^5 mid-size lists of the 10^8 + 10^7 extent workload)
     int m = 64;
     while (m < n) m <<= 1;
-    for (int i = lane; i < m; i += 64) s_v[i] = (i < n) ? out[i] : INT32_MAX;
+    for (int i = n + lane; i < m; i += 64) s_v[i] = INT32_MAX;
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     for (int k = 2; k <= m; k <<= 1) {
@@ -954,7 +1078,7 @@ __global__ __launch_bounds__(256) void l1_finalize_wave_kernel(TravArgs<T, D> a,
     for (int i = lane; i < n; i += 64)
         out[i < k0 ? i : i + blk_len] = ft.box_of_rank[s_v[i]];
     if (blk_len > 0 && lane == 0) {
-        const int32_t j = atomicAdd(jobs.count, 1);
+        const int32_t j = tbn;                  // one slot per target box: no shared counter
         jobs.dst[j] = l1_starts[tbn] + k0;
         jobs.src[j] = blk_src;
         jobs.len[j] = blk_len;
@@ -969,7 +1093,7 @@ __global__ __launch_bounds__(256) void l1_finalize_wave_kernel(TravArgs<T, D> a,
 template <class T, int D>
 __global__ __launch_bounds__(256) void l1_finalize_block_kernel(TravArgs<T, D> a, FastTree ft,
         const int32_t *big_list, const int32_t *d_nbig, const int32_t *l1_starts,
-        int32_t *l1_lists, BlockJobs jobs)
+        int32_t *l1_lists, BlockJobs jobs, int boxes /* see l1_finalize32_kernel */)
 {
     __shared__ int32_t s_v[L1_BLOCK_MAX];
     const int32_t nbig = *d_nbig;
@@ -988,7 +1112,8 @@ __global__ __launch_bounds__(256) void l1_finalize_block_kernel(TravArgs<T, D> a
     const int32_t n = n_all - blk_len;
     int m = 64;
     while (m < n) m <<= 1;
-    for (int i = threadIdx.x; i < m; i += 256) s_v[i] = (i < n) ? out[i] : INT32_MAX;
+    for (int i = threadIdx.x; i < m; i += 256)
+        s_v[i] = (i < n) ? (boxes ? ft.dfs_rank[out[i]] : out[i]) : INT32_MAX;
     __syncthreads();
     for (int k = 2; k <= m; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
@@ -1013,7 +1138,7 @@ __global__ __launch_bounds__(256) void l1_finalize_block_kernel(TravArgs<T, D> a
     for (int i = threadIdx.x; i < n; i += 256)
         out[i < k0 ? i : i + blk_len] = ft.box_of_rank[s_v[i]];
     if (blk_len > 0 && threadIdx.x == 0) {
-        const int32_t j = atomicAdd(jobs.count, 1);
+        const int32_t j = tbn;                  // one slot per target box: no shared counter
         jobs.dst[j] = l1_starts[tbn] + k0;
         jobs.src[j] = blk_src;
         jobs.len[j] = blk_len;

@@ -407,31 +407,6 @@ __global__ __launch_bounds__(256) void make_items_v2_kernel(int32_t ntb, const i
 // ROWS = false: the items of the overflow list are walked again and write straight to
 //   their final places.
 
-// box numbers -> depth-first ranks in the list-1 segments of the items that were walked a
-// second time (one wave per item; the slots reserved behind an item's entries for its own
-// block hold no box numbers yet)
-__global__ __launch_bounds__(256) void ranks_of_overflow_kernel(const int32_t *ovf_count,
-        const int32_t *ovf_list, const int32_t *starts, const int32_t *rank, int32_t nboxes,
-        int32_t *lists)
-{
-    const int32_t idx = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    if (idx >= *ovf_count) return;
-    const int32_t item = ovf_list[idx];
-    const int32_t s = starts[item], e = starts[item + 1];
-    for (int32_t k0 = s + lane; k0 < e; k0 += 4 * 64) {
-        int32_t v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (k0 + u * 64 < e) ? lists[k0 + u * 64] : -1;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            v[u] = ((uint32_t) v[u] < (uint32_t) nboxes) ? rank[v[u]] : 0;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (k0 + u * 64 < e) lists[k0 + u * 64] = v[u];
-    }
-}
-
 // Per-level list-3 counts of the items, "staircase" layout: an item of a target box at
 // level tl can only have entries at source levels > tl, and items are numbered in
 // target-box (= level) order, so row l needs columns for the items of levels < l only:
@@ -516,10 +491,10 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         e1 = V2Emit<ROWS>{w.l1_lists + w.l1_cs[item], 1, INT_MAX, 0};
         ec = V2Emit<ROWS>{w.close_lists ? w.close_lists + w.close_cs[item] : nullptr, 1, INT_MAX, 0};
     }
-    // List 1 holds depth-first ranks until its final ordering.  The walk writes box numbers
-    // and the ranks are looked up afterwards (rows_to_csr_v2_kernel, ranks_of_overflow_kernel:
-    // independent loads, several per lane in flight); a lookup here would stall the walk once
-    // per entry, the store having to wait for the load.
+    // List 1 is ordered by depth-first rank at the end.  The walk writes box numbers and the
+    // ordering kernels look the ranks up (l1_finalize*_kernel: one lookup per entry, none to
+    // map back); a lookup here would stall the walk once per entry, the store having to wait
+    // for the load.
     auto emit1 = [&](int32_t box) { e1(box); };
     int32_t *lvl = s_walk_lds + w.walk_cap * WALK_THREADS + threadIdx.x;
     int n3 = 0;
@@ -728,7 +703,17 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         if (w.close_cs) w.close_cs[item] = ec.n;
         const bool ovf = e1.n > w.K1 || n3 > w.K3 || (w.close_cs && ec.n > w.Kc);
         w.overflow[item] = ovf ? 1 : 0;
-        if (ovf) w.ovf_list[atomicAdd(w.ovf_count, 1)] = item;
+        // one append per wave (the lanes are together again here): 10^5 appends to one
+        // counter, one by one, cost as much as a tenth of the walk
+        const uint64_t obal = __ballot(ovf);
+        if (obal) {
+            const int lane = threadIdx.x & 63;
+            const int leader = __ffsll((long long) obal) - 1;
+            int32_t base = 0;
+            if (lane == leader) base = atomicAdd(w.ovf_count, (int32_t) __popcll(obal));
+            base = __shfl(base, leader, 64);
+            if (ovf) w.ovf_list[base + __popcll(obal & ((1ull << lane) - 1ull))] = item;
+        }
         if (ovf && w.dbg_counts) {          // BT_TRAV_STATS: why items overflow
             if (e1.n > w.K1) atomicAdd(w.dbg_counts + 0, 1);
             if (n3 > w.K3) atomicAdd(w.dbg_counts + 1, 1);
