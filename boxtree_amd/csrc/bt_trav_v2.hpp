@@ -601,6 +601,16 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         // a 4-byte load per step made every step wait for a load of its own.
         uint32_t cw[C];
         v2_load_children<C>(w.child_t, parent, cw);
+        // With target extents the separation criteria need the centre of every candidate.
+        // On this path the tree is a lattice, i.e. every stored centre IS "parent centre
+        // +/- level_to_rad(child level)" bit for bit (check_structure_kernel), so a child's
+        // centre is computed from the centre of the box being scanned; that centre is
+        // loaded when the scan enters a colleague or returns to a box -- once per box
+        // instead of once per child (a random 24-byte load each: 10^8 of them at c4).
+        T pcen[D];
+#pragma unroll
+        for (int q = 0; q < D; ++q) pcen[q] = 0;
+        if (a.targets_have_extent) load_center(a, parent, pcen);
         while (go) {
             uint32_t raw = cw[0];
 #pragma unroll
@@ -608,6 +618,9 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             const int32_t wb = (int32_t) (raw & CH_ID_MASK);
             bool descend = false;
             int rel[D];
+            T wc[D];                                    // centre of wb (target extents only)
+#pragma unroll
+            for (int q = 0; q < D; ++q) wc[q] = 0;
             if (wb && (raw & (CH_SRC | CH_HSC))) {
                 const int k = size + 1;                 // level of wb minus tl
                 bool in_list_1 = true;
@@ -617,14 +630,18 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                     in_list_1 = in_list_1 && rel[ax] >= -1 && rel[ax] <= (1 << k);
                 }
                 const int wl = tl + k;
+                if (a.targets_have_extent) {
+                    const T child_rad = level_to_rad(a.root_extent, wl);
+#pragma unroll
+                    for (int q = 0; q < D; ++q)
+                        wc[q] = v2_mbit<D>(mnr, q) ? pcen[q] + child_rad : pcen[q] - child_rad;
+                }
                 if (in_list_1) {
                     if (raw & CH_SRC) emit1(wb);
                     descend = (raw & CH_HSC) != 0;
                 } else {
                     bool meets = true;
                     if (a.targets_have_extent) {
-                        T wc[D];
-                        load_center(a, wb, wc);
                         const T source_rad = level_to_rad(a.root_extent, wl);
                         if (a.crit == BT_CRIT_STATIC_LINF) {
                             T l_inf = 0;
@@ -675,7 +692,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                 parent = wb; mnr = 0;
                 v2_load_children<C>(w.child_t, parent, cw);
 #pragma unroll
-                for (int ax = 0; ax < D; ++ax) prel[ax] = rel[ax];
+                for (int ax = 0; ax < D; ++ax) { prel[ax] = rel[ax]; pcen[ax] = wc[ax]; }
                 continue;
             }
             bool popped = false;
@@ -692,7 +709,10 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
 #pragma unroll
                 for (int ax = 0; ax < D; ++ax) prel[ax] >>= 1;
             }
-            if (popped && go) v2_load_children<C>(w.child_t, parent, cw);
+            if (popped && go) {
+                v2_load_children<C>(w.child_t, parent, cw);
+                if (a.targets_have_extent) load_center(a, parent, pcen);
+            }
         }
     }
 
