@@ -171,6 +171,10 @@ struct bt_context {
     // queues the status read instead of waiting for it; sync_stream examines it later
     bool stream_ordered = false;
     bool status_inflight = false;
+    // a block of zeroed device memory for the small counters and flags of a call
+    // (bt::zero_alloc): one memset per API call instead of one per counter
+    char *zero_block = nullptr;
+    size_t zero_cap = 0, zero_used = 0;
     bool stage_timing = true;        // record the per-stage events (bt_set_stage_timing)
     bool pinned_stores_ok = false;   // kernels may store into h_ring / h_status (probed at creation)
 };
@@ -185,6 +189,11 @@ int reset_status(bt_context *ctx);
 int d2h(bt_context *ctx, void *host_dst, const void *dev_src, size_t bytes);
 int sync_stream(bt_context *ctx);    // hipStreamSynchronize + delivery of the pending reads
                                      // + the verdict on a status read queued by finish_call
+// Zeroed device memory for the duration of the current API call (256-byte aligned), or
+// nullptr if the block is used up (the caller then allocates and clears its own).
+// zero_begin, at the entry of an API call, clears what the previous call used.
+void *zero_alloc(bt_context *ctx, size_t bytes);
+int zero_begin(bt_context *ctx);
 int finish_call(bt_context *ctx);    // end of an API call: check_status, or (stream-ordered
                                      // contexts) queue the status read and return
 }  // namespace bt

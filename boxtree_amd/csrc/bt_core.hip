@@ -215,6 +215,23 @@ int sync_stream(bt_context *ctx)
     return BT_OK;
 }
 
+void *zero_alloc(bt_context *ctx, size_t bytes)
+{
+    const size_t need = (bytes + 255) & ~(size_t) 255;
+    if (!ctx->zero_block || need > ctx->zero_cap - ctx->zero_used) return nullptr;
+    void *p = ctx->zero_block + ctx->zero_used;
+    ctx->zero_used += need;
+    return p;
+}
+
+int zero_begin(bt_context *ctx)
+{
+    if (ctx->zero_block && ctx->zero_used > 0)
+        BT_HIP_CHECK(hipMemsetAsync(ctx->zero_block, 0, ctx->zero_used, ctx->stream));
+    ctx->zero_used = 0;
+    return BT_OK;
+}
+
 int finish_call(bt_context *ctx)
 {
     if (!ctx->stream_ordered) return check_status(ctx);
@@ -276,6 +293,11 @@ int bt_create(int device, void *hip_stream, bt_context **out)
     if (e == hipSuccess)
         e = hipHostMalloc((void **) &ctx->h_status, sizeof(bt::DeviceStatus), hipHostMallocDefault);
     if (e == hipSuccess) {
+        ctx->zero_cap = 64 << 10;
+        e = hipMalloc((void **) &ctx->zero_block, ctx->zero_cap);
+        if (e == hipSuccess) e = hipMemset(ctx->zero_block, 0, ctx->zero_cap);
+    }
+    if (e == hipSuccess) {
         ctx->h_ring_cap = 256 << 10;
         e = hipHostMalloc((void **) &ctx->h_ring, ctx->h_ring_cap, hipHostMallocDefault);
     }
@@ -310,6 +332,7 @@ void bt_destroy(bt_context *ctx)
     bt_free_mgpu_state(ctx);
     ctx->pool.release_all();
     if (ctx->d_status) (void) hipFree(ctx->d_status);
+    if (ctx->zero_block) (void) hipFree(ctx->zero_block);
     for (void *&e : ctx->sort_ev)
         if (e) { (void) hipEventDestroy((hipEvent_t) e); e = nullptr; }
     if (ctx->scan_desc) (void) hipFree(ctx->scan_desc);

@@ -373,7 +373,11 @@ int radix_sort_pairs_w(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32
     Buf<uint32_t> hist;      // [npasses][RADIX] then tile counters [npasses]
     Buf<W> lookback;         // [ntiles][RADIX] (x npasses for 32-bit words)
     const int64_t lb_per_pass = (int64_t) ntiles * RADIX;
-    BT_CHECK(hist.alloc(ctx->pool, (int64_t) npasses * RADIX + MAXP));
+    // (the histograms come from the call's zeroed block when it has room)
+    const int64_t hist_words = (int64_t) npasses * RADIX + MAXP;
+    uint32_t *hist_zero = (uint32_t *) zero_alloc(ctx, (size_t) hist_words * 4);
+    if (hist_zero) hist.set_external(hist_zero, hist_words);
+    else BT_CHECK(hist.alloc(ctx->pool, hist_words));
     BT_CHECK(lookback.alloc(ctx->pool, lb_per_pass * (PER_PASS ? npasses : 1)));
     uint32_t *tile_counters = hist.get() + (int64_t) npasses * RADIX;
 
@@ -385,7 +389,8 @@ int radix_sort_pairs_w(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32
     if (timed && !ev[0])
         for (int i = 0; i < 4; ++i) BT_HIP_CHECK(hipEventCreate(&ev[i]));
 
-    BT_HIP_CHECK(hipMemsetAsync(hist.get(), 0, ((size_t) npasses * RADIX + MAXP) * 4, ctx->stream));
+    if (!hist_zero)
+        BT_HIP_CHECK(hipMemsetAsync(hist.get(), 0, ((size_t) npasses * RADIX + MAXP) * 4, ctx->stream));
     BT_HIP_CHECK(hipMemsetAsync(lookback.get(), 0,
                                 (size_t) lb_per_pass * (PER_PASS ? npasses : 1) * sizeof(W), ctx->stream));
 
@@ -498,6 +503,7 @@ static int sort_api(bt_context *ctx, KeyT *keys_in, uint32_t *vals_in, KeyT *key
     if (n == 0) return BT_OK;
     BT_HIP_CHECK(hipSetDevice(ctx->device));
     BT_CHECK(bt::reset_status(ctx));
+    BT_CHECK(bt::zero_begin(ctx));
     bool in_b = false;
     BT_CHECK(bt::radix_sort_pairs<KeyT>(ctx, keys_in, vals_in, keys_out, vals_out, n,
                                         begin_bit, end_bit, false, &in_b));

@@ -479,6 +479,70 @@ __global__ __launch_bounds__(256) void compact_kernel(FlagPred pr, int32_t n, co
     if (pr(i)) out[pos[i]] = i;
 }
 
+// What the host reads in the first wait of a traversal, in one block ("mail"):
+// rows[k][l] = pos[k][level_start_box_nrs[l]] for the five box lists (the number of listed
+// boxes before the level's first box), the flags of check_structure_kernel (written there),
+// and the root's centre -- one kernel and one read instead of five gathers, a row copy and
+// five reads.
+struct BoxListMarks {
+    const int32_t *pos[5];        // scans of the list predicates, [nboxes + 1]
+    int32_t *rows;                // [5][nlevels + 1]
+    const void *centers;          // [d][aligned]
+    int64_t aligned;
+    void *root_center;            // [d] of the coordinate type
+    int nlevels, dims, csize;
+};
+
+__global__ void box_list_marks_kernel(BoxListMarks m, const int32_t *level_start_box_nrs)
+{
+    const int t = threadIdx.x;
+    const int n1 = m.nlevels + 1;
+    for (int i = t; i < 5 * n1; i += blockDim.x) {
+        const int k = i / n1, l = i % n1;
+        m.rows[i] = m.pos[k][level_start_box_nrs[l]];
+    }
+    if (t < m.dims) {
+        if (m.csize == 8) ((double *) m.root_center)[t] = ((const double *) m.centers)[(int64_t) t * m.aligned];
+        else ((float *) m.root_center)[t] = ((const float *) m.centers)[(int64_t) t * m.aligned];
+    }
+}
+
+// the box lists themselves: list k gets the boxes with pred k, in box order
+struct BoxLists {
+    FlagPred pred[5];
+    const int32_t *pos[5];
+    int32_t *out[5];              // null: not wanted (a list that shares another's array)
+};
+
+__global__ __launch_bounds__(256) void compact_lists_kernel(BoxLists bl, int32_t n)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+#pragma unroll
+    for (int k = 0; k < 5; ++k)
+        if (bl.out[k] && bl.pred[k](i)) bl.out[k][bl.pos[k][i]] = i;
+}
+
+// up to 40 array copies in one launch (blockIdx.y = the copy): the result arrays that
+// were made in scratch before the caller's block existed
+struct SpanCopies {
+    enum { MAX = 40 };
+    const int32_t *src[MAX];
+    int32_t *dst[MAX];
+    int64_t n[MAX];
+    int count;
+};
+
+__global__ __launch_bounds__(256) void copy_spans_kernel(SpanCopies c)
+{
+    const int k = blockIdx.y;
+    const int32_t *src = c.src[k];
+    int32_t *dst = c.dst[k];
+    const int64_t n = c.n[k];
+    for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256)
+        dst[i] = src[i];
+}
+
 // level starts in a box list: traversal.py:361-392 + 2093-2096 (== lower_bound of the
 // level's first box id in the ascending list)
 __global__ void level_starts_kernel(const int32_t *list, int32_t n, const int32_t *level_start_box_nrs,
@@ -1401,13 +1465,12 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     Buf<int32_t> &srccoll_rows = st->srccoll_rows, &srccoll_cnt = st->srccoll_cnt;
     BT_CHECK(coll_rows.alloc(ctx->pool, B * P));
     BT_CHECK(srccoll_rows.alloc(ctx->pool, B * P));
-    // coll_cnt | coll_ins | srccoll_cnt | l2_cnt are zeroed together
-    Buf<int32_t> zeroed;
-    BT_CHECK(zeroed.alloc(ctx->pool, 3 * B));
-    BT_CHECK(srccoll_cnt.alloc(ctx->pool, B));
-    BT_HIP_CHECK(hipMemsetAsync(zeroed.get(), 0, (size_t) (3 * B) * 4, ctx->stream));
-    BT_HIP_CHECK(hipMemsetAsync(srccoll_cnt.get(), 0, (size_t) B * 4, ctx->stream));
-    int32_t *d_coll_cnt = zeroed.get(), *d_coll_ins = zeroed.get() + B, *d_l2_cnt = zeroed.get() + 2 * B;
+    // coll_cnt | coll_ins | l2_cnt | srccoll_cnt are one array, zeroed together (the last
+    // quarter outlives this function: list 4 reads it)
+    BT_CHECK(srccoll_cnt.alloc(ctx->pool, 4 * B));
+    BT_HIP_CHECK(hipMemsetAsync(srccoll_cnt.get(), 0, (size_t) (4 * B) * 4, ctx->stream));
+    int32_t *d_coll_cnt = srccoll_cnt.get() + B, *d_coll_ins = srccoll_cnt.get() + 2 * B,
+            *d_l2_cnt = srccoll_cnt.get() + 3 * B;
     V2Rows<D> rows{};
     rows.child_t = st->child_t.get();
     rows.parent = p.box_parent_ids;
@@ -1465,8 +1528,12 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     Buf<int32_t> item_cnt, first_item, item_tbn, item_slot;
     Buf<int64_t> totals;            // device: nitems, coll, l2, l1, l3, close
     enum { T_NITEMS = 0, T_COLL, T_L2, T_L1, T_L3, T_CLOSE, T_L4, T_L4RAW, T_OVF, T_COUNT };
-    BT_CHECK(totals.alloc(ctx->pool, T_COUNT));
-    BT_HIP_CHECK(hipMemsetAsync(totals.get(), 0, T_COUNT * 8, ctx->stream));
+    if (int64_t *z = (int64_t *) bt::zero_alloc(ctx, T_COUNT * 8)) {
+        totals.set_external(z, T_COUNT);
+    } else {
+        BT_CHECK(totals.alloc(ctx->pool, T_COUNT));
+        BT_HIP_CHECK(hipMemsetAsync(totals.get(), 0, T_COUNT * 8, ctx->stream));
+    }
     BT_CHECK(item_cnt.alloc(ctx->pool, ntb));
     BT_CHECK(first_item.alloc(ctx->pool, ntb + 1));
     BT_CHECK(item_tbn.alloc(ctx->pool, items_cap));
@@ -1720,8 +1787,9 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
 
     // list 1: order by depth-first rank, insert the own-subtree blocks
     {
+        // [count | dst | src | len | tier bytes]: len and tier are cleared together
         Buf<int32_t> jobbuf;
-        BT_CHECK(jobbuf.alloc(ctx->pool, 3 * ntb + 1));
+        BT_CHECK(jobbuf.alloc(ctx->pool, 3 * ntb + 1 + div_up(ntb, 4) + 1));
         static const bool l1_stats = [] { const char *e = getenv("BT_TRAV_STATS"); return e && atoi(e); }();
         Buf<int32_t> l1_dbg;
         if (l1_stats) {
@@ -1730,13 +1798,16 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         }
         BlockJobs jobs{jobbuf.get(), jobbuf.get() + 1, jobbuf.get() + 1 + ntb,
                        jobbuf.get() + 1 + 2 * ntb, l1_dbg.get()};
-        BT_HIP_CHECK(hipMemsetAsync(jobs.len, 0, (size_t) ntb * 4, ctx->stream));
         Buf<uint8_t> tier;
         Buf<int32_t> tier_present;
-        BT_CHECK(tier.alloc(ctx->pool, ntb));
-        BT_CHECK(tier_present.alloc(ctx->pool, 2));
-        BT_HIP_CHECK(hipMemsetAsync(tier.get(), 0, (size_t) ntb, ctx->stream));
-        BT_HIP_CHECK(hipMemsetAsync(tier_present.get(), 0, 8, ctx->stream));
+        tier.set_external((uint8_t *) (jobs.len + ntb), ntb);
+        BT_HIP_CHECK(hipMemsetAsync(jobs.len, 0, (size_t) ntb * 4 + (size_t) ntb, ctx->stream));
+        if (int32_t *z = (int32_t *) bt::zero_alloc(ctx, 8)) {
+            tier_present.set_external(z, 2);
+        } else {
+            BT_CHECK(tier_present.alloc(ctx->pool, 2));
+            BT_HIP_CHECK(hipMemsetAsync(tier_present.get(), 0, 8, ctx->stream));
+        }
         l1_finalize32_kernel<T, D><<<nblk(ntb * 16), 256, 0, ctx->stream>>>(
             a, ft, (int32_t) ntb, c1.starts.get(), c1.lists.get(), jobs, tier.get(),
             tier_present.get(), 1);
@@ -1802,7 +1873,6 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     // (a fifth list, not part of the result: the boxes that have children, level by
     // level -- the colleague-row kernels run one group of lanes per such box)
     constexpr int NL = 5;
-    BT_CHECK(st->lev_starts.alloc(ctx->pool, NL * (nlevels + 1)));
     const bool shared_tb = sat && !p.target_boxes_mask;     // target_boxes is source_boxes
     FlagPred preds[NL] = {
         {p.box_flags, p.source_boxes_mask, BT_BOX_IS_SOURCE_BOX},
@@ -1816,29 +1886,35 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         BT_CHECK(pos[k].alloc(ctx->pool, B + 1));
         BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, preds[k], B, pos[k].get(),
                                                           (int32_t *) nullptr, true)));
-        gather_i32_kernel<<<1, 64, 0, ctx->stream>>>(nlevels + 1, st->d_level_start_box_nrs.get(),
-                                                     pos[k].get(), st->lev_starts.get() + k * (nlevels + 1));
     }
-    if (shared_tb)
-        BT_HIP_CHECK(hipMemcpyAsync(st->lev_starts.get() + (nlevels + 1), st->lev_starts.get(),
-                                    (size_t) (nlevels + 1) * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    Buf<int> bad;
-    BT_CHECK(bad.alloc(ctx->pool, 4));
-    BT_HIP_CHECK(hipMemsetAsync(bad.get(), 0, 4 * sizeof(int), ctx->stream));
+    // the mail block: [NL * (nlevels + 1) level starts | 4 flags | root centre (8 bytes an axis)]
+    const size_t n_rows = (size_t) NL * (nlevels + 1);
+    const size_t mail_words = n_rows + 4 + 2 * BT_MAX_DIMS;
+    BT_CHECK(st->lev_starts.alloc(ctx->pool, (int64_t) mail_words));
+    int32_t *d_bad = st->lev_starts.get() + n_rows;
+    BT_HIP_CHECK(hipMemsetAsync(d_bad, 0, 4 * sizeof(int32_t), ctx->stream));
     if (p.force_generic != 1)
         check_structure_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
             (int32_t) B, p.aligned_nboxes, p.box_parent_ids, p.box_child_ids, p.box_levels,
-            p.box_flags, (const T *) p.box_centers, (T) p.root_extent, bad.get());
-    int32_t hb[4] = {1, 1, 1, 0};
-    T root_center[D];
-    st->h_lev_starts.assign((size_t) NL * (nlevels + 1), 0);
-    BT_CHECK(bt::d2h(ctx, st->h_lev_starts.data(), st->lev_starts.get(), st->h_lev_starts.size() * 4));
-    BT_CHECK(bt::d2h(ctx, hb, bad.get(), 16));
-    for (int d = 0; d < D; ++d)
-        BT_CHECK(bt::d2h(ctx, &root_center[d], (const T *) p.box_centers + (size_t) d * p.aligned_nboxes,
-                         sizeof(T)));
+            p.box_flags, (const T *) p.box_centers, (T) p.root_extent, (int *) d_bad);
+    {
+        BoxListMarks mk{};
+        for (int k = 0; k < NL; ++k) mk.pos[k] = pos[(k == 1 && shared_tb) ? 0 : k].get();
+        mk.rows = st->lev_starts.get();
+        mk.centers = p.box_centers; mk.aligned = p.aligned_nboxes;
+        mk.root_center = st->lev_starts.get() + n_rows + 4;
+        mk.nlevels = nlevels; mk.dims = D; mk.csize = (int) sizeof(T);
+        box_list_marks_kernel<<<1, 128, 0, ctx->stream>>>(mk, st->d_level_start_box_nrs.get());
+    }
+    std::vector<int32_t> h_mail(mail_words, 0);
+    BT_CHECK(bt::d2h(ctx, h_mail.data(), st->lev_starts.get(), mail_words * 4));
     BT_CHECK(bt::sync_stream(ctx));
     ctx->n_host_syncs++;
+    int32_t hb[4] = {1, 1, 1, 0};
+    T root_center[D];
+    st->h_lev_starts.assign(h_mail.begin(), h_mail.begin() + (long) n_rows);
+    memcpy(hb, h_mail.data() + n_rows, 16);
+    memcpy(root_center, h_mail.data() + n_rows + 4, sizeof(T) * D);
     {
         const int32_t *h = st->h_lev_starts.data();
         st->nsb = h[0 * (nlevels + 1) + nlevels];
@@ -1849,12 +1925,16 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         Buf<int32_t> *lists[NL] = {&st->source_boxes, &st->target_boxes_buf,
                                    &st->source_parent_boxes, &st->ttp_boxes, &st->parent_boxes};
         const int64_t ns[NL] = {st->nsb, st->ntb, st->nspb, st->nttp, st->nparents};
+        BoxLists bl{};
         for (int k = 0; k < NL; ++k) {
+            bl.pred[k] = preds[k];
+            bl.pos[k] = pos[k].get();
+            bl.out[k] = nullptr;
             if (k == 1 && shared_tb) continue;
             BT_CHECK(lists[k]->alloc(ctx->pool, ns[k]));
-            compact_kernel<<<nblk(B), 256, 0, ctx->stream>>>(preds[k], (int32_t) B, pos[k].get(),
-                                                            lists[k]->get());
+            bl.out[k] = lists[k]->get();
         }
+        compact_lists_kernel<<<nblk(B), 256, 0, ctx->stream>>>(bl, (int32_t) B);
         st->target_boxes = shared_tb ? st->source_boxes.get() : st->target_boxes_buf.get();
     }
 
@@ -2035,13 +2115,6 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     return BT_OK;
 }
 
-int copy_i32(bt_context *ctx, int32_t *dst, const int32_t *src, int64_t n)
-{
-    // (dst == src: the list was built in the caller's block, nothing to move)
-    if (n > 0 && dst && dst != src)
-        BT_HIP_CHECK(hipMemcpyAsync(dst, src, (size_t) n * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    return BT_OK;
-}
 
 }  // namespace
 
@@ -2090,6 +2163,7 @@ static int trav_build_entry(bt_context *ctx, const bt_trav_params *p, bt_trav_si
     st->nlevels = p->nlevels;
     st->packed_alloc = alloc; st->packed_user = user; st->packed = packed;
     BT_CHECK(reset_status(ctx));
+    BT_CHECK(bt::zero_begin(ctx));
     int s = BT_ERR_INVALID;
     const bool f64 = p->coord_kind == BT_F64;
     switch (p->dims) {
@@ -2104,19 +2178,42 @@ static int trav_build_entry(bt_context *ctx, const bt_trav_params *p, bt_trav_si
 static int export_impl(bt_context *ctx, TravState *st, const bt_trav_arrays *o)
 {
     const int nl = st->nlevels;
-    BT_CHECK(copy_i32(ctx, o->source_boxes, st->source_boxes.get(), st->nsb));
+    // arrays that were made in scratch before the caller's block existed are moved by ONE
+    // kernel (a dozen runtime copies cost a pipeline bubble each)
+    SpanCopies sc{};
+    int64_t sc_max = 0;
+    auto flush = [&]() -> int {
+        if (sc.count > 0) {
+            const unsigned gx = (unsigned) std::max<int64_t>(
+                1, std::min<int64_t>(ctx->num_cus * 2, div_up(sc_max, 256 * 4)));
+            copy_spans_kernel<<<dim3(gx, (unsigned) sc.count), 256, 0, ctx->stream>>>(sc);
+            BT_HIP_CHECK(hipGetLastError());
+        }
+        sc.count = 0; sc_max = 0;
+        return BT_OK;
+    };
+    auto copy = [&](int32_t *dst, const int32_t *src, int64_t n) -> int {
+        // (dst == src: the list was built in the caller's block, nothing to move)
+        if (n <= 0 || !dst || dst == src) return BT_OK;
+        if (sc.count == SpanCopies::MAX) BT_CHECK(flush());
+        sc.src[sc.count] = src; sc.dst[sc.count] = dst; sc.n[sc.count] = n;
+        sc.count++;
+        sc_max = std::max(sc_max, n);
+        return BT_OK;
+    };
+    BT_CHECK(copy(o->source_boxes, st->source_boxes.get(), st->nsb));
     if (!st->p.sources_are_targets || st->p.target_boxes_mask)
-        BT_CHECK(copy_i32(ctx, o->target_boxes, st->target_boxes, st->ntb));
-    BT_CHECK(copy_i32(ctx, o->source_parent_boxes, st->source_parent_boxes.get(), st->nspb));
-    BT_CHECK(copy_i32(ctx, o->target_or_target_parent_boxes, st->ttp_boxes.get(), st->nttp));
-    BT_CHECK(copy_i32(ctx, o->level_start_source_box_nrs, st->lev_starts.get() + 0 * (nl + 1), nl + 1));
-    BT_CHECK(copy_i32(ctx, o->level_start_target_box_nrs, st->lev_starts.get() + 1 * (nl + 1), nl + 1));
-    BT_CHECK(copy_i32(ctx, o->level_start_source_parent_box_nrs, st->lev_starts.get() + 2 * (nl + 1), nl + 1));
-    BT_CHECK(copy_i32(ctx, o->level_start_target_or_target_parent_box_nrs,
-                      st->lev_starts.get() + 3 * (nl + 1), nl + 1));
+        BT_CHECK(copy(o->target_boxes, st->target_boxes, st->ntb));
+    BT_CHECK(copy(o->source_parent_boxes, st->source_parent_boxes.get(), st->nspb));
+    BT_CHECK(copy(o->target_or_target_parent_boxes, st->ttp_boxes.get(), st->nttp));
+    BT_CHECK(copy(o->level_start_source_box_nrs, st->lev_starts.get() + 0 * (nl + 1), nl + 1));
+    BT_CHECK(copy(o->level_start_target_box_nrs, st->lev_starts.get() + 1 * (nl + 1), nl + 1));
+    BT_CHECK(copy(o->level_start_source_parent_box_nrs, st->lev_starts.get() + 2 * (nl + 1), nl + 1));
+    BT_CHECK(copy(o->level_start_target_or_target_parent_box_nrs,
+                  st->lev_starts.get() + 3 * (nl + 1), nl + 1));
     auto put = [&](const CsrList &c, int32_t *starts, int32_t *lists) -> int {
-        BT_CHECK(copy_i32(ctx, starts, c.starts.get(), c.n + 1));
-        BT_CHECK(copy_i32(ctx, lists, c.lists.get(), c.total));
+        BT_CHECK(copy(starts, c.starts.get(), c.n + 1));
+        BT_CHECK(copy(lists, c.lists.get(), c.total));
         return BT_OK;
     };
     BT_CHECK(put(st->coll, o->same_level_non_well_sep_boxes_starts, o->same_level_non_well_sep_boxes_lists));
@@ -2124,7 +2221,7 @@ static int export_impl(bt_context *ctx, TravState *st, const bt_trav_arrays *o)
     if (st->l2_pending.empty()) {
         BT_CHECK(put(st->l2, o->from_sep_siblings_starts, o->from_sep_siblings_lists));
     } else {
-        BT_CHECK(copy_i32(ctx, o->from_sep_siblings_starts, st->l2.starts.get(), st->l2.n + 1));
+        BT_CHECK(copy(o->from_sep_siblings_starts, st->l2.starts.get(), st->l2.n + 1));
         for (const L2Pending &pend : st->l2_pending)
             compact_strided_rows_kernel<16><<<nblk((int64_t) pend.nb * 16), 256, 0, ctx->stream>>>(
                 pend.nb, pend.stride, pend.rows.get(), pend.rel.get(), (int32_t) pend.base,
@@ -2143,8 +2240,8 @@ static int export_impl(bt_context *ctx, TravState *st, const bt_trav_arrays *o)
             set_error("bt_traversal_export: NULL list-3 output for level %d", l);
             return BT_ERR_INVALID;
         }
-        BT_CHECK(copy_i32(ctx, o->from_sep_smaller_lists[l],
-                          st->l3_lists.get() + st->l3_level_base[l], st->l3_level_count[l]));
+        BT_CHECK(copy(o->from_sep_smaller_lists[l], st->l3_lists.get() + st->l3_level_base[l],
+                      st->l3_level_count[l]));
         ca.starts[l] = o->from_sep_smaller_starts[l];
         ca.nonempty[l] = o->from_sep_smaller_nonempty_indices[l];
         ca.cidx[l] = o->from_sep_smaller_compressed_indices[l];
@@ -2153,6 +2250,7 @@ static int export_impl(bt_context *ctx, TravState *st, const bt_trav_arrays *o)
         ca.cidx_base[l] = (int32_t) st->l3_cidx_base[l];
         ca.lev_count[l] = (int32_t) st->l3_level_count[l];
     }
+    BT_CHECK(flush());
     l3_compress_all_kernel<<<nblk((int64_t) nl * (ntb + 1)), 256, 0, ctx->stream>>>(
         (int32_t) ntb, nl, st->l3_starts.get(), st->l3_cidx.get(), st->target_boxes, ca);
     BT_HIP_CHECK(hipGetLastError());

@@ -1428,6 +1428,7 @@ struct BoxInfoArgs {
     const void *centers;           // [nboxes][D], T = float (csize 4) or double (8)
     void *o_centers;               // [D][aligned]
     int csize;
+    void *o_extents[4];            // [D][aligned] arrays whose padding columns are zeroed (or null)
     int32_t *o_level_starts;       // [n_level_starts] or null
     int n_level_starts;
     int32_t level_starts[BT_MAX_LEVELS + 1];
@@ -1451,6 +1452,12 @@ __global__ __launch_bounds__(256) void box_info_kernel(BoxInfoArgs a)
             for (int ax = 0; ax < a.D; ++ax) {
                 if (a.csize == 8) ((double *) a.o_centers)[(int64_t) ax * a.aligned + b] = 0.0;
                 else ((float *) a.o_centers)[(int64_t) ax * a.aligned + b] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (!a.o_extents[k]) continue;
+                    if (a.csize == 8) ((double *) a.o_extents[k])[(int64_t) ax * a.aligned + b] = 0.0;
+                    else ((float *) a.o_extents[k])[(int64_t) ax * a.aligned + b] = 0.f;
+                }
             }
         }
         return;
@@ -2205,8 +2212,15 @@ int fixup_launch(bt_context *ctx, TreeState *st)
     const bool can_be_huge = st->have_extent || p.refine_weights != nullptr
         || p.max_leaf_refine_weight > SEG_BLOCK_MAX || p.kind != BT_KIND_ADAPTIVE;
     BT_CHECK(st->fix_large_list.alloc(ctx->pool, N / 64 + 1));
-    BT_CHECK(st->fix_flags.alloc(ctx->pool, 1));
-    BT_HIP_CHECK(hipMemsetAsync(st->fix_flags.get(), 0, sizeof(SegSortFlags), ctx->stream));
+    // (when the host will not look at the flags they can live in the call's zeroed block;
+    // otherwise they must survive until the export's call)
+    SegSortFlags *zf = can_be_huge ? nullptr : (SegSortFlags *) bt::zero_alloc(ctx, sizeof(SegSortFlags));
+    if (zf) {
+        st->fix_flags.set_external(zf, 1);
+    } else {
+        BT_CHECK(st->fix_flags.alloc(ctx->pool, 1));
+        BT_HIP_CHECK(hipMemsetAsync(st->fix_flags.get(), 0, sizeof(SegSortFlags), ctx->stream));
+    }
     segment_sort_wave_kernel<<<(unsigned) div_up(st->nboxes * 32, 256), 256, 0, ctx->stream>>>(
         (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_haschild.get(),
         st->ids, st->fix_large_list.get(), st->fix_flags.get());
@@ -2885,6 +2899,11 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
         a.o_parent = o->box_parent_ids; a.o_child = o->box_child_ids;
         a.o_levels = o->box_levels; a.o_flags = o->box_flags;
         a.centers = st->centers.get(); a.o_centers = o->box_centers; a.csize = (int) sizeof(T);
+        // (box_extent_kernel writes every box of every level: only the padding needs zeros)
+        a.o_extents[0] = fused ? nullptr : o->box_source_bounding_box_min;
+        a.o_extents[1] = fused ? nullptr : o->box_source_bounding_box_max;
+        a.o_extents[2] = (fused || sat) ? nullptr : o->box_target_bounding_box_min;
+        a.o_extents[3] = (fused || sat) ? nullptr : o->box_target_bounding_box_max;
         a.o_level_starts = o->level_start_box_nrs;
         a.n_level_starts = (int) std::min<size_t>(st->level_start.size(), BT_MAX_LEVELS + 1);
         for (int i = 0; i < a.n_level_starts; ++i) a.level_starts[i] = st->level_start[(size_t) i];
@@ -2898,10 +2917,7 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
         if (round == 1 && sat) continue;
         T *bmin = (T *) (round == 0 ? o->box_source_bounding_box_min : o->box_target_bounding_box_min);
         T *bmax = (T *) (round == 0 ? o->box_source_bounding_box_max : o->box_target_bounding_box_max);
-        if (!fused) {
-            BT_HIP_CHECK(hipMemsetAsync(bmin, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
-            BT_HIP_CHECK(hipMemsetAsync(bmax, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
-        }
+
         // (with the leaves done the deepest level has nothing left)
         for (int lev = nlevels - 1 - (fused ? 1 : 0); lev >= 0; --lev) {
             ExtentArgs<T, D> a;
@@ -3069,6 +3085,7 @@ int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
     st->L = std::min(31, (63 - st->capbits) / st->D);
 
     BT_CHECK(reset_status(ctx));
+    BT_CHECK(bt::zero_begin(ctx));
     int s = st->f64 ? dispatch_dims_build<double>(ctx, st, out)
                     : dispatch_dims_build<float>(ctx, st, out);
     if (s != BT_OK) { (void) bt::sync_stream(ctx); bt_free_tree_state(ctx); }
@@ -3104,6 +3121,7 @@ int bt_tree_export(bt_context *ctx, const bt_tree_arrays *o)
             return BT_ERR_INVALID;
         }
     host_trace("export:enter");
+    BT_CHECK(bt::zero_begin(ctx));
     int s = st->f64 ? dispatch_dims_export<double>(ctx, st, o)
                     : dispatch_dims_export<float>(ctx, st, o);
     host_trace("export:leave");
