@@ -226,9 +226,10 @@ void *zero_alloc(bt_context *ctx, size_t bytes)
 
 int zero_begin(bt_context *ctx)
 {
-    if (ctx->zero_block && ctx->zero_used > 0)
-        BT_HIP_CHECK(hipMemsetAsync(ctx->zero_block, 0, ctx->zero_used, ctx->stream));
-    ctx->zero_used = 0;
+    // (from offset 0: the status word is reset with the rest)
+    if (ctx->zero_block)
+        BT_HIP_CHECK(hipMemsetAsync(ctx->zero_block, 0, std::max<size_t>(ctx->zero_used, 256), ctx->stream));
+    ctx->zero_used = 256;
     return BT_OK;
 }
 
@@ -289,13 +290,16 @@ int bt_create(int device, void *hip_stream, bt_context **out)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess)
         ctx->num_cus = prop.multiProcessorCount;
-    hipError_t e = hipMalloc((void **) &ctx->d_status, sizeof(bt::DeviceStatus));
-    if (e == hipSuccess)
-        e = hipHostMalloc((void **) &ctx->h_status, sizeof(bt::DeviceStatus), hipHostMallocDefault);
+    // the zeroed block of a call; its first 256 bytes are the status word, so that the
+    // memset at the entry of a build / traversal clears both
+    static_assert(sizeof(bt::DeviceStatus) <= 256, "status word must fit its slot");
+    ctx->zero_cap = 2 << 20;
+    hipError_t e = hipMalloc((void **) &ctx->zero_block, ctx->zero_cap);
+    if (e == hipSuccess) e = hipMemset(ctx->zero_block, 0, ctx->zero_cap);
     if (e == hipSuccess) {
-        ctx->zero_cap = 64 << 10;
-        e = hipMalloc((void **) &ctx->zero_block, ctx->zero_cap);
-        if (e == hipSuccess) e = hipMemset(ctx->zero_block, 0, ctx->zero_cap);
+        ctx->d_status = (bt::DeviceStatus *) ctx->zero_block;
+        ctx->zero_used = 256;
+        e = hipHostMalloc((void **) &ctx->h_status, sizeof(bt::DeviceStatus), hipHostMallocDefault);
     }
     if (e == hipSuccess) {
         ctx->h_ring_cap = 256 << 10;
@@ -331,8 +335,7 @@ void bt_destroy(bt_context *ctx)
     bt_free_aq_state(ctx);
     bt_free_mgpu_state(ctx);
     ctx->pool.release_all();
-    if (ctx->d_status) (void) hipFree(ctx->d_status);
-    if (ctx->zero_block) (void) hipFree(ctx->zero_block);
+    if (ctx->zero_block) (void) hipFree(ctx->zero_block);     // (holds the status word)
     for (void *&e : ctx->sort_ev)
         if (e) { (void) hipEventDestroy((hipEvent_t) e); e = nullptr; }
     if (ctx->scan_desc) (void) hipFree(ctx->scan_desc);

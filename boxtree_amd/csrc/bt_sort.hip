@@ -502,8 +502,7 @@ static int sort_api(bt_context *ctx, KeyT *keys_in, uint32_t *vals_in, KeyT *key
     }
     if (n == 0) return BT_OK;
     BT_HIP_CHECK(hipSetDevice(ctx->device));
-    BT_CHECK(bt::reset_status(ctx));
-    BT_CHECK(bt::zero_begin(ctx));
+    BT_CHECK(bt::zero_begin(ctx));          // (resets the status word too)
     bool in_b = false;
     BT_CHECK(bt::radix_sort_pairs<KeyT>(ctx, keys_in, vals_in, keys_out, vals_out, n,
                                         begin_bit, end_bit, false, &in_b));

@@ -2162,8 +2162,7 @@ static int trav_build_entry(bt_context *ctx, const bt_trav_params *p, bt_trav_si
     st->p = *p;
     st->nlevels = p->nlevels;
     st->packed_alloc = alloc; st->packed_user = user; st->packed = packed;
-    BT_CHECK(reset_status(ctx));
-    BT_CHECK(bt::zero_begin(ctx));
+    BT_CHECK(bt::zero_begin(ctx));          // (resets the status word too)
     int s = BT_ERR_INVALID;
     const bool f64 = p->coord_kind == BT_F64;
     switch (p->dims) {

@@ -42,9 +42,29 @@ template <> struct CoordTraits<double> { static constexpr double maxval = 1.7976
 
 constexpr int BBOX_THREADS = 256;
 
+template <class T> struct BboxAxes { const T *x[3]; };
+
+template <class T>
+__device__ __forceinline__ void bbox_block(const T *__restrict__ x, const T *__restrict__ radii,
+                                           int64_t n, T *partial /* [2*gridDim.x] */);
+
 template <class T>
 __global__ __launch_bounds__(BBOX_THREADS) void bbox_kernel(const T *__restrict__ x,
         const T *__restrict__ radii, int64_t n, T *partial /* [2*gridDim.x] */)
+{
+    bbox_block<T>(x, radii, n, partial);
+}
+
+// all axes in one launch: blockIdx.y = axis, partial[axis][2*gridDim.x]
+template <class T>
+__global__ __launch_bounds__(BBOX_THREADS) void bbox_axes_kernel(BboxAxes<T> ax, int64_t n, T *partial)
+{
+    bbox_block<T>(ax.x[blockIdx.y], (const T *) nullptr, n, partial + (int64_t) 2 * gridDim.x * blockIdx.y);
+}
+
+template <class T>
+__device__ __forceinline__ void bbox_block(const T *__restrict__ x, const T *__restrict__ radii,
+                                           int64_t n, T *partial /* [2*gridDim.x] */)
 {
     __shared__ T s_mn[BBOX_THREADS / 64], s_mx[BBOX_THREADS / 64];
     T mn = CoordTraits<T>::maxval, mx = -CoordTraits<T>::maxval;
@@ -2306,14 +2326,17 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         const int64_t bs = nblocks(ns), bt_ = nblocks(nt);
         Buf<T> partial;
         BT_CHECK(partial.alloc(ctx->pool, 2 * (bs + bt_) * D + 2));
-        for (int ax = 0; ax < D; ++ax) {
-            if (bs > 0)
-                bbox_kernel<T><<<(unsigned) bs, BBOX_THREADS, 0, ctx->stream>>>(
-                    (const T *) p.sources[ax], (const T *) nullptr, ns, partial.get() + 2 * bs * ax);
-            if (bt_ > 0)
-                bbox_kernel<T><<<(unsigned) bt_, BBOX_THREADS, 0, ctx->stream>>>(
-                    (const T *) p.targets[ax], (const T *) nullptr, nt,
-                    partial.get() + 2 * bs * D + 2 * bt_ * ax);
+        if (bs > 0) {
+            BboxAxes<T> axs{};
+            for (int ax = 0; ax < D; ++ax) axs.x[ax] = (const T *) p.sources[ax];
+            bbox_axes_kernel<T><<<dim3((unsigned) bs, D), BBOX_THREADS, 0, ctx->stream>>>(
+                axs, ns, partial.get());
+        }
+        if (bt_ > 0) {
+            BboxAxes<T> axs{};
+            for (int ax = 0; ax < D; ++ax) axs.x[ax] = (const T *) p.targets[ax];
+            bbox_axes_kernel<T><<<dim3((unsigned) bt_, D), BBOX_THREADS, 0, ctx->stream>>>(
+                axs, nt, partial.get() + 2 * bs * D);
         }
         BT_CHECK(st->rootbox.alloc(ctx->pool, 8 * sizeof(T)));
         root_box_kernel<T, D><<<1, 256, 0, ctx->stream>>>(
@@ -2510,8 +2533,12 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     auto ensure_desc = [&]() -> int {
         const int64_t need = st->cap / (256 / C * SL_SUB) + 2;
         if (sl_desc.size() < need) {
-            BT_CHECK(sl_desc.alloc(ctx->pool, need));
-            BT_HIP_CHECK(hipMemsetAsync(sl_desc.get(), 0, (size_t) need * 8, ctx->stream));
+            if (uint64_t *z = (uint64_t *) bt::zero_alloc(ctx, (size_t) need * 8)) {
+                sl_desc.set_external(z, need);
+            } else {
+                BT_CHECK(sl_desc.alloc(ctx->pool, need));
+                BT_HIP_CHECK(hipMemsetAsync(sl_desc.get(), 0, (size_t) need * 8, ctx->stream));
+            }
         }
         return BT_OK;
     };
@@ -3084,8 +3111,7 @@ int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
     // levels addressable by the 64-bit key (per-axis value must fit 31 bits)
     st->L = std::min(31, (63 - st->capbits) / st->D);
 
-    BT_CHECK(reset_status(ctx));
-    BT_CHECK(bt::zero_begin(ctx));
+    BT_CHECK(bt::zero_begin(ctx));          // (resets the status word too)
     int s = st->f64 ? dispatch_dims_build<double>(ctx, st, out)
                     : dispatch_dims_build<float>(ctx, st, out);
     if (s != BT_OK) { (void) bt::sync_stream(ctx); bt_free_tree_state(ctx); }
@@ -3121,7 +3147,8 @@ int bt_tree_export(bt_context *ctx, const bt_tree_arrays *o)
             return BT_ERR_INVALID;
         }
     host_trace("export:enter");
-    BT_CHECK(bt::zero_begin(ctx));
+    // (the export goes on taking from the zeroed block the build started: no clearing here,
+    // and the status word keeps what the build's last kernels may have reported)
     int s = st->f64 ? dispatch_dims_export<double>(ctx, st, o)
                     : dispatch_dims_export<float>(ctx, st, o);
     host_trace("export:leave");
