@@ -17,7 +17,7 @@ print("$WL", "%.4g"%d["value"], "%.3f ms"%d["ms_per_step"], "roofline %.3f"%d["r
 PY
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/fr_$WL -o p -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 6 --warmup 2 --cpu-sample 0 > /tmp/fr_$WL.log 2>&1)
   DB=$(find /tmp/fr_$WL -name '*.db' | head -1)
-  if [ -n "$DB" ]; then python tools/rocpd_stats.py $DB $OUT/${WL}_kernel_stats.csv; python tools/timeline_gaps.py $DB bbox_kernel 4 --kernels > $OUT/${WL}_timeline.txt 2>&1; fi
+  if [ -n "$DB" ]; then python tools/rocpd_stats.py $DB $OUT/${WL}_kernel_stats.csv; python tools/timeline_gaps.py $DB bbox_ 4 --kernels > $OUT/${WL}_timeline.txt 2>&1; fi
   CSV=$(find /tmp/fr_$WL -name '*kernel_stats.csv' | head -1)
   if [ -n "$CSV" ]; then cp $CSV $OUT/${WL}_kernel_stats.csv; fi
   head -2 $OUT/${WL}_timeline.txt

@@ -11,7 +11,7 @@ import sqlite3
 import sys
 
 
-def main(path, first="bbox_kernel", min_gap_us="4"):
+def main(path, first="bbox_", min_gap_us="4"):
     min_gap = float(min_gap_us) * 1e3
     db = sqlite3.connect(path)
     rows = db.execute("select name, start, end from kernels order by start").fetchall()
