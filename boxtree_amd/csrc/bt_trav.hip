@@ -568,13 +568,15 @@ struct NonEmptyPred {
 };
 
 // values at the level boundaries of two flat [nlevels*ntb + 1] arrays -> small arrays
+// (rows exist for the levels lev0 .. nlevels-1; the levels above them are empty)
 __global__ void l3_level_marks_kernel(int nlevels, int64_t ntb, const int32_t *starts,
-                                      const int32_t *scan, int32_t *out /* [2][nlevels+1] */)
+                                      const int32_t *scan, int32_t *out /* [2][nlevels+1] */, int lev0)
 {
     const int l = threadIdx.x;
     if (l > nlevels) return;
-    out[l] = starts[(int64_t) l * ntb];
-    out[nlevels + 1 + l] = scan[(int64_t) l * ntb];
+    const int r = l > lev0 ? l - lev0 : 0;
+    out[l] = starts[(int64_t) r * ntb];
+    out[nlevels + 1 + l] = scan[(int64_t) r * ntb];
 }
 
 __global__ __launch_bounds__(256) void l3_compress_kernel(int32_t ntb, const int32_t *lev_starts,
@@ -602,6 +604,7 @@ struct L3CompressAll {
     int32_t *starts[BT_MAX_LEVELS], *nonempty[BT_MAX_LEVELS], *cidx[BT_MAX_LEVELS],
             *tboxes[BT_MAX_LEVELS];
     int32_t lev_base[BT_MAX_LEVELS], cidx_base[BT_MAX_LEVELS], lev_count[BT_MAX_LEVELS];
+    int lev0;                      // TravState::l3_lo
 };
 
 __global__ __launch_bounds__(256) void l3_compress_all_kernel(int32_t ntb, int nlevels,
@@ -612,8 +615,14 @@ __global__ __launch_bounds__(256) void l3_compress_all_kernel(int32_t ntb, int n
     const int l = (int) (gid / (ntb + 1));
     const int32_t i = (int32_t) (gid % (ntb + 1));
     if (l >= nlevels) return;
-    const int32_t *lev_starts = l3_starts + (int64_t) l * ntb;
-    const int32_t *cidx = l3_cidx + (int64_t) l * ntb;
+    if (l < o.lev0) {
+        // a source level without rows: nothing there
+        if (o.cidx[l]) o.cidx[l][i] = 0;
+        if (i == ntb) o.starts[l][0] = 0;
+        return;
+    }
+    const int32_t *lev_starts = l3_starts + (int64_t) (l - o.lev0) * ntb;
+    const int32_t *cidx = l3_cidx + (int64_t) (l - o.lev0) * ntb;
     if (o.cidx[l]) o.cidx[l][i] = cidx[i] - o.cidx_base[l];
     if (i == ntb) {
         o.starts[l][cidx[ntb] - o.cidx_base[l]] = o.lev_count[l];
@@ -722,7 +731,8 @@ struct TravState {
     Buf<int32_t> d_level_start_box_nrs;
     CsrList coll, l1, l2, l4, close_smaller, close_bigger;
     // list 3: flat level-major
-    Buf<int32_t> l3_starts;            // [nlevels*ntb + 1]
+    int l3_lo = 0;                     // first source level with a row in the two arrays below
+    Buf<int32_t> l3_starts;            // [(nlevels - l3_lo)*ntb + 1]
     Buf<int32_t> l3_lists;
     Buf<int32_t> l3_cidx;              // flat scan [nlevels*ntb + 1]
     std::vector<int64_t> l3_level_base, l3_level_count, l3_nonempty, l3_cidx_base;
@@ -856,7 +866,7 @@ int l3_postprocess(bt_context *ctx, TravState *st)
     Buf<int32_t> marks;
     BT_CHECK(marks.alloc(ctx->pool, 2 * (nlevels + 1)));
     l3_level_marks_kernel<<<1, 128, 0, ctx->stream>>>(nlevels, ntb, st->l3_starts.get(),
-                                                     st->l3_cidx.get(), marks.get());
+                                                     st->l3_cidx.get(), marks.get(), st->l3_lo);
     std::vector<int32_t> h((size_t) 2 * (nlevels + 1));
     BT_CHECK(bt::d2h(ctx, h.data(), marks.get(), h.size() * 4));
     BT_CHECK(bt::sync_stream(ctx));
@@ -1621,19 +1631,31 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     if (st->with_extent)
         BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{close_cnt.get()}, items_cap,
                                                           close_item.get(), totals.get() + T_CLOSE, true)));
-    // list 3 per (level, target box): starts, and the compressed (non-empty) numbering
-    const int64_t nflat_box = (int64_t) nlevels * ntb;
+    // list 3 per (level, target box): starts, and the compressed (non-empty) numbering.
+    // A source level can only have entries if some target box sits on a coarser level (the
+    // entries themselves may be boxes of any level: a box stands for the sources below it):
+    // the levels up to the first one with target boxes get no rows (at 10^8 sphere points
+    // leaves start at level 6: 5 of 12 levels have rows, and these per-(level, box) arrays
+    // are what the bookkeeping scans run over).
+    {
+        const int32_t *tls = st->h_lev_starts.data() + (nlevels + 1);    // target boxes per level
+        int first_tgt = 0;
+        while (first_tgt < nlevels && tls[first_tgt + 1] == tls[first_tgt]) ++first_tgt;
+        st->l3_lo = std::max(0, std::min(nlevels - 1, first_tgt + 1));
+        if (p.target_boxes_mask) st->l3_lo = 0;
+    }
+    const int64_t nflat_box = (int64_t) (nlevels - st->l3_lo) * ntb;
     BT_CHECK(st->l3_starts.alloc(ctx->pool, nflat_box + 1));
     l3_box_starts_v2_kernel<<<nblk(nflat_box + 1), 256, 0, ctx->stream>>>(
         nflat_box, (int32_t) ntb, lay, nlevels, first_item.get(), l3_item.get(),
-        st->l3_starts.get());
+        st->l3_starts.get(), st->l3_lo);
     BT_CHECK(st->l3_cidx.alloc(ctx->pool, nflat_box + 1));
     BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, NonEmptyPred{st->l3_starts.get()}, nflat_box,
                                                       st->l3_cidx.get(), (int32_t *) nullptr, true)));
     Buf<int32_t> marks;
     BT_CHECK(marks.alloc(ctx->pool, 2 * (nlevels + 1)));
     l3_level_marks_kernel<<<1, 128, 0, ctx->stream>>>(nlevels, ntb, st->l3_starts.get(),
-                                                     st->l3_cidx.get(), marks.get());
+                                                     st->l3_cidx.get(), marks.get(), st->l3_lo);
     // list 4 (+ close): counts now, lists after the totals are known
     CsrList &c4 = st->l4;
     c4.n = st->nttp;
@@ -2250,6 +2272,7 @@ static int export_impl(bt_context *ctx, TravState *st, const bt_trav_arrays *o)
         ca.lev_count[l] = (int32_t) st->l3_level_count[l];
     }
     BT_CHECK(flush());
+    ca.lev0 = st->l3_lo;
     l3_compress_all_kernel<<<nblk((int64_t) nl * (ntb + 1)), 256, 0, ctx->stream>>>(
         (int32_t) ntb, nl, st->l3_starts.get(), st->l3_cidx.get(), st->target_boxes, ca);
     BT_HIP_CHECK(hipGetLastError());

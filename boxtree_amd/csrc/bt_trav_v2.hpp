@@ -822,12 +822,12 @@ __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nit
 // the level ends
 __global__ __launch_bounds__(256) void l3_box_starts_v2_kernel(int64_t nflat_box, int32_t ntb,
         L3Layout lay, int nlevels, const int32_t *first_item, const int32_t *item_starts,
-        int32_t *box_starts)
+        int32_t *box_starts, int lev0 /* the first level with a row */)
 {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (i > nflat_box) return;
     if (i == nflat_box) { box_starts[i] = item_starts[lay.base[nlevels]]; return; }
-    const int lev = (int) (i / ntb);
+    const int lev = lev0 + (int) (i / ntb);
     const int32_t tbn = (int32_t) (i % ntb);
     const int32_t item = first_item[tbn];
     const int32_t col = item < lay.ecap[lev] ? item : lay.ecap[lev];
