@@ -525,6 +525,8 @@ struct BuildArgs {
     const int32_t *parent_list; // level restriction: force-split these boxes (any level)
     int top_level;              // sharded builds: levels above it use global counts
     const int64_t *top_prefix;  // [C^top_level + 1] or null
+    int top_local;              // top_prefix holds THIS key array's cell starts (cell_starts_kernel):
+                                // child ranges down to top_level are looked up, not searched
     int loff;                   // the key addresses levels loff+1 .. loff+L (continuation keys)
     int can_continue;           // a continuation key exists below level loff+L
     const uint8_t *cand;        // continuation: which boxes of level loff were re-keyed
@@ -804,6 +806,11 @@ __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState
                             } else {
                                 lo = hi = s;
                             }
+                        } else if (!EXT && a.top_local && a.loff == 0 && level <= a.top_level) {
+                            // the child's first particle = the first particle of its first
+                            // level-top_level cell
+                            const int sh = D * (a.top_level - level);
+                            lo = hi = (int) a.top_prefix[((prefix << D) | (uint64_t) m) << sh];
                         } else {
                             const uint64_t ck = ((prefix << D) | (uint64_t) m) << cshift;
                             if (ck == 0) { lo = hi = s; }
@@ -978,6 +985,24 @@ __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState
             }
         }
     }
+}
+
+// first particle of every level-k Morton cell in the sorted keys (lower bounds; out[ncells]
+// = n): the child ranges of the top k levels are read from here instead of being found by a
+// binary search over all n keys per child -- 20 to 27 dependent loads each, which is what
+// the launches of the small top levels spend their time on
+__global__ __launch_bounds__(256) void cell_starts_kernel(const uint64_t *keys, int64_t n, int shift,
+        int64_t ncells, int64_t *out)
+{
+    const int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (c > ncells) return;
+    if (c == ncells) { out[c] = n; return; }
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = lo + ((hi - lo) >> 1);
+        if ((int64_t) (keys[mid] >> shift) < c) lo = mid + 1; else hi = mid;
+    }
+    out[c] = lo;
 }
 
 template <class T, int D>
@@ -2478,6 +2503,24 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         const int64_t guess = (int64_t) std::min(2.0 * C * per_leaf + 4096.0, 2.0e9);
         BT_CHECK(ensure_box_capacity(ctx, st, std::max<int64_t>(guess, 1024), sizeof(T)));
     }
+    // ---- cell starts of the top levels (point particles, unit weights, a self-contained
+    // build): see cell_starts_kernel ---------------------------------------------------------
+    Buf<int64_t> local_cells;
+    int local_top_level = 0;
+    {
+        static const bool off = [] { const char *e = getenv("BT_NO_CELL_STARTS"); return e && atoi(e); }();
+        int k = D == 3 ? 5 : D == 2 ? 7 : 15;
+        k = std::min(k, st->L);
+        if (!off && !EXT && !p.refine_weights && !p.top_cell_prefix && N >= 4096 && k >= 2
+                && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED) {
+            const int64_t ncells = (int64_t) 1 << (D * k);
+            BT_CHECK(local_cells.alloc(ctx->pool, ncells + 1));
+            cell_starts_kernel<<<(unsigned) div_up(ncells + 1, 256), 256, 0, ctx->stream>>>(
+                keys, N, D * (st->L - k), ncells, local_cells.get());
+            BT_HIP_CHECK(hipGetLastError());
+            local_top_level = k;
+        }
+    }
     Buf<LoopState> d_ls;
     Buf<uint32_t> tickets;
     BT_CHECK(d_ls.alloc(ctx->pool, 1));
@@ -2498,6 +2541,12 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         a.adaptive = p.kind != BT_KIND_NON_ADAPTIVE;
         a.top_level = p.top_level;
         a.top_prefix = p.top_cell_prefix;
+        a.top_local = 0;
+        if (local_cells.get()) {
+            a.top_level = local_top_level;
+            a.top_prefix = local_cells.get();
+            a.top_local = 1;
+        }
         a.keep_empty = p.skip_prune ? 1 : 0;
     };
     {
