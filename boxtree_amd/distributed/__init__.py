@@ -259,14 +259,18 @@ A2A_MESSAGE_LIMIT_BYTES = 512 << 20
 
 
 def all_to_all_chunked(dist, recv, send, r_split, s_split, limit_bytes=None,
-                       biggest_bytes=None):
+                       biggest_bytes=None, self_in_place=False):
     """``dist.all_to_all_single(recv, send, r_split, s_split)`` in as many rounds as
     it takes to keep every peer-to-peer message below *limit_bytes*.  Round k moves
     the k-th slice of every peer's segment; sender and receiver cut a segment of
     length c at ``floor(k*c/R)``, so both sides agree without communicating.  A
     rank's segment for itself never enters the collective: it is one device copy.
     *biggest_bytes*: the largest peer-to-peer message of ANY rank, if the caller
-    already knows it (saves the MAX all-reduce that agrees on the round count)."""
+    already knows it (saves the MAX all-reduce that agrees on the round count).
+    *self_in_place*: the caller has already written this rank's own segment into *recv*
+    (and need not have filled it in *send*).  On CUDA tensors with a backend that has the
+    list form of the collective (RCCL), every round exchanges VIEWS of the two buffers --
+    no staging copies of the payload on either side."""
     import torch
     if limit_bytes is None:
         limit_bytes = A2A_MESSAGE_LIMIT_BYTES
@@ -291,13 +295,24 @@ def all_to_all_chunked(dist, recv, send, r_split, s_split, limit_bytes=None,
     # The self segment is always a device copy and every decision below uses the
     # globally agreed `biggest` only: a choice that depended on a rank's own segment
     # sizes could send some ranks into a collective the others skip.
-    if s_split[me]:
+    if s_split[me] and not self_in_place:
         recv[r_off[me]:r_off[me + 1]].copy_(send[s_off[me]:s_off[me + 1]])
     if biggest == 0:
         return 1
 
     def cut(c, k):
         return (k * int(c)) // rounds
+
+    if send.is_cuda and hasattr(dist, "all_to_all") and getattr(dist, "get_backend", None) \
+            and dist.get_backend() == "nccl":
+        # grouped point-to-point transfers between views: nothing is staged
+        for k in range(rounds):
+            ins = [send[s_off[p] + cut(s_peer[p], k):s_off[p] + cut(s_peer[p], k + 1)]
+                   for p in range(len(s_peer))]
+            outs = [recv[r_off[p] + cut(r_peer[p], k):r_off[p] + cut(r_peer[p], k + 1)]
+                    for p in range(len(r_peer))]
+            dist.all_to_all(outs, ins)
+        return rounds
 
     for k in range(rounds):
         s_sub = [cut(c, k + 1) - cut(c, k) for c in s_peer]
@@ -432,16 +447,16 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
             ct.c_void_p(order.data_ptr()), len(a), ct.c_void_p(out.data_ptr())))
         return out
 
-    def timed_a2a(recv, send, r_split, s_split):
+    def timed_a2a(recv, send, r_split, s_split, self_in_place=False):
         # device time of the payload collectives, for the per-link rate bench.py
         # reports (events on the stream the collective is enqueued on; resolved by
         # the caller after its own synchronisation)
         if dev.type != "cuda":
-            all_to_all_chunked(dist, recv, send, r_split, s_split)
+            all_to_all_chunked(dist, recv, send, r_split, s_split, self_in_place=self_in_place)
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        all_to_all_chunked(dist, recv, send, r_split, s_split)
+        all_to_all_chunked(dist, recv, send, r_split, s_split, self_in_place=self_in_place)
         e1.record()
         stats.setdefault("a2a_events", []).append((e0, e1))
 
@@ -464,15 +479,25 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
             d = len(arrs)
             n = len(arrs[0])
             es = arrs[0].element_size()
+            # the segment a rank keeps is packed straight into the receive buffer; what
+            # goes to the peers into the send buffer, at the offsets of the full layout
             send = torch.empty(n * d, dtype=arrs[0].dtype, device=dev)
-            ptrs = (ct.c_void_p * d)(*[a.contiguous().data_ptr() for a in arrs])
-            actx.sync_in()
-            _lib.check(actx.lib.bt_gather_pack(
-                actx.handle, d, es, ptrs, ct.c_void_p(order.data_ptr()), n,
-                ct.c_void_p(send.data_ptr())))
-            tick("pack")
             recv = torch.empty(nrecv * d, dtype=arrs[0].dtype, device=dev)
-            timed_a2a(recv, send, [r * d for r in r_split], [c * d for c in s_split])
+            ptrs = (ct.c_void_p * d)(*[a.contiguous().data_ptr() for a in arrs])
+            s_off = np.concatenate([[0], np.cumsum(s_split)]).astype(np.int64)
+            r_off = np.concatenate([[0], np.cumsum(r_split)]).astype(np.int64)
+            actx.sync_in()
+            pieces = [(0, int(s_off[rank]), send, 0),
+                      (int(s_off[rank]), int(s_off[rank + 1]), recv, int(r_off[rank])),
+                      (int(s_off[rank + 1]), n, send, int(s_off[rank + 1]))]
+            for lo, hi, dst, dst_at in pieces:
+                if hi > lo:
+                    _lib.check(actx.lib.bt_gather_pack(
+                        actx.handle, d, es, ptrs, ct.c_void_p(order.data_ptr() + 4 * lo), hi - lo,
+                        ct.c_void_p(dst.data_ptr() + dst_at * d * es)))
+            tick("pack")
+            timed_a2a(recv, send, [r * d for r in r_split], [c * d for c in s_split],
+                      self_in_place=True)
             tick("payload a2a")
             if keep_interleaved:
                 # the tree build reads the receive buffer in place
