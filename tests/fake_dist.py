@@ -11,10 +11,13 @@ class _ReduceOp:
 
 
 class FakeWorld:
-    def __init__(self, world):
+    def __init__(self, world, backend=None):
         self.world = world
         self.barrier = threading.Barrier(world)
         self.slots = [None] * world
+        # "nccl": the stand-in also offers the list form of all_to_all and names that
+        # backend, so that all_to_all_chunked takes the path it takes on RCCL
+        self.backend = backend
 
     def rank_view(self, rank):
         return FakeDist(self, rank)
@@ -29,6 +32,24 @@ class FakeDist:
 
     def get_world_size(self):
         return self._w.world
+
+    def get_backend(self):
+        return self._w.backend
+
+    def __getattr__(self, name):
+        # the list form exists only on worlds that play RCCL
+        if name == "all_to_all" and self._w.backend == "nccl":
+            return self._all_to_all
+        raise AttributeError(name)
+
+    def _all_to_all(self, outs, ins):
+        self._w.slots[self._rank] = list(ins)
+        self._sync()
+        for src in range(self._w.world):
+            piece = self._w.slots[src][self._rank]
+            assert outs[src].shape == piece.shape and outs[src].is_contiguous()
+            outs[src].copy_(piece)
+        self._sync()
 
     def get_rank(self):
         return self._rank

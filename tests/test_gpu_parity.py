@@ -882,6 +882,62 @@ def test_cuda_array_interface_inputs(actx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_all_to_all_chunked_on_views(world):
+    """The RCCL path of all_to_all_chunked -- views of the send and receive buffers handed
+    to the list form of the collective, a rank's own segment already in place -- against
+    the plain single-buffer exchange, with several rounds (ranks as threads on one GPU;
+    tests/fake_dist.py plays the backend)."""
+    import threading
+
+    import torch
+    from boxtree_amd.distributed import all_to_all_chunked
+    from fake_dist import FakeWorld
+    rng = np.random.default_rng(world)
+    splits = rng.integers(1500, 3000, size=(world, world))
+    splits[0, world - 1] = 0                            # an empty message
+    sends = [torch.from_numpy(rng.random(int(splits[r].sum()))).cuda() for r in range(world)]
+    results = {}
+
+    def run(backend, self_in_place):
+        fw = FakeWorld(world, backend=backend)
+        out = [None] * world
+        errs = []
+
+        def worker(rank):
+            try:
+                d = fw.rank_view(rank)
+                s_split = [int(c) for c in splits[rank]]
+                r_split = [int(splits[src][rank]) for src in range(world)]
+                recv = torch.full((sum(r_split),), -1.0, dtype=torch.float64, device="cuda")
+                if self_in_place:
+                    s0 = sum(s_split[:rank])
+                    r0 = sum(r_split[:rank])
+                    recv[r0:r0 + r_split[rank]] = sends[rank][s0:s0 + s_split[rank]]
+                rounds = all_to_all_chunked(d, recv, sends[rank], r_split, s_split,
+                                            limit_bytes=8 * 700, self_in_place=self_in_place)
+                out[rank] = (rounds, recv.cpu())
+            except Exception as exc:          # noqa: BLE001
+                errs.append(exc)
+                fw.barrier.abort()
+        threads = [threading.Thread(target=worker, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errs, errs
+        return out
+
+    plain = run(None, False)
+    views = run("nccl", True)
+    assert max(v[0] for v in views) > 1           # several rounds were needed
+    for rank in range(world):
+        assert views[rank][0] == plain[rank][0]
+        assert torch.equal(views[rank][1], plain[rank][1])
+        assert not bool((views[rank][1] < 0).any())
+
+
+@pytest.mark.gpu
 def test_exchange_large_messages_nccl_single_rank():
     """Regression: a 1.44 GB all_to_all_single message (6*10^7 packed 3D points, one
     rank sending to itself over RCCL) arrived with its second half corrupted; the
@@ -908,6 +964,13 @@ def test_exchange_large_messages_nccl_single_rank():
         assert kw.get("_point_stride") == 3
         for a, b in zip(pts, p2):
             assert bool(torch.equal(a, b))          # one rank: nothing moves
+        # the list form of the collective as all_to_all_chunked calls it, on the real backend
+        src = torch.arange(1000, dtype=torch.float64, device="cuda")
+        dst = torch.zeros(1000, dtype=torch.float64, device="cuda")
+        dist.all_to_all([dst[100:600]], [src[200:700]])
+        dist.all_to_all([dst[:0]], [src[:0]])        # an empty segment
+        torch.cuda.synchronize()
+        assert bool(torch.equal(dst[100:600], src[200:700])) and float(dst[:100].sum()) == 0.0
     finally:
         dist.destroy_process_group()
 
