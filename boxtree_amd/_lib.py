@@ -221,7 +221,8 @@ EXPORTED_SYMBOLS = [
     "bt_dfs_order", "bt_partition_work", "bt_ancestor_mask", "bt_mark_list_boxes",
     "bt_local_particles", "bt_modify_target_flags", "bt_box_to_user_ranks",
     "bt_boxes_used_by_ranks",
-    "bt_morton_cells", "bt_bucket_permutation", "bt_gather", "bt_gather_pack", "bt_unpack",
+    "bt_morton_cells", "bt_bucket_permutation", "bt_partition_pack", "bt_gather", "bt_gather_pack",
+    "bt_unpack",
 ]
 
 _lib = None
@@ -319,6 +320,8 @@ def load():
     lib.bt_bucket_permutation.argtypes = [vp, vp, ct.c_int64, vp, ct.c_int, vp]
     lib.bt_gather.argtypes = [vp, ct.c_int, vp, vp, ct.c_int64, vp]
     lib.bt_gather_pack.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), vp, ct.c_int64, vp]
+    lib.bt_partition_pack.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp), vp, ct.c_int64, vp,
+                                      ct.c_int, ct.c_int, ct.c_int64, ct.c_int64, vp, vp]
     lib.bt_unpack.argtypes = [vp, ct.c_int, ct.c_int, vp, ct.c_int64, ct.POINTER(vp)]
     if lib.bt_abi_version() != ABI_VERSION:
         raise RuntimeError("libboxtree_hip.so ABI version mismatch")

@@ -163,6 +163,131 @@ int cells_impl(bt_context *ctx, const void *const *coords, int64_t n, const doub
     return BT_OK;
 }
 
+// ---- stable partition of the particles by owner rank, payload carried along -------------
+//
+// The send buffer of the exchange, made in one sweep over the coordinates: a wave owns 1024
+// consecutive particles, counts them per owner (pp_count_kernel), a scan over (owner, wave)
+// turns the counts into record offsets, and pp_scatter_kernel writes every particle's
+// coordinates, interleaved, at its place -- the segment a rank keeps straight into the
+// receive buffer.  Reads are sequential, writes go to `nranks` advancing runs.  (A
+// permutation by owner followed by a gather reads the coordinate arrays in `nranks`
+// interleaved strided passes: with 8 ranks every 64-byte line is fetched 8 times.)
+constexpr int PP_MAX_RANKS = 256;
+constexpr int PP_ITEMS = 16;                    // particles per lane
+constexpr int PP_WAVE_ITEMS = 64 * PP_ITEMS;
+
+// lanes of the wave whose value equals this lane's (match-any by ballots over `bits` bits)
+__device__ __forceinline__ uint64_t pp_match(uint32_t d, int bits)
+{
+    uint64_t mask = ~0ull;
+    for (int b = 0; b < bits; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t bal = __ballot(bit);
+        mask &= bit ? bal : ~bal;
+    }
+    return mask;
+}
+
+// counts[owner * nwaves + wave]
+__global__ __launch_bounds__(256) void pp_count_kernel(const uint32_t *cells, int64_t n,
+        const int32_t *owner_of_cell, int nranks, int bits, int64_t nwaves, int32_t *counts)
+{
+    __shared__ int32_t s_cnt[4][PP_MAX_RANKS];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t) blockIdx.x * 4 + w;
+    for (int r = lane; r < nranks; r += 64) s_cnt[w][r] = 0;
+    __builtin_amdgcn_wave_barrier();
+    if (wave >= nwaves) return;
+    const int64_t base = wave * PP_WAVE_ITEMS + lane;
+    for (int j = 0; j < PP_ITEMS; ++j) {
+        const int64_t i = base + (int64_t) j * 64;
+        const bool in = i < n;
+        // (lanes past the end form a group of their own)
+        const uint32_t d = in ? (uint32_t) owner_of_cell[cells[i]] : (uint32_t) nranks;
+        const uint64_t mask = pp_match(d, bits + 1);
+        const bool leader = (mask & ((1ull << lane) - 1ull)) == 0ull;
+        if (in && leader) s_cnt[w][d] += (int32_t) __popcll(mask);
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int r = lane; r < nranks; r += 64) counts[(int64_t) r * nwaves + wave] = s_cnt[w][r];
+}
+
+struct PpScan {
+    const int32_t *c;
+    __device__ int64_t operator()(int64_t i) const { return (int64_t) c[i]; }
+};
+
+template <class U, int D>
+struct PpArgs {
+    const U *in[D];
+    const uint32_t *cells;
+    const int32_t *owner_of_cell;
+    const int32_t *offsets;         // [nranks * nwaves] exclusive scan of the counts
+    int64_t n, nwaves;
+    int nranks, bits, self_rank;
+    int64_t self_delta;             // receive offset of the own segment minus its send offset
+    U *send, *recv;
+};
+
+template <class U, int D>
+__global__ __launch_bounds__(256) void pp_scatter_kernel(PpArgs<U, D> a)
+{
+    __shared__ int32_t s_run[4][PP_MAX_RANKS];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t) blockIdx.x * 4 + w;
+    if (wave >= a.nwaves) return;
+    for (int r = lane; r < a.nranks; r += 64) s_run[w][r] = a.offsets[(int64_t) r * a.nwaves + wave];
+    __builtin_amdgcn_wave_barrier();
+    const int64_t base = wave * PP_WAVE_ITEMS + lane;
+    for (int j = 0; j < PP_ITEMS; ++j) {
+        const int64_t i = base + (int64_t) j * 64;
+        const bool in = i < a.n;
+        const uint32_t d = in ? (uint32_t) a.owner_of_cell[a.cells[i]] : (uint32_t) a.nranks;
+        U v[D];
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) v[ax] = in ? a.in[ax][i] : (U) 0;
+        const uint64_t mask = pp_match(d, a.bits + 1);
+        const uint64_t below = mask & ((1ull << lane) - 1ull);
+        int32_t old = 0;
+        if (in) old = s_run[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (in && below == 0ull) s_run[w][d] = old + (int32_t) __popcll(mask);
+        __builtin_amdgcn_wave_barrier();
+        if (in) {
+            const int64_t pos = (int64_t) old + __popcll(below);      // record index, owner-major
+            U *dst = ((int) d == a.self_rank) ? a.recv + (pos + a.self_delta) * D : a.send + pos * D;
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) dst[ax] = v[ax];
+        }
+    }
+}
+
+template <class U, int D>
+int partition_pack_impl(bt_context *ctx, const void *const *in, const uint32_t *cells, int64_t n,
+                        const int32_t *owner_of_cell, int nranks, int self_rank,
+                        int64_t self_send_offset, int64_t self_recv_offset, void *send, void *recv)
+{
+    const int64_t nwaves = div_up(n, PP_WAVE_ITEMS);
+    int bits = 0;
+    while ((1 << bits) < nranks) ++bits;
+    Buf<int32_t> counts, offsets;
+    BT_CHECK(counts.alloc(ctx->pool, (int64_t) nranks * nwaves));
+    BT_CHECK(offsets.alloc(ctx->pool, (int64_t) nranks * nwaves + 1));
+    pp_count_kernel<<<(unsigned) div_up(nwaves, 4), 256, 0, ctx->stream>>>(
+        cells, n, owner_of_cell, nranks, bits, nwaves, counts.get());
+    BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, PpScan{counts.get()}, (int64_t) nranks * nwaves,
+                                                      offsets.get(), (int64_t *) nullptr, true)));
+    PpArgs<U, D> a{};
+    for (int ax = 0; ax < D; ++ax) a.in[ax] = (const U *) in[ax];
+    a.cells = cells; a.owner_of_cell = owner_of_cell; a.offsets = offsets.get();
+    a.n = n; a.nwaves = nwaves; a.nranks = nranks; a.bits = bits; a.self_rank = self_rank;
+    a.self_delta = self_recv_offset - self_send_offset;
+    a.send = (U *) send; a.recv = (U *) recv;
+    pp_scatter_kernel<U, D><<<(unsigned) div_up(nwaves, 4), 256, 0, ctx->stream>>>(a);
+    BT_HIP_CHECK(hipGetLastError());
+    return bt::finish_call(ctx);
+}
+
 }  // namespace
 
 extern "C" {
@@ -213,6 +338,31 @@ int bt_bucket_permutation(bt_context *ctx, const uint32_t *cells, int64_t n,
         BT_HIP_CHECK(hipMemcpyAsync(perm_out, vb.get(), (size_t) n * 4, hipMemcpyDeviceToDevice,
                                     ctx->stream));
     return check_status(ctx);
+}
+
+int bt_partition_pack(bt_context *ctx, int dims, int elem_size, const void *const *in,
+                      const uint32_t *cells, int64_t n, const int32_t *owner_of_cell, int nranks,
+                      int self_rank, int64_t self_send_offset, int64_t self_recv_offset,
+                      void *send, void *recv)
+{
+    if (!ctx || n < 0 || dims < 1 || dims > BT_MAX_DIMS || (elem_size != 4 && elem_size != 8)
+            || nranks < 1 || nranks > PP_MAX_RANKS || self_rank < 0 || self_rank >= nranks
+            || (n > 0 && (!in || !cells || !owner_of_cell))) {
+        // (send / recv may be NULL for a rank that keeps nothing / sends nothing)
+        set_error("bt_partition_pack: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    if (n == 0) return BT_OK;
+    if (n >= ((int64_t) 1 << 31)) {
+        set_error("bt_partition_pack: n=%lld exceeds 2^31-1", (long long) n);
+        return BT_ERR_INVALID;
+    }
+#define BT_PP(U, D) partition_pack_impl<U, D>(ctx, in, cells, n, owner_of_cell, nranks, self_rank, \
+                                              self_send_offset, self_recv_offset, send, recv)
+    if (elem_size == 8) return dims == 1 ? BT_PP(uint64_t, 1) : dims == 2 ? BT_PP(uint64_t, 2) : BT_PP(uint64_t, 3);
+    return dims == 1 ? BT_PP(uint32_t, 1) : dims == 2 ? BT_PP(uint32_t, 2) : BT_PP(uint32_t, 3);
+#undef BT_PP
 }
 
 int bt_gather(bt_context *ctx, int elem_size, const void *in, const uint32_t *perm, int64_t n,

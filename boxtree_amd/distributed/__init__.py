@@ -40,6 +40,8 @@ FMM *evaluation* on a replicated global tree: :mod:`.partition`,
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 ROOT_EXTENT_STRETCH_FACTOR = 1e-4        # tree_build.py:101
@@ -462,7 +464,15 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
 
     def route(arrs, cells, local_hist, extra, keep_interleaved=False):
         """all-to-all-v of the coordinate arrays (+ extras) by owner of `cells`."""
-        order, send_counts = send_order(cells, local_hist)
+        # coordinates alone are partitioned by owner in one sweep that writes the send buffer
+        # (bt_partition_pack); arrays that travel with them need the permutation
+        use_partition = native and not extra and os.environ.get("BOXTREE_HIP_PARTITION_PACK", "1") != "0"
+        if use_partition:
+            order = None
+            send_counts = torch.zeros(world, dtype=torch.int64, device=dev)
+            send_counts.index_add_(0, owner_t, local_hist)
+        else:
+            order, send_counts = send_order(cells, local_hist)
         tick("bucket")
         recv_counts = torch.empty_like(send_counts)
         dist.all_to_all_single(recv_counts, send_counts)
@@ -487,14 +497,21 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
             s_off = np.concatenate([[0], np.cumsum(s_split)]).astype(np.int64)
             r_off = np.concatenate([[0], np.cumsum(r_split)]).astype(np.int64)
             actx.sync_in()
-            pieces = [(0, int(s_off[rank]), send, 0),
-                      (int(s_off[rank]), int(s_off[rank + 1]), recv, int(r_off[rank])),
-                      (int(s_off[rank + 1]), n, send, int(s_off[rank + 1]))]
-            for lo, hi, dst, dst_at in pieces:
-                if hi > lo:
-                    _lib.check(actx.lib.bt_gather_pack(
-                        actx.handle, d, es, ptrs, ct.c_void_p(order.data_ptr() + 4 * lo), hi - lo,
-                        ct.c_void_p(dst.data_ptr() + dst_at * d * es)))
+            if use_partition:
+                owner32 = owner_t.to(torch.int32)
+                _lib.check(actx.lib.bt_partition_pack(
+                    actx.handle, d, es, ptrs, ct.c_void_p(cells.data_ptr()), n,
+                    ct.c_void_p(owner32.data_ptr()), world, rank, int(s_off[rank]), int(r_off[rank]),
+                    ct.c_void_p(send.data_ptr()), ct.c_void_p(recv.data_ptr())))
+            else:
+                pieces = [(0, int(s_off[rank]), send, 0),
+                          (int(s_off[rank]), int(s_off[rank + 1]), recv, int(r_off[rank])),
+                          (int(s_off[rank + 1]), n, send, int(s_off[rank + 1]))]
+                for lo, hi, dst, dst_at in pieces:
+                    if hi > lo:
+                        _lib.check(actx.lib.bt_gather_pack(
+                            actx.handle, d, es, ptrs, ct.c_void_p(order.data_ptr() + 4 * lo), hi - lo,
+                            ct.c_void_p(dst.data_ptr() + dst_at * d * es)))
             tick("pack")
             timed_a2a(recv, send, [r * d for r in r_split], [c * d for c in s_split],
                       self_in_place=True)

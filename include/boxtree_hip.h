@@ -495,6 +495,18 @@ int bt_morton_cells(bt_context *ctx, int dims, int coord_kind, const void *const
 int bt_bucket_permutation(bt_context *ctx, const uint32_t *cells, int64_t n,
                           const int32_t *owner_of_cell, int nranks, uint32_t *perm_out);
 
+/* The same send buffer in ONE sweep over the coordinates (no permutation, no gather): the
+ * particles are partitioned by owner_of_cell[cells[i]], stably, and their coordinates are
+ * written interleaved (out[k*dims + ax]) in owner order into `send` -- except the segment
+ * of self_rank, which goes straight to `recv` at record offset self_recv_offset (its send
+ * offset, self_send_offset, is the number of particles of the lower ranks).  Reads are
+ * sequential and writes go to nranks advancing runs, whereas bucket permutation + gather
+ * reads the coordinate arrays in nranks interleaved strided passes. */
+int bt_partition_pack(bt_context *ctx, int dims, int elem_size, const void *const *in,
+                      const uint32_t *cells, int64_t n, const int32_t *owner_of_cell, int nranks,
+                      int self_rank, int64_t self_send_offset, int64_t self_recv_offset,
+                      void *send, void *recv);
+
 /* out[i] = in[perm[i]] for 4- or 8-byte elements */
 int bt_gather(bt_context *ctx, int elem_size, const void *in, const uint32_t *perm, int64_t n,
               void *out);

@@ -882,6 +882,51 @@ def test_cuda_array_interface_inputs(actx, oracle):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims,dtype,world,n", [(3, np.float64, 8, 300001), (2, np.float32, 3, 50000),
+                                                (1, np.float64, 2, 777), (3, np.float64, 1, 4096),
+                                                (3, np.float32, 256, 200000)])
+def test_partition_pack_equals_permutation_and_gather(dims, dtype, world, n):
+    """bt_partition_pack (one sweep: count per wave and owner, scan, scatter of the
+    interleaved coordinates) writes the records bt_bucket_permutation + bt_gather_pack write,
+    the own segment straight into the receive buffer at the given offset."""
+    import ctypes as ct
+
+    import torch
+    from boxtree_amd import HIPArrayContext, _lib
+    actx = HIPArrayContext(0)
+    rng = np.random.default_rng(n + world)
+    pts = [actx.from_numpy(rng.random(n).astype(dtype)) for _ in range(dims)]
+    ncells = 4096
+    cells = actx.from_numpy(rng.integers(0, ncells, n).astype(np.int32))
+    owner_np = np.sort(rng.integers(0, world, ncells)).astype(np.int32)
+    owner = actx.from_numpy(owner_np)
+    counts = np.bincount(owner_np[actx.to_numpy(cells)], minlength=world)
+    me = int(rng.integers(0, world))
+    s_off = np.concatenate([[0], np.cumsum(counts)])
+    es = np.dtype(dtype).itemsize
+    ptrs = (ct.c_void_p * dims)(*[p.data_ptr() for p in pts])
+    tdt = pts[0].dtype
+    perm = torch.empty(n, dtype=torch.int32, device="cuda")
+    want = torch.empty(dims * n, dtype=tdt, device="cuda")
+    _lib.check(actx.lib.bt_bucket_permutation(actx.handle, ct.c_void_p(cells.data_ptr()), n,
+                                              ct.c_void_p(owner.data_ptr()), world,
+                                              ct.c_void_p(perm.data_ptr())))
+    _lib.check(actx.lib.bt_gather_pack(actx.handle, dims, es, ptrs, ct.c_void_p(perm.data_ptr()), n,
+                                       ct.c_void_p(want.data_ptr())))
+    pad = 17                                               # the own segment lands behind `pad` records
+    send = torch.full((dims * n,), -1, dtype=tdt, device="cuda")
+    recv = torch.full((dims * (pad + int(counts[me])),), -1, dtype=tdt, device="cuda")
+    _lib.check(actx.lib.bt_partition_pack(
+        actx.handle, dims, es, ptrs, ct.c_void_p(cells.data_ptr()), n, ct.c_void_p(owner.data_ptr()),
+        world, me, int(s_off[me]), pad, ct.c_void_p(send.data_ptr()), ct.c_void_p(recv.data_ptr())))
+    actx.synchronize()
+    lo, hi = dims * int(s_off[me]), dims * int(s_off[me + 1])
+    assert torch.equal(send[:lo], want[:lo]) and torch.equal(send[hi:], want[hi:])
+    assert torch.equal(recv[dims * pad:], want[lo:hi])
+    assert bool((recv[:dims * pad] == -1).all()) and bool((send[lo:hi] == -1).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("world", [2, 3, 5])
 def test_all_to_all_chunked_on_views(world):
     """The RCCL path of all_to_all_chunked -- views of the send and receive buffers handed
