@@ -7,7 +7,7 @@
 //      -> the same root box on every rank (host arithmetic of tree_build.py:462-476);
 //   2. level-k Morton-cell histogram, ncclAllReduce(sum) -> every rank derives the same
 //      top of the global tree and the same owner of every cell (bt_mgpu_plan);
-//   3. stable bucketing by owner, coordinates packed interleaved, one grouped
+//   3. stable partition by owner that carries the coordinates (interleaved), one grouped
 //      ncclSend/ncclRecv round per 512 MiB of the largest peer message (a rank's own
 //      segment is a device copy): the all-to-all-v over the point-to-point xGMI links;
 //   4. the caller builds its subtrees with bt_tree_build on the returned shard
@@ -223,11 +223,10 @@ int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
     // ---- 2. cell histogram, all-reduced ----------------------------------------------------
     const int k = p->top_level > 0 ? p->top_level : (D == 3 ? 5 : D == 2 ? 7 : 12);
     const int64_t ncells = (int64_t) 1 << (D * k);
-    Buf<uint32_t> cells, perm;
+    Buf<uint32_t> cells;
     Buf<int32_t> hist32, owner_d;
     Buf<int64_t> hist64;
     BT_CHECK(cells.alloc(ctx->pool, n));
-    BT_CHECK(perm.alloc(ctx->pool, n));
     BT_CHECK(hist32.alloc(ctx->pool, ncells));
     BT_CHECK(hist64.alloc(ctx->pool, ncells));
     BT_CHECK(owner_d.alloc(ctx->pool, ncells));
@@ -246,7 +245,6 @@ int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
     std::vector<int64_t> prefix((size_t) ncells + 1);
     BT_CHECK(bt_mgpu_plan(D, k, p->max_particles_in_box, nranks, ghist.data(), owner.data(), prefix.data()));
     BT_HIP_CHECK(hipMemcpyAsync(owner_d.get(), owner.data(), (size_t) ncells * 4, hipMemcpyHostToDevice, stream));
-    BT_CHECK(bt_bucket_permutation(ctx, cells.get(), n, owner_d.get(), nranks, perm.get()));
     std::vector<int64_t> send_counts((size_t) nranks, 0);
     for (int64_t c = 0; c < ncells; ++c) send_counts[owner[c]] += h_local[c];
     Buf<int64_t> counts_d;
@@ -273,11 +271,11 @@ int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
     Buf<unsigned char> send;
     BT_CHECK(send.alloc(ctx->pool, n * D * es));
     BT_CHECK(ms->points.alloc(ctx->pool, std::max<int64_t>(nrecv, 1) * D * es));
-    BT_CHECK(bt_gather_pack(ctx, D, es, p->coords, perm.get(), n, send.get()));
+    // one sweep over the coordinates: stable partition by owner into the send buffer, the
+    // segment this rank keeps straight into the receive buffer (bt_shard.hip)
+    BT_CHECK(bt_partition_pack(ctx, D, es, p->coords, cells.get(), n, owner_d.get(), nranks, rank,
+                               s_off[rank], r_off[rank], send.get(), ms->points.get()));
     const int64_t rec = (int64_t) D * es;                       // bytes per particle
-    if (send_counts[rank] > 0)
-        BT_HIP_CHECK(hipMemcpyAsync(ms->points.get() + r_off[rank] * rec, send.get() + s_off[rank] * rec,
-                                    (size_t) (send_counts[rank] * rec), hipMemcpyDeviceToDevice, stream));
     const int64_t rounds = std::max<int64_t>(1, div_up(biggest * rec, MESSAGE_LIMIT_BYTES));
     auto cut = [&](int64_t c, int64_t j) { return (j * c) / rounds; };
     if (biggest > 0) {
