@@ -543,23 +543,6 @@ __global__ __launch_bounds__(256) void copy_spans_kernel(SpanCopies c)
         dst[i] = src[i];
 }
 
-// level starts in a box list: traversal.py:361-392 + 2093-2096 (== lower_bound of the
-// level's first box id in the ascending list)
-__global__ void level_starts_kernel(const int32_t *list, int32_t n, const int32_t *level_start_box_nrs,
-                                    int nlevels, int32_t *out)
-{
-    const int l = threadIdx.x;
-    if (l > nlevels) return;
-    if (l == nlevels) { out[l] = n; return; }
-    const int32_t v = level_start_box_nrs[l];
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = lo + ((hi - lo) >> 1);
-        if (list[mid] < v) lo = mid + 1; else hi = mid;
-    }
-    out[l] = lo;
-}
-
 // ---- list 3 per-level post-processing (BuiltList with eliminate_empty) --------------------
 
 struct NonEmptyPred {
@@ -577,26 +560,6 @@ __global__ void l3_level_marks_kernel(int nlevels, int64_t ntb, const int32_t *s
     const int r = l > lev0 ? l - lev0 : 0;
     out[l] = starts[(int64_t) r * ntb];
     out[nlevels + 1 + l] = scan[(int64_t) r * ntb];
-}
-
-__global__ __launch_bounds__(256) void l3_compress_kernel(int32_t ntb, const int32_t *lev_starts,
-        int32_t lev_base, const int32_t *cidx /* [ntb+1] slice of the flat scan of nonempty */,
-        int32_t cidx_base, const int32_t *target_boxes, int32_t *o_starts, int32_t *o_nonempty,
-        int32_t *o_cidx, int32_t *o_tboxes, int32_t lev_total)
-{
-    const int32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i > ntb) return;
-    if (o_cidx) o_cidx[i] = cidx[i] - cidx_base;
-    if (i == ntb) {
-        o_starts[cidx[ntb] - cidx_base] = lev_total;
-        return;
-    }
-    if (lev_starts[i + 1] > lev_starts[i]) {
-        const int32_t k = cidx[i] - cidx_base;
-        o_starts[k] = lev_starts[i] - lev_base;
-        o_nonempty[k] = i;
-        o_tboxes[k] = target_boxes[i];
-    }
 }
 
 // all source levels in one launch (thread = (level, target box number))

@@ -720,7 +720,7 @@ __global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree 
         if (box_flags(a, 0) & BT_BOX_IS_SOURCE_BOX) e1(0);       // traversal.py:489-495
         // b itself; the sources inside b (target boxes with children: extents only) are
         // a contiguous block of preorder ranks: space is reserved here, the entries are
-        // written by l1_finalize_kernel / copy_rank_blocks_kernel
+        // written by l1_finalize32_kernel / copy_rank_blocks_kernel
         if (level >= 1 && (box_flags(a, b) & BT_BOX_IS_SOURCE_BOX)) e1(b);
         // coarser levels: source-box colleagues of the ancestors, and the ancestors
         if (level >= 2) {
@@ -775,39 +775,7 @@ __global__ __launch_bounds__(256) void list13_kernel(TravArgs<T, D> a, FastTree 
     }
 }
 
-// one thread per target box: order list 1 by depth-first rank (the items wrote ranks),
-// open the gap for the own-subtree block and turn ranks into box ids
-template <class T, int D>
-__global__ __launch_bounds__(256) void l1_finalize_kernel(TravArgs<T, D> a, FastTree ft,
-        int32_t ntb, const int32_t *l1_starts, int32_t *l1_lists, BlockJobs jobs)
-{
-    const int32_t tbn = blockIdx.x * 256 + threadIdx.x;
-    if (tbn >= ntb) return;
-    const int32_t b = a.target_boxes[tbn];
-    int32_t *out = l1_lists + l1_starts[tbn];
-    const int32_t n_all = l1_starts[tbn + 1] - l1_starts[tbn];
-    int32_t blk_len = 0, blk_src = 0;
-    const int32_t my_rank = ft.dfs_rank[b];
-    if (box_flags(a, b) & BT_BOX_HAS_SOURCE_CHILD_BOXES) {
-        blk_src = ft.src_prefix[my_rank + 1];
-        blk_len = ft.src_prefix[my_rank + ft.subtree_size[b]] - blk_src;
-    }
-    const int32_t n = n_all - blk_len;              // the ranks; the reserved space follows
-    sort_i32_inplace(out, n);                       // depth-first preorder
-    int32_t k = n;
-    if (blk_len > 0) {
-        k = 0;
-        while (k < n && out[k] <= my_rank) ++k;
-        for (int32_t i = n - 1; i >= k; --i) out[i + blk_len] = ft.box_of_rank[out[i]];
-        const int32_t j = tbn;                  // one slot per target box: no shared counter
-        jobs.dst[j] = l1_starts[tbn] + k;
-        jobs.src[j] = blk_src;
-        jobs.len[j] = blk_len;
-    }
-    for (int32_t i = 0; i < k; ++i) out[i] = ft.box_of_rank[out[i]];
-}
-
-// Same as l1_finalize_kernel with 16 lanes per target box: lists of up to 64 ranks
+// List 1 is ordered with 16 lanes per target box: lists of up to 64 entries
 // (nearly all of them) are ordered by counting in registers; longer ones go to a wave
 // or a workgroup.
 constexpr int L1_BLOCK_MAX = 8192;
