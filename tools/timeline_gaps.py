@@ -4,7 +4,7 @@
 usage: timeline_gaps.py DB [first-kernel-substring] [min-gap-us]
 
 A step starts at the first launch whose name contains the given substring (default
-"bbox_kernel") after a launch that does not; the last complete step is printed as a
+"bbox_") after a launch that does not; the last complete step is printed as a
 timeline: every gap of at least min-gap-us (default 4) with the kernels either side,
 and the totals (span, busy, idle, launches)."""
 import sqlite3
