@@ -82,6 +82,7 @@ class TreeArrays(ct.Structure):
         ("box_source_bounding_box_min", vp), ("box_source_bounding_box_max", vp),
         ("box_target_bounding_box_min", vp), ("box_target_bounding_box_max", vp),
         ("level_start_box_nrs", vp),
+        ("box_subtree_sizes", vp),
     ]
 
 
@@ -109,6 +110,7 @@ class TravParams(ct.Structure):
         ("source_boxes_mask", vp), ("source_parent_boxes_mask", vp),
         ("force_generic", ct.c_int32),
         ("target_boxes_mask", vp), ("active_level_ranges", ct.POINTER(ct.c_int32)),
+        ("box_subtree_sizes", vp),
     ]
 
 

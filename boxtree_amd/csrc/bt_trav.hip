@@ -712,7 +712,6 @@ struct TravState {
     bool lattice = false;              // bt_trav_v2.hpp kernels apply
     bool has_blocks = true;            // some target box has source boxes below it
     Buf<unsigned char> cells;          // ICell[nboxes]
-    Buf<uint8_t> slot_of;
     std::vector<std::pair<const char *, hipEvent_t>> events;
     bool built = false;
 };
@@ -1057,17 +1056,21 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     const size_t lvl_lds = (size_t) nlevels * WALK_THREADS * 4;
 
     // depth-first preorder ranks
-    BT_CHECK(st->subtree_size.alloc(ctx->pool, B));
+    const int32_t *sizes = p.box_subtree_sizes;      // from bt_tree_export, or counted here
     BT_CHECK(st->dfs_rank.alloc(ctx->pool, B));
     BT_CHECK(st->box_of_rank.alloc(ctx->pool, B));
-    for (int lev = nlevels - 1; lev >= 0; --lev)
-        subtree_size_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
-            ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
-            st->subtree_size.get());
+    if (!sizes) {
+        BT_CHECK(st->subtree_size.alloc(ctx->pool, B));
+        for (int lev = nlevels - 1; lev >= 0; --lev)
+            subtree_size_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
+                ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
+                st->subtree_size.get());
+        sizes = st->subtree_size.get();
+    }
     for (int lev = 0; lev < nlevels; ++lev)
         dfs_rank_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
             ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
-            st->subtree_size.get(), st->dfs_rank.get(), st->box_of_rank.get());
+            sizes, st->dfs_rank.get(), st->box_of_rank.get());
     // source boxes in depth-first order (+ prefix counts over ranks)
     BT_CHECK(st->src_rank_prefix.alloc(ctx->pool, B + 1));
     {
@@ -1081,7 +1084,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             f, (int32_t) B, st->src_rank_prefix.get(), st->src_by_rank.get());
     }
     a.dfs_rank = st->dfs_rank.get();
-    FastTree ft{st->dfs_rank.get(), st->box_of_rank.get(), st->subtree_size.get(),
+    FastTree ft{st->dfs_rank.get(), st->box_of_rank.get(), sizes,
                 st->src_rank_prefix.get(), st->src_by_rank.get()};
 
     // colleagues + list 2, level by level
@@ -1403,37 +1406,20 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     const int64_t ntb = st->ntb;
     const bool with_blocks = st->has_blocks;
 
-    // ---- per-tree tables ----------------------------------------------------------
-    BT_CHECK(st->subtree_size.alloc(ctx->pool, B));
+    // ---- per-tree tables and colleague rows, level by level ---------------------------------
+    const int32_t *sizes = p.box_subtree_sizes;      // from bt_tree_export, or counted here
     BT_CHECK(st->dfs_rank.alloc(ctx->pool, B));
     BT_CHECK(st->box_of_rank.alloc(ctx->pool, B));
-    BT_CHECK(st->slot_of.alloc(ctx->pool, B));
     BT_CHECK(st->cells.alloc(ctx->pool, B * (int64_t) sizeof(ICell)));
     ICell *cells = (ICell *) st->cells.get();
-    for (int lev = nlevels - 1; lev >= 0; --lev)
-        subtree_size_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
-            ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
-            st->subtree_size.get());
-    for (int lev = 0; lev < nlevels; ++lev)
-        dfs_rank_cells_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
-            ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
-            st->subtree_size.get(), p.box_levels, p.box_flags, st->dfs_rank.get(),
-            st->box_of_rank.get(), st->slot_of.get(), cells);
-    if (with_blocks) {
-        // source boxes in depth-first order (+ prefix counts over ranks): own-subtree blocks
-        BT_CHECK(st->src_rank_prefix.alloc(ctx->pool, B + 1));
-        SourceRankFlag<T, D> f{a.nodes, st->box_of_rank.get()};
-        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, f, B, st->src_rank_prefix.get(),
-                                                          (int32_t *) nullptr, true)));
-        BT_CHECK(st->src_by_rank.alloc(ctx->pool, B + 1));
-        compact_sources_by_rank_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
-            f, (int32_t) B, st->src_rank_prefix.get(), st->src_by_rank.get());
+    if (!sizes) {
+        BT_CHECK(st->subtree_size.alloc(ctx->pool, B));
+        for (int lev = nlevels - 1; lev >= 0; --lev)
+            subtree_size_kernel<D><<<nblk(ls[lev + 1] - ls[lev]), 256, 0, ctx->stream>>>(
+                ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids,
+                st->subtree_size.get());
+        sizes = st->subtree_size.get();
     }
-    a.dfs_rank = st->dfs_rank.get();
-    FastTree ft{st->dfs_rank.get(), st->box_of_rank.get(), st->subtree_size.get(),
-                st->src_rank_prefix.get(), st->src_by_rank.get()};
-
-    // ---- colleague rows, level by level ----------------------------------------------
     Buf<int32_t> coll_rows, coll_cnt, coll_ins, l2_cnt;
     Buf<int32_t> &srccoll_rows = st->srccoll_rows, &srccoll_cnt = st->srccoll_cnt;
     BT_CHECK(coll_rows.alloc(ctx->pool, B * P));
@@ -1448,24 +1434,48 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     rows.child_t = st->child_t.get();
     rows.parent = p.box_parent_ids;
     rows.flags = p.box_flags;
-    rows.slot_of = st->slot_of.get();
     rows.target_mask = p.target_boxes_mask;
     rows.coll_rows = coll_rows.get(); rows.coll_cnt = d_coll_cnt; rows.coll_ins = d_coll_ins;
     rows.srccoll_rows = srccoll_rows.get(); rows.srccoll_cnt = srccoll_cnt.get();
     rows.l2_cnt = d_l2_cnt;
-    for (int lev = 1; lev < nlevels; ++lev) {
-        int32_t b0 = ls[lev], nb = ls[lev + 1] - ls[lev];
-        if (p.active_level_ranges) {        // sharded traversal: this rank's boxes only
-            b0 = p.active_level_ranges[2 * lev];
-            nb = p.active_level_ranges[2 * lev + 1] - b0;
-        }
-        // a group of lanes per box of the level above that has children
+    // Level lev: its boxes hand depth-first ranks and cells to their children, and the rows
+    // of level lev + 1 are built from those of level lev -- one launch for both
+    // (level_tables_kernel).  The last level has no children: nothing to do there.
+    for (int lev = 0; lev < nlevels; ++lev) {
+        if (lev > 0 && lev == nlevels - 1) break;
+        DfsLevel dl{ls[lev], ls[lev + 1] - ls[lev], p.aligned_nboxes, p.box_child_ids, sizes,
+                    p.box_levels, p.box_flags, st->dfs_rank.get(), st->box_of_rank.get(), cells};
+        const int32_t dfs_blocks = (int32_t) nblk(dl.nb);
+        int32_t np = 0, b0 = 0, nb = 0;
         const int32_t *pls = st->h_lev_starts.data() + 4 * (nlevels + 1);
-        const int32_t np = pls[lev] - pls[lev - 1];
+        if (lev + 1 < nlevels) {
+            b0 = ls[lev + 1]; nb = ls[lev + 2] - ls[lev + 1];
+            if (p.active_level_ranges) {        // sharded traversal: this rank's boxes only
+                b0 = p.active_level_ranges[2 * (lev + 1)];
+                nb = p.active_level_ranges[2 * (lev + 1) + 1] - b0;
+            }
+            // a group of lanes per box of this level that has children
+            np = pls[lev + 1] - pls[lev];
+        }
         if (nb > 0 && np > 0)
-            coll_rows_v3_kernel<D, false><<<nblk((int64_t) np * V3Lanes<D>::N), 256, 0, ctx->stream>>>(
-                rows, st->parent_boxes.get() + pls[lev - 1], np, b0, b0 + nb);
+            level_tables_kernel<D><<<dfs_blocks + nblk((int64_t) np * V3Lanes<D>::N), 256, 0, ctx->stream>>>(
+                dl, dfs_blocks, rows, st->parent_boxes.get() + pls[lev], np, b0, b0 + nb);
+        else
+            dfs_rank_cells_kernel<D><<<dfs_blocks, 256, 0, ctx->stream>>>(dl);
     }
+    if (with_blocks) {
+        // source boxes in depth-first order (+ prefix counts over ranks): own-subtree blocks
+        BT_CHECK(st->src_rank_prefix.alloc(ctx->pool, B + 1));
+        SourceRankFlag<T, D> f{a.nodes, st->box_of_rank.get()};
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, f, B, st->src_rank_prefix.get(),
+                                                          (int32_t *) nullptr, true)));
+        BT_CHECK(st->src_by_rank.alloc(ctx->pool, B + 1));
+        compact_sources_by_rank_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
+            f, (int32_t) B, st->src_rank_prefix.get(), st->src_by_rank.get());
+    }
+    a.dfs_rank = st->dfs_rank.get();
+    FastTree ft{st->dfs_rank.get(), st->box_of_rank.get(), sizes,
+                st->src_rank_prefix.get(), st->src_by_rank.get()};
     a.srccoll_rows = srccoll_rows.get();       // list 4 walks the same rows
     a.srccoll_cnt = srccoll_cnt.get();
     a.srccoll_stride = P;

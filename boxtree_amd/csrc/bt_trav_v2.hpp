@@ -67,20 +67,33 @@ __device__ __forceinline__ void v2_load_children(const int32_t *child_t, int32_t
     }
 }
 
-// ---- per-tree tables: slot in the parent, integer cells, depth-first ranks ----------
+// ---- per-tree tables: integer cells, depth-first ranks -------------------------------
+
+struct DfsLevel {
+    int32_t b0, nb;                    // the parents: boxes of one level
+    int64_t aligned;
+    const int32_t *child, *size;
+    const uint8_t *levels, *flags;
+    int32_t *rank, *box_of_rank;
+    ICell *cells;
+};
 
 template <int D>
-__global__ __launch_bounds__(256) void dfs_rank_cells_kernel(int32_t b0, int32_t nb, int64_t aligned,
-        const int32_t *child, const int32_t *size, const uint8_t *levels, const uint8_t *flags,
-        int32_t *rank, int32_t *box_of_rank, uint8_t *slot_of, ICell *cells)
+__device__ __forceinline__ void dfs_rank_cells_block(const DfsLevel &a, int32_t blk)
 {
     constexpr int C = 1 << D;
-    const int32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= nb) return;
+    const int32_t b0 = a.b0;
+    const int64_t aligned = a.aligned;
+    const int32_t *child = a.child, *size = a.size;
+    const uint8_t *levels = a.levels, *flags = a.flags;
+    int32_t *rank = a.rank, *box_of_rank = a.box_of_rank;
+    ICell *cells = a.cells;
+    const int32_t i = blk * 256 + threadIdx.x;
+    if (i >= a.nb) return;
     const int32_t p = b0 + i;          // parent whose children get their ranks
     ICell pc;
     if (p == 0) {
-        rank[0] = 0; box_of_rank[0] = 0; slot_of[0] = 0;
+        rank[0] = 0; box_of_rank[0] = 0;
         pc.c[0] = pc.c[1] = pc.c[2] = 0;
         pc.lf = (uint32_t) levels[0] | ((uint32_t) flags[0] << 8);
         cells[0] = pc;
@@ -95,7 +108,6 @@ __global__ __launch_bounds__(256) void dfs_rank_cells_kernel(int32_t b0, int32_t
             rank[c] = run;
             box_of_rank[run] = c;
             run += size[c];
-            slot_of[c] = (uint8_t) m;
             ICell cc;
             cc.c[0] = cc.c[1] = cc.c[2] = 0;
 #pragma unroll
@@ -106,6 +118,12 @@ __global__ __launch_bounds__(256) void dfs_rank_cells_kernel(int32_t b0, int32_t
     }
 }
 
+template <int D>
+__global__ __launch_bounds__(256) void dfs_rank_cells_kernel(DfsLevel a)
+{
+    dfs_rank_cells_block<D>(a, (int32_t) blockIdx.x);
+}
+
 // ---- colleague rows (+ list-2 counts), one level, top-down ---------------------------
 
 template <int D>
@@ -113,7 +131,6 @@ struct V2Rows {
     const int32_t *child_t;        // packed
     const int32_t *parent;
     const uint8_t *flags;
-    const uint8_t *slot_of;
     const int8_t *target_mask;
     int32_t *coll_rows, *coll_cnt, *coll_ins;
     int32_t *srccoll_rows, *srccoll_cnt;
@@ -192,14 +209,14 @@ __device__ __forceinline__ constexpr uint32_t v3_set_mask(int ax)
 // parents[0 .. np): boxes that have children; rows / lists are made for their children in
 // [b_lo, b_hi)
 template <int D, bool FILL>
-__global__ __launch_bounds__(256) void coll_rows_v3_kernel(V2Rows<D> t, const int32_t *parents, int32_t np,
-        int32_t b_lo, int32_t b_hi)
+__device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int32_t *parents, int32_t np,
+        int32_t b_lo, int32_t b_hi, int32_t blk)
 {
     constexpr int C = 1 << D;
     constexpr int P = V2Dims<D>::P;
     constexpr int LANES = V3Lanes<D>::N;
     constexpr uint32_t FULL = (1u << C) - 1u;
-    const int32_t tid = blockIdx.x * 256 + threadIdx.x;
+    const int32_t tid = blk * 256 + threadIdx.x;
     const int32_t g = tid / LANES;
     const int j = tid % LANES;
     if (g >= np) return;                 // whole groups drop out together
@@ -356,6 +373,24 @@ __global__ __launch_bounds__(256) void coll_rows_v3_kernel(V2Rows<D> t, const in
                 if ((lm >> m) & 1u) t.l2_lists[pl++] = (int32_t) (ch[m] & CH_ID_MASK);
         }
     }
+}
+
+template <int D, bool FILL>
+__global__ __launch_bounds__(256) void coll_rows_v3_kernel(V2Rows<D> t, const int32_t *parents, int32_t np,
+        int32_t b_lo, int32_t b_hi)
+{
+    coll_rows_v3_block<D, FILL>(t, parents, np, b_lo, b_hi, (int32_t) blockIdx.x);
+}
+
+// One launch per level for the two top-down tables: the first dfs_blocks workgroups give the
+// children of level `lev` their depth-first ranks and cells, the others build the colleague
+// rows of level `lev + 1` from those of level `lev`.  Neither reads what the other writes.
+template <int D>
+__global__ __launch_bounds__(256) void level_tables_kernel(DfsLevel d, int32_t dfs_blocks, V2Rows<D> t,
+        const int32_t *parents, int32_t np, int32_t b_lo, int32_t b_hi)
+{
+    if ((int32_t) blockIdx.x < dfs_blocks) dfs_rank_cells_block<D>(d, (int32_t) blockIdx.x);
+    else coll_rows_v3_block<D, false>(t, parents, np, b_lo, b_hi, (int32_t) blockIdx.x - dfs_blocks);
 }
 
 // colleague CSR from the rows (codes stripped); LANES lanes per row

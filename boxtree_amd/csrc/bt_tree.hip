@@ -1475,6 +1475,8 @@ struct BoxInfoArgs {
     int csize;
     void *o_extents[4];            // [D][aligned] arrays whose padding columns are zeroed (or null)
     int32_t *o_level_starts;       // [n_level_starts] or null
+    int32_t *o_sizes;              // [nboxes] boxes per subtree: 1 here, box_extent_kernel adds
+                                   // the children's (or null)
     int n_level_starts;
     int32_t level_starts[BT_MAX_LEVELS + 1];
 };
@@ -1550,6 +1552,7 @@ __global__ __launch_bounds__(256) void box_info_kernel(BoxInfoArgs a)
     a.o_parent[b] = a.box_parent[b];
     a.o_levels[b] = a.box_level[b];
     a.o_flags[b] = flags;
+    if (a.o_sizes) a.o_sizes[b] = 1;
     for (int m = 0; m < a.C; ++m)
         a.o_child[(int64_t) m * a.aligned + b] = a.box_child[(int64_t) b * a.C + m];
 }
@@ -1582,6 +1585,9 @@ struct ExtentArgs {
     const T *radii;          // null if disabled
     T *bmin, *bmax;          // [D][aligned]
     int leaves_done;         // leaf_gather_*_kernel wrote the extents of the leaves
+    int32_t *sizes;          // [nboxes] boxes per subtree, 1 on entry (or null): the sweep is
+                             // bottom-up over the child table anyway, so the traversal's
+                             // depth-first ranks need no sweep of their own
 };
 
 template <class T, int D>
@@ -1599,6 +1605,7 @@ __global__ __launch_bounds__(256) void box_extent_kernel(ExtentArgs<T, D> a)
         if (!any_child) return;
     }
     T mn[D], mx[D];
+    int32_t below = 0;       // boxes under child l16
 #pragma unroll
     for (int ax = 0; ax < D; ++ax) mn[ax] = mx[ax] = a.centers[(int64_t) ax * a.aligned + b];
     if (active) {
@@ -1616,6 +1623,7 @@ __global__ __launch_bounds__(256) void box_extent_kernel(ExtentArgs<T, D> a)
         if (l16 < C) {
             const int32_t ch = a.child[(int64_t) l16 * a.aligned + b];
             if (ch != 0) {
+                if (a.sizes) below = a.sizes[ch];
 #pragma unroll
                 for (int ax = 0; ax < D; ++ax) {
                     const T lo = a.bmin[(int64_t) ax * a.aligned + ch];
@@ -1640,12 +1648,19 @@ __global__ __launch_bounds__(256) void box_extent_kernel(ExtentArgs<T, D> a)
         omn = dpp_row_mov<0x101>(mn[ax]); omx = dpp_row_mov<0x101>(mx[ax]);
         mn[ax] = (omn < mn[ax]) ? omn : mn[ax]; mx[ax] = (omx > mx[ax]) ? omx : mx[ax];
     }
+    if (a.sizes) {
+        // lanes >= 2^d hold 0: the sum of the first 8 lanes lands in lane 0
+        below += __builtin_amdgcn_update_dpp(0, below, 0x104, 0xf, 0xf, true);
+        below += __builtin_amdgcn_update_dpp(0, below, 0x102, 0xf, 0xf, true);
+        below += __builtin_amdgcn_update_dpp(0, below, 0x101, 0xf, 0xf, true);
+    }
     if (active && l16 == 0) {
 #pragma unroll
         for (int ax = 0; ax < D; ++ax) {
             a.bmin[(int64_t) ax * a.aligned + b] = mn[ax];
             a.bmax[(int64_t) ax * a.aligned + b] = mx[ax];
         }
+        if (a.sizes) a.sizes[b] = 1 + below;
     }
 }
 
@@ -2981,6 +2996,7 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
         a.o_extents[2] = (fused || sat) ? nullptr : o->box_target_bounding_box_min;
         a.o_extents[3] = (fused || sat) ? nullptr : o->box_target_bounding_box_max;
         a.o_level_starts = o->level_start_box_nrs;
+        a.o_sizes = o->box_subtree_sizes;
         a.n_level_starts = (int) std::min<size_t>(st->level_start.size(), BT_MAX_LEVELS + 1);
         for (int i = 0; i < a.n_level_starts; ++i) a.level_starts[i] = st->level_start[(size_t) i];
         box_info_kernel<<<blocks(aligned), 256, 0, ctx->stream>>>(a);
@@ -3011,6 +3027,7 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
             a.radii = (const T *) (round == 0 ? (p.source_radii ? o->source_radii : nullptr)
                                               : (p.target_radii ? o->target_radii : nullptr));
             a.bmin = bmin; a.bmax = bmax;
+            a.sizes = round == 0 ? o->box_subtree_sizes : nullptr;
             box_extent_kernel<T, D><<<blocks((int64_t) a.nb * 16), 256, 0, ctx->stream>>>(a);
         }
     }

@@ -7,6 +7,7 @@ from __future__ import annotations
 import ctypes as ct
 import dataclasses
 import logging
+import os
 from dataclasses import dataclass
 from typing import Any
 
@@ -254,11 +255,14 @@ class FMMTraversalBuilder:
         # a TreeOfBoxes made by boxtree.tree_of_boxes arrives as numpy arrays with
         # int32 levels and a root whose parent is -1 (tree_of_boxes.py:392-465)
         torch = actx.torch
+        subtree_sizes = None
         if getattr(tree, "_host_level_starts", None) is not None:
             # made by TreeBuilder on this device: contiguous arrays of the library's types
             box_centers, box_levels, box_child_ids = (tree.box_centers, tree.box_levels,
                                                       tree.box_child_ids)
             box_flags, box_parent_ids = tree.box_flags, tree.box_parent_ids
+            if os.environ.get("BOXTREE_HIP_SUBTREE_SIZES", "1") != "0":
+                subtree_sizes = getattr(tree, "_subtree_sizes", None)
         else:
             box_centers = dev(tree.box_centers)
             box_levels = dev(tree.box_levels).to(torch.uint8)
@@ -286,6 +290,7 @@ class FMMTraversalBuilder:
         tp.box_child_ids = ptr(box_child_ids)
         tp.box_flags = ptr(box_flags)
         tp.box_parent_ids = ptr(box_parent_ids)
+        tp.box_subtree_sizes = ptr(subtree_sizes)
         keep = []
         if tree.targets_have_extent:
             for name in ("box_target_bounding_box_min", "box_target_bounding_box_max",
@@ -305,7 +310,6 @@ class FMMTraversalBuilder:
         tp.source_boxes_mask = ptr(sbm)
         tp.source_parent_boxes_mask = ptr(spbm)
         if _force_generic is None:
-            import os
             _force_generic = os.environ.get("BOXTREE_HIP_FORCE_GENERIC", "0") == "1"
         # True: walk-from-root kernels; "float": parent-colleague kernels with the float
         # predicates; False: the default choice (integer-lattice form where it applies)

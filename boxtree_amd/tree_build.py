@@ -395,12 +395,13 @@ class TreeBuilder:
         (user_source_ids, sorted_target_ids, box_source_starts, box_source_counts_nonchild,
          box_source_counts_cumul, box_parent_ids, box_child_ids, box_centers, box_levels,
          box_flags, box_source_bounding_box_min, box_source_bounding_box_max,
-         level_start_box_nrs_dev, *sources) = actx.empty_block([
+         level_start_box_nrs_dev, subtree_sizes, *sources) = actx.empty_block([
              (nsources, i32), (ntargets, i32), (nboxes, i32), (nboxes, i32), (nboxes, i32),
              (nboxes, i32), ((C, aligned_nboxes), i32), (grid, coord_dtype), (nboxes, np.uint8),
              (nboxes, np.uint8), (grid, coord_dtype), (grid, coord_dtype), (nlevels + 1, i32),
-             *[(nsources, coord_dtype) for _ in range(dimensions)]])
+             (nboxes, i32), *[(nsources, coord_dtype) for _ in range(dimensions)]])
         out.level_start_box_nrs = ptr(level_start_box_nrs_dev)
+        out.box_subtree_sizes = ptr(subtree_sizes)
 
         out.user_source_ids = ptr(user_source_ids)
         out.sorted_target_ids = ptr(sorted_target_ids)
@@ -503,6 +504,9 @@ class TreeBuilder:
         # host copy of the level starts for the traversal builder (a private attribute,
         # not a field: copies made field by field fall back to reading the device array)
         object.__setattr__(tree, "_host_level_starts", level_start_box_nrs.astype(np.int32))
+        # boxes per subtree, a by-product of the bottom-up sweep for the bounding boxes: the
+        # traversal builder's depth-first ranks start from it (bt_trav_params.box_subtree_sizes)
+        object.__setattr__(tree, "_subtree_sizes", subtree_sizes)
 
         if srcntgts_have_extent and kind == "adaptive-level-restricted":
             # Upstream never tests this combination, and its algorithm -- followed line

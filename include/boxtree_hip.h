@@ -209,6 +209,11 @@ typedef struct {
     void *box_source_bounding_box_min, *box_source_bounding_box_max;  /* [d, aligned] */
     void *box_target_bounding_box_min, *box_target_bounding_box_max;  /* or NULL */
     int32_t *level_start_box_nrs;          /* [nlevels+1] device copy of bt_tree_sizes', or NULL */
+    /* Not a boxtree.Tree array: the number of boxes in the subtree of every box (itself
+     * included), a by-product of the bottom-up sweep that computes the bounding boxes.
+     * bt_trav_params.box_subtree_sizes takes it back and saves the traversal a sweep of
+     * its own (one launch per level).  [nboxes], or NULL. */
+    int32_t *box_subtree_sizes;
 } bt_tree_arrays;
 
 int bt_tree_export(bt_context *ctx, const bt_tree_arrays *out);
@@ -260,6 +265,9 @@ typedef struct {
      * lists are only built (and only valid) inside these ranges. */
     const int8_t *target_boxes_mask;
     const int32_t *active_level_ranges;
+    /* Optional: bt_tree_arrays.box_subtree_sizes of the SAME tree (device, [nboxes]), or
+     * NULL -- the traversal then counts the subtrees itself. */
+    const int32_t *box_subtree_sizes;
 } bt_trav_params;
 
 typedef struct {

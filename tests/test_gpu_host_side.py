@@ -113,3 +113,47 @@ def test_stage_events_are_optional():
     assert tb.last_stage_times == {}
     assert_same_tree(actx.to_numpy(tree2), actx.to_numpy(tree))
     actx.set_stage_timing(True)
+
+
+def _subtree_sizes_by_hand(h_tree):
+    child = np.asarray(h_tree.box_child_ids)[:, :h_tree.nboxes]
+    levels = np.asarray(h_tree.box_levels)
+    sizes = np.ones(h_tree.nboxes, np.int64)
+    for b in np.argsort(-levels.astype(np.int64), kind="stable"):    # deepest first
+        kids = child[:, b]
+        sizes[b] += sizes[kids[kids != 0]].sum()
+    return sizes
+
+
+@pytest.mark.parametrize("d,n,kw", [
+    (3, 60000, {}),
+    (2, 30000, {}),
+    (1, 700, {}),
+    (3, 20000, {"kind": "adaptive-level-restricted"}),
+    (2, 20000, {"kind": "non-adaptive"}),
+    (3, 30000, {"separate_targets": True}),
+    (2, 20000, {"separate_targets": True, "target_radii": True}),
+])
+def test_subtree_sizes_of_the_export(monkeypatch, d, n, kw):
+    """bt_tree_arrays.box_subtree_sizes counts the boxes under every box, and a traversal
+    that starts from it (bt_trav_params.box_subtree_sizes) equals one that counts itself."""
+    from boxtree_amd import HIPArrayContext
+    actx = HIPArrayContext(0)
+    kw = dict(kw)
+    pts = points(n, d)
+    targets = points(n // 2, d, seed=5) if kw.pop("separate_targets", False) else None
+    if kw.pop("target_radii", False):
+        rng = np.random.default_rng(9)
+        kw["target_radii"] = actx.from_numpy(rng.random(n // 2) * 1e-3)
+        kw["stick_out_factor"] = 0.25
+    tree, trav, _, _ = build(actx, pts, targets, **kw)
+    h_tree = actx.to_numpy(tree)
+    got = tree._subtree_sizes.cpu().numpy()
+    assert got.dtype == np.int32 and got.shape == (h_tree.nboxes,)
+    assert np.array_equal(got, _subtree_sizes_by_hand(h_tree))
+    assert got[0] == h_tree.nboxes
+    monkeypatch.setenv("BOXTREE_HIP_SUBTREE_SIZES", "0")
+    from boxtree_amd import FMMTraversalBuilder
+    trav_counted, _ = FMMTraversalBuilder(actx)(actx, tree)
+    monkeypatch.delenv("BOXTREE_HIP_SUBTREE_SIZES")
+    assert_same_traversal(actx.to_numpy(trav), actx.to_numpy(trav_counted))
