@@ -191,21 +191,17 @@ __device__ __forceinline__ uint64_t sp_add_sat(uint64_t a, uint64_t b)
 // look-back chain advances by about 64 tiles per poll round trip (~1.5 us under load),
 // i.e. some 40 tiles/us -- 4096-element tiles cap a 32-bit scan at ~1.3 TB/s (measured:
 // 1.6*10^8 elements in 2.2 ms), four times larger tiles leave the chain idle.
+// one tile of a scan whose descriptors start at desc (tile = ticket within the scan)
 template <class AccT, class OutT, class F, int THREADS>
-__global__ __launch_bounds__(THREADS) void scan_single_pass_kernel(F f, int64_t n, OutT *out,
-        AccT *d_total, bool write_total_at_n, uint64_t *desc, uint32_t *ticket_counter,
-        uint32_t ticket_base, uint32_t gen, DeviceStatus *status)
+__device__ __forceinline__ void scan_tile(const F &f, int64_t n, OutT *out, AccT *d_total,
+        bool write_total_at_n, uint64_t *desc, uint32_t tile, uint32_t gen, DeviceStatus *status)
 {
     constexpr int NW = THREADS / 64;
     constexpr int64_t TILE = (int64_t) THREADS * SCAN_ITEMS;
     using W = uint32_t;
-    __shared__ uint32_t s_tile;
     __shared__ W s_wave[NW];
     __shared__ uint64_t s_wave_tot[NW];
     __shared__ uint64_t s_excl;
-    if (threadIdx.x == 0) s_tile = atomicAdd(ticket_counter, 1u) - ticket_base;
-    __syncthreads();
-    const uint32_t tile = s_tile;
     const int w = threadIdx.x >> 6, lane = lane_id();
     const int64_t wave_base = (int64_t) tile * TILE + (int64_t) w * (64 * SCAN_ITEMS);
     W v[SCAN_ITEMS], ex[SCAN_ITEMS];
@@ -292,6 +288,47 @@ __global__ __launch_bounds__(THREADS) void scan_single_pass_kernel(F f, int64_t 
     }
 }
 
+template <class AccT, class OutT, class F, int THREADS>
+__global__ __launch_bounds__(THREADS) void scan_single_pass_kernel(F f, int64_t n, OutT *out,
+        AccT *d_total, bool write_total_at_n, uint64_t *desc, uint32_t *ticket_counter,
+        uint32_t ticket_base, uint32_t gen, DeviceStatus *status)
+{
+    __shared__ uint32_t s_tile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket_counter, 1u) - ticket_base;
+    __syncthreads();
+    scan_tile<AccT, OutT, F, THREADS>(f, n, out, d_total, write_total_at_n, desc, s_tile, gen, status);
+}
+
+// Up to K scans of the same kind in one launch: the tiles of scan k are the tickets
+// [first_tile[k], first_tile[k + 1]), and its look-back stops at its own first descriptor.
+// Tickets are handed out in order, so a tile only ever waits for tiles that already run.
+template <class AccT, class OutT, class F, int K>
+struct ScanBatch {
+    F f[K];
+    int64_t n[K];
+    OutT *out[K];
+    AccT *total[K];
+    uint32_t first_tile[K + 1];
+    int count;
+};
+
+template <class AccT, class OutT, class F, int THREADS, int K>
+__global__ __launch_bounds__(THREADS) void scan_batch_kernel(ScanBatch<AccT, OutT, F, K> b,
+        bool write_total_at_n, uint64_t *desc, uint32_t *ticket_counter, uint32_t ticket_base,
+        uint32_t gen, DeviceStatus *status)
+{
+    __shared__ uint32_t s_tile;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket_counter, 1u) - ticket_base;
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < K; ++i)
+        if (i < b.count && tile >= b.first_tile[i]) k = i;
+    scan_tile<AccT, OutT, F, THREADS>(b.f[k], b.n[k], b.out[k], b.total[k], write_total_at_n,
+                                      desc + b.first_tile[k], tile - b.first_tile[k], gen, status);
+}
+
 int scan_prepare(bt_context *ctx, int64_t ntiles, uint32_t *gen, uint32_t *ticket_base);   // bt_core.hip
 
 // out must have n (+1 if write_total_at_n) elements.  d_total may be null.
@@ -336,6 +373,47 @@ int device_exclusive_scan(bt_context *ctx, F f, int64_t n, OutT *out, AccT *d_to
         // note: `sums` returns to the pool here; the pool never hands memory to
         // another stream and all work is stream-ordered, so reuse is safe.
     }
+}
+
+// count <= K scans into 32-bit outputs in one launch (see scan_batch_kernel); same contract
+// per scan as device_exclusive_scan.
+template <class AccT, class OutT, class F, int K>
+int device_exclusive_scan_batch(bt_context *ctx, int count, const F *f, const int64_t *n,
+                                OutT *const *out, AccT *const *d_total, bool write_total_at_n)
+{
+    static_assert(std::is_integral<AccT>::value && sizeof(OutT) == 4, "32-bit outputs only");
+    ScanBatch<AccT, OutT, F, K> b{};
+    bool big = false;
+    for (int k = 0; k < count; ++k) {
+        if (n[k] <= 0) {
+            if (d_total && d_total[k])
+                BT_HIP_CHECK(hipMemsetAsync(d_total[k], 0, sizeof(AccT), ctx->stream));
+            if (write_total_at_n) BT_HIP_CHECK(hipMemsetAsync(out[k], 0, sizeof(OutT), ctx->stream));
+            continue;
+        }
+        const int c = b.count++;
+        b.f[c] = f[k]; b.n[c] = n[k]; b.out[c] = out[k];
+        b.total[c] = d_total ? d_total[k] : nullptr;
+        big = big || div_up(n[k], SCAN_TILE) > 2048;
+    }
+    if (b.count == 0) return BT_OK;
+    const int64_t tile = big ? (int64_t) 1024 * SCAN_ITEMS : SCAN_TILE;
+    int64_t ntiles = 0;
+    for (int c = 0; c < b.count; ++c) {
+        b.first_tile[c] = (uint32_t) ntiles;
+        ntiles += div_up(b.n[c], tile);
+    }
+    b.first_tile[b.count] = (uint32_t) ntiles;
+    uint32_t gen = 0, base = 0;
+    BT_CHECK(scan_prepare(ctx, ntiles, &gen, &base));
+    if (big)
+        scan_batch_kernel<AccT, OutT, F, 1024, K><<<(unsigned) ntiles, 1024, 0, ctx->stream>>>(
+            b, write_total_at_n, ctx->scan_desc, ctx->scan_ticket, base, gen, ctx->d_status);
+    else
+        scan_batch_kernel<AccT, OutT, F, SCAN_THREADS, K><<<(unsigned) ntiles, SCAN_THREADS, 0, ctx->stream>>>(
+            b, write_total_at_n, ctx->scan_desc, ctx->scan_ticket, base, gen, ctx->d_status);
+    BT_HIP_CHECK(hipGetLastError());
+    return BT_OK;
 }
 
 }  // namespace bt

@@ -1593,17 +1593,17 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     Buf<int32_t> l2_by_box;
     BT_CHECK(coll.starts.alloc(ctx->pool, B + 1));
     BT_CHECK(l2_by_box.alloc(ctx->pool, B + 1));
-    BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{d_coll_cnt}, B, coll.starts.get(),
-                                                      totals.get() + T_COLL, true)));
-    BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{d_l2_cnt}, B, l2_by_box.get(),
-                                                      totals.get() + T_L2, true)));
-    BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{l1_cnt.get()}, items_cap,
-                                                      l1_item.get(), totals.get() + T_L1, true)));
-    BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{l3_cnt.get()}, nflat,
-                                                      l3_item.get(), totals.get() + T_L3, true)));
-    if (st->with_extent)
-        BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{close_cnt.get()}, items_cap,
-                                                          close_item.get(), totals.get() + T_CLOSE, true)));
+    {
+        // one launch for the scans of all counts
+        ScanI32 fs[5] = {{d_coll_cnt}, {d_l2_cnt}, {l1_cnt.get()}, {l3_cnt.get()}, {close_cnt.get()}};
+        const int64_t ns[5] = {B, B, items_cap, nflat, items_cap};
+        int32_t *outs[5] = {coll.starts.get(), l2_by_box.get(), l1_item.get(), l3_item.get(),
+                            close_item.get()};
+        int64_t *tots[5] = {totals.get() + T_COLL, totals.get() + T_L2, totals.get() + T_L1,
+                            totals.get() + T_L3, totals.get() + T_CLOSE};
+        BT_CHECK((device_exclusive_scan_batch<int64_t, int32_t, ScanI32, 5>(
+            ctx, st->with_extent ? 5 : 4, fs, ns, outs, tots, true)));
+    }
     // list 3 per (level, target box): starts, and the compressed (non-empty) numbering.
     // A source level can only have entries if some target box sits on a coarser level (the
     // entries themselves may be boxes of any level: a box stands for the sources below it):
@@ -1876,11 +1876,20 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         {p.box_flags, p.target_boxes_mask, BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX},
         {p.box_flags, nullptr, BT_BOX_HAS_SOURCE_CHILD_BOXES | BT_BOX_HAS_TARGET_CHILD_BOXES}};
     Buf<int32_t> pos[NL];
-    for (int k = 0; k < NL; ++k) {
-        if (k == 1 && shared_tb) continue;
-        BT_CHECK(pos[k].alloc(ctx->pool, B + 1));
-        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, preds[k], B, pos[k].get(),
-                                                          (int32_t *) nullptr, true)));
+    {
+        // the positions of all lists in one launch
+        FlagPred fs[NL];
+        int64_t ns[NL];
+        int32_t *outs[NL];
+        int cnt = 0;
+        for (int k = 0; k < NL; ++k) {
+            if (k == 1 && shared_tb) continue;
+            BT_CHECK(pos[k].alloc(ctx->pool, B + 1));
+            fs[cnt] = preds[k]; ns[cnt] = B; outs[cnt] = pos[k].get();
+            ++cnt;
+        }
+        BT_CHECK((device_exclusive_scan_batch<int32_t, int32_t, FlagPred, NL>(
+            ctx, cnt, fs, ns, outs, (int32_t *const *) nullptr, true)));
     }
     // the mail block: [NL * (nlevels + 1) level starts | 4 flags | root centre (8 bytes an axis)]
     const size_t n_rows = (size_t) NL * (nlevels + 1);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Idle time between kernels of the last bench step in a rocprofv3 rocpd database.
 
-usage: timeline_gaps.py DB [first-kernel-substring] [min-gap-us]
+usage: timeline_gaps.py DB [first-kernel-substring] [min-gap-us] [--kernels] [--all]
 
 A step starts at the first launch whose name contains the given substring (default
 "bbox_") after a launch that does not; the last complete step is printed as a
@@ -40,6 +40,11 @@ def main(path, first="bbox_", min_gap_us="4"):
             if e_ - s_ >= 20e3:
                 print(f"  t={(s_ - t0) / 1e3:9.1f} us  {(e_ - s_) / 1e3:8.1f} us  "
                       f"{n_.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:70]}")
+    if "--all" in sys.argv:
+        print("every launch of the step:")
+        for k, (n_, s_, e_) in enumerate(step):
+            print(f"  {k:3d} t={(s_ - t0) / 1e3:9.1f} us  {(e_ - s_) / 1e3:8.1f} us  "
+                  f"{n_.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:70]}")
     small = sum(g for g in gaps if 0 < g < min_gap)
     print(f"gaps below {min_gap / 1e3:.0f} us: {small / 1e6:.3f} ms in "
           f"{sum(1 for g in gaps if 0 < g < min_gap)} places; "
