@@ -459,6 +459,19 @@ struct ScanI32 {
     __device__ int32_t operator()(int64_t i) const { return p[i]; }
 };
 
+struct HostWords { int32_t v[BT_MAX_LEVELS + 2]; };
+
+// out[0 .. n) = w; zeros[0 .. nzeros) = 0
+__global__ __launch_bounds__(128) void store_host_words_kernel(HostWords w, int n, int32_t *out,
+                                                               int32_t *zeros, int nzeros)
+{
+    int32_t x = 0;
+#pragma unroll
+    for (int i = 0; i < BT_MAX_LEVELS + 2; ++i) x = ((int) threadIdx.x == i) ? w.v[i] : x;
+    if ((int) threadIdx.x < n) out[threadIdx.x] = x;
+    if ((int) threadIdx.x < nzeros) zeros[threadIdx.x] = 0;
+}
+
 // ---- box lists by flag (T1, traversal.py:326-355) ---------------------------------------
 
 struct FlagPred {
@@ -1782,21 +1795,23 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
 
     // list 1: order by depth-first rank, insert the own-subtree blocks
     {
-        // [count | dst | src | len | tier bytes]: len and tier are cleared together
+        // [len | tier bytes | count | dst | src]: len and tier are cleared together, as one
+        // 16-byte-aligned range (a ragged memset is two or three fill kernels)
+        const int64_t clr_words = div_up(ntb + div_up(ntb, 4), 4) * 4;
         Buf<int32_t> jobbuf;
-        BT_CHECK(jobbuf.alloc(ctx->pool, 3 * ntb + 1 + div_up(ntb, 4) + 1));
+        BT_CHECK(jobbuf.alloc(ctx->pool, clr_words + 1 + 2 * ntb));
         static const bool l1_stats = [] { const char *e = getenv("BT_TRAV_STATS"); return e && atoi(e); }();
         Buf<int32_t> l1_dbg;
         if (l1_stats) {
             BT_CHECK(l1_dbg.alloc(ctx->pool, 16));
             BT_HIP_CHECK(hipMemsetAsync(l1_dbg.get(), 0, 64, ctx->stream));
         }
-        BlockJobs jobs{jobbuf.get(), jobbuf.get() + 1, jobbuf.get() + 1 + ntb,
-                       jobbuf.get() + 1 + 2 * ntb, l1_dbg.get()};
+        int32_t *jb = jobbuf.get() + clr_words;
+        BlockJobs jobs{jb, jb + 1, jb + 1 + ntb, jobbuf.get(), l1_dbg.get()};
         Buf<uint8_t> tier;
         Buf<int32_t> tier_present;
         tier.set_external((uint8_t *) (jobs.len + ntb), ntb);
-        BT_HIP_CHECK(hipMemsetAsync(jobs.len, 0, (size_t) ntb * 4 + (size_t) ntb, ctx->stream));
+        BT_HIP_CHECK(hipMemsetAsync(jobs.len, 0, (size_t) clr_words * 4, ctx->stream));
         if (int32_t *z = (int32_t *) bt::zero_alloc(ctx, 8)) {
             tier_present.set_external(z, 2);
         } else {
@@ -1863,11 +1878,23 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     // the number of listed boxes before the level's first box, which is what
     // traversal.py:361-392 + 2093-2096 compute).
     BT_CHECK(st->d_level_start_box_nrs.alloc(ctx->pool, nlevels + 1));
-    BT_HIP_CHECK(hipMemcpyAsync(st->d_level_start_box_nrs.get(), p.level_start_box_nrs,
-                                (size_t) (nlevels + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
     // (a fifth list, not part of the result: the boxes that have children, level by
     // level -- the colleague-row kernels run one group of lanes per such box)
     constexpr int NL = 5;
+    // the mail block: [NL * (nlevels + 1) level starts | 4 flags | root centre (8 bytes an axis)]
+    const size_t n_rows = (size_t) NL * (nlevels + 1);
+    const size_t mail_words = n_rows + 4 + 2 * BT_MAX_DIMS;
+    BT_CHECK(st->lev_starts.alloc(ctx->pool, (int64_t) mail_words));
+    int32_t *d_bad = st->lev_starts.get() + n_rows;
+    {
+        // the level starts travel as kernel arguments (a host-to-device copy of 50 bytes is
+        // a runtime blit with its bubbles either side); the same launch clears the flags
+        HostWords hw{};
+        if (nlevels + 1 > (int) (sizeof(hw.v) / sizeof(hw.v[0]))) return BT_ERR_INVALID;
+        for (int i = 0; i <= nlevels; ++i) hw.v[i] = p.level_start_box_nrs[i];
+        store_host_words_kernel<<<1, 128, 0, ctx->stream>>>(
+            hw, nlevels + 1, st->d_level_start_box_nrs.get(), d_bad, 4);
+    }
     const bool shared_tb = sat && !p.target_boxes_mask;     // target_boxes is source_boxes
     FlagPred preds[NL] = {
         {p.box_flags, p.source_boxes_mask, BT_BOX_IS_SOURCE_BOX},
@@ -1891,12 +1918,6 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         BT_CHECK((device_exclusive_scan_batch<int32_t, int32_t, FlagPred, NL>(
             ctx, cnt, fs, ns, outs, (int32_t *const *) nullptr, true)));
     }
-    // the mail block: [NL * (nlevels + 1) level starts | 4 flags | root centre (8 bytes an axis)]
-    const size_t n_rows = (size_t) NL * (nlevels + 1);
-    const size_t mail_words = n_rows + 4 + 2 * BT_MAX_DIMS;
-    BT_CHECK(st->lev_starts.alloc(ctx->pool, (int64_t) mail_words));
-    int32_t *d_bad = st->lev_starts.get() + n_rows;
-    BT_HIP_CHECK(hipMemsetAsync(d_bad, 0, 4 * sizeof(int32_t), ctx->stream));
     if (p.force_generic != 1)
         check_structure_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
             (int32_t) B, p.aligned_nboxes, p.box_parent_ids, p.box_child_ids, p.box_levels,
