@@ -277,6 +277,8 @@ def run(ncases, first_seed, verbose=True, aux=True):
                   f"trav={trav_kw}", flush=True)
             raise
         stats["ok"] += 1
+        if verbose and stats["ok"] % 500 == 0:
+            print(f"  ... {stats['ok']} ok after {time.time() - t0:.0f} s (seed {seed})", flush=True)
     if verbose:
         print(f"{ncases} cases from seed {first_seed}: {stats} in {time.time() - t0:.1f} s")
     return stats
