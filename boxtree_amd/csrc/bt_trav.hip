@@ -1597,7 +1597,10 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         BT_HIP_CHECK(hipMemsetAsync(dbg_counts.get(), 0, 16, ctx->stream));
         w.dbg_counts = dbg_counts.get();
     }
-    walk13_v2_kernel<T, D, true><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
+    if (a.targets_have_extent)
+        walk13_v2_kernel<T, D, true, true><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
+    else
+        walk13_v2_kernel<T, D, true, false><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
     BT_CHECK(tmark(ctx, st, "trav:walk (rows)"));
 
     // ---- starts of everything, totals in one transfer -------------------------------------------
@@ -1758,7 +1761,10 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         wf.close_cs = st->with_extent ? close_item.get() : nullptr;
         wf.l1_lists = c1.lists.get(); wf.l3_lists = st->l3_lists.get();
         wf.close_lists = st->with_extent ? cs.lists.get() : nullptr;
-        walk13_v2_kernel<T, D, false><<<nblk(novf), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, wf);
+        if (a.targets_have_extent)
+            walk13_v2_kernel<T, D, false, true><<<nblk(novf), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, wf);
+        else
+            walk13_v2_kernel<T, D, false, false><<<nblk(novf), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, wf);
     }
     BT_CHECK(tmark(ctx, st, "trav:lists 1+3 (final)"));
 

@@ -485,9 +485,14 @@ struct V2Emit {                        // list 1 / close list of one item
     }
 };
 
-template <class T, int D, bool ROWS>
+// TEXT: targets may have extents (the separation criteria in floating point: box centres
+// and the target's bounding box live in registers).  Without them the kernel needs a
+// quarter fewer registers, which is a wave more per SIMD for a kernel bound by the latency
+// of dependent loads.
+template <class T, int D, bool ROWS, bool TEXT>
 __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTree ft, V2Walk w)
 {
+    const bool targets_have_extent = TEXT && a.targets_have_extent;
     constexpr int C = 1 << D;
     constexpr int P = V2Dims<D>::P;
     int32_t item;
@@ -593,21 +598,25 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
     }
 
     // float data of the separation criteria with target extents (traversal.py:757-820)
-    T tc[D], ext_center[D], radii_vec[D];
-    T stickout_rad = 0;
+    // One centre and one radius per axis serve all criteria (registers decide how many
+    // waves fit): the box centre and the stick-out radius (static criteria), or centre and
+    // half widths of the targets' bounding box (precise criterion).
+    T cen[D], rad[D];
 #pragma unroll
-    for (int i = 0; i < D; ++i) { tc[i] = 0; ext_center[i] = 0; radii_vec[i] = 0; }
-    if (a.targets_have_extent) {
-        load_center(a, b, tc);
+    for (int i = 0; i < D; ++i) { cen[i] = 0; rad[i] = 0; }
+    if (targets_have_extent) {
         if (a.crit == BT_CRIT_STATIC_LINF || a.crit == BT_CRIT_STATIC_L2) {
-            stickout_rad = (1 + a.stick_out_factor) * level_to_rad(a.root_extent, tl);
+            load_center(a, b, cen);
+            const T stickout_rad = (1 + a.stick_out_factor) * level_to_rad(a.root_extent, tl);
+#pragma unroll
+            for (int i = 0; i < D; ++i) rad[i] = stickout_rad;
         } else {
 #pragma unroll
             for (int i = 0; i < D; ++i) {          // load_true_box_extent, :177-198
                 const T mn = a.tgt_bbox_min[i * a.aligned + b];
                 const T mx = a.tgt_bbox_max[i * a.aligned + b];
-                ext_center[i] = ((T) 0.5) * (mn + mx);
-                radii_vec[i] = ((T) 0.5) * (mx - mn);
+                cen[i] = ((T) 0.5) * (mn + mx);
+                rad[i] = ((T) 0.5) * (mx - mn);
             }
         }
     }
@@ -645,7 +654,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         T pcen[D];
 #pragma unroll
         for (int q = 0; q < D; ++q) pcen[q] = 0;
-        if (a.targets_have_extent) load_center(a, parent, pcen);
+        if (targets_have_extent) load_center(a, parent, pcen);
         while (go) {
             uint32_t raw = cw[0];
 #pragma unroll
@@ -665,7 +674,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                     in_list_1 = in_list_1 && rel[ax] >= -1 && rel[ax] <= (1 << k);
                 }
                 const int wl = tl + k;
-                if (a.targets_have_extent) {
+                if (targets_have_extent) {
                     const T child_rad = level_to_rad(a.root_extent, wl);
 #pragma unroll
                     for (int q = 0; q < D; ++q)
@@ -676,25 +685,15 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                     descend = (raw & CH_HSC) != 0;
                 } else {
                     bool meets = true;
-                    if (a.targets_have_extent) {
+                    if (targets_have_extent) {
                         const T source_rad = level_to_rad(a.root_extent, wl);
-                        if (a.crit == BT_CRIT_STATIC_LINF) {
+                        if (a.crit == BT_CRIT_STATIC_LINF || a.crit == BT_CRIT_PRECISE_LINF) {
                             T l_inf = 0;
 #pragma unroll
                             for (int q = 0; q < D; ++q) {
-                                T d = tc[q] - wc[q];
+                                T d = cen[q] - wc[q];
                                 d = (d < 0) ? -d : d;
-                                const T v = d - stickout_rad - source_rad;
-                                l_inf = (v > l_inf) ? v : l_inf;
-                            }
-                            meets = l_inf >= (2 - 8 * Eps<T>::v) * source_rad;
-                        } else if (a.crit == BT_CRIT_PRECISE_LINF) {
-                            T l_inf = 0;
-#pragma unroll
-                            for (int q = 0; q < D; ++q) {
-                                T d = ext_center[q] - wc[q];
-                                d = (d < 0) ? -d : d;
-                                const T v = d - radii_vec[q] - source_rad;
+                                const T v = d - rad[q] - source_rad;
                                 l_inf = (v > l_inf) ? v : l_inf;
                             }
                             meets = l_inf >= (2 - 8 * Eps<T>::v) * source_rad;
@@ -702,10 +701,10 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                             T l2sq = 0;
 #pragma unroll
                             for (int q = 0; q < D; ++q) {
-                                const T d = tc[q] - wc[q];
+                                const T d = cen[q] - wc[q];
                                 l2sq = l2sq + d * d;
                             }
-                            const T rhs = sqrt(l2sq) - sqrt((T) D) * stickout_rad - source_rad;
+                            const T rhs = sqrt(l2sq) - sqrt((T) D) * rad[0] - source_rad;
                             meets = ((2 - 8 * Eps<T>::v) * source_rad <= rhs);
                         }
                     }
@@ -746,7 +745,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             }
             if (popped && go) {
                 v2_load_children<C>(w.child_t, parent, cw);
-                if (a.targets_have_extent) load_center(a, parent, pcen);
+                if (targets_have_extent) load_center(a, parent, pcen);
             }
         }
     }

@@ -4,7 +4,7 @@
 usage: timeline_gaps.py DB [first-kernel-substring] [min-gap-us] [--kernels] [--all]
 
 A step starts at the first launch whose name contains the given substring (default
-"bbox_") after a launch that does not; the last complete step is printed as a
+"bbox_") with no such launch among the 20 before it; the last complete step is printed as a
 timeline: every gap of at least min-gap-us (default 4) with the kernels either side,
 and the totals (span, busy, idle, launches)."""
 import sqlite3
@@ -15,8 +15,9 @@ def main(path, first="bbox_", min_gap_us="4"):
     min_gap = float(min_gap_us) * 1e3
     db = sqlite3.connect(path)
     rows = db.execute("select name, start, end from kernels order by start").fetchall()
+    # (separate targets have a bounding-box pass of their own a few launches later)
     starts = [i for i, r in enumerate(rows)
-              if first in r[0] and (i == 0 or first not in rows[i - 1][0])]
+              if first in r[0] and not any(first in q[0] for q in rows[max(0, i - 20):i])]
     if len(starts) < 2:
         print("fewer than two steps found")
         return
