@@ -662,9 +662,6 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             const int32_t wb = (int32_t) (raw & CH_ID_MASK);
             bool descend = false;
             int rel[D];
-            T wc[D];                                    // centre of wb (target extents only)
-#pragma unroll
-            for (int q = 0; q < D; ++q) wc[q] = 0;
             if (wb && (raw & (CH_SRC | CH_HSC))) {
                 const int k = size + 1;                 // level of wb minus tl
                 bool in_list_1 = true;
@@ -674,12 +671,12 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                     in_list_1 = in_list_1 && rel[ax] >= -1 && rel[ax] <= (1 << k);
                 }
                 const int wl = tl + k;
-                if (targets_have_extent) {
-                    const T child_rad = level_to_rad(a.root_extent, wl);
-#pragma unroll
-                    for (int q = 0; q < D; ++q)
-                        wc[q] = v2_mbit<D>(mnr, q) ? pcen[q] + child_rad : pcen[q] - child_rad;
-                }
+                // centre of wb (target extents only): pcen +/- the radius of its level, per
+                // axis where it is needed -- not kept across the emits
+                const T child_rad = targets_have_extent ? level_to_rad(a.root_extent, wl) : (T) 0;
+                auto wc = [&](int q) -> T {
+                    return v2_mbit<D>(mnr, q) ? pcen[q] + child_rad : pcen[q] - child_rad;
+                };
                 if (in_list_1) {
                     if (raw & CH_SRC) emit1(wb);
                     descend = (raw & CH_HSC) != 0;
@@ -691,7 +688,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                             T l_inf = 0;
 #pragma unroll
                             for (int q = 0; q < D; ++q) {
-                                T d = cen[q] - wc[q];
+                                T d = cen[q] - wc(q);
                                 d = (d < 0) ? -d : d;
                                 const T v = d - rad[q] - source_rad;
                                 l_inf = (v > l_inf) ? v : l_inf;
@@ -701,7 +698,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                             T l2sq = 0;
 #pragma unroll
                             for (int q = 0; q < D; ++q) {
-                                const T d = cen[q] - wc[q];
+                                const T d = cen[q] - wc(q);
                                 l2sq = l2sq + d * d;
                             }
                             const T rhs = sqrt(l2sq) - sqrt((T) D) * rad[0] - source_rad;
@@ -723,10 +720,16 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             if (descend) {
                 stk[size * WALK_THREADS] = parent | (mnr << 28);
                 ++size;
+                if (targets_have_extent) {
+                    const T child_rad = level_to_rad(a.root_extent, tl + size);
+#pragma unroll
+                    for (int q = 0; q < D; ++q)
+                        pcen[q] = v2_mbit<D>(mnr, q) ? pcen[q] + child_rad : pcen[q] - child_rad;
+                }
                 parent = wb; mnr = 0;
                 v2_load_children<C>(w.child_t, parent, cw);
 #pragma unroll
-                for (int ax = 0; ax < D; ++ax) { prel[ax] = rel[ax]; pcen[ax] = wc[ax]; }
+                for (int ax = 0; ax < D; ++ax) prel[ax] = rel[ax];
                 continue;
             }
             bool popped = false;
