@@ -1653,8 +1653,15 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     Buf<int32_t> l4_cnt, raw4_cnt;
     BT_CHECK(l4_cnt.alloc(ctx->pool, c4.n));
     if (st->with_extent) BT_CHECK(raw4_cnt.alloc(ctx->pool, raw4.n));
-    list4_kernel<T, D, false><<<nblk(c4.n), 256, 0, ctx->stream>>>(
-        a, (int32_t) c4.n, l4_cnt.get(), nullptr, st->with_extent ? raw4_cnt.get() : nullptr, nullptr);
+    static const bool l4_float = [] { const char *e = getenv("BT_LIST4_FLOAT"); return e && atoi(e); }();
+    const bool l4_lattice = !st->with_extent && a.nway == 1 && !l4_float;
+    if (l4_lattice)
+        list4_lattice_kernel<D, false><<<nblk(c4.n), 256, 0, ctx->stream>>>(
+            (int32_t) c4.n, st->ttp_boxes.get(), cells, p.box_parent_ids, srccoll_rows.get(),
+            srccoll_cnt.get(), P, l4_cnt.get(), nullptr);
+    else
+        list4_kernel<T, D, false><<<nblk(c4.n), 256, 0, ctx->stream>>>(
+            a, (int32_t) c4.n, l4_cnt.get(), nullptr, st->with_extent ? raw4_cnt.get() : nullptr, nullptr);
     BT_CHECK(c4.starts.alloc(ctx->pool, c4.n + 1));
     BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, ScanI32{l4_cnt.get()}, c4.n, c4.starts.get(),
                                                       totals.get() + T_L4, true)));
@@ -1781,9 +1788,14 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     // list 4 (+ close, re-indexed to target boxes: _ListMerger, traversal.py:1259-1344)
     BT_CHECK(place_list(ctx, st, c4.lists, c4.total, pk ? &pk->from_sep_bigger_lists : nullptr));
     if (st->with_extent) BT_CHECK(raw4.lists.alloc(ctx->pool, raw4.total));
-    list4_kernel<T, D, true><<<nblk(c4.n), 256, 0, ctx->stream>>>(
-        a, (int32_t) c4.n, c4.starts.get(), c4.lists.get(),
-        st->with_extent ? raw4.starts.get() : nullptr, st->with_extent ? raw4.lists.get() : nullptr);
+    if (l4_lattice)
+        list4_lattice_kernel<D, true><<<nblk(c4.n), 256, 0, ctx->stream>>>(
+            (int32_t) c4.n, st->ttp_boxes.get(), cells, p.box_parent_ids, srccoll_rows.get(),
+            srccoll_cnt.get(), P, c4.starts.get(), c4.lists.get());
+    else
+        list4_kernel<T, D, true><<<nblk(c4.n), 256, 0, ctx->stream>>>(
+            a, (int32_t) c4.n, c4.starts.get(), c4.lists.get(),
+            st->with_extent ? raw4.starts.get() : nullptr, st->with_extent ? raw4.lists.get() : nullptr);
     if (st->with_extent) {
         Buf<int32_t> ttp_from_all;
         BT_CHECK(ttp_from_all.alloc(ctx->pool, B));

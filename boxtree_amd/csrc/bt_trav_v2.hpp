@@ -393,6 +393,56 @@ __global__ __launch_bounds__(256) void level_tables_kernel(DfsLevel d, int32_t d
     else coll_rows_v3_block<D, false>(t, parents, np, b_lo, b_hi, (int32_t) blockIdx.x - dfs_blocks);
 }
 
+// List 4 without extents (traversal.py:931-1146, no close lists), thread per target (or
+// target-parent) box: the source colleagues of the box's ancestors that touch the box's
+// parent but not the box.  A row entry carries the colleague's offset from the ancestor's
+// cell, so both tests are integer arithmetic on the box's own cell -- no centre is loaded
+// (the float form loads three coordinates per candidate).  With k = level(box) - level(
+// ancestor): the box relative to the colleague is (low k bits of its cell) - offset * 2^k
+// per axis, and boxes touch iff that is in [-1, 2^k] on every axis.
+template <int D, bool FILL>
+__global__ __launch_bounds__(256) void list4_lattice_kernel(int32_t n, const int32_t *ttp_boxes,
+        const ICell *cells, const int32_t *parent, const int32_t *srccoll_rows,
+        const int32_t *srccoll_cnt, int stride, int32_t *counts_or_starts, int32_t *lists)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t tgt = ttp_boxes[i];
+    const ICell tc = cells[tgt];
+    const int tl = (int) (tc.lf & 0xffu);
+    int32_t cnt = 0;
+    int32_t *out = FILL ? lists + counts_or_starts[i] : nullptr;
+    int32_t cur = tgt;
+    for (int k = 1; k < tl; ++k) {                      // ancestors on levels tl-1 .. 1
+        cur = parent[cur];
+        int64_t lt[D], lp[D];
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) {
+            lt[ax] = (int64_t) (tc.c[ax] & ((1u << k) - 1u));
+            lp[ax] = (int64_t) ((tc.c[ax] >> 1) & ((1u << (k - 1)) - 1u));
+        }
+        const int32_t *row = srccoll_rows + (int64_t) cur * stride;
+        const int nrow = srccoll_cnt[cur];
+        for (int j = 0; j < nrow; ++j) {
+            const uint32_t e = (uint32_t) row[j];
+            bool adj_box = true, adj_parent = true;
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) {
+                const int64_t off = v2_off(e, ax);
+                const int64_t rt = lt[ax] - off * ((int64_t) 1 << k);
+                const int64_t rp = lp[ax] - off * ((int64_t) 1 << (k - 1));
+                adj_box = adj_box && rt >= -1 && rt <= ((int64_t) 1 << k);
+                adj_parent = adj_parent && rp >= -1 && rp <= ((int64_t) 1 << (k - 1));
+            }
+            if (!adj_box && adj_parent) {
+                if (FILL) out[cnt] = (int32_t) (e & V2_ID_MASK);
+                ++cnt;
+            }
+        }
+    }
+    if (!FILL) counts_or_starts[i] = cnt;
+}
+
 // colleague CSR from the rows (codes stripped); LANES lanes per row
 template <int LANES>
 __global__ __launch_bounds__(256) void compact_coll_rows_v2_kernel(int64_t nrows, int stride,
