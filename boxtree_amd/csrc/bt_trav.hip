@@ -41,7 +41,7 @@ struct TravArgs {
     int32_t min_nsources_cumul;
     int targets_have_extent;
     int close_lists_exist;
-    int fast;                     // structure verified by check_structure_kernel
+    int fast;                     // structure verified by check_pack_kernel
     // lists built earlier
     const int32_t *target_boxes; int32_t ntarget_boxes;
     const int32_t *ttp_boxes; int32_t nttp;
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(256) void compact_kernel(FlagPred pr, int32_t n, co
 
 // What the host reads in the first wait of a traversal, in one block ("mail"):
 // rows[k][l] = pos[k][level_start_box_nrs[l]] for the five box lists (the number of listed
-// boxes before the level's first box), the flags of check_structure_kernel (written there),
+// boxes before the level's first box), the flags of check_pack_kernel (written there),
 // and the root's centre -- one kernel and one read instead of five gathers, a row copy and
 // five reads.
 struct BoxListMarks {
@@ -1936,10 +1936,19 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         BT_CHECK((device_exclusive_scan_batch<int32_t, int32_t, FlagPred, NL>(
             ctx, cnt, fs, ns, outs, (int32_t *const *) nullptr, true)));
     }
+    // the packed box records of the walks, and (unless the generic kernels are forced) the
+    // structure check, in one pass over the boxes
+    BT_CHECK(st->nodes.alloc(ctx->pool, B * (int64_t) sizeof(Node<T, D>)));
+    BT_CHECK(st->child_t.alloc(ctx->pool, B * (1 << D)));
     if (p.force_generic != 1)
-        check_structure_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
+        check_pack_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
             (int32_t) B, p.aligned_nboxes, p.box_parent_ids, p.box_child_ids, p.box_levels,
-            p.box_flags, (const T *) p.box_centers, (T) p.root_extent, (int *) d_bad);
+            p.box_flags, (const T *) p.box_centers, (T) p.root_extent, (int *) d_bad,
+            (Node<T, D> *) st->nodes.get(), st->child_t.get());
+    else
+        pack_nodes_kernel<T, D, true><<<nblk(B), 256, 0, ctx->stream>>>(
+            (int32_t) B, p.aligned_nboxes, (const T *) p.box_centers, p.box_levels, p.box_flags,
+            p.box_child_ids, (Node<T, D> *) st->nodes.get(), st->child_t.get());
     {
         BoxListMarks mk{};
         for (int k = 0; k < NL; ++k) mk.pos[k] = pos[(k == 1 && shared_tb) ? 0 : k].get();
@@ -1980,12 +1989,6 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         compact_lists_kernel<<<nblk(B), 256, 0, ctx->stream>>>(bl, (int32_t) B);
         st->target_boxes = shared_tb ? st->source_boxes.get() : st->target_boxes_buf.get();
     }
-
-    BT_CHECK(st->nodes.alloc(ctx->pool, B * (int64_t) sizeof(Node<T, D>)));
-    BT_CHECK(st->child_t.alloc(ctx->pool, B * (1 << D)));
-    pack_nodes_kernel<T, D, true><<<nblk(B), 256, 0, ctx->stream>>>(
-        (int32_t) B, p.aligned_nboxes, (const T *) p.box_centers, p.box_levels, p.box_flags,
-        p.box_child_ids, (Node<T, D> *) st->nodes.get(), st->child_t.get());
 
     TravArgs<T, D> a{};
     a.nodes = (const Node<T, D> *) st->nodes.get();

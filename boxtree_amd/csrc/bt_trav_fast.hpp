@@ -1,6 +1,6 @@
 // Fast list generation for trees whose boxes are numbered level-major with
 // every level in depth-first (Morton) order -- which is what the tree builder
-// produces and what check_structure_kernel verifies for
+// produces and what check_pack_kernel verifies for
 // any input tree.  Included by bt_trav.hip inside its anonymous namespace.
 //
 // Instead of walking from the root for every box (traversal.py:398-550), the
@@ -92,44 +92,69 @@ __device__ __forceinline__ int find_slot(const int32_t *child, int64_t aligned, 
 // bad[2]: (information) some target box has source boxes below it.
 // bad[1]: some box centre is not exactly "parent centre +/- root_extent / 2^(level+1)"
 //         (the lattice kernels of bt_trav_v2.hpp then must not be used).
+// The structure check and pack_nodes_kernel<.., true> (bt_geom.hpp) in one pass over the
+// boxes: both read the child table, the centres, levels and flags of a box.
 template <class T, int D>
-__global__ __launch_bounds__(256) void check_structure_kernel(int32_t nboxes, int64_t aligned,
+__global__ __launch_bounds__(256) void check_pack_kernel(int32_t nboxes, int64_t aligned,
         const int32_t *parent, const int32_t *child, const uint8_t *levels, const uint8_t *flags,
-        const T *centers, T root_extent, int *bad)
+        const T *centers, T root_extent, int *bad, Node<T, D> *nodes, int32_t *child_t)
 {
     constexpr int C = 1 << D;
     const int32_t b = blockIdx.x * 256 + threadIdx.x;
     if (b >= nboxes) return;
+    int32_t ch[C];
+#pragma unroll
+    for (int m = 0; m < C; ++m) ch[m] = child[(int64_t) m * aligned + b];
+    T cen[D];
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) cen[ax] = centers[(int64_t) ax * aligned + b];
+    const uint8_t lev = levels[b], fl = flags[b];
+
+    // ---- the packed records ------------------------------------------------------------
+    Node<T, D> n;
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) n.c[ax] = cen[ax];
+    n.lf = (uint32_t) lev | ((uint32_t) fl << 8);
+    nodes[b] = n;
     bool ok = true, geom_ok = true;
+#pragma unroll
     for (int m = 0; m < C; ++m) {
-        const int32_t c = child[(int64_t) m * aligned + b];
+        const int32_t c = ch[m];
+        uint32_t e = (uint32_t) c;
+        if (c > 0 && c < nboxes) {
+            const uint8_t cf = flags[c];
+            if (cf & BT_BOX_IS_SOURCE_BOX) e |= CH_SRC;
+            if (cf & BT_BOX_HAS_SOURCE_CHILD_BOXES) e |= CH_HSC;
+        }
+        child_t[(int64_t) b * C + m] = (int32_t) e;
         if (c != 0) ok = ok && c > b && c < nboxes && parent[c] == b;
     }
+
+    // ---- the structure check ---------------------------------------------------------------
+    // level-major numbering; the order within a level is free (level-restricted trees append
+    // force-split children at the end of their level: every order-sensitive step works on
+    // depth-first ranks); anything with sources below must be reachable through the flags;
+    // centres as tree_build_kernels.py:698-705 evaluates them
     if (b == 0) {
-        ok = ok && levels[0] == 0;
+        ok = ok && lev == 0;
     } else {
         const int32_t p = parent[b];
         ok = ok && p >= 0 && p < b;
         if (ok) {
-            ok = ok && levels[b] == levels[p] + 1;
+            ok = ok && lev == levels[p] + 1;
             const int slot = find_slot<D>(child, aligned, p, b);
             ok = ok && slot >= 0;
-            // level-major numbering; the order within a level is free (level-restricted
-            // trees append force-split children at the end of their level): every
-            // order-sensitive step works on depth-first ranks
-            ok = ok && levels[b - 1] <= levels[b];
-            // flag consistency: anything with sources below must be reachable
-            if (flags[b] & (BT_BOX_IS_SOURCE_BOX | BT_BOX_HAS_SOURCE_CHILD_BOXES))
+            ok = ok && levels[b - 1] <= lev;
+            if (fl & (BT_BOX_IS_SOURCE_BOX | BT_BOX_HAS_SOURCE_CHILD_BOXES))
                 ok = ok && (flags[p] & BT_BOX_HAS_SOURCE_CHILD_BOXES);
-            if (ok && levels[b] < 63) {
-                // tree_build_kernels.py:698-705, as the builder evaluates it
-                const T radius = (root_extent * 1 / (T) (1ull << (1 + (int) levels[b])));
+            if (ok && lev < 63) {
+                const T radius = (root_extent * 1 / (T) (1ull << (1 + (int) lev)));
 #pragma unroll
                 for (int ax = 0; ax < D; ++ax) {
                     const bool has_bit = (slot >> (D - 1 - ax)) & 1;
                     const T pc = centers[(int64_t) ax * aligned + p];
                     const T want = has_bit ? pc + radius : pc - radius;
-                    geom_ok = geom_ok && want == centers[(int64_t) ax * aligned + b];
+                    geom_ok = geom_ok && want == cen[ax];
                 }
             } else {
                 geom_ok = false;
@@ -138,11 +163,7 @@ __global__ __launch_bounds__(256) void check_structure_kernel(int32_t nboxes, in
     }
     if (!ok) atomicExch(bad, 1);
     if (!geom_ok) atomicExch(bad + 1, 1);
-    // a target box with sources below it (extents, or a TreeOfBoxes): list 1 then holds
-    // a whole block of depth-first ranks (BlockJobs)
-    // (one idempotent store at most per box and none once the flag is up: millions of
-    // same-address atomics serialise in L2 -- 3.9 ms on the 3.4*10^6 boxes of c4)
-    if ((flags[b] & BT_BOX_IS_TARGET_BOX) && (flags[b] & BT_BOX_HAS_SOURCE_CHILD_BOXES)
+    if ((fl & BT_BOX_IS_TARGET_BOX) && (fl & BT_BOX_HAS_SOURCE_CHILD_BOXES)
             && __hip_atomic_load(bad + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
         __hip_atomic_store(bad + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

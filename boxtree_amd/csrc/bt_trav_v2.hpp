@@ -2,7 +2,7 @@
 // well_sep_is_n_away == 1.  Included by bt_trav.hip inside its anonymous namespace.
 //
 // A tree whose box centres are exactly "parent centre +/- root_extent / 2^(level+1)"
-// (check_structure_kernel verifies it bit for bit) is a set of cells of a dyadic
+// (check_pack_kernel verifies it bit for bit) is a set of cells of a dyadic
 // lattice.  On such a tree the reference's adjacency predicate
 //     |c_t - c_s|_inf <= r_t + r_s + min(r_t, r_s)          (traversal.py:255-320)
 // separates lattice distances r_t + r_s (touching or overlapping) from
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         v2_load_children<C>(w.child_t, parent, cw);
         // With target extents the separation criteria need the centre of every candidate.
         // On this path the tree is a lattice, i.e. every stored centre IS "parent centre
-        // +/- level_to_rad(child level)" bit for bit (check_structure_kernel), so a child's
+        // +/- level_to_rad(child level)" bit for bit (check_pack_kernel), so a child's
         // centre is computed from the centre of the box being scanned; that centre is
         // loaded when the scan enters a colleague or returns to a box -- once per box
         // instead of once per child (a random 24-byte load each: 10^8 of them at c4).
