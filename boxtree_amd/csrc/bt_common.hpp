@@ -141,6 +141,9 @@ struct bt_context {
     // timing of the last bt_radix_sort call (HIP events on ctx->stream)
     float last_sort_pass_ms = 0.f;
     int last_sort_passes = 0;
+    // the next radix sort's histogram pass also copies its input keys here (consumed by
+    // that call): the histogram reads every key anyway
+    void *sort_copy_keys = nullptr;
     int64_t last_sort_n = 0;
     // same, for the last 64-bit-key sort (the tree build's main sort)
     float last_sort64_pass_ms = 0.f;

@@ -102,14 +102,17 @@ __device__ __forceinline__ W lb_load(const W *p)
 
 template <class KeyT, int MAXP>
 __global__ __launch_bounds__(256) void sort_hist_kernel(const KeyT *keys, uint32_t n,
-        int begin_bit, int npasses, uint32_t *ghist /* [npasses][RADIX] */)
+        int begin_bit, int npasses, uint32_t *ghist /* [npasses][RADIX] */,
+        KeyT *copy_out /* or null: a copy of the keys */)
 {
     __shared__ uint32_t s_h[MAXP * RADIX];
     for (int i = threadIdx.x; i < npasses * RADIX; i += 256) s_h[i] = 0;
     __syncthreads();
     const uint32_t stride = gridDim.x * 256;
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-        KeyT k = keys[i] >> begin_bit;
+        KeyT k = keys[i];
+        if (copy_out) copy_out[i] = k;
+        k >>= begin_bit;
 #pragma unroll
         for (int p = 0; p < MAXP; ++p) {
             if (p < npasses) {
@@ -349,6 +352,8 @@ int radix_sort_pairs_w(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32
     constexpr int MAXP = (int) sizeof(KeyT);   // at most one pass per key byte
 
     *in_b = false;
+    KeyT *copy_out = (KeyT *) ctx->sort_copy_keys;
+    ctx->sort_copy_keys = nullptr;
     ctx->last_sort_passes = 0;
     ctx->last_sort_pass_ms = 0.f;
     if (n >= ((int64_t) 1 << 31)) {
@@ -361,6 +366,10 @@ int radix_sort_pairs_w(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32
     }
     const int npasses = (end_bit - begin_bit + RADIX_BITS - 1) / RADIX_BITS;
     if (n == 0) return BT_OK;
+    if (copy_out && npasses == 0) {
+        set_error("radix sort: a key copy needs at least one pass");
+        return BT_ERR_INVALID;
+    }
     if (npasses == 0) {
         if (identity_vals) {
             set_error("radix sort: identity values need at least one pass");
@@ -400,7 +409,7 @@ int radix_sort_pairs_w(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32
         int64_t cap = (int64_t) ctx->num_cus * 8;
         if (blocks > cap) blocks = cap;
         sort_hist_kernel<KeyT, MAXP><<<(unsigned) blocks, 256, 0, ctx->stream>>>(
-            ka, (uint32_t) n, begin_bit, npasses, hist.get());
+            ka, (uint32_t) n, begin_bit, npasses, hist.get(), copy_out);
         sort_hist_scan_kernel<<<npasses, RADIX, 0, ctx->stream>>>(hist.get());
     }
     if (timed) BT_HIP_CHECK(hipEventRecord(ev[1], ctx->stream));

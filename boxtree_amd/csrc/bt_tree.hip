@@ -2913,13 +2913,14 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
             // windows 1.86 ms; grouping the (id, position) pairs by the id's top byte
             // first (one 32-bit onesweep pass that synthesises the positions) makes
             // the scatter local.
-            if (!fused) copy_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(N, st->ids, o->user_source_ids);
             int bits = 0;
             while (((int64_t) 1 << bits) < N) ++bits;
             Buf<uint32_t> grouped_ids, positions;
             BT_CHECK(grouped_ids.alloc(ctx->pool, N));
             BT_CHECK(positions.alloc(ctx->pool, N));
             bool in_b = false;
+            // (user_source_ids is a copy of the ids: the sort's histogram pass writes it)
+            if (!fused) ctx->sort_copy_keys = o->user_source_ids;
             BT_CHECK(radix_sort_pairs<uint32_t>(ctx, const_cast<uint32_t *>(final_ids), nullptr,
                                                 grouped_ids.get(), positions.get(), N, bits - 8, bits,
                                                 true, &in_b));
