@@ -30,7 +30,7 @@ P3 = vp * BT_MAX_DIMS
 PL = vp * BT_MAX_LEVELS
 
 
-ABI_VERSION = 2      # BT_ABI_VERSION of include/boxtree_hip.h
+ABI_VERSION = 3      # BT_ABI_VERSION of include/boxtree_hip.h
 
 
 class SortStats(ct.Structure):

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BT_ABI_VERSION 2
+#define BT_ABI_VERSION 3
 #define BT_MAX_DIMS 3
 #define BT_MAX_LEVELS 64       /* capacity of per-level arrays in the structs */
 
