@@ -1597,8 +1597,10 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         BT_HIP_CHECK(hipMemsetAsync(dbg_counts.get(), 0, 16, ctx->stream));
         w.dbg_counts = dbg_counts.get();
     }
+    // (with target extents the centre of the box being scanned has an LDS column as well)
+    const size_t cen_lds = (size_t) D * sizeof(T) * WALK_THREADS;
     if (a.targets_have_extent)
-        walk13_v2_kernel<T, D, true, true><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
+        walk13_v2_kernel<T, D, true, true><<<nblk(items_cap), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
     else
         walk13_v2_kernel<T, D, true, false><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
     BT_CHECK(tmark(ctx, st, "trav:walk (rows)"));
@@ -1769,7 +1771,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         wf.l1_lists = c1.lists.get(); wf.l3_lists = st->l3_lists.get();
         wf.close_lists = st->with_extent ? cs.lists.get() : nullptr;
         if (a.targets_have_extent)
-            walk13_v2_kernel<T, D, false, true><<<nblk(novf), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, wf);
+            walk13_v2_kernel<T, D, false, true><<<nblk(novf), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, wf);
         else
             walk13_v2_kernel<T, D, false, false><<<nblk(novf), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, wf);
     }

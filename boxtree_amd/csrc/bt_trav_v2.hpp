@@ -701,10 +701,15 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         // centre is computed from the centre of the box being scanned; that centre is
         // loaded when the scan enters a colleague or returns to a box -- once per box
         // instead of once per child (a random 24-byte load each: 10^8 of them at c4).
-        T pcen[D];
+        // (kept in an LDS column: three more coordinates in registers cost a wave of occupancy)
+        T *pcen = reinterpret_cast<T *>(s_walk_lds + (w.walk_cap + w.nlevels) * WALK_THREADS)
+            + threadIdx.x;
+        if (targets_have_extent) {
+            T pc0[D];
+            load_center(a, parent, pc0);
 #pragma unroll
-        for (int q = 0; q < D; ++q) pcen[q] = 0;
-        if (targets_have_extent) load_center(a, parent, pcen);
+            for (int q = 0; q < D; ++q) pcen[q * WALK_THREADS] = pc0[q];
+        }
         while (go) {
             uint32_t raw = cw[0];
 #pragma unroll
@@ -725,7 +730,8 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                 // axis where it is needed -- not kept across the emits
                 const T child_rad = targets_have_extent ? level_to_rad(a.root_extent, wl) : (T) 0;
                 auto wc = [&](int q) -> T {
-                    return v2_mbit<D>(mnr, q) ? pcen[q] + child_rad : pcen[q] - child_rad;
+                    const T pq = pcen[q * WALK_THREADS];
+                    return v2_mbit<D>(mnr, q) ? pq + child_rad : pq - child_rad;
                 };
                 if (in_list_1) {
                     if (raw & CH_SRC) emit1(wb);
@@ -774,7 +780,8 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                     const T child_rad = level_to_rad(a.root_extent, tl + size);
 #pragma unroll
                     for (int q = 0; q < D; ++q)
-                        pcen[q] = v2_mbit<D>(mnr, q) ? pcen[q] + child_rad : pcen[q] - child_rad;
+                        pcen[q * WALK_THREADS] = v2_mbit<D>(mnr, q) ? pcen[q * WALK_THREADS] + child_rad
+                                                                   : pcen[q * WALK_THREADS] - child_rad;
                 }
                 parent = wb; mnr = 0;
                 v2_load_children<C>(w.child_t, parent, cw);
@@ -798,7 +805,12 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             }
             if (popped && go) {
                 v2_load_children<C>(w.child_t, parent, cw);
-                if (targets_have_extent) load_center(a, parent, pcen);
+                if (targets_have_extent) {
+                    T pc0[D];
+                    load_center(a, parent, pc0);
+#pragma unroll
+                    for (int q = 0; q < D; ++q) pcen[q * WALK_THREADS] = pc0[q];
+                }
             }
         }
     }
