@@ -14,9 +14,20 @@ Workloads (BASELINE.json configs):
   c3c the clustered variant of c3: z -> sign(z)|z|^(1/4), renormalised
   c1  2D uniform, 10^5 points, max_particles_in_box=30 (the reference's CPU-runnable case)
   c4  3D 10^8 sources + 10^7 targets with target radii, stick_out_factor=0.25
+  c5  3D uniform, 1.25*10^8 points per rank drawn with default_rng(15 + rank): BASELINE
+      configs[4] (10^9 points over 8 GPUs); the default for --gpus N > 1
 For --gpus N > 1 every rank holds its own chunk of the workload (weak scaling):
 global bounding box by RCCL all-reduce, particles exchanged all-to-all by
-top-level Morton cell, then every rank builds the subtrees it owns.
+top-level Morton cell, then every rank builds the subtrees it owns, numbers them
+globally and builds the lists of its own boxes on a local essential tree.
+
+Launching.  Under a launcher (torch.distributed.run sets RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_*) the script is one rank.  Without one, ``--gpus N`` with N > 1 starts the N ranks
+itself (one child process per GPU, rendezvous on 127.0.0.1) and rank 0 prints the line.
+Ranks that have to share a GPU (fewer devices than ranks: a test setup, not a
+measurement) talk over gloo instead of RCCL, which refuses two ranks on one device.
+``--dry-run`` does the rendezvous and the particle exchange only (CPU tensors over gloo
+when there is no GPU): it checks the launcher, it measures nothing.
 """
 
 from __future__ import annotations
@@ -41,8 +52,19 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c3c", "c4", "c5"])
-    ap.add_argument("--n", type=int, default=None, help="override particle count per GPU")
+    ap.add_argument("--workload", default=None, choices=["c1", "c2", "c3", "c3c", "c4", "c5"],
+                    help="default: c3 on one GPU, c5 (BASELINE configs[4]) for --gpus N > 1")
+    ap.add_argument("--backend", default=None, choices=["nccl", "gloo"],
+                    help="collectives (default: nccl = RCCL; gloo if ranks share a GPU or there is none)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous + particle exchange only; no tree, no measurement")
+    ap.add_argument("--rng", default="numpy", choices=["numpy", "torch"],
+                    help="numpy: SURVEY 8d's host recipes (np.random.default_rng), uploaded; "
+                         "torch: the same distributions drawn on the device")
+    # (--points-per-gpu: `--n` is read as an abbreviation of its own options by
+    # torch.distributed.run's parser, even after the script name)
+    ap.add_argument("--n", "--points-per-gpu", dest="n", type=int, default=None,
+                    help="override particle count per GPU")
     ap.add_argument("--cpu-sample", type=int, default=16_000_000,
                     help="particles in the CPU-baseline sample (0 disables)")
     ap.add_argument("--mpb", type=int, default=None)
@@ -194,36 +216,136 @@ def cpu_baseline(workload, n_sample, mpb, reps=3):
     }
 
 
+WORKLOAD_NAMES = {
+    "c1": "2D uniform random, sources=targets",
+    "c2": "3D uniform random, sources=targets",
+    "c5": "3D uniform random, sources=targets",
+    "c3": "3D sphere-surface points, sources=targets",
+    "c3c": "3D sphere surface clustered towards the poles, sources=targets",
+    "c4": "3D uniform sources + 10% targets with radii",
+}
+WORKLOAD_N = {"c1": 10**5, "c2": 10**7, "c3": 10**8, "c3c": 10**8, "c4": 10**8, "c5": 125 * 10**6}
+
+
+def make_workload_uploaded(torch, device, workload, n, seed):
+    """SURVEY 8d's recipes as written (np.random.default_rng(seed) on the host), uploaded
+    one array at a time: the inputs the parity tests use at oracle size, at full size."""
+    n = n or WORKLOAD_N[workload]
+    w = make_workload_numpy(workload, n, seed)
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+    particles = [up(a) for a in w["particles"]]
+    w["particles"] = None
+    targets = None
+    if w["targets"] is not None:
+        targets = [up(a) for a in w["targets"]]
+    kw = {k: (up(v) if isinstance(v, np.ndarray) else v) for k, v in w["kw"].items()}
+    nn = len(particles[0]) + (len(targets[0]) if targets is not None else 0)
+    return dict(name=WORKLOAD_NAMES[workload], n=nn, particles=particles, targets=targets, kw=kw)
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n_ranks):
+    """`--gpus N` without a launcher's environment: start the N ranks (this script, one
+    child per GPU, LOCAL_RANK = RANK, rendezvous on 127.0.0.1), let rank 0's stdout through
+    (the single JSON line) and the other ranks' to stderr.  The first rank that fails takes
+    the others down (by their own PIDs)."""
+    import subprocess
+    port = free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks),
+                   LOCAL_WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), BOXTREE_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]],
+                                      env=env, stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    live = set(range(n_ranks))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py: rank {r} exited with status {code}; stopping the others",
+                      file=sys.stderr)
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     args = parse_args()
-    if args.mpb is None:
-        args.mpb = WORKLOAD_MPB.get(args.workload, 64)
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); "
+              f"reporting n_gpus = {world}", file=sys.stderr)
+    if args.workload is None:
+        args.workload = "c5" if world > 1 else "c3"
+    if args.mpb is None:
+        args.mpb = WORKLOAD_MPB.get(args.workload, 64)
     distributed = world > 1 or args.force_dist
+    have_gpu = torch.cuda.is_available()
+    if not have_gpu and not args.dry_run:
+        raise RuntimeError("bench.py needs a HIP device: the hot path has no CPU fallback "
+                           "(--dry-run checks the launcher and the exchange plumbing only)")
+    ndev = torch.cuda.device_count() if have_gpu else 0
+    shared_gpu = have_gpu and ndev < local_world
+    dev_index = local_rank % ndev if have_gpu else None
+    backend = args.backend or ("nccl" if have_gpu and not shared_gpu else "gloo")
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    device = torch.device("cuda", local_rank)
-    torch.cuda.set_device(device)
+        if have_gpu:
+            torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
+    device = torch.device("cuda", dev_index) if have_gpu else torch.device("cpu")
+    if have_gpu:
+        torch.cuda.set_device(device)
+
+    if args.dry_run:
+        return dry_run(args, torch, dist, device, world, rank, backend, distributed)
 
     from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
     from boxtree_amd import _lib
 
-    actx = HIPArrayContext(local_rank)
+    actx = HIPArrayContext(dev_index)
     tb = TreeBuilder(actx)
     tg = FMMTraversalBuilder(actx)
 
-    w = make_workload(torch, device, args.workload, args.n, 15 + rank)
+    if args.rng == "numpy":
+        w = make_workload_uploaded(torch, device, args.workload, args.n, 15 + rank)
+    else:
+        w = make_workload(torch, device, args.workload, args.n, 15 + rank)
     n_local = w["n"]
     build_kw = dict(w["kw"])
     particles, targets = w["particles"], w["targets"]
@@ -248,9 +370,8 @@ def main():
             from boxtree_amd.distributed import exchange_particles
             p_, t_, kw_, xs = exchange_particles(
                 actx, dist, particles, targets, build_kw, max_particles_in_box=args.mpb)
-            xinfo.update(exchange_bytes_sent_rank0=int(xs["bytes_sent"]),
-                         owned_particles_rank0=int(len(p_[0])))
-            last_exchange["events"] = xs.get("a2a_events", [])
+            last_exchange.update(bytes_sent=int(xs["bytes_sent"]), owned=int(len(p_[0])),
+                                 events=xs.get("a2a_events", []))
         tree, _ = tb(actx, p_, targets=t_, max_particles_in_box=args.mpb, **kw_)
         st = _lib.SortStats()
         actx.lib.bt_get_sort_stats(actx.handle, st)
@@ -307,9 +428,11 @@ def main():
     for _ in range(args.steps):
         st, times = step()
         sort_ms.append((st.full_pass_ms_avg, st.passes, st.n, st.first_pass_ms,
-                        st.first_pass_identity, st.full_passes))
+                        st.first_pass_identity, st.full_passes, st.bytes_per_element_per_pass,
+                        st.digit_bits))
     barrier()
     elapsed = time.perf_counter() - t0
+    actx.synchronize()                # a device-side failure of the last step raises here
     n_instrumented = 3
     actx.set_stage_timing(True)
     for _ in range(n_instrumented):
@@ -318,44 +441,49 @@ def main():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
     if distributed:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        nn = torch.tensor([n_local], dtype=torch.int64, device=device)
-        dist.all_reduce(nn)
-        n_total = int(nn.item())
+        xinfo.update(exchange_report(torch, dist, device, world, elapsed, n_local, last_exchange,
+                                     backend, shared_gpu))
+        elapsed = xinfo.pop("_elapsed_max")
+        n_total = xinfo.pop("_n_total")
     else:
         n_total = n_local
 
-    if rank == 0 and last_exchange.get("events"):
-        # payload all-to-all of the last step: every peer sits on its own xGMI link
-        a2a_ms = sum(e0.elapsed_time(e1) for e0, e1 in last_exchange["events"])
-        xinfo["exchange_a2a_ms_rank0"] = a2a_ms
-        if world > 1 and a2a_ms > 0:
-            xinfo["exchange_GBps_per_link_rank0"] = (
-                xinfo["exchange_bytes_sent_rank0"] / (world - 1) / (a2a_ms * 1e-3) / 1e9)
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = n_total * args.steps / elapsed
         pass_ms = float(np.mean([s[0] for s in sort_ms]))
         n_sorted = sort_ms[-1][2]
-        achieved = 24.0 * n_sorted / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
-        # HBM bytes per launch from the PMC counters (separate rocprofv3 --pmc passes,
-        # corrected as MI355X_MICROARCH.md prescribes; see profiles/*_pmc_onesweep.json)
-        traffic = None
+        # bytes a digit pass reads + writes per particle: 24 for (u64 key, u32 id) pairs, 16
+        # when the build packs the id under the path bits of one 64-bit word (point
+        # particles; DESIGN.md "packed keys")
+        pass_bytes = float(sort_ms[-1][6] or 24)
+        keys_only = pass_bytes == 16.0
+        achieved = pass_bytes * n_sorted / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0
+        # HBM bytes per launch from the PMC counters: they cannot be collected in this
+        # process (separate rocprofv3 --pmc passes, corrected as MI355X_MICROARCH.md
+        # prescribes: tools/pmc_onesweep.sh), so the figure is read from the committed
+        # summary of those passes -- when it was taken at this N -- and its file is named
+        traffic, traffic_source = None, None
         try:
             pmc_files = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
-                               if f.endswith("_pmc_onesweep.json"))
+                               if f.endswith("_pmc_onesweep_keys.json" if keys_only
+                                             else "_pmc_onesweep.json"))
             pmc = json.load(open(os.path.join(ROOT, "profiles", pmc_files[-1])))
             if int(pmc["n_pairs"]) == int(n_sorted):
                 traffic = pmc["traffic_bytes_per_launch"]
-        except (OSError, KeyError, ValueError):
-            pass
+                traffic_source = (f"profiles/{pmc_files[-1]} (separate rocprofv3 --pmc FETCH_SIZE / "
+                                  f"WRITE_SIZE passes over tools/sort_bench.py at n = {n_sorted}; "
+                                  "not measured in this run)")
+            else:
+                traffic_source = (f"null: profiles/{pmc_files[-1]} was taken at n = {pmc['n_pairs']}, "
+                                  f"this run sorts {n_sorted} pairs")
+        except (OSError, KeyError, ValueError, IndexError) as e:
+            traffic_source = f"null: no PMC summary under profiles/ ({type(e).__name__})"
         # what a plain device-to-device copy of the same byte count reaches on this GPU,
         # measured here: the practical ceiling the sort pass is to be read against
         copy_gbps = None
         try:
-            nbytes = int(12 * n_sorted)
+            nbytes = int(pass_bytes / 2 * n_sorted)
             src_b = torch.empty(nbytes, dtype=torch.uint8, device=device)
             dst_b = torch.empty_like(src_b)
             dst_b.copy_(src_b)
@@ -369,6 +497,8 @@ def main():
             del src_b, dst_b
         except RuntimeError:
             pass
+        rng_note = ("np.random.default_rng(15 + rank) on the host, uploaded (SURVEY 8d recipe)"
+                    if args.rng == "numpy" else "torch.Generator(15 + rank) on the device")
         out = {
             "metric": "particles/sec tree build+traversal, 3D 10^8 pts; radix-sort HBM GB/s vs peak",
             "value": value,
@@ -384,7 +514,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"{args.workload}: {w['name']}, {n_local} particles per GPU, "
-                            f"max_particles_in_box={args.mpb}, kind=adaptive",
+                            f"max_particles_in_box={args.mpb}, kind=adaptive; inputs: {rng_note}",
                 "nboxes": info.get("nboxes"), "nlevels": info.get("nlevels"),
                 "list1_entries": info.get("n_list1"), "list2_entries": info.get("n_list2"),
                 "parallelism": f"{world} rank(s), one per GPU, shard by top-level Morton cell",
@@ -392,16 +522,23 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "bt::onesweep_kernel<unsigned long, ..., false> (one 8-bit digit pass of "
-                          "the 64-bit Morton-key sort that reads and writes keys and values: "
-                          "24 bytes per pair; the first pass synthesises its values, moves "
-                          "20 bytes per pair and is reported apart)",
+                "kernel": (f"bt::onesweep_keys_kernel<..., {sort_ms[-1][7]}> (one {sort_ms[-1][7]}-bit "
+                           "digit pass of the tree build's sort: ONE 64-bit word per particle, "
+                           "Morton path bits over the user id, read and written once: 16 bytes "
+                           "per particle)" if keys_only else
+                           "bt::onesweep_kernel<unsigned long, ..., false> (one 8-bit digit pass of "
+                           "the 64-bit Morton-key sort that reads and writes keys and values: "
+                           "24 bytes per pair; the first pass synthesises its values, moves "
+                           "20 bytes per pair and is reported apart)"),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "algorithmic_bytes_per_launch": 24.0 * n_sorted,
+                "traffic_source": traffic_source,
+                "algorithmic_bytes_per_launch": pass_bytes * n_sorted,
+                "algorithmic_bytes_per_particle": pass_bytes,
+                "digit_bits": sort_ms[-1][7],
                 "device_copy_GBps_same_bytes": copy_gbps,
                 "avg_launch_ms": pass_ms,
                 "passes_per_sort": sort_ms[-1][1],
@@ -409,7 +546,7 @@ def main():
                 "first_pass": {
                     "synthesised_values": bool(sort_ms[-1][4]),
                     "avg_launch_ms": float(np.mean([s[3] for s in sort_ms])),
-                    "algorithmic_bytes_per_launch": (20.0 if sort_ms[-1][4] else 24.0) * n_sorted,
+                    "algorithmic_bytes_per_launch": (20.0 if sort_ms[-1][4] else pass_bytes) * n_sorted,
                 },
             },
             "stages_ms": {k: v / n_instrumented for k, v in stage_acc.items()},
@@ -437,14 +574,99 @@ def main():
                 "n_colleagues", "n_list1", "n_list2", "n_list3", "n_list4", "n_close")),
                 *trav_stages),
         }
-        if args.cpu_sample > 0:
+        # the CPU baseline is a one-GPU figure (rank 0 at N = 1): beside N ranks it would
+        # only lengthen the run
+        if args.cpu_sample > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, args.mpb)
-        # RCCL writes its banner through C stdio, which is block-buffered when stdout
-        # is a pipe: push it out first so that the JSON line is the last line
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-        sys.stdout.flush()
-        print(json.dumps(out), flush=True)
+        emit(out)
+    if distributed:
+        dist.destroy_process_group()
+
+
+def emit(out):
+    # RCCL writes its banner through C stdio, which is block-buffered when stdout
+    # is a pipe: push it out first so that the JSON line is the last line
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
+
+
+def exchange_report(torch, dist, device, world, elapsed, n_local, last_exchange, backend,
+                    shared_gpu):
+    """What the N ranks did, gathered on every rank (collective): the maximum of the timed
+    region, the total particle count, the bytes that crossed the links, the device time of
+    the payload all-to-all and the owned-particle imbalance after the exchange."""
+    a2a_ms = 0.0
+    if last_exchange.get("events"):
+        a2a_ms = float(sum(e0.elapsed_time(e1) for e0, e1 in last_exchange["events"]))
+    mine = torch.tensor([elapsed, float(n_local), float(last_exchange.get("bytes_sent", 0)),
+                         float(last_exchange.get("owned", n_local)), a2a_ms],
+                        dtype=torch.float64, device=device)
+    rows = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine)
+    t = torch.stack(rows).cpu().numpy()
+    owned = t[:, 3]
+    sent = t[:, 2]
+    a2a = t[:, 4]
+    rep = {
+        "_elapsed_max": float(t[:, 0].max()), "_n_total": int(round(t[:, 1].sum())),
+        "collectives": {
+            "backend": backend + (" (RCCL %s)" % ".".join(map(str, torch.cuda.nccl.version()))
+                                  if backend == "nccl" else
+                                  " (ranks share a GPU: not a scaling measurement)" if shared_gpu
+                                  else ""),
+            "ranks_in_group": int(dist.get_world_size()),
+        },
+        "exchange_bytes": int(round(sent.sum())),
+        "exchange_bytes_by_rank": [int(round(v)) for v in sent],
+        "exchange_a2a_ms_by_rank": [float(v) for v in a2a],
+        "owned_particles_by_rank": [int(round(v)) for v in owned],
+        "owned_particle_imbalance": float(owned.max() / max(owned.mean(), 1.0)),
+    }
+    if world > 1 and a2a.max() > 0:
+        # every peer sits on its own xGMI link: a rank's payload leaves over world-1 links
+        rep["exchange_GBps_per_link"] = float(
+            (sent / (world - 1) / np.maximum(a2a, 1e-9) / 1e6).min())
+        rep["exchange_GBps_per_gpu"] = float((sent / np.maximum(a2a, 1e-9) / 1e6).min())
+    return rep
+
+
+def dry_run(args, torch, dist, device, world, rank, backend, distributed):
+    """Launcher and exchange plumbing without the hot path: every rank draws a small chunk,
+    the ranks agree on the root box and the cell owners and trade particles; rank 0 prints
+    the line with "dry_run": true and no measurement."""
+    n = args.n or 20000
+    w = make_workload_numpy(args.workload, n, 15 + rank)
+    particles = [torch.from_numpy(a).to(device) for a in w["particles"]]
+    xinfo = {}
+    if distributed:
+        from boxtree_amd.distributed import exchange_particles
+        actx = None
+        if device.type == "cuda":
+            from boxtree_amd import HIPArrayContext
+            actx = HIPArrayContext(device.index)
+        newp, _, _, xs = exchange_particles(actx, dist, particles, None, {},
+                                            max_particles_in_box=args.mpb)
+        xinfo = exchange_report(torch, dist, device, world, 0.0, n,
+                                dict(bytes_sent=int(xs["bytes_sent"]), owned=int(len(newp[0])),
+                                     events=xs.get("a2a_events", [])), backend, False)
+        xinfo.pop("_elapsed_max")
+        n_total = xinfo.pop("_n_total")
+    else:
+        n_total = n
+    if rank == 0:
+        emit({
+            "metric": "particles/sec tree build+traversal, 3D 10^8 pts; radix-sort HBM GB/s vs peak",
+            "value": None, "unit": "particles/s", "n_gpus": world, "steps": 0, "warmup": 0,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64 coordinates, u64 Morton keys, int32 ids",
+            "data": "synthetic", "dry_run": True,
+            "config": {"workload": f"{args.workload}: {WORKLOAD_NAMES[args.workload]}, {n} "
+                                   f"particles per rank; DRY RUN: rendezvous + particle exchange "
+                                   f"only, device {device.type}",
+                       "particles_total": n_total, **xinfo},
+        })
     if distributed:
         dist.destroy_process_group()
 

@@ -30,14 +30,15 @@ P3 = vp * BT_MAX_DIMS
 PL = vp * BT_MAX_LEVELS
 
 
-ABI_VERSION = 3      # BT_ABI_VERSION of include/boxtree_hip.h
+ABI_VERSION = 4      # BT_ABI_VERSION of include/boxtree_hip.h
 
 
 class SortStats(ct.Structure):
     _fields_ = [("n", ct.c_int64), ("passes", ct.c_int32), ("pass_ms_avg", ct.c_float),
                 ("hist_ms", ct.c_float), ("total_ms", ct.c_float),
                 ("first_pass_ms", ct.c_float), ("first_pass_identity", ct.c_int32),
-                ("full_pass_ms_avg", ct.c_float), ("full_passes", ct.c_int32)]
+                ("full_pass_ms_avg", ct.c_float), ("full_passes", ct.c_int32),
+                ("bytes_per_element_per_pass", ct.c_int32), ("digit_bits", ct.c_int32)]
 
 
 class TreeParams(ct.Structure):
@@ -211,7 +212,8 @@ class TravPacked(ct.Structure):
 EXPORTED_SYMBOLS = [
     "bt_abi_version", "bt_create", "bt_destroy", "bt_trim", "bt_last_error_string",
     "bt_set_stream", "bt_set_stream_ordered", "bt_synchronize", "bt_set_stage_timing",
-    "bt_bbox", "bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32", "bt_get_sort_stats",
+    "bt_bbox", "bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32", "bt_radix_sort_u64_keys",
+    "bt_get_sort_stats",
     "bt_tree_build", "bt_tree_export", "bt_get_stage_times",
     "bt_traversal_build", "bt_traversal_export", "bt_traversal_build_packed", "bt_merge_csr_lists",
     "bt_peer_lists_build", "bt_area_query_build", "bt_csr_export", "bt_leaves_to_balls",
@@ -268,6 +270,7 @@ def load():
                             ct.POINTER(ct.c_double), ct.POINTER(ct.c_double)]
     for name in ("bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32"):
         getattr(lib, name).argtypes = [vp, vp, vp, vp, vp, ct.c_int64, ct.c_int, ct.c_int]
+    lib.bt_radix_sort_u64_keys.argtypes = [vp, vp, vp, ct.c_int64, ct.c_int, ct.c_int]
     lib.bt_get_sort_stats.argtypes = [vp, ct.POINTER(SortStats)]
     lib.bt_tree_build.argtypes = [vp, ct.POINTER(TreeParams), ct.POINTER(TreeSizes)]
     lib.bt_tree_export.argtypes = [vp, ct.POINTER(TreeArrays)]

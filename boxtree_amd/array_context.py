@@ -99,6 +99,14 @@ class HIPArrayContext:
         return torch.from_numpy(np.ascontiguousarray(ary)).to(self.device)
 
     def to_numpy(self, obj):
+        """Host copy of an array or a whole container.  Results are stream-ordered and a
+        builder may have returned before its last kernels ran: the first host read waits
+        for the library's stream and raises if the device reported a failure after the
+        call returned (callers that drop the builders' events still see it here)."""
+        self.synchronize()
+        return self._to_numpy(obj)
+
+    def _to_numpy(self, obj):
         torch = self.torch
         if obj is None or isinstance(obj, (int, float, str, bool, np.generic, np.dtype)):
             return obj
@@ -108,13 +116,13 @@ class HIPArrayContext:
             if obj.dtype.char == "O":
                 out = np.empty(obj.shape, dtype=object)
                 for i, a in np.ndenumerate(obj):
-                    out[i] = self.to_numpy(a)
+                    out[i] = self._to_numpy(a)
                 return out
             return obj
         if isinstance(obj, (list, tuple)):
-            return type(obj)(self.to_numpy(o) for o in obj)
+            return type(obj)(self._to_numpy(o) for o in obj)
         if dataclasses.is_dataclass(obj):
-            return obj._map_arrays(self.to_numpy)
+            return obj._map_arrays(self._to_numpy)
         return obj
 
     def freeze(self, obj):

@@ -29,6 +29,7 @@ struct AqState {
 
 void bt_free_aq_state(bt_context *ctx)
 {
+    bt::CallScope bt_call_scope_(ctx);
     delete ctx->aq;
     ctx->aq = nullptr;
 }
@@ -515,6 +516,7 @@ extern "C" {
 
 int bt_peer_lists_build(bt_context *ctx, const bt_aq_tree *tree, int64_t *n_entries)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || !n_entries) { set_error("bt_peer_lists_build: NULL argument"); return BT_ERR_INVALID; }
     BT_CHECK(check_tree_args(tree, "bt_peer_lists_build"));
     BT_HIP_CHECK(hipSetDevice(ctx->device));
@@ -528,6 +530,7 @@ int bt_area_query_build(bt_context *ctx, const bt_aq_tree *tree, const int32_t *
                         const void *const *ball_centers, const void *ball_radii,
                         int64_t *n_entries)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || !n_entries || !peer_list_starts || nballs < 0 || nballs > INT32_MAX
             || (nballs > 0 && (!ball_centers || !ball_radii))) {
         set_error("bt_area_query_build: invalid argument");
@@ -543,6 +546,7 @@ int bt_area_query_build(bt_context *ctx, const bt_aq_tree *tree, const int32_t *
 
 int bt_csr_export(bt_context *ctx, int32_t *starts, int32_t *lists)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || !ctx->aq) { set_error("bt_csr_export: nothing was built"); return BT_ERR_INVALID; }
     AqState *st = ctx->aq;
     BT_HIP_CHECK(hipSetDevice(ctx->device));
@@ -562,6 +566,7 @@ int bt_space_invader_query(bt_context *ctx, const bt_aq_tree *tree,
                            int64_t nballs, const void *const *ball_centers,
                            const void *ball_radii, float *out)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || !out || !peer_list_starts || nballs < 0
             || (nballs > 0 && (!ball_centers || !ball_radii))) {
         set_error("bt_space_invader_query: invalid argument");
@@ -580,6 +585,7 @@ int bt_leaves_to_balls(bt_context *ctx, int64_t nballs, int64_t nboxes,
                        const int32_t *leaves_near_ball_lists, int64_t n_entries,
                        int32_t *balls_near_box_starts, int32_t *balls_near_box_lists)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nballs < 0 || nboxes < 1 || n_entries < 0 || !balls_near_box_starts
             || !leaves_near_ball_starts || (n_entries > 0 && (!leaves_near_ball_lists
                                                                 || !balls_near_box_lists))) {

@@ -58,6 +58,8 @@ struct DeviceStatus {
     int pad;
 };
 
+constexpr int STATUS_SLOTS = 16;
+
 // Caching device allocator: blocks are kept until bt_destroy / trim.  All
 // allocations are 256-byte aligned (hipMalloc guarantees it).
 class Pool {
@@ -133,7 +135,8 @@ struct bt_context {
     int num_cus = 256;
     bt::Pool pool;
     bt::DeviceStatus *d_status = nullptr;     // device
-    bt::DeviceStatus *h_status = nullptr;     // pinned host mirror
+    bt::DeviceStatus *h_status = nullptr;     // pinned host mirror: STATUS_SLOTS of them, one per
+                                              // status read queued since the last wait
     TreeState *tree = nullptr;
     TravState *trav = nullptr;
     AqState *aq = nullptr;
@@ -159,7 +162,10 @@ struct bt_context {
     uint32_t scan_gen = 0;
     // sort timing is resolved lazily (bt_get_sort_stats): events of the last sort
     void *sort_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    int sort_ev_passes = 0, sort_ev_first_identity = 0, sort_ev_key_bytes = 0;
+    int sort_ev_passes = 0, sort_ev_first_identity = 0;
+    int sort_ev_key_bytes = 0;       // bytes per element a pass reads (and writes): 12 = (u64, u32)
+                                     // pairs, 8 = keys only (the id packed into the key)
+    int sort_ev_digit_bits = 8;
     int64_t sort_ev_n = 0;
     bool sort_ev_pending = false;
     // statistics of the last build (host-side counters)
@@ -168,12 +174,13 @@ struct bt_context {
     // the copies waiting for the next synchronisation
     char *h_ring = nullptr;
     size_t h_ring_cap = 0, h_ring_used = 0;
-    struct PendingRead { void *dst; const char *src; size_t bytes; };
+    struct PendingRead { void *dst; const char *src; size_t bytes; uint64_t seq; bool persistent; };
+    uint64_t read_seq = 0;
     std::vector<PendingRead> pending_reads;
     // stream-ordered results (bt_set_stream_ordered): calls end with finish_call(), which
     // queues the status read instead of waiting for it; sync_stream examines it later
     bool stream_ordered = false;
-    bool status_inflight = false;
+    int status_inflight = 0;         // status reads queued since the last wait (slots of h_status)
     // a block of zeroed device memory for the small counters and flags of a call
     // (bt::zero_alloc): one memset per API call instead of one per counter
     char *zero_block = nullptr;
@@ -189,7 +196,27 @@ int reset_status(bt_context *ctx);
 // sync_stream(ctx).  hipMemcpyAsync into pageable memory blocks the host for a staged copy
 // (30-80 us of idle GPU per read, measured); here the copy goes to pinned memory as a queued
 // command and any number of reads share one wait.
-int d2h(bt_context *ctx, void *host_dst, const void *dev_src, size_t bytes);
+// `persistent`: the destination outlives the API call (context-owned); all other destinations
+// are forgotten when the API call that queued them returns (CallScope), so an error exit
+// between a d2h and its wait cannot make a later wait write into a dead stack frame.
+int d2h(bt_context *ctx, void *host_dst, const void *dev_src, size_t bytes, bool persistent = false);
+// First line of every extern "C" entry point that takes a context.
+struct CallScope {
+    bt_context *ctx;
+    uint64_t seq0;
+    explicit CallScope(bt_context *c) : ctx(c), seq0(c ? c->read_seq : 0) {}
+    CallScope(const CallScope &) = delete;
+    CallScope &operator=(const CallScope &) = delete;
+    ~CallScope() {
+        if (!ctx || ctx->pending_reads.empty()) return;
+        auto &v = ctx->pending_reads;
+        size_t k = 0;
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i].persistent || v[i].seq < seq0) v[k++] = v[i];
+        v.resize(k);
+    }
+};
+void drop_pending_reads(bt_context *ctx);   // error exits: wait, forget queued reads and verdicts
 int sync_stream(bt_context *ctx);    // hipStreamSynchronize + delivery of the pending reads
                                      // + the verdict on a status read queued by finish_call
 // Zeroed device memory for the duration of the current API call (256-byte aligned), or

@@ -166,7 +166,7 @@ static int copy_to_pinned(bt_context *ctx, void *pinned_dst, const void *dev_src
     return BT_OK;
 }
 
-int d2h(bt_context *ctx, void *host_dst, const void *dev_src, size_t bytes)
+int d2h(bt_context *ctx, void *host_dst, const void *dev_src, size_t bytes, bool persistent)
 {
     if (bytes == 0) return BT_OK;
     const size_t need = (bytes + 15) & ~(size_t) 15;
@@ -179,21 +179,21 @@ int d2h(bt_context *ctx, void *host_dst, const void *dev_src, size_t bytes)
     char *slot = ctx->h_ring + ctx->h_ring_used;
     ctx->h_ring_used += need;
     BT_CHECK(copy_to_pinned(ctx, slot, dev_src, bytes));
-    ctx->pending_reads.push_back({host_dst, slot, bytes});
+    ctx->pending_reads.push_back({host_dst, slot, bytes, ctx->read_seq++, persistent});
     return BT_OK;
 }
 
-static int status_verdict(bt_context *ctx)
+static int status_verdict(const DeviceStatus *st)
 {
-    if (ctx->h_status->lookback_timeout) {
+    if (st->lookback_timeout) {
         set_error("radix sort: decoupled look-back spin bound exceeded");
         return BT_ERR_INTERNAL;
     }
-    if (ctx->h_status->internal) {
-        set_error("device-side consistency check failed (code %d)", ctx->h_status->internal);
+    if (st->internal) {
+        set_error("device-side consistency check failed (code %d)", st->internal);
         return BT_ERR_INTERNAL;
     }
-    if (ctx->h_status->max_levels) {
+    if (st->max_levels) {
         set_error("Level count exceeded the depth addressable by the 64-bit Morton key "
                   "(a large number of particles is indistinguishable at that depth).");
         return BT_ERR_MAX_LEVELS;
@@ -207,11 +207,35 @@ int sync_stream(bt_context *ctx)
     for (auto &r : ctx->pending_reads) memcpy(r.dst, r.src, r.bytes);
     ctx->pending_reads.clear();
     ctx->h_ring_used = 0;
+    // every status read queued since the last wait has its own slot: the first failure
+    // (in the order the calls were made) is the one reported
+    const int n = ctx->status_inflight;
+    ctx->status_inflight = 0;
     BT_HIP_CHECK(e);
-    if (ctx->status_inflight) {
-        ctx->status_inflight = false;
-        return status_verdict(ctx);
+    for (int i = 0; i < n; ++i) {
+        int v = status_verdict(&ctx->h_status[i]);
+        if (v != BT_OK) return v;
     }
+    return BT_OK;
+}
+
+// An error exit between a d2h() and its wait must not leave destinations queued: they are
+// mostly locals of the frame that is being left.
+void drop_pending_reads(bt_context *ctx)
+{
+    (void) hipStreamSynchronize(ctx->stream);
+    ctx->pending_reads.clear();
+    ctx->h_ring_used = 0;
+    ctx->status_inflight = 0;
+}
+
+static int queue_status_read(bt_context *ctx)
+{
+    // a slot per queued read; a caller that makes more calls than there are slots without
+    // ever waiting gets the verdicts so far first
+    if (ctx->status_inflight >= STATUS_SLOTS) BT_CHECK(sync_stream(ctx));
+    BT_CHECK(copy_to_pinned(ctx, &ctx->h_status[ctx->status_inflight], ctx->d_status, sizeof(DeviceStatus)));
+    ++ctx->status_inflight;
     return BT_OK;
 }
 
@@ -236,9 +260,7 @@ int zero_begin(bt_context *ctx)
 int finish_call(bt_context *ctx)
 {
     if (!ctx->stream_ordered) return check_status(ctx);
-    BT_CHECK(copy_to_pinned(ctx, ctx->h_status, ctx->d_status, sizeof(DeviceStatus)));
-    ctx->status_inflight = true;
-    return BT_OK;
+    return queue_status_read(ctx);
 }
 
 int reset_status(bt_context *ctx)
@@ -249,8 +271,7 @@ int reset_status(bt_context *ctx)
 
 int check_status(bt_context *ctx)
 {
-    BT_CHECK(copy_to_pinned(ctx, ctx->h_status, ctx->d_status, sizeof(DeviceStatus)));
-    ctx->status_inflight = true;
+    BT_CHECK(queue_status_read(ctx));
     return sync_stream(ctx);
 }
 
@@ -299,14 +320,15 @@ int bt_create(int device, void *hip_stream, bt_context **out)
     if (e == hipSuccess) {
         ctx->d_status = (bt::DeviceStatus *) ctx->zero_block;
         ctx->zero_used = 256;
-        e = hipHostMalloc((void **) &ctx->h_status, sizeof(bt::DeviceStatus), hipHostMallocDefault);
+        e = hipHostMalloc((void **) &ctx->h_status, bt::STATUS_SLOTS * sizeof(bt::DeviceStatus),
+                          hipHostMallocDefault);
     }
     if (e == hipSuccess) {
         ctx->h_ring_cap = 256 << 10;
         e = hipHostMalloc((void **) &ctx->h_ring, ctx->h_ring_cap, hipHostMallocDefault);
     }
     if (e != hipSuccess) { bt_destroy(ctx); BT_HIP_CHECK(e); }
-    memset(ctx->h_status, 0, sizeof(bt::DeviceStatus));
+    memset(ctx->h_status, 0, bt::STATUS_SLOTS * sizeof(bt::DeviceStatus));
     int s = bt::reset_status(ctx);
     if (s != BT_OK) { bt_destroy(ctx); return s; }
     {
@@ -348,6 +370,7 @@ void bt_destroy(bt_context *ctx)
 
 int bt_set_stream(bt_context *ctx, void *hip_stream)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx) return BT_ERR_INVALID;
     if (ctx->stream == (hipStream_t) hip_stream && !ctx->own_stream) return BT_OK;
     BT_HIP_CHECK(hipSetDevice(ctx->device));
@@ -359,6 +382,7 @@ int bt_set_stream(bt_context *ctx, void *hip_stream)
 
 int bt_set_stream_ordered(bt_context *ctx, int on)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx) return BT_ERR_INVALID;
     ctx->stream_ordered = on != 0;
     return BT_OK;
@@ -366,6 +390,7 @@ int bt_set_stream_ordered(bt_context *ctx, int on)
 
 int bt_set_stage_timing(bt_context *ctx, int on)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx) return BT_ERR_INVALID;
     ctx->stage_timing = on != 0;
     return BT_OK;
@@ -373,6 +398,7 @@ int bt_set_stage_timing(bt_context *ctx, int on)
 
 int bt_synchronize(bt_context *ctx)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx) return BT_ERR_INVALID;
     BT_HIP_CHECK(hipSetDevice(ctx->device));
     return bt::sync_stream(ctx);
@@ -380,6 +406,7 @@ int bt_synchronize(bt_context *ctx)
 
 int bt_trim(bt_context *ctx)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx) return BT_ERR_INVALID;
     BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     bt_free_tree_state(ctx);

@@ -142,6 +142,7 @@ int bt_fmm_box_particle_sums(bt_context *ctx, int64_t n, const int32_t *boxes,
                              const int32_t *box_starts, const int32_t *box_counts,
                              const double *values, double *out, int accumulate)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || n < 0 || !box_starts || !box_counts || !out || (n > 0 && !values)) {
         set_error("bt_fmm_box_particle_sums: invalid argument");
         return BT_ERR_INVALID;
@@ -159,6 +160,7 @@ int bt_fmm_csr_sum(bt_context *ctx, int64_t nrows, const int32_t *starts, const 
                    const double *box_values, const int32_t *row_boxes, double *out,
                    int scatter_add)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nrows < 0 || !starts || !box_values || !out || (scatter_add && !row_boxes)) {
         set_error("bt_fmm_csr_sum: invalid argument");
         return BT_ERR_INVALID;
@@ -188,6 +190,7 @@ int bt_fmm_box_to_particles(bt_context *ctx, int64_t nrows, const int32_t *row_b
                             const double *row_values, const double *box_values, double *pot,
                             int accumulate)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nrows < 0 || !box_starts || !box_counts || !pot || (nrows > 0 && !row_boxes)
             || (!row_values && !box_values)) {
         set_error("bt_fmm_box_to_particles: invalid argument");
@@ -206,6 +209,7 @@ int bt_fmm_tree_sweep(bt_context *ctx, int64_t n, const int32_t *boxes, const in
                       int64_t aligned_nboxes, int nchildren, const int32_t *parent_ids,
                       double *box_values)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || n < 0 || !box_values || (n > 0 && !boxes) || (!child_ids && !parent_ids)) {
         set_error("bt_fmm_tree_sweep: invalid argument");
         return BT_ERR_INVALID;
@@ -232,6 +236,7 @@ int bt_translation_classes(bt_context *ctx, int dims, int coord_kind, int64_t n_
                            const uint8_t *box_levels, int well_sep_is_n_away, int per_level,
                            int nclasses, int32_t *classes, int32_t *class_is_used, int32_t *error)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || dims < 1 || dims > 3 || n_entries < 0 || nttp < 0 || nclasses < 1
             || !from_sep_siblings_starts || !box_centers || !box_levels || !class_is_used || !error
             || (n_entries > 0 && (!from_sep_siblings_lists || !target_or_target_parent_boxes

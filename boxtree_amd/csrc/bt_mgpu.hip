@@ -95,6 +95,7 @@ struct MgpuState {
 
 void bt_free_mgpu_state(bt_context *ctx)
 {
+    bt::CallScope bt_call_scope_(ctx);
     delete ctx->mgpu;
     ctx->mgpu = nullptr;
 }
@@ -172,6 +173,7 @@ int bt_mgpu_plan(int dims, int top_level, int64_t max_particles_in_box, int nran
 int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
                      const bt_mgpu_params *p, bt_mgpu_shard *out)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || !rccl_comm || !p || !out || rank < 0 || rank >= nranks) {
         set_error("bt_mgpu_exchange: invalid argument");
         return BT_ERR_INVALID;
@@ -179,6 +181,11 @@ int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
     if (p->dims < 1 || p->dims > 3 || (p->coord_kind != BT_F32 && p->coord_kind != BT_F64) || p->n < 0) {
         set_error("bt_mgpu_exchange: bad dims / coord_kind / n");
         return BT_ERR_INVALID;
+    }
+    if (nranks > BT_MGPU_MAX_RANKS) {
+        set_error("bt_mgpu_exchange: %d ranks; the one-sweep partition supports at most %d owners",
+                  nranks, BT_MGPU_MAX_RANKS);
+        return BT_ERR_UNSUPPORTED;
     }
     if (!nccl().ok) {
         set_error("bt_mgpu_exchange: librccl.so could not be loaded");
@@ -281,17 +288,24 @@ int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
     if (biggest > 0) {
         for (int64_t j = 0; j < rounds; ++j) {
             BT_NCCL_CHECK(nc.GroupStart());
-            for (int peer = 0; peer < nranks; ++peer) {
-                if (peer == rank) continue;
-                const int64_t s0 = cut(send_counts[peer], j), s1 = cut(send_counts[peer], j + 1);
-                const int64_t r0 = cut(recv_counts[peer], j), r1 = cut(recv_counts[peer], j + 1);
-                if (s1 > s0)
-                    BT_NCCL_CHECK(nc.Send(send.get() + (s_off[peer] + s0) * rec, (size_t) ((s1 - s0) * rec),
-                                          NCCL_UINT8, peer, comm, stream));
-                if (r1 > r0)
-                    BT_NCCL_CHECK(nc.Recv(ms->points.get() + (r_off[peer] + r0) * rec,
-                                          (size_t) ((r1 - r0) * rec), NCCL_UINT8, peer, comm, stream));
-            }
+            // (a failure inside the group still closes it: RCCL keeps an open group per thread)
+            int group_status = BT_OK;
+            auto in_group = [&]() -> int {
+                for (int peer = 0; peer < nranks; ++peer) {
+                    if (peer == rank) continue;
+                    const int64_t s0 = cut(send_counts[peer], j), s1 = cut(send_counts[peer], j + 1);
+                    const int64_t r0 = cut(recv_counts[peer], j), r1 = cut(recv_counts[peer], j + 1);
+                    if (s1 > s0)
+                        BT_NCCL_CHECK(nc.Send(send.get() + (s_off[peer] + s0) * rec, (size_t) ((s1 - s0) * rec),
+                                              NCCL_UINT8, peer, comm, stream));
+                    if (r1 > r0)
+                        BT_NCCL_CHECK(nc.Recv(ms->points.get() + (r_off[peer] + r0) * rec,
+                                              (size_t) ((r1 - r0) * rec), NCCL_UINT8, peer, comm, stream));
+                }
+                return BT_OK;
+            };
+            group_status = in_group();
+            if (group_status != BT_OK) { (void) nc.GroupEnd(); return group_status; }
             BT_NCCL_CHECK(nc.GroupEnd());
         }
     }

@@ -165,6 +165,7 @@ int bt_filter_targets_user_order(bt_context *ctx, int64_t nboxes, int64_t ntarge
                                  int32_t *target_starts, int32_t *target_lists,
                                  int64_t *nfiltered)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nboxes < 1 || ntargets < 0 || ntargets > INT32_MAX || !box_target_starts
             || !box_target_counts_nonchild || !target_starts || !nfiltered
             || (ntargets > 0 && (!user_order_flags || !sorted_target_ids || !target_lists))) {
@@ -197,6 +198,7 @@ int bt_filter_targets_tree_order(bt_context *ctx, int64_t nboxes, int64_t ntarge
                                  int32_t *box_target_counts_nonchild_filtered,
                                  int32_t *unfiltered_from_filtered, int64_t *nfiltered)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nboxes < 1 || ntargets < 0 || ntargets > INT32_MAX || !box_target_starts
             || !box_target_counts_nonchild || !box_target_starts_filtered
             || !box_target_counts_nonchild_filtered || !nfiltered
@@ -234,6 +236,7 @@ int bt_link_point_sources(bt_context *ctx, int64_t nsources, int64_t nboxes,
                           int32_t *box_point_source_counts_nonchild,
                           int32_t *box_point_source_counts_cumul)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nsources < 1 || nboxes < 1 || npoint_sources < 0 || npoint_sources > INT32_MAX
             || !point_source_starts || !user_source_ids || !box_source_starts
             || !box_source_counts_nonchild || !box_source_counts_cumul

@@ -208,6 +208,7 @@ int bt_dfs_order(bt_context *ctx, int nchildren, int nlevels, const int32_t *lev
                  int64_t nboxes, int64_t aligned_nboxes, const int32_t *box_child_ids,
                  int32_t *dfs_order)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nchildren < 2 || nlevels < 1 || !level_start_box_nrs || nboxes < 1
             || nboxes > INT32_MAX || aligned_nboxes < nboxes || !box_child_ids || !dfs_order
             || level_start_box_nrs[0] != 0 || level_start_box_nrs[nlevels] != nboxes) {
@@ -240,6 +241,7 @@ int bt_dfs_order(bt_context *ctx, int nchildren, int nlevels, const int32_t *lev
 int bt_partition_work(bt_context *ctx, int64_t nboxes, const int32_t *dfs_order,
                       const double *cost_per_box, int nranks, int32_t *segments)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nboxes < 1 || nboxes > INT32_MAX || !dfs_order || !cost_per_box || nranks < 1
             || !segments) {
         set_error("bt_partition_work: invalid argument");
@@ -296,6 +298,7 @@ int bt_partition_work(bt_context *ctx, int64_t nboxes, const int32_t *dfs_order,
 int bt_ancestor_mask(bt_context *ctx, int64_t nboxes, const int32_t *box_parent_ids,
                      const int8_t *boxes_mask, int8_t *ancestors)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nboxes < 1 || !box_parent_ids || !boxes_mask || !ancestors) {
         set_error("bt_ancestor_mask: invalid argument");
         return BT_ERR_INVALID;
@@ -313,6 +316,7 @@ int bt_mark_list_boxes(bt_context *ctx, int64_t nrows, const int32_t *box_list,
                        const int8_t *mask_a, const int8_t *mask_b, const int32_t *starts,
                        const int32_t *lists, int8_t *out_mask)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nrows < 0 || !mask_a || !out_mask || (nrows > 0 && (!box_list || !starts))) {
         set_error("bt_mark_list_boxes: invalid argument");
         return BT_ERR_INVALID;
@@ -333,6 +337,7 @@ int bt_local_particles(bt_context *ctx, int64_t nboxes, int64_t nparticles, cons
                        int32_t *local_counts_nonchild, int32_t *local_counts_cumul,
                        int32_t *particle_idx, int64_t *nlocal)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nboxes < 1 || nparticles < 0 || nparticles > INT32_MAX || !box_mask
             || !box_particle_starts || !box_particle_counts_nonchild || !box_particle_counts_cumul
             || !local_starts || !local_counts_nonchild || !local_counts_cumul || !nlocal
@@ -371,6 +376,7 @@ int bt_local_particles(bt_context *ctx, int64_t nboxes, int64_t nparticles, cons
 int bt_modify_target_flags(bt_context *ctx, int64_t nboxes, const int32_t *counts_nonchild,
                            const int32_t *counts_cumul, uint8_t *box_flags)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nboxes < 1 || !counts_nonchild || !counts_cumul || !box_flags) {
         set_error("bt_modify_target_flags: invalid argument");
         return BT_ERR_INVALID;
@@ -386,6 +392,7 @@ int bt_modify_target_flags(bt_context *ctx, int64_t nboxes, const int32_t *count
 int bt_box_to_user_ranks(bt_context *ctx, int nranks, int64_t nboxes, const int8_t *masks,
                          int32_t *starts, int32_t *lists, int64_t *nentries)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nranks < 1 || nboxes < 1 || !masks || !starts || !nentries) {
         set_error("bt_box_to_user_ranks: invalid argument");
         return BT_ERR_INVALID;
@@ -415,6 +422,7 @@ int bt_boxes_used_by_ranks(bt_context *ctx, int64_t nboxes, const int8_t *contri
                            int rank_lo, int rank_hi, const int32_t *box_to_user_rank_starts,
                            const int32_t *box_to_user_rank_lists, int32_t *boxes, int64_t *n)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nboxes < 1 || !contributing || !box_to_user_rank_starts || !boxes || !n) {
         set_error("bt_boxes_used_by_ranks: invalid argument");
         return BT_ERR_INVALID;

@@ -172,7 +172,7 @@ int cells_impl(bt_context *ctx, const void *const *coords, int64_t n, const doub
 // receive buffer.  Reads are sequential, writes go to `nranks` advancing runs.  (A
 // permutation by owner followed by a gather reads the coordinate arrays in `nranks`
 // interleaved strided passes: with 8 ranks every 64-byte line is fetched 8 times.)
-constexpr int PP_MAX_RANKS = 256;
+constexpr int PP_MAX_RANKS = BT_MGPU_MAX_RANKS;
 constexpr int PP_ITEMS = 16;                    // particles per lane
 constexpr int PP_WAVE_ITEMS = 64 * PP_ITEMS;
 
@@ -296,6 +296,7 @@ int bt_morton_cells(bt_context *ctx, int dims, int coord_kind, const void *const
                     int64_t n, const double *bbox_min, const double *bbox_max, int level,
                     uint32_t *cells_out, int32_t *hist_inout)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || !coords || !bbox_min || !bbox_max || n < 0 || dims < 1 || dims > BT_MAX_DIMS
             || level < 1 || dims * level > 24 || (n > 0 && (!cells_out || !hist_inout))) {
         set_error("bt_morton_cells: invalid argument");
@@ -316,6 +317,7 @@ int bt_morton_cells(bt_context *ctx, int dims, int coord_kind, const void *const
 int bt_bucket_permutation(bt_context *ctx, const uint32_t *cells, int64_t n,
                           const int32_t *owner_of_cell, int nranks, uint32_t *perm_out)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || n < 0 || nranks < 1 || nranks > 256 || (n > 0 && (!cells || !owner_of_cell || !perm_out))) {
         set_error("bt_bucket_permutation: invalid argument");
         return BT_ERR_INVALID;
@@ -345,6 +347,7 @@ int bt_partition_pack(bt_context *ctx, int dims, int elem_size, const void *cons
                       int self_rank, int64_t self_send_offset, int64_t self_recv_offset,
                       void *send, void *recv)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || n < 0 || dims < 1 || dims > BT_MAX_DIMS || (elem_size != 4 && elem_size != 8)
             || nranks < 1 || nranks > PP_MAX_RANKS || self_rank < 0 || self_rank >= nranks
             || (n > 0 && (!in || !cells || !owner_of_cell))) {
@@ -368,6 +371,7 @@ int bt_partition_pack(bt_context *ctx, int dims, int elem_size, const void *cons
 int bt_gather(bt_context *ctx, int elem_size, const void *in, const uint32_t *perm, int64_t n,
               void *out)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || n < 0 || (elem_size != 4 && elem_size != 8) || (n > 0 && (!in || !perm || !out))) {
         set_error("bt_gather: invalid argument");
         return BT_ERR_INVALID;
@@ -388,6 +392,7 @@ int bt_gather(bt_context *ctx, int elem_size, const void *in, const uint32_t *pe
 int bt_gather_pack(bt_context *ctx, int dims, int elem_size, const void *const *in,
                    const uint32_t *perm, int64_t n, void *out)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || n < 0 || dims < 1 || dims > BT_MAX_DIMS || (elem_size != 4 && elem_size != 8)
             || (n > 0 && (!in || !perm || !out))) {
         set_error("bt_gather_pack: invalid argument");
@@ -413,6 +418,7 @@ int bt_gather_pack(bt_context *ctx, int dims, int elem_size, const void *const *
 
 int bt_unpack(bt_context *ctx, int dims, int elem_size, const void *in, int64_t n, void *const *out)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || n < 0 || dims < 1 || dims > BT_MAX_DIMS || (elem_size != 4 && elem_size != 8)
             || (n > 0 && (!in || !out))) {
         set_error("bt_unpack: invalid argument");
@@ -573,6 +579,7 @@ int bt_box_morton_paths(bt_context *ctx, int dims, int coord_kind, int64_t nboxe
                         int64_t aligned_nboxes, const void *box_centers, const uint8_t *box_levels,
                         const double *bbox_min, double root_extent, uint64_t *paths)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || dims < 1 || dims > 3 || nboxes < 0 || !box_centers || !box_levels || !bbox_min
             || !paths || (coord_kind != BT_F32 && coord_kind != BT_F64)) {
         set_error("bt_box_morton_paths: invalid argument");
@@ -597,6 +604,7 @@ int bt_let_build(bt_context *ctx, int dims, int coord_kind, int nlevels,
                  const double *bbox_min, const double *bbox_max, double root_extent,
                  int32_t *box_parent_ids, int32_t *box_child_ids, void *box_centers)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || dims < 1 || dims > 3 || nlevels < 1 || nlevels > BT_MAX_LEVELS
             || !level_start_box_nrs || !paths || !bbox_min || !bbox_max || !box_parent_ids
             || !box_child_ids || !box_centers || (coord_kind != BT_F32 && coord_kind != BT_F64)) {

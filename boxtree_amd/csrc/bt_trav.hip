@@ -731,6 +731,7 @@ struct TravState {
 
 void bt_free_trav_state(bt_context *ctx)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (ctx->trav) {
         for (auto &e : ctx->trav->events) (void) hipEventDestroy(e.second);
         delete ctx->trav;
@@ -740,6 +741,7 @@ void bt_free_trav_state(bt_context *ctx)
 
 int bt_trav_stage_times(bt_context *ctx, bt_stage_times *out, int n)
 {
+    bt::CallScope bt_call_scope_(ctx);
     TravState *st = ctx->trav;
     if (!st) return n;
     if (!st->events.empty()) (void) hipEventSynchronize(st->events.back().second);
@@ -2218,7 +2220,7 @@ static int trav_build_entry(bt_context *ctx, const bt_trav_params *p, bt_trav_si
     case 2: s = f64 ? trav_build_impl<double, 2>(ctx, st, out) : trav_build_impl<float, 2>(ctx, st, out); break;
     case 3: s = f64 ? trav_build_impl<double, 3>(ctx, st, out) : trav_build_impl<float, 3>(ctx, st, out); break;
     }
-    if (s != BT_OK) { (void) bt::sync_stream(ctx); bt_free_trav_state(ctx); }
+    if (s != BT_OK) { bt::drop_pending_reads(ctx); bt_free_trav_state(ctx); }
     return s;
 }
 
@@ -2310,11 +2312,13 @@ static int export_impl(bt_context *ctx, TravState *st, const bt_trav_arrays *o)
 
 int bt_traversal_build(bt_context *ctx, const bt_trav_params *p, bt_trav_sizes *out)
 {
+    bt::CallScope bt_call_scope_(ctx);
     return trav_build_entry(ctx, p, out, nullptr, nullptr, nullptr);
 }
 
 int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || !o) { set_error("bt_traversal_export: NULL argument"); return BT_ERR_INVALID; }
     TravState *st = ctx->trav;
     if (!st || !st->built) {
@@ -2328,6 +2332,7 @@ int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *o)
 int bt_traversal_build_packed(bt_context *ctx, const bt_trav_params *p, bt_alloc_fn alloc,
                               void *user, bt_trav_packed *out)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!alloc || !out) { set_error("bt_traversal_build_packed: NULL argument"); return BT_ERR_INVALID; }
     memset(out, 0, sizeof(*out));
     bt_trav_sizes sizes;
@@ -2370,6 +2375,7 @@ int bt_merge_csr_lists(bt_context *ctx, int nlists, const int32_t *const *starts
                        const int32_t *const *lists, int64_t nrows, int32_t *out_starts,
                        int32_t *out_lists)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || nlists < 1 || nlists > 4 || !starts || !lists || nrows < 0 || !out_starts) {
         set_error("bt_merge_csr_lists: invalid argument");
         return BT_ERR_INVALID;

@@ -214,6 +214,8 @@ struct KeygenArgs {
     int L;          // levels in the key
     int norm;       // BT_NORM_*
     int point_skip_levels;   // levels 1..this cannot stop a particle of radius 0
+    // packed keys (point particles): key = (path >> pack_drop) << pack_idbits | srcntgt id
+    int pack_idbits, pack_drop;
 };
 
 // Records of the interleaved coordinate copy: 3-D points are padded to four
@@ -311,9 +313,53 @@ __global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_
         const int drop = D * (L - cap);
         if (drop > 0) kt = (drop >= 64) ? 0 : (kt >> drop) << drop;
         keys[i] = (kt << CAPBITS_EXT) | (uint64_t) cap;
+    } else if (a.pack_idbits > 0) {
+        keys[i] = ((kt >> a.pack_drop) << a.pack_idbits) | (uint64_t) i;
     } else {
         keys[i] = kt;
     }
+}
+
+// ---------------------------------------------------------------------------
+// Packed keys.  A build of N < 2^idbits point particles (no extents, unit weights,
+// kind "adaptive") sorts ONE word per particle: the Morton path of the levels the tree
+// is expected to reach (Lk of them) shifted over the particle's srcntgt id.  A stable
+// LSD sort on the path bits alone (bt::radix_sort_keys: 16 bytes per particle and pass
+// instead of 24) leaves the ids of equal paths ascending -- the pair sort's order.  The
+// level kernels read the array as a key of Lk levels with idbits "cap" bits below the
+// path; the fix-up unpacks the ids while it orders the leaves.  A tree deeper than Lk
+// levels goes back to full keys (rekey_full_kernel + the pair sort) at that point.
+// ---------------------------------------------------------------------------
+
+template <class T, int D>
+struct RekeyArgs {
+    const T *packed;          // [n][PackStride<D>] coordinates by srcntgt id
+    const T *rootbox;         // device root box or null
+    T bbox_min[D], bbox_max[D];
+    int L;
+};
+
+template <class T, int D>
+__global__ __launch_bounds__(256) void rekey_full_kernel(int64_t n, const uint64_t *pk, uint64_t id_mask,
+        RekeyArgs<T, D> a, uint32_t *ids_out, uint64_t *keys_out)
+{
+    const int64_t p = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t id = (uint32_t) (pk[p] & id_mask);
+    ids_out[p] = id;
+    if (!keys_out) return;
+    constexpr int PS = PackStride<D>::value;
+    uint64_t kt = 0;
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        const T x = a.packed[(int64_t) id * PS + ax];
+        const T gmin = a.rootbox ? a.rootbox[ax] : a.bbox_min[ax];
+        const T gext = (a.rootbox ? a.rootbox[3 + ax] : a.bbox_max[ax]) - gmin;
+        const uint32_t v = (uint32_t) (((x - gmin) / gext) * (T) (1u << a.L));     // keygen_kernel
+        const uint32_t m = (a.L >= 32) ? v : (v & ((1u << a.L) - 1u));
+        kt |= spread_bits<D>(m) << (D - 1 - ax);
+    }
+    keys_out[p] = kt;
 }
 
 // ---------------------------------------------------------------------------
@@ -1084,9 +1130,12 @@ struct SegSortFlags {
 // inside a row of 16 lanes -- 1 LDS round trip instead of 15 -- were measured 13 % SLOWER
 // at 10^8 points: the kernel is bound by vector-ALU issue, and the shuffles run on the LDS
 // pipeline beside it.)
+// PACKED: the ids are the low bits of the packed keys (above); every leaf's ids are written
+// to `ids`, ordered or not, and a leaf of one particle is copied.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, const int32_t *box_start,
         const int32_t *box_count, const uint8_t *box_haschild, uint32_t *ids,
-        int32_t *large_list, SegSortFlags *flags)
+        int32_t *large_list, SegSortFlags *flags, const uint64_t *pk, uint64_t id_mask)
 {
     const int b = (blockIdx.x * 256 + threadIdx.x) >> 5;
     const int lane = threadIdx.x & 31;
@@ -1095,7 +1144,8 @@ __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, cons
     const int n = box_count[b];
     const int s = box_start[b];
     // a split box's own particles share one key: the stable sort left them in id order
-    if (has_children || n <= 1) return;
+    // (packed keys: point particles, a split box has none of its own)
+    if (has_children || n <= (PACKED ? 0 : 1)) return;
     if (n > 64) {
         if (lane == 0) {
             if (n <= SEG_BLOCK_MAX) large_list[atomicAdd(&flags->n_large, 1)] = b;
@@ -1103,8 +1153,14 @@ __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, cons
         }
         return;
     }
-    uint32_t v0 = (lane < n) ? ids[s + lane] : 0xFFFFFFFFu;
-    uint32_t v1 = (lane + 32 < n) ? ids[s + lane + 32] : 0xFFFFFFFFu;
+    uint32_t v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
+    if (PACKED) {
+        if (lane < n) v0 = (uint32_t) (pk[s + lane] & id_mask);
+        if (lane + 32 < n) v1 = (uint32_t) (pk[s + lane + 32] & id_mask);
+    } else {
+        if (lane < n) v0 = ids[s + lane];
+        if (lane + 32 < n) v1 = ids[s + lane + 32];
+    }
     // element index of v0 is `lane`, of v1 `lane + 32`
     auto cmpx = [&](uint32_t v, int idx, int k, int j) {
         const uint32_t o = __shfl_xor(v, j, 32);
@@ -1140,9 +1196,11 @@ __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, cons
 // The number of listed runs is read on the device (flags->n_large): the launch needs no
 // host round trip; a run longer than the workgroup sort on a build that cannot have one
 // is reported through the status word.
+template <bool PACKED>
 __global__ __launch_bounds__(256) void segment_sort_block_kernel(const int32_t *large_list,
         const SegSortFlags *flags, int huge_is_error, DeviceStatus *status,
-        const int32_t *box_start, const int32_t *box_count, uint32_t *ids)
+        const int32_t *box_start, const int32_t *box_count, uint32_t *ids,
+        const uint64_t *pk, uint64_t id_mask)
 {
     __shared__ uint32_t s_v[SEG_BLOCK_MAX];
     if (huge_is_error && flags->has_huge && blockIdx.x == 0 && threadIdx.x == 0)
@@ -1153,7 +1211,8 @@ __global__ __launch_bounds__(256) void segment_sort_block_kernel(const int32_t *
         const int s = box_start[b], n = box_count[b];
         int m = 128;
         while (m < n) m <<= 1;
-        for (int i = threadIdx.x; i < m; i += 256) s_v[i] = (i < n) ? ids[s + i] : 0xFFFFFFFFu;
+        for (int i = threadIdx.x; i < m; i += 256)
+            s_v[i] = (i < n) ? (PACKED ? (uint32_t) (pk[s + i] & id_mask) : ids[s + i]) : 0xFFFFFFFFu;
         __syncthreads();
         for (int k = 2; k <= m; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -1680,6 +1739,8 @@ struct TreeState {
 
     Buf<uint64_t> keys_a, keys_b;
     Buf<uint32_t> ids_a, ids_b;
+    const uint64_t *pk = nullptr;      // packed keys (path << idbits | id) still holding the ids:
+    uint64_t pk_mask = 0;              // the fix-up unpacks them into `ids`
     uint32_t *ids = nullptr;           // final tree order -> user srcntgt id
     uint32_t *ids_other = nullptr;     // the other id buffer (scratch of the global fix-up)
     bool fixup_done = false;           // ids are in the reference's within-box order
@@ -1707,6 +1768,7 @@ struct TreeState {
 
 void bt_free_tree_state(bt_context *ctx)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (ctx->tree) {
         // a read queued into this state (fixup_launch) must not outlive it
         if (ctx->tree->fixup_pending) (void) bt::sync_stream(ctx);
@@ -2281,21 +2343,35 @@ int fixup_launch(bt_context *ctx, TreeState *st)
         BT_CHECK(st->fix_flags.alloc(ctx->pool, 1));
         BT_HIP_CHECK(hipMemsetAsync(st->fix_flags.get(), 0, sizeof(SegSortFlags), ctx->stream));
     }
-    segment_sort_wave_kernel<<<(unsigned) div_up(st->nboxes * 32, 256), 256, 0, ctx->stream>>>(
-        (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_haschild.get(),
-        st->ids, st->fix_large_list.get(), st->fix_flags.get());
+    const unsigned wgrid = (unsigned) div_up(st->nboxes * 32, 256);
+    if (st->pk) {
+        if (can_be_huge) { set_error("internal: packed keys with runs beyond the workgroup sort"); return BT_ERR_INTERNAL; }
+        segment_sort_wave_kernel<true><<<wgrid, 256, 0, ctx->stream>>>(
+            (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_haschild.get(),
+            st->ids, st->fix_large_list.get(), st->fix_flags.get(), st->pk, st->pk_mask);
+    } else {
+        segment_sort_wave_kernel<false><<<wgrid, 256, 0, ctx->stream>>>(
+            (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_haschild.get(),
+            st->ids, st->fix_large_list.get(), st->fix_flags.get(), nullptr, 0);
+    }
     if (!can_be_huge) {
         const unsigned grid = (unsigned) std::min<int64_t>(ctx->num_cus * 4, N / 64 + 1);
-        segment_sort_block_kernel<<<grid, 256, 0, ctx->stream>>>(
-            st->fix_large_list.get(), st->fix_flags.get(), 1, ctx->d_status, st->box_start.get(),
-            st->box_count.get(), st->ids);
+        if (st->pk)
+            segment_sort_block_kernel<true><<<grid, 256, 0, ctx->stream>>>(
+                st->fix_large_list.get(), st->fix_flags.get(), 1, ctx->d_status, st->box_start.get(),
+                st->box_count.get(), st->ids, st->pk, st->pk_mask);
+        else
+            segment_sort_block_kernel<false><<<grid, 256, 0, ctx->stream>>>(
+                st->fix_large_list.get(), st->fix_flags.get(), 1, ctx->d_status, st->box_start.get(),
+                st->box_count.get(), st->ids, nullptr, 0);
+        st->pk = nullptr;
         BT_HIP_CHECK(hipGetLastError());
         st->fix_large_list.reset();
         st->fix_flags.reset();
         st->fixup_done = true;
         return BT_OK;
     }
-    BT_CHECK(bt::d2h(ctx, &st->h_fix, st->fix_flags.get(), sizeof(SegSortFlags)));
+    BT_CHECK(bt::d2h(ctx, &st->h_fix, st->fix_flags.get(), sizeof(SegSortFlags), /*persistent=*/true));
     st->fixup_pending = true;
     return BT_OK;
 }
@@ -2309,10 +2385,10 @@ int fixup_finish(bt_context *ctx, TreeState *st)
     ctx->n_host_syncs++;
     if (!st->h_fix.has_huge) {
         if (st->h_fix.n_large > 0)
-            segment_sort_block_kernel<<<(unsigned) std::min<int64_t>(st->h_fix.n_large, ctx->num_cus * 8),
-                                        256, 0, ctx->stream>>>(
+            segment_sort_block_kernel<false><<<(unsigned) std::min<int64_t>(st->h_fix.n_large, ctx->num_cus * 8),
+                                               256, 0, ctx->stream>>>(
                 st->fix_large_list.get(), st->fix_flags.get(), 0, ctx->d_status, st->box_start.get(),
-                st->box_count.get(), st->ids);
+                st->box_count.get(), st->ids, nullptr, 0);
         BT_HIP_CHECK(hipGetLastError());
     } else {
         uint32_t *ids = st->ids, *ids_other = st->ids_other;
@@ -2383,14 +2459,56 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
             partial.get(), (int) bs, (int) bt_, (T) (1.0 + p.root_extent_stretch), (T *) st->rootbox.get());
         BT_HIP_CHECK(hipGetLastError());
         // the host copy arrives with the level loop's first wait
-        BT_CHECK(bt::d2h(ctx, st->h_rootbox, st->rootbox.get(), 8 * sizeof(T)));
+        BT_CHECK(bt::d2h(ctx, st->h_rootbox, st->rootbox.get(), 8 * sizeof(T), /*persistent=*/true));
+    }
+
+    // ---- how deep will the tree get?  Points on a (D-1)-dimensional set (surfaces are the
+    // deep case in practice) fill 2^(D-1) children per split, plus two levels of slack; a
+    // sharded build is as deep as the GLOBAL point set makes it -------------------------------
+    int est_levels = st->L;
+    if (!p.refine_weights) {
+        double npts = (double) N;
+        if (p.top_cell_prefix) {
+            int64_t total = 0;
+            BT_CHECK(bt::d2h(ctx, &total, p.top_cell_prefix + ((int64_t) 1 << (D * p.top_level)), 8));
+            BT_CHECK(bt::sync_stream(ctx));
+            npts = (double) total;
+        }
+        const double per_leaf = std::max(1.0, npts / std::max(1, p.max_leaf_refine_weight));
+        const int fan = D > 1 ? D - 1 : 1;
+        est_levels = (int) std::ceil(std::log2(per_leaf) / fan) + 2;
+    }
+    // ---- packed keys (see rekey_full_kernel): path bits of Lk levels over the id ---------------
+    bool packed = false;
+    int pk_idbits = 0, pk_levels = 0;
+    {
+        const char *e_off = getenv("BT_NO_PACKED_KEYS");           // testing / tuning aids
+        const char *e_lev = getenv("BT_PACKED_LEVELS");
+        const char *e_fused = getenv("BT_FUSED_LEAVES"), *e_full = getenv("BT_FULL_SORT");
+        int idbits = 1;
+        while (((int64_t) 1 << idbits) < N) ++idbits;
+        const int lk_max = std::min(st->L, (64 - idbits) / D);
+        if (!(e_off && atoi(e_off)) && !(e_fused && atoi(e_fused)) && !(e_full && atoi(e_full))
+                && !EXT && !p.refine_weights && p.kind == BT_KIND_ADAPTIVE
+                && p.max_leaf_refine_weight <= SEG_BLOCK_MAX && N >= 2
+                && lk_max >= 1 && lk_max >= est_levels - 1) {
+            int lk = std::min(lk_max, std::max(est_levels, 1));
+            // the passes are whole digits: take the levels they cover anyway
+            int rb = 8;
+            const int np = bt::radix_sort_keys_plan(D * lk, &rb);
+            lk = std::min(lk_max, std::max(lk, np * rb / D));
+            if (e_lev && atoi(e_lev) > 0) lk = std::min(lk, atoi(e_lev));
+            packed = true;
+            pk_idbits = idbits;
+            pk_levels = lk;
+        }
     }
 
     // ---- keys ----------------------------------------------------------------
     BT_CHECK(st->keys_a.alloc(ctx->pool, N));
     BT_CHECK(st->keys_b.alloc(ctx->pool, N));
     BT_CHECK(st->ids_a.alloc(ctx->pool, N));
-    BT_CHECK(st->ids_b.alloc(ctx->pool, N));
+    if (!packed) BT_CHECK(st->ids_b.alloc(ctx->pool, N));
     if (N > 0) {
         KeygenArgs<T, D> ka;
         for (int ax = 0; ax < D; ++ax) {
@@ -2409,6 +2527,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         ka.stick_out_factor = (T) p.stick_out_factor;
         ka.L = st->L;
         ka.norm = p.extent_norm;
+        ka.pack_idbits = packed ? pk_idbits : 0;
+        ka.pack_drop = packed ? D * (st->L - pk_levels) : 0;
         {
             // margin at level l: (stick_out_factor / 2) * extent * 2^-l; rounding of the
             // cell assignment, the centre and the limit: a few spacings of T at the
@@ -2459,25 +2579,20 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     }();
     if (partial_sort_ok && !p.refine_weights && keybits > 40 + (EXT ? 8 : 0)
             && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED) {
-        // depth estimate: points on a (D-1)-dimensional set (surfaces are the deep
-        // case in practice) fill 2^(D-1) children per split, plus two levels of
-        // slack; a sharded build is as deep as the GLOBAL point set makes it
-        double npts = (double) N;
-        if (p.top_cell_prefix) {
-            int64_t total = 0;
-            BT_CHECK(bt::d2h(ctx, &total, p.top_cell_prefix + ((int64_t) 1 << (D * p.top_level)), 8));
-            BT_CHECK(bt::sync_stream(ctx));
-            npts = (double) total;
-        }
-        const double per_leaf = std::max(1.0, npts / std::max(1, p.max_leaf_refine_weight));
-        const int fan = D > 1 ? D - 1 : 1;
-        const int est_levels = (int) std::ceil(std::log2(per_leaf) / fan) + 2;
+        // (depth estimate above)
         int bits = ((D * est_levels + 7) / 8) * 8;
         bits = std::max(40, bits);
         if (bits < keybits) sorted_high_bits = bits;
     }
     uint64_t *keys_cur = st->keys_a.get(), *keys_oth = st->keys_b.get();
-    if (N > 0) {
+    if (packed) {
+        bool in_b = false;
+        BT_CHECK(bt::radix_sort_keys(ctx, keys_cur, keys_oth, N, pk_idbits, pk_idbits + D * pk_levels, &in_b));
+        if (in_b) std::swap(keys_cur, keys_oth);
+        keys = keys_cur;
+        ids = st->ids_a.get(); ids_other = nullptr;       // filled by the fix-up
+        sorted_high_bits = D * pk_levels;
+    } else if (N > 0) {
         uint64_t *ka = st->keys_a.get(), *kb = st->keys_b.get();
         uint32_t *ia = st->ids_a.get(), *ib = st->ids_b.get();
         bool identity = true;
@@ -2525,13 +2640,14 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     {
         static const bool off = [] { const char *e = getenv("BT_NO_CELL_STARTS"); return e && atoi(e); }();
         int k = D == 3 ? 5 : D == 2 ? 7 : 15;
-        k = std::min(k, st->L);
+        k = std::min(k, packed ? pk_levels : st->L);
         if (!off && !EXT && !p.refine_weights && !p.top_cell_prefix && N >= 4096 && k >= 2
                 && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED) {
             const int64_t ncells = (int64_t) 1 << (D * k);
             BT_CHECK(local_cells.alloc(ctx->pool, ncells + 1));
             cell_starts_kernel<<<(unsigned) div_up(ncells + 1, 256), 256, 0, ctx->stream>>>(
-                keys, N, D * (st->L - k), ncells, local_cells.get());
+                keys, N, packed ? pk_idbits + D * (pk_levels - k) : D * (st->L - k), ncells,
+                local_cells.get());
             BT_HIP_CHECK(hipGetLastError());
             local_top_level = k;
         }
@@ -2552,7 +2668,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         a.box_level = st->box_level.get(); a.box_haschild = st->box_haschild.get();
         a.status = ctx->d_status;
         a.max_weight = p.max_leaf_refine_weight;
-        a.capbits = st->capbits;
+        a.capbits = packed ? pk_idbits : st->capbits;     // (packed: the id bits sit where the cap would)
         a.adaptive = p.kind != BT_KIND_NON_ADAPTIVE;
         a.top_level = p.top_level;
         a.top_prefix = p.top_cell_prefix;
@@ -2608,6 +2724,24 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     };
     uint32_t sl_gen = 0;
 
+    // Packed keys -> (full key, id) arrays in the current order: the tree got deeper than
+    // the packed path bits reach (with_keys), or the continuation below needs the ids.
+    auto unpack_keys = [&](bool with_keys) -> int {
+        RekeyArgs<T, D> ra{};
+        ra.packed = (const T *) st->packed.get();
+        ra.rootbox = (const T *) st->rootbox.get();
+        for (int ax = 0; ax < D; ++ax) { ra.bbox_min[ax] = (T) p.bbox_min[ax]; ra.bbox_max[ax] = (T) p.bbox_max[ax]; }
+        ra.L = st->L;
+        if (!st->ids_b.get()) BT_CHECK(st->ids_b.alloc(ctx->pool, N));
+        ids = st->ids_a.get(); ids_other = st->ids_b.get();
+        rekey_full_kernel<T, D><<<(unsigned) div_up(N, 256), 256, 0, ctx->stream>>>(
+            N, keys_cur, ((uint64_t) 1 << pk_idbits) - 1, ra, ids, with_keys ? keys_oth : nullptr);
+        BT_HIP_CHECK(hipGetLastError());
+        if (with_keys) std::swap(keys_cur, keys_oth);
+        packed = false;
+        return BT_OK;
+    };
+
     // Levels first_level .. on one key array (`kkeys` addresses the levels loff+1 ..
     // loff+Lkey).  Launches are queued in batches without looking at the result; the
     // state comes back once per batch.  *need_more: a box of level loff+Lkey must split
@@ -2629,6 +2763,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
                 // deeper than the sorted key bits reach: order all bits now.  Box ranges
                 // stay valid (the order of the top bits does not change); ties keep
                 // whatever order they have, the fix-up sorts leaves by user id anyway.
+                if (packed) BT_CHECK(unpack_keys(true));
                 bool in_b = false;
                 BT_CHECK(radix_sort_pairs<uint64_t>(ctx, keys_cur, ids, keys_oth, ids_other, N, 0,
                                                     keybits, false, &in_b));
@@ -2643,7 +2778,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
                 BuildArgs a;
                 base_args(a);
                 a.keys = kkeys;
-                a.level = l; a.L = Lkey; a.loff = loff;
+                a.level = l; a.L = (packed && loff == 0) ? pk_levels : Lkey; a.loff = loff;
                 a.can_continue = can_continue ? 1 : 0;
                 a.cand = (l == loff + 1) ? cand : nullptr;
                 sl_gen += 1;
@@ -2722,6 +2857,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     }
     if (need_more) {
         // ---- continuation below level L1 = st->L (keygen2_kernel) ---------------------
+        if (packed) BT_CHECK(unpack_keys(false));
         const int L1 = st->L;
         const int keybits2 = D * L2 + st->capbits;
         const int b0 = st->level_start[L1];
@@ -2812,6 +2948,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     // ---- within-box order fix-up ----------------------------------------------
     st->ids = ids;
     st->ids_other = ids_other;
+    st->pk = packed ? keys_cur : nullptr;
+    st->pk_mask = packed ? ((uint64_t) 1 << pk_idbits) - 1 : 0;
     // sources == targets without extents: the leaves CAN be ordered, gathered and
     // measured in one pass at export time (leaf_gather_wave_kernel, BT_FUSED_LEAVES=1).
     // Measured at 10^8 sphere points: 4.5 ms against 0.9 + 2.6 + 0.4 ms for the separate
@@ -3037,7 +3175,7 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
     if (fused) {
         SegSortFlags hf;
         BT_CHECK(bt::d2h(ctx, &hf, sflags.get(), sizeof(hf)));
-        BT_CHECK(bt::sync_stream(ctx));
+        BT_CHECK(bt::check_status(ctx));       // waits; the sort and the scans above report here
         ctx->n_host_syncs++;
         if (hf.has_huge) {
             // a leaf beyond the workgroup sort (zero refine weights): order the ids with
@@ -3084,6 +3222,7 @@ extern "C" {
 int bt_bbox(bt_context *ctx, int dims, int coord_kind, const void *const *coords,
             const void *radii, int64_t n, double *out_min, double *out_max)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || !coords || !out_min || !out_max || dims < 1 || dims > BT_MAX_DIMS || n < 0) {
         set_error("bt_bbox: invalid argument");
         return BT_ERR_INVALID;
@@ -3097,6 +3236,7 @@ int bt_bbox(bt_context *ctx, int dims, int coord_kind, const void *const *coords
 
 int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || !p || !out) { set_error("bt_tree_build: NULL argument"); return BT_ERR_INVALID; }
     host_trace("build:enter");
     BT_HIP_CHECK(hipSetDevice(ctx->device));
@@ -3181,13 +3321,14 @@ int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
     BT_CHECK(bt::zero_begin(ctx));          // (resets the status word too)
     int s = st->f64 ? dispatch_dims_build<double>(ctx, st, out)
                     : dispatch_dims_build<float>(ctx, st, out);
-    if (s != BT_OK) { (void) bt::sync_stream(ctx); bt_free_tree_state(ctx); }
+    if (s != BT_OK) { bt::drop_pending_reads(ctx); bt_free_tree_state(ctx); }
     host_trace("build:leave");
     return s;
 }
 
 int bt_tree_export(bt_context *ctx, const bt_tree_arrays *o)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || !o) { set_error("bt_tree_export: NULL argument"); return BT_ERR_INVALID; }
     TreeState *st = ctx->tree;
     if (!st || !st->built) {
@@ -3224,6 +3365,7 @@ int bt_tree_export(bt_context *ctx, const bt_tree_arrays *o)
 
 int bt_get_stage_times(bt_context *ctx, bt_stage_times *out)
 {
+    bt::CallScope bt_call_scope_(ctx);
     if (!ctx || !out) return BT_ERR_INVALID;
     memset(out, 0, sizeof(*out));
     TreeState *st = ctx->tree;

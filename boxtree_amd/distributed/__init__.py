@@ -466,7 +466,9 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         """all-to-all-v of the coordinate arrays (+ extras) by owner of `cells`."""
         # coordinates alone are partitioned by owner in one sweep that writes the send buffer
         # (bt_partition_pack); arrays that travel with them need the permutation
-        use_partition = native and not extra and os.environ.get("BOXTREE_HIP_PARTITION_PACK", "1") != "0"
+        # (bt_partition_pack keeps one run per owner in LDS: BT_MGPU_MAX_RANKS = 256)
+        use_partition = (native and not extra and world <= 256
+                         and os.environ.get("BOXTREE_HIP_PARTITION_PACK", "1") != "0")
         if use_partition:
             order = None
             send_counts = torch.zeros(world, dtype=torch.int64, device=dev)

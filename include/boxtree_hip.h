@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BT_ABI_VERSION 3
+#define BT_ABI_VERSION 4
 #define BT_MAX_DIMS 3
 #define BT_MAX_LEVELS 64       /* capacity of per-level arrays in the structs */
 
@@ -117,6 +117,13 @@ int bt_radix_sort_u32_u32(bt_context *ctx, uint32_t *keys_in, uint32_t *vals_in,
                           uint32_t *keys_out, uint32_t *vals_out, int64_t n,
                           int begin_bit, int end_bit);
 
+/* Keys only: stable LSD sort of 64-bit words on bits [begin_bit, end_bit); the bits
+ * below begin_bit ride along (the tree build of point particles packs the user id there:
+ * one word per particle, 16*n algorithmic bytes per digit pass).  8- or 9-bit digits,
+ * whichever needs fewer passes.  keys_in is clobbered; the result is in keys_out. */
+int bt_radix_sort_u64_keys(bt_context *ctx, uint64_t *keys_in, uint64_t *keys_out, int64_t n,
+                           int begin_bit, int end_bit);
+
 typedef struct {
     int64_t n;                 /* pairs sorted                                    */
     int32_t passes;            /* digit passes of the last 64-bit-key sort (the   */
@@ -130,6 +137,11 @@ typedef struct {
     int32_t first_pass_identity;
     float full_pass_ms_avg;    /* passes that read and write keys and values      */
     int32_t full_passes;
+    /* what a full pass moves per element: 24 = (u64 key, u32 value) pairs read and     */
+    /* written; 16 = keys only -- a tree build of point particles packs the user id     */
+    /* under the Morton path bits of ONE 64-bit word (bt_tree.hip, "packed keys") --    */
+    int32_t bytes_per_element_per_pass;
+    int32_t digit_bits;        /* 8, or 9 for the keys-only sort when that saves a pass */
 } bt_sort_stats;
 int bt_get_sort_stats(bt_context *ctx, bt_sort_stats *out);
 
@@ -549,6 +561,10 @@ typedef struct {
     int64_t bytes_sent;                /* payload bytes that left this GPU              */
     int32_t rounds;                    /* point-to-point rounds of the all-to-all       */
 } bt_mgpu_shard;
+
+/* the one-sweep partition (bt_partition_pack) keeps one run per owner in LDS: at most this
+ * many ranks; bt_mgpu_exchange returns BT_ERR_UNSUPPORTED beyond (one node has 8) */
+#define BT_MGPU_MAX_RANKS 256
 
 /* rccl_comm: an ncclComm_t of nranks ranks with this process at `rank`, created on the
  * context's device.  Collectives are enqueued on the context's stream; the call

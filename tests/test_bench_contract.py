@@ -14,9 +14,11 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "roofline", "cpu_baseline"}
 
 
-def run_bench(*extra):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *extra],
-                         capture_output=True, text=True, timeout=900, cwd=ROOT)
+def run_bench(*extra, launcher=()):
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, *launcher, os.path.join(ROOT, "bench.py"), *extra],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -54,3 +56,74 @@ def test_bench_forced_distributed_path_matches_single():
     for key in ("nboxes", "nlevels", "list1_entries", "list2_entries"):
         assert a["config"][key] == b["config"][key], key
     assert b["config"]["global_nboxes"] == a["config"]["nboxes"]
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def check_two_ranks(d, n):
+    assert d["n_gpus"] == 2
+    c = d["config"]
+    assert c["workload"].startswith("c5:")            # BASELINE configs[4] is the N > 1 default
+    assert c["collectives"]["ranks_in_group"] == 2
+    assert len(c["owned_particles_by_rank"]) == 2 and sum(c["owned_particles_by_rank"]) == 2 * n
+    assert 1.0 <= c["owned_particle_imbalance"] < 1.2
+    assert c["exchange_bytes"] == sum(c["exchange_bytes_by_rank"]) > 0
+    # uniform points, two owners: about half of a rank's 24-byte records leave it
+    assert 0.3 * 24 * n < c["exchange_bytes_by_rank"][0] < 0.7 * 24 * n
+
+
+def test_bench_gpus_2_starts_two_ranks_cpu():
+    """`bench.py --gpus 2` without a launcher starts two ranks itself (gloo on the CPU here;
+    --dry-run: rendezvous + particle exchange, the hot path has no CPU fallback)."""
+    d = run_bench("--gpus", "2", "--dry-run", "--n", "20000")
+    assert d["dry_run"] is True and d["value"] is None
+    check_two_ranks(d, 20000)
+
+
+def test_bench_under_torch_distributed_run_cpu():
+    """The driver's N > 1 command line: one rank per process from torch.distributed.run."""
+    d = run_bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run",
+                  "--points-per-gpu", "20000",
+                  launcher=("-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                            "--master-addr", "127.0.0.1", "--master-port", str(_free_port())))
+    check_two_ranks(d, 20000)
+
+
+def test_bench_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a HIP device")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "1000"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "no CPU fallback" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_real_processes_one_gpu():
+    """Two REAL rank processes through the whole N > 1 path -- exchange, per-rank build,
+    global numbering, local essential tree, lists -- on however many GPUs the box has (one:
+    the ranks share it and talk over gloo, RCCL refuses two ranks on a device).  The global
+    tree of the two shards must be the tree one rank builds from both chunks."""
+    n = 400000
+    d = run_bench("--gpus", "2", "--n", str(n), "--steps", "1", "--warmup", "1")
+    check_two_ranks(d, n)
+    assert d["value"] > 0 and d["steps"] == 1 and "cpu_baseline" not in d
+    import numpy as np
+    from boxtree_amd import HIPArrayContext, TreeBuilder
+    actx = HIPArrayContext(0)
+    # (the recipe draws x, then y, then z: make_workload_numpy)
+    chunks = []
+    for r in range(2):
+        rng = np.random.default_rng(15 + r)
+        chunks.append([rng.random(n) for _ in range(3)])
+    pts = [np.concatenate([chunks[0][ax], chunks[1][ax]]) for ax in range(3)]
+    tree, _ = TreeBuilder(actx)(actx, [actx.from_numpy(p) for p in pts], max_particles_in_box=64)
+    assert d["config"]["global_nboxes"] == int(tree.nboxes)
+    assert d["config"]["nlevels"] == int(tree.nlevels)

@@ -80,6 +80,54 @@ def test_radix_sort_u64(actx, n, bits):
     assert np.array_equal(ov.cpu().numpy().view(np.uint32), vals[order])
 
 
+@pytest.mark.parametrize("n", [1, 2, 63, 8192, 8193, 100003, 3 * 10**6])
+@pytest.mark.parametrize("bits", [(17, 53), (22, 46), (5, 14), (27, 63), (0, 64), (3, 3)])
+def test_radix_sort_u64_keys(actx, n, bits):
+    """Keys-only sort (packed-key tree builds): stable on [begin, end), the low bits ride
+    along; 8- and 9-bit digits (36 bits = 4 x 9, 24 = 3 x 8, 9 = 1 x 9)."""
+    import torch
+    rng = np.random.default_rng(n + 7 * bits[1])
+    keys = rng.integers(0, 2**63, size=n, dtype=np.int64).astype(np.uint64)
+    if n > 10:
+        keys[: n // 3] &= np.uint64((1 << bits[0]) - 1)      # heavy duplicates of the sorted bits
+        keys[n // 2:] |= np.uint64(1 << 63)
+    dk = torch.from_numpy(keys.view(np.int64)).cuda()
+    ok = torch.empty_like(dk)
+    from boxtree_amd import _lib
+    torch.cuda.synchronize()
+    _lib.check(actx.lib.bt_radix_sort_u64_keys(
+        actx.handle, ct.c_void_p(dk.data_ptr()), ct.c_void_p(ok.data_ptr()), n, bits[0], bits[1]))
+    width = bits[1] - bits[0]
+    mask = np.uint64((((1 << width) - 1) << bits[0]) & (2**64 - 1))
+    order = np.argsort(keys & mask, kind="stable")
+    assert np.array_equal(ok.cpu().numpy().view(np.uint64), keys[order])
+    if n and width:
+        st = _lib.SortStats()
+        actx.lib.bt_get_sort_stats(actx.handle, st)
+        assert st.bytes_per_element_per_pass == 16 and st.passes == min(-(-width // 8), -(-width // 9))
+
+
+@pytest.mark.parametrize("mode", ["packed", "packed-shallow", "packed-rb8", "pairs"])
+@pytest.mark.parametrize("dims,n,mpb", [(3, 60000, 30), (2, 40000, 5), (3, 7, 2), (3, 2, 1),
+                                        (2, 100003, 64)])
+def test_packed_key_build_modes(actx, mode, dims, n, mpb, monkeypatch):
+    """Point-particle builds sort one word per particle (path bits over the id).  The same
+    trees must come out when the packed path bits end above the tree's depth (the build
+    returns to full keys there), with 8-bit digits, and with the (key, id) pair sort."""
+    from oracle import oracle
+    if mode == "packed-shallow":
+        monkeypatch.setenv("BT_PACKED_LEVELS", "3")
+    elif mode == "packed-rb8":
+        monkeypatch.setenv("BT_SORT_KEYS_RB", "8")
+    elif mode == "pairs":
+        monkeypatch.setenv("BT_NO_PACKED_KEYS", "1")
+    rng = np.random.default_rng(n + dims)
+    pts = [rng.standard_normal(n) for _ in range(dims)]
+    build_both(actx, oracle, pts, max_particles_in_box=mpb, trav_kw={})
+    tg = [rng.standard_normal(n // 3 + 1) for _ in range(dims)]
+    build_both(actx, oracle, pts, targets=tg, max_particles_in_box=mpb)
+
+
 @pytest.mark.parametrize("n", [1, 777, 10**6])
 def test_radix_sort_u32(actx, n):
     import torch
