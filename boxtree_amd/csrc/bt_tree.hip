@@ -224,43 +224,24 @@ struct KeygenArgs {
 template <int D>
 struct PackStride { static constexpr int value = D == 3 ? 4 : D; };
 
+// The sort key of one particle: (Kt << capbits) | cap with extents, Kt without (see the head of
+// DESIGN.md section 3).  x: coordinates, radius: its extent radius (EXT only).
 template <class T, int D, bool EXT>
-__global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_t *__restrict__ keys,
-                                                     T *__restrict__ packed /* [n][PackStride<D>] */)
+__device__ __forceinline__ uint64_t particle_key(const KeygenArgs<T, D> &a, const T (&x)[D], T radius)
 {
-    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n) return;
-    const bool is_src = i < a.nsources;
-    const int64_t j = is_src ? i : i - a.nsources;
-
-    T x[D], gmin[D], gext[D];
+    T gmin[D], gext[D];
     uint32_t v[D];
     const int L = a.L;
 #pragma unroll
     for (int ax = 0; ax < D; ++ax) {
-        x[ax] = is_src ? a.src[ax][j * a.src_stride] : a.tgt[ax][j * a.tgt_stride];
         gmin[ax] = a.rootbox ? a.rootbox[ax] : a.bbox_min[ax];                    // tbk:358
         gext[ax] = (a.rootbox ? a.rootbox[3 + ax] : a.bbox_max[ax]) - gmin[ax];   // tbk:359
         // tbk:374-376 evaluated at the deepest level; scaling by 2^k is exact,
         // so (v >> (L-l)) is the reference's level-l value.
         v[ax] = (uint32_t) (((x[ax] - gmin[ax]) / gext[ax]) * (T) (1u << L));
     }
-    // interleaved copy: the tree-order gather later needs ONE random access per
-    // particle instead of one per axis
-    {
-        constexpr int PS = PackStride<D>::value;
-        T rec[PS];
-#pragma unroll
-        for (int ax = 0; ax < PS; ++ax) rec[ax] = ax < D ? x[ax] : (T) 0;
-#pragma unroll
-        for (int ax = 0; ax < PS; ++ax) packed[i * PS + ax] = rec[ax];
-    }
-
     int cap = L;
     if (EXT) {
-        T radius = (T) 0;
-        if (is_src) { if (a.src_radii) radius = a.src_radii[j]; }
-        else        { if (a.tgt_radii) radius = a.tgt_radii[j]; }
         const T one_half = ((T) 1) / 2;
         const T brf = (T) ((1. + (double) a.stick_out_factor) * (double) one_half);   // tbk:342-346
         // A point (radius 0) lies inside every box of its own path, at least
@@ -312,12 +293,50 @@ __global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_
     if (EXT) {
         const int drop = D * (L - cap);
         if (drop > 0) kt = (drop >= 64) ? 0 : (kt >> drop) << drop;
-        keys[i] = (kt << CAPBITS_EXT) | (uint64_t) cap;
-    } else if (a.pack_idbits > 0) {
-        keys[i] = ((kt >> a.pack_drop) << a.pack_idbits) | (uint64_t) i;
-    } else {
-        keys[i] = kt;
+        return (kt << CAPBITS_EXT) | (uint64_t) cap;
     }
+    return kt;
+}
+
+// packed word of a key: the path bits of the first pack_levels levels, the cap (extents), the id
+template <int D, bool EXT>
+__device__ __forceinline__ uint64_t pack_key(uint64_t key, int pack_drop, int pack_idbits, uint64_t id)
+{
+    constexpr int CB = EXT ? CAPBITS_EXT : 0;
+    const uint64_t top = ((key >> CB) >> pack_drop) << CB | (key & (((uint64_t) 1 << CB) - 1));
+    return (top << pack_idbits) | id;
+}
+
+template <class T, int D, bool EXT>
+__global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_t *__restrict__ keys,
+                                                     T *__restrict__ packed /* [n][PackStride<D>] */)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const bool is_src = i < a.nsources;
+    const int64_t j = is_src ? i : i - a.nsources;
+
+    T x[D];
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax)
+        x[ax] = is_src ? a.src[ax][j * a.src_stride] : a.tgt[ax][j * a.tgt_stride];
+    // interleaved copy: the tree-order gather later needs ONE random access per
+    // particle instead of one per axis
+    {
+        constexpr int PS = PackStride<D>::value;
+        T rec[PS];
+#pragma unroll
+        for (int ax = 0; ax < PS; ++ax) rec[ax] = ax < D ? x[ax] : (T) 0;
+#pragma unroll
+        for (int ax = 0; ax < PS; ++ax) packed[i * PS + ax] = rec[ax];
+    }
+    T radius = (T) 0;
+    if (EXT) {
+        if (is_src) { if (a.src_radii) radius = a.src_radii[j]; }
+        else        { if (a.tgt_radii) radius = a.tgt_radii[j]; }
+    }
+    const uint64_t key = particle_key<T, D, EXT>(a, x, radius);
+    keys[i] = a.pack_idbits > 0 ? pack_key<D, EXT>(key, a.pack_drop, a.pack_idbits, (uint64_t) i) : key;
 }
 
 // ---------------------------------------------------------------------------
@@ -331,17 +350,10 @@ __global__ __launch_bounds__(256) void keygen_kernel(KeygenArgs<T, D> a, uint64_
 // levels goes back to full keys (rekey_full_kernel + the pair sort) at that point.
 // ---------------------------------------------------------------------------
 
-template <class T, int D>
-struct RekeyArgs {
-    const T *packed;          // [n][PackStride<D>] coordinates by srcntgt id
-    const T *rootbox;         // device root box or null
-    T bbox_min[D], bbox_max[D];
-    int L;
-};
-
-template <class T, int D>
+// ids (and, with keys_out, the full keys) of the particles in their current order
+template <class T, int D, bool EXT>
 __global__ __launch_bounds__(256) void rekey_full_kernel(int64_t n, const uint64_t *pk, uint64_t id_mask,
-        RekeyArgs<T, D> a, uint32_t *ids_out, uint64_t *keys_out)
+        KeygenArgs<T, D> a, const T *__restrict__ packed, uint32_t *ids_out, uint64_t *keys_out)
 {
     const int64_t p = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
@@ -349,17 +361,87 @@ __global__ __launch_bounds__(256) void rekey_full_kernel(int64_t n, const uint64
     ids_out[p] = id;
     if (!keys_out) return;
     constexpr int PS = PackStride<D>::value;
-    uint64_t kt = 0;
+    T x[D];
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) x[ax] = packed[(int64_t) id * PS + ax];
+    T radius = (T) 0;
+    if (EXT) {
+        if ((int64_t) id < a.nsources) { if (a.src_radii) radius = a.src_radii[id]; }
+        else                           { if (a.tgt_radii) radius = a.tgt_radii[id - a.nsources]; }
+    }
+    keys_out[p] = particle_key<T, D, EXT>(a, x, radius);
+}
+
+// ---------------------------------------------------------------------------
+// Depth probe: cells of level k of (a sample of) the particles.  The densest cell and
+// the ratio of occupied cells between levels k and k-1 (the dimension of the set the
+// points lie on, at that scale) give the depth estimate that decides how many key bits
+// are sorted up front -- N alone has to assume a surface.
+// ---------------------------------------------------------------------------
+
+template <class T, int D>
+__global__ __launch_bounds__(256) void depth_probe_kernel(KeygenArgs<T, D> a, int64_t nsample, int64_t stride,
+                                                          int k, uint32_t *hist)
+{
+    const int64_t sidx = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (sidx >= nsample) return;
+    const int64_t i = sidx * stride;
+    const bool is_src = i < a.nsources;
+    const int64_t j = is_src ? i : i - a.nsources;
+    uint64_t cell = 0;
 #pragma unroll
     for (int ax = 0; ax < D; ++ax) {
-        const T x = a.packed[(int64_t) id * PS + ax];
+        const T x = is_src ? a.src[ax][j * a.src_stride] : a.tgt[ax][j * a.tgt_stride];
         const T gmin = a.rootbox ? a.rootbox[ax] : a.bbox_min[ax];
         const T gext = (a.rootbox ? a.rootbox[3 + ax] : a.bbox_max[ax]) - gmin;
-        const uint32_t v = (uint32_t) (((x - gmin) / gext) * (T) (1u << a.L));     // keygen_kernel
-        const uint32_t m = (a.L >= 32) ? v : (v & ((1u << a.L) - 1u));
-        kt |= spread_bits<D>(m) << (D - 1 - ax);
+        uint32_t v = (uint32_t) (((x - gmin) / gext) * (T) (1u << k));
+        v = v < (1u << k) ? v : (1u << k) - 1u;
+        cell |= spread_bits<D>(v) << (D - 1 - ax);
     }
-    keys_out[p] = kt;
+    atomicAdd(&hist[cell], 1u);
+}
+
+__global__ __launch_bounds__(256) void prefix_to_hist_kernel(const int64_t *prefix, int64_t ncells, uint32_t *hist)
+{
+    const int64_t c = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncells) return;
+    const int64_t w = prefix[c + 1] - prefix[c];
+    hist[c] = w > 0x7fffffff ? 0x7fffffffu : (uint32_t) w;
+}
+
+// out[0] = largest cell count, out[1] = occupied cells, out[2] = occupied parent cells
+__global__ __launch_bounds__(256) void depth_probe_reduce_kernel(const uint32_t *hist, int64_t ncells, int C,
+                                                                 uint32_t *out)
+{
+    uint32_t cmax = 0, occ = 0, occp = 0;
+    for (int64_t g = (int64_t) blockIdx.x * 256 + threadIdx.x; g * C < ncells; g += (int64_t) gridDim.x * 256) {
+        bool any = false;
+        for (int c = 0; c < C; ++c) {
+            const uint32_t h = hist[g * C + c];
+            cmax = h > cmax ? h : cmax;
+            occ += h ? 1u : 0u;
+            any = any || h;
+        }
+        occp += any ? 1u : 0u;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(cmax, off, 64);
+        cmax = o > cmax ? o : cmax;
+        occ += __shfl_xor(occ, off, 64);
+        occp += __shfl_xor(occp, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&out[0], cmax);
+        atomicAdd(&out[1], occ);
+        atomicAdd(&out[2], occp);
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_ids_kernel(int64_t n, const uint64_t *pk, uint64_t id_mask,
+                                                         uint32_t *ids)
+{
+    const int64_t p = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (p < n) ids[p] = (uint32_t) (pk[p] & id_mask);
 }
 
 // ---------------------------------------------------------------------------
@@ -564,6 +646,7 @@ struct BuildArgs {
     int32_t max_weight;
     int level;                  // level being built
     int L, capbits;
+    int idshift;                // packed keys: the key proper is keys[i] >> idshift (the id rides below)
     int b0, nprev;              // boxes of level-1: [b0, b0+nprev)
     int new_level_start;
     int adaptive;
@@ -840,7 +923,7 @@ __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState
                         will_split = range_weight(a, s, e) > a.max_weight;
                     if (lr - 1 < a.L && e > s && !skipped && will_split) {
                         const int pshift = a.capbits + D * (a.L - (lr - 1));
-                        prefix = (pshift >= 64) ? 0 : (a.keys[s] >> pshift);
+                        prefix = (pshift >= 64) ? 0 : ((a.keys[s] >> a.idshift) >> pshift);
                         const int cshift = a.capbits + D * (a.L - lr);
                         // first position whose key is > tgt (upper bound); a lower bound
                         // of ck is the upper bound of ck - 1
@@ -876,7 +959,7 @@ __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState
                 for (int k = 0; k < SL_SUB; ++k) {
                     if (lo_[k] < shi[k]) {
                         const int mid = lo_[k] + ((shi[k] - lo_[k]) >> 1);
-                        if (a.keys[mid] <= tgt_[k]) lo_[k] = mid + 1; else shi[k] = mid;
+                        if ((a.keys[mid] >> a.idshift) <= tgt_[k]) lo_[k] = mid + 1; else shi[k] = mid;
                         any = true;
                     }
                 }
@@ -2344,8 +2427,14 @@ int fixup_launch(bt_context *ctx, TreeState *st)
         BT_HIP_CHECK(hipMemsetAsync(st->fix_flags.get(), 0, sizeof(SegSortFlags), ctx->stream));
     }
     const unsigned wgrid = (unsigned) div_up(st->nboxes * 32, 256);
+    if (st->pk && can_be_huge) {
+        // runs of any length (particles stuck in a split box): the host may have to take the
+        // global route, which works on the id arrays -- unpack them first (12 bytes per
+        // particle, 0.3 ms at 10^8) and order them in place
+        unpack_ids_kernel<<<(unsigned) div_up(N, 256), 256, 0, ctx->stream>>>(N, st->pk, st->pk_mask, st->ids);
+        st->pk = nullptr;
+    }
     if (st->pk) {
-        if (can_be_huge) { set_error("internal: packed keys with runs beyond the workgroup sort"); return BT_ERR_INTERNAL; }
         segment_sort_wave_kernel<true><<<wgrid, 256, 0, ctx->stream>>>(
             (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_haschild.get(),
             st->ids, st->fix_large_list.get(), st->fix_flags.get(), st->pk, st->pk_mask);
@@ -2391,6 +2480,10 @@ int fixup_finish(bt_context *ctx, TreeState *st)
                 st->box_count.get(), st->ids, nullptr, 0);
         BT_HIP_CHECK(hipGetLastError());
     } else {
+        if (!st->ids_other) {          // (packed keys: the second id buffer was never needed)
+            BT_CHECK(st->ids_b.alloc(ctx->pool, N));
+            st->ids_other = st->ids_b.get();
+        }
         uint32_t *ids = st->ids, *ids_other = st->ids_other;
         Buf<uint32_t> fk_a, fk_b;
         BT_CHECK(fk_a.alloc(ctx->pool, N));
@@ -2462,23 +2555,92 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         BT_CHECK(bt::d2h(ctx, st->h_rootbox, st->rootbox.get(), 8 * sizeof(T), /*persistent=*/true));
     }
 
-    // ---- how deep will the tree get?  Points on a (D-1)-dimensional set (surfaces are the
-    // deep case in practice) fill 2^(D-1) children per split, plus two levels of slack; a
-    // sharded build is as deep as the GLOBAL point set makes it -------------------------------
+    // ---- key generator arguments (also the depth probe's and the re-keying kernel's) -------
+    KeygenArgs<T, D> ka{};
+    for (int ax = 0; ax < D; ++ax) {
+        ka.src[ax] = (const T *) p.sources[ax];
+        ka.tgt[ax] = (const T *) p.targets[ax];
+        ka.bbox_min[ax] = (T) p.bbox_min[ax];
+        ka.bbox_max[ax] = (T) p.bbox_max[ax];
+    }
+    ka.rootbox = (const T *) st->rootbox.get();
+    ka.src_radii = (const T *) p.source_radii;
+    ka.tgt_radii = (const T *) p.target_radii;
+    ka.nsources = st->nsources;
+    ka.n = N;
+    ka.src_stride = p.source_stride > 0 ? p.source_stride : 1;
+    ka.tgt_stride = p.target_stride > 0 ? p.target_stride : 1;
+    ka.stick_out_factor = (T) p.stick_out_factor;
+    ka.L = st->L;
+    ka.norm = p.extent_norm;
+    {
+        // margin at level l: (stick_out_factor / 2) * extent * 2^-l; rounding of the
+        // cell assignment, the centre and the limit: a few spacings of T at the
+        // magnitude of the coordinates.  Require margin >= 128 spacings.
+        double scale = std::fabs(p.root_extent);
+        for (int ax = 0; ax < D; ++ax)
+            scale = std::max(scale, std::max(std::fabs(p.bbox_min[ax]), std::fabs(p.bbox_max[ax])));
+        const double eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
+        const double ratio = p.stick_out_factor * p.root_extent / (256.0 * eps * scale);
+        int skip = 0;
+        // (extents only; with compute_root_box there are none and the root box is not
+        // known here)
+        if (EXT && ratio > 1.0) skip = (int) std::floor(std::log2(ratio));
+        point_skip_raw = std::max(0, skip);
+        ka.point_skip_levels = std::max(0, std::min(skip, st->L));
+    }
+
+    // ---- how deep will the tree get?  From N alone: points on a (D-1)-dimensional set
+    // (surfaces are the deep case in practice) fill 2^(D-1) children per split, plus two
+    // levels of slack.  Large builds look first (depth probe): the densest level-k cell of a
+    // sample of the particles -- of the global histogram for a sharded build -- and the
+    // dimension of the occupied cells; the smaller of the two estimates counts.  A tree
+    // that turns out deeper still builds (the level loop sorts the remaining bits when it
+    // gets there), it only costs those extra passes.
     int est_levels = st->L;
     if (!p.refine_weights) {
-        double npts = (double) N;
-        if (p.top_cell_prefix) {
-            int64_t total = 0;
-            BT_CHECK(bt::d2h(ctx, &total, p.top_cell_prefix + ((int64_t) 1 << (D * p.top_level)), 8));
-            BT_CHECK(bt::sync_stream(ctx));
-            npts = (double) total;
-        }
-        const double per_leaf = std::max(1.0, npts / std::max(1, p.max_leaf_refine_weight));
+        const double per_leaf = std::max(1.0, (double) N / std::max(1, p.max_leaf_refine_weight));
         const int fan = D > 1 ? D - 1 : 1;
-        est_levels = (int) std::ceil(std::log2(per_leaf) / fan) + 2;
+        if (!p.top_cell_prefix) est_levels = (int) std::ceil(std::log2(per_leaf) / fan) + 2;
+        static const bool probe_off = [] { const char *e = getenv("BT_NO_DEPTH_PROBE"); return e && atoi(e); }();
+        const bool probe = !probe_off && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED
+            && (p.top_cell_prefix || N >= ((int64_t) 1 << 20));
+        if (probe) {
+            int k = p.top_cell_prefix ? p.top_level : (D == 3 ? 4 : D == 2 ? 6 : 12);
+            k = std::min(k, st->L);
+            const int64_t ncells = (int64_t) 1 << (D * k);
+            const int64_t nsample = p.top_cell_prefix ? 0 : std::min<int64_t>(N, (int64_t) 1 << 17);
+            const int64_t stride = nsample > 0 ? N / nsample : 1;
+            Buf<uint32_t> hist;
+            BT_CHECK(hist.alloc(ctx->pool, ncells + 4));
+            BT_HIP_CHECK(hipMemsetAsync(hist.get(), 0, (size_t) (ncells + 4) * 4, ctx->stream));
+            if (p.top_cell_prefix)
+                prefix_to_hist_kernel<<<(unsigned) div_up(ncells, 256), 256, 0, ctx->stream>>>(
+                    p.top_cell_prefix, ncells, hist.get());
+            else
+                depth_probe_kernel<T, D><<<(unsigned) div_up(nsample, 256), 256, 0, ctx->stream>>>(
+                    ka, nsample, stride, k, hist.get());
+            depth_probe_reduce_kernel<<<(unsigned) std::min<int64_t>(div_up(ncells / C, 256), 256), 256, 0,
+                                        ctx->stream>>>(hist.get(), ncells, k > 0 ? C : 1, hist.get() + ncells);
+            BT_HIP_CHECK(hipGetLastError());
+            uint32_t h_probe[3] = {0, 0, 0};
+            BT_CHECK(bt::d2h(ctx, h_probe, hist.get() + ncells, sizeof(h_probe)));
+            BT_CHECK(bt::sync_stream(ctx));
+            ctx->n_host_syncs++;
+            // largest cell: the sample's count scaled up, with three standard deviations
+            double cmax = (double) h_probe[0];
+            if (nsample > 0) cmax = (cmax + 3.0 * std::sqrt(cmax)) * ((double) N / (double) (nsample));
+            const double ratio = h_probe[2] > 0 ? (double) h_probe[1] / (double) h_probe[2] : 1.0;
+            // dimension of the occupied set at this scale, never below a surface's
+            int pfan = (int) std::floor(std::log2(std::max(1.0, ratio)) + 0.2);
+            pfan = std::max(fan, std::min(D, pfan));
+            const int est_probe = k + (int) std::ceil(std::log2(std::max(
+                1.0, cmax / std::max(1, p.max_leaf_refine_weight))) / pfan) + 2;
+            est_levels = std::min(est_levels, est_probe);
+        }
+        est_levels = std::max(1, std::min(est_levels, st->L));
     }
-    // ---- packed keys (see rekey_full_kernel): path bits of Lk levels over the id ---------------
+    // ---- packed keys (see rekey_full_kernel): path bits of Lk levels (and the cap) over the id --
     bool packed = false;
     int pk_idbits = 0, pk_levels = 0;
     {
@@ -2487,16 +2649,16 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         const char *e_fused = getenv("BT_FUSED_LEAVES"), *e_full = getenv("BT_FULL_SORT");
         int idbits = 1;
         while (((int64_t) 1 << idbits) < N) ++idbits;
-        const int lk_max = std::min(st->L, (64 - idbits) / D);
+        const int lk_max = std::min(st->L, (64 - idbits - st->capbits) / D);
         if (!(e_off && atoi(e_off)) && !(e_fused && atoi(e_fused)) && !(e_full && atoi(e_full))
-                && !EXT && !p.refine_weights && p.kind == BT_KIND_ADAPTIVE
-                && p.max_leaf_refine_weight <= SEG_BLOCK_MAX && N >= 2
+                && !p.refine_weights && p.kind == BT_KIND_ADAPTIVE
+                && (EXT || p.max_leaf_refine_weight <= SEG_BLOCK_MAX) && N >= 2
                 && lk_max >= 1 && lk_max >= est_levels - 1) {
             int lk = std::min(lk_max, std::max(est_levels, 1));
             // the passes are whole digits: take the levels they cover anyway
             int rb = 8;
-            const int np = bt::radix_sort_keys_plan(D * lk, &rb);
-            lk = std::min(lk_max, std::max(lk, np * rb / D));
+            const int np = bt::radix_sort_keys_plan(D * lk + st->capbits, &rb);
+            lk = std::min(lk_max, std::max(lk, (np * rb - st->capbits) / D));
             if (e_lev && atoi(e_lev) > 0) lk = std::min(lk, atoi(e_lev));
             packed = true;
             pk_idbits = idbits;
@@ -2510,46 +2672,14 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     BT_CHECK(st->ids_a.alloc(ctx->pool, N));
     if (!packed) BT_CHECK(st->ids_b.alloc(ctx->pool, N));
     if (N > 0) {
-        KeygenArgs<T, D> ka;
-        for (int ax = 0; ax < D; ++ax) {
-            ka.src[ax] = (const T *) p.sources[ax];
-            ka.tgt[ax] = (const T *) p.targets[ax];
-            ka.bbox_min[ax] = (T) p.bbox_min[ax];
-            ka.bbox_max[ax] = (T) p.bbox_max[ax];
-        }
-        ka.rootbox = (const T *) st->rootbox.get();
-        ka.src_radii = (const T *) p.source_radii;
-        ka.tgt_radii = (const T *) p.target_radii;
-        ka.nsources = st->nsources;
-        ka.n = N;
-        ka.src_stride = p.source_stride > 0 ? p.source_stride : 1;
-        ka.tgt_stride = p.target_stride > 0 ? p.target_stride : 1;
-        ka.stick_out_factor = (T) p.stick_out_factor;
-        ka.L = st->L;
-        ka.norm = p.extent_norm;
-        ka.pack_idbits = packed ? pk_idbits : 0;
-        ka.pack_drop = packed ? D * (st->L - pk_levels) : 0;
-        {
-            // margin at level l: (stick_out_factor / 2) * extent * 2^-l; rounding of the
-            // cell assignment, the centre and the limit: a few spacings of T at the
-            // magnitude of the coordinates.  Require margin >= 128 spacings.
-            double scale = std::fabs(p.root_extent);
-            for (int ax = 0; ax < D; ++ax)
-                scale = std::max(scale, std::max(std::fabs(p.bbox_min[ax]), std::fabs(p.bbox_max[ax])));
-            const double eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
-            const double ratio = p.stick_out_factor * p.root_extent / (256.0 * eps * scale);
-            int skip = 0;
-            // (extents only; with compute_root_box there are none and the root box is not
-            // known here)
-            if (EXT && ratio > 1.0) skip = (int) std::floor(std::log2(ratio));
-            point_skip_raw = std::max(0, skip);
-            ka.point_skip_levels = std::max(0, std::min(skip, st->L));
-        }
+        KeygenArgs<T, D> kg = ka;
+        kg.pack_idbits = packed ? pk_idbits : 0;
+        kg.pack_drop = packed ? D * (st->L - pk_levels) : 0;
         const unsigned blocks = (unsigned) div_up(N, 256);
         BT_CHECK(st->packed.alloc(ctx->pool, N * PackStride<D>::value * (int64_t) sizeof(T)));
-        T *packed = (T *) st->packed.get();
-        if (EXT) keygen_kernel<T, D, true><<<blocks, 256, 0, ctx->stream>>>(ka, st->keys_a.get(), packed);
-        else keygen_kernel<T, D, false><<<blocks, 256, 0, ctx->stream>>>(ka, st->keys_a.get(), packed);
+        T *packed_coords = (T *) st->packed.get();
+        if (EXT) keygen_kernel<T, D, true><<<blocks, 256, 0, ctx->stream>>>(kg, st->keys_a.get(), packed_coords);
+        else keygen_kernel<T, D, false><<<blocks, 256, 0, ctx->stream>>>(kg, st->keys_a.get(), packed_coords);
         BT_HIP_CHECK(hipGetLastError());
     }
     BT_CHECK(mark(ctx, st, "keygen"));
@@ -2587,7 +2717,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     uint64_t *keys_cur = st->keys_a.get(), *keys_oth = st->keys_b.get();
     if (packed) {
         bool in_b = false;
-        BT_CHECK(bt::radix_sort_keys(ctx, keys_cur, keys_oth, N, pk_idbits, pk_idbits + D * pk_levels, &in_b));
+        BT_CHECK(bt::radix_sort_keys(ctx, keys_cur, keys_oth, N, pk_idbits,
+                                     pk_idbits + st->capbits + D * pk_levels, &in_b));
         if (in_b) std::swap(keys_cur, keys_oth);
         keys = keys_cur;
         ids = st->ids_a.get(); ids_other = nullptr;       // filled by the fix-up
@@ -2668,7 +2799,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         a.box_level = st->box_level.get(); a.box_haschild = st->box_haschild.get();
         a.status = ctx->d_status;
         a.max_weight = p.max_leaf_refine_weight;
-        a.capbits = packed ? pk_idbits : st->capbits;     // (packed: the id bits sit where the cap would)
+        a.capbits = st->capbits;
+        a.idshift = packed ? pk_idbits : 0;
         a.adaptive = p.kind != BT_KIND_NON_ADAPTIVE;
         a.top_level = p.top_level;
         a.top_prefix = p.top_cell_prefix;
@@ -2727,15 +2859,16 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     // Packed keys -> (full key, id) arrays in the current order: the tree got deeper than
     // the packed path bits reach (with_keys), or the continuation below needs the ids.
     auto unpack_keys = [&](bool with_keys) -> int {
-        RekeyArgs<T, D> ra{};
-        ra.packed = (const T *) st->packed.get();
-        ra.rootbox = (const T *) st->rootbox.get();
-        for (int ax = 0; ax < D; ++ax) { ra.bbox_min[ax] = (T) p.bbox_min[ax]; ra.bbox_max[ax] = (T) p.bbox_max[ax]; }
-        ra.L = st->L;
         if (!st->ids_b.get()) BT_CHECK(st->ids_b.alloc(ctx->pool, N));
         ids = st->ids_a.get(); ids_other = st->ids_b.get();
-        rekey_full_kernel<T, D><<<(unsigned) div_up(N, 256), 256, 0, ctx->stream>>>(
-            N, keys_cur, ((uint64_t) 1 << pk_idbits) - 1, ra, ids, with_keys ? keys_oth : nullptr);
+        const uint64_t mask = ((uint64_t) 1 << pk_idbits) - 1;
+        const unsigned nblk = (unsigned) div_up(N, 256);
+        if (EXT)
+            rekey_full_kernel<T, D, true><<<nblk, 256, 0, ctx->stream>>>(
+                N, keys_cur, mask, ka, (const T *) st->packed.get(), ids, with_keys ? keys_oth : nullptr);
+        else
+            rekey_full_kernel<T, D, false><<<nblk, 256, 0, ctx->stream>>>(
+                N, keys_cur, mask, ka, (const T *) st->packed.get(), ids, with_keys ? keys_oth : nullptr);
         BT_HIP_CHECK(hipGetLastError());
         if (with_keys) std::swap(keys_cur, keys_oth);
         packed = false;

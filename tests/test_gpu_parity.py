@@ -126,6 +126,39 @@ def test_packed_key_build_modes(actx, mode, dims, n, mpb, monkeypatch):
     build_both(actx, oracle, pts, max_particles_in_box=mpb, trav_kw={})
     tg = [rng.standard_normal(n // 3 + 1) for _ in range(dims)]
     build_both(actx, oracle, pts, targets=tg, max_particles_in_box=mpb)
+    # extents: the cap rides between the path bits and the id
+    radii = 2.0 ** rng.uniform(-10, 0, len(tg[0])) * 0.1
+    for norm in ("linf", "l2"):
+        build_both(actx, oracle, pts, targets=tg, max_particles_in_box=mpb, target_radii=radii,
+                   stick_out_factor=0.25, extent_norm=norm, trav_kw={} if norm == "linf" else None)
+    if n > 1000:
+        sr = 2.0 ** rng.uniform(-12, -3, n) * 0.05
+        build_both(actx, oracle, pts, targets=tg, max_particles_in_box=mpb, source_radii=sr,
+                   target_radii=radii, stick_out_factor=0.1)
+
+
+@pytest.mark.parametrize("kind", ["uniform", "surface", "blob"])
+def test_depth_probe_large_build(actx, kind):
+    """Builds of 2^20 particles and more look at a sample of the particles before they choose
+    how many key bits to sort (depth probe): volume-filling, surface and clustered clouds,
+    the last one deeper than the probe's estimate can cover (back to full keys mid-build)."""
+    from oracle import oracle
+    rng = np.random.default_rng(5)
+    n = (1 << 20) + 12345
+    if kind == "uniform":
+        pts = [rng.random(n) for _ in range(3)]
+    elif kind == "surface":
+        v = rng.standard_normal((3, n))
+        v /= np.sqrt((v * v).sum(axis=0))
+        pts = [np.ascontiguousarray(v[i]) for i in range(3)]
+    else:
+        pts = [np.concatenate([rng.random(n - 200000), 0.5 + 1e-7 * rng.standard_normal(200000)])
+               for _ in range(3)]
+    build_both(actx, oracle, pts, max_particles_in_box=32)
+    tg = [rng.random(n // 8) for _ in range(3)]
+    radii = 2.0 ** rng.uniform(-10, 0, n // 8) * 2.0 ** -7
+    build_both(actx, oracle, pts, targets=tg, max_particles_in_box=32, target_radii=radii,
+               stick_out_factor=0.25)
 
 
 @pytest.mark.parametrize("n", [1, 777, 10**6])
