@@ -353,6 +353,15 @@ def main():
     torch.cuda.synchronize()
     xinfo = {}
 
+    # N > 1 over RCCL, point particles: the library's own multi-GPU entries.  Other process
+    # groups (gloo: ranks that share a GPU) and workloads with separate targets / extents
+    # go through the torch implementation of the same steps.
+    native_comm = None
+    if (distributed and backend == "nccl" and targets is None and not build_kw
+            and os.environ.get("BOXTREE_HIP_NATIVE_MGPU", "1") != "0"):
+        from boxtree_amd.distributed import native as nat
+        native_comm = nat.rccl_comm(actx, dist)
+
     stage_acc: dict[str, float] = {}
     sort_ms = []
     info = {}
@@ -365,6 +374,27 @@ def main():
         from extra, untimed steps after the timed region (instrumented=True)."""
         p_, t_, kw_ = particles, targets, build_kw
         xs = None
+        if native_comm is not None:
+            # steps 1-6 behind the C ABI (bt_mgpu_*): exchange, build, numbering, local
+            # essential tree, lists of the rank's own boxes
+            from boxtree_amd.distributed import native as nat
+            p_, kw_, xs = nat.exchange_particles(actx, native_comm, particles, args.mpb)
+            last_exchange.update(bytes_sent=int(xs["bytes_sent"]), owned=int(len(p_[0])),
+                                 a2a_ms=xs["a2a_ms"])
+            tree, _ = tb(actx, p_, max_particles_in_box=args.mpb, **kw_)
+            st = _lib.SortStats()
+            actx.lib.bt_get_sort_stats(actx.handle, st)
+            num = nat.number_sharded_tree(actx, native_comm, tree)
+            gtree, let = nat.build_local_essential_tree(actx, native_comm, tree, num)
+            trav, _ = tg(actx, gtree, _target_boxes_mask=let["target_boxes_mask"],
+                         _active_level_ranges=let["active_level_ranges"])
+            xinfo.update(let_nboxes_rank0=int(let["nboxes"]),
+                         halo_boxes_received_rank0=int(let["halo_boxes_received"]),
+                         global_nboxes=int(num["nboxes"]),
+                         sharded_traversal="bt_mgpu_* entries: local essential tree (halo of "
+                                           "neighbouring cells); lists for own boxes + shared top levels")
+            nboxes, nlevels = int(num["nboxes"]), int(gtree.nlevels)
+            return finish_step(st, trav, nboxes, nlevels, instrumented)
         if distributed:
             # the exchange is part of the path (and of the timed step) for N > 1
             from boxtree_amd.distributed import exchange_particles
@@ -375,7 +405,6 @@ def main():
         tree, _ = tb(actx, p_, targets=t_, max_particles_in_box=args.mpb, **kw_)
         st = _lib.SortStats()
         actx.lib.bt_get_sort_stats(actx.handle, st)
-        times = {}
         if distributed and xs["plan"] is not None:
             # global box numbers, box arrays of all ranks, then the interaction lists
             # of this rank's boxes (cross-boundary lists included)
@@ -401,6 +430,10 @@ def main():
         else:
             trav, _ = tg(actx, tree)
             nboxes, nlevels = int(tree.nboxes), int(tree.nlevels)
+        return finish_step(st, trav, nboxes, nlevels, instrumented)
+
+    def finish_step(st, trav, nboxes, nlevels, instrumented):
+        times = {}
         if instrumented:
             times = dict(tb.last_stage_times)       # build and traversal stages
         info.update(nboxes=nboxes, nlevels=nlevels,
@@ -579,6 +612,8 @@ def main():
         if args.cpu_sample > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_sample, args.mpb)
         emit(out)
+    if native_comm is not None:
+        native_comm.close()
     if distributed:
         dist.destroy_process_group()
 
@@ -597,7 +632,7 @@ def exchange_report(torch, dist, device, world, elapsed, n_local, last_exchange,
     """What the N ranks did, gathered on every rank (collective): the maximum of the timed
     region, the total particle count, the bytes that crossed the links, the device time of
     the payload all-to-all and the owned-particle imbalance after the exchange."""
-    a2a_ms = 0.0
+    a2a_ms = float(last_exchange.get("a2a_ms", 0.0))
     if last_exchange.get("events"):
         a2a_ms = float(sum(e0.elapsed_time(e1) for e0, e1 in last_exchange["events"]))
     mine = torch.tensor([elapsed, float(n_local), float(last_exchange.get("bytes_sent", 0)),

@@ -167,14 +167,43 @@ class AqTree(ct.Structure):
 class MgpuParams(ct.Structure):
     _fields_ = [("dims", ct.c_int32), ("coord_kind", ct.c_int32), ("n", ct.c_int64),
                 ("coords", P3), ("top_level", ct.c_int32),
-                ("max_particles_in_box", ct.c_int64)]
+                ("max_particles_in_box", ct.c_int64), ("alloc", vp), ("alloc_user", vp)]
 
 
 class MgpuShard(ct.Structure):
     _fields_ = [("n_owned", ct.c_int64), ("points", vp),
                 ("bbox_min", ct.c_double * 3), ("bbox_max", ct.c_double * 3),
                 ("root_extent", ct.c_double), ("top_level", ct.c_int32),
-                ("top_cell_prefix", vp), ("bytes_sent", ct.c_int64), ("rounds", ct.c_int32)]
+                ("top_cell_prefix", vp), ("bytes_sent", ct.c_int64), ("rounds", ct.c_int32),
+                ("a2a_ms", ct.c_float)]
+
+
+class MgpuLocalTree(ct.Structure):
+    _fields_ = [("dims", ct.c_int32), ("coord_kind", ct.c_int32), ("nboxes", ct.c_int64),
+                ("aligned_nboxes", ct.c_int64), ("nlevels", ct.c_int32),
+                ("level_start_box_nrs", ct.POINTER(ct.c_int32)), ("box_centers", vp),
+                ("box_levels", vp), ("box_flags", vp), ("nsources", ct.c_int64),
+                ("ntargets", ct.c_int64)]
+
+
+class MgpuNumbering(ct.Structure):
+    _fields_ = [("nlevels", ct.c_int32), ("level_start_box_nrs", ct.c_int32 * (BT_MAX_LEVELS + 2)),
+                ("deep_base", ct.c_int32 * (BT_MAX_LEVELS + 1)), ("nboxes", ct.c_int64),
+                ("nsources", ct.c_int64), ("ntargets", ct.c_int64),
+                ("source_offset", ct.c_int64), ("target_offset", ct.c_int64)]
+
+
+class MgpuLetSizes(ct.Structure):
+    _fields_ = [("nboxes", ct.c_int64), ("aligned_nboxes", ct.c_int64), ("nlevels", ct.c_int32),
+                ("level_start_box_nrs", ct.c_int32 * (BT_MAX_LEVELS + 2)),
+                ("active_level_ranges", (ct.c_int32 * 2) * (BT_MAX_LEVELS + 1)),
+                ("halo_boxes_sent", ct.c_int64), ("halo_boxes_received", ct.c_int64)]
+
+
+class MgpuLetArrays(ct.Structure):
+    _fields_ = [("box_centers", vp), ("box_parent_ids", vp), ("box_child_ids", vp),
+                ("box_levels", vp), ("box_flags", vp), ("global_box_ids", vp),
+                ("target_boxes_mask", vp)]
 
 
 class Span(ct.Structure):
@@ -222,6 +251,9 @@ EXPORTED_SYMBOLS = [
     "bt_translation_classes",
     "bt_filter_targets_user_order", "bt_filter_targets_tree_order", "bt_link_point_sources",
     "bt_box_morton_paths", "bt_let_build", "bt_mgpu_exchange", "bt_mgpu_plan",
+    "bt_mgpu_comm_rccl", "bt_mgpu_local_group_create", "bt_mgpu_local_group_destroy",
+    "bt_mgpu_comm_local", "bt_mgpu_comm_destroy", "bt_mgpu_number", "bt_mgpu_let_build",
+    "bt_mgpu_let_export",
     "bt_dfs_order", "bt_partition_work", "bt_ancestor_mask", "bt_mark_list_boxes",
     "bt_local_particles", "bt_modify_target_flags", "bt_box_to_user_ranks",
     "bt_boxes_used_by_ranks",
@@ -277,8 +309,18 @@ def load():
     lib.bt_get_stage_times.argtypes = [vp, ct.POINTER(StageTimes)]
     lib.bt_traversal_build.argtypes = [vp, ct.POINTER(TravParams), ct.POINTER(TravSizes)]
     lib.bt_traversal_export.argtypes = [vp, ct.POINTER(TravArrays)]
-    lib.bt_mgpu_exchange.argtypes = [vp, vp, ct.c_int, ct.c_int, ct.POINTER(MgpuParams),
-                                     ct.POINTER(MgpuShard)]
+    lib.bt_mgpu_exchange.argtypes = [vp, vp, ct.POINTER(MgpuParams), ct.POINTER(MgpuShard)]
+    lib.bt_mgpu_comm_rccl.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp)]
+    lib.bt_mgpu_local_group_create.argtypes = [ct.c_int, ct.POINTER(vp)]
+    lib.bt_mgpu_local_group_destroy.argtypes = [vp]
+    lib.bt_mgpu_local_group_destroy.restype = None
+    lib.bt_mgpu_comm_local.argtypes = [vp, ct.c_int, ct.POINTER(vp)]
+    lib.bt_mgpu_comm_destroy.argtypes = [vp]
+    lib.bt_mgpu_comm_destroy.restype = None
+    lib.bt_mgpu_number.argtypes = [vp, vp, ct.POINTER(MgpuLocalTree), vp, ct.POINTER(MgpuNumbering)]
+    lib.bt_mgpu_let_build.argtypes = [vp, vp, ct.POINTER(MgpuLocalTree), vp,
+                                      ct.POINTER(MgpuNumbering), ct.c_int, ct.POINTER(MgpuLetSizes)]
+    lib.bt_mgpu_let_export.argtypes = [vp, ct.POINTER(MgpuLetArrays)]
     lib.bt_mgpu_plan.argtypes = [ct.c_int, ct.c_int, ct.c_int64, ct.c_int, vp, vp, vp]
     lib.bt_traversal_build_packed.argtypes = [vp, ct.POINTER(TravParams), ALLOC_FN, vp,
                                               ct.POINTER(TravPacked)]

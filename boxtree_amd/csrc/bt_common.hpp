@@ -74,6 +74,7 @@ private:
     struct Block { void *ptr; size_t size; bool used; };
     std::vector<Block> blocks_;
     size_t reserved_ = 0;
+    size_t purge_slack_ = (size_t) 1 << 30;
 };
 
 // RAII handle on a pool allocation.

@@ -1,29 +1,43 @@
-// Multi-GPU entry of the C ABI: the particle exchange of a sharded tree build over an
-// RCCL communicator the caller owns (one process per GPU).  The
-// reference builds its tree on one rank and broadcasts it
-// (boxtree/distributed/__init__.py:183-199); nothing here has a counterpart upstream.
+// Multi-GPU entries of the C ABI: a sharded tree build and the lists of a rank's own boxes,
+// one process (or thread) per GPU.  The reference builds its tree on
+// one rank and broadcasts it (boxtree/distributed/__init__.py:183-199); nothing here has a
+// counterpart upstream.
 //
-//   1. bounding box: local min/max, ncclAllReduce(min) over (min, -max)
+//   1. bounding box: local min/max, all-reduce(min) over (min, -max)
 //      -> the same root box on every rank (host arithmetic of tree_build.py:462-476);
-//   2. level-k Morton-cell histogram, ncclAllReduce(sum) -> every rank derives the same
+//   2. level-k Morton-cell histogram, all-reduce(sum) -> every rank derives the same
 //      top of the global tree and the same owner of every cell (bt_mgpu_plan);
 //   3. stable partition by owner that carries the coordinates (interleaved), one grouped
-//      ncclSend/ncclRecv round per 512 MiB of the largest peer message (a rank's own
-//      segment is a device copy): the all-to-all-v over the point-to-point xGMI links;
+//      send/recv round per 512 MiB of the largest peer message (a rank's own segment is
+//      a device copy): the all-to-all-v over the point-to-point xGMI links;
 //   4. the caller builds its subtrees with bt_tree_build on the returned shard
 //      (sources = points + axis, source_stride = dims, bbox_*, top_level,
-//      top_cell_prefix).
+//      top_cell_prefix);
+//   5. bt_mgpu_number: all-gather of the per-level box counts -> the numbers the rank's
+//      boxes carry in the global (single-GPU) tree, global level starts, particle offsets;
+//   6. bt_mgpu_let_build / _export: the local essential tree -- shared top levels (from the
+//      plan, no communication), the rank's own subtrees, and the subtrees of other ranks'
+//      cells within well_sep_is_n_away cells of its own, which their owners send as 16-byte
+//      records (Morton path, level, flags, global number) in one all-to-all-v.  Boxes are
+//      ordered by (level, Morton path) with one onesweep sort and linked by path lookup
+//      (bt_shard.hip), so the LET is the global tree restricted to its boxes.
 //
-// RCCL is bound at run time (dlopen of the librccl.so.1 already in the process, or the
-// system one), so the library itself has no link-time dependency on it.
+// Collectives go through a small communicator object (bt_mgpu_comm): RCCL (bound at run
+// time by dlopen of the librccl.so already in the process, no link-time dependency), or
+// ranks that are threads of one process and trade device pointers through a shared table
+// -- the latter exists so that the multi-rank logic of steps 1-6 can run, and be compared
+// with the single-GPU tree, on a box with one GPU (RCCL refuses two ranks on a device).
 #include "bt_common.hpp"
 #include "bt_prims.hpp"
+#include "bt_sort.hpp"
 
 #include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdlib>
+#include <mutex>
 #include <vector>
 
 using namespace bt;
@@ -80,10 +94,235 @@ Nccl &nccl()
 
 constexpr int64_t MESSAGE_LIMIT_BYTES = (int64_t) 512 << 20;   // see DESIGN.md (RCCL, > 1 GB)
 
+// ranks as threads of one process: a table of pointers and a generation barrier
+struct LocalGroup {
+    int n = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t gen = 0;
+    std::vector<const void *> ptr;
+    std::vector<const int64_t *> off, cnt;
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t g = gen;
+        if (++arrived == n) { arrived = 0; ++gen; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
+}  // namespace
+
+struct bt_mgpu_comm {
+    int kind = 0;                 // 0: RCCL, 1: threads of one process
+    int rank = 0, nranks = 1;
+    nccl_comm_t nccl = nullptr;
+    LocalGroup *group = nullptr;
+};
+
+namespace {
+
+enum { RED_SUM_I64 = 0, RED_MIN_F64 = 1 };
+
+// in-place all-reduce of a small device array (8-byte elements)
+int comm_all_reduce(bt_mgpu_comm *c, hipStream_t stream, void *dev, size_t count, int what)
+{
+    if (c->kind == 0) {
+        Nccl &nc = nccl();
+        BT_NCCL_CHECK(nc.AllReduce(dev, dev, count, what == RED_SUM_I64 ? NCCL_INT64 : NCCL_FLOAT64,
+                                   what == RED_SUM_I64 ? NCCL_SUM : NCCL_MIN, c->nccl, stream));
+        return BT_OK;
+    }
+    LocalGroup *g = c->group;
+    std::vector<int64_t> mine(count), res(count);
+    BT_HIP_CHECK(hipMemcpyAsync(mine.data(), dev, count * 8, hipMemcpyDeviceToHost, stream));
+    BT_HIP_CHECK(hipStreamSynchronize(stream));
+    g->ptr[c->rank] = mine.data();
+    g->barrier();
+    for (size_t i = 0; i < count; ++i) {
+        if (what == RED_SUM_I64) {
+            int64_t s = 0;
+            for (int q = 0; q < c->nranks; ++q) s += ((const int64_t *) g->ptr[q])[i];
+            res[i] = s;
+        } else {
+            double s = ((const double *) g->ptr[0])[i];
+            for (int q = 1; q < c->nranks; ++q) s = std::min(s, ((const double *) g->ptr[q])[i]);
+            memcpy(&res[i], &s, 8);
+        }
+    }
+    g->barrier();                 // every rank has read every vector
+    BT_HIP_CHECK(hipMemcpyAsync(dev, res.data(), count * 8, hipMemcpyHostToDevice, stream));
+    BT_HIP_CHECK(hipStreamSynchronize(stream));
+    return BT_OK;
+}
+
+// recv[q * bytes ...] = rank q's send[0 .. bytes)
+int comm_all_gather(bt_mgpu_comm *c, hipStream_t stream, const void *send, void *recv, size_t bytes)
+{
+    if (c->kind == 0) {
+        BT_NCCL_CHECK(nccl().AllGather(send, recv, bytes, NCCL_UINT8, c->nccl, stream));
+        return BT_OK;
+    }
+    LocalGroup *g = c->group;
+    BT_HIP_CHECK(hipStreamSynchronize(stream));
+    g->ptr[c->rank] = send;
+    g->barrier();
+    for (int q = 0; q < c->nranks; ++q)
+        BT_HIP_CHECK(hipMemcpyAsync((char *) recv + (size_t) q * bytes, g->ptr[q], bytes,
+                                    hipMemcpyDeviceToDevice, stream));
+    BT_HIP_CHECK(hipStreamSynchronize(stream));
+    g->barrier();
+    return BT_OK;
+}
+
+// all-to-all-v in bytes; offsets and counts are host arrays [nranks].  A rank's segment for
+// itself is a device copy (skipped when self_done: the caller wrote it in place).  `biggest`:
+// the largest peer-to-peer message of ANY rank (every rank runs the same number of rounds).
+int comm_all_to_all_v(bt_mgpu_comm *c, hipStream_t stream, const char *send, const int64_t *s_off,
+                      const int64_t *s_cnt, char *recv, const int64_t *r_off, const int64_t *r_cnt,
+                      int64_t biggest, bool self_done, int32_t *rounds_out)
+{
+    const int me = c->rank, n = c->nranks;
+    if (rounds_out) *rounds_out = 1;
+    if (!self_done && s_cnt[me] > 0)
+        BT_HIP_CHECK(hipMemcpyAsync(recv + r_off[me], send + s_off[me], (size_t) s_cnt[me],
+                                    hipMemcpyDeviceToDevice, stream));
+    if (c->kind == 1) {
+        LocalGroup *g = c->group;
+        BT_HIP_CHECK(hipStreamSynchronize(stream));
+        g->ptr[me] = send; g->off[me] = s_off; g->cnt[me] = s_cnt;
+        g->barrier();
+        for (int q = 0; q < n; ++q) {
+            if (q == me) continue;
+            const int64_t nb = g->cnt[q][me];
+            if (nb != r_cnt[q]) {
+                set_error("all-to-all-v: rank %d sends %lld bytes to rank %d, which expects %lld",
+                          q, (long long) nb, me, (long long) r_cnt[q]);
+                g->barrier();
+                return BT_ERR_INTERNAL;
+            }
+            if (nb > 0)
+                BT_HIP_CHECK(hipMemcpyAsync(recv + r_off[q], (const char *) g->ptr[q] + g->off[q][me],
+                                            (size_t) nb, hipMemcpyDeviceToDevice, stream));
+        }
+        BT_HIP_CHECK(hipStreamSynchronize(stream));
+        g->barrier();
+        return BT_OK;
+    }
+    if (biggest <= 0) return BT_OK;
+    Nccl &nc = nccl();
+    const int64_t rounds = std::max<int64_t>(1, div_up(biggest, MESSAGE_LIMIT_BYTES));
+    if (rounds_out) *rounds_out = (int32_t) rounds;
+    auto cut = [&](int64_t cnt, int64_t j) { return (j * cnt) / rounds; };
+    for (int64_t j = 0; j < rounds; ++j) {
+        BT_NCCL_CHECK(nc.GroupStart());
+        // (a failure inside the group still closes it: RCCL keeps an open group per thread)
+        auto in_group = [&]() -> int {
+            for (int peer = 0; peer < n; ++peer) {
+                if (peer == me) continue;
+                const int64_t s0 = cut(s_cnt[peer], j), s1 = cut(s_cnt[peer], j + 1);
+                const int64_t r0 = cut(r_cnt[peer], j), r1 = cut(r_cnt[peer], j + 1);
+                if (s1 > s0)
+                    BT_NCCL_CHECK(nc.Send(send + s_off[peer] + s0, (size_t) (s1 - s0), NCCL_UINT8, peer,
+                                          c->nccl, stream));
+                if (r1 > r0)
+                    BT_NCCL_CHECK(nc.Recv(recv + r_off[peer] + r0, (size_t) (r1 - r0), NCCL_UINT8, peer,
+                                          c->nccl, stream));
+            }
+            return BT_OK;
+        };
+        const int gs = in_group();
+        if (gs != BT_OK) { (void) nc.GroupEnd(); return gs; }
+        BT_NCCL_CHECK(nc.GroupEnd());
+    }
+    return BT_OK;
+}
+
 __global__ __launch_bounds__(256) void widen_hist_kernel(int64_t n, const int32_t *in, int64_t *out)
 {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = in[i];
+}
+
+// The top of the GLOBAL tree (levels 0..k), a pure function of the all-reduced level-k cell
+// histogram (kind "adaptive", point particles, unit weights: a box splits iff it holds more
+// than max_particles_in_box particles, tree_build_kernels.py:577-591; empty boxes pruned).
+// Paths are Morton paths, x most significant in every digit -- the order of the box numbers
+// within a level.
+struct TopPlan {
+    bool valid = false;
+    int D = 0, k = 0, nranks = 0;
+    int64_t mpb = 0;
+    std::vector<std::vector<int64_t>> counts;     // [k+1][C^lev]
+    std::vector<std::vector<char>> exists, split;
+    std::vector<std::vector<int32_t>> index;      // number of a box among the existing boxes of its level
+    std::vector<int32_t> nboxes;                  // [k+1]
+    std::vector<int32_t> owner;                   // [C^k]
+    std::vector<int64_t> prefix;                  // [C^k + 1]
+    double bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0}, root_extent = 0;
+};
+
+void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, TopPlan &pl)
+{
+    const int C = 1 << D;
+    const int64_t ncells = (int64_t) 1 << (D * k);
+    pl.D = D; pl.k = k; pl.mpb = mpb; pl.nranks = nranks;
+    pl.counts.assign((size_t) k + 1, {});
+    pl.counts[k].assign(hist, hist + ncells);
+    for (int lev = k - 1; lev >= 0; --lev) {
+        const int64_t n = (int64_t) 1 << (D * lev);
+        pl.counts[lev].assign((size_t) n, 0);
+        for (int64_t i = 0; i < n; ++i)
+            for (int m = 0; m < C; ++m) pl.counts[lev][i] += pl.counts[lev + 1][i * C + m];
+    }
+    std::vector<int64_t> unit_start((size_t) ncells);
+    pl.valid = mpb > 0;
+    if (mpb > 0) {
+        pl.exists.assign((size_t) k + 1, {});
+        pl.split.assign((size_t) k + 1, {});
+        pl.index.assign((size_t) k + 1, {});
+        pl.nboxes.assign((size_t) k + 1, 0);
+        pl.exists[0].assign(1, 1);
+        for (int lev = 0; lev <= k; ++lev) {
+            const int64_t n = (int64_t) 1 << (D * lev);
+            pl.split[lev].assign((size_t) n, 0);
+            pl.index[lev].assign((size_t) n, 0);
+            int32_t run = 0;
+            for (int64_t i = 0; i < n; ++i) {
+                pl.split[lev][i] = pl.exists[lev][i] && pl.counts[lev][i] > mpb;
+                run += pl.exists[lev][i] ? 1 : 0;
+                pl.index[lev][i] = run - 1;
+            }
+            pl.nboxes[lev] = run;
+            if (lev < k) {
+                pl.exists[lev + 1].assign((size_t) n * C, 0);
+                for (int64_t i = 0; i < n * C; ++i)
+                    pl.exists[lev + 1][i] = pl.split[lev][i / C] && pl.counts[lev + 1][i] > 0;
+            }
+        }
+        // frontier: the first cell of the top-tree leaf a cell lies in
+        for (int64_t c = 0; c < ncells; ++c) {
+            int leaf_level = k;
+            for (int lev = k - 1; lev >= 0; --lev)
+                if (!pl.split[lev][c >> (D * (k - lev))]) leaf_level = lev;
+            const int sh = D * (k - leaf_level);
+            unit_start[c] = (c >> sh) << sh;
+        }
+    } else {
+        for (int64_t c = 0; c < ncells; ++c) unit_start[c] = c;
+    }
+    // contiguous Morton ranges balanced by particle count: a cell goes to the rank whose
+    // ideal range contains its first particle
+    const int64_t total = pl.counts[0][0];
+    pl.prefix.assign((size_t) ncells + 1, 0);
+    for (int64_t c = 0; c < ncells; ++c) pl.prefix[c + 1] = pl.prefix[c] + hist[c];
+    pl.owner.assign((size_t) ncells, 0);
+    for (int64_t c = 0; c < ncells; ++c) {
+        const int64_t u = unit_start[c];
+        const int64_t o = (int64_t) (((__int128) pl.prefix[u] * nranks) / std::max<int64_t>(total, 1));
+        pl.owner[c] = (int32_t) std::min<int64_t>(o, nranks - 1);
+    }
 }
 
 }  // namespace
@@ -91,6 +330,15 @@ __global__ __launch_bounds__(256) void widen_hist_kernel(int64_t n, const int32_
 struct MgpuState {
     Buf<unsigned char> points;       // received particles, interleaved [n_owned][dims]
     Buf<int64_t> cell_prefix;        // [C^top_level + 1]
+    TopPlan plan;                    // of the last exchange on this context
+    hipEvent_t ev[2] = {nullptr, nullptr};   // around the payload all-to-all-v
+    ~MgpuState() { for (auto &e : ev) if (e) (void) hipEventDestroy(e); }
+    // local essential tree between bt_mgpu_let_build and bt_mgpu_let_export
+    Buf<uint64_t> let_paths;         // [B] level-major, Morton order within a level
+    Buf<int32_t> let_meta, let_gid;  // level | flags << 8; global box number
+    Buf<int8_t> let_mask;            // 1: lists are built for this box on this rank
+    int let_nlevels = 0, let_dims = 0, let_kind = 0;
+    std::vector<int32_t> let_level_starts;
 };
 
 void bt_free_mgpu_state(bt_context *ctx)
@@ -100,15 +348,253 @@ void bt_free_mgpu_state(bt_context *ctx)
     ctx->mgpu = nullptr;
 }
 
+namespace {
+
+MgpuState *mgpu_state(bt_context *ctx)
+{
+    if (!ctx->mgpu) ctx->mgpu = new MgpuState();
+    return ctx->mgpu;
+}
+
+constexpr int TOPMAX = 16;            // top levels a numbering kernel looks up by path
+
+struct NumberArgs {
+    int k, nlevels;
+    int32_t shift[BT_MAX_LEVELS + 1];  // deep levels: global = local + shift[level]
+    int32_t gstart[TOPMAX];            // shared top levels: global start of the level
+    int32_t toff[TOPMAX];              // ... and where its index table starts
+    const int32_t *index;              // concatenated index tables of the top levels
+    double bmin[3], root_extent;
+};
+
+// Morton path of a top box from its centre (box_paths_kernel of bt_shard.hip), then the
+// box's number in the global tree: position among the existing boxes of its level.
+template <class T, int D>
+__global__ __launch_bounds__(256) void number_boxes_kernel(int64_t nboxes, int64_t aligned,
+        const T *centers, const uint8_t *levels, NumberArgs a, int32_t *box_ids)
+{
+    const int64_t b = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (b >= nboxes) return;
+    const int level = levels[b];
+    if (level > a.k) { box_ids[b] = (int32_t) b + a.shift[level]; return; }
+    uint64_t path = 0;
+    const double scale = (double) (1ull << level);
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        const double t = ((double) centers[(int64_t) ax * aligned + b] - a.bmin[ax]) / a.root_extent * scale;
+        int64_t v = (int64_t) floor(t);
+        v = v < 0 ? 0 : (v >= (int64_t) scale ? (int64_t) scale - 1 : v);
+        for (int bit = 0; bit < level; ++bit)
+            path |= (uint64_t) ((v >> bit) & 1) << (D * bit + (D - 1 - ax));
+    }
+    box_ids[b] = a.gstart[level] + a.index[a.toff[level] + (int64_t) path];
+}
+
+// ---- local essential tree --------------------------------------------------------------------
+
+// does peer q need box b (a box below the ownership level in one of the cells q's lists reach)?
+struct NeedPred {
+    const uint64_t *paths;
+    const uint8_t *levels;
+    const uint64_t *need_bits;       // [ncells][nwords]: bit q of cell c
+    int64_t b0;                      // first deep box
+    int k, D, nwords, q;
+    __device__ int32_t operator()(int64_t i) const
+    {
+        const int64_t b = b0 + i;
+        const int lev = levels[b];
+        const uint64_t cell = paths[b] >> (D * (lev - k));
+        return (int32_t) ((need_bits[cell * nwords + (q >> 6)] >> (q & 63)) & 1ull);
+    }
+};
+
+// one 16-byte record per box: (path, level | flags << 8 | global id << 32)
+__global__ __launch_bounds__(256) void let_pack_kernel(int64_t n, NeedPred pr, const int32_t *pos,
+        const uint8_t *flags, const int32_t *gids, uint64_t *rec /* at the peer's offset */)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !pr(i)) return;
+    const int64_t b = pr.b0 + i;
+    const uint64_t meta = (uint64_t) pr.levels[b] | ((uint64_t) flags[b] << 8);
+    rec[2 * (int64_t) pos[i]] = pr.paths[b];
+    rec[2 * (int64_t) pos[i] + 1] = meta | ((uint64_t) (uint32_t) gids[b] << 32);
+}
+
+// deep boxes of the LET before the sort: this rank's own (contiguous in the local tree), then
+// the halo records; key = level << pathbits | path
+__global__ __launch_bounds__(256) void let_deep_kernel(int64_t n_mine, int64_t n_halo, int64_t b0,
+        const uint64_t *paths, const uint8_t *levels, const uint8_t *flags, const int32_t *gids,
+        const uint64_t *halo_rec, int pathbits, uint64_t *key, uint64_t *d_path, int32_t *d_meta,
+        int32_t *d_gid)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_mine + n_halo) return;
+    uint64_t path;
+    int32_t meta, gid;
+    if (i < n_mine) {
+        const int64_t b = b0 + i;
+        path = paths[b];
+        meta = (int32_t) levels[b] | ((int32_t) flags[b] << 8);
+        gid = gids[b];
+    } else {
+        const int64_t j = i - n_mine;
+        path = halo_rec[2 * j];
+        const uint64_t w = halo_rec[2 * j + 1];
+        meta = (int32_t) (w & 0xffffffffu);
+        gid = (int32_t) (w >> 32);
+    }
+    d_path[i] = path; d_meta[i] = meta; d_gid[i] = gid;
+    key[i] = ((uint64_t) (meta & 0xff) << pathbits) | path;
+}
+
+// sorted deep boxes into the LET arrays behind the top boxes; per level: count, and the first
+// and last position of this rank's own boxes (they are one contiguous run: its cells are one
+// Morton range)
+// (boundaries of the sorted order, one writer each: atomics on a dozen addresses from
+// millions of threads serialise in L2 -- 60 ms at 5*10^6 boxes)
+struct LetLevelInfo {
+    int32_t level_first[BT_MAX_LEVELS + 1];   // first sorted position of a level, or -1
+    int32_t mine_runs[BT_MAX_LEVELS + 1];     // runs of this rank's boxes in the level (must be <= 1)
+    int32_t mine_first[BT_MAX_LEVELS + 1];
+    int32_t mine_last[BT_MAX_LEVELS + 1];
+};
+
+__global__ __launch_bounds__(256) void let_place_kernel(int64_t nd, int64_t n_mine, int64_t ntop,
+        const uint32_t *order, const uint64_t *d_path, const int32_t *d_meta, const int32_t *d_gid,
+        uint64_t *all_paths, int32_t *all_meta, int32_t *all_gid, int8_t *mask, LetLevelInfo *info)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= nd) return;
+    const uint32_t o = order[i];
+    const int32_t meta = d_meta[o];
+    const bool mine = (int64_t) o < n_mine;
+    all_paths[ntop + i] = d_path[o];
+    all_meta[ntop + i] = meta;
+    all_gid[ntop + i] = d_gid[o];
+    mask[ntop + i] = mine ? 1 : 0;
+    const int lev = meta & 0xff;
+    int prev_lev = -1, next_lev = -1;
+    bool prev_mine = false, next_mine = false;
+    if (i > 0) { const uint32_t po = order[i - 1]; prev_lev = d_meta[po] & 0xff; prev_mine = (int64_t) po < n_mine; }
+    if (i + 1 < nd) { const uint32_t no = order[i + 1]; next_lev = d_meta[no] & 0xff; next_mine = (int64_t) no < n_mine; }
+    if (prev_lev != lev) info->level_first[lev] = (int32_t) i;
+    if (mine && !(prev_mine && prev_lev == lev)) {
+        info->mine_first[lev] = (int32_t) i;
+        atomicAdd(&info->mine_runs[lev], 1);
+    }
+    if (mine && !(next_mine && next_lev == lev)) info->mine_last[lev] = (int32_t) i;
+}
+
+__global__ __launch_bounds__(256) void let_split_meta_kernel(int64_t n, const int32_t *meta,
+                                                             uint8_t *levels, uint8_t *flags)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    levels[i] = (uint8_t) (meta[i] & 0xff);
+    flags[i] = (uint8_t) ((meta[i] >> 8) & 0xff);
+}
+
+// need[q] = my non-empty cells within `ring` cells (Chebyshev) of a cell owned by rank q --
+// the subtrees q's lists can reach -- as bit q of a word per cell.  The set of q's cells is
+// dilated by `ring` along every axis of the cell grid and intersected with my cells.
+void cells_needed_by(const TopPlan &pl, int rank, int ring, int nwords, std::vector<uint64_t> &bits,
+                     std::vector<char> &any_for_peer)
+{
+    const int D = pl.D, k = pl.k, n = 1 << k;
+    const int64_t ncells = (int64_t) 1 << (D * k);
+    bits.assign((size_t) ncells * nwords, 0);
+    any_for_peer.assign((size_t) pl.nranks, 0);
+    if (pl.nranks < 2) return;
+    // grid position <-> Morton index (x most significant in every digit), as tables
+    int64_t gridn = 1;
+    for (int ax = 0; ax < D; ++ax) gridn *= n;
+    std::vector<int32_t> cell_of_grid((size_t) gridn);
+    std::vector<int16_t> xyz_of_cell((size_t) ncells * 3, 0);
+    for (int64_t c = 0; c < ncells; ++c) {
+        int64_t gi = 0;
+        for (int ax = 0; ax < D; ++ax) {
+            int v = 0;
+            for (int bit = 0; bit < k; ++bit) v |= (int) ((c >> (D * bit + (D - 1 - ax))) & 1) << bit;
+            xyz_of_cell[(size_t) c * 3 + ax] = (int16_t) v;
+            gi = gi * n + v;
+        }
+        cell_of_grid[(size_t) gi] = (int32_t) c;
+    }
+    // for each of my non-empty cells: the owners of the cells within `ring`
+    for (int64_t c = 0; c < ncells; ++c) {
+        if (pl.owner[c] != rank || pl.counts[k][c] <= 0) continue;
+        int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (int ax = 0; ax < D; ++ax) {
+            const int v = xyz_of_cell[(size_t) c * 3 + ax];
+            lo[ax] = std::max(0, v - ring); hi[ax] = std::min(n - 1, v + ring);
+        }
+        int p[3];
+        for (p[0] = lo[0]; p[0] <= hi[0]; ++p[0])
+            for (p[1] = lo[1]; p[1] <= hi[1]; ++p[1])
+                for (p[2] = lo[2]; p[2] <= hi[2]; ++p[2]) {
+                    int64_t gi = 0;
+                    for (int ax = 0; ax < D; ++ax) gi = gi * n + p[ax];
+                    const int q = pl.owner[cell_of_grid[(size_t) gi]];
+                    if (q == rank) continue;
+                    bits[(size_t) c * nwords + (q >> 6)] |= 1ull << (q & 63);
+                    any_for_peer[q] = 1;
+                }
+    }
+}
+
+}  // namespace
+
 extern "C" {
+
+// ---- communicators ---------------------------------------------------------------------------
+
+int bt_mgpu_comm_rccl(void *nccl_comm, int rank, int nranks, bt_mgpu_comm **out)
+{
+    if (!nccl_comm || !out || nranks < 1 || rank < 0 || rank >= nranks) {
+        set_error("bt_mgpu_comm_rccl: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    if (!nccl().ok) {
+        set_error("bt_mgpu_comm_rccl: librccl.so could not be loaded");
+        return BT_ERR_UNSUPPORTED;
+    }
+    bt_mgpu_comm *c = new bt_mgpu_comm();
+    c->kind = 0; c->rank = rank; c->nranks = nranks; c->nccl = (nccl_comm_t) nccl_comm;
+    *out = c;
+    return BT_OK;
+}
+
+int bt_mgpu_local_group_create(int nranks, void **group)
+{
+    if (nranks < 1 || !group) { set_error("bt_mgpu_local_group_create: invalid argument"); return BT_ERR_INVALID; }
+    LocalGroup *g = new LocalGroup();
+    g->n = nranks;
+    g->ptr.assign((size_t) nranks, nullptr);
+    g->off.assign((size_t) nranks, nullptr);
+    g->cnt.assign((size_t) nranks, nullptr);
+    *group = g;
+    return BT_OK;
+}
+
+void bt_mgpu_local_group_destroy(void *group) { delete (LocalGroup *) group; }
+
+int bt_mgpu_comm_local(void *group, int rank, bt_mgpu_comm **out)
+{
+    LocalGroup *g = (LocalGroup *) group;
+    if (!g || !out || rank < 0 || rank >= g->n) { set_error("bt_mgpu_comm_local: invalid argument"); return BT_ERR_INVALID; }
+    bt_mgpu_comm *c = new bt_mgpu_comm();
+    c->kind = 1; c->rank = rank; c->nranks = g->n; c->group = g;
+    *out = c;
+    return BT_OK;
+}
+
+void bt_mgpu_comm_destroy(bt_mgpu_comm *c) { delete c; }
 
 // Host part, a pure function of the all-reduced histogram (identical on every rank):
 // owner rank of every level-`top_level` cell, and the exclusive prefix sums of the
-// histogram.  kind "adaptive", point particles, unit weights: a box of the global top
-// tree splits iff it holds more than max_particles_in_box particles
-// (tree_build_kernels.py:577-591); all cells below a leaf of that top tree go to one
-// rank, so no global leaf straddles ranks.  max_particles_in_box <= 0: cells are
-// assigned individually (no top-tree plan).
+// histogram.  All cells below a leaf of the global top tree go to one rank, so no global
+// leaf straddles ranks.  max_particles_in_box <= 0: cells are assigned individually (no
+// top-tree plan).
 int bt_mgpu_plan(int dims, int top_level, int64_t max_particles_in_box, int nranks,
                  const int64_t *global_hist, int32_t *owner_of_cell, int64_t *cell_prefix)
 {
@@ -117,64 +603,17 @@ int bt_mgpu_plan(int dims, int top_level, int64_t max_particles_in_box, int nran
         set_error("bt_mgpu_plan: invalid argument");
         return BT_ERR_INVALID;
     }
-    const int C = 1 << dims, k = top_level;
-    const int64_t ncells = (int64_t) 1 << (dims * k);
-    // counts per level, paths in Morton order
-    std::vector<std::vector<int64_t>> counts((size_t) k + 1);
-    counts[k].assign(global_hist, global_hist + ncells);
-    for (int lev = k - 1; lev >= 0; --lev) {
-        const int64_t n = (int64_t) 1 << (dims * lev);
-        counts[lev].assign((size_t) n, 0);
-        for (int64_t i = 0; i < n; ++i)
-            for (int m = 0; m < C; ++m) counts[lev][i] += counts[lev + 1][i * C + m];
-    }
-    // frontier: the first cell of the top-tree leaf a cell lies in
-    std::vector<int64_t> unit_start((size_t) ncells);
-    if (max_particles_in_box > 0) {
-        std::vector<std::vector<char>> split((size_t) k + 1);
-        std::vector<char> exists(1, 1);
-        for (int lev = 0; lev <= k; ++lev) {
-            const int64_t n = (int64_t) 1 << (dims * lev);
-            split[lev].assign((size_t) n, 0);
-            for (int64_t i = 0; i < n; ++i)
-                split[lev][i] = exists[i] && counts[lev][i] > max_particles_in_box;
-            if (lev < k) {
-                std::vector<char> next((size_t) n * C, 0);
-                for (int64_t i = 0; i < n * C; ++i)
-                    next[i] = split[lev][i / C] && counts[lev + 1][i] > 0;
-                exists.swap(next);
-            }
-        }
-        for (int64_t c = 0; c < ncells; ++c) {
-            int leaf_level = k;
-            for (int lev = k - 1; lev >= 0; --lev)
-                if (!split[lev][c >> (dims * (k - lev))]) leaf_level = lev;
-            const int sh = dims * (k - leaf_level);
-            unit_start[c] = (c >> sh) << sh;
-        }
-    } else {
-        for (int64_t c = 0; c < ncells; ++c) unit_start[c] = c;
-    }
-    // contiguous Morton ranges balanced by particle count: a cell goes to the rank whose
-    // ideal range contains its first particle
-    const int64_t total = counts[0][0];
-    std::vector<int64_t> cum((size_t) ncells + 1, 0);
-    for (int64_t c = 0; c < ncells; ++c) cum[c + 1] = cum[c] + global_hist[c];
-    for (int64_t c = 0; c < ncells; ++c) {
-        const int64_t u = unit_start[c];
-        const int64_t o = (int64_t) (((__int128) cum[u] * nranks) / std::max<int64_t>(total, 1));
-        owner_of_cell[c] = (int32_t) std::min<int64_t>(o, nranks - 1);
-    }
-    if (cell_prefix)
-        for (int64_t c = 0; c <= ncells; ++c) cell_prefix[c] = cum[c];
+    TopPlan pl;
+    compute_plan(dims, top_level, max_particles_in_box, nranks, global_hist, pl);
+    std::copy(pl.owner.begin(), pl.owner.end(), owner_of_cell);
+    if (cell_prefix) std::copy(pl.prefix.begin(), pl.prefix.end(), cell_prefix);
     return BT_OK;
 }
 
-int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
-                     const bt_mgpu_params *p, bt_mgpu_shard *out)
+int bt_mgpu_exchange(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *p, bt_mgpu_shard *out)
 {
     bt::CallScope bt_call_scope_(ctx);
-    if (!ctx || !rccl_comm || !p || !out || rank < 0 || rank >= nranks) {
+    if (!ctx || !comm || !p || !out) {
         set_error("bt_mgpu_exchange: invalid argument");
         return BT_ERR_INVALID;
     }
@@ -182,13 +621,10 @@ int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
         set_error("bt_mgpu_exchange: bad dims / coord_kind / n");
         return BT_ERR_INVALID;
     }
+    const int rank = comm->rank, nranks = comm->nranks;
     if (nranks > BT_MGPU_MAX_RANKS) {
         set_error("bt_mgpu_exchange: %d ranks; the one-sweep partition supports at most %d owners",
                   nranks, BT_MGPU_MAX_RANKS);
-        return BT_ERR_UNSUPPORTED;
-    }
-    if (!nccl().ok) {
-        set_error("bt_mgpu_exchange: librccl.so could not be loaded");
         return BT_ERR_UNSUPPORTED;
     }
     BT_HIP_CHECK(hipSetDevice(ctx->device));
@@ -197,8 +633,6 @@ int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
     const bool f64 = p->coord_kind == BT_F64;
     const int es = f64 ? 8 : 4;
     const int64_t n = p->n;
-    Nccl &nc = nccl();
-    nccl_comm_t comm = (nccl_comm_t) rccl_comm;
     hipStream_t stream = ctx->stream;
 
     // ---- 1. global bounding box -> root box --------------------------------------------
@@ -209,7 +643,7 @@ int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
     double h_mm[6];
     for (int ax = 0; ax < D; ++ax) { h_mm[ax] = lmin[ax]; h_mm[D + ax] = -lmax[ax]; }
     BT_HIP_CHECK(hipMemcpyAsync(mm.get(), h_mm, sizeof(double) * 2 * D, hipMemcpyHostToDevice, stream));
-    BT_NCCL_CHECK(nc.AllReduce(mm.get(), mm.get(), 2 * D, NCCL_FLOAT64, NCCL_MIN, comm, stream));
+    BT_CHECK(comm_all_reduce(comm, stream, mm.get(), 2 * D, RED_MIN_F64));
     BT_HIP_CHECK(hipMemcpyAsync(h_mm, mm.get(), sizeof(double) * 2 * D, hipMemcpyDeviceToHost, stream));
     BT_HIP_CHECK(hipStreamSynchronize(stream));
     double bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0}, root_extent = 0;
@@ -242,86 +676,433 @@ int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
     widen_hist_kernel<<<(unsigned) div_up(ncells, 256), 256, 0, stream>>>(ncells, hist32.get(), hist64.get());
     std::vector<int32_t> h_local((size_t) ncells);
     BT_HIP_CHECK(hipMemcpyAsync(h_local.data(), hist32.get(), (size_t) ncells * 4, hipMemcpyDeviceToHost, stream));
-    BT_NCCL_CHECK(nc.AllReduce(hist64.get(), hist64.get(), (size_t) ncells, NCCL_INT64, NCCL_SUM, comm, stream));
+    BT_CHECK(comm_all_reduce(comm, stream, hist64.get(), (size_t) ncells, RED_SUM_I64));
     std::vector<int64_t> ghist((size_t) ncells);
     BT_HIP_CHECK(hipMemcpyAsync(ghist.data(), hist64.get(), (size_t) ncells * 8, hipMemcpyDeviceToHost, stream));
     BT_HIP_CHECK(hipStreamSynchronize(stream));
 
-    // ---- 3. plan (host, identical on all ranks), bucketing, counts ---------------------------
-    std::vector<int32_t> owner((size_t) ncells);
-    std::vector<int64_t> prefix((size_t) ncells + 1);
-    BT_CHECK(bt_mgpu_plan(D, k, p->max_particles_in_box, nranks, ghist.data(), owner.data(), prefix.data()));
-    BT_HIP_CHECK(hipMemcpyAsync(owner_d.get(), owner.data(), (size_t) ncells * 4, hipMemcpyHostToDevice, stream));
+    // ---- 3. plan (host, identical on all ranks), counts --------------------------------------
+    MgpuState *ms = mgpu_state(ctx);
+    TopPlan &pl = ms->plan;
+    compute_plan(D, k, p->max_particles_in_box, nranks, ghist.data(), pl);
+    for (int ax = 0; ax < 3; ++ax) { pl.bbox_min[ax] = bmin[ax]; pl.bbox_max[ax] = bmax[ax]; }
+    pl.root_extent = root_extent;
+    BT_HIP_CHECK(hipMemcpyAsync(owner_d.get(), pl.owner.data(), (size_t) ncells * 4, hipMemcpyHostToDevice, stream));
     std::vector<int64_t> send_counts((size_t) nranks, 0);
-    for (int64_t c = 0; c < ncells; ++c) send_counts[owner[c]] += h_local[c];
+    for (int64_t c = 0; c < ncells; ++c) send_counts[pl.owner[c]] += h_local[c];
     Buf<int64_t> counts_d;
     BT_CHECK(counts_d.alloc(ctx->pool, (int64_t) nranks * (nranks + 1)));
     BT_HIP_CHECK(hipMemcpyAsync(counts_d.get(), send_counts.data(), (size_t) nranks * 8, hipMemcpyHostToDevice, stream));
-    BT_NCCL_CHECK(nc.AllGather(counts_d.get(), counts_d.get() + nranks, (size_t) nranks, NCCL_INT64, comm, stream));
+    BT_CHECK(comm_all_gather(comm, stream, counts_d.get(), counts_d.get() + nranks, (size_t) nranks * 8));
     std::vector<int64_t> matrix((size_t) nranks * nranks);      // [sender][receiver]
     BT_HIP_CHECK(hipMemcpyAsync(matrix.data(), counts_d.get() + nranks, matrix.size() * 8, hipMemcpyDeviceToHost, stream));
     BT_HIP_CHECK(hipStreamSynchronize(stream));
-    std::vector<int64_t> recv_counts((size_t) nranks), s_off((size_t) nranks + 1, 0), r_off((size_t) nranks + 1, 0);
+    const int64_t rec = (int64_t) D * es;                       // bytes per particle
+    std::vector<int64_t> s_off((size_t) nranks + 1, 0), r_off((size_t) nranks + 1, 0);
+    std::vector<int64_t> s_cnt_b((size_t) nranks), r_cnt_b((size_t) nranks), s_off_b((size_t) nranks),
+        r_off_b((size_t) nranks);
     int64_t biggest = 0;
     for (int r = 0; r < nranks; ++r) {
-        recv_counts[r] = matrix[(size_t) r * nranks + rank];
+        const int64_t rc = matrix[(size_t) r * nranks + rank];
         s_off[r + 1] = s_off[r] + send_counts[r];
-        r_off[r + 1] = r_off[r] + recv_counts[r];
+        r_off[r + 1] = r_off[r] + rc;
+        s_cnt_b[r] = send_counts[r] * rec; r_cnt_b[r] = rc * rec;
+        s_off_b[r] = s_off[r] * rec; r_off_b[r] = r_off[r] * rec;
         for (int q = 0; q < nranks; ++q)
-            if (q != r) biggest = std::max(biggest, matrix[(size_t) r * nranks + q]);
+            if (q != r) biggest = std::max(biggest, matrix[(size_t) r * nranks + q] * rec);
     }
     const int64_t nrecv = r_off[nranks];
 
-    // ---- 4. payload: interleaved coordinates, grouped point-to-point rounds -------------------
-    MgpuState *ms = ctx->mgpu;
-    if (!ms) { ms = new MgpuState(); ctx->mgpu = ms; }
+    // ---- 4. payload: interleaved coordinates -------------------------------------------------
     Buf<unsigned char> send;
     BT_CHECK(send.alloc(ctx->pool, n * D * es));
-    BT_CHECK(ms->points.alloc(ctx->pool, std::max<int64_t>(nrecv, 1) * D * es));
+    unsigned char *points = nullptr;
+    const int64_t points_bytes = std::max<int64_t>(nrecv, 1) * D * es;
+    if (p->alloc) {
+        points = (unsigned char *) p->alloc(p->alloc_user, points_bytes);
+        if (!points) { set_error("bt_mgpu_exchange: the caller's allocator returned NULL"); return BT_ERR_ALLOC; }
+        ms->points.reset();
+    } else {
+        BT_CHECK(ms->points.alloc(ctx->pool, points_bytes));
+        points = ms->points.get();
+    }
     // one sweep over the coordinates: stable partition by owner into the send buffer, the
     // segment this rank keeps straight into the receive buffer (bt_shard.hip)
     BT_CHECK(bt_partition_pack(ctx, D, es, p->coords, cells.get(), n, owner_d.get(), nranks, rank,
-                               s_off[rank], r_off[rank], send.get(), ms->points.get()));
-    const int64_t rec = (int64_t) D * es;                       // bytes per particle
-    const int64_t rounds = std::max<int64_t>(1, div_up(biggest * rec, MESSAGE_LIMIT_BYTES));
-    auto cut = [&](int64_t c, int64_t j) { return (j * c) / rounds; };
-    if (biggest > 0) {
-        for (int64_t j = 0; j < rounds; ++j) {
-            BT_NCCL_CHECK(nc.GroupStart());
-            // (a failure inside the group still closes it: RCCL keeps an open group per thread)
-            int group_status = BT_OK;
-            auto in_group = [&]() -> int {
-                for (int peer = 0; peer < nranks; ++peer) {
-                    if (peer == rank) continue;
-                    const int64_t s0 = cut(send_counts[peer], j), s1 = cut(send_counts[peer], j + 1);
-                    const int64_t r0 = cut(recv_counts[peer], j), r1 = cut(recv_counts[peer], j + 1);
-                    if (s1 > s0)
-                        BT_NCCL_CHECK(nc.Send(send.get() + (s_off[peer] + s0) * rec, (size_t) ((s1 - s0) * rec),
-                                              NCCL_UINT8, peer, comm, stream));
-                    if (r1 > r0)
-                        BT_NCCL_CHECK(nc.Recv(ms->points.get() + (r_off[peer] + r0) * rec,
-                                              (size_t) ((r1 - r0) * rec), NCCL_UINT8, peer, comm, stream));
-                }
-                return BT_OK;
-            };
-            group_status = in_group();
-            if (group_status != BT_OK) { (void) nc.GroupEnd(); return group_status; }
-            BT_NCCL_CHECK(nc.GroupEnd());
-        }
-    }
+                               s_off[rank], r_off[rank], send.get(), points));
+    int32_t rounds = 1;
+    s_cnt_b[rank] = 0; r_cnt_b[rank] = 0;       // (own segment: packed in place)
+    if (!ms->ev[0]) { BT_HIP_CHECK(hipEventCreate(&ms->ev[0])); BT_HIP_CHECK(hipEventCreate(&ms->ev[1])); }
+    BT_HIP_CHECK(hipEventRecord(ms->ev[0], stream));
+    BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send.get(), s_off_b.data(), s_cnt_b.data(),
+                               (char *) points, r_off_b.data(), r_cnt_b.data(), biggest, true, &rounds));
+    BT_HIP_CHECK(hipEventRecord(ms->ev[1], stream));
     BT_CHECK(ms->cell_prefix.alloc(ctx->pool, ncells + 1));
-    BT_HIP_CHECK(hipMemcpyAsync(ms->cell_prefix.get(), prefix.data(), (size_t) (ncells + 1) * 8,
+    BT_HIP_CHECK(hipMemcpyAsync(ms->cell_prefix.get(), pl.prefix.data(), (size_t) (ncells + 1) * 8,
                                 hipMemcpyHostToDevice, stream));
     BT_HIP_CHECK(hipStreamSynchronize(stream));     // host vectors above go out of scope
 
     out->n_owned = nrecv;
-    out->points = ms->points.get();
+    out->points = points;
     for (int ax = 0; ax < D; ++ax) { out->bbox_min[ax] = bmin[ax]; out->bbox_max[ax] = bmax[ax]; }
     out->root_extent = root_extent;
     out->top_level = k;
     out->top_cell_prefix = p->max_particles_in_box > 0 ? ms->cell_prefix.get() : nullptr;
     out->bytes_sent = (n - send_counts[rank]) * rec;
-    out->rounds = (int32_t) rounds;
+    out->rounds = rounds;
+    (void) hipEventElapsedTime(&out->a2a_ms, ms->ev[0], ms->ev[1]);
+    return BT_OK;
+}
+
+// ---- step 5: global numbering ------------------------------------------------------------------
+
+int bt_mgpu_number(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
+                   int32_t *box_ids, bt_mgpu_numbering *out)
+{
+    bt::CallScope bt_call_scope_(ctx);
+    if (!ctx || !comm || !tree || !out || !tree->level_start_box_nrs || tree->nlevels < 1
+            || tree->nlevels > BT_MAX_LEVELS || (tree->nboxes > 0 && (!box_ids || !tree->box_centers || !tree->box_levels))) {
+        set_error("bt_mgpu_number: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    MgpuState *ms = ctx->mgpu;
+    if (!ms || !ms->plan.valid) {
+        set_error("bt_mgpu_number: no top-tree plan on this context (bt_mgpu_exchange with "
+                  "max_particles_in_box > 0 comes first)");
+        return BT_ERR_INVALID;
+    }
+    const TopPlan &pl = ms->plan;
+    if (pl.D != tree->dims || pl.k >= TOPMAX) { set_error("bt_mgpu_number: plan / tree mismatch"); return BT_ERR_INVALID; }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    memset(out, 0, sizeof(*out));
+    hipStream_t stream = ctx->stream;
+    const int rank = comm->rank, nranks = comm->nranks, k = pl.k, nlev = tree->nlevels;
+    constexpr int W = BT_MAX_LEVELS + 2;
+    std::vector<int64_t> mine((size_t) W, 0), all((size_t) W * nranks);
+    for (int l = 0; l < nlev; ++l) mine[l] = tree->level_start_box_nrs[l + 1] - tree->level_start_box_nrs[l];
+    mine[BT_MAX_LEVELS] = tree->nsources;
+    mine[BT_MAX_LEVELS + 1] = tree->ntargets;
+    Buf<int64_t> gath;
+    BT_CHECK(gath.alloc(ctx->pool, (int64_t) W * (nranks + 1)));
+    BT_HIP_CHECK(hipMemcpyAsync(gath.get(), mine.data(), (size_t) W * 8, hipMemcpyHostToDevice, stream));
+    BT_CHECK(comm_all_gather(comm, stream, gath.get(), gath.get() + W, (size_t) W * 8));
+    BT_HIP_CHECK(hipMemcpyAsync(all.data(), gath.get() + W, all.size() * 8, hipMemcpyDeviceToHost, stream));
+    BT_HIP_CHECK(hipStreamSynchronize(stream));
+    // the deepest local tree; boxes of levels <= k are shared and numbered by Morton path
+    // from the plan, deeper levels are the concatenation of the ranks' level slices
+    int gl = 0;
+    for (int r = 0; r < nranks; ++r) {
+        int c = 0;
+        for (int l = 0; l < BT_MAX_LEVELS; ++l) c += all[(size_t) r * W + l] > 0 ? 1 : 0;
+        gl = std::max(gl, c);
+    }
+    out->nlevels = gl;
+    NumberArgs na{};
+    na.k = k; na.nlevels = nlev;
+    int64_t start = 0;
+    for (int l = 0; l < gl; ++l) {
+        int64_t nl = 0;
+        out->level_start_box_nrs[l] = (int32_t) start;
+        if (l <= k) {
+            nl = pl.nboxes[l];
+        } else {
+            int64_t before = 0;
+            for (int r = 0; r < nranks; ++r) {
+                if (r < rank) before += all[(size_t) r * W + l];
+                nl += all[(size_t) r * W + l];
+            }
+            out->deep_base[l] = (int32_t) (start + before);
+            if (l < nlev) na.shift[l] = out->deep_base[l] - tree->level_start_box_nrs[l];
+        }
+        start += nl;
+        if (start > 0x7fffffff) { set_error("bt_mgpu_number: more than 2^31-1 boxes in the global tree"); return BT_ERR_UNSUPPORTED; }
+    }
+    out->level_start_box_nrs[gl] = (int32_t) start;
+    out->nboxes = start;
+    for (int r = 0; r < nranks; ++r) {
+        out->nsources += all[(size_t) r * W + BT_MAX_LEVELS];
+        out->ntargets += all[(size_t) r * W + BT_MAX_LEVELS + 1];
+        if (r < rank) {
+            out->source_offset += all[(size_t) r * W + BT_MAX_LEVELS];
+            out->target_offset += all[(size_t) r * W + BT_MAX_LEVELS + 1];
+        }
+    }
+    if (tree->nboxes == 0) return BT_OK;
+    // index tables of the shared top levels
+    std::vector<int32_t> index;
+    const int ntop_levels = std::min(k + 1, nlev);
+    for (int l = 0; l < ntop_levels; ++l) {
+        na.toff[l] = (int32_t) index.size();
+        na.gstart[l] = out->level_start_box_nrs[l];
+        index.insert(index.end(), pl.index[l].begin(), pl.index[l].end());
+    }
+    Buf<int32_t> index_d;
+    BT_CHECK(index_d.alloc(ctx->pool, (int64_t) index.size()));
+    BT_HIP_CHECK(hipMemcpyAsync(index_d.get(), index.data(), index.size() * 4, hipMemcpyHostToDevice, stream));
+    na.index = index_d.get();
+    for (int ax = 0; ax < 3; ++ax) na.bmin[ax] = pl.bbox_min[ax];
+    na.root_extent = pl.root_extent;
+    const unsigned blocks = (unsigned) div_up(tree->nboxes, 256);
+#define NB(T, D) number_boxes_kernel<T, D><<<blocks, 256, 0, stream>>>(tree->nboxes, tree->aligned_nboxes, \
+        (const T *) tree->box_centers, tree->box_levels, na, box_ids)
+    if (tree->coord_kind == BT_F64) { if (pl.D == 1) NB(double, 1); else if (pl.D == 2) NB(double, 2); else NB(double, 3); }
+    else { if (pl.D == 1) NB(float, 1); else if (pl.D == 2) NB(float, 2); else NB(float, 3); }
+#undef NB
+    BT_HIP_CHECK(hipGetLastError());
+    BT_HIP_CHECK(hipStreamSynchronize(stream));     // `index` goes out of scope
+    return BT_OK;
+}
+
+// ---- step 6: local essential tree ----------------------------------------------------------------
+
+int bt_mgpu_let_build(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
+                      const int32_t *box_ids, const bt_mgpu_numbering *num, int well_sep_is_n_away,
+                      bt_mgpu_let_sizes *out)
+{
+    bt::CallScope bt_call_scope_(ctx);
+    if (!ctx || !comm || !tree || !num || !out || !tree->level_start_box_nrs || well_sep_is_n_away < 1
+            || (tree->nboxes > 0 && (!box_ids || !tree->box_centers || !tree->box_levels || !tree->box_flags))) {
+        set_error("bt_mgpu_let_build: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    MgpuState *ms = ctx->mgpu;
+    if (!ms || !ms->plan.valid) {
+        set_error("bt_mgpu_let_build: no top-tree plan on this context (bt_mgpu_exchange with "
+                  "max_particles_in_box > 0 comes first)");
+        return BT_ERR_INVALID;
+    }
+    const TopPlan &pl = ms->plan;
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    BT_CHECK(bt::zero_begin(ctx));
+    memset(out, 0, sizeof(*out));
+    hipStream_t stream = ctx->stream;
+    const int rank = comm->rank, nranks = comm->nranks, D = pl.D, k = pl.k;
+    const int nlev_local = tree->nlevels, nlev = num->nlevels;
+    const int64_t nb = tree->nboxes;
+    const int ntop_levels = std::min(k + 1, nlev);
+    const int lmax = std::max(nlev - 1, 1);
+    const int pathbits = D * lmax;
+    int levbits = 1;
+    while ((1 << levbits) <= lmax) ++levbits;
+    if (pathbits + levbits > 64) {
+        set_error("bt_mgpu_let_build: a tree of %d levels does not fit the 64-bit (level, path) key", nlev);
+        return BT_ERR_UNSUPPORTED;
+    }
+
+    // -- Morton paths of my boxes ----------------------------------------------------------------
+    Buf<uint64_t> paths;
+    BT_CHECK(paths.alloc(ctx->pool, nb));
+    if (nb > 0)
+        BT_CHECK(bt_box_morton_paths(ctx, D, tree->coord_kind, nb, tree->aligned_nboxes, tree->box_centers,
+                                     tree->box_levels, pl.bbox_min, pl.root_extent, paths.get()));
+    // my deep boxes (levels > k) are the tail of the level-major local tree
+    const int64_t b0 = nlev_local > k + 1 ? tree->level_start_box_nrs[k + 1] : nb;
+    const int64_t n_mine = nb - b0;
+
+    // -- halo: my deep boxes in the cells other ranks' lists can reach ------------------------------
+    const int nwords = (nranks + 63) / 64;
+    std::vector<uint64_t> need_bits;
+    std::vector<char> any_for_peer;
+    cells_needed_by(pl, rank, well_sep_is_n_away, nwords, need_bits, any_for_peer);
+    Buf<uint64_t> need_d;
+    BT_CHECK(need_d.alloc(ctx->pool, (int64_t) need_bits.size()));
+    BT_HIP_CHECK(hipMemcpyAsync(need_d.get(), need_bits.data(), need_bits.size() * 8, hipMemcpyHostToDevice, stream));
+    std::vector<int> peers;
+    for (int q = 0; q < nranks; ++q)
+        if (q != rank && any_for_peer[q] && n_mine > 0) peers.push_back(q);
+    Buf<int32_t> pos;                 // [peers][n_mine + 1]
+    BT_CHECK(pos.alloc(ctx->pool, (int64_t) peers.size() * (n_mine + 1)));
+    std::vector<int32_t> h_tot(peers.size(), 0);
+    NeedPred pr{paths.get(), tree->box_levels, need_d.get(), b0, k, D, nwords, 0};
+    for (size_t i = 0; i < peers.size(); ++i) {
+        pr.q = peers[i];
+        int32_t *pp = pos.get() + (int64_t) i * (n_mine + 1);
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, pr, n_mine, pp, (int32_t *) nullptr, true)));
+        BT_CHECK(bt::d2h(ctx, &h_tot[i], pp + n_mine, 4));
+    }
+    BT_CHECK(bt::sync_stream(ctx));
+    std::vector<int64_t> s_cnt((size_t) nranks, 0), s_off((size_t) nranks, 0);
+    for (size_t i = 0; i < peers.size(); ++i) s_cnt[peers[i]] = h_tot[i];
+    int64_t nsend = 0;
+    for (int q = 0; q < nranks; ++q) { s_off[q] = nsend; nsend += s_cnt[q]; }
+    Buf<uint64_t> send_rec;
+    BT_CHECK(send_rec.alloc(ctx->pool, 2 * std::max<int64_t>(nsend, 1)));
+    for (size_t i = 0; i < peers.size(); ++i) {
+        if (h_tot[i] == 0) continue;
+        pr.q = peers[i];
+        let_pack_kernel<<<(unsigned) div_up(n_mine, 256), 256, 0, stream>>>(
+            n_mine, pr, pos.get() + (int64_t) i * (n_mine + 1), tree->box_flags, box_ids,
+            send_rec.get() + 2 * s_off[peers[i]]);
+    }
+    BT_HIP_CHECK(hipGetLastError());
+    // counts: every rank learns the whole matrix (and with it the largest message)
+    Buf<int64_t> cm;
+    BT_CHECK(cm.alloc(ctx->pool, (int64_t) nranks * (nranks + 1)));
+    BT_HIP_CHECK(hipMemcpyAsync(cm.get(), s_cnt.data(), (size_t) nranks * 8, hipMemcpyHostToDevice, stream));
+    BT_CHECK(comm_all_gather(comm, stream, cm.get(), cm.get() + nranks, (size_t) nranks * 8));
+    std::vector<int64_t> matrix((size_t) nranks * nranks);
+    BT_HIP_CHECK(hipMemcpyAsync(matrix.data(), cm.get() + nranks, matrix.size() * 8, hipMemcpyDeviceToHost, stream));
+    BT_HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<int64_t> r_cnt((size_t) nranks), r_off((size_t) nranks);
+    int64_t nrecv = 0, biggest = 0;
+    for (int q = 0; q < nranks; ++q) {
+        r_cnt[q] = matrix[(size_t) q * nranks + rank];
+        r_off[q] = nrecv;
+        nrecv += r_cnt[q];
+        for (int t = 0; t < nranks; ++t)
+            if (t != q) biggest = std::max(biggest, matrix[(size_t) q * nranks + t] * 16);
+    }
+    Buf<uint64_t> halo_rec;
+    BT_CHECK(halo_rec.alloc(ctx->pool, 2 * std::max<int64_t>(nrecv, 1)));
+    {
+        std::vector<int64_t> sob((size_t) nranks), scb((size_t) nranks), rob((size_t) nranks), rcb((size_t) nranks);
+        for (int q = 0; q < nranks; ++q) {
+            sob[q] = s_off[q] * 16; scb[q] = s_cnt[q] * 16; rob[q] = r_off[q] * 16; rcb[q] = r_cnt[q] * 16;
+        }
+        BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send_rec.get(), sob.data(), scb.data(),
+                                   (char *) halo_rec.get(), rob.data(), rcb.data(), biggest, false, nullptr));
+        BT_HIP_CHECK(hipStreamSynchronize(stream));       // (host vectors)
+    }
+
+    // -- the box set: top levels from the plan, my deep boxes, the halo ----------------------------
+    std::vector<uint64_t> t_paths;
+    std::vector<int32_t> t_meta, t_gid;
+    std::vector<int8_t> t_mine;
+    std::vector<int32_t> level_starts(1, 0);
+    for (int lev = 0; lev < ntop_levels; ++lev) {
+        const int64_t n = (int64_t) 1 << (D * lev);
+        for (int64_t pth = 0; pth < n; ++pth) {
+            if (!pl.exists[lev][pth]) continue;
+            const bool internal = pl.split[lev][pth];
+            // tree.py:109-145 with sources = targets: children on both sides, or a leaf that is both
+            const int32_t flags = internal ? (BT_BOX_HAS_SOURCE_CHILD_BOXES | BT_BOX_HAS_TARGET_CHILD_BOXES)
+                                           : (BT_BOX_IS_SOURCE_BOX | BT_BOX_IS_TARGET_BOX);
+            // lists of the shared internal boxes are built by every rank, those of a top LEAF
+            // only by the rank that owns its cells
+            const int64_t first_cell = pth << (D * (k - lev));
+            t_paths.push_back((uint64_t) pth);
+            t_meta.push_back(lev | (flags << 8));
+            t_gid.push_back(num->level_start_box_nrs[lev] + pl.index[lev][pth]);
+            t_mine.push_back((internal || pl.owner[first_cell] == rank) ? 1 : 0);
+        }
+        level_starts.push_back((int32_t) t_paths.size());
+    }
+    const int64_t ntop = (int64_t) t_paths.size();
+    const int64_t nd = n_mine + nrecv;
+    const int64_t B = ntop + nd;
+    if (B > 0x7fffffff) { set_error("bt_mgpu_let_build: more than 2^31-1 boxes"); return BT_ERR_UNSUPPORTED; }
+    BT_CHECK(ms->let_paths.alloc(ctx->pool, B));
+    BT_CHECK(ms->let_meta.alloc(ctx->pool, B));
+    BT_CHECK(ms->let_gid.alloc(ctx->pool, B));
+    BT_CHECK(ms->let_mask.alloc(ctx->pool, B));
+    BT_HIP_CHECK(hipMemcpyAsync(ms->let_paths.get(), t_paths.data(), (size_t) ntop * 8, hipMemcpyHostToDevice, stream));
+    BT_HIP_CHECK(hipMemcpyAsync(ms->let_meta.get(), t_meta.data(), (size_t) ntop * 4, hipMemcpyHostToDevice, stream));
+    BT_HIP_CHECK(hipMemcpyAsync(ms->let_gid.get(), t_gid.data(), (size_t) ntop * 4, hipMemcpyHostToDevice, stream));
+    BT_HIP_CHECK(hipMemcpyAsync(ms->let_mask.get(), t_mine.data(), (size_t) ntop, hipMemcpyHostToDevice, stream));
+
+    LetLevelInfo h_info{};
+    for (int l = 0; l <= BT_MAX_LEVELS; ++l) { h_info.level_first[l] = -1; h_info.mine_last[l] = -1; }
+    if (nd > 0) {
+        Buf<uint64_t> key_a, key_b, d_path;
+        Buf<uint32_t> ord_a, ord_b;
+        Buf<int32_t> d_meta, d_gid;
+        Buf<LetLevelInfo> info;
+        BT_CHECK(key_a.alloc(ctx->pool, nd)); BT_CHECK(key_b.alloc(ctx->pool, nd));
+        BT_CHECK(ord_a.alloc(ctx->pool, nd)); BT_CHECK(ord_b.alloc(ctx->pool, nd));
+        BT_CHECK(d_path.alloc(ctx->pool, nd)); BT_CHECK(d_meta.alloc(ctx->pool, nd)); BT_CHECK(d_gid.alloc(ctx->pool, nd));
+        BT_CHECK(info.alloc(ctx->pool, 1));
+        let_deep_kernel<<<(unsigned) div_up(nd, 256), 256, 0, stream>>>(
+            n_mine, nrecv, b0, paths.get(), tree->box_levels, tree->box_flags, box_ids, halo_rec.get(),
+            pathbits, key_a.get(), d_path.get(), d_meta.get(), d_gid.get());
+        // (level, Morton path) order; equal keys cannot occur (a box is sent by its one owner)
+        bool in_b = false;
+        BT_CHECK(radix_sort_pairs<uint64_t>(ctx, key_a.get(), ord_a.get(), key_b.get(), ord_b.get(), nd, 0,
+                                            pathbits + levbits, true, &in_b));
+        LetLevelInfo init{};
+        for (int l = 0; l <= BT_MAX_LEVELS; ++l) { init.level_first[l] = -1; init.mine_first[l] = 0; init.mine_last[l] = -1; }
+        BT_HIP_CHECK(hipMemcpyAsync(info.get(), &init, sizeof(init), hipMemcpyHostToDevice, stream));
+        let_place_kernel<<<(unsigned) div_up(nd, 256), 256, 0, stream>>>(
+            nd, n_mine, ntop, in_b ? ord_b.get() : ord_a.get(), d_path.get(), d_meta.get(), d_gid.get(),
+            ms->let_paths.get(), ms->let_meta.get(), ms->let_gid.get(), ms->let_mask.get(), info.get());
+        BT_HIP_CHECK(hipGetLastError());
+        BT_HIP_CHECK(hipMemcpyAsync(&h_info, info.get(), sizeof(h_info), hipMemcpyDeviceToHost, stream));
+    }
+    BT_CHECK(bt::check_status(ctx));           // waits; the sort and the scans report here
+
+    // -- level starts; the range of a level that holds this rank's boxes ---------------------------
+    for (int lev = 0; lev < nlev; ++lev) {
+        const int32_t s = level_starts[(size_t) lev];
+        if (lev < ntop_levels) {
+            out->active_level_ranges[lev][0] = s;
+            out->active_level_ranges[lev][1] = level_starts[(size_t) lev + 1];
+            continue;
+        }
+        // the sorted deep boxes of this level: from its first position to the next level's
+        int32_t cnt = 0;
+        if (h_info.level_first[lev] >= 0) {
+            int32_t end = (int32_t) nd;
+            for (int l2 = lev + 1; l2 <= BT_MAX_LEVELS; ++l2)
+                if (h_info.level_first[l2] >= 0) { end = h_info.level_first[l2]; break; }
+            cnt = end - h_info.level_first[lev];
+        }
+        if (h_info.mine_runs[lev] > 0) {
+            if (h_info.mine_runs[lev] != 1) {
+                set_error("bt_mgpu_let_build: the rank's boxes of level %d are not one run", lev);
+                return BT_ERR_INTERNAL;
+            }
+            out->active_level_ranges[lev][0] = (int32_t) (ntop + h_info.mine_first[lev]);
+            out->active_level_ranges[lev][1] = (int32_t) (ntop + h_info.mine_last[lev] + 1);
+        } else {
+            out->active_level_ranges[lev][0] = out->active_level_ranges[lev][1] = s;
+        }
+        level_starts.push_back(s + cnt);
+    }
+    if (level_starts.back() != (int32_t) B) {
+        set_error("bt_mgpu_let_build: level counts (%d) do not add up to the box count (%lld)",
+                  level_starts.back(), (long long) B);
+        return BT_ERR_INTERNAL;
+    }
+    ms->let_level_starts = level_starts;
+    ms->let_nlevels = nlev;
+    ms->let_dims = D;
+    ms->let_kind = tree->coord_kind;
+    out->nboxes = B;
+    out->aligned_nboxes = div_up(B, 32) * 32;
+    out->nlevels = nlev;
+    for (int l = 0; l <= nlev; ++l) out->level_start_box_nrs[l] = level_starts[(size_t) l];
+    out->halo_boxes_sent = nsend;
+    out->halo_boxes_received = nrecv;
+    return BT_OK;
+}
+
+int bt_mgpu_let_export(bt_context *ctx, const bt_mgpu_let_arrays *o)
+{
+    bt::CallScope bt_call_scope_(ctx);
+    MgpuState *ms = ctx ? ctx->mgpu : nullptr;
+    if (!ctx || !o || !ms || ms->let_nlevels < 1 || !o->box_centers || !o->box_parent_ids || !o->box_child_ids
+            || !o->box_levels || !o->box_flags) {
+        set_error("bt_mgpu_let_export: invalid argument, or no bt_mgpu_let_build before it");
+        return BT_ERR_INVALID;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    const TopPlan &pl = ms->plan;
+    const int64_t B = ms->let_level_starts.back();
+    const int64_t aligned = div_up(B, 32) * 32;
+    hipStream_t stream = ctx->stream;
+    let_split_meta_kernel<<<(unsigned) div_up(B, 256), 256, 0, stream>>>(B, ms->let_meta.get(), o->box_levels,
+                                                                         o->box_flags);
+    if (o->global_box_ids)
+        BT_HIP_CHECK(hipMemcpyAsync(o->global_box_ids, ms->let_gid.get(), (size_t) B * 4, hipMemcpyDeviceToDevice, stream));
+    if (o->target_boxes_mask)
+        BT_HIP_CHECK(hipMemcpyAsync(o->target_boxes_mask, ms->let_mask.get(), (size_t) B, hipMemcpyDeviceToDevice, stream));
+    BT_HIP_CHECK(hipMemsetAsync(o->box_parent_ids, 0, (size_t) B * 4, stream));
+    const size_t cs = ms->let_kind == BT_F64 ? 8 : 4;
+    BT_HIP_CHECK(hipMemsetAsync(o->box_centers, 0, (size_t) ms->let_dims * (size_t) aligned * cs, stream));
+    BT_CHECK(bt_let_build(ctx, ms->let_dims, ms->let_kind, ms->let_nlevels, ms->let_level_starts.data(),
+                          ms->let_paths.get(), aligned, pl.bbox_min, pl.bbox_max, pl.root_extent,
+                          o->box_parent_ids, o->box_child_ids, o->box_centers));
+    ms->let_paths.reset(); ms->let_meta.reset(); ms->let_gid.reset(); ms->let_mask.reset();
+    ms->let_nlevels = 0;
     return BT_OK;
 }
 

@@ -1,0 +1,252 @@
+"""The sharded build through the library's own multi-GPU entries (``bt_mgpu_*``,
+``csrc/bt_mgpu.hip``): particle exchange, global numbering and the local essential tree
+run in C++/HIP behind the C ABI, over an RCCL communicator -- or over ranks that are
+threads of one process (:class:`LocalGroup`), which is how the multi-rank logic is
+exercised on a box with one GPU.  This module is the thin Python caller; the torch
+implementation of the same steps in :mod:`boxtree_amd.distributed` remains for the CPU
+(gloo) tests of the plan and for process groups whose ranks share a GPU.
+
+SURVEY.md section 8e steps 1-6; the reference has no counterpart (it builds on one rank,
+boxtree/distributed/__init__.py:183-199).
+"""
+
+from __future__ import annotations
+
+import ctypes as ct
+import os
+
+import numpy as np
+
+from boxtree_amd import _lib
+
+
+class _DevicePointer:
+    """A device allocation that is not torch's, for ``torch.as_tensor`` (zero copy)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {
+            "shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+class NativeComm:
+    """Handle on a ``bt_mgpu_comm``."""
+
+    def __init__(self, lib, handle, rank, nranks, kind, keep=None):
+        self.lib, self.handle, self.rank, self.nranks, self.kind = lib, handle, rank, nranks, kind
+        self._keep = keep
+
+    def close(self):
+        if self.handle:
+            self.lib.bt_mgpu_comm_destroy(self.handle)
+            self.handle = None
+        if self._keep is not None and hasattr(self._keep, "close"):
+            self._keep.close()
+            self._keep = None
+
+
+class LocalGroup:
+    """*nranks* ranks as threads of this process (one ``bt_context`` each, on any device):
+    every thread takes ``group.comm(rank)`` and makes the same sequence of ``bt_mgpu_*``
+    calls.  For tests: RCCL refuses two ranks on one GPU."""
+
+    def __init__(self, nranks):
+        self.lib = _lib.load()
+        self.nranks = nranks
+        g = ct.c_void_p()
+        _lib.check(self.lib.bt_mgpu_local_group_create(nranks, ct.byref(g)))
+        self.handle = g
+
+    def comm(self, rank):
+        h = ct.c_void_p()
+        _lib.check(self.lib.bt_mgpu_comm_local(self.handle, rank, ct.byref(h)))
+        return NativeComm(self.lib, h, rank, self.nranks, "threads")
+
+    def close(self):
+        if self.handle:
+            self.lib.bt_mgpu_local_group_destroy(self.handle)
+            self.handle = None
+
+
+class _RcclComm:
+    """An RCCL communicator of our own, created through ctypes (torch does not hand out
+    the ``ncclComm_t`` of its process groups).  The unique id travels over *dist*."""
+
+    def __init__(self, dist, device_index):
+        import torch
+        self.rccl = ct.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+
+        class UniqueId(ct.Structure):
+            _fields_ = [("internal", ct.c_char * 128)]
+
+        rank, world = dist.get_rank(), dist.get_world_size()
+        uid = UniqueId()
+        if rank == 0:
+            if self.rccl.ncclGetUniqueId(ct.byref(uid)) != 0:
+                raise RuntimeError("ncclGetUniqueId failed")
+        box = [bytes(uid)]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+            ct.memmove(ct.byref(uid), box[0], ct.sizeof(uid))
+        torch.cuda.set_device(device_index)
+        self.comm = ct.c_void_p()
+        self.rccl.ncclCommInitRank.argtypes = [ct.POINTER(ct.c_void_p), ct.c_int, UniqueId, ct.c_int]
+        code = self.rccl.ncclCommInitRank(ct.byref(self.comm), world, uid, rank)
+        if code != 0:
+            raise RuntimeError(f"ncclCommInitRank failed with code {code}")
+
+    def close(self):
+        if self.comm:
+            self.rccl.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+def rccl_comm(actx, dist):
+    """A :class:`NativeComm` over RCCL with the ranks of *dist* (collective)."""
+    rc = _RcclComm(dist, actx.device_index)
+    h = ct.c_void_p()
+    _lib.check(actx.lib.bt_mgpu_comm_rccl(rc.comm, dist.get_rank(), dist.get_world_size(),
+                                          ct.byref(h)))
+    return NativeComm(actx.lib, h, dist.get_rank(), dist.get_world_size(), "rccl", keep=rc)
+
+
+def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=None,
+                       own_buffer=False):
+    """Steps 1-3 (``bt_mgpu_exchange``).  Returns ``(particles, build_kw, stats)`` for the
+    local ``TreeBuilder`` call: views of the interleaved receive buffer, and ``_root_box`` /
+    ``_top_tree`` / ``_point_stride``.  The receive buffer belongs to the context and is
+    valid until its next exchange (the tree build copies what it keeps); with
+    *own_buffer* it is a torch allocation the returned views keep alive."""
+    import torch
+    dims = len(particles)
+    dev = particles[0].device
+    dtype = particles[0].dtype
+    es = particles[0].element_size()
+    par = _lib.MgpuParams()
+    par.dims = dims
+    par.coord_kind = _lib.BT_F64 if dtype == torch.float64 else _lib.BT_F32
+    par.n = len(particles[0])
+    keep = [p.contiguous() for p in particles]
+    for ax in range(dims):
+        par.coords[ax] = keep[ax].data_ptr()
+    par.top_level = int(top_level or 0)
+    par.max_particles_in_box = int(max_particles_in_box or 0)
+    got = {}
+
+    def alloc(_user, nbytes):
+        got["buf"] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        return got["buf"].data_ptr()
+
+    cb = _lib.ALLOC_FN(alloc)
+    if own_buffer:
+        par.alloc = ct.cast(cb, ct.c_void_p)
+    shard = _lib.MgpuShard()
+    actx.sync_in()
+    _lib.check(actx.lib.bt_mgpu_exchange(actx.handle, comm.handle, ct.byref(par), ct.byref(shard)))
+    n_owned = int(shard.n_owned)
+    if own_buffer:
+        recv = got["buf"][:n_owned * dims * es].view(dtype).view(n_owned, dims)
+    else:
+        recv = torch.as_tensor(
+            _DevicePointer(shard.points, (max(n_owned, 1) * dims,), "<f8" if es == 8 else "<f4"),
+            device=dev)[:n_owned * dims].view(n_owned, dims)
+    new_particles = [recv[:, ax] for ax in range(dims)]
+    coord = np.dtype(np.float64 if dtype == torch.float64 else np.float32)
+    bbox_min = np.array(shard.bbox_min[:dims], dtype=coord)
+    bbox_max = np.array(shard.bbox_max[:dims], dtype=coord)
+    root_extent = coord.type(shard.root_extent)
+    build_kw = {"_root_box": (bbox_min, bbox_max, root_extent)}
+    if dims > 1:
+        build_kw["_point_stride"] = dims
+    else:
+        new_particles = [p.contiguous() for p in new_particles]
+    k = int(shard.top_level)
+    if shard.top_cell_prefix:
+        prefix = torch.as_tensor(
+            _DevicePointer(shard.top_cell_prefix, ((1 << (dims * k)) + 1,), "<i8"), device=dev)
+        build_kw["_top_tree"] = (k, prefix)
+    stats = dict(bytes_sent=int(shard.bytes_sent), rounds=int(shard.rounds), top_level=k,
+                 a2a_ms=float(shard.a2a_ms),
+                 bbox_min=bbox_min, bbox_max=bbox_max, root_extent=root_extent,
+                 planned=bool(shard.top_cell_prefix), recv_buffer=got.get("buf"))
+    return new_particles, build_kw, stats
+
+
+def _local_tree_view(actx, tree):
+    import torch
+
+    from boxtree_amd.tree import level_start_box_nrs_of
+    lsb = np.ascontiguousarray(level_start_box_nrs_of(actx, tree), dtype=np.int32)
+    v = _lib.MgpuLocalTree()
+    v.dims = int(tree.dimensions)
+    v.coord_kind = _lib.BT_F64 if tree.box_centers.dtype == torch.float64 else _lib.BT_F32
+    v.nboxes = int(tree.nboxes)
+    v.aligned_nboxes = int(tree.box_centers.shape[1])
+    v.nlevels = int(tree.nlevels)
+    v.level_start_box_nrs = lsb.ctypes.data_as(ct.POINTER(ct.c_int32))
+    v.box_centers = tree.box_centers.data_ptr()
+    v.box_levels = tree.box_levels.data_ptr()
+    v.box_flags = tree.box_flags.data_ptr()
+    v.nsources = int(tree.nsources)
+    v.ntargets = int(tree.ntargets)
+    return v, lsb
+
+
+def number_sharded_tree(actx, comm, tree):
+    """Step 5 (``bt_mgpu_number``): global box numbers of the rank's boxes (int32 device
+    tensor), global level starts and particle offsets."""
+    import torch
+    view, _keep = _local_tree_view(actx, tree)
+    box_ids = torch.empty(int(tree.nboxes), dtype=torch.int32, device=tree.box_centers.device)
+    num = _lib.MgpuNumbering()
+    actx.sync_in()
+    _lib.check(actx.lib.bt_mgpu_number(actx.handle, comm.handle, ct.byref(view),
+                                       ct.c_void_p(box_ids.data_ptr()), ct.byref(num)))
+    nl = int(num.nlevels)
+    return dict(box_ids=box_ids, struct=num, nlevels=nl,
+                global_level_start_box_nrs=np.array(num.level_start_box_nrs[:nl + 1], dtype=np.int64),
+                deep_base=np.array(num.deep_base[:nl], dtype=np.int64),
+                nboxes=int(num.nboxes), nsources=int(num.nsources), ntargets=int(num.ntargets),
+                source_offset=int(num.source_offset), target_offset=int(num.target_offset))
+
+
+def build_local_essential_tree(actx, comm, tree, numbering, well_sep_is_n_away=1):
+    """Step 6 (``bt_mgpu_let_build`` / ``bt_mgpu_let_export``).  Returns ``(let, info)`` like
+    :func:`boxtree_amd.distributed.build_local_essential_tree`."""
+    import torch
+
+    from boxtree_amd.tree import TreeOfBoxes
+    view, _keep = _local_tree_view(actx, tree)
+    sizes = _lib.MgpuLetSizes()
+    actx.sync_in()
+    _lib.check(actx.lib.bt_mgpu_let_build(
+        actx.handle, comm.handle, ct.byref(view), ct.c_void_p(numbering["box_ids"].data_ptr()),
+        ct.byref(numbering["struct"]), int(well_sep_is_n_away), ct.byref(sizes)))
+    B, aligned, nlev = int(sizes.nboxes), int(sizes.aligned_nboxes), int(sizes.nlevels)
+    dims = int(tree.dimensions)
+    C = 1 << dims
+    coord_dtype = np.dtype(np.float64 if tree.box_centers.dtype == torch.float64 else np.float32)
+    centers, parents, children, levels, flags, gids, mask = actx.empty_block([
+        ((dims, aligned), coord_dtype), (B, np.int32), ((C, aligned), np.int32), (B, np.uint8),
+        (B, np.uint8), (B, np.int32), (B, np.int8)])
+    arrs = _lib.MgpuLetArrays()
+    arrs.box_centers = centers.data_ptr()
+    arrs.box_parent_ids = parents.data_ptr()
+    arrs.box_child_ids = children.data_ptr()
+    arrs.box_levels = levels.data_ptr()
+    arrs.box_flags = flags.data_ptr()
+    arrs.global_box_ids = gids.data_ptr()
+    arrs.target_boxes_mask = mask.data_ptr()
+    _lib.check(actx.lib.bt_mgpu_let_export(actx.handle, ct.byref(arrs)))
+    lsb = np.array(sizes.level_start_box_nrs[:nlev + 1], dtype=np.int32)
+    let = TreeOfBoxes(
+        root_extent=tree.root_extent, box_centers=centers, box_parent_ids=parents,
+        box_child_ids=children, box_levels=levels, box_flags=flags, level_start_box_nrs=lsb,
+        box_id_dtype=np.dtype(np.int32), box_level_dtype=np.dtype(np.uint8),
+        coord_dtype=coord_dtype, sources_have_extent=False, targets_have_extent=False,
+        extent_norm=None, stick_out_factor=tree.stick_out_factor, _is_pruned=True)
+    ranges = np.array([[sizes.active_level_ranges[l][0], sizes.active_level_ranges[l][1]]
+                       for l in range(nlev)], dtype=np.int32)
+    info = dict(target_boxes_mask=mask, active_level_ranges=ranges, global_box_ids=gids,
+                halo_boxes_received=int(sizes.halo_boxes_received),
+                halo_boxes_sent=int(sizes.halo_boxes_sent), nboxes=B)
+    return let, info

@@ -43,6 +43,10 @@ extern "C" {
 #define BT_MAX_DIMS 3
 #define BT_MAX_LEVELS 64       /* capacity of per-level arrays in the structs */
 
+/* device memory from the caller (e.g. a torch tensor it keeps): returns a pointer to
+ * nbytes of device memory, or NULL */
+typedef void *(*bt_alloc_fn)(void *user, int64_t nbytes);
+
 enum {
     BT_OK = 0,
     BT_ERR_INVALID = 1,        /* bad argument (ValueError/TypeError upstream)   */
@@ -326,7 +330,6 @@ int bt_traversal_export(bt_context *ctx, const bt_trav_arrays *out);
  * counts in int32 elements from `base`) plus host copies of the four level-start
  * arrays, which the reference hands out as host arrays (traversal.py:2091).
  * target_boxes is the span of source_boxes when the tree's sources are its targets. */
-typedef void *(*bt_alloc_fn)(void *user, int64_t nbytes);
 typedef struct { int64_t offset, count; } bt_span;
 typedef struct {
     void *base;
@@ -539,8 +542,23 @@ int bt_gather_pack(bt_context *ctx, int dims, int elem_size, const void *const *
 int bt_unpack(bt_context *ctx, int dims, int elem_size, const void *in, int64_t n,
               void *const *out);
 
-/* ---- multi-GPU entry: the particle exchange of a sharded build over an RCCL
- *      communicator owned by the caller (one process per GPU) ---- */
+/* ---- multi-GPU entries: a sharded build and the lists of a rank's own boxes, one process
+ *      (or thread) per GPU (no counterpart in the reference, which
+ *      builds on one rank: boxtree/distributed/__init__.py:183-199) ---- */
+
+/* A communicator: an RCCL communicator the caller owns (ncclComm_t of nranks ranks with
+ * this process at `rank`, created on the context's device), or -- so that the multi-rank
+ * logic can run on a box with one GPU, which RCCL refuses to share between ranks -- ranks
+ * that are threads of one process: bt_mgpu_local_group_create makes the rendezvous object
+ * all of them pass to bt_mgpu_comm_local, and every rank calls the collective entries
+ * below from its own thread with its own bt_context.  Collectives are enqueued on the
+ * context's stream. */
+typedef struct bt_mgpu_comm bt_mgpu_comm;
+int bt_mgpu_comm_rccl(void *nccl_comm, int rank, int nranks, bt_mgpu_comm **out);
+int bt_mgpu_local_group_create(int nranks, void **group);
+void bt_mgpu_local_group_destroy(void *group);
+int bt_mgpu_comm_local(void *group, int rank, bt_mgpu_comm **out);
+void bt_mgpu_comm_destroy(bt_mgpu_comm *comm);
 
 typedef struct {
     int32_t dims, coord_kind;
@@ -549,30 +567,35 @@ typedef struct {
     int32_t top_level;                 /* level of the ownership cells; 0: default (5 in 3D) */
     int64_t max_particles_in_box;      /* > 0: derive the top of the global tree, keep its  */
                                        /* leaves on one rank (kind "adaptive", unit weights) */
+    bt_alloc_fn alloc;                 /* NULL: `points` below is owned by the context;     */
+    void *alloc_user;                  /* else the receive buffer comes from the caller     */
 } bt_mgpu_params;
 
 typedef struct {
     int64_t n_owned;                   /* particles this rank owns after the exchange  */
     void *points;                      /* device, interleaved [n_owned][dims]; owned by the */
                                        /* context until the next exchange / bt_destroy  */
+                                       /* unless params.alloc provided it               */
     double bbox_min[BT_MAX_DIMS], bbox_max[BT_MAX_DIMS], root_extent;   /* global root box */
     int32_t top_level;
     const int64_t *top_cell_prefix;    /* device [2^(dims*top_level) + 1] or NULL        */
     int64_t bytes_sent;                /* payload bytes that left this GPU              */
     int32_t rounds;                    /* point-to-point rounds of the all-to-all       */
+    float a2a_ms;                      /* device time of the payload all-to-all-v (HIP   */
+                                       /* events on the context's stream)               */
 } bt_mgpu_shard;
 
 /* the one-sweep partition (bt_partition_pack) keeps one run per owner in LDS: at most this
  * many ranks; bt_mgpu_exchange returns BT_ERR_UNSUPPORTED beyond (one node has 8) */
 #define BT_MGPU_MAX_RANKS 256
 
-/* rccl_comm: an ncclComm_t of nranks ranks with this process at `rank`, created on the
- * context's device.  Collectives are enqueued on the context's stream; the call
- * returns when the shard is complete.  Feed the shard to bt_tree_build with
- * sources[ax] = (char *) points + ax * sizeof(coord), source_stride = dims, the root
- * box, top_level and top_cell_prefix. */
-int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
-                     const bt_mgpu_params *params, bt_mgpu_shard *out);
+/* Steps 1-3: global root box, ownership cells, the particles this rank owns.  The call
+ * returns when the shard is complete.  Feed the shard to bt_tree_build with sources[ax] =
+ * (char *) points + ax * sizeof(coord), source_stride = dims, the root box, top_level and
+ * top_cell_prefix.  The context remembers the plan (the top of the global tree, the owner
+ * of every cell) for bt_mgpu_number and bt_mgpu_let_build. */
+int bt_mgpu_exchange(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *params,
+                     bt_mgpu_shard *out);
 
 /* The host part of the exchange, a pure function of the all-reduced level-top_level
  * cell histogram: owner rank of every cell (contiguous Morton ranges balanced by
@@ -580,6 +603,63 @@ int bt_mgpu_exchange(bt_context *ctx, void *rccl_comm, int rank, int nranks,
  * sums of the histogram [ncells + 1] (may be NULL). */
 int bt_mgpu_plan(int dims, int top_level, int64_t max_particles_in_box, int nranks,
                  const int64_t *global_hist, int32_t *owner_of_cell, int64_t *cell_prefix);
+
+/* the tree a rank built from its shard (bt_tree_sizes / bt_tree_arrays of that build) */
+typedef struct {
+    int32_t dims, coord_kind;
+    int64_t nboxes, aligned_nboxes;
+    int32_t nlevels;
+    const int32_t *level_start_box_nrs;   /* HOST [nlevels + 1]                     */
+    const void *box_centers;              /* device [dims][aligned_nboxes]          */
+    const uint8_t *box_levels;            /* device [nboxes]                        */
+    const uint8_t *box_flags;             /* device [nboxes] (bt_mgpu_let_build)    */
+    int64_t nsources, ntargets;
+} bt_mgpu_local_tree;
+
+/* Step 5: where the rank's tree sits in the global one -- the tree a single GPU builds
+ * from the concatenated input.  Boxes of levels <= top_level are shared between ranks and
+ * numbered by Morton path (from the plan); deeper levels are the concatenation of the
+ * ranks' level slices (ranks own ascending Morton ranges).  One all-gather of the
+ * per-level box counts.  box_ids [nboxes] (device, out): global number of every local
+ * box.  Renumbered with these, the per-rank arrays are slices of the single-GPU tree
+ * (tests/test_gpu_mgpu.py). */
+typedef struct {
+    int32_t nlevels;                                   /* of the global tree          */
+    int32_t level_start_box_nrs[BT_MAX_LEVELS + 2];     /* global, [nlevels + 1] valid  */
+    int32_t deep_base[BT_MAX_LEVELS + 1];   /* global number of this rank's first box of a level > top_level */
+    int64_t nboxes, nsources, ntargets;                /* global totals               */
+    int64_t source_offset, target_offset;   /* global tree-order index of local particle 0 */
+} bt_mgpu_numbering;
+int bt_mgpu_number(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
+                   int32_t *box_ids, bt_mgpu_numbering *out);
+
+/* Step 6: the local essential tree -- the boxes a rank needs for the interaction lists
+ * of its own boxes: the shared top levels, its own subtrees, and the subtrees of other
+ * ranks' cells within well_sep_is_n_away cells of its own (one all-to-all-v of 16-byte
+ * box records between neighbours).  Boxes are level-major, Morton order within a level;
+ * the result is the global tree restricted to these boxes.  _build returns the sizes,
+ * _export fills caller-allocated arrays laid out as in bt_tree_arrays (box_child_ids
+ * [2^d][aligned], box_centers [d][aligned]); global_box_ids [nboxes] and
+ * target_boxes_mask [nboxes] (1: this rank builds the lists of the box) may be NULL.
+ * Hand the arrays to bt_traversal_build with target_boxes_mask and active_level_ranges. */
+typedef struct {
+    int64_t nboxes, aligned_nboxes;
+    int32_t nlevels;
+    int32_t level_start_box_nrs[BT_MAX_LEVELS + 2];
+    int32_t active_level_ranges[BT_MAX_LEVELS + 1][2];  /* per level: [begin, end) of the rank's boxes */
+    int64_t halo_boxes_sent, halo_boxes_received;
+} bt_mgpu_let_sizes;
+typedef struct {
+    void *box_centers;
+    int32_t *box_parent_ids, *box_child_ids;
+    uint8_t *box_levels, *box_flags;
+    int32_t *global_box_ids;
+    int8_t *target_boxes_mask;
+} bt_mgpu_let_arrays;
+int bt_mgpu_let_build(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
+                      const int32_t *box_ids, const bt_mgpu_numbering *numbering,
+                      int well_sep_is_n_away, bt_mgpu_let_sizes *out);
+int bt_mgpu_let_export(bt_context *ctx, const bt_mgpu_let_arrays *arrays);
 
 /* Morton path (x most significant in every digit, level*dims bits) of every box,
  * from its centre and level. */

@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from compare import assert_same_tree
+from compare import assert_same_tree  # noqa: I001
 
 pytestmark = pytest.mark.gpu
 
@@ -53,7 +53,10 @@ def test_exchange_one_rank(dims, dtype):
         par.max_particles_in_box = mpb
         shard = _lib.MgpuShard()
         torch.cuda.synchronize()
-        _lib.check(actx.lib.bt_mgpu_exchange(actx.handle, comm, 0, 1, ct.byref(par), ct.byref(shard)))
+        mc = ct.c_void_p()
+        _lib.check(actx.lib.bt_mgpu_comm_rccl(comm, 0, 1, ct.byref(mc)))
+        _lib.check(actx.lib.bt_mgpu_exchange(actx.handle, mc, ct.byref(par), ct.byref(shard)))
+        actx.lib.bt_mgpu_comm_destroy(mc)
         assert shard.n_owned == n and shard.bytes_sent == 0 and shard.rounds == 1
 
         # the receive buffer: one rank owns everything, in the original order
@@ -96,3 +99,60 @@ def test_exchange_one_rank(dims, dtype):
         assert_same_tree(actx.to_numpy(t_shard), actx.to_numpy(t_plain))
     finally:
         rccl.ncclCommDestroy(comm)
+
+
+@pytest.mark.parametrize("dims,nway", [(3, 1), (2, 2)])
+def test_steps_1_to_6_one_rank_rccl(dims, nway):
+    """Exchange, build, numbering and the local essential tree through the C ABI on a real
+    one-rank RCCL communicator (boxtree_amd.distributed.native): the numbering is the
+    identity, the LET is the tree itself and its lists are the plain traversal's."""
+    import torch
+    import torch.distributed as dist
+    from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
+    from boxtree_amd.distributed import native as nat
+    from compare import assert_same_traversal
+    actx = HIPArrayContext(0)
+    torch.cuda.set_device(0)
+
+    class OneRank:           # the unique id needs no broadcast with one rank
+        @staticmethod
+        def get_rank():
+            return 0
+
+        @staticmethod
+        def get_world_size():
+            return 1
+
+    comm = nat.rccl_comm(actx, OneRank)
+    try:
+        rng = np.random.default_rng(3 + dims)
+        n, mpb = 150000, 20
+        pts = [torch.from_numpy(rng.standard_normal(n)).cuda() for _ in range(dims)]
+        p2, kw, stats = nat.exchange_particles(actx, comm, pts, mpb)
+        assert stats["bytes_sent"] == 0 and stats["planned"]
+        tree, _ = TreeBuilder(actx)(actx, p2, max_particles_in_box=mpb, **kw)
+        plain, _ = TreeBuilder(actx)(actx, pts, max_particles_in_box=mpb)
+        assert_same_tree(actx.to_numpy(tree), actx.to_numpy(plain))
+        num = nat.number_sharded_tree(actx, comm, tree)
+        assert num["nboxes"] == int(tree.nboxes) and num["nsources"] == n
+        assert num["source_offset"] == 0
+        assert np.array_equal(num["box_ids"].cpu().numpy(), np.arange(int(tree.nboxes)))
+        assert np.array_equal(num["global_level_start_box_nrs"],
+                              actx.to_numpy(tree.level_start_box_nrs))
+        let, info = nat.build_local_essential_tree(actx, comm, tree, num, well_sep_is_n_away=nway)
+        assert info["halo_boxes_received"] == 0 and info["nboxes"] == int(tree.nboxes)
+        assert np.array_equal(info["global_box_ids"].cpu().numpy(), np.arange(int(tree.nboxes)))
+        h = actx.to_numpy(let)
+        g = actx.to_numpy(tree)
+        nb = g.nboxes
+        assert np.array_equal(h.box_levels, g.box_levels) and np.array_equal(h.box_flags, g.box_flags)
+        assert np.array_equal(h.box_centers[:, :nb], g.box_centers[:, :nb])
+        assert np.array_equal(h.box_parent_ids, g.box_parent_ids)
+        assert np.array_equal(h.box_child_ids[:, :nb], g.box_child_ids[:, :nb])
+        tb = FMMTraversalBuilder(actx, well_sep_is_n_away=nway)
+        t_let, _ = tb(actx, let, _target_boxes_mask=info["target_boxes_mask"],
+                      _active_level_ranges=info["active_level_ranges"])
+        t_plain, _ = tb(actx, tree)
+        assert_same_traversal(actx.to_numpy(t_let), actx.to_numpy(t_plain))
+    finally:
+        comm.close()

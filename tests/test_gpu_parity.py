@@ -1114,6 +1114,30 @@ def test_multi_rank_local_essential_tree(dims, world, dist_kind, nway):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims,world,dist_kind,nway", [(3, 3, "sphere", 1), (3, 4, "uniform", 1),
+                                                       (2, 2, "normal", 1), (2, 4, "uniform", 2),
+                                                       (3, 8, "sphere", 1), (3, 1, "normal", 1)])
+def test_multi_rank_native_entries(dims, world, dist_kind, nway):
+    """The same check with steps 1-6 run by the library (bt_mgpu_exchange, bt_mgpu_number,
+    bt_mgpu_let_build/_export; ranks = threads over a local communicator)."""
+    check_multi_rank_let(dims, world, dist_kind, nway, native=True, expect_partial=world > 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(10))
+def test_multi_rank_native_entries_random(seed):
+    rng = np.random.default_rng(9000 + seed)
+    dims = int(rng.choice([2, 3]))
+    check_multi_rank_let(
+        dims, world=int(rng.integers(2, 9)),
+        dist_kind=str(rng.choice(["sphere", "uniform", "normal", "clustered"])),
+        nway=int(rng.choice([1, 1, 2])), n_per=int(rng.choice([3000, 20000, 50000])),
+        mpb=int(rng.choice([8, 30, 64])),
+        top_level=int(rng.integers(2, 5) if dims == 3 else rng.integers(3, 6)),
+        seed=int(rng.integers(0, 10**6)), expect_partial=False, native=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(10))
 def test_multi_rank_local_essential_tree_random(seed):
     """The same check on random rank counts, sizes, distributions, leaf sizes and
@@ -1130,7 +1154,9 @@ def test_multi_rank_local_essential_tree_random(seed):
 
 
 def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_level=None,
-                         seed=200, expect_partial=True):
+                         seed=200, expect_partial=True, native=False):
+    """native: steps 1-6 through the library's bt_mgpu_* entries, the ranks being threads
+    that share a LocalGroup; otherwise the torch implementation over tests/fake_dist.py."""
     import threading
 
     import torch
@@ -1156,20 +1182,33 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
 
     chunks = [chunk(r) for r in range(world)]
     fw = FakeWorld(world)
+    group = None
+    if native:
+        from boxtree_amd.distributed import native as nat
+        group = nat.LocalGroup(world)
     results = [None] * world
     errors = []
 
     def run(rank):
         try:
             actx = HIPArrayContext(0)
-            dist = fw.rank_view(rank)
             pts = [torch.from_numpy(a).cuda() for a in chunks[rank]]
-            p2, _, kw, stats = exchange_particles(actx, dist, pts, None, {}, top_level=top_level,
-                                                  max_particles_in_box=mpb)
-            tree, _ = TreeBuilder(actx)(actx, p2, max_particles_in_box=mpb, **kw)
-            num = number_sharded_tree(dist, tree, stats)
-            let, info = build_local_essential_tree(actx, dist, tree, stats, num,
-                                                   well_sep_is_n_away=nway)
+            if native:
+                comm = group.comm(rank)
+                p2, kw, stats = nat.exchange_particles(actx, comm, pts, mpb, top_level=top_level)
+                tree, _ = TreeBuilder(actx)(actx, p2, max_particles_in_box=mpb, **kw)
+                num = nat.number_sharded_tree(actx, comm, tree)
+                let, info = nat.build_local_essential_tree(actx, comm, tree, num,
+                                                           well_sep_is_n_away=nway)
+                comm.close()
+            else:
+                dist = fw.rank_view(rank)
+                p2, _, kw, stats = exchange_particles(actx, dist, pts, None, {}, top_level=top_level,
+                                                      max_particles_in_box=mpb)
+                tree, _ = TreeBuilder(actx)(actx, p2, max_particles_in_box=mpb, **kw)
+                num = number_sharded_tree(dist, tree, stats)
+                let, info = build_local_essential_tree(actx, dist, tree, stats, num,
+                                                       well_sep_is_n_away=nway)
             trav, _ = FMMTraversalBuilder(actx, well_sep_is_n_away=nway)(
                 actx, let, _target_boxes_mask=info["target_boxes_mask"],
                 _active_level_ranges=info["active_level_ranges"])
@@ -1192,6 +1231,9 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
     for t in threads:
         t.join(timeout=600)
     assert not errors, errors
+    assert all(not t.is_alive() for t in threads), "a rank is stuck in a collective"
+    if group is not None:
+        group.close()
 
     actx = HIPArrayContext(0)
     allpts = [torch.from_numpy(np.concatenate([c[ax] for c in chunks])).cuda()
