@@ -43,9 +43,13 @@ int orc_abi_version(void) { return 1; }
 
 /* threads used by the loops (1 in the sequential build) */
 int orc_max_threads(void) { return ORC_NTHREADS(); }
+#ifdef _OPENMP
+__attribute__((constructor)) static void orc_no_dynamic_teams(void) { omp_set_dynamic(0); }
+#endif
 void orc_set_num_threads(int n)
 {
 #ifdef _OPENMP
+    omp_set_dynamic(0);            /* the chunking assumes the team it asks for */
     if (n > 0) omp_set_num_threads(n);
 #else
     (void) n;

@@ -47,13 +47,31 @@
  * (tests/test_oracle_openmp.py). */
 #ifdef _OPENMP
 #include <omp.h>
+#include <stdio.h>
+#include <stdlib.h>
 #define ORC_NTHREADS() omp_get_max_threads()
 #define ORC_TID() omp_get_thread_num()
+/* the team a parallel region actually got (inside the region) */
+#define ORC_TEAM() omp_get_num_threads()
 #define ORC_PRAGMA(x) _Pragma(#x)
+/* Regions that size per-thread arrays by the REQUESTED team (num_threads(nth)) must get it:
+ * with a smaller team (OMP_THREAD_LIMIT, cgroup limits, nested regions; dynamic teams are
+ * switched off in orc_set_num_threads and at load time) the chunks of the missing threads
+ * would silently never be processed.  Fail loudly instead. */
+#define ORC_CHECK_TEAM(nth)                                                                   \
+    do {                                                                                      \
+        if (omp_get_num_threads() != (nth)) {                                                 \
+            fprintf(stderr, "boxtree oracle: asked for %d OpenMP threads, the runtime gave %d\n", \
+                    (int) (nth), omp_get_num_threads());                                      \
+            abort();                                                                          \
+        }                                                                                     \
+    } while (0)
 #else
 #define ORC_NTHREADS() 1
 #define ORC_TID() 0
+#define ORC_TEAM() 1
 #define ORC_PRAGMA(x)
+#define ORC_CHECK_TEAM(nth) do { } while (0)
 #endif
 /* chunk [lo_, hi_) of [0, n) of thread t out of nth */
 #define ORC_CHUNK(n, t, nth, lo_, hi_) \
@@ -178,7 +196,7 @@ void SFX(orc_bbox)(int dims, int64_t n, const COORD_T *const *coords,
         ORC_PRAGMA(omp parallel)
         {
             COORD_T tmn = COORD_MAX, tmx = -COORD_MAX;
-            ORC_CHUNK(n, ORC_TID(), ORC_NTHREADS(), lo_, hi_);
+            ORC_CHUNK(n, ORC_TID(), ORC_TEAM(), lo_, hi_);
             for (int64_t i = lo_; i < hi_; ++i) {
                 COORD_T r = radii ? radii[i] : 0;
                 COORD_T lo = coords[d][i] - r, hi = coords[d][i] + r;  /* :77-90 */
@@ -437,6 +455,7 @@ int SFX(orc_tree_build)(const SFX(orc_tree_in) *in, SFX(orc_tree_out) *out)
             if (!chunk_end || !first_boundary) { status = ORC_ERR_ALLOC; goto done; }
             ORC_PRAGMA(omp parallel num_threads(nth))
             {
+                ORC_CHECK_TEAM(nth);
                 const int t = ORC_TID();
                 ORC_CHUNK(N, t, nth, lo_, hi_);
                 orc_mc_t acc; memset(&acc, 0, sizeof(acc));

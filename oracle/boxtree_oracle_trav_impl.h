@@ -391,6 +391,7 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
         orc_ivec *parts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
         ORC_PRAGMA(omp parallel num_threads(nth))
         {
+            ORC_CHECK_TEAM(nth);
         ORC_WALK_DECL;
         orc_ivec *pl = &parts[ORC_TID()];
         ORC_CHUNK(B, ORC_TID(), nth, lo_, hi_);
@@ -436,6 +437,7 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
         orc_ivec *parts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
         ORC_PRAGMA(omp parallel num_threads(nth))
         {
+            ORC_CHECK_TEAM(nth);
         ORC_WALK_DECL;
         orc_ivec *pl = &parts[ORC_TID()];
         ORC_CHUNK(ntarget_boxes, ORC_TID(), nth, lo_, hi_);
@@ -479,6 +481,7 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
         orc_ivec *parts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
         ORC_PRAGMA(omp parallel num_threads(nth))
         {
+            ORC_CHECK_TEAM(nth);
         orc_ivec *pl = &parts[ORC_TID()];
         ORC_CHUNK(nttp, ORC_TID(), nth, lo_, hi_);
         for (int64_t it = lo_; it < hi_; ++it) {
@@ -520,6 +523,7 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
             orc_ivec *parts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
             ORC_PRAGMA(omp parallel num_threads(nth))
             {
+                ORC_CHECK_TEAM(nth);
                 orc_ivec *pl = &parts[ORC_TID()];
                 orc_ivec dummy = {0};
                 ORC_CHUNK(ntarget_boxes, ORC_TID(), nth, lo_, hi_);
@@ -541,6 +545,7 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
             orc_ivec *parts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
             ORC_PRAGMA(omp parallel num_threads(nth))
             {
+                ORC_CHECK_TEAM(nth);
                 orc_ivec *pl = &parts[ORC_TID()];
                 orc_ivec dummy = {0};
                 ORC_CHUNK(ntarget_boxes, ORC_TID(), nth, lo_, hi_);
@@ -568,6 +573,7 @@ int SFX(orc_trav_build)(const SFX(orc_trav_in) *in, SFX(orc_trav_out) *out)
         orc_ivec *cparts = (orc_ivec *) calloc((size_t) nth, sizeof(orc_ivec));
         ORC_PRAGMA(omp parallel num_threads(nth))
         {
+            ORC_CHECK_TEAM(nth);
         orc_ivec *pl = &parts[ORC_TID()], *plc = &cparts[ORC_TID()];
         ORC_CHUNK(nttp, ORC_TID(), nth, lo_, hi_);
         for (int64_t it = lo_; it < hi_; ++it) {
