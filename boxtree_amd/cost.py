@@ -65,9 +65,34 @@ def evaluate(expr, context):
 
 # {{{ translation cost model (cost.py:87-183)
 
+# Every translation is "calibration constant x size term".  The size term of a
+# particle <-> expansion operator is the coefficient count of its level; that of an
+# expansion -> expansion operator couples the counts of both levels (product, or the
+# rotate-translate-rotate sum when point-and-shoot is used).
+_PARTICLE_OPERATORS = ("p2l", "l2p", "p2m", "m2p")          # (level)
+_EXPANSION_OPERATORS = ("m2m", "l2l", "m2l")                # (source level, target level)
+
+
+def _level_operator(name):
+    def cost(self, level):
+        return var("c_" + name) * self.ncoeffs_fmm_by_level[level]
+    cost.__name__ = name
+    return cost
+
+
+def _pair_operator(name):
+    def cost(self, src_level, tgt_level):
+        counts = self.ncoeffs_fmm_by_level
+        return var("c_" + name) * self.e2e_cost(counts[src_level], counts[tgt_level])
+    cost.__name__ = name
+    return cost
+
+
 class FMMTranslationCostModel:
-    """Modeled costs of the individual translations; linear in the calibration
-    parameters ``c_*`` (cost.py:87-150)."""
+    """Modeled costs of the individual translations, linear in the calibration
+    parameters ``c_*`` (interface of ``boxtree.cost.FMMTranslationCostModel``,
+    cost.py:87-150: ``direct()``, ``p2l/l2p/p2m/m2p(level)``,
+    ``m2m/l2l/m2l(src_level, tgt_level)``, ``e2e_cost``)."""
 
     def __init__(self, ncoeffs_fmm_by_level, uses_point_and_shoot):
         self.ncoeffs_fmm_by_level = ncoeffs_fmm_by_level
@@ -77,37 +102,20 @@ class FMMTranslationCostModel:
     def direct():
         return var("c_p2p")
 
-    def p2l(self, level):
-        return var("c_p2l") * self.ncoeffs_fmm_by_level[level]
-
-    def l2p(self, level):
-        return var("c_l2p") * self.ncoeffs_fmm_by_level[level]
-
-    def p2m(self, level):
-        return var("c_p2m") * self.ncoeffs_fmm_by_level[level]
-
-    def m2p(self, level):
-        return var("c_m2p") * self.ncoeffs_fmm_by_level[level]
-
-    def m2m(self, src_level, tgt_level):
-        return var("c_m2m") * self.e2e_cost(self.ncoeffs_fmm_by_level[src_level],
-                                            self.ncoeffs_fmm_by_level[tgt_level])
-
-    def l2l(self, src_level, tgt_level):
-        return var("c_l2l") * self.e2e_cost(self.ncoeffs_fmm_by_level[src_level],
-                                            self.ncoeffs_fmm_by_level[tgt_level])
-
-    def m2l(self, src_level, tgt_level):
-        return var("c_m2l") * self.e2e_cost(self.ncoeffs_fmm_by_level[src_level],
-                                            self.ncoeffs_fmm_by_level[tgt_level])
-
     def e2e_cost(self, nsource_coeffs, ntarget_coeffs):
-        if self.uses_point_and_shoot:
-            # rotate to the z axis, translate along it, rotate back (cost.py:136-145)
-            return (nsource_coeffs ** (3 / 2)
-                    + nsource_coeffs ** (1 / 2) * ntarget_coeffs
-                    + ntarget_coeffs ** (3 / 2))
-        return nsource_coeffs * ntarget_coeffs
+        if not self.uses_point_and_shoot:
+            return nsource_coeffs * ntarget_coeffs
+        # rotation to the z axis, translation along it, rotation back (cost.py:136-145)
+        legs = ((nsource_coeffs, 3 / 2, 1), (nsource_coeffs, 1 / 2, ntarget_coeffs),
+                (ntarget_coeffs, 3 / 2, 1))
+        return sum(base ** power * factor for base, power, factor in legs)
+
+
+for _name in _PARTICLE_OPERATORS:
+    setattr(FMMTranslationCostModel, _name, _level_operator(_name))
+for _name in _EXPANSION_OPERATORS:
+    setattr(FMMTranslationCostModel, _name, _pair_operator(_name))
+del _name
 
 
 def make_pde_aware_translation_cost_model(dim, nlevels):
