@@ -2598,10 +2598,56 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     // that turns out deeper still builds (the level loop sorts the remaining bits when it
     // gets there), it only costs those extra passes.
     int est_levels = st->L;
+    // what packing depends on besides the depth
+    int pk_idbits = 1;
+    while (((int64_t) 1 << pk_idbits) < N) ++pk_idbits;
+    const int lk_max = std::min(st->L, (64 - pk_idbits - st->capbits) / D);
+    const char *e_lev = getenv("BT_PACKED_LEVELS");                // testing / tuning aids
+    bool can_pack;
+    {
+        const char *e_off = getenv("BT_NO_PACKED_KEYS");
+        const char *e_fused = getenv("BT_FUSED_LEAVES"), *e_full = getenv("BT_FULL_SORT");
+        can_pack = !(e_off && atoi(e_off)) && !(e_fused && atoi(e_fused)) && !(e_full && atoi(e_full))
+            && !p.refine_weights && p.kind == BT_KIND_ADAPTIVE
+            && (EXT || p.max_leaf_refine_weight <= SEG_BLOCK_MAX) && N >= 2 && lk_max >= 1;
+    }
+    // levels the packed word holds for a depth estimate: the passes are whole digits, take
+    // the levels they cover anyway
+    auto packed_levels_for = [&](int est) {
+        int lk = std::min(lk_max, std::max(est, 1));
+        int rb = 8;
+        const int np = bt::radix_sort_keys_plan(D * lk + st->capbits, &rb);
+        lk = std::min(lk_max, std::max(lk, (np * rb - st->capbits) / D));
+        if (e_lev && atoi(e_lev) > 0) lk = std::min(lk, atoi(e_lev));
+        return lk;
+    };
+    bool packed = false;
+    int pk_levels = 0;           // path levels in the packed word
+    int pk_sorted = 0;           // ... of which the sort orders the first pk_sorted
+    bool keys_queued = false;
+    auto queue_keygen = [&]() -> int {
+        BT_CHECK(st->keys_a.alloc(ctx->pool, N));
+        BT_CHECK(st->keys_b.alloc(ctx->pool, N));
+        BT_CHECK(st->ids_a.alloc(ctx->pool, N));
+        if (!packed) BT_CHECK(st->ids_b.alloc(ctx->pool, N));
+        keys_queued = true;
+        if (N <= 0) return BT_OK;
+        KeygenArgs<T, D> kg = ka;
+        kg.pack_idbits = packed ? pk_idbits : 0;
+        kg.pack_drop = packed ? D * (st->L - pk_levels) : 0;
+        const unsigned blocks = (unsigned) div_up(N, 256);
+        BT_CHECK(st->packed.alloc(ctx->pool, N * PackStride<D>::value * (int64_t) sizeof(T)));
+        T *packed_coords = (T *) st->packed.get();
+        if (EXT) keygen_kernel<T, D, true><<<blocks, 256, 0, ctx->stream>>>(kg, st->keys_a.get(), packed_coords);
+        else keygen_kernel<T, D, false><<<blocks, 256, 0, ctx->stream>>>(kg, st->keys_a.get(), packed_coords);
+        BT_HIP_CHECK(hipGetLastError());
+        return BT_OK;
+    };
     if (!p.refine_weights) {
         const double per_leaf = std::max(1.0, (double) N / std::max(1, p.max_leaf_refine_weight));
         const int fan = D > 1 ? D - 1 : 1;
         if (!p.top_cell_prefix) est_levels = (int) std::ceil(std::log2(per_leaf) / fan) + 2;
+        est_levels = std::max(1, std::min(est_levels, st->L));
         static const bool probe_off = [] { const char *e = getenv("BT_NO_DEPTH_PROBE"); return e && atoi(e); }();
         const bool probe = !probe_off && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED
             && (p.top_cell_prefix || N >= ((int64_t) 1 << 20));
@@ -2625,6 +2671,16 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
             BT_HIP_CHECK(hipGetLastError());
             uint32_t h_probe[3] = {0, 0, 0};
             BT_CHECK(bt::d2h(ctx, h_probe, hist.get() + ncells, sizeof(h_probe)));
+            // If N alone already allows packing, the word's format does not depend on what
+            // the probe finds -- only how many of its path bits get sorted does: the key
+            // kernel is queued first and runs while the host waits for the probe.  (With
+            // extents the cap sits between the path and the id, and sorting fewer path bits
+            // would take two bit ranges: those builds wait for the probe first.)
+            if (can_pack && !EXT && lk_max >= est_levels - 1) {
+                packed = true;
+                pk_levels = packed_levels_for(est_levels);
+                BT_CHECK(queue_keygen());
+            }
             BT_CHECK(bt::sync_stream(ctx));
             ctx->n_host_syncs++;
             // largest cell: the sample's count scaled up, with three standard deviations
@@ -2641,46 +2697,14 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         est_levels = std::max(1, std::min(est_levels, st->L));
     }
     // ---- packed keys (see rekey_full_kernel): path bits of Lk levels (and the cap) over the id --
-    bool packed = false;
-    int pk_idbits = 0, pk_levels = 0;
-    {
-        const char *e_off = getenv("BT_NO_PACKED_KEYS");           // testing / tuning aids
-        const char *e_lev = getenv("BT_PACKED_LEVELS");
-        const char *e_fused = getenv("BT_FUSED_LEAVES"), *e_full = getenv("BT_FULL_SORT");
-        int idbits = 1;
-        while (((int64_t) 1 << idbits) < N) ++idbits;
-        const int lk_max = std::min(st->L, (64 - idbits - st->capbits) / D);
-        if (!(e_off && atoi(e_off)) && !(e_fused && atoi(e_fused)) && !(e_full && atoi(e_full))
-                && !p.refine_weights && p.kind == BT_KIND_ADAPTIVE
-                && (EXT || p.max_leaf_refine_weight <= SEG_BLOCK_MAX) && N >= 2
-                && lk_max >= 1 && lk_max >= est_levels - 1) {
-            int lk = std::min(lk_max, std::max(est_levels, 1));
-            // the passes are whole digits: take the levels they cover anyway
-            int rb = 8;
-            const int np = bt::radix_sort_keys_plan(D * lk + st->capbits, &rb);
-            lk = std::min(lk_max, std::max(lk, (np * rb - st->capbits) / D));
-            if (e_lev && atoi(e_lev) > 0) lk = std::min(lk, atoi(e_lev));
+    if (keys_queued) {
+        pk_sorted = std::min(pk_levels, packed_levels_for(est_levels));
+    } else {
+        if (can_pack && lk_max >= est_levels - 1) {
             packed = true;
-            pk_idbits = idbits;
-            pk_levels = lk;
+            pk_levels = pk_sorted = packed_levels_for(est_levels);
         }
-    }
-
-    // ---- keys ----------------------------------------------------------------
-    BT_CHECK(st->keys_a.alloc(ctx->pool, N));
-    BT_CHECK(st->keys_b.alloc(ctx->pool, N));
-    BT_CHECK(st->ids_a.alloc(ctx->pool, N));
-    if (!packed) BT_CHECK(st->ids_b.alloc(ctx->pool, N));
-    if (N > 0) {
-        KeygenArgs<T, D> kg = ka;
-        kg.pack_idbits = packed ? pk_idbits : 0;
-        kg.pack_drop = packed ? D * (st->L - pk_levels) : 0;
-        const unsigned blocks = (unsigned) div_up(N, 256);
-        BT_CHECK(st->packed.alloc(ctx->pool, N * PackStride<D>::value * (int64_t) sizeof(T)));
-        T *packed_coords = (T *) st->packed.get();
-        if (EXT) keygen_kernel<T, D, true><<<blocks, 256, 0, ctx->stream>>>(kg, st->keys_a.get(), packed_coords);
-        else keygen_kernel<T, D, false><<<blocks, 256, 0, ctx->stream>>>(kg, st->keys_a.get(), packed_coords);
-        BT_HIP_CHECK(hipGetLastError());
+        BT_CHECK(queue_keygen());
     }
     BT_CHECK(mark(ctx, st, "keygen"));
 
@@ -2717,12 +2741,13 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     uint64_t *keys_cur = st->keys_a.get(), *keys_oth = st->keys_b.get();
     if (packed) {
         bool in_b = false;
-        BT_CHECK(bt::radix_sort_keys(ctx, keys_cur, keys_oth, N, pk_idbits,
+        BT_CHECK(bt::radix_sort_keys(ctx, keys_cur, keys_oth, N,
+                                     pk_idbits + (pk_sorted < pk_levels ? D * (pk_levels - pk_sorted) : 0),
                                      pk_idbits + st->capbits + D * pk_levels, &in_b));
         if (in_b) std::swap(keys_cur, keys_oth);
         keys = keys_cur;
         ids = st->ids_a.get(); ids_other = nullptr;       // filled by the fix-up
-        sorted_high_bits = D * pk_levels;
+        sorted_high_bits = D * pk_sorted;
     } else if (N > 0) {
         uint64_t *ka = st->keys_a.get(), *kb = st->keys_b.get();
         uint32_t *ia = st->ids_a.get(), *ib = st->ids_b.get();
@@ -2771,7 +2796,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     {
         static const bool off = [] { const char *e = getenv("BT_NO_CELL_STARTS"); return e && atoi(e); }();
         int k = D == 3 ? 5 : D == 2 ? 7 : 15;
-        k = std::min(k, packed ? pk_levels : st->L);
+        k = std::min(k, packed ? pk_sorted : st->L);
         if (!off && !EXT && !p.refine_weights && !p.top_cell_prefix && N >= 4096 && k >= 2
                 && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED) {
             const int64_t ncells = (int64_t) 1 << (D * k);
