@@ -167,7 +167,8 @@ class AqTree(ct.Structure):
 class MgpuParams(ct.Structure):
     _fields_ = [("dims", ct.c_int32), ("coord_kind", ct.c_int32), ("n", ct.c_int64),
                 ("coords", P3), ("top_level", ct.c_int32),
-                ("max_particles_in_box", ct.c_int64), ("alloc", vp), ("alloc_user", vp)]
+                ("max_particles_in_box", ct.c_int64), ("alloc", vp), ("alloc_user", vp),
+                ("ntargets", ct.c_int64), ("targets", P3)]
 
 
 class MgpuShard(ct.Structure):
@@ -175,7 +176,7 @@ class MgpuShard(ct.Structure):
                 ("bbox_min", ct.c_double * 3), ("bbox_max", ct.c_double * 3),
                 ("root_extent", ct.c_double), ("top_level", ct.c_int32),
                 ("top_cell_prefix", vp), ("bytes_sent", ct.c_int64), ("rounds", ct.c_int32),
-                ("a2a_ms", ct.c_float)]
+                ("a2a_ms", ct.c_float), ("n_owned_targets", ct.c_int64), ("target_points", vp)]
 
 
 class MgpuLocalTree(ct.Structure):

@@ -258,6 +258,8 @@ struct TopPlan {
     std::vector<std::vector<char>> exists, split;
     std::vector<std::vector<int32_t>> index;      // number of a box among the existing boxes of its level
     std::vector<int32_t> nboxes;                  // [k+1]
+    bool sep_targets = false;                     // the build has separate targets
+    std::vector<std::vector<int64_t>> src_counts; // [k+1][C^lev]: the sources among `counts`
     std::vector<int32_t> owner;                   // [C^k]
     std::vector<int64_t> prefix;                  // [C^k + 1]
     double bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0}, root_extent = 0;
@@ -329,6 +331,7 @@ void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, To
 
 struct MgpuState {
     Buf<unsigned char> points;       // received particles, interleaved [n_owned][dims]
+    Buf<unsigned char> tpoints;      // ... separate targets
     Buf<int64_t> cell_prefix;        // [C^top_level + 1]
     TopPlan plan;                    // of the last exchange on this context
     hipEvent_t ev[2] = {nullptr, nullptr};   // around the payload all-to-all-v
@@ -617,7 +620,8 @@ int bt_mgpu_exchange(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *
         set_error("bt_mgpu_exchange: invalid argument");
         return BT_ERR_INVALID;
     }
-    if (p->dims < 1 || p->dims > 3 || (p->coord_kind != BT_F32 && p->coord_kind != BT_F64) || p->n < 0) {
+    if (p->dims < 1 || p->dims > 3 || (p->coord_kind != BT_F32 && p->coord_kind != BT_F64) || p->n < 0
+            || p->ntargets < 0) {
         set_error("bt_mgpu_exchange: bad dims / coord_kind / n");
         return BT_ERR_INVALID;
     }
@@ -632,16 +636,23 @@ int bt_mgpu_exchange(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *
     const int D = p->dims;
     const bool f64 = p->coord_kind == BT_F64;
     const int es = f64 ? 8 : 4;
-    const int64_t n = p->n;
+    // particle sets: sources, and separate targets if there are any
+    const bool sep = p->ntargets > 0;
+    const int nsets = sep ? 2 : 1;
+    const int64_t nset[2] = {p->n, p->ntargets};
+    const void *const *cset[2] = {p->coords, p->targets};
     hipStream_t stream = ctx->stream;
 
     // ---- 1. global bounding box -> root box --------------------------------------------
-    double lmin[3], lmax[3];
-    BT_CHECK(bt_bbox(ctx, D, p->coord_kind, p->coords, nullptr, n, lmin, lmax));
+    double h_mm[6];
+    for (int ax = 0; ax < D; ++ax) { h_mm[ax] = 1.7976931348623158e+308; h_mm[D + ax] = 1.7976931348623158e+308; }
+    for (int s = 0; s < nsets; ++s) {
+        double lmin[3], lmax[3];
+        BT_CHECK(bt_bbox(ctx, D, p->coord_kind, cset[s], nullptr, nset[s], lmin, lmax));
+        for (int ax = 0; ax < D; ++ax) { h_mm[ax] = std::min(h_mm[ax], lmin[ax]); h_mm[D + ax] = std::min(h_mm[D + ax], -lmax[ax]); }
+    }
     Buf<double> mm;
     BT_CHECK(mm.alloc(ctx->pool, 2 * D));
-    double h_mm[6];
-    for (int ax = 0; ax < D; ++ax) { h_mm[ax] = lmin[ax]; h_mm[D + ax] = -lmax[ax]; }
     BT_HIP_CHECK(hipMemcpyAsync(mm.get(), h_mm, sizeof(double) * 2 * D, hipMemcpyHostToDevice, stream));
     BT_CHECK(comm_all_reduce(comm, stream, mm.get(), 2 * D, RED_MIN_F64));
     BT_HIP_CHECK(hipMemcpyAsync(h_mm, mm.get(), sizeof(double) * 2 * D, hipMemcpyDeviceToHost, stream));
@@ -661,95 +672,127 @@ int bt_mgpu_exchange(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *
         for (int ax = 0; ax < D; ++ax) { bmin[ax] = (float) h_mm[ax]; bmax[ax] = (float) ((float) h_mm[ax] + re); }
     }
 
-    // ---- 2. cell histogram, all-reduced ----------------------------------------------------
+    // ---- 2. cell histograms (sources, targets), all-reduced ------------------------------------
     const int k = p->top_level > 0 ? p->top_level : (D == 3 ? 5 : D == 2 ? 7 : 12);
     const int64_t ncells = (int64_t) 1 << (D * k);
-    Buf<uint32_t> cells;
+    Buf<uint32_t> cells[2];
     Buf<int32_t> hist32, owner_d;
     Buf<int64_t> hist64;
-    BT_CHECK(cells.alloc(ctx->pool, n));
-    BT_CHECK(hist32.alloc(ctx->pool, ncells));
-    BT_CHECK(hist64.alloc(ctx->pool, ncells));
+    BT_CHECK(hist32.alloc(ctx->pool, 2 * ncells));
+    BT_CHECK(hist64.alloc(ctx->pool, 2 * ncells));
     BT_CHECK(owner_d.alloc(ctx->pool, ncells));
-    BT_HIP_CHECK(hipMemsetAsync(hist32.get(), 0, (size_t) ncells * 4, stream));
-    BT_CHECK(bt_morton_cells(ctx, D, p->coord_kind, p->coords, n, bmin, bmax, k, cells.get(), hist32.get()));
-    widen_hist_kernel<<<(unsigned) div_up(ncells, 256), 256, 0, stream>>>(ncells, hist32.get(), hist64.get());
-    std::vector<int32_t> h_local((size_t) ncells);
-    BT_HIP_CHECK(hipMemcpyAsync(h_local.data(), hist32.get(), (size_t) ncells * 4, hipMemcpyDeviceToHost, stream));
-    BT_CHECK(comm_all_reduce(comm, stream, hist64.get(), (size_t) ncells, RED_SUM_I64));
-    std::vector<int64_t> ghist((size_t) ncells);
-    BT_HIP_CHECK(hipMemcpyAsync(ghist.data(), hist64.get(), (size_t) ncells * 8, hipMemcpyDeviceToHost, stream));
+    BT_HIP_CHECK(hipMemsetAsync(hist32.get(), 0, (size_t) ncells * 8, stream));
+    for (int s = 0; s < nsets; ++s) {
+        BT_CHECK(cells[s].alloc(ctx->pool, nset[s]));
+        BT_CHECK(bt_morton_cells(ctx, D, p->coord_kind, cset[s], nset[s], bmin, bmax, k, cells[s].get(),
+                                 hist32.get() + s * ncells));
+    }
+    widen_hist_kernel<<<(unsigned) div_up(2 * ncells, 256), 256, 0, stream>>>(2 * ncells, hist32.get(), hist64.get());
+    std::vector<int32_t> h_local((size_t) 2 * ncells);
+    BT_HIP_CHECK(hipMemcpyAsync(h_local.data(), hist32.get(), (size_t) ncells * 8, hipMemcpyDeviceToHost, stream));
+    BT_CHECK(comm_all_reduce(comm, stream, hist64.get(), (size_t) (nsets * ncells), RED_SUM_I64));
+    std::vector<int64_t> ghist2((size_t) 2 * ncells, 0), ghist((size_t) ncells);
+    BT_HIP_CHECK(hipMemcpyAsync(ghist2.data(), hist64.get(), (size_t) (nsets * ncells) * 8, hipMemcpyDeviceToHost, stream));
     BT_HIP_CHECK(hipStreamSynchronize(stream));
+    for (int64_t c = 0; c < ncells; ++c) ghist[c] = ghist2[c] + ghist2[ncells + c];
 
     // ---- 3. plan (host, identical on all ranks), counts --------------------------------------
     MgpuState *ms = mgpu_state(ctx);
     TopPlan &pl = ms->plan;
     compute_plan(D, k, p->max_particles_in_box, nranks, ghist.data(), pl);
+    // which top boxes hold sources / targets (flags of the shared top levels)
+    pl.sep_targets = sep;
+    pl.src_counts.assign((size_t) k + 1, {});
+    pl.src_counts[k].assign(ghist2.begin(), ghist2.begin() + ncells);
+    for (int lev = k - 1; lev >= 0; --lev) {
+        const int64_t n = (int64_t) 1 << (D * lev);
+        pl.src_counts[lev].assign((size_t) n, 0);
+        for (int64_t i = 0; i < n; ++i)
+            for (int m = 0; m < (1 << D); ++m) pl.src_counts[lev][i] += pl.src_counts[lev + 1][i * (1 << D) + m];
+    }
     for (int ax = 0; ax < 3; ++ax) { pl.bbox_min[ax] = bmin[ax]; pl.bbox_max[ax] = bmax[ax]; }
     pl.root_extent = root_extent;
     BT_HIP_CHECK(hipMemcpyAsync(owner_d.get(), pl.owner.data(), (size_t) ncells * 4, hipMemcpyHostToDevice, stream));
-    std::vector<int64_t> send_counts((size_t) nranks, 0);
-    for (int64_t c = 0; c < ncells; ++c) send_counts[pl.owner[c]] += h_local[c];
+    std::vector<int64_t> send_counts((size_t) 2 * nranks, 0);       // [set][owner]
+    for (int s = 0; s < nsets; ++s)
+        for (int64_t c = 0; c < ncells; ++c) send_counts[(size_t) s * nranks + pl.owner[c]] += h_local[(size_t) s * ncells + c];
     Buf<int64_t> counts_d;
-    BT_CHECK(counts_d.alloc(ctx->pool, (int64_t) nranks * (nranks + 1)));
-    BT_HIP_CHECK(hipMemcpyAsync(counts_d.get(), send_counts.data(), (size_t) nranks * 8, hipMemcpyHostToDevice, stream));
-    BT_CHECK(comm_all_gather(comm, stream, counts_d.get(), counts_d.get() + nranks, (size_t) nranks * 8));
-    std::vector<int64_t> matrix((size_t) nranks * nranks);      // [sender][receiver]
-    BT_HIP_CHECK(hipMemcpyAsync(matrix.data(), counts_d.get() + nranks, matrix.size() * 8, hipMemcpyDeviceToHost, stream));
+    const int64_t row = 2 * nranks;
+    BT_CHECK(counts_d.alloc(ctx->pool, row * (nranks + 1)));
+    BT_HIP_CHECK(hipMemcpyAsync(counts_d.get(), send_counts.data(), (size_t) row * 8, hipMemcpyHostToDevice, stream));
+    BT_CHECK(comm_all_gather(comm, stream, counts_d.get(), counts_d.get() + row, (size_t) row * 8));
+    std::vector<int64_t> matrix((size_t) row * nranks);      // [sender][set][receiver]
+    BT_HIP_CHECK(hipMemcpyAsync(matrix.data(), counts_d.get() + row, matrix.size() * 8, hipMemcpyDeviceToHost, stream));
     BT_HIP_CHECK(hipStreamSynchronize(stream));
     const int64_t rec = (int64_t) D * es;                       // bytes per particle
-    std::vector<int64_t> s_off((size_t) nranks + 1, 0), r_off((size_t) nranks + 1, 0);
-    std::vector<int64_t> s_cnt_b((size_t) nranks), r_cnt_b((size_t) nranks), s_off_b((size_t) nranks),
-        r_off_b((size_t) nranks);
-    int64_t biggest = 0;
-    for (int r = 0; r < nranks; ++r) {
-        const int64_t rc = matrix[(size_t) r * nranks + rank];
-        s_off[r + 1] = s_off[r] + send_counts[r];
-        r_off[r + 1] = r_off[r] + rc;
-        s_cnt_b[r] = send_counts[r] * rec; r_cnt_b[r] = rc * rec;
-        s_off_b[r] = s_off[r] * rec; r_off_b[r] = r_off[r] * rec;
-        for (int q = 0; q < nranks; ++q)
-            if (q != r) biggest = std::max(biggest, matrix[(size_t) r * nranks + q] * rec);
-    }
-    const int64_t nrecv = r_off[nranks];
 
-    // ---- 4. payload: interleaved coordinates -------------------------------------------------
-    Buf<unsigned char> send;
-    BT_CHECK(send.alloc(ctx->pool, n * D * es));
-    unsigned char *points = nullptr;
-    const int64_t points_bytes = std::max<int64_t>(nrecv, 1) * D * es;
-    if (p->alloc) {
-        points = (unsigned char *) p->alloc(p->alloc_user, points_bytes);
-        if (!points) { set_error("bt_mgpu_exchange: the caller's allocator returned NULL"); return BT_ERR_ALLOC; }
-        ms->points.reset();
-    } else {
-        BT_CHECK(ms->points.alloc(ctx->pool, points_bytes));
-        points = ms->points.get();
-    }
-    // one sweep over the coordinates: stable partition by owner into the send buffer, the
-    // segment this rank keeps straight into the receive buffer (bt_shard.hip)
-    BT_CHECK(bt_partition_pack(ctx, D, es, p->coords, cells.get(), n, owner_d.get(), nranks, rank,
-                               s_off[rank], r_off[rank], send.get(), points));
-    int32_t rounds = 1;
-    s_cnt_b[rank] = 0; r_cnt_b[rank] = 0;       // (own segment: packed in place)
+    // ---- 4. payload: interleaved coordinates, one exchange per particle set -------------------
     if (!ms->ev[0]) { BT_HIP_CHECK(hipEventCreate(&ms->ev[0])); BT_HIP_CHECK(hipEventCreate(&ms->ev[1])); }
     BT_HIP_CHECK(hipEventRecord(ms->ev[0], stream));
-    BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send.get(), s_off_b.data(), s_cnt_b.data(),
-                               (char *) points, r_off_b.data(), r_cnt_b.data(), biggest, true, &rounds));
+    int32_t rounds_total = 0;
+    int64_t bytes_sent = 0;
+    unsigned char *points_of[2] = {nullptr, nullptr};
+    int64_t nrecv_of[2] = {0, 0};
+    for (int s = 0; s < nsets; ++s) {
+        const int64_t n = nset[s];
+        std::vector<int64_t> s_off((size_t) nranks + 1, 0), r_off((size_t) nranks + 1, 0);
+        std::vector<int64_t> s_cnt_b((size_t) nranks), r_cnt_b((size_t) nranks), s_off_b((size_t) nranks),
+            r_off_b((size_t) nranks);
+        int64_t biggest = 0;
+        for (int r = 0; r < nranks; ++r) {
+            const int64_t sc = send_counts[(size_t) s * nranks + r];
+            const int64_t rc = matrix[(size_t) r * row + (size_t) s * nranks + rank];
+            s_off[r + 1] = s_off[r] + sc;
+            r_off[r + 1] = r_off[r] + rc;
+            s_cnt_b[r] = sc * rec; r_cnt_b[r] = rc * rec;
+            s_off_b[r] = s_off[r] * rec; r_off_b[r] = r_off[r] * rec;
+            for (int q = 0; q < nranks; ++q)
+                if (q != r) biggest = std::max(biggest, matrix[(size_t) r * row + (size_t) s * nranks + q] * rec);
+        }
+        const int64_t nrecv = r_off[nranks];
+        Buf<unsigned char> send;
+        BT_CHECK(send.alloc(ctx->pool, n * D * es));
+        unsigned char *points = nullptr;
+        const int64_t points_bytes = std::max<int64_t>(nrecv, 1) * D * es;
+        Buf<unsigned char> &own = s == 0 ? ms->points : ms->tpoints;
+        if (p->alloc) {
+            points = (unsigned char *) p->alloc(p->alloc_user, points_bytes);
+            if (!points) { set_error("bt_mgpu_exchange: the caller's allocator returned NULL"); return BT_ERR_ALLOC; }
+            own.reset();
+        } else {
+            BT_CHECK(own.alloc(ctx->pool, points_bytes));
+            points = own.get();
+        }
+        // one sweep over the coordinates: stable partition by owner into the send buffer, the
+        // segment this rank keeps straight into the receive buffer (bt_shard.hip)
+        BT_CHECK(bt_partition_pack(ctx, D, es, cset[s], cells[s].get(), n, owner_d.get(), nranks, rank,
+                                   s_off[rank], r_off[rank], send.get(), points));
+        int32_t rounds = 1;
+        s_cnt_b[rank] = 0; r_cnt_b[rank] = 0;       // (own segment: packed in place)
+        BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send.get(), s_off_b.data(), s_cnt_b.data(),
+                                   (char *) points, r_off_b.data(), r_cnt_b.data(), biggest, true, &rounds));
+        BT_HIP_CHECK(hipStreamSynchronize(stream));     // the send buffer and the host vectors go out of scope
+        rounds_total += rounds;
+        bytes_sent += (n - send_counts[(size_t) s * nranks + rank]) * rec;
+        points_of[s] = points;
+        nrecv_of[s] = nrecv;
+    }
     BT_HIP_CHECK(hipEventRecord(ms->ev[1], stream));
     BT_CHECK(ms->cell_prefix.alloc(ctx->pool, ncells + 1));
     BT_HIP_CHECK(hipMemcpyAsync(ms->cell_prefix.get(), pl.prefix.data(), (size_t) (ncells + 1) * 8,
                                 hipMemcpyHostToDevice, stream));
     BT_HIP_CHECK(hipStreamSynchronize(stream));     // host vectors above go out of scope
 
-    out->n_owned = nrecv;
-    out->points = points;
+    out->n_owned = nrecv_of[0];
+    out->points = points_of[0];
+    out->n_owned_targets = nrecv_of[1];
+    out->target_points = points_of[1];
     for (int ax = 0; ax < D; ++ax) { out->bbox_min[ax] = bmin[ax]; out->bbox_max[ax] = bmax[ax]; }
     out->root_extent = root_extent;
     out->top_level = k;
     out->top_cell_prefix = p->max_particles_in_box > 0 ? ms->cell_prefix.get() : nullptr;
-    out->bytes_sent = (n - send_counts[rank]) * rec;
-    out->rounds = rounds;
+    out->bytes_sent = bytes_sent;
+    out->rounds = rounds_total;
     (void) hipEventElapsedTime(&out->a2a_ms, ms->ev[0], ms->ev[1]);
     return BT_OK;
 }
@@ -975,8 +1018,13 @@ int bt_mgpu_let_build(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_t
             if (!pl.exists[lev][pth]) continue;
             const bool internal = pl.split[lev][pth];
             // tree.py:109-145 with sources = targets: children on both sides, or a leaf that is both
-            const int32_t flags = internal ? (BT_BOX_HAS_SOURCE_CHILD_BOXES | BT_BOX_HAS_TARGET_CHILD_BOXES)
-                                           : (BT_BOX_IS_SOURCE_BOX | BT_BOX_IS_TARGET_BOX);
+            int32_t flags = internal ? (BT_BOX_HAS_SOURCE_CHILD_BOXES | BT_BOX_HAS_TARGET_CHILD_BOXES)
+                                     : (BT_BOX_IS_SOURCE_BOX | BT_BOX_IS_TARGET_BOX);
+            if (!internal && pl.sep_targets) {
+                // a leaf is a source box iff it holds sources, a target box iff targets (tbk:1258-1262)
+                const int64_t ns = pl.src_counts[lev][pth], nt = pl.counts[lev][pth] - ns;
+                flags = (ns > 0 ? BT_BOX_IS_SOURCE_BOX : 0) | (nt > 0 ? BT_BOX_IS_TARGET_BOX : 0);
+            }
             // lists of the shared internal boxes are built by every rank, those of a top LEAF
             // only by the rank that owns its cells
             const int64_t first_cell = pth << (D * (k - lev));

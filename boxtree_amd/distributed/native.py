@@ -110,12 +110,15 @@ def rccl_comm(actx, dist):
 
 
 def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=None,
-                       own_buffer=False):
+                       own_buffer=False, targets=None):
     """Steps 1-3 (``bt_mgpu_exchange``).  Returns ``(particles, build_kw, stats)`` for the
     local ``TreeBuilder`` call: views of the interleaved receive buffer, and ``_root_box`` /
     ``_top_tree`` / ``_point_stride``.  The receive buffer belongs to the context and is
     valid until its next exchange (the tree build copies what it keeps); with
-    *own_buffer* it is a torch allocation the returned views keep alive."""
+    *own_buffer* it is a torch allocation the returned views keep alive.  With separate
+    point *targets* the return value is ``(particles, targets, build_kw, stats)``: both sets
+    travel to the owners of their cells (cells are counted over sources and targets), and
+    come back as contiguous arrays."""
     import torch
     dims = len(particles)
     dev = particles[0].device
@@ -130,10 +133,18 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
         par.coords[ax] = keep[ax].data_ptr()
     par.top_level = int(top_level or 0)
     par.max_particles_in_box = int(max_particles_in_box or 0)
+    if targets is not None:
+        keep_t = [t.contiguous() for t in targets]
+        par.ntargets = len(keep_t[0])
+        for ax in range(dims):
+            par.targets[ax] = keep_t[ax].data_ptr()
+        own_buffer = True
     got = {}
+    bufs = []
 
     def alloc(_user, nbytes):
         got["buf"] = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        bufs.append(got["buf"])
         return got["buf"].data_ptr()
 
     cb = _lib.ALLOC_FN(alloc)
@@ -143,6 +154,8 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
     actx.sync_in()
     _lib.check(actx.lib.bt_mgpu_exchange(actx.handle, comm.handle, ct.byref(par), ct.byref(shard)))
     n_owned = int(shard.n_owned)
+    if targets is not None:
+        return _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev)
     if own_buffer:
         recv = got["buf"][:n_owned * dims * es].view(dtype).view(n_owned, dims)
     else:
@@ -169,6 +182,32 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
                  bbox_min=bbox_min, bbox_max=bbox_max, root_extent=root_extent,
                  planned=bool(shard.top_cell_prefix), recv_buffer=got.get("buf"))
     return new_particles, build_kw, stats
+
+
+def _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev):
+    """Contiguous coordinate arrays of both received sets (``bt_unpack``) + build kwargs."""
+    import torch
+    out = []
+    for buf, n in ((bufs[0], int(shard.n_owned)), (bufs[1], int(shard.n_owned_targets))):
+        arrs = [torch.empty(n, dtype=dtype, device=dev) for _ in range(dims)]
+        optrs = (ct.c_void_p * dims)(*[a.data_ptr() for a in arrs])
+        if n:
+            _lib.check(actx.lib.bt_unpack(actx.handle, dims, es, ct.c_void_p(buf.data_ptr()), n, optrs))
+        out.append(arrs)
+    coord = np.dtype(np.float64 if dtype == torch.float64 else np.float32)
+    bbox_min = np.array(shard.bbox_min[:dims], dtype=coord)
+    bbox_max = np.array(shard.bbox_max[:dims], dtype=coord)
+    root_extent = coord.type(shard.root_extent)
+    build_kw = {"_root_box": (bbox_min, bbox_max, root_extent)}
+    k = int(shard.top_level)
+    if shard.top_cell_prefix:
+        prefix = torch.as_tensor(
+            _DevicePointer(shard.top_cell_prefix, ((1 << (dims * k)) + 1,), "<i8"), device=dev)
+        build_kw["_top_tree"] = (k, prefix)
+    stats = dict(bytes_sent=int(shard.bytes_sent), rounds=int(shard.rounds), top_level=k,
+                 a2a_ms=float(shard.a2a_ms), bbox_min=bbox_min, bbox_max=bbox_max,
+                 root_extent=root_extent, planned=bool(shard.top_cell_prefix))
+    return out[0], out[1], build_kw, stats
 
 
 def _local_tree_view(actx, tree):

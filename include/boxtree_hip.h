@@ -569,6 +569,9 @@ typedef struct {
                                        /* leaves on one rank (kind "adaptive", unit weights) */
     bt_alloc_fn alloc;                 /* NULL: `points` below is owned by the context;     */
     void *alloc_user;                  /* else the receive buffer comes from the caller     */
+    int64_t ntargets;                  /* separate point targets of this rank's chunk, or 0 */
+    const void *targets[BT_MAX_DIMS];  /* (sources are the targets); exchanged by the same  */
+                                       /* owners, cells counted over sources AND targets     */
 } bt_mgpu_params;
 
 typedef struct {
@@ -583,6 +586,8 @@ typedef struct {
     int32_t rounds;                    /* point-to-point rounds of the all-to-all       */
     float a2a_ms;                      /* device time of the payload all-to-all-v (HIP   */
                                        /* events on the context's stream)               */
+    int64_t n_owned_targets;           /* separate targets: the ones this rank owns, laid */
+    void *target_points;               /* out like `points` (second allocation)          */
 } bt_mgpu_shard;
 
 /* the one-sweep partition (bt_partition_pack) keeps one run per owner in LDS: at most this

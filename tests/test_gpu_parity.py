@@ -868,6 +868,14 @@ def test_multi_rank_pipeline_in_process(dims, world, dist_kind):
         return [rng.standard_normal(n_per) for _ in range(dims)]
 
     chunks = [chunk(r) for r in range(world)]
+    # separate point targets (native entries only): a third as many, another stream
+    tchunks = None
+    if sep_targets:
+        assert native
+        full_n = n_per
+        n_per = max(n_per // 3, 1)
+        tchunks = [chunk(1000 + r) for r in range(world)]
+        n_per = full_n
     fw = FakeWorld(world)
     results = [None] * world
     errors = []
@@ -906,7 +914,11 @@ def test_multi_rank_pipeline_in_process(dims, world, dist_kind):
     actx = HIPArrayContext(0)
     allpts = [torch.from_numpy(np.concatenate([c[ax] for c in chunks])).cuda()
               for ax in range(dims)]
-    gt, _ = TreeBuilder(actx)(actx, allpts, max_particles_in_box=mpb)
+    alltgts = None
+    if sep_targets:
+        alltgts = [torch.from_numpy(np.concatenate([c[ax] for c in tchunks])).cuda()
+                   for ax in range(dims)]
+    gt, _ = TreeBuilder(actx)(actx, allpts, targets=alltgts, max_particles_in_box=mpb)
     full = actx.to_numpy(FMMTraversalBuilder(actx)(actx, gt)[0])
     g = actx.to_numpy(gt)
     assert sum(r["nlocal"] for r in results) == world * n_per
@@ -1124,6 +1136,17 @@ def test_multi_rank_native_entries(dims, world, dist_kind, nway):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims,world,dist_kind,nway", [(3, 3, "sphere", 1), (2, 4, "uniform", 2),
+                                                       (3, 5, "clustered", 1), (2, 2, "normal", 1)])
+def test_multi_rank_native_entries_separate_targets(dims, world, dist_kind, nway):
+    """Sources and separate point targets through bt_mgpu_exchange: cells are counted over
+    both sets, the flags of the shared top boxes come from the per-cell source and target
+    counts, and the per-rank trees and lists are those of the single-GPU build."""
+    check_multi_rank_let(dims, world, dist_kind, nway, native=True, expect_partial=False,
+                         sep_targets=True)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(10))
 def test_multi_rank_native_entries_random(seed):
     rng = np.random.default_rng(9000 + seed)
@@ -1154,7 +1177,7 @@ def test_multi_rank_local_essential_tree_random(seed):
 
 
 def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_level=None,
-                         seed=200, expect_partial=True, native=False):
+                         seed=200, expect_partial=True, native=False, sep_targets=False):
     """native: steps 1-6 through the library's bt_mgpu_* entries, the ranks being threads
     that share a LocalGroup; otherwise the torch implementation over tests/fake_dist.py."""
     import threading
@@ -1181,6 +1204,14 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
         return [rng.standard_normal(n_per) for _ in range(dims)]
 
     chunks = [chunk(r) for r in range(world)]
+    # separate point targets (native entries only): a third as many, another stream
+    tchunks = None
+    if sep_targets:
+        assert native
+        full_n = n_per
+        n_per = max(n_per // 3, 1)
+        tchunks = [chunk(1000 + r) for r in range(world)]
+        n_per = full_n
     fw = FakeWorld(world)
     group = None
     if native:
@@ -1195,8 +1226,14 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
             pts = [torch.from_numpy(a).cuda() for a in chunks[rank]]
             if native:
                 comm = group.comm(rank)
-                p2, kw, stats = nat.exchange_particles(actx, comm, pts, mpb, top_level=top_level)
-                tree, _ = TreeBuilder(actx)(actx, p2, max_particles_in_box=mpb, **kw)
+                if sep_targets:
+                    tg = [torch.from_numpy(a).cuda() for a in tchunks[rank]]
+                    p2, t2, kw, stats = nat.exchange_particles(actx, comm, pts, mpb, top_level=top_level,
+                                                               targets=tg)
+                    tree, _ = TreeBuilder(actx)(actx, p2, targets=t2, max_particles_in_box=mpb, **kw)
+                else:
+                    p2, kw, stats = nat.exchange_particles(actx, comm, pts, mpb, top_level=top_level)
+                    tree, _ = TreeBuilder(actx)(actx, p2, max_particles_in_box=mpb, **kw)
                 num = nat.number_sharded_tree(actx, comm, tree)
                 let, info = nat.build_local_essential_tree(actx, comm, tree, num,
                                                            well_sep_is_n_away=nway)
@@ -1238,7 +1275,11 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
     actx = HIPArrayContext(0)
     allpts = [torch.from_numpy(np.concatenate([c[ax] for c in chunks])).cuda()
               for ax in range(dims)]
-    gt, _ = TreeBuilder(actx)(actx, allpts, max_particles_in_box=mpb)
+    alltgts = None
+    if sep_targets:
+        alltgts = [torch.from_numpy(np.concatenate([c[ax] for c in tchunks])).cuda()
+                   for ax in range(dims)]
+    gt, _ = TreeBuilder(actx)(actx, allpts, targets=alltgts, max_particles_in_box=mpb)
     full = actx.to_numpy(FMMTraversalBuilder(actx, well_sep_is_n_away=nway)(actx, gt)[0])
     g = actx.to_numpy(gt)
 
