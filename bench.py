@@ -360,7 +360,13 @@ def main():
     if (distributed and backend == "nccl" and targets is None and not build_kw
             and os.environ.get("BOXTREE_HIP_NATIVE_MGPU", "1") != "0"):
         from boxtree_amd.distributed import native as nat
-        native_comm = nat.rccl_comm(actx, dist)
+        try:
+            native_comm = nat.rccl_comm(actx, dist)
+        except (RuntimeError, OSError) as e:
+            # (every rank fails or succeeds alike: the same library, the same call)
+            print(f"bench.py: no RCCL communicator of our own ({e}); the torch.distributed "
+                  "implementation of the sharded build runs instead", file=sys.stderr)
+            native_comm = None
 
     stage_acc: dict[str, float] = {}
     sort_ms = []

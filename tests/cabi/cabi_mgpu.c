@@ -1,0 +1,194 @@
+/* A plain-C consumer of the multi-GPU entries of include/boxtree_hip.h: no Python, no
+ * torch.  NRANKS ranks run as threads of this process (bt_mgpu_local_group_create: a test
+ * box has one GPU, which RCCL will not share between ranks; with an RCCL communicator per
+ * process the calls are the same), every rank with a context of its own:
+ *
+ *   bt_mgpu_exchange -> bt_tree_build / bt_tree_export -> bt_mgpu_number
+ *   -> bt_mgpu_let_build / bt_mgpu_let_export
+ *
+ *   cabi_mgpu <nranks> <dims> <n_per_rank> <max_particles_in_box> <seed>
+ *
+ * Rank r draws its chunk from the stream seeded with seed + r (splitmix64, uniform).  One
+ * line per rank: what it owns and where its boxes sit in the global tree;
+ * tests/test_gpu_cabi.py compares the global figures with the tree the Python layer
+ * builds on one GPU from all chunks. */
+#include <hip/hip_runtime_api.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "boxtree_hip.h"
+
+#define CHECK_HIP(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { \
+    fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); return 2; } } while (0)
+#define CHECK_BT(e) do { int s_ = (e); if (s_ != 0) { \
+    fprintf(stderr, "%s:%d: boxtree error %d: %s\n", __FILE__, __LINE__, s_, \
+            bt_last_error_string()); return 3; } } while (0)
+
+static uint64_t splitmix64(uint64_t *s)
+{
+    uint64_t z = (*s += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+typedef struct {
+    int rank, nranks, dims, mpb;
+    int64_t n;
+    uint64_t seed;
+    void *group;
+    int status;
+    /* results */
+    int64_t n_owned, nboxes_local, nboxes_global, let_nboxes, halo_in, source_offset, nsources_global;
+    int32_t nlevels_global;
+    uint64_t digest_ids;           /* sum of the global numbers of the rank's deep boxes */
+} rank_args;
+
+static int run_rank(rank_args *a)
+{
+    const int dims = a->dims;
+    const int64_t n = a->n;
+    CHECK_HIP(hipSetDevice(0));
+    uint64_t seed = a->seed + (uint64_t) a->rank;
+    void *dev[3] = {0, 0, 0};
+    for (int ax = 0; ax < dims; ++ax) {
+        double *host = (double *) malloc((size_t) n * sizeof(double));
+        for (int64_t i = 0; i < n; ++i)
+            host[i] = (double) (splitmix64(&seed) >> 11) * (1.0 / 9007199254740992.0);
+        CHECK_HIP(hipMalloc(&dev[ax], (size_t) n * sizeof(double)));
+        CHECK_HIP(hipMemcpy(dev[ax], host, (size_t) n * sizeof(double), hipMemcpyHostToDevice));
+        free(host);
+    }
+    bt_context *ctx = NULL;
+    CHECK_BT(bt_create(0, NULL, &ctx));
+    bt_mgpu_comm *comm = NULL;
+    CHECK_BT(bt_mgpu_comm_local(a->group, a->rank, &comm));
+
+    /* steps 1-3 */
+    bt_mgpu_params mp;
+    memset(&mp, 0, sizeof(mp));
+    mp.dims = dims; mp.coord_kind = BT_F64; mp.n = n; mp.max_particles_in_box = a->mpb;
+    for (int ax = 0; ax < dims; ++ax) mp.coords[ax] = dev[ax];
+    bt_mgpu_shard sh;
+    CHECK_BT(bt_mgpu_exchange(ctx, comm, &mp, &sh));
+
+    /* step 4 */
+    bt_tree_params tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.dims = dims; tp.coord_kind = BT_F64; tp.nsources = sh.n_owned; tp.ntargets = -1;
+    tp.max_leaf_refine_weight = a->mpb; tp.kind = BT_KIND_ADAPTIVE; tp.extent_norm = BT_NORM_NONE;
+    tp.root_extent = sh.root_extent; tp.top_level = sh.top_level; tp.top_cell_prefix = sh.top_cell_prefix;
+    tp.source_stride = dims;
+    for (int ax = 0; ax < dims; ++ax) {
+        tp.sources[ax] = (const double *) sh.points + ax;
+        tp.bbox_min[ax] = sh.bbox_min[ax]; tp.bbox_max[ax] = sh.bbox_max[ax];
+    }
+    bt_tree_sizes sz;
+    CHECK_BT(bt_tree_build(ctx, &tp, &sz));
+    const int C = 1 << dims;
+    const size_t nb = (size_t) sz.nboxes, al = (size_t) sz.aligned_nboxes, no = (size_t) (sh.n_owned > 0 ? sh.n_owned : 1);
+    bt_tree_arrays o;
+    memset(&o, 0, sizeof(o));
+    CHECK_HIP(hipMalloc((void **) &o.user_source_ids, no * 4));
+    CHECK_HIP(hipMalloc((void **) &o.sorted_target_ids, no * 4));
+    for (int ax = 0; ax < dims; ++ax) CHECK_HIP(hipMalloc(&o.sources[ax], no * 8));
+    CHECK_HIP(hipMalloc((void **) &o.box_source_starts, nb * 4));
+    CHECK_HIP(hipMalloc((void **) &o.box_source_counts_nonchild, nb * 4));
+    CHECK_HIP(hipMalloc((void **) &o.box_source_counts_cumul, nb * 4));
+    CHECK_HIP(hipMalloc((void **) &o.box_parent_ids, nb * 4));
+    CHECK_HIP(hipMalloc((void **) &o.box_child_ids, (size_t) C * al * 4));
+    CHECK_HIP(hipMalloc(&o.box_centers, (size_t) dims * al * 8));
+    CHECK_HIP(hipMalloc((void **) &o.box_levels, nb));
+    CHECK_HIP(hipMalloc((void **) &o.box_flags, nb));
+    CHECK_HIP(hipMalloc(&o.box_source_bounding_box_min, (size_t) dims * al * 8));
+    CHECK_HIP(hipMalloc(&o.box_source_bounding_box_max, (size_t) dims * al * 8));
+    CHECK_BT(bt_tree_export(ctx, &o));
+    CHECK_BT(bt_synchronize(ctx));
+
+    /* step 5 */
+    bt_mgpu_local_tree lt;
+    memset(&lt, 0, sizeof(lt));
+    lt.dims = dims; lt.coord_kind = BT_F64; lt.nboxes = sz.nboxes; lt.aligned_nboxes = sz.aligned_nboxes;
+    lt.nlevels = sz.nlevels; lt.level_start_box_nrs = sz.level_start_box_nrs;
+    lt.box_centers = o.box_centers; lt.box_levels = o.box_levels; lt.box_flags = o.box_flags;
+    lt.nsources = sh.n_owned; lt.ntargets = sh.n_owned;
+    int32_t *d_box_ids = NULL;
+    CHECK_HIP(hipMalloc((void **) &d_box_ids, nb * 4));
+    bt_mgpu_numbering num;
+    CHECK_BT(bt_mgpu_number(ctx, comm, &lt, d_box_ids, &num));
+
+    /* step 6 */
+    bt_mgpu_let_sizes ls;
+    CHECK_BT(bt_mgpu_let_build(ctx, comm, &lt, d_box_ids, &num, 1, &ls));
+    bt_mgpu_let_arrays la;
+    memset(&la, 0, sizeof(la));
+    const size_t lb = (size_t) ls.nboxes, lal = (size_t) ls.aligned_nboxes;
+    CHECK_HIP(hipMalloc(&la.box_centers, (size_t) dims * lal * 8));
+    CHECK_HIP(hipMalloc((void **) &la.box_parent_ids, lb * 4));
+    CHECK_HIP(hipMalloc((void **) &la.box_child_ids, (size_t) C * lal * 4));
+    CHECK_HIP(hipMalloc((void **) &la.box_levels, lb));
+    CHECK_HIP(hipMalloc((void **) &la.box_flags, lb));
+    CHECK_HIP(hipMalloc((void **) &la.global_box_ids, lb * 4));
+    CHECK_HIP(hipMalloc((void **) &la.target_boxes_mask, lb));
+    CHECK_BT(bt_mgpu_let_export(ctx, &la));
+    CHECK_BT(bt_synchronize(ctx));
+
+    /* digest: global numbers of the boxes this rank owns below the shared top levels */
+    int32_t *h_ids = (int32_t *) malloc(nb * 4);
+    uint8_t *h_lev = (uint8_t *) malloc(nb);
+    CHECK_HIP(hipMemcpy(h_ids, d_box_ids, nb * 4, hipMemcpyDeviceToHost));
+    CHECK_HIP(hipMemcpy(h_lev, o.box_levels, nb, hipMemcpyDeviceToHost));
+    uint64_t dg = 0;
+    for (size_t b = 0; b < nb; ++b)
+        if (h_lev[b] > sh.top_level) dg += (uint64_t) h_ids[b];
+    a->n_owned = sh.n_owned; a->nboxes_local = sz.nboxes; a->nboxes_global = num.nboxes;
+    a->nlevels_global = num.nlevels; a->let_nboxes = ls.nboxes; a->halo_in = ls.halo_boxes_received;
+    a->source_offset = num.source_offset; a->nsources_global = num.nsources; a->digest_ids = dg;
+    bt_mgpu_comm_destroy(comm);
+    bt_destroy(ctx);
+    return 0;
+}
+
+static void *thread_main(void *p)
+{
+    rank_args *a = (rank_args *) p;
+    a->status = run_rank(a);
+    if (a->status != 0) {           /* the other ranks would wait for this one forever */
+        fprintf(stderr, "rank %d failed with status %d\n", a->rank, a->status);
+        exit(a->status);
+    }
+    return NULL;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc != 6) { fprintf(stderr, "usage: %s nranks dims n_per_rank mpb seed\n", argv[0]); return 1; }
+    const int nranks = atoi(argv[1]), dims = atoi(argv[2]), mpb = atoi(argv[4]);
+    const int64_t n = atoll(argv[3]);
+    const uint64_t seed = (uint64_t) atoll(argv[5]);
+    if (nranks < 1 || nranks > 64 || dims < 1 || dims > 3 || n < 1) return 1;
+    if (bt_abi_version() != BT_ABI_VERSION) { fprintf(stderr, "ABI version mismatch\n"); return 4; }
+    void *group = NULL;
+    CHECK_BT(bt_mgpu_local_group_create(nranks, &group));
+    rank_args *args = (rank_args *) calloc((size_t) nranks, sizeof(rank_args));
+    pthread_t *th = (pthread_t *) calloc((size_t) nranks, sizeof(pthread_t));
+    for (int r = 0; r < nranks; ++r) {
+        args[r].rank = r; args[r].nranks = nranks; args[r].dims = dims; args[r].mpb = mpb;
+        args[r].n = n; args[r].seed = seed; args[r].group = group;
+        pthread_create(&th[r], NULL, thread_main, &args[r]);
+    }
+    for (int r = 0; r < nranks; ++r) pthread_join(th[r], NULL);
+    for (int r = 0; r < nranks; ++r)
+        printf("rank %d owned %lld source_offset %lld nboxes_local %lld nboxes_global %lld "
+               "nlevels_global %d nsources_global %lld let_nboxes %lld halo_in %lld deep_ids %llu\n",
+               r, (long long) args[r].n_owned, (long long) args[r].source_offset,
+               (long long) args[r].nboxes_local, (long long) args[r].nboxes_global,
+               args[r].nlevels_global, (long long) args[r].nsources_global,
+               (long long) args[r].let_nboxes, (long long) args[r].halo_in,
+               (unsigned long long) args[r].digest_ids);
+    bt_mgpu_local_group_destroy(group);
+    return 0;
+}

@@ -54,3 +54,44 @@ def test_plain_c_program_builds_the_same_tree(dims, n, mpb, seed):
     assert int(got["cumul"]) == cumul
     assert int(got["ids"]) == ids
     assert int(got["levels"]) == int(h.box_levels.astype(np.uint64).sum())
+
+
+@pytest.mark.parametrize("nranks,dims,n,mpb,seed", [(1, 3, 100000, 30, 21), (3, 3, 80000, 30, 5),
+                                                   (4, 2, 60000, 10, 9), (8, 3, 40000, 64, 2)])
+def test_plain_c_program_runs_the_sharded_build(nranks, dims, n, mpb, seed):
+    """tests/cabi/cabi_mgpu.c: steps 1-6 of the sharded build (exchange, per-rank build,
+    global numbering, local essential tree) from plain C, the ranks being pthreads over the
+    library's local communicator.  The global figures every rank reports must be those of the
+    tree one GPU builds from all chunks; the ranks' deep boxes carry every global number
+    below the shared top levels exactly once."""
+    exe = os.path.join(HERE, "cabi", "cabi_mgpu")
+    if not os.path.exists(exe):
+        pytest.fail("tests/cabi/cabi_mgpu missing: __graft_entry__.build() compiles it")
+    out = subprocess.run([exe, str(nranks), str(dims), str(n), str(mpb), str(seed)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    rows = []
+    for line in out.stdout.splitlines():
+        tok = line.split()
+        if tok and tok[0] == "rank":
+            rows.append({tok[i]: int(tok[i + 1]) for i in range(0, len(tok), 2)})
+    assert [r["rank"] for r in rows] == list(range(nranks))
+
+    from boxtree_amd import HIPArrayContext, TreeBuilder
+    actx = HIPArrayContext(0)
+    chunks = [[splitmix64_uniform(seed + r, n * dims)[ax * n:(ax + 1) * n] for ax in range(dims)]
+              for r in range(nranks)]
+    pts = [np.concatenate([c[ax] for c in chunks]) for ax in range(dims)]
+    tree, _ = TreeBuilder(actx)(actx, [actx.from_numpy(p) for p in pts], max_particles_in_box=mpb)
+    h = actx.to_numpy(tree)
+    top_level = 5 if dims == 3 else 7
+    assert sum(r["owned"] for r in rows) == nranks * n
+    offsets = np.cumsum([0] + [r["owned"] for r in rows[:-1]])
+    for r, off in zip(rows, offsets):
+        assert r["nboxes_global"] == h.nboxes and r["nlevels_global"] == h.nlevels
+        assert r["nsources_global"] == nranks * n and r["source_offset"] == int(off)
+        assert r["let_nboxes"] <= h.nboxes
+    if nranks == 1:
+        assert rows[0]["let_nboxes"] == h.nboxes and rows[0]["halo_in"] == 0
+    deep = np.nonzero(h.box_levels > top_level)[0].astype(np.uint64)
+    assert sum(r["deep_ids"] for r in rows) == int(deep.sum())
