@@ -643,8 +643,8 @@ int bt_mgpu_number(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree
  * ranks' cells within well_sep_is_n_away cells of its own (one all-to-all-v of 16-byte
  * box records between neighbours).  Boxes are level-major, Morton order within a level;
  * the result is the global tree restricted to these boxes.  _build returns the sizes,
- * _export fills caller-allocated arrays laid out as in bt_tree_arrays (box_child_ids
- * [2^d][aligned], box_centers [d][aligned]); global_box_ids [nboxes] and
+ * _export fills caller-allocated arrays laid out as in the tree export: box_child_ids
+ * [2^d][aligned], box_centers [d][aligned]; global_box_ids [nboxes] and
  * target_boxes_mask [nboxes] (1: this rank builds the lists of the box) may be NULL.
  * Hand the arrays to bt_traversal_build with target_boxes_mask and active_level_ranges. */
 typedef struct {
