@@ -1215,34 +1215,52 @@ struct SegSortFlags {
 // pipeline beside it.)
 // PACKED: the ids are the low bits of the packed keys (above); every leaf's ids are written
 // to `ids`, ordered or not, and a leaf of one particle is copied.
+// (Two boxes per half-wave, their loads issued together: the kernel holds all the waves a
+// SIMD takes and still spends its time waiting for the chain box record -> ids; with the
+// loads of two boxes in flight per lane a wave covers its latency twice as well.)
+constexpr int SEG_BOXES_PER_HALF_WAVE = 2;
+
 template <bool PACKED>
 __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, const int32_t *box_start,
         const int32_t *box_count, const uint8_t *box_haschild, uint32_t *ids,
         int32_t *large_list, SegSortFlags *flags, const uint64_t *pk, uint64_t id_mask)
 {
-    const int b = (blockIdx.x * 256 + threadIdx.x) >> 5;
+    constexpr int NB = SEG_BOXES_PER_HALF_WAVE;
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 5;
     const int lane = threadIdx.x & 31;
-    if (b >= nboxes) return;
-    const uint8_t has_children = box_haschild[b];
-    const int n = box_count[b];
-    const int s = box_start[b];
-    // a split box's own particles share one key: the stable sort left them in id order
-    // (packed keys: point particles, a split box has none of its own)
-    if (has_children || n <= (PACKED ? 0 : 1)) return;
-    if (n > 64) {
-        if (lane == 0) {
-            if (n <= SEG_BLOCK_MAX) large_list[atomicAdd(&flags->n_large, 1)] = b;
-            else atomicExch(&flags->has_huge, 1);
+    int n[NB], s[NB];
+    bool act[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int b = g * NB + q;
+        const bool in = b < nboxes;
+        const uint8_t has_children = in ? box_haschild[b] : 1;
+        n[q] = in ? box_count[b] : 0;
+        s[q] = in ? box_start[b] : 0;
+        // a split box's own particles share one key: the stable sort left them in id order
+        // (packed keys: point particles, a split box has none of its own)
+        act[q] = in && !has_children && n[q] > (PACKED ? 0 : 1);
+        if (act[q] && n[q] > 64) {
+            if (lane == 0) {
+                if (n[q] <= SEG_BLOCK_MAX) large_list[atomicAdd(&flags->n_large, 1)] = b;
+                else atomicExch(&flags->has_huge, 1);
+            }
+            act[q] = false;
         }
-        return;
     }
-    uint32_t v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
-    if (PACKED) {
-        if (lane < n) v0 = (uint32_t) (pk[s + lane] & id_mask);
-        if (lane + 32 < n) v1 = (uint32_t) (pk[s + lane + 32] & id_mask);
-    } else {
-        if (lane < n) v0 = ids[s + lane];
-        if (lane + 32 < n) v1 = ids[s + lane + 32];
+    uint32_t v0[NB], v1[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        v0[q] = v1[q] = 0xFFFFFFFFu;
+        if (act[q]) {
+            if (PACKED) {
+                if (lane < n[q]) v0[q] = (uint32_t) (pk[s[q] + lane] & id_mask);
+                if (lane + 32 < n[q]) v1[q] = (uint32_t) (pk[s[q] + lane + 32] & id_mask);
+            } else {
+                if (lane < n[q]) v0[q] = ids[s[q] + lane];
+                if (lane + 32 < n[q]) v1[q] = ids[s[q] + lane + 32];
+            }
+        }
     }
     // element index of v0 is `lane`, of v1 `lane + 32`
     auto cmpx = [&](uint32_t v, int idx, int k, int j) {
@@ -1253,27 +1271,33 @@ __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, cons
         return (lower == up) ? mn : mx;
     };
 #pragma unroll
-    for (int k = 2; k <= 32; k <<= 1) {
+    for (int q = 0; q < NB; ++q) {
+        if (!act[q]) continue;                  // (uniform over the half-wave)
+        uint32_t a0 = v0[q], a1 = v1[q];
+        const int nq = n[q];
 #pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            v0 = cmpx(v0, lane, k, j);
-            if (n > 32) v1 = cmpx(v1, lane + 32, k, j);
-        }
-    }
-    if (n > 32) {
-        // k = 64: both halves ascending overall; j = 32 pairs v0 with v1 of the same lane
-        {
-            const uint32_t mn = v0 < v1 ? v0 : v1, mx = v0 < v1 ? v1 : v0;
-            v0 = mn; v1 = mx;
-        }
+        for (int k = 2; k <= 32; k <<= 1) {
 #pragma unroll
-        for (int j = 16; j > 0; j >>= 1) {
-            v0 = cmpx(v0, lane, 64, j);
-            v1 = cmpx(v1, lane + 32, 64, j);
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                a0 = cmpx(a0, lane, k, j);
+                if (nq > 32) a1 = cmpx(a1, lane + 32, k, j);
+            }
         }
+        if (nq > 32) {
+            // k = 64: both halves ascending overall; j = 32 pairs a0 with a1 of the same lane
+            {
+                const uint32_t mn = a0 < a1 ? a0 : a1, mx = a0 < a1 ? a1 : a0;
+                a0 = mn; a1 = mx;
+            }
+#pragma unroll
+            for (int j = 16; j > 0; j >>= 1) {
+                a0 = cmpx(a0, lane, 64, j);
+                a1 = cmpx(a1, lane + 32, 64, j);
+            }
+        }
+        if (lane < nq) ids[s[q] + lane] = a0;
+        if (lane + 32 < nq) ids[s[q] + lane + 32] = a1;
     }
-    if (lane < n) ids[s + lane] = v0;
-    if (lane + 32 < n) ids[s + lane + 32] = v1;
 }
 
 // The number of listed runs is read on the device (flags->n_large): the launch needs no
@@ -2426,7 +2450,7 @@ int fixup_launch(bt_context *ctx, TreeState *st)
         BT_CHECK(st->fix_flags.alloc(ctx->pool, 1));
         BT_HIP_CHECK(hipMemsetAsync(st->fix_flags.get(), 0, sizeof(SegSortFlags), ctx->stream));
     }
-    const unsigned wgrid = (unsigned) div_up(st->nboxes * 32, 256);
+    const unsigned wgrid = (unsigned) div_up(div_up(st->nboxes, SEG_BOXES_PER_HALF_WAVE) * 32, 256);
     if (st->pk && can_be_huge) {
         // runs of any length (particles stuck in a split box): the host may have to take the
         // global route, which works on the id arrays -- unpack them first (12 bytes per

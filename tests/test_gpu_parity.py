@@ -868,14 +868,6 @@ def test_multi_rank_pipeline_in_process(dims, world, dist_kind):
         return [rng.standard_normal(n_per) for _ in range(dims)]
 
     chunks = [chunk(r) for r in range(world)]
-    # separate point targets (native entries only): a third as many, another stream
-    tchunks = None
-    if sep_targets:
-        assert native
-        full_n = n_per
-        n_per = max(n_per // 3, 1)
-        tchunks = [chunk(1000 + r) for r in range(world)]
-        n_per = full_n
     fw = FakeWorld(world)
     results = [None] * world
     errors = []
@@ -914,11 +906,7 @@ def test_multi_rank_pipeline_in_process(dims, world, dist_kind):
     actx = HIPArrayContext(0)
     allpts = [torch.from_numpy(np.concatenate([c[ax] for c in chunks])).cuda()
               for ax in range(dims)]
-    alltgts = None
-    if sep_targets:
-        alltgts = [torch.from_numpy(np.concatenate([c[ax] for c in tchunks])).cuda()
-                   for ax in range(dims)]
-    gt, _ = TreeBuilder(actx)(actx, allpts, targets=alltgts, max_particles_in_box=mpb)
+    gt, _ = TreeBuilder(actx)(actx, allpts, max_particles_in_box=mpb)
     full = actx.to_numpy(FMMTraversalBuilder(actx)(actx, gt)[0])
     g = actx.to_numpy(gt)
     assert sum(r["nlocal"] for r in results) == world * n_per
