@@ -289,3 +289,31 @@ def build_local_essential_tree(actx, comm, tree, numbering, well_sep_is_n_away=1
                 halo_boxes_received=int(sizes.halo_boxes_received),
                 halo_boxes_sent=int(sizes.halo_boxes_sent), nboxes=B)
     return let, info
+
+
+def sharded_tree_and_lists(actx, comm, particles, max_particles_in_box, targets=None,
+                           well_sep_is_n_away=1, tree_builder=None, traversal_builder=None):
+    """Steps 1-6 in one call (collective over *comm*, a :class:`NativeComm`): exchange the
+    particles, build the subtrees this rank owns, number them globally, assemble the local
+    essential tree and build the interaction lists of the rank's own boxes.
+
+    Returns a dict: ``tree`` (the rank's :class:`~boxtree_amd.tree.Tree`, local box
+    numbers), ``numbering`` (:func:`number_sharded_tree`: ``box_ids`` maps them to the
+    global tree's), ``let`` / ``let_info`` (:func:`build_local_essential_tree`:
+    ``let_info["global_box_ids"]`` maps LET boxes to global numbers), ``traversal`` (lists
+    on the LET for the boxes with ``let_info["target_boxes_mask"]``) and ``exchange`` (bytes
+    sent, device time of the all-to-all-v, root box)."""
+    from boxtree_amd import FMMTraversalBuilder, TreeBuilder
+    tb = tree_builder or TreeBuilder(actx)
+    tg = traversal_builder or FMMTraversalBuilder(actx, well_sep_is_n_away=well_sep_is_n_away)
+    if targets is None:
+        p2, kw, xs = exchange_particles(actx, comm, particles, max_particles_in_box)
+        tree, _ = tb(actx, p2, max_particles_in_box=max_particles_in_box, **kw)
+    else:
+        p2, t2, kw, xs = exchange_particles(actx, comm, particles, max_particles_in_box, targets=targets)
+        tree, _ = tb(actx, p2, targets=t2, max_particles_in_box=max_particles_in_box, **kw)
+    num = number_sharded_tree(actx, comm, tree)
+    let, info = build_local_essential_tree(actx, comm, tree, num, well_sep_is_n_away=well_sep_is_n_away)
+    trav, _ = tg(actx, let, _target_boxes_mask=info["target_boxes_mask"],
+                 _active_level_ranges=info["active_level_ranges"])
+    return dict(tree=tree, numbering=num, let=let, let_info=info, traversal=trav, exchange=xs)

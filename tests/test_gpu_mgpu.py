@@ -156,3 +156,43 @@ def test_steps_1_to_6_one_rank_rccl(dims, nway):
         assert_same_traversal(actx.to_numpy(t_let), actx.to_numpy(t_plain))
     finally:
         comm.close()
+
+
+def test_sharded_tree_and_lists_one_call():
+    """boxtree_amd.distributed.native.sharded_tree_and_lists with two thread-ranks: the
+    global box count of both ranks is the single-GPU tree's, every deep box is owned once."""
+    import threading
+
+    import torch
+    from boxtree_amd import HIPArrayContext, TreeBuilder
+    from boxtree_amd.distributed import native as nat
+    world, n, mpb = 2, 50000, 30
+    chunks = [[np.random.default_rng(40 + r).standard_normal(n) for _ in range(3)] for r in range(world)]
+    group = nat.LocalGroup(world)
+    res, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            actx = HIPArrayContext(0)
+            comm = group.comm(rank)
+            out = nat.sharded_tree_and_lists(actx, comm, [torch.from_numpy(a).cuda() for a in chunks[rank]], mpb)
+            res[rank] = (out["numbering"]["nboxes"], int(out["tree"].nsources),
+                         int(out["let_info"]["target_boxes_mask"].sum()),
+                         int(out["traversal"].target_boxes.shape[0]))
+            comm.close()
+        except BaseException as e:      # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    group.close()
+    assert not errors, errors
+    actx = HIPArrayContext(0)
+    pts = [torch.from_numpy(np.concatenate([c[ax] for c in chunks])).cuda() for ax in range(3)]
+    g, _ = TreeBuilder(actx)(actx, pts, max_particles_in_box=mpb)
+    assert res[0][0] == res[1][0] == int(g.nboxes)
+    assert res[0][1] + res[1][1] == world * n
+    assert all(r[3] > 0 and r[2] >= r[3] for r in res)
