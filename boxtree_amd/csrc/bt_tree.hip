@@ -1204,6 +1204,7 @@ constexpr int SEG_BLOCK_MAX = 4096;
 struct SegSortFlags {
     int32_t n_large;      // runs in (64, SEG_BLOCK_MAX]
     int32_t has_huge;     // some run > SEG_BLOCK_MAX
+    int32_t n_copy;       // packed keys with extents: runs > 64 whose ids a second kernel unpacks
 };
 
 // Half a wave per box, up to two ids per lane: the kernel is bound by the latency of
@@ -1297,6 +1298,100 @@ __global__ __launch_bounds__(256) void segment_sort_wave_kernel(int nboxes, cons
         }
         if (lane < nq) ids[s[q] + lane] = a0;
         if (lane + 32 < nq) ids[s[q] + lane + 32] = a1;
+    }
+}
+
+// Packed keys with extents (path | cap | id): runs of any length occur -- the particles stuck
+// in a split box, which keep their order, and leaves --, and the global fix-up route needs
+// every id in the id array.  This kernel unpacks every run of at most 64 ids, ordering the
+// leaves among them; longer runs go on a list for segment_unpack_block_kernel (and, leaves,
+// on the lists of the ordering kernels, which then work on the id array as always).
+__global__ __launch_bounds__(256) void segment_unpack_sort_wave_kernel(int nboxes, const int32_t *box_start,
+        const int32_t *box_count, const int32_t *box_nonchild, const uint8_t *box_haschild, uint32_t *ids,
+        int32_t *large_list, int32_t *copy_list, SegSortFlags *flags, const uint64_t *pk, uint64_t id_mask)
+{
+    constexpr int NB = SEG_BOXES_PER_HALF_WAVE;
+    const int g = (blockIdx.x * 256 + threadIdx.x) >> 5;
+    const int lane = threadIdx.x & 31;
+    int n[NB], s[NB];
+    bool act[NB], leaf[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        const int b = g * NB + q;
+        const bool in = b < nboxes;
+        const uint8_t has_children = in ? box_haschild[b] : 1;
+        leaf[q] = !has_children;
+        n[q] = in ? (has_children ? box_nonchild[b] : box_count[b]) : 0;
+        s[q] = in ? box_start[b] : 0;
+        act[q] = in && n[q] > 0;
+        if (act[q] && n[q] > 64) {
+            if (lane == 0) {
+                copy_list[atomicAdd(&flags->n_copy, 1)] = b;
+                if (leaf[q]) {
+                    if (n[q] <= SEG_BLOCK_MAX) large_list[atomicAdd(&flags->n_large, 1)] = b;
+                    else atomicExch(&flags->has_huge, 1);
+                }
+            }
+            act[q] = false;
+        }
+    }
+    uint32_t v0[NB], v1[NB];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        v0[q] = v1[q] = 0xFFFFFFFFu;
+        if (act[q]) {
+            if (lane < n[q]) v0[q] = (uint32_t) (pk[s[q] + lane] & id_mask);
+            if (lane + 32 < n[q]) v1[q] = (uint32_t) (pk[s[q] + lane + 32] & id_mask);
+        }
+    }
+    auto cmpx = [&](uint32_t v, int idx, int k, int j) {
+        const uint32_t o = __shfl_xor(v, j, 32);
+        const bool up = (idx & k) == 0;
+        const bool lower = (idx & j) == 0;
+        const uint32_t mn = v < o ? v : o, mx = v < o ? o : v;
+        return (lower == up) ? mn : mx;
+    };
+#pragma unroll
+    for (int q = 0; q < NB; ++q) {
+        if (!act[q]) continue;                  // (uniform over the half-wave)
+        uint32_t a0 = v0[q], a1 = v1[q];
+        const int nq = n[q];
+        if (leaf[q] && nq > 1) {
+#pragma unroll
+            for (int k = 2; k <= 32; k <<= 1) {
+#pragma unroll
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    a0 = cmpx(a0, lane, k, j);
+                    if (nq > 32) a1 = cmpx(a1, lane + 32, k, j);
+                }
+            }
+            if (nq > 32) {
+                {
+                    const uint32_t mn = a0 < a1 ? a0 : a1, mx = a0 < a1 ? a1 : a0;
+                    a0 = mn; a1 = mx;
+                }
+#pragma unroll
+                for (int j = 16; j > 0; j >>= 1) {
+                    a0 = cmpx(a0, lane, 64, j);
+                    a1 = cmpx(a1, lane + 32, 64, j);
+                }
+            }
+        }
+        if (lane < nq) ids[s[q] + lane] = a0;
+        if (lane + 32 < nq) ids[s[q] + lane + 32] = a1;
+    }
+}
+
+__global__ __launch_bounds__(256) void segment_unpack_block_kernel(const int32_t *copy_list,
+        const SegSortFlags *flags, const int32_t *box_start, const int32_t *box_count,
+        const int32_t *box_nonchild, const uint8_t *box_haschild, uint32_t *ids, const uint64_t *pk,
+        uint64_t id_mask)
+{
+    const int nc = flags->n_copy;
+    for (int r = blockIdx.x; r < nc; r += gridDim.x) {
+        const int b = copy_list[r];
+        const int s = box_start[b], n = box_haschild[b] ? box_nonchild[b] : box_count[b];
+        for (int i = threadIdx.x; i < n; i += 256) ids[s + i] = (uint32_t) (pk[s + i] & id_mask);
     }
 }
 
@@ -2453,10 +2548,30 @@ int fixup_launch(bt_context *ctx, TreeState *st)
     const unsigned wgrid = (unsigned) div_up(div_up(st->nboxes, SEG_BOXES_PER_HALF_WAVE) * 32, 256);
     if (st->pk && can_be_huge) {
         // runs of any length (particles stuck in a split box): the host may have to take the
-        // global route, which works on the id arrays -- unpack them first (12 bytes per
-        // particle, 0.3 ms at 10^8) and order them in place
-        unpack_ids_kernel<<<(unsigned) div_up(N, 256), 256, 0, ctx->stream>>>(N, st->pk, st->pk_mask, st->ids);
-        st->pk = nullptr;
+        // global route, which works on the id array -- every run is unpacked into it, the
+        // short ones (and the leaves among them ordered) by the wave kernel, the rest by a
+        // kernel over the list it makes
+        if (!st->have_extent) {
+            // (refine weights etc. never come with packed keys; belt and braces)
+            unpack_ids_kernel<<<(unsigned) div_up(N, 256), 256, 0, ctx->stream>>>(N, st->pk, st->pk_mask, st->ids);
+            st->pk = nullptr;
+        } else {
+            Buf<int32_t> copy_list;
+            BT_CHECK(copy_list.alloc(ctx->pool, N / 64 + 1));
+            segment_unpack_sort_wave_kernel<<<wgrid, 256, 0, ctx->stream>>>(
+                (int) st->nboxes, st->box_start.get(), st->box_count.get(), st->box_nonchild.get(),
+                st->box_haschild.get(), st->ids, st->fix_large_list.get(), copy_list.get(),
+                st->fix_flags.get(), st->pk, st->pk_mask);
+            segment_unpack_block_kernel<<<(unsigned) std::min<int64_t>(ctx->num_cus * 4, N / 64 + 1), 256, 0,
+                                          ctx->stream>>>(
+                copy_list.get(), st->fix_flags.get(), st->box_start.get(), st->box_count.get(),
+                st->box_nonchild.get(), st->box_haschild.get(), st->ids, st->pk, st->pk_mask);
+            BT_HIP_CHECK(hipGetLastError());
+            st->pk = nullptr;
+            BT_CHECK(bt::d2h(ctx, &st->h_fix, st->fix_flags.get(), sizeof(SegSortFlags), /*persistent=*/true));
+            st->fixup_pending = true;
+            return BT_OK;
+        }
     }
     if (st->pk) {
         segment_sort_wave_kernel<true><<<wgrid, 256, 0, ctx->stream>>>(
