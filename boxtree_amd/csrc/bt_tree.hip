@@ -1622,14 +1622,52 @@ struct IsSource {
     __device__ int32_t operator()(int64_t i) const { return ids[i] < nsources ? 1 : 0; }
 };
 
+// Sources before a tree-order position, without an N-sized prefix array: one bit per position
+// ("is a source") in 64-bit words and the number of sources before every word.  S(p) is two
+// loads and a population count; a kernel that walks the positions in order gets the word
+// from a ballot of its own flags and loads one count per wave.
+struct SrcPrefix {
+    const uint64_t *bits;       // [ceil(N / 64)]
+    const int32_t *before;      // [ceil(N / 64) + 1] sources before the word
+    __device__ __forceinline__ int32_t operator()(int64_t p) const
+    {
+        const int64_t w = p >> 6;
+        const int r = (int) (p & 63);
+        if (r == 0) return before[w];
+        return before[w] + __popcll(bits[w] & ((1ull << r) - 1ull));
+    }
+};
+
+// one wave per 64 positions: the word of flags and its population count
+__global__ __launch_bounds__(256) void source_bits_kernel(int64_t n, const uint32_t *ids, uint32_t nsources,
+                                                          uint64_t *bits, int32_t *counts)
+{
+    const int64_t p = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const bool src = p < n && ids[p] < nsources;
+    const uint64_t bal = __ballot(src);
+    if ((threadIdx.x & 63) == 0 && (p >> 6) < ((n + 63) >> 6)) {
+        bits[p >> 6] = bal;
+        counts[p >> 6] = __popcll(bal);
+    }
+}
+
+struct ScanCounts {
+    const int32_t *c;
+    __device__ int32_t operator()(int64_t i) const { return c[i]; }
+};
+
 __global__ __launch_bounds__(256) void split_ids_kernel(int64_t n, const uint32_t *ids,
-        const int32_t *src_prefix, uint32_t nsources, int32_t *user_source_ids,
+        const int32_t *words_before, uint32_t nsources, int32_t *user_source_ids,
         int32_t *srcntgt_target_ids, int32_t *sorted_target_ids)
 {
     const int64_t p = (int64_t) blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t id = ids[p];
-    const int32_t source_nr = src_prefix[p];
+    const bool in = p < n;
+    const uint32_t id = in ? ids[p] : 0xffffffffu;
+    // (a wave covers exactly one 64-position word)
+    const uint64_t bal = __ballot(in && id < nsources);
+    if (!in) return;
+    const int lane = threadIdx.x & 63;
+    const int32_t source_nr = words_before[p >> 6] + __popcll(bal & ((1ull << lane) - 1ull));
     if (id < nsources) {
         user_source_ids[source_nr] = (int32_t) id;
     } else {
@@ -1726,7 +1764,7 @@ struct BoxInfoArgs {
     int sat, have_extent;
     const int32_t *box_start, *box_count, *box_parent, *box_nonchild, *box_child;
     const uint8_t *box_level, *box_haschild;
-    const int32_t *src_prefix;     // [N+1] or null when sat
+    SrcPrefix src_prefix;          // (sat: unused)
     int32_t *o_src_starts, *o_src_nonchild, *o_src_cumul;
     int32_t *o_tgt_starts, *o_tgt_nonchild, *o_tgt_cumul;
     int32_t *o_parent, *o_child;
@@ -1787,11 +1825,11 @@ __global__ __launch_bounds__(256) void box_info_kernel(BoxInfoArgs a)
         src_cumul = tgt_cumul = cnt;
         src_nc = tgt_nc = haschild ? n0 : cnt;
     } else {
-        const int32_t S0 = a.src_prefix[s], S1 = a.src_prefix[s + cnt];
+        const int32_t S0 = a.src_prefix(s), S1 = a.src_prefix((int64_t) s + cnt);
         src_start = S0; tgt_start = s - S0;
         src_cumul = S1 - S0; tgt_cumul = cnt - src_cumul;
         if (haschild) {
-            const int32_t Sn = a.src_prefix[s + n0];
+            const int32_t Sn = a.src_prefix((int64_t) s + n0);
             src_nc = Sn - S0; tgt_nc = n0 - src_nc;
         } else {
             src_nc = src_cumul; tgt_nc = tgt_cumul;
@@ -1956,7 +1994,8 @@ struct TreeState {
     Buf<SegSortFlags> fix_flags;
     SegSortFlags h_fix{};
     Buf<int64_t> wprefix;
-    Buf<int32_t> src_prefix;           // [N+1] (separate targets only)
+    Buf<uint64_t> src_bits;            // separate targets only: "is a source" per tree-order
+    Buf<int32_t> src_before;           // position, and the sources before every 64-bit word
     Buf<int32_t> srcntgt_target_ids;   // [ntargets]
 
     Buf<int32_t> box_start, box_count, box_parent, box_nonchild, box_child;
@@ -3297,11 +3336,19 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
     BT_CHECK(mark(ctx, st, "(host gap)"));
     BT_CHECK(fixup_finish(ctx, st));
     // ---- source prefix (separate targets), over the ids in their final order -------------
-    if (!st->sat && !st->src_prefix.get()) {
-        BT_CHECK(st->src_prefix.alloc(ctx->pool, N + 1));
-        IsSource is{st->ids, (uint32_t) st->nsources};
-        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, is, N, st->src_prefix.get(),
-                                                          (int32_t *) nullptr, true)));
+    if (!st->sat && !st->src_before.get()) {
+        const int64_t nw = div_up(N, 64);
+        Buf<int32_t> counts;
+        BT_CHECK(st->src_bits.alloc(ctx->pool, nw + 1));
+        BT_CHECK(st->src_before.alloc(ctx->pool, nw + 2));
+        BT_CHECK(counts.alloc(ctx->pool, nw + 1));
+        // (one more word than positions need: S(N) looks at word N / 64 when N is a multiple of 64)
+        BT_HIP_CHECK(hipMemsetAsync(st->src_bits.get() + nw, 0, 8, ctx->stream));
+        BT_HIP_CHECK(hipMemsetAsync(counts.get() + nw, 0, 4, ctx->stream));
+        source_bits_kernel<<<blocks(nw * 64), 256, 0, ctx->stream>>>(N, st->ids, (uint32_t) st->nsources,
+                                                                   st->src_bits.get(), counts.get());
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, ScanCounts{counts.get()}, nw + 1,
+                                                          st->src_before.get(), (int32_t *) nullptr, true)));
     }
     BT_CHECK(mark(ctx, st, "srcscan"));
     // ---- leaves in one pass (sources == targets, no extents): ids in their final order,
@@ -3379,7 +3426,7 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
         } else {
             BT_CHECK(st->srcntgt_target_ids.alloc(ctx->pool, st->ntargets));
             split_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(
-                N, st->ids, st->src_prefix.get(), (uint32_t) st->nsources, o->user_source_ids,
+                N, st->ids, st->src_before.get(), (uint32_t) st->nsources, o->user_source_ids,
                 st->srcntgt_target_ids.get(), o->sorted_target_ids);
         }
     }
@@ -3418,7 +3465,7 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
         a.box_parent = st->box_parent.get(); a.box_nonchild = st->box_nonchild.get();
         a.box_child = st->box_child.get(); a.box_level = st->box_level.get();
         a.box_haschild = st->box_haschild.get();
-        a.src_prefix = st->src_prefix.get();
+        a.src_prefix = SrcPrefix{st->src_bits.get(), st->src_before.get()};
         a.o_src_starts = o->box_source_starts; a.o_src_nonchild = o->box_source_counts_nonchild;
         a.o_src_cumul = o->box_source_counts_cumul;
         a.o_tgt_starts = o->box_target_starts; a.o_tgt_nonchild = o->box_target_counts_nonchild;
