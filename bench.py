@@ -613,6 +613,19 @@ def main():
                 "n_colleagues", "n_list1", "n_list2", "n_list3", "n_list4", "n_close")),
                 *trav_stages),
         }
+        # kernel launches and idle GPU time of a step: counted by rocprofv3 (tools/timeline_gaps.py
+        # over the kernel trace of this command), not in this process -- the committed
+        # timeline of the same workload, named
+        try:
+            tls = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
+                         if f.endswith(f"_{args.workload}_timeline.txt"))
+            first = open(os.path.join(ROOT, "profiles", tls[-1])).readline().split()
+            # "launches 104  span 17.530 ms  busy 17.131 ms  idle 0.399 ms"
+            out["launches_per_step"] = {"value": int(first[1]), "gpu_idle_ms": float(first[9]),
+                                        "source": f"profiles/{tls[-1]} (rocprofv3 --kernel-trace of "
+                                                  "bench.py on this workload; not measured in this run)"}
+        except (OSError, IndexError, ValueError):
+            out["launches_per_step"] = None
         # the CPU baseline is a one-GPU figure (rank 0 at N = 1): beside N ranks it would
         # only lengthen the run
         if args.cpu_sample > 0 and world == 1:
