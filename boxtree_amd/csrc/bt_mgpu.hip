@@ -92,6 +92,14 @@ Nccl &nccl()
         }                                                                         \
     } while (0)
 
+#define BT_PEER_BARRIER(g)                                                        \
+    do {                                                                          \
+        if (!(g)->barrier()) {                                                    \
+            ::bt::set_error("a peer rank of the local group failed");              \
+            return BT_ERR_INTERNAL;                                               \
+        }                                                                         \
+    } while (0)
+
 constexpr int64_t MESSAGE_LIMIT_BYTES = (int64_t) 512 << 20;   // see DESIGN.md (RCCL, > 1 GB)
 
 // ranks as threads of one process: a table of pointers and a generation barrier
@@ -103,12 +111,23 @@ struct LocalGroup {
     uint64_t gen = 0;
     std::vector<const void *> ptr;
     std::vector<const int64_t *> off, cnt;
-    void barrier()
+    bool failed = false;          // a rank left a collective entry with an error: the others
+                                  // must not wait for it
+    // false: a peer has failed (the caller returns an error too)
+    bool barrier()
     {
         std::unique_lock<std::mutex> lk(m);
+        if (failed) return false;
         const uint64_t g = gen;
         if (++arrived == n) { arrived = 0; ++gen; cv.notify_all(); }
-        else cv.wait(lk, [&] { return gen != g; });
+        else cv.wait(lk, [&] { return gen != g || failed; });
+        return !failed;
+    }
+    void fail()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        failed = true;
+        cv.notify_all();
     }
 };
 
@@ -139,7 +158,7 @@ int comm_all_reduce(bt_mgpu_comm *c, hipStream_t stream, void *dev, size_t count
     BT_HIP_CHECK(hipMemcpyAsync(mine.data(), dev, count * 8, hipMemcpyDeviceToHost, stream));
     BT_HIP_CHECK(hipStreamSynchronize(stream));
     g->ptr[c->rank] = mine.data();
-    g->barrier();
+    BT_PEER_BARRIER(g);
     for (size_t i = 0; i < count; ++i) {
         if (what == RED_SUM_I64) {
             int64_t s = 0;
@@ -151,7 +170,7 @@ int comm_all_reduce(bt_mgpu_comm *c, hipStream_t stream, void *dev, size_t count
             memcpy(&res[i], &s, 8);
         }
     }
-    g->barrier();                 // every rank has read every vector
+    BT_PEER_BARRIER(g);           // every rank has read every vector
     BT_HIP_CHECK(hipMemcpyAsync(dev, res.data(), count * 8, hipMemcpyHostToDevice, stream));
     BT_HIP_CHECK(hipStreamSynchronize(stream));
     return BT_OK;
@@ -167,12 +186,12 @@ int comm_all_gather(bt_mgpu_comm *c, hipStream_t stream, const void *send, void 
     LocalGroup *g = c->group;
     BT_HIP_CHECK(hipStreamSynchronize(stream));
     g->ptr[c->rank] = send;
-    g->barrier();
+    BT_PEER_BARRIER(g);
     for (int q = 0; q < c->nranks; ++q)
         BT_HIP_CHECK(hipMemcpyAsync((char *) recv + (size_t) q * bytes, g->ptr[q], bytes,
                                     hipMemcpyDeviceToDevice, stream));
     BT_HIP_CHECK(hipStreamSynchronize(stream));
-    g->barrier();
+    BT_PEER_BARRIER(g);
     return BT_OK;
 }
 
@@ -192,14 +211,14 @@ int comm_all_to_all_v(bt_mgpu_comm *c, hipStream_t stream, const char *send, con
         LocalGroup *g = c->group;
         BT_HIP_CHECK(hipStreamSynchronize(stream));
         g->ptr[me] = send; g->off[me] = s_off; g->cnt[me] = s_cnt;
-        g->barrier();
+        BT_PEER_BARRIER(g);
         for (int q = 0; q < n; ++q) {
             if (q == me) continue;
             const int64_t nb = g->cnt[q][me];
             if (nb != r_cnt[q]) {
                 set_error("all-to-all-v: rank %d sends %lld bytes to rank %d, which expects %lld",
                           q, (long long) nb, me, (long long) r_cnt[q]);
-                g->barrier();
+                g->fail();
                 return BT_ERR_INTERNAL;
             }
             if (nb > 0)
@@ -207,7 +226,7 @@ int comm_all_to_all_v(bt_mgpu_comm *c, hipStream_t stream, const char *send, con
                                             (size_t) nb, hipMemcpyDeviceToDevice, stream));
         }
         BT_HIP_CHECK(hipStreamSynchronize(stream));
-        g->barrier();
+        BT_PEER_BARRIER(g);
         return BT_OK;
     }
     if (biggest <= 0) return BT_OK;
@@ -613,7 +632,7 @@ int bt_mgpu_plan(int dims, int top_level, int64_t max_particles_in_box, int nran
     return BT_OK;
 }
 
-int bt_mgpu_exchange(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *p, bt_mgpu_shard *out)
+static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *p, bt_mgpu_shard *out)
 {
     bt::CallScope bt_call_scope_(ctx);
     if (!ctx || !comm || !p || !out) {
@@ -799,7 +818,7 @@ int bt_mgpu_exchange(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *
 
 // ---- step 5: global numbering ------------------------------------------------------------------
 
-int bt_mgpu_number(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
+static int bt_mgpu_number_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
                    int32_t *box_ids, bt_mgpu_numbering *out)
 {
     bt::CallScope bt_call_scope_(ctx);
@@ -898,7 +917,7 @@ int bt_mgpu_number(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree
 
 // ---- step 6: local essential tree ----------------------------------------------------------------
 
-int bt_mgpu_let_build(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
+static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
                       const int32_t *box_ids, const bt_mgpu_numbering *num, int well_sep_is_n_away,
                       bt_mgpu_let_sizes *out)
 {
@@ -1121,6 +1140,32 @@ int bt_mgpu_let_build(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_t
     out->halo_boxes_sent = nsend;
     out->halo_boxes_received = nrecv;
     return BT_OK;
+}
+
+// A rank that leaves a collective entry with an error tells the local group, so that its peers
+// (threads waiting at a barrier of the same collective) return an error instead of waiting.
+static int peer_result(bt_mgpu_comm *comm, int status)
+{
+    if (status != BT_OK && comm && comm->kind == 1 && comm->group) comm->group->fail();
+    return status;
+}
+
+int bt_mgpu_exchange(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *p, bt_mgpu_shard *out)
+{
+    return peer_result(comm, bt_mgpu_exchange_body(ctx, comm, p, out));
+}
+
+int bt_mgpu_number(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
+                   int32_t *box_ids, bt_mgpu_numbering *out)
+{
+    return peer_result(comm, bt_mgpu_number_body(ctx, comm, tree, box_ids, out));
+}
+
+int bt_mgpu_let_build(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
+                      const int32_t *box_ids, const bt_mgpu_numbering *num, int well_sep_is_n_away,
+                      bt_mgpu_let_sizes *out)
+{
+    return peer_result(comm, bt_mgpu_let_build_body(ctx, comm, tree, box_ids, num, well_sep_is_n_away, out));
 }
 
 int bt_mgpu_let_export(bt_context *ctx, const bt_mgpu_let_arrays *o)

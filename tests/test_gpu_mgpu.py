@@ -196,3 +196,43 @@ def test_sharded_tree_and_lists_one_call():
     assert res[0][0] == res[1][0] == int(g.nboxes)
     assert res[0][1] + res[1][1] == world * n
     assert all(r[3] > 0 and r[2] >= r[3] for r in res)
+
+
+def test_failing_rank_does_not_hang_its_peers():
+    """A rank that leaves a collective entry with an error (here: no plan on its context for
+    bt_mgpu_number) tells the local group; the peer, waiting in the same collective, returns an
+    error too instead of waiting forever."""
+    import threading
+
+    import torch
+    from boxtree_amd import HIPArrayContext, TreeBuilder, _lib
+    from boxtree_amd.distributed import native as nat
+    group = nat.LocalGroup(2)
+    outcome = [None, None]
+
+    def run(rank):
+        actx = HIPArrayContext(0)
+        comm = group.comm(rank)
+        pts = [torch.from_numpy(np.random.default_rng(rank).random(20000)).cuda() for _ in range(3)]
+        try:
+            if rank == 0:
+                # skips the exchange: its context has no plan, bt_mgpu_number refuses
+                tree, _ = TreeBuilder(actx)(actx, pts, max_particles_in_box=30)
+                nat.number_sharded_tree(actx, comm, tree)
+            else:
+                nat.exchange_particles(actx, comm, pts, 30)
+            outcome[rank] = "ok"
+        except _lib.BoxtreeHipError as e:
+            outcome[rank] = e.msg
+        finally:
+            comm.close()
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=60)
+    assert all(not t.is_alive() for t in threads), "a rank hangs"
+    group.close()
+    assert "no top-tree plan" in outcome[0]
+    assert "peer rank" in outcome[1]
