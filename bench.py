@@ -557,6 +557,10 @@ def main():
                 "nboxes": info.get("nboxes"), "nlevels": info.get("nlevels"),
                 "list1_entries": info.get("n_list1"), "list2_entries": info.get("n_list2"),
                 "parallelism": f"{world} rank(s), one per GPU, shard by top-level Morton cell",
+                **({"scaling_note": "weak scaling of BASELINE configs[4] (1.25e8 uniform points per rank): "
+                                    "the matching one-GPU figure is `bench.py --gpus 1 --workload c5`; the "
+                                    "default N = 1 line measures configs[2] (10^8 sphere-surface points)"}
+                   if world > 1 and args.workload == "c5" else {}),
                 **xinfo,
             },
             "roofline": {
