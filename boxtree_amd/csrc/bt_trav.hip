@@ -1552,8 +1552,12 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     static const int k3_env = [] { const char *e = getenv("BT_V2_K3"); return e ? atoi(e) : 0; }();
     const int K1 = k1_env > 0 ? k1_env : (D == 3 ? 64 : D == 2 ? 24 : 8);
     // (with extents the lists 3 of the per-colleague items are long: at 10^8 + 10^7
-    // particles 8 % of the items overflow 32 entries, 1 % overflow 64)
-    const int K3 = k3_env > 0 ? k3_env : (D == 3 ? (st->with_extent ? 64 : 32) : D == 2 ? 16 : 8);
+    // particles 8 % of the items overflow 32 entries, 1 % overflow 64.  Without extents a
+    // volume-filling cloud is what fills them: a leaf beside refined neighbours takes the
+    // non-adjacent children of up to 26 of them -- at 1.25*10^8 uniform points 17.5 % of the
+    // items overflow 32 entries and their second walk costs 1.7 ms; with 64 it is < 0.1 ms,
+    // the first walk 0.3 ms longer, 96 and 128 change nothing more)
+    const int K3 = k3_env > 0 ? k3_env : (D == 3 ? 64 : D == 2 ? 24 : 8);
     const int Kc = st->with_extent ? K3 : 0;
     Buf<int32_t> row1, row3, rowc, l1_item, l3_item, close_item, ovf_list;
     Buf<uint8_t> row3lev, overflow;

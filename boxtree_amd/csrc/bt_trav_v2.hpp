@@ -156,6 +156,9 @@ struct V2Rows {
 // both forms are bound by vector-ALU issue (SQ_INSTS_VALU x 4 cycles per wave64
 // instruction / 1024 SIMDs accounts for the whole duration), not by memory: see DESIGN.md
 // section 4.
+// four list entries stored at once at any 4-byte boundary (global_store_dwordx4)
+struct __attribute__((packed, aligned(4))) PackedI4 { int32_t x, y, z, w; };
+
 template <int D> struct V3Lanes { static constexpr int N = D == 3 ? 32 : D == 2 ? 16 : 4; };
 
 // inclusive prefix sum over aligned groups of LANES (4, 16 or 32) lanes with DPP moves
@@ -318,9 +321,9 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
         off += (uint32_t) (2 * d + 1) << (2 * ax);
     }
     off <<= V2_CODE_SHIFT;
-    uint32_t chid[C];
+    uint32_t chid[C], plain[C];
 #pragma unroll
-    for (int m = 0; m < C; ++m) chid[m] = (ch[m] & CH_ID_MASK) + off;
+    for (int m = 0; m < C; ++m) { plain[m] = ch[m] & CH_ID_MASK; chid[m] = plain[m] + off; }
 
 #pragma unroll
     for (int sb = 0; sb < C; ++sb) {
@@ -368,9 +371,19 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
             }
         } else {
             int32_t pl = lbase + (int32_t) excl;
+            // A candidate that touches the box nowhere gives all its children (19 of the 27
+            // candidates of a box in a uniform octree, 152 of its 189 entries): two 16-byte
+            // stores instead of eight predicated 4-byte ones.
+            if (C == 8 && lm == FULL) {
+                PackedI4 *dst = reinterpret_cast<PackedI4 *>(t.l2_lists + pl);
+                dst[0] = PackedI4{(int32_t) plain[0], (int32_t) plain[1], (int32_t) plain[2], (int32_t) plain[3]};
+                dst[1] = PackedI4{(int32_t) plain[C > 4 ? 4 : 0], (int32_t) plain[C > 5 ? 5 : 0],
+                                  (int32_t) plain[C > 6 ? 6 : 0], (int32_t) plain[C > 7 ? 7 : 0]};
+            } else {
 #pragma unroll
-            for (int m = 0; m < C; ++m)
-                if ((lm >> m) & 1u) t.l2_lists[pl++] = (int32_t) (ch[m] & CH_ID_MASK);
+                for (int m = 0; m < C; ++m)
+                    if ((lm >> m) & 1u) t.l2_lists[pl++] = (int32_t) plain[m];
+            }
         }
     }
 }
@@ -412,6 +425,7 @@ __global__ __launch_bounds__(256) void list4_lattice_kernel(int32_t n, const int
     const int tl = (int) (tc.lf & 0xffu);
     int32_t cnt = 0;
     int32_t *out = FILL ? lists + counts_or_starts[i] : nullptr;
+    PackedI4 buf{0, 0, 0, 0};
     int32_t cur = tgt;
     for (int k = 1; k < tl; ++k) {                      // ancestors on levels tl-1 .. 1
         cur = parent[cur];
@@ -435,10 +449,23 @@ __global__ __launch_bounds__(256) void list4_lattice_kernel(int32_t n, const int
                 adj_parent = adj_parent && rp >= -1 && rp <= ((int64_t) 1 << (k - 1));
             }
             if (!adj_box && adj_parent) {
-                if (FILL) out[cnt] = (int32_t) (e & V2_ID_MASK);
+                if (FILL) {
+                    // entries leave four at a time (one 16-byte store per lane instead of four
+                    // lane-strided 4-byte ones)
+                    const int32_t id = (int32_t) (e & V2_ID_MASK);
+                    const int q = cnt & 3;
+                    if (q == 0) buf.x = id; else if (q == 1) buf.y = id; else if (q == 2) buf.z = id;
+                    else { buf.w = id; *reinterpret_cast<PackedI4 *>(out + cnt - 3) = buf; }
+                }
                 ++cnt;
             }
         }
+    }
+    if (FILL) {
+        const int q = cnt & 3, c0 = cnt - q;
+        if (q >= 1) out[c0] = buf.x;
+        if (q >= 2) out[c0 + 1] = buf.y;
+        if (q >= 3) out[c0 + 2] = buf.z;
     }
     if (!FILL) counts_or_starts[i] = cnt;
 }
@@ -875,9 +902,20 @@ __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_ni
             for (int u = 0; u < UNR; ++u)
                 v[u] = (j0 + u < n && (uint32_t) v[u] < (uint32_t) ntranslate) ? translate[v[u]] : 0;
         }
+        // a lane's entries are contiguous in ITS segment: full groups of four leave as one
+        // 16-byte store (4-byte aligned -- the hardware takes that), a quarter of the write
+        // requests of the lane-strided single stores this kernel is bound by
+        int32_t *dst = lists + (int64_t) s + j0;
 #pragma unroll
-        for (int u = 0; u < UNR; ++u)
-            if (j0 + u < n) lists[(int64_t) s + j0 + u] = v[u];
+        for (int u = 0; u < UNR; u += 4) {
+            if (j0 + u + 4 <= n) {
+                *reinterpret_cast<PackedI4 *>(dst + u) = PackedI4{v[u], v[u + 1], v[u + 2], v[u + 3]};
+            } else {
+#pragma unroll
+                for (int q = u; q < u + 4; ++q)
+                    if (j0 + q < n) dst[q] = v[q];
+            }
+        }
     }
 }
 
