@@ -379,6 +379,9 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
                 dst[0] = PackedI4{(int32_t) plain[0], (int32_t) plain[1], (int32_t) plain[2], (int32_t) plain[3]};
                 dst[1] = PackedI4{(int32_t) plain[C > 4 ? 4 : 0], (int32_t) plain[C > 5 ? 5 : 0],
                                   (int32_t) plain[C > 6 ? 6 : 0], (int32_t) plain[C > 7 ? 7 : 0]};
+                // (the same for half a candidate -- the four children beyond a face across the
+                // first axis -- was measured: -0.04 ms at 1.25*10^8 uniform points, +0.05 ms at
+                // 10^8 sphere-surface points, where few halves are full; not kept)
             } else {
 #pragma unroll
                 for (int m = 0; m < C; ++m)
@@ -948,9 +951,21 @@ __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nit
             v[u] = in ? row[(int64_t) (j0 + u) * 64] : 0;
             lev[u] = in ? (int) rl[(int64_t) (j0 + u) * 64] : 0;
         }
+        // the walk emits the children of a box one after the other: four entries of one level
+        // leave as one 16-byte store
 #pragma unroll
-        for (int u = 0; u < UNR; ++u)
-            if (j0 + u < n) l3_lists[cur[lev[u] * WALK_THREADS]++] = v[u];
+        for (int u = 0; u < UNR; u += 4) {
+            if (j0 + u + 4 <= n && lev[u] == lev[u + 1] && lev[u] == lev[u + 2] && lev[u] == lev[u + 3]) {
+                int32_t *cp = cur + lev[u] * WALK_THREADS;
+                const int32_t c = *cp;
+                *reinterpret_cast<PackedI4 *>(l3_lists + c) = PackedI4{v[u], v[u + 1], v[u + 2], v[u + 3]};
+                *cp = c + 4;
+            } else {
+#pragma unroll
+                for (int q = u; q < u + 4; ++q)
+                    if (j0 + q < n) l3_lists[cur[lev[q] * WALK_THREADS]++] = v[q];
+            }
+        }
     }
 }
 

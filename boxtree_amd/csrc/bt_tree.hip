@@ -1715,8 +1715,12 @@ __global__ __launch_bounds__(256) void scatter_inverse_kernel(int64_t n, const u
     const int64_t logical = (int64_t) (blockIdx.x % 8) * per_xcd + blockIdx.x / 8;
     const int64_t j = logical * 256 + threadIdx.x;
     if (j >= n) return;
-    const uint32_t id = ids[j];
-    if ((int64_t) id < n) sorted_target_ids[id] = (int32_t) positions[j];
+    // (the pairs stream through once: read past the L2's replacement order so that they do
+    // not push out the window the writes are being merged in)
+    constexpr bool nt = true;
+    const uint32_t id = nt ? __builtin_nontemporal_load(ids + j) : ids[j];
+    const uint32_t pos = nt ? __builtin_nontemporal_load(positions + j) : positions[j];
+    if ((int64_t) id < n) sorted_target_ids[id] = (int32_t) pos;
 }
 
 __global__ __launch_bounds__(256) void copy_ids_kernel(int64_t n, const uint32_t *ids,
@@ -1908,8 +1912,43 @@ __global__ __launch_bounds__(256) void box_extent_kernel(ExtentArgs<T, D> a)
 #pragma unroll
     for (int ax = 0; ax < D; ++ax) mn[ax] = mx[ax] = a.centers[(int64_t) ax * a.aligned + b];
     if (active) {
+        // Two chains of dependent loads per box -- range -> coordinates, child -> its extents --
+        // and a box is a few dozen particles: what bounds this kernel is how many loads a lane
+        // has in flight, so both chains start together and the first 64 own particles (every
+        // particle of an ordinary leaf) are fetched in one go before anything is reduced.
         const int s = a.starts[b], e = s + a.counts_nonchild[b];
-        for (int p = s + l16; p < e; p += 16) {
+        const int32_t ch = l16 < C ? a.child[(int64_t) l16 * a.aligned + b] : 0;
+        constexpr int UNR = 4;
+        T pc[UNR][D], pr[UNR];
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+            const int p = s + l16 + 16 * k;
+            const bool in = p < e;
+            pr[k] = (in && a.radii) ? a.radii[p] : (T) 0;
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) pc[k][ax] = in ? a.part[ax][p] : mn[ax];
+        }
+        T cmn[D], cmx[D];
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) { cmn[ax] = mn[ax]; cmx[ax] = mx[ax]; }
+        if (ch != 0) {
+            if (a.sizes) below = a.sizes[ch];
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) {
+                cmn[ax] = a.bmin[(int64_t) ax * a.aligned + ch];
+                cmx[ax] = a.bmax[(int64_t) ax * a.aligned + ch];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < UNR; ++k) {
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) {
+                const T lo = pc[k][ax] - pr[k], hi = pc[k][ax] + pr[k];
+                mn[ax] = (lo < mn[ax]) ? lo : mn[ax];
+                mx[ax] = (hi > mx[ax]) ? hi : mx[ax];
+            }
+        }
+        for (int p = s + l16 + 16 * UNR; p < e; p += 16) {
             const T r = a.radii ? a.radii[p] : (T) 0;
 #pragma unroll
             for (int ax = 0; ax < D; ++ax) {
@@ -1919,18 +1958,10 @@ __global__ __launch_bounds__(256) void box_extent_kernel(ExtentArgs<T, D> a)
                 mx[ax] = (hi > mx[ax]) ? hi : mx[ax];
             }
         }
-        if (l16 < C) {
-            const int32_t ch = a.child[(int64_t) l16 * a.aligned + b];
-            if (ch != 0) {
-                if (a.sizes) below = a.sizes[ch];
 #pragma unroll
-                for (int ax = 0; ax < D; ++ax) {
-                    const T lo = a.bmin[(int64_t) ax * a.aligned + ch];
-                    const T hi = a.bmax[(int64_t) ax * a.aligned + ch];
-                    mn[ax] = (lo < mn[ax]) ? lo : mn[ax];
-                    mx[ax] = (hi > mx[ax]) ? hi : mx[ax];
-                }
-            }
+        for (int ax = 0; ax < D; ++ax) {
+            mn[ax] = (cmn[ax] < mn[ax]) ? cmn[ax] : mn[ax];
+            mx[ax] = (cmx[ax] > mx[ax]) ? cmx[ax] : mx[ax];
         }
     }
     // reduction over the group's 16 lanes (one DPP row) into lane 0: row_shl:8/4/2/1 moves
