@@ -725,6 +725,42 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         // a 4-byte load per step made every step wait for a load of its own.
         uint32_t cw[C];
         v2_load_children<C>(w.child_t, parent, cw);
+        if (!TEXT && !a.close_lists_exist) {
+            // The bottom of the tree, where most of the walk happens: a colleague whose
+            // children are all leaves.  Nothing is descended into, so its children are
+            // handled in straight-line code -- the child words and the Morton bits are
+            // compile-time selections, no stack, one update of the level counter -- instead
+            // of one trip of the general loop each (a volume-filling cloud at 1.25*10^8
+            // points: walk 3.0 -> see DESIGN.md).
+            uint32_t any = 0;
+#pragma unroll
+            for (int m = 0; m < C; ++m) any |= cw[m];
+            if (!(any & CH_HSC)) {
+                int n3_here = 0;
+#pragma unroll
+                for (int m = 0; m < C; ++m) {
+                    const uint32_t raw = cw[m];
+                    const int32_t wb = (int32_t) (raw & CH_ID_MASK);
+                    if (!wb || !(raw & CH_SRC)) continue;
+                    bool in_list_1 = true;
+#pragma unroll
+                    for (int ax = 0; ax < D; ++ax) {
+                        const int r = 2 * prel[ax] + v2_mbit<D>(m, ax);
+                        in_list_1 = in_list_1 && r >= -1 && r <= 2;
+                    }
+                    if (in_list_1) {
+                        emit1(wb);
+                    } else if (ROWS) {
+                        if (n3 < w.K3) { row3[(int64_t) n3 * 64] = wb; row3lev[(int64_t) n3 * 64] = (uint8_t) (tl + 1); }
+                        ++n3; ++n3_here;
+                    } else {
+                        emit3(tl + 1, wb);
+                    }
+                }
+                if (ROWS) lvl[(tl + 1) * WALK_THREADS] += n3_here;
+                continue;
+            }
+        }
         // With target extents the separation criteria need the centre of every candidate.
         // On this path the tree is a lattice, i.e. every stored centre IS "parent centre
         // +/- level_to_rad(child level)" bit for bit (check_pack_kernel), so a child's
