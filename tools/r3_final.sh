@@ -14,7 +14,7 @@ if [ "$MODE" = full ]; then
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 fi
 timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; echo "default bench rc=$?"
-for WL in c3 c2 c4 c3c c1; do
+for WL in c3 c2 c4 c3c c1 c5; do
   timeout 600 python bench.py --workload $WL --steps 10 --warmup 3 --cpu-sample 0 > $OUT/bench_$WL.json 2> $OUT/bench_$WL.err
   python - <<PY
 import json
