@@ -1548,8 +1548,9 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     const int32_t *d_nitems = (const int32_t *) (totals.get() + T_NITEMS);
 
     // ---- the walk: lists 1 and 3 (+ close) into rows ------------------------------------------
-    static const int k1_env = [] { const char *e = getenv("BT_V2_K1"); return e ? atoi(e) : 0; }();
-    static const int k3_env = [] { const char *e = getenv("BT_V2_K3"); return e ? atoi(e) : 0; }();
+    // (read per call: tests shrink the rows to send every item through the second walk)
+    const int k1_env = [] { const char *e = getenv("BT_V2_K1"); return e ? atoi(e) : 0; }();
+    const int k3_env = [] { const char *e = getenv("BT_V2_K3"); return e ? atoi(e) : 0; }();
     const int K1 = k1_env > 0 ? k1_env : (D == 3 ? 64 : D == 2 ? 24 : 8);
     // (with extents the lists 3 of the per-colleague items are long: at 10^8 + 10^7
     // particles 8 % of the items overflow 32 entries, 1 % overflow 64.  Without extents a
