@@ -1572,6 +1572,20 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     (void) sizeof(nflat);
     BT_CHECK(overflow.alloc(ctx->pool, items_cap));
     BT_CHECK(ovf_list.alloc(ctx->pool, items_cap));
+    // spill chunks for the items whose list 3 outgrows its row (see V2Walk): one chunk per 64
+    // items at most -- beyond that the rows are simply too short for the tree
+    const bool spill_env = [] { const char *e = getenv("BT_V2_SPILL"); return !e || atoi(e); }();
+    Buf<int32_t> spill3, spill_count, spill_idx;
+    Buf<uint8_t> spill3lev;
+    const int32_t spill_per_shard = (int32_t) std::max<int64_t>(16, items_cap / 64 / SPILL_SHARDS);
+    if (spill_env) {
+        const int64_t nch = (int64_t) spill_per_shard * SPILL_SHARDS;
+        BT_CHECK(spill3.alloc(ctx->pool, nch * SPILL_CHUNK));
+        BT_CHECK(spill3lev.alloc(ctx->pool, nch * SPILL_CHUNK));
+        BT_CHECK(spill_idx.alloc(ctx->pool, items_cap));
+        BT_CHECK(spill_count.alloc(ctx->pool, SPILL_SHARDS * 16));
+        BT_HIP_CHECK(hipMemsetAsync(spill_count.get(), 0, SPILL_SHARDS * 16 * 4, ctx->stream));
+    }
     Buf<int32_t> l1_cnt, l3_cnt, close_cnt;
     BT_CHECK(l1_cnt.alloc(ctx->pool, items_cap));
     BT_CHECK(l3_cnt.alloc(ctx->pool, nflat));
@@ -1595,6 +1609,8 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     w.l1_cs = l1_cnt.get(); w.l3_cs = l3_cnt.get();
     w.close_cs = st->with_extent ? close_cnt.get() : nullptr;
     w.overflow = overflow.get();
+    w.spill3 = spill3.get(); w.spill3lev = spill3lev.get(); w.spill_count = spill_count.get();
+    w.spill_idx = spill_idx.get(); w.spill_per_shard = spill_per_shard;
     w.ovf_count = (int32_t *) (totals.get() + T_OVF);
     w.ovf_list = ovf_list.get();
     static const bool trav_stats = [] { const char *e = getenv("BT_TRAV_STATS"); return e && atoi(e); }();
@@ -1763,7 +1779,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     if (total3 > 0)
         l3_scatter_v2_kernel<<<nblk(items_cap), 256, lvl_lds, ctx->stream>>>(
             d_nitems, lay, nlevels, overflow.get(), row3.get(), row3lev.get(), K3,
-            l3_item.get(), st->l3_lists.get());
+            l3_item.get(), st->l3_lists.get(), spill_idx.get(), spill3.get(), spill3lev.get());
     if (st->with_extent) {
         BT_CHECK(place_list(ctx, st, cs.lists, cs.total, pk ? &pk->from_sep_close_smaller_lists : nullptr));
         if (cs.total > 0)

@@ -549,10 +549,21 @@ struct V2Walk {
     int32_t *l1_cs, *l3_cs, *close_cs; // counts (ROWS) / starts (!ROWS)
     uint8_t *overflow;                 // [items_cap]
     int32_t *ovf_count, *ovf_list;
+    // list-3 entries beyond an item's row: one chunk of SPILL_CHUNK entries per such item,
+    // handed out by SPILL_SHARDS counters (one word for all would serialise); an item whose
+    // chunk cannot be had, or does not suffice, is walked again (overflow list)
+    int32_t *spill3;                   // [SPILL_SHARDS * spill_per_shard][SPILL_CHUNK], or null
+    uint8_t *spill3lev;
+    int32_t *spill_count;              // [SPILL_SHARDS * 16] (a cache line apart), zeroed
+    int32_t *spill_idx;                // [items_cap] chunk of the item, or -1
+    int32_t spill_per_shard;
     int32_t *dbg_counts;               // optional [4]
     // final places (!ROWS)
     int32_t *l1_lists, *l3_lists, *close_lists;
 };
+
+constexpr int SPILL_CHUNK = 1024;
+constexpr int SPILL_SHARDS = 64;
 
 template <bool ROWS>
 struct V2Emit {                        // list 1 / close list of one item
@@ -626,11 +637,30 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         for (int l = 0; l < w.nlevels; ++l)
             lvl[l * WALK_THREADS] = item < w.lay.ecap[l] ? w.l3_cs[w.lay.base[l] + item] : 0;
     }
+    int32_t sp = -1;                   // spill chunk of this item: -1 none yet, -2 not to be had
+    auto store3 = [&](int lev, int32_t box) {          // ROWS: entry n3 of the item's list 3
+        if (n3 < w.K3) {
+            row3[(int64_t) n3 * 64] = box; row3lev[(int64_t) n3 * 64] = (uint8_t) lev;
+        } else if (!TEXT && w.spill3 && sp != -2) {     // (with extents: 8 registers = a wave less)
+            if (sp == -1) {
+                const int shard = blockIdx.x & (SPILL_SHARDS - 1);
+                const int32_t got = atomicAdd(w.spill_count + shard * 16, 1);
+                sp = got < w.spill_per_shard ? shard * w.spill_per_shard + got : -2;
+            }
+            const int j = n3 - w.K3;
+            if (sp >= 0 && j < SPILL_CHUNK) {
+                w.spill3[(int64_t) sp * SPILL_CHUNK + j] = box;
+                w.spill3lev[(int64_t) sp * SPILL_CHUNK + j] = (uint8_t) lev;
+            } else {
+                sp = -2;
+            }
+        }
+        ++n3;
+    };
     auto emit3 = [&](int lev, int32_t box) {
         if (ROWS) {
             ++lvl[lev * WALK_THREADS];
-            if (n3 < w.K3) { row3[(int64_t) n3 * 64] = box; row3lev[(int64_t) n3 * 64] = (uint8_t) lev; }
-            ++n3;
+            store3(lev, box);
         } else {
             w.l3_lists[lvl[lev * WALK_THREADS]++] = box;
         }
@@ -751,8 +781,8 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                     if (in_list_1) {
                         emit1(wb);
                     } else if (ROWS) {
-                        if (n3 < w.K3) { row3[(int64_t) n3 * 64] = wb; row3lev[(int64_t) n3 * 64] = (uint8_t) (tl + 1); }
-                        ++n3; ++n3_here;
+                        store3(tl + 1, wb);
+                        ++n3_here;
                     } else {
                         emit3(tl + 1, wb);
                     }
@@ -886,8 +916,9 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             if (item < w.lay.ecap[l]) w.l3_cs[w.lay.base[l] + item] = lvl[l * WALK_THREADS];
         w.l1_cs[item] = e1.n + blk_len;
         if (w.close_cs) w.close_cs[item] = ec.n;
-        const bool ovf = e1.n > w.K1 || n3 > w.K3 || (w.close_cs && ec.n > w.Kc);
+        const bool ovf = e1.n > w.K1 || (n3 > w.K3 && sp < 0) || (w.close_cs && ec.n > w.Kc);
         w.overflow[item] = ovf ? 1 : 0;
+        if (w.spill_idx) w.spill_idx[item] = (!ovf && n3 > w.K3) ? sp : -1;
         // one append per wave (the lanes are together again here): 10^5 appends to one
         // counter, one by one, cost as much as a tenth of the walk
         const uint64_t obal = __ballot(ovf);
@@ -901,7 +932,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         }
         if (ovf && w.dbg_counts) {          // BT_TRAV_STATS: why items overflow
             if (e1.n > w.K1) atomicAdd(w.dbg_counts + 0, 1);
-            if (n3 > w.K3) atomicAdd(w.dbg_counts + 1, 1);
+            if (n3 > w.K3 && sp < 0) atomicAdd(w.dbg_counts + 1, 1);
             if (w.close_cs && ec.n > w.Kc) atomicAdd(w.dbg_counts + 2, 1);
             if (slot >= 0) atomicAdd(w.dbg_counts + 3, 1);
         }
@@ -961,7 +992,8 @@ __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_ni
 // list 3: rows -> per-level lists (cursors start at the item's per-level starts)
 __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nitems, L3Layout lay,
         int nlevels, const uint8_t *overflow, const int32_t *row3, const uint8_t *row3lev, int K3,
-        const int32_t *l3_item_starts, int32_t *l3_lists)
+        const int32_t *l3_item_starts, int32_t *l3_lists, const int32_t *spill_idx,
+        const int32_t *spill3, const uint8_t *spill3lev)
 {
     const int32_t item = blockIdx.x * 256 + threadIdx.x;
     if (item >= *d_nitems || overflow[item]) return;
@@ -978,6 +1010,8 @@ __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nit
     const int32_t *row = row3 + (int64_t) (item >> 6) * 64 * K3 + (item & 63);
     const uint8_t *rl = row3lev + (int64_t) (item >> 6) * 64 * K3 + (item & 63);
     constexpr int UNR = 8;                 // loads in flight per lane (see rows_to_csr_v2_kernel)
+    const int n_all = n;
+    n = n < K3 ? n : K3;                   // the rest is in the item's spill chunk
     for (int j0 = 0; j0 < n; j0 += UNR) {
         int32_t v[UNR];
         int lev[UNR];
@@ -1002,6 +1036,12 @@ __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nit
                     if (j0 + q < n) l3_lists[cur[lev[q] * WALK_THREADS]++] = v[q];
             }
         }
+    }
+    if (n_all > K3 && spill_idx) {
+        // (few items, long lists: a lane reads its own chunk front to back)
+        const int64_t base = (int64_t) spill_idx[item] * SPILL_CHUNK;
+        for (int j = 0; j < n_all - K3; ++j)
+            l3_lists[cur[(int) spill3lev[base + j] * WALK_THREADS]++] = spill3[base + j];
     }
 }
 

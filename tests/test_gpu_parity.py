@@ -137,16 +137,18 @@ def test_packed_key_build_modes(actx, mode, dims, n, mpb, monkeypatch):
                    target_radii=radii, stick_out_factor=0.1)
 
 
-@pytest.mark.parametrize("k1,k3", [(2, 2), (64, 3), (5, 64)])
+@pytest.mark.parametrize("k1,k3,spill", [(2, 2, 1), (64, 3, 1), (64, 3, 0), (5, 64, 1)])
 @pytest.mark.parametrize("dims,n,mpb", [(3, 50000, 20), (2, 30000, 6)])
-def test_walk_rows_overflow(actx, k1, k3, dims, n, mpb, monkeypatch):
-    """Lists 1 and 3 (+ close) are written into fixed-capacity scratch rows by one walk; an
-    item whose lists do not fit is walked a second time straight into the final lists.  With
-    rows of a few entries nearly every item takes that second walk (with the default 64 / 24
-    almost none does): same lists."""
+def test_walk_rows_overflow(actx, k1, k3, spill, dims, n, mpb, monkeypatch):
+    """Lists 1 and 3 (+ close) are written into fixed-capacity scratch rows by one walk; a
+    list 3 that outgrows its row continues in a spill chunk (trees without extents) as long
+    as chunks last, and an item whose lists still do not fit is walked a second time straight
+    into the final lists.  With rows of a few entries nearly every item takes one of those
+    routes (with the default 64 / 24 almost none does): same lists."""
     from oracle import oracle
     monkeypatch.setenv("BT_V2_K1", str(k1))
     monkeypatch.setenv("BT_V2_K3", str(k3))
+    monkeypatch.setenv("BT_V2_SPILL", str(spill))
     rng = np.random.default_rng(1000 * k1 + k3 + dims)
     # clustered + uniform: leaves of several levels side by side (long lists 1, 3 and 4)
     pts = [np.concatenate([rng.random(n // 2), 0.3 + 0.02 * rng.standard_normal(n - n // 2)])
