@@ -1578,11 +1578,11 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     Buf<int32_t> spill3, spill_count, spill_idx;
     Buf<uint8_t> spill3lev;
     const int32_t spill_per_shard = (int32_t) std::max<int64_t>(16, items_cap / 64 / SPILL_SHARDS);
-    if (spill_env) {
+    if (spill_env && !st->with_extent) {     // (extent trees: own-subtree blocks, close lists, registers)
         const int64_t nch = (int64_t) spill_per_shard * SPILL_SHARDS;
         BT_CHECK(spill3.alloc(ctx->pool, nch * SPILL_CHUNK));
         BT_CHECK(spill3lev.alloc(ctx->pool, nch * SPILL_CHUNK));
-        BT_CHECK(spill_idx.alloc(ctx->pool, items_cap));
+        BT_CHECK(spill_idx.alloc(ctx->pool, 2 * items_cap));
         BT_CHECK(spill_count.alloc(ctx->pool, SPILL_SHARDS * 16));
         BT_HIP_CHECK(hipMemsetAsync(spill_count.get(), 0, SPILL_SHARDS * 16 * 4, ctx->stream));
     }
@@ -1775,7 +1775,8 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     BT_CHECK(place_list(ctx, st, c1.lists, c1.total, pk ? &pk->neighbor_source_boxes_lists : nullptr));
     BT_CHECK(place_list(ctx, st, st->l3_lists, total3, pk ? &pk->from_sep_smaller_lists[0] : nullptr));
     rows_to_csr_v2_kernel<<<nblk(items_cap), 256, 0, ctx->stream>>>(
-        d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, 0, c1.lists.get());
+        d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, 0, c1.lists.get(),
+        spill_idx.get() ? spill_idx.get() + items_cap : nullptr, spill3.get());
     if (total3 > 0)
         l3_scatter_v2_kernel<<<nblk(items_cap), 256, lvl_lds, ctx->stream>>>(
             d_nitems, lay, nlevels, overflow.get(), row3.get(), row3lev.get(), K3,

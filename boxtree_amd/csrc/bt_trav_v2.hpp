@@ -555,7 +555,7 @@ struct V2Walk {
     int32_t *spill3;                   // [SPILL_SHARDS * spill_per_shard][SPILL_CHUNK], or null
     uint8_t *spill3lev;
     int32_t *spill_count;              // [SPILL_SHARDS * 16] (a cache line apart), zeroed
-    int32_t *spill_idx;                // [items_cap] chunk of the item, or -1
+    int32_t *spill_idx;                // [2][items_cap] chunk of the item's list 3 / list 1, or -1
     int32_t spill_per_shard;
     int32_t *dbg_counts;               // optional [4]
     // final places (!ROWS)
@@ -626,7 +626,20 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
     // ordering kernels look the ranks up (l1_finalize*_kernel: one lookup per entry, none to
     // map back); a lookup here would stall the walk once per entry, the store having to wait
     // for the load.
-    auto emit1 = [&](int32_t box) { e1(box); };
+    int32_t sp1 = -1;                  // list 1 beyond its row: as for list 3 (store3, below)
+    auto emit1 = [&](int32_t box) {
+        if (ROWS && !TEXT && e1.n >= e1.cap && w.spill3 && sp1 != -2) {
+            if (sp1 == -1) {
+                const int shard = blockIdx.x & (SPILL_SHARDS - 1);
+                const int32_t got = atomicAdd(w.spill_count + shard * 16, 1);
+                sp1 = got < w.spill_per_shard ? shard * w.spill_per_shard + got : -2;
+            }
+            const int j = e1.n - e1.cap;
+            if (sp1 >= 0 && j < SPILL_CHUNK) w.spill3[(int64_t) sp1 * SPILL_CHUNK + j] = box;
+            else sp1 = -2;
+        }
+        e1(box);
+    };
     int32_t *lvl = s_walk_lds + w.walk_cap * WALK_THREADS + threadIdx.x;
     int n3 = 0;
     int32_t *row3 = ROWS ? w.row3 + tile * w.K3 + tl64 : nullptr;
@@ -916,9 +929,12 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             if (item < w.lay.ecap[l]) w.l3_cs[w.lay.base[l] + item] = lvl[l * WALK_THREADS];
         w.l1_cs[item] = e1.n + blk_len;
         if (w.close_cs) w.close_cs[item] = ec.n;
-        const bool ovf = e1.n > w.K1 || (n3 > w.K3 && sp < 0) || (w.close_cs && ec.n > w.Kc);
+        const bool ovf = (e1.n > w.K1 && sp1 < 0) || (n3 > w.K3 && sp < 0) || (w.close_cs && ec.n > w.Kc);
         w.overflow[item] = ovf ? 1 : 0;
-        if (w.spill_idx) w.spill_idx[item] = (!ovf && n3 > w.K3) ? sp : -1;
+        if (w.spill_idx) {
+            w.spill_idx[item] = (!ovf && n3 > w.K3) ? sp : -1;
+            w.spill_idx[w.items_cap + item] = (!ovf && e1.n > w.K1) ? sp1 : -1;
+        }
         // one append per wave (the lanes are together again here): 10^5 appends to one
         // counter, one by one, cost as much as a tenth of the walk
         const uint64_t obal = __ballot(ovf);
@@ -931,7 +947,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             if (ovf) w.ovf_list[base + __popcll(obal & ((1ull << lane) - 1ull))] = item;
         }
         if (ovf && w.dbg_counts) {          // BT_TRAV_STATS: why items overflow
-            if (e1.n > w.K1) atomicAdd(w.dbg_counts + 0, 1);
+            if (e1.n > w.K1 && sp1 < 0) atomicAdd(w.dbg_counts + 0, 1);
             if (n3 > w.K3 && sp < 0) atomicAdd(w.dbg_counts + 1, 1);
             if (w.close_cs && ec.n > w.Kc) atomicAdd(w.dbg_counts + 2, 1);
             if (slot >= 0) atomicAdd(w.dbg_counts + 3, 1);
@@ -944,13 +960,15 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
 __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_nitems,
         const uint8_t *overflow, const int32_t *rows, int K, const int32_t *starts,
         const int32_t *translate /* entries are indices into this table, or null */,
-        int32_t ntranslate, int32_t *lists)
+        int32_t ntranslate, int32_t *lists,
+        const int32_t *spill_idx = nullptr /* [items]: chunk with the entries beyond K, or -1 */,
+        const int32_t *spill = nullptr)
 {
     const int32_t item = blockIdx.x * 256 + threadIdx.x;
     const int32_t nitems = *d_nitems;
     const bool active = item < nitems && !overflow[item];
-    int32_t s = 0, n = 0;
-    if (active) { s = starts[item]; n = starts[item + 1] - s; if (n > K) n = K; }
+    int32_t s = 0, n = 0, n_all = 0;
+    if (active) { s = starts[item]; n = n_all = starts[item + 1] - s; if (n > K) n = K; }
     int nmax = n;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -986,6 +1004,13 @@ __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_ni
                     if (j0 + q < n) dst[q] = v[q];
             }
         }
+    }
+    if (spill_idx && n_all > K) {
+        // (few items, long lists: a lane copies its own chunk front to back)
+        const int32_t sp = spill_idx[item];
+        if (sp >= 0)
+            for (int j = 0; j < n_all - K; ++j)
+                lists[(int64_t) s + K + j] = spill[(int64_t) sp * SPILL_CHUNK + j];
     }
 }
 

@@ -8,10 +8,6 @@ print('$WL $*', '%.3f ms' % d['ms_per_step'], ' '.join('%s=%.2f' % (k.replace('t
   for kv in "$@"; do unset "${kv%%=*}"; done; }
 timeout 900 python -m pytest tests -q -m gpu -x -k "trav or list or fmm or golden or parity" > $OUT/pytest_k3.log 2>&1; grep -n "passed\|failed" $OUT/pytest_k3.log
 run c3
-run c3 BT_V2_SPILL=0
 run c3c
-run c3c BT_V2_SPILL=0
 run c5
-run c5 BT_V2_SPILL=0
-run c2
-for WL in c3 c3c; do BT_TRAV_STATS=1 timeout 300 python bench.py --workload $WL --steps 1 --warmup 1 --cpu-sample 0 2>&1 >/dev/null | grep "bt trav. boxes" | tail -1 | cut -c1-330; done
+run c4
