@@ -1561,10 +1561,9 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     const int K3 = k3_env > 0 ? k3_env : (D == 3 ? 64 : D == 2 ? 24 : 8);
     const int Kc = st->with_extent ? K3 : 0;
     Buf<int32_t> row1, row3, rowc, l1_item, l3_item, close_item, ovf_list;
-    Buf<uint8_t> row3lev, overflow;
+    Buf<uint8_t> overflow;
     BT_CHECK(row1.alloc(ctx->pool, items_cap * K1));
     BT_CHECK(row3.alloc(ctx->pool, items_cap * K3));
-    BT_CHECK(row3lev.alloc(ctx->pool, items_cap * K3));
     if (Kc) BT_CHECK(rowc.alloc(ctx->pool, items_cap * Kc));
     BT_CHECK(l1_item.alloc(ctx->pool, items_cap + 1));
     BT_CHECK(l3_item.alloc(ctx->pool, nflat + 1));
@@ -1576,12 +1575,10 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     // items at most -- beyond that the rows are simply too short for the tree
     const bool spill_env = [] { const char *e = getenv("BT_V2_SPILL"); return !e || atoi(e); }();
     Buf<int32_t> spill3, spill_count, spill_idx;
-    Buf<uint8_t> spill3lev;
     const int32_t spill_per_shard = (int32_t) std::max<int64_t>(16, items_cap / 64 / SPILL_SHARDS);
     if (spill_env && !st->with_extent) {     // (extent trees: own-subtree blocks, close lists, registers)
         const int64_t nch = (int64_t) spill_per_shard * SPILL_SHARDS;
         BT_CHECK(spill3.alloc(ctx->pool, nch * SPILL_CHUNK));
-        BT_CHECK(spill3lev.alloc(ctx->pool, nch * SPILL_CHUNK));
         BT_CHECK(spill_idx.alloc(ctx->pool, 2 * items_cap));
         BT_CHECK(spill_count.alloc(ctx->pool, SPILL_SHARDS * 16));
         BT_HIP_CHECK(hipMemsetAsync(spill_count.get(), 0, SPILL_SHARDS * 16 * 4, ctx->stream));
@@ -1604,12 +1601,11 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     w.nlevels = nlevels; w.walk_cap = walk_cap;
     w.with_blocks = with_blocks ? 1 : 0;
     w.row1 = row1.get(); w.row3 = row3.get(); w.rowc = Kc ? rowc.get() : nullptr;
-    w.row3lev = row3lev.get();
     w.K1 = K1; w.K3 = K3; w.Kc = Kc;
     w.l1_cs = l1_cnt.get(); w.l3_cs = l3_cnt.get();
     w.close_cs = st->with_extent ? close_cnt.get() : nullptr;
     w.overflow = overflow.get();
-    w.spill3 = spill3.get(); w.spill3lev = spill3lev.get(); w.spill_count = spill_count.get();
+    w.spill3 = spill3.get(); w.spill_count = spill_count.get();
     w.spill_idx = spill_idx.get(); w.spill_per_shard = spill_per_shard;
     w.ovf_count = (int32_t *) (totals.get() + T_OVF);
     w.ovf_list = ovf_list.get();
@@ -1779,8 +1775,8 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         spill_idx.get() ? spill_idx.get() + items_cap : nullptr, spill3.get());
     if (total3 > 0)
         l3_scatter_v2_kernel<<<nblk(items_cap), 256, lvl_lds, ctx->stream>>>(
-            d_nitems, lay, nlevels, overflow.get(), row3.get(), row3lev.get(), K3,
-            l3_item.get(), st->l3_lists.get(), spill_idx.get(), spill3.get(), spill3lev.get());
+            d_nitems, lay, nlevels, overflow.get(), row3.get(), K3,
+            l3_item.get(), st->l3_lists.get(), spill_idx.get(), spill3.get());
     if (st->with_extent) {
         BT_CHECK(place_list(ctx, st, cs.lists, cs.total, pk ? &pk->from_sep_close_smaller_lists : nullptr));
         if (cs.total > 0)

@@ -543,8 +543,7 @@ struct V2Walk {
     int nlevels, walk_cap;
     int with_blocks;                   // own-subtree blocks exist (extents)
     // rows
-    int32_t *row1, *row3, *rowc;
-    uint8_t *row3lev;
+    int32_t *row1, *row3 /* box | level << V2_CODE_SHIFT */, *rowc;
     int K1, K3, Kc;
     int32_t *l1_cs, *l3_cs, *close_cs; // counts (ROWS) / starts (!ROWS)
     uint8_t *overflow;                 // [items_cap]
@@ -553,7 +552,6 @@ struct V2Walk {
     // handed out by SPILL_SHARDS counters (one word for all would serialise); an item whose
     // chunk cannot be had, or does not suffice, is walked again (overflow list)
     int32_t *spill3;                   // [SPILL_SHARDS * spill_per_shard][SPILL_CHUNK], or null
-    uint8_t *spill3lev;
     int32_t *spill_count;              // [SPILL_SHARDS * 16] (a cache line apart), zeroed
     int32_t *spill_idx;                // [2][items_cap] chunk of the item's list 3 / list 1, or -1
     int32_t spill_per_shard;
@@ -643,7 +641,6 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
     int32_t *lvl = s_walk_lds + w.walk_cap * WALK_THREADS + threadIdx.x;
     int n3 = 0;
     int32_t *row3 = ROWS ? w.row3 + tile * w.K3 + tl64 : nullptr;
-    uint8_t *row3lev = ROWS ? w.row3lev + tile * w.K3 + tl64 : nullptr;
     if (ROWS) {
         for (int l = 0; l < w.nlevels; ++l) lvl[l * WALK_THREADS] = 0;
     } else {
@@ -652,21 +649,20 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
     }
     int32_t sp = -1;                   // spill chunk of this item: -1 none yet, -2 not to be had
     auto store3 = [&](int lev, int32_t box) {          // ROWS: entry n3 of the item's list 3
+        // (box numbers have V2_CODE_SHIFT bits on this path: the level rides above them,
+        // one store per entry instead of two)
+        const int32_t packed = box | (lev << V2_CODE_SHIFT);
         if (n3 < w.K3) {
-            row3[(int64_t) n3 * 64] = box; row3lev[(int64_t) n3 * 64] = (uint8_t) lev;
-        } else if (!TEXT && w.spill3 && sp != -2) {     // (with extents: 8 registers = a wave less)
+            row3[(int64_t) n3 * 64] = packed;
+        } else if (!TEXT && w.spill3 && sp != -2) {     // (with extents: 2 registers over what six waves allow)
             if (sp == -1) {
                 const int shard = blockIdx.x & (SPILL_SHARDS - 1);
                 const int32_t got = atomicAdd(w.spill_count + shard * 16, 1);
                 sp = got < w.spill_per_shard ? shard * w.spill_per_shard + got : -2;
             }
             const int j = n3 - w.K3;
-            if (sp >= 0 && j < SPILL_CHUNK) {
-                w.spill3[(int64_t) sp * SPILL_CHUNK + j] = box;
-                w.spill3lev[(int64_t) sp * SPILL_CHUNK + j] = (uint8_t) lev;
-            } else {
-                sp = -2;
-            }
+            if (sp >= 0 && j < SPILL_CHUNK) w.spill3[(int64_t) sp * SPILL_CHUNK + j] = packed;
+            else sp = -2;
         }
         ++n3;
     };
@@ -1016,9 +1012,9 @@ __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_ni
 
 // list 3: rows -> per-level lists (cursors start at the item's per-level starts)
 __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nitems, L3Layout lay,
-        int nlevels, const uint8_t *overflow, const int32_t *row3, const uint8_t *row3lev, int K3,
+        int nlevels, const uint8_t *overflow, const int32_t *row3, int K3,
         const int32_t *l3_item_starts, int32_t *l3_lists, const int32_t *spill_idx,
-        const int32_t *spill3, const uint8_t *spill3lev)
+        const int32_t *spill3)
 {
     const int32_t item = blockIdx.x * 256 + threadIdx.x;
     if (item >= *d_nitems || overflow[item]) return;
@@ -1033,7 +1029,6 @@ __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nit
         cur[l * WALK_THREADS] = s;
     }
     const int32_t *row = row3 + (int64_t) (item >> 6) * 64 * K3 + (item & 63);
-    const uint8_t *rl = row3lev + (int64_t) (item >> 6) * 64 * K3 + (item & 63);
     constexpr int UNR = 8;                 // loads in flight per lane (see rows_to_csr_v2_kernel)
     const int n_all = n;
     n = n < K3 ? n : K3;                   // the rest is in the item's spill chunk
@@ -1043,8 +1038,9 @@ __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nit
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const bool in = j0 + u < n;
-            v[u] = in ? row[(int64_t) (j0 + u) * 64] : 0;
-            lev[u] = in ? (int) rl[(int64_t) (j0 + u) * 64] : 0;
+            const int32_t e = in ? row[(int64_t) (j0 + u) * 64] : 0;
+            v[u] = e & (int32_t) V2_ID_MASK;
+            lev[u] = e >> V2_CODE_SHIFT;
         }
         // the walk emits the children of a box one after the other: four entries of one level
         // leave as one 16-byte store
@@ -1065,8 +1061,10 @@ __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nit
     if (n_all > K3 && spill_idx) {
         // (few items, long lists: a lane reads its own chunk front to back)
         const int64_t base = (int64_t) spill_idx[item] * SPILL_CHUNK;
-        for (int j = 0; j < n_all - K3; ++j)
-            l3_lists[cur[(int) spill3lev[base + j] * WALK_THREADS]++] = spill3[base + j];
+        for (int j = 0; j < n_all - K3; ++j) {
+            const int32_t e = spill3[base + j];
+            l3_lists[cur[(e >> V2_CODE_SHIFT) * WALK_THREADS]++] = e & (int32_t) V2_ID_MASK;
+        }
     }
 }
 

@@ -11,3 +11,4 @@ run c3
 run c3c
 run c5
 run c4
+run c2
