@@ -1551,14 +1551,18 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     // (read per call: tests shrink the rows to send every item through the second walk)
     const int k1_env = [] { const char *e = getenv("BT_V2_K1"); return e ? atoi(e) : 0; }();
     const int k3_env = [] { const char *e = getenv("BT_V2_K3"); return e ? atoi(e) : 0; }();
-    const int K1 = k1_env > 0 ? k1_env : (D == 3 ? 64 : D == 2 ? 24 : 8);
+    // (rows written in groups of four entries -- the walk without target extents, RowGroup --
+    // hold whole groups)
+    const int row_group = a.targets_have_extent ? 1 : 4;
+    auto whole_groups = [&](int k) { return (k + row_group - 1) / row_group * row_group; };
+    const int K1 = whole_groups(k1_env > 0 ? k1_env : (D == 3 ? 64 : D == 2 ? 24 : 8));
     // (with extents the lists 3 of the per-colleague items are long: at 10^8 + 10^7
     // particles 8 % of the items overflow 32 entries, 1 % overflow 64.  Without extents a
     // volume-filling cloud is what fills them: a leaf beside refined neighbours takes the
     // non-adjacent children of up to 26 of them -- at 1.25*10^8 uniform points 17.5 % of the
     // items overflow 32 entries and their second walk costs 1.7 ms; with 64 it is < 0.1 ms,
     // the first walk 0.3 ms longer, 96 and 128 change nothing more)
-    const int K3 = k3_env > 0 ? k3_env : (D == 3 ? 64 : D == 2 ? 24 : 8);
+    const int K3 = whole_groups(k3_env > 0 ? k3_env : (D == 3 ? 64 : D == 2 ? 24 : 8));
     const int Kc = st->with_extent ? K3 : 0;
     Buf<int32_t> row1, row3, rowc, l1_item, l3_item, close_item, ovf_list;
     Buf<uint8_t> overflow;
@@ -1770,18 +1774,36 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
 
     BT_CHECK(place_list(ctx, st, c1.lists, c1.total, pk ? &pk->neighbor_source_boxes_lists : nullptr));
     BT_CHECK(place_list(ctx, st, st->l3_lists, total3, pk ? &pk->from_sep_smaller_lists[0] : nullptr));
-    rows_to_csr_v2_kernel<<<nblk(items_cap), 256, 0, ctx->stream>>>(
-        d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, 0, c1.lists.get(),
-        spill_idx.get() ? spill_idx.get() + items_cap : nullptr, spill3.get());
-    if (total3 > 0)
-        l3_scatter_v2_kernel<<<nblk(items_cap), 256, lvl_lds, ctx->stream>>>(
-            d_nitems, lay, nlevels, overflow.get(), row3.get(), K3,
-            l3_item.get(), st->l3_lists.get(), spill_idx.get(), spill3.get());
+    // (the rows' layout follows the walk kernel that wrote them: RowGroup)
+    if (a.targets_have_extent)
+        rows_to_csr_v2_kernel<1><<<nblk(items_cap), 256, 0, ctx->stream>>>(
+            d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, 0, c1.lists.get(),
+            spill_idx.get() ? spill_idx.get() + items_cap : nullptr, spill3.get());
+    else
+        rows_to_csr_v2_kernel<4><<<nblk(items_cap), 256, 0, ctx->stream>>>(
+            d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, 0, c1.lists.get(),
+            spill_idx.get() ? spill_idx.get() + items_cap : nullptr, spill3.get());
+    if (total3 > 0) {
+        if (a.targets_have_extent)
+            l3_scatter_v2_kernel<1><<<nblk(items_cap), 256, lvl_lds, ctx->stream>>>(
+                d_nitems, lay, nlevels, overflow.get(), row3.get(), K3,
+                l3_item.get(), st->l3_lists.get(), spill_idx.get(), spill3.get());
+        else
+            l3_scatter_v2_kernel<4><<<nblk(items_cap), 256, lvl_lds, ctx->stream>>>(
+                d_nitems, lay, nlevels, overflow.get(), row3.get(), K3,
+                l3_item.get(), st->l3_lists.get(), spill_idx.get(), spill3.get());
+    }
     if (st->with_extent) {
         BT_CHECK(place_list(ctx, st, cs.lists, cs.total, pk ? &pk->from_sep_close_smaller_lists : nullptr));
         if (cs.total > 0)
-            rows_to_csr_v2_kernel<<<nblk(items_cap), 256, 0, ctx->stream>>>(
-                d_nitems, overflow.get(), rowc.get(), Kc, close_item.get(), nullptr, 0, cs.lists.get());
+        {
+            if (a.targets_have_extent)
+                rows_to_csr_v2_kernel<1><<<nblk(items_cap), 256, 0, ctx->stream>>>(
+                    d_nitems, overflow.get(), rowc.get(), Kc, close_item.get(), nullptr, 0, cs.lists.get());
+            else
+                rows_to_csr_v2_kernel<4><<<nblk(items_cap), 256, 0, ctx->stream>>>(
+                    d_nitems, overflow.get(), rowc.get(), Kc, close_item.get(), nullptr, 0, cs.lists.get());
+        }
     }
     if (novf > 0) {
         // items whose lists did not fit their rows: walk again, straight to the final places

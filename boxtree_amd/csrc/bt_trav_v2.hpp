@@ -563,14 +563,42 @@ struct V2Walk {
 constexpr int SPILL_CHUNK = 1024;
 constexpr int SPILL_SHARDS = 64;
 
-template <bool ROWS>
+// Scratch rows, G = entries per group: entry j of item t of a tile of 64 items sits at
+// (j / G) * 64 * G + t * G + j % G.  G = 1 is "entry j of the 64 items contiguous"; with
+// G = 4 a lane keeps three entries in registers and writes four with one 16-byte store --
+// the walk of a volume-filling cloud spends a third of its time on row stores, and what they
+// cost is their number, not their bytes (run with every other store left out: 2.6 -> 1.9 ms at
+// 1.25*10^8 points).  The extent-tree walk has no registers to spare: G = 1 there.
+template <bool TEXT> struct RowGroup { static constexpr int G = TEXT ? 1 : 4; };
+
+template <bool ROWS, int G>
 struct V2Emit {                        // list 1 / close list of one item
-    int32_t *base;
-    int stride, cap, n;
+    int32_t *base;                     // ROWS: the item's slot 0 of group 0; else: final place
+    int cap, n;
+    int32_t p0, p1, p2;                // G = 4: entries of the group being filled
     __device__ __forceinline__ void operator()(int32_t v)
     {
-        if (!ROWS || n < cap) base[(int64_t) n * stride] = v;
+        if (!ROWS) {
+            base[n] = v;
+        } else if (n < cap) {
+            if (G == 1) {
+                base[(int64_t) n * 64] = v;
+            } else {
+                const int q = n & 3;
+                if (q == 0) p0 = v; else if (q == 1) p1 = v; else if (q == 2) p2 = v;
+                else *reinterpret_cast<PackedI4 *>(base + (int64_t) (n >> 2) * 256) = PackedI4{p0, p1, p2, v};
+            }
+        }
         ++n;
+    }
+    __device__ __forceinline__ void flush()            // the entries of a group left open
+    {
+        if (!ROWS || G == 1) return;
+        const int m = n < cap ? n : cap, q = m & 3;
+        int32_t *g = base + (int64_t) (m >> 2) * 256;
+        if (q >= 1) g[0] = p0;
+        if (q >= 2) g[1] = p1;
+        if (q >= 3) g[2] = p2;
     }
 };
 
@@ -612,13 +640,14 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
 
     const int64_t tile = (int64_t) (item >> 6) * 64;
     const int tl64 = item & 63;
-    V2Emit<ROWS> e1, ec;
+    constexpr int G = RowGroup<TEXT>::G;
+    V2Emit<ROWS, G> e1, ec;
     if (ROWS) {
-        e1 = V2Emit<ROWS>{w.row1 + tile * w.K1 + tl64, 64, w.K1, 0};
-        ec = V2Emit<ROWS>{w.rowc ? w.rowc + tile * w.Kc + tl64 : nullptr, 64, w.rowc ? w.Kc : 0, 0};
+        e1 = V2Emit<ROWS, G>{w.row1 + tile * w.K1 + tl64 * G, w.K1, 0, 0, 0, 0};
+        ec = V2Emit<ROWS, G>{w.rowc ? w.rowc + tile * w.Kc + tl64 * G : nullptr, w.rowc ? w.Kc : 0, 0, 0, 0, 0};
     } else {
-        e1 = V2Emit<ROWS>{w.l1_lists + w.l1_cs[item], 1, INT_MAX, 0};
-        ec = V2Emit<ROWS>{w.close_lists ? w.close_lists + w.close_cs[item] : nullptr, 1, INT_MAX, 0};
+        e1 = V2Emit<ROWS, G>{w.l1_lists + w.l1_cs[item], INT_MAX, 0, 0, 0, 0};
+        ec = V2Emit<ROWS, G>{w.close_lists ? w.close_lists + w.close_cs[item] : nullptr, INT_MAX, 0, 0, 0, 0};
     }
     // List 1 is ordered by depth-first rank at the end.  The walk writes box numbers and the
     // ordering kernels look the ranks up (l1_finalize*_kernel: one lookup per entry, none to
@@ -640,7 +669,8 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
     };
     int32_t *lvl = s_walk_lds + w.walk_cap * WALK_THREADS + threadIdx.x;
     int n3 = 0;
-    int32_t *row3 = ROWS ? w.row3 + tile * w.K3 + tl64 : nullptr;
+    int32_t *row3 = ROWS ? w.row3 + tile * w.K3 + tl64 * G : nullptr;
+    int32_t q0 = 0, q1 = 0, q2 = 0;    // G = 4: list-3 entries of the group being filled
     if (ROWS) {
         for (int l = 0; l < w.nlevels; ++l) lvl[l * WALK_THREADS] = 0;
     } else {
@@ -653,7 +683,13 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         // one store per entry instead of two)
         const int32_t packed = box | (lev << V2_CODE_SHIFT);
         if (n3 < w.K3) {
-            row3[(int64_t) n3 * 64] = packed;
+            if (G == 1) {
+                row3[(int64_t) n3 * 64] = packed;
+            } else {
+                const int q = n3 & 3;
+                if (q == 0) q0 = packed; else if (q == 1) q1 = packed; else if (q == 2) q2 = packed;
+                else *reinterpret_cast<PackedI4 *>(row3 + (int64_t) (n3 >> 2) * 256) = PackedI4{q0, q1, q2, packed};
+            }
         } else if (!TEXT && w.spill3 && sp != -2) {     // (with extents: 2 registers over what six waves allow)
             if (sp == -1) {
                 const int shard = blockIdx.x & (SPILL_SHARDS - 1);
@@ -921,6 +957,15 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
     }
 
     if (ROWS) {
+        e1.flush();
+        ec.flush();
+        if (G == 4) {
+            const int m = n3 < w.K3 ? n3 : w.K3, q = m & 3;
+            int32_t *g = row3 + (int64_t) (m >> 2) * 256;
+            if (q >= 1) g[0] = q0;
+            if (q >= 2) g[1] = q1;
+            if (q >= 3) g[2] = q2;
+        }
         for (int l = 0; l < w.nlevels; ++l)
             if (item < w.lay.ecap[l]) w.l3_cs[w.lay.base[l] + item] = lvl[l * WALK_THREADS];
         w.l1_cs[item] = e1.n + blk_len;
@@ -953,6 +998,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
 
 // rows -> final places, one wave per tile of 64 items: a lane reads entry j of its own
 // item (the wave reads 256 contiguous bytes) and writes it to the item's CSR segment
+template <int G /* entries per group of the rows, see V2Emit */>
 __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_nitems,
         const uint8_t *overflow, const int32_t *rows, int K, const int32_t *starts,
         const int32_t *translate /* entries are indices into this table, or null */,
@@ -971,14 +1017,23 @@ __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_ni
         const int o = __shfl_xor(nmax, off, 64);
         nmax = o > nmax ? o : nmax;
     }
-    const int32_t *row = rows + (int64_t) (item >> 6) * 64 * K + (item & 63);
+    const int32_t *row = rows + (int64_t) (item >> 6) * 64 * K + (item & 63) * G;
     // eight loads in flight per lane: one load and one store per trip made every trip wait
     // for its load (the stores may alias the rows as far as the compiler knows)
     constexpr int UNR = 8;
     for (int j0 = 0; j0 < nmax; j0 += UNR) {
         int32_t v[UNR];
+        if (G == 1) {
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) v[u] = (j0 + u < n) ? row[(int64_t) (j0 + u) * 64] : 0;
+            for (int u = 0; u < UNR; ++u) v[u] = (j0 + u < n) ? row[(int64_t) (j0 + u) * 64] : 0;
+        } else {
+#pragma unroll
+            for (int u = 0; u < UNR; u += 4) {
+                PackedI4 g{0, 0, 0, 0};
+                if (j0 + u < n) g = *reinterpret_cast<const PackedI4 *>(row + (int64_t) ((j0 + u) >> 2) * 256);
+                v[u] = g.x; v[u + 1] = g.y; v[u + 2] = g.z; v[u + 3] = g.w;
+            }
+        }
         if (translate) {
 #pragma unroll
             // (a list's segment may end with space reserved for a block that is copied in
@@ -1011,6 +1066,7 @@ __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_ni
 }
 
 // list 3: rows -> per-level lists (cursors start at the item's per-level starts)
+template <int G /* entries per group of the rows, see V2Emit */>
 __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nitems, L3Layout lay,
         int nlevels, const uint8_t *overflow, const int32_t *row3, int K3,
         const int32_t *l3_item_starts, int32_t *l3_lists, const int32_t *spill_idx,
@@ -1028,19 +1084,29 @@ __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nit
         }
         cur[l * WALK_THREADS] = s;
     }
-    const int32_t *row = row3 + (int64_t) (item >> 6) * 64 * K3 + (item & 63);
+    const int32_t *row = row3 + (int64_t) (item >> 6) * 64 * K3 + (item & 63) * G;
     constexpr int UNR = 8;                 // loads in flight per lane (see rows_to_csr_v2_kernel)
     const int n_all = n;
     n = n < K3 ? n : K3;                   // the rest is in the item's spill chunk
     for (int j0 = 0; j0 < n; j0 += UNR) {
         int32_t v[UNR];
         int lev[UNR];
+        int32_t raw[UNR];
+        if (G == 1) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) raw[u] = (j0 + u < n) ? row[(int64_t) (j0 + u) * 64] : 0;
+        } else {
+#pragma unroll
+            for (int u = 0; u < UNR; u += 4) {
+                PackedI4 g{0, 0, 0, 0};
+                if (j0 + u < n) g = *reinterpret_cast<const PackedI4 *>(row + (int64_t) ((j0 + u) >> 2) * 256);
+                raw[u] = g.x; raw[u + 1] = g.y; raw[u + 2] = g.z; raw[u + 3] = g.w;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-            const bool in = j0 + u < n;
-            const int32_t e = in ? row[(int64_t) (j0 + u) * 64] : 0;
-            v[u] = e & (int32_t) V2_ID_MASK;
-            lev[u] = e >> V2_CODE_SHIFT;
+            v[u] = raw[u] & (int32_t) V2_ID_MASK;
+            lev[u] = raw[u] >> V2_CODE_SHIFT;
         }
         // the walk emits the children of a box one after the other: four entries of one level
         // leave as one 16-byte store
