@@ -12,4 +12,3 @@ run c3c
 run c5
 run c4
 run c2
-run c1
