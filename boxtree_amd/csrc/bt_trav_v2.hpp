@@ -137,6 +137,7 @@ struct V2Rows {
     int32_t *l2_cnt;               // [nboxes]
     const int32_t *l2_starts;      // fill pass: [nboxes + 1]
     int32_t *l2_lists;
+    int l2_stage;                  // fill pass: a child's List 2 is put together in LDS (3D)
 };
 
 // One group of lanes per PARENT and one lane per candidate (a colleague of the parent, or
@@ -397,6 +398,29 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
                 t.srccoll_cnt[b] = (int32_t) ((incl >> 10) & 0x3ffu);
                 t.l2_cnt[b] = (int32_t) (incl >> 20);
             }
+        } else if (LANES == 32 && t.l2_stage) {
+            // the group's List 2 of this child through LDS: every lane drops its entries at
+            // their places, the group writes the row out in 16-byte pieces
+            __shared__ int32_t s_l2[256 / 32][192];
+            int32_t *lr = s_l2[threadIdx.x / 32];
+            int pos = (int) excl;
+#pragma unroll
+            for (int m = 0; m < C; ++m)
+                if ((lm >> m) & 1u) lr[pos++] = (int32_t) plain[m];
+            if (j == LANES - 1) lr[191] = (int32_t) incl;          // (at most 189 entries)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int tot = lr[191];
+            int32_t *dst = t.l2_lists + lbase;
+            for (int k = j * 4; k < tot; k += 128) {
+                if (k + 4 <= tot) {
+                    *reinterpret_cast<PackedI4 *>(dst + k) = PackedI4{lr[k], lr[k + 1], lr[k + 2], lr[k + 3]};
+                } else {
+                    for (int q = k; q < tot; ++q) dst[q] = lr[q];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         } else {
             int32_t pl = lbase + (int32_t) excl;
             // A candidate that touches the box nowhere gives all its children (19 of the 27
