@@ -6,10 +6,10 @@ import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1]); s = d['stages_ms']
 print('$WL $*', '%.3f ms' % d['ms_per_step'], ' '.join('%s=%.2f' % (k.replace('trav:','t:'), v) for k, v in s.items() if v > 0.05 and k.startswith('trav')))"
   for kv in "$@"; do unset "${kv%%=*}"; done; }
-BT_L2_STAGE=1 timeout 900 python -m pytest tests -q -m gpu -x -k "trav or list or golden" > $OUT/pytest_k3.log 2>&1; grep -n "passed\|failed" $OUT/pytest_k3.log; grep -n "Error\|assert" $OUT/pytest_k3.log | head -5
+timeout 900 python -m pytest tests -q -m gpu -x -k "trav or list or fmm or golden or parity" > $OUT/pytest_k3.log 2>&1; grep -n "passed\|failed" $OUT/pytest_k3.log; grep -n "Error\|assert" $OUT/pytest_k3.log | head -5
 run c3
-run c3 BT_L2_STAGE=1
+run c3 BT_L1_INPLACE=0
 run c5
-run c5 BT_L2_STAGE=1
-run c4
-run c4 BT_L2_STAGE=1
+run c5 BT_L1_INPLACE=0
+run c3c
+run c2
