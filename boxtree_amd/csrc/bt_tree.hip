@@ -677,6 +677,21 @@ __device__ __forceinline__ int32_t range_weight(const BuildArgs &a, int lo, int 
     return (w > (int64_t) INT_MAX) ? INT_MAX : (int32_t) w;     // my_add_sat, tbk:270-274
 }
 
+// a new box has no children yet: its row of the child table in as few stores as its
+// alignment allows (2^d ints at a multiple of 2^d ints from a 256-byte-aligned base)
+template <int C>
+__device__ __forceinline__ void zero_child_row(int32_t *row)
+{
+    if constexpr (C == 8) {
+        int4 *r = reinterpret_cast<int4 *>(row);
+        r[0] = make_int4(0, 0, 0, 0); r[1] = make_int4(0, 0, 0, 0);
+    } else if constexpr (C == 4) {
+        *reinterpret_cast<int4 *>(row) = make_int4(0, 0, 0, 0);
+    } else {
+        *reinterpret_cast<int2 *>(row) = make_int2(0, 0);
+    }
+}
+
 // one thread per (box of level-1, child morton number)
 template <int D, bool EXT>
 __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
@@ -817,8 +832,7 @@ __global__ __launch_bounds__(256) void write_children_kernel(BuildArgs a, T *cen
             const T pc = centers[(int64_t) b * D + ax];
             centers[(int64_t) child_id * D + ax] = has_bit ? pc + radius : pc - radius;
         }
-#pragma unroll
-        for (int mm = 0; mm < C; ++mm) a.box_child[(int64_t) child_id * C + mm] = 0;
+        zero_child_row<C>(a.box_child + (int64_t) child_id * C);
     }
     a.box_child[(int64_t) b * C + m] = child_id;
 }
@@ -1104,8 +1118,7 @@ __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState
                     const T pc = centers[(int64_t) b * D + ax];
                     centers[(int64_t) child_id * D + ax] = has_bit ? pc + radius : pc - radius;
                 }
-#pragma unroll
-                for (int mm = 0; mm < C; ++mm) a.box_child[(int64_t) child_id * C + mm] = 0;
+                zero_child_row<C>(a.box_child + (int64_t) child_id * C);
             }
             a.box_child[(int64_t) b * C + m] = child_id;
             if (m == 0) {
