@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void check_pack_kernel(int32_t nboxes, int64_t
     n.lf = (uint32_t) lev | ((uint32_t) fl << 8);
     nodes[b] = n;
     bool ok = true, geom_ok = true;
+    int32_t row[C];
 #pragma unroll
     for (int m = 0; m < C; ++m) {
         const int32_t c = ch[m];
@@ -126,8 +127,18 @@ __global__ __launch_bounds__(256) void check_pack_kernel(int32_t nboxes, int64_t
             if (cf & BT_BOX_IS_SOURCE_BOX) e |= CH_SRC;
             if (cf & BT_BOX_HAS_SOURCE_CHILD_BOXES) e |= CH_HSC;
         }
-        child_t[(int64_t) b * C + m] = (int32_t) e;
+        row[m] = (int32_t) e;
         if (c != 0) ok = ok && c > b && c < nboxes && parent[c] == b;
+    }
+    // (the row in as few stores as its alignment allows: 2^d ints at a multiple of 2^d ints)
+    if constexpr (C == 8) {
+        int4 *r = reinterpret_cast<int4 *>(child_t + (int64_t) b * C);
+        r[0] = make_int4(row[0], row[1], row[2], row[3]);
+        r[1] = make_int4(row[4], row[5], row[6], row[7]);
+    } else if constexpr (C == 4) {
+        *reinterpret_cast<int4 *>(child_t + (int64_t) b * C) = make_int4(row[0], row[1], row[2], row[3]);
+    } else {
+        *reinterpret_cast<int2 *>(child_t + (int64_t) b * C) = make_int2(row[0], row[1]);
     }
 
     // ---- the structure check ---------------------------------------------------------------
