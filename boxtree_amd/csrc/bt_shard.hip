@@ -239,29 +239,13 @@ __global__ __launch_bounds__(256) void pp_scatter_kernel(PpArgs<U, D> a)
     for (int r = lane; r < a.nranks; r += 64) s_run[w][r] = a.offsets[(int64_t) r * a.nwaves + wave];
     __builtin_amdgcn_wave_barrier();
     const int64_t base = wave * PP_WAVE_ITEMS + lane;
-    // four items' loads are in flight before the first of them is placed: placing is a chain
-    // of ballots, LDS turns and stores per item, and a load issued behind a store waits for it
-    constexpr int PRE = 4;
-    static_assert(PP_ITEMS % PRE == 0, "items per lane in batches of PRE");
-    for (int j0 = 0; j0 < PP_ITEMS; j0 += PRE) {
-      uint32_t dd[PRE];
-      U vv[PRE][D];
-#pragma unroll
-      for (int u = 0; u < PRE; ++u) {
-        const int64_t i = base + (int64_t) (j0 + u) * 64;
+    for (int j = 0; j < PP_ITEMS; ++j) {
+        const int64_t i = base + (int64_t) j * 64;
         const bool in = i < a.n;
-        dd[u] = in ? (uint32_t) a.owner_of_cell[a.cells[i]] : (uint32_t) a.nranks;
-#pragma unroll
-        for (int ax = 0; ax < D; ++ax) vv[u][ax] = in ? a.in[ax][i] : (U) 0;
-      }
-#pragma unroll
-      for (int u = 0; u < PRE; ++u) {
-        const int64_t i = base + (int64_t) (j0 + u) * 64;
-        const bool in = i < a.n;
-        const uint32_t d = dd[u];
+        const uint32_t d = in ? (uint32_t) a.owner_of_cell[a.cells[i]] : (uint32_t) a.nranks;
         U v[D];
 #pragma unroll
-        for (int ax = 0; ax < D; ++ax) v[ax] = vv[u][ax];
+        for (int ax = 0; ax < D; ++ax) v[ax] = in ? a.in[ax][i] : (U) 0;
         const uint64_t mask = pp_match(d, a.bits + 1);
         const uint64_t below = mask & ((1ull << lane) - 1ull);
         int32_t old = 0;
@@ -272,25 +256,9 @@ __global__ __launch_bounds__(256) void pp_scatter_kernel(PpArgs<U, D> a)
         if (in) {
             const int64_t pos = (int64_t) old + __popcll(below);      // record index, owner-major
             U *dst = ((int) d == a.self_rank) ? a.recv + (pos + a.self_delta) * D : a.send + pos * D;
-            // a record in as few stores as it takes (16 bytes at a time at the alignment of one
-            // coordinate): every store instruction of the wave touches all the lines its
-            // records spread over
-            if constexpr (D == 3 && sizeof(U) == 8) {
-                struct __attribute__((packed, aligned(8))) U2 { U x, y; };
-                *reinterpret_cast<U2 *>(dst) = U2{v[0], v[1]};
-                dst[2] = v[2];
-            } else if constexpr (D == 2 && sizeof(U) == 8) {
-                struct __attribute__((packed, aligned(8))) U2 { U x, y; };
-                *reinterpret_cast<U2 *>(dst) = U2{v[0], v[1]};
-            } else if constexpr (D == 3 && sizeof(U) == 4) {
-                struct __attribute__((packed, aligned(4))) U3 { U x, y, z; };
-                *reinterpret_cast<U3 *>(dst) = U3{v[0], v[1], v[2]};
-            } else {
 #pragma unroll
-                for (int ax = 0; ax < D; ++ax) dst[ax] = v[ax];
-            }
+            for (int ax = 0; ax < D; ++ax) dst[ax] = v[ax];
         }
-      }
     }
 }
 
