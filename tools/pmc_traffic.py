@@ -50,6 +50,12 @@ SPECS = {
 }
 SPECS["c4"] = SPECS["c3"]
 SPECS["c2"] = SPECS["c3"]
+SPECS["c5"] = SPECS["c3"] + [
+    ("rows_to_csr_v2_kernel", None, "4 bytes per list-1 entry read and written"),
+    ("l1_finalize32_kernel", None, "4 bytes per list-1 entry read and written, one rank lookup each"),
+    ("l3_scatter_v2_kernel", None, "4 bytes per list-3 entry read and written"),
+    ("list4_lattice_kernel", None, "4 bytes per list-4 entry written"),
+]
 
 
 def main(workload, n, fetch_csv, write_csv, stats_csv, out_path):
