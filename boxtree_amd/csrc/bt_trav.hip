@@ -715,6 +715,7 @@ struct TravState {
     Buf<int32_t> subtree_size, dfs_rank, box_of_rank, src_rank_prefix, src_by_rank;
     Buf<unsigned char> nodes;          // packed Node<T, D>[nboxes]
     Buf<int32_t> child_t;              // [nboxes][C]
+    Buf<uint64_t> child8;              // [nboxes] Kids (bt_trav_v2.hpp)
     // one-block output (bt_traversal_build_packed)
     bt_alloc_fn packed_alloc = nullptr;
     void *packed_user = nullptr;
@@ -1446,7 +1447,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     int32_t *d_coll_cnt = srccoll_cnt.get() + B, *d_coll_ins = srccoll_cnt.get() + 2 * B,
             *d_l2_cnt = srccoll_cnt.get() + 3 * B;
     V2Rows<D> rows{};
-    rows.child_t = st->child_t.get();
+    rows.child8 = st->child8.get();
     rows.parent = p.box_parent_ids;
     rows.flags = p.box_flags;
     rows.target_mask = p.target_boxes_mask;
@@ -1595,7 +1596,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     V2Walk w{};
     w.cells = cells;
     w.flags = p.box_flags;
-    w.child_t = st->child_t.get();
+    w.child8 = st->child8.get();
     w.coll_rows = coll_rows.get(); w.coll_cnt = d_coll_cnt;
     w.srccoll_rows = srccoll_rows.get(); w.srccoll_cnt = srccoll_cnt.get();
     w.item_tbn = item_tbn.get(); w.item_slot = item_slot.get();
@@ -1987,11 +1988,12 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     // structure check, in one pass over the boxes
     BT_CHECK(st->nodes.alloc(ctx->pool, B * (int64_t) sizeof(Node<T, D>)));
     BT_CHECK(st->child_t.alloc(ctx->pool, B * (1 << D)));
+    if (p.force_generic != 1) BT_CHECK(st->child8.alloc(ctx->pool, B));
     if (p.force_generic != 1)
         check_pack_kernel<T, D><<<nblk(B), 256, 0, ctx->stream>>>(
             (int32_t) B, p.aligned_nboxes, p.box_parent_ids, p.box_child_ids, p.box_levels,
             p.box_flags, (const T *) p.box_centers, (T) p.root_extent, (int *) d_bad,
-            (Node<T, D> *) st->nodes.get(), st->child_t.get());
+            (Node<T, D> *) st->nodes.get(), st->child_t.get(), st->child8.get());
     else
         pack_nodes_kernel<T, D, true><<<nblk(B), 256, 0, ctx->stream>>>(
             (int32_t) B, p.aligned_nboxes, (const T *) p.box_centers, p.box_levels, p.box_flags,
@@ -2077,7 +2079,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
             const char *e = getenv("BT_TRAV_V1");            // debugging aid: the float kernels
             return e && atoi(e);
         }();
-        st->lattice = st->fast && hb[1] == 0 && levels_ok && p.well_sep_is_n_away == 1
+        st->lattice = st->fast && hb[1] == 0 && hb[3] == 0 && levels_ok && p.well_sep_is_n_away == 1
             && B < ((int64_t) 1 << 26) && nlevels <= 29 && !v2_off_env && p.force_generic != 2;
     }
     a.fast = st->fast ? 1 : 0;

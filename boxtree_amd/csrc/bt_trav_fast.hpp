@@ -97,7 +97,9 @@ __device__ __forceinline__ int find_slot(const int32_t *child, int64_t aligned, 
 template <class T, int D>
 __global__ __launch_bounds__(256) void check_pack_kernel(int32_t nboxes, int64_t aligned,
         const int32_t *parent, const int32_t *child, const uint8_t *levels, const uint8_t *flags,
-        const T *centers, T root_extent, int *bad, Node<T, D> *nodes, int32_t *child_t)
+        const T *centers, T root_extent, int *bad, Node<T, D> *nodes, int32_t *child_t,
+        uint64_t *child8 /* Kids of bt_trav_v2.hpp; bad[3]: some box's children are not numbered
+                            consecutively in slot order (the lattice kernels must not be used) */)
 {
     constexpr int C = 1 << D;
     const int32_t b = blockIdx.x * 256 + threadIdx.x;
@@ -116,20 +118,29 @@ __global__ __launch_bounds__(256) void check_pack_kernel(int32_t nboxes, int64_t
     for (int ax = 0; ax < D; ++ax) n.c[ax] = cen[ax];
     n.lf = (uint32_t) lev | ((uint32_t) fl << 8);
     nodes[b] = n;
-    bool ok = true, geom_ok = true;
+    bool ok = true, geom_ok = true, consecutive = true;
     int32_t row[C];
+    uint32_t first = 0, nkids = 0, masks = 0;
 #pragma unroll
     for (int m = 0; m < C; ++m) {
         const int32_t c = ch[m];
         uint32_t e = (uint32_t) c;
         if (c > 0 && c < nboxes) {
             const uint8_t cf = flags[c];
-            if (cf & BT_BOX_IS_SOURCE_BOX) e |= CH_SRC;
-            if (cf & BT_BOX_HAS_SOURCE_CHILD_BOXES) e |= CH_HSC;
+            if (cf & BT_BOX_IS_SOURCE_BOX) { e |= CH_SRC; masks |= 0x100u << m; }
+            if (cf & BT_BOX_HAS_SOURCE_CHILD_BOXES) { e |= CH_HSC; masks |= 0x10000u << m; }
         }
         row[m] = (int32_t) e;
-        if (c != 0) ok = ok && c > b && c < nboxes && parent[c] == b;
+        if (c != 0) {
+            ok = ok && c > b && c < nboxes && parent[c] == b;
+            if (nkids == 0) first = (uint32_t) c;
+            else consecutive = consecutive && (uint32_t) c == first + nkids;
+            ++nkids;
+            masks |= 1u << m;
+        }
     }
+    child8[b] = (uint64_t) first | ((uint64_t) masks << 32);
+    if (!consecutive) atomicExch(bad + 3, 1);
     // (the row in as few stores as its alignment allows: 2^d ints at a multiple of 2^d ints)
     if constexpr (C == 8) {
         int4 *r = reinterpret_cast<int4 *>(child_t + (int64_t) b * C);

@@ -67,6 +67,30 @@ __device__ __forceinline__ void v2_load_children(const int32_t *child_t, int32_t
     }
 }
 
+// The children of a box in 8 bytes.  Every tree this path accepts numbers the children of a
+// box consecutively, in slot order (check_pack_kernel verifies it), so a box's row of the
+// child table is its first child plus three masks over the slots: present | is a source box
+// << 8 | has source child boxes << 16.  A quarter of the bytes of the 2^d packed words -- the
+// walks read a record per box they visit, at random --, two registers instead of 2^d, and
+// the masks are what the kernels want anyway.
+struct Kids {
+    uint32_t first, masks;
+    __device__ __forceinline__ uint32_t present() const { return masks & 0xffu; }
+    __device__ __forceinline__ uint32_t source() const { return (masks >> 8) & 0xffu; }
+    __device__ __forceinline__ uint32_t has_src_children() const { return (masks >> 16) & 0xffu; }
+    // number of the child in slot m (which must be present)
+    __device__ __forceinline__ int32_t id(int m) const
+    {
+        return (int32_t) (first + (uint32_t) __popc(masks & 0xffu & ((1u << m) - 1u)));
+    }
+};
+
+__device__ __forceinline__ Kids v2_load_kids(const uint64_t *child8, int32_t box)
+{
+    const uint64_t w = child8[box];
+    return Kids{(uint32_t) w, (uint32_t) (w >> 32)};
+}
+
 // ---- per-tree tables: integer cells, depth-first ranks -------------------------------
 
 struct DfsLevel {
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(256) void dfs_rank_cells_kernel(DfsLevel a)
 
 template <int D>
 struct V2Rows {
-    const int32_t *child_t;        // packed
+    const uint64_t *child8;        // Kids
     const int32_t *parent;
     const uint8_t *flags;
     const int8_t *target_mask;
@@ -226,23 +250,8 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
     if (g >= np) return;                 // whole groups drop out together
     const int32_t p = parents[g];
 
-    // the parent's own children (every lane reads the same words)
-    uint32_t kid[C];
-    {
-        const int32_t *src = t.child_t + (int64_t) p * C;
-        if constexpr (C == 8) {
-            const int4 lo = *reinterpret_cast<const int4 *>(src);
-            const int4 hi = *reinterpret_cast<const int4 *>(src + 4);
-            kid[0] = lo.x; kid[1] = lo.y; kid[2] = lo.z; kid[3] = lo.w;
-            kid[4] = hi.x; kid[5] = hi.y; kid[6] = hi.z; kid[7] = hi.w;
-        } else if constexpr (C == 4) {
-            const int4 lo = *reinterpret_cast<const int4 *>(src);
-            kid[0] = lo.x; kid[1] = lo.y; kid[2] = lo.z; kid[3] = lo.w;
-        } else {
-            const int2 lo = *reinterpret_cast<const int2 *>(src);
-            kid[0] = lo.x; kid[1] = lo.y;
-        }
-    }
+    // the parent's own children (every lane reads the same word)
+    const Kids pk = v2_load_kids(t.child8, p);
 
     // Everything the children's turns need is loaded here, before the first store: loads
     // and stores complete in order on this hardware, so a load issued after a turn's stores
@@ -255,7 +264,7 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
     int32_t lstart[C];
 #pragma unroll
     for (int sb = 0; sb < C; ++sb) {
-        const int32_t b = (int32_t) (kid[sb] & CH_ID_MASK);
+        const int32_t b = ((pk.masks >> sb) & 1u) ? pk.id(sb) : 0;
         const bool mine = b != 0 && b >= b_lo && b < b_hi;
         want[sb] = false; lstart[sb] = 0;
         if (FILL) {
@@ -278,33 +287,11 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
         e = self ? ((uint32_t) p | (V2_CODE_SELF << V2_CODE_SHIFT)) : (j < ins ? e_at : e_before);
     const uint32_t q = e & V2_ID_MASK;
 
-    uint32_t ch[C];
-#pragma unroll
-    for (int m = 0; m < C; ++m) ch[m] = 0;
-    if (valid && !self) {
-        const int32_t *src = t.child_t + (int64_t) q * C;
-        if constexpr (C == 8) {
-            const int4 lo = *reinterpret_cast<const int4 *>(src);
-            const int4 hi = *reinterpret_cast<const int4 *>(src + 4);
-            ch[0] = lo.x; ch[1] = lo.y; ch[2] = lo.z; ch[3] = lo.w;
-            ch[4] = hi.x; ch[5] = hi.y; ch[6] = hi.z; ch[7] = hi.w;
-        } else if constexpr (C == 4) {
-            const int4 lo = *reinterpret_cast<const int4 *>(src);
-            ch[0] = lo.x; ch[1] = lo.y; ch[2] = lo.z; ch[3] = lo.w;
-        } else {
-            const int2 lo = *reinterpret_cast<const int2 *>(src);
-            ch[0] = lo.x; ch[1] = lo.y;
-        }
-    } else if (self) {
-#pragma unroll
-        for (int m = 0; m < C; ++m) ch[m] = kid[m];
-    }
-    uint32_t present = 0, source = 0;
-#pragma unroll
-    for (int m = 0; m < C; ++m) {
-        present |= ((ch[m] & CH_ID_MASK) != 0u ? 1u : 0u) << m;
-        source |= ((ch[m] & CH_SRC) != 0u ? 1u : 0u) << m;
-    }
+    // the candidate's children (the parent's own for the parent itself)
+    Kids ck{0u, 0u};
+    if (valid && !self) ck = v2_load_kids(t.child8, (int32_t) q);
+    else if (self) ck = pk;
+    const uint32_t present = ck.present(), source = ck.source();
     // per axis: the child slots of this candidate adjacent to a child whose own bit on
     // that axis is 0 (adj0) or 1 (adj1)
     uint32_t adj0[D], adj1[D];
@@ -322,13 +309,14 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
         off += (uint32_t) (2 * d + 1) << (2 * ax);
     }
     off <<= V2_CODE_SHIFT;
+    // (numbers of absent children are never used: every use is under `present`)
     uint32_t chid[C], plain[C];
 #pragma unroll
-    for (int m = 0; m < C; ++m) { plain[m] = ch[m] & CH_ID_MASK; chid[m] = plain[m] + off; }
+    for (int m = 0; m < C; ++m) { plain[m] = (uint32_t) ck.id(m); chid[m] = plain[m] + off; }
 
 #pragma unroll
     for (int sb = 0; sb < C; ++sb) {
-        const int32_t b = (int32_t) (kid[sb] & CH_ID_MASK);
+        const int32_t b = ((pk.masks >> sb) & 1u) ? pk.id(sb) : 0;
         if (b == 0 || b < b_lo || b >= b_hi) continue;          // group-uniform
         if (FILL && !want[sb]) continue;                        // group-uniform
         const int32_t lbase = lstart[sb];
@@ -586,7 +574,7 @@ struct L3Layout {
 struct V2Walk {
     const ICell *cells;
     const uint8_t *flags;
-    const int32_t *child_t;            // packed
+    const uint64_t *child8;            // Kids
     const int32_t *coll_rows, *coll_cnt, *srccoll_rows, *srccoll_cnt;
     const int32_t *item_tbn, *item_slot;
     const int32_t *d_nitems;           // actual item count (device)
@@ -847,11 +835,10 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         int size = 0, mnr = 0;
         int32_t parent = nws;
         bool go = true;
-        // The 2^d child words of the box being scanned sit in registers (one or two vector
-        // loads when the scan enters or returns to a box) and a step selects among them:
-        // a 4-byte load per step made every step wait for a load of its own.
-        uint32_t cw[C];
-        v2_load_children<C>(w.child_t, parent, cw);
+        // The children of the box being scanned sit in two registers (Kids: one 8-byte load
+        // when the scan enters or returns to a box) and a step picks its child out of them:
+        // a load per step made every step wait for a load of its own.
+        Kids kd = v2_load_kids(w.child8, parent);
         if (!TEXT && !a.close_lists_exist) {
             // The bottom of the tree, where most of the walk happens: a colleague whose
             // children are all leaves.  Nothing is descended into, so its children are
@@ -859,16 +846,12 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             // compile-time selections, no stack, one update of the level counter -- instead
             // of one trip of the general loop each (a volume-filling cloud at 1.25*10^8
             // points: walk 3.0 -> see DESIGN.md).
-            uint32_t any = 0;
-#pragma unroll
-            for (int m = 0; m < C; ++m) any |= cw[m];
-            if (!(any & CH_HSC)) {
+            if (!kd.has_src_children()) {
                 int n3_here = 0;
 #pragma unroll
                 for (int m = 0; m < C; ++m) {
-                    const uint32_t raw = cw[m];
-                    const int32_t wb = (int32_t) (raw & CH_ID_MASK);
-                    if (!wb || !(raw & CH_SRC)) continue;
+                    if (!((kd.source() >> m) & 1u)) continue;
+                    const int32_t wb = kd.id(m);
                     bool in_list_1 = true;
 #pragma unroll
                     for (int ax = 0; ax < D; ++ax) {
@@ -904,13 +887,11 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             for (int q = 0; q < D; ++q) pcen[q * WALK_THREADS] = pc0[q];
         }
         while (go) {
-            uint32_t raw = cw[0];
-#pragma unroll
-            for (int m = 1; m < C; ++m) raw = (mnr == m) ? cw[m] : raw;
-            const int32_t wb = (int32_t) (raw & CH_ID_MASK);
+            const bool wb_src = (kd.source() >> mnr) & 1u, wb_hsc = (kd.has_src_children() >> mnr) & 1u;
+            const int32_t wb = kd.id(mnr);              // (used only if the child is there)
             bool descend = false;
             int rel[D];
-            if (wb && (raw & (CH_SRC | CH_HSC))) {
+            if (wb_src || wb_hsc) {                     // (set for present children only)
                 const int k = size + 1;                 // level of wb minus tl
                 bool in_list_1 = true;
 #pragma unroll
@@ -927,8 +908,8 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                     return v2_mbit<D>(mnr, q) ? pq + child_rad : pq - child_rad;
                 };
                 if (in_list_1) {
-                    if (raw & CH_SRC) emit1(wb);
-                    descend = (raw & CH_HSC) != 0;
+                    if (wb_src) emit1(wb);
+                    descend = wb_hsc;
                 } else {
                     bool meets = true;
                     if (targets_have_extent) {
@@ -961,8 +942,8 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                     if (meets && !force_close) {
                         emit3(wl, wb);
                     } else if (a.close_lists_exist) {
-                        if (raw & CH_SRC) ec(wb);
-                        descend = (raw & CH_HSC) != 0;
+                        if (wb_src) ec(wb);
+                        descend = wb_hsc;
                     }
                 }
             }
@@ -977,7 +958,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                                                                    : pcen[q * WALK_THREADS] - child_rad;
                 }
                 parent = wb; mnr = 0;
-                v2_load_children<C>(w.child_t, parent, cw);
+                kd = v2_load_kids(w.child8, parent);
 #pragma unroll
                 for (int ax = 0; ax < D; ++ax) prel[ax] = rel[ax];
                 continue;
@@ -997,7 +978,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                 for (int ax = 0; ax < D; ++ax) prel[ax] >>= 1;
             }
             if (popped && go) {
-                v2_load_children<C>(w.child_t, parent, cw);
+                kd = v2_load_kids(w.child8, parent);
                 if (targets_have_extent) {
                     T pc0[D];
                     load_center(a, parent, pc0);
