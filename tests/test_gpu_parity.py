@@ -1390,3 +1390,67 @@ def test_tree_of_boxes_without_level_starts(actx, oracle):
     opl = oracle.peer_lists(otree)
     assert np.array_equal(actx.to_numpy(pl.peer_list_starts), opl.peer_list_starts)
     assert np.array_equal(actx.to_numpy(pl.peer_lists), opl.peer_lists)
+
+
+@pytest.mark.gpu
+def test_tree_of_boxes_children_not_consecutive(actx):
+    """The lattice list kernels keep a box's children as "first child + masks", which needs
+    the children of a box numbered consecutively in slot order; the structure check must send
+    any other tree to the kernels that read the child table as it is.  The boxes of every
+    level of a built tree are renumbered in reverse (still level by level, parents before
+    children): the lists of the renumbered tree are the original lists, renumbered."""
+    from boxtree_amd import FMMTraversalBuilder, TreeBuilder, TreeOfBoxes
+    p = normal_particles(30000, 3, np.float64, seed=11)
+    tree, _ = TreeBuilder(actx)(actx, [actx.from_numpy(x) for x in p], max_particles_in_box=25)
+    h = actx.to_numpy(tree)
+    nb, al = h.nboxes, h.box_child_ids.shape[-1]
+    ls = np.asarray(h.level_start_box_nrs)
+    new_of_old = np.arange(nb)
+    for lev in range(len(ls) - 1):
+        a, b = int(ls[lev]), int(ls[lev + 1])
+        new_of_old[a:b] = np.arange(b - 1, a - 1, -1)
+    old_of_new = np.empty(nb, np.int64)
+    old_of_new[new_of_old] = np.arange(nb)
+
+    def per_box(arr):                       # [..., aligned] -> boxes permuted, padding kept
+        out = arr.copy()
+        out[..., :nb] = arr[..., :nb][..., old_of_new]
+        return out
+
+    child = per_box(h.box_child_ids)
+    kids = child[:, :nb]
+    kids[kids != 0] = new_of_old[kids[kids != 0]]
+    parent = per_box(h.box_parent_ids)
+    parent[:nb] = new_of_old[parent[:nb]]
+    tob = TreeOfBoxes(
+        root_extent=h.root_extent, box_centers=actx.from_numpy(per_box(h.box_centers)),
+        box_parent_ids=actx.from_numpy(parent), box_child_ids=actx.from_numpy(child),
+        box_levels=actx.from_numpy(per_box(h.box_levels)), box_flags=actx.from_numpy(per_box(h.box_flags)),
+        level_start_box_nrs=h.level_start_box_nrs,
+        box_id_dtype=np.dtype(np.int32), box_level_dtype=np.dtype(np.uint8),
+        coord_dtype=np.dtype(np.float64), sources_have_extent=False,
+        targets_have_extent=False, extent_norm=None, stick_out_factor=0.0, _is_pruned=True)
+    assert child.shape[-1] == al
+    ref = actx.to_numpy(FMMTraversalBuilder(actx)(actx, tree)[0])
+    got = actx.to_numpy(FMMTraversalBuilder(actx)(actx, tob)[0])
+
+    def rows(t, starts, lists, boxes, to_old):
+        s, l = np.asarray(getattr(t, starts)), np.asarray(getattr(t, lists))
+        return {int(to_old[int(b)]): sorted(to_old[l[s[i]:s[i + 1]]].tolist())
+                for i, b in enumerate(np.asarray(boxes))}
+
+    ident = np.arange(nb)
+    for name, boxes in (("same_level_non_well_sep_boxes", lambda t: np.arange(nb)),
+                        ("neighbor_source_boxes", lambda t: t.target_boxes),
+                        ("from_sep_siblings", lambda t: t.target_or_target_parent_boxes),
+                        ("from_sep_bigger", lambda t: t.target_or_target_parent_boxes)):
+        want = rows(ref, name + "_starts", name + "_lists", boxes(ref), ident)
+        have = rows(got, name + "_starts", name + "_lists", boxes(got), old_of_new)
+        assert have == want, name
+    for lev in range(h.nlevels):
+        a, b = got.from_sep_smaller_by_level[lev], ref.from_sep_smaller_by_level[lev]
+        have = {int(old_of_new[tb]): sorted(old_of_new[a.lists[a.starts[i]:a.starts[i + 1]]].tolist())
+                for i, tb in enumerate(got.target_boxes_sep_smaller_by_source_level[lev])}
+        want = {int(tb): sorted(b.lists[b.starts[i]:b.starts[i + 1]].tolist())
+                for i, tb in enumerate(ref.target_boxes_sep_smaller_by_source_level[lev])}
+        assert have == want, lev
