@@ -30,7 +30,7 @@ P3 = vp * BT_MAX_DIMS
 PL = vp * BT_MAX_LEVELS
 
 
-ABI_VERSION = 4      # BT_ABI_VERSION of include/boxtree_hip.h
+ABI_VERSION = 5      # BT_ABI_VERSION of include/boxtree_hip.h
 
 
 class SortStats(ct.Structure):
@@ -176,7 +176,8 @@ class MgpuShard(ct.Structure):
                 ("bbox_min", ct.c_double * 3), ("bbox_max", ct.c_double * 3),
                 ("root_extent", ct.c_double), ("top_level", ct.c_int32),
                 ("top_cell_prefix", vp), ("bytes_sent", ct.c_int64), ("rounds", ct.c_int32),
-                ("a2a_ms", ct.c_float), ("n_owned_targets", ct.c_int64), ("target_points", vp)]
+                ("a2a_ms", ct.c_float), ("n_owned_targets", ct.c_int64), ("target_points", vp),
+                ("sep_targets", ct.c_int32)]
 
 
 class MgpuLocalTree(ct.Structure):
@@ -198,7 +199,8 @@ class MgpuLetSizes(ct.Structure):
     _fields_ = [("nboxes", ct.c_int64), ("aligned_nboxes", ct.c_int64), ("nlevels", ct.c_int32),
                 ("level_start_box_nrs", ct.c_int32 * (BT_MAX_LEVELS + 2)),
                 ("active_level_ranges", (ct.c_int32 * 2) * (BT_MAX_LEVELS + 1)),
-                ("halo_boxes_sent", ct.c_int64), ("halo_boxes_received", ct.c_int64)]
+                ("halo_boxes_sent", ct.c_int64), ("halo_boxes_received", ct.c_int64),
+                ("loopback_records", ct.c_int64), ("loopback_mismatches", ct.c_int64)]
 
 
 class MgpuLetArrays(ct.Structure):
@@ -253,7 +255,8 @@ EXPORTED_SYMBOLS = [
     "bt_filter_targets_user_order", "bt_filter_targets_tree_order", "bt_link_point_sources",
     "bt_box_morton_paths", "bt_let_build", "bt_mgpu_exchange", "bt_mgpu_plan",
     "bt_mgpu_comm_rccl", "bt_mgpu_local_group_create", "bt_mgpu_local_group_destroy",
-    "bt_mgpu_comm_local", "bt_mgpu_comm_destroy", "bt_mgpu_number", "bt_mgpu_let_build",
+    "bt_mgpu_comm_local", "bt_mgpu_comm_destroy", "bt_mgpu_use_rccl_library",
+    "bt_mgpu_comm_set_self_loopback", "bt_mgpu_number", "bt_mgpu_let_build",
     "bt_mgpu_let_export",
     "bt_dfs_order", "bt_partition_work", "bt_ancestor_mask", "bt_mark_list_boxes",
     "bt_local_particles", "bt_modify_target_flags", "bt_box_to_user_ranks",
@@ -318,6 +321,8 @@ def load():
     lib.bt_mgpu_comm_local.argtypes = [vp, ct.c_int, ct.POINTER(vp)]
     lib.bt_mgpu_comm_destroy.argtypes = [vp]
     lib.bt_mgpu_comm_destroy.restype = None
+    lib.bt_mgpu_use_rccl_library.argtypes = [ct.c_char_p]
+    lib.bt_mgpu_comm_set_self_loopback.argtypes = [vp, ct.c_int]
     lib.bt_mgpu_number.argtypes = [vp, vp, ct.POINTER(MgpuLocalTree), vp, ct.POINTER(MgpuNumbering)]
     lib.bt_mgpu_let_build.argtypes = [vp, vp, ct.POINTER(MgpuLocalTree), vp,
                                       ct.POINTER(MgpuNumbering), ct.c_int, ct.POINTER(MgpuLetSizes)]

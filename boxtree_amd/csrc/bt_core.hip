@@ -54,7 +54,11 @@ int Pool::alloc(void **out, size_t bytes)
         // pool -- exchange buffers, then the build's -- would otherwise free and re-allocate
         // gigabytes on every step: 135 ms per build at 1.25*10^8 points)
         if (idle > 2 * busy + purge_slack_) {
-            purge_slack_ *= 4;
+            // ... up to a quarter of the device: beyond that the trim could never fire again
+            // and other allocators in the process (torch) would starve beside an idle cache
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void) hipGetLastError(); total_b = (size_t) 64 << 30; }
+            purge_slack_ = std::min(purge_slack_ * 4, std::max(total_b / 4, (size_t) 1 << 30));
             std::vector<Block> keep;
             for (auto &b : blocks_) {
                 if (b.used) keep.push_back(b);

@@ -38,6 +38,7 @@
 #include <condition_variable>
 #include <cstdlib>
 #include <mutex>
+#include <string>
 #include <vector>
 
 using namespace bt;
@@ -59,15 +60,29 @@ struct Nccl {
     bool ok = false;
 };
 
+// The communicator a caller hands over was made by ONE loaded image of RCCL, and its entry
+// points must come from that image: the caller may name it (bt_mgpu_use_rccl_library, before
+// the first communicator), otherwise an image already in the process is taken (RTLD_NOLOAD;
+// a library loaded under another path is found by its SONAME librccl.so.1) and only then a
+// fresh one is loaded.
+std::string &nccl_library_path()
+{
+    static std::string p;
+    return p;
+}
+
 Nccl &nccl()
 {
     static Nccl n = [] {
         Nccl r;
         void *h = nullptr;
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-            if (h) break;
-        }
+        if (!nccl_library_path().empty())
+            h = dlopen(nccl_library_path().c_str(), RTLD_NOW | RTLD_GLOBAL);
+        for (int pass = 0; pass < 2 && !h; ++pass)
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_GLOBAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (h) break;
+            }
         if (!h) return r;
         r.AllReduce = (decltype(r.AllReduce)) dlsym(h, "ncclAllReduce");
         r.AllGather = (decltype(r.AllGather)) dlsym(h, "ncclAllGather");
@@ -138,6 +153,7 @@ struct bt_mgpu_comm {
     int rank = 0, nranks = 1;
     nccl_comm_t nccl = nullptr;
     LocalGroup *group = nullptr;
+    bool self_loopback = false;   // RCCL: a rank's message to itself travels as ncclSend/ncclRecv too
 };
 
 namespace {
@@ -204,7 +220,8 @@ int comm_all_to_all_v(bt_mgpu_comm *c, hipStream_t stream, const char *send, con
 {
     const int me = c->rank, n = c->nranks;
     if (rounds_out) *rounds_out = 1;
-    if (!self_done && s_cnt[me] > 0)
+    const bool loop_self = c->kind == 0 && c->self_loopback && !self_done;
+    if (!self_done && !loop_self && s_cnt[me] > 0)
         BT_HIP_CHECK(hipMemcpyAsync(recv + r_off[me], send + s_off[me], (size_t) s_cnt[me],
                                     hipMemcpyDeviceToDevice, stream));
     if (c->kind == 1) {
@@ -239,7 +256,7 @@ int comm_all_to_all_v(bt_mgpu_comm *c, hipStream_t stream, const char *send, con
         // (a failure inside the group still closes it: RCCL keeps an open group per thread)
         auto in_group = [&]() -> int {
             for (int peer = 0; peer < n; ++peer) {
-                if (peer == me) continue;
+                if (peer == me && !loop_self) continue;
                 const int64_t s0 = cut(s_cnt[peer], j), s1 = cut(s_cnt[peer], j + 1);
                 const int64_t r0 = cut(r_cnt[peer], j), r1 = cut(r_cnt[peer], j + 1);
                 if (s1 > s0)
@@ -425,6 +442,7 @@ struct NeedPred {
     {
         const int64_t b = b0 + i;
         const int lev = levels[b];
+        if (!need_bits) return 1;
         const uint64_t cell = paths[b] >> (D * (lev - k));
         return (int32_t) ((need_bits[cell * nwords + (q >> 6)] >> (q & 63)) & 1ull);
     }
@@ -440,6 +458,22 @@ __global__ __launch_bounds__(256) void let_pack_kernel(int64_t n, NeedPred pr, c
     const uint64_t meta = (uint64_t) pr.levels[b] | ((uint64_t) flags[b] << 8);
     rec[2 * (int64_t) pos[i]] = pr.paths[b];
     rec[2 * (int64_t) pos[i] + 1] = meta | ((uint64_t) (uint32_t) gids[b] << 32);
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(int64_t n, int32_t *out)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (int32_t) i;
+}
+
+__global__ __launch_bounds__(256) void count_diff_kernel(int64_t n, const uint64_t *a, const uint64_t *b,
+                                                         int64_t *bad)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    const bool d = i < n && a[i] != b[i];
+    const uint64_t m = __ballot(d);
+    if (m && (threadIdx.x & 63) == (unsigned) __ffsll((long long) m) - 1)
+        atomicAdd((unsigned long long *) bad, (unsigned long long) __popcll(m));
 }
 
 // deep boxes of the LET before the sort: this rank's own (contiguous in the local tree), then
@@ -582,6 +616,8 @@ int bt_mgpu_comm_rccl(void *nccl_comm, int rank, int nranks, bt_mgpu_comm **out)
     }
     bt_mgpu_comm *c = new bt_mgpu_comm();
     c->kind = 0; c->rank = rank; c->nranks = nranks; c->nccl = (nccl_comm_t) nccl_comm;
+    const char *lb = getenv("BT_MGPU_SELF_LOOPBACK");
+    c->self_loopback = lb && atoi(lb) != 0;
     *out = c;
     return BT_OK;
 }
@@ -611,6 +647,20 @@ int bt_mgpu_comm_local(void *group, int rank, bt_mgpu_comm **out)
 }
 
 void bt_mgpu_comm_destroy(bt_mgpu_comm *c) { delete c; }
+
+int bt_mgpu_use_rccl_library(const char *path)
+{
+    if (!path || !*path) { set_error("bt_mgpu_use_rccl_library: empty path"); return BT_ERR_INVALID; }
+    nccl_library_path() = path;
+    return BT_OK;
+}
+
+int bt_mgpu_comm_set_self_loopback(bt_mgpu_comm *c, int on)
+{
+    if (!c) { set_error("bt_mgpu_comm_set_self_loopback: invalid argument"); return BT_ERR_INVALID; }
+    c->self_loopback = on != 0;
+    return BT_OK;
+}
 
 // Host part, a pure function of the all-reduced histogram (identical on every rank):
 // owner rank of every level-`top_level` cell, and the exclusive prefix sums of the
@@ -655,27 +705,35 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     const int D = p->dims;
     const bool f64 = p->coord_kind == BT_F64;
     const int es = f64 ? 8 : 4;
-    // particle sets: sources, and separate targets if there are any
-    const bool sep = p->ntargets > 0;
-    const int nsets = sep ? 2 : 1;
+    // particle sets: sources, and separate targets if ANY rank has some (a property of the
+    // job, agreed below with the bounding box: it sizes the collectives and decides the flags
+    // of the shared top boxes, so it cannot be a rank's own view of its chunk)
     const int64_t nset[2] = {p->n, p->ntargets};
     const void *const *cset[2] = {p->coords, p->targets};
     hipStream_t stream = ctx->stream;
 
     // ---- 1. global bounding box -> root box --------------------------------------------
-    double h_mm[6];
+    double h_mm[7];
     for (int ax = 0; ax < D; ++ax) { h_mm[ax] = 1.7976931348623158e+308; h_mm[D + ax] = 1.7976931348623158e+308; }
-    for (int s = 0; s < nsets; ++s) {
+    for (int s = 0; s < 2; ++s) {
+        if (nset[s] == 0) continue;
         double lmin[3], lmax[3];
         BT_CHECK(bt_bbox(ctx, D, p->coord_kind, cset[s], nullptr, nset[s], lmin, lmax));
         for (int ax = 0; ax < D; ++ax) { h_mm[ax] = std::min(h_mm[ax], lmin[ax]); h_mm[D + ax] = std::min(h_mm[D + ax], -lmax[ax]); }
     }
+    h_mm[2 * D] = p->ntargets > 0 ? -1.0 : 0.0;      // MIN: -1 if some rank has targets
     Buf<double> mm;
-    BT_CHECK(mm.alloc(ctx->pool, 2 * D));
-    BT_HIP_CHECK(hipMemcpyAsync(mm.get(), h_mm, sizeof(double) * 2 * D, hipMemcpyHostToDevice, stream));
-    BT_CHECK(comm_all_reduce(comm, stream, mm.get(), 2 * D, RED_MIN_F64));
-    BT_HIP_CHECK(hipMemcpyAsync(h_mm, mm.get(), sizeof(double) * 2 * D, hipMemcpyDeviceToHost, stream));
+    BT_CHECK(mm.alloc(ctx->pool, 2 * D + 1));
+    BT_HIP_CHECK(hipMemcpyAsync(mm.get(), h_mm, sizeof(double) * (2 * D + 1), hipMemcpyHostToDevice, stream));
+    BT_CHECK(comm_all_reduce(comm, stream, mm.get(), 2 * D + 1, RED_MIN_F64));
+    BT_HIP_CHECK(hipMemcpyAsync(h_mm, mm.get(), sizeof(double) * (2 * D + 1), hipMemcpyDeviceToHost, stream));
     BT_HIP_CHECK(hipStreamSynchronize(stream));
+    const bool sep = h_mm[2 * D] < 0;
+    const int nsets = sep ? 2 : 1;
+    if (h_mm[0] > -h_mm[D]) {
+        set_error("bt_mgpu_exchange: no rank has any particle");
+        return BT_ERR_INVALID;
+    }
     double bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0}, root_extent = 0;
     if (f64) {
         // tree_build.py:462-476 in the coordinate type
@@ -702,11 +760,13 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     BT_CHECK(owner_d.alloc(ctx->pool, ncells));
     BT_HIP_CHECK(hipMemsetAsync(hist32.get(), 0, (size_t) ncells * 8, stream));
     for (int s = 0; s < nsets; ++s) {
+        if (nset[s] == 0) continue;
         BT_CHECK(cells[s].alloc(ctx->pool, nset[s]));
         BT_CHECK(bt_morton_cells(ctx, D, p->coord_kind, cset[s], nset[s], bmin, bmax, k, cells[s].get(),
                                  hist32.get() + s * ncells));
     }
     widen_hist_kernel<<<(unsigned) div_up(2 * ncells, 256), 256, 0, stream>>>(2 * ncells, hist32.get(), hist64.get());
+    BT_HIP_CHECK(hipGetLastError());
     std::vector<int32_t> h_local((size_t) 2 * ncells);
     BT_HIP_CHECK(hipMemcpyAsync(h_local.data(), hist32.get(), (size_t) ncells * 8, hipMemcpyDeviceToHost, stream));
     BT_CHECK(comm_all_reduce(comm, stream, hist64.get(), (size_t) (nsets * ncells), RED_SUM_I64));
@@ -784,15 +844,24 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
         }
         // one sweep over the coordinates: stable partition by owner into the send buffer, the
         // segment this rank keeps straight into the receive buffer (bt_shard.hip)
-        BT_CHECK(bt_partition_pack(ctx, D, es, cset[s], cells[s].get(), n, owner_d.get(), nranks, rank,
-                                   s_off[rank], r_off[rank], send.get(), points));
+        const bool loop_self = comm->kind == 0 && comm->self_loopback;
         int32_t rounds = 1;
-        s_cnt_b[rank] = 0; r_cnt_b[rank] = 0;       // (own segment: packed in place)
+        if (!loop_self) {
+            BT_CHECK(bt_partition_pack(ctx, D, es, cset[s], cells[s].get(), n, owner_d.get(), nranks, rank,
+                                       s_off[rank], r_off[rank], send.get(), points));
+            s_cnt_b[rank] = 0; r_cnt_b[rank] = 0;       // (own segment: packed in place)
+        } else {
+            // test switch (bt_mgpu_comm_set_self_loopback): the own segment is packed into the
+            // send buffer like any other and makes the trip through ncclSend / ncclRecv
+            BT_CHECK(bt_partition_pack(ctx, D, es, cset[s], cells[s].get(), n, owner_d.get(), nranks, rank,
+                                       s_off[rank], s_off[rank], send.get(), send.get()));
+            biggest = std::max(biggest, s_cnt_b[rank]);
+        }
         BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send.get(), s_off_b.data(), s_cnt_b.data(),
-                                   (char *) points, r_off_b.data(), r_cnt_b.data(), biggest, true, &rounds));
+                                   (char *) points, r_off_b.data(), r_cnt_b.data(), biggest, !loop_self, &rounds));
         BT_HIP_CHECK(hipStreamSynchronize(stream));     // the send buffer and the host vectors go out of scope
         rounds_total += rounds;
-        bytes_sent += (n - send_counts[(size_t) s * nranks + rank]) * rec;
+        bytes_sent += (n - (loop_self ? 0 : send_counts[(size_t) s * nranks + rank])) * rec;
         points_of[s] = points;
         nrecv_of[s] = nrecv;
     }
@@ -812,6 +881,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     out->top_cell_prefix = p->max_particles_in_box > 0 ? ms->cell_prefix.get() : nullptr;
     out->bytes_sent = bytes_sent;
     out->rounds = rounds_total;
+    out->sep_targets = sep ? 1 : 0;
     (void) hipEventElapsedTime(&out->a2a_ms, ms->ev[0], ms->ev[1]);
     return BT_OK;
 }
@@ -934,6 +1004,12 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
         return BT_ERR_INVALID;
     }
     const TopPlan &pl = ms->plan;
+    if (pl.D != tree->dims || num->nlevels < 1 || num->nlevels > BT_MAX_LEVELS || tree->nlevels < 1
+            || tree->nlevels > num->nlevels) {
+        set_error("bt_mgpu_let_build: plan / tree / numbering mismatch (dims %d vs %d, %d local and %d "
+                  "global levels)", pl.D, tree->dims, tree->nlevels, num->nlevels);
+        return BT_ERR_INVALID;
+    }
     BT_HIP_CHECK(hipSetDevice(ctx->device));
     BT_CHECK(bt::zero_begin(ctx));
     memset(out, 0, sizeof(*out));
@@ -1016,6 +1092,34 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
     }
     Buf<uint64_t> halo_rec;
     BT_CHECK(halo_rec.alloc(ctx->pool, 2 * std::max<int64_t>(nrecv, 1)));
+    if (comm->kind == 0 && comm->self_loopback && n_mine > 0) {
+        // test switch: no peer of a one-rank world gets halo records, so the records of ALL my
+        // deep boxes make the trip to myself through ncclSend / ncclRecv and are compared with
+        // what was sent; they are not boxes of the LET (they are mine already)
+        Buf<uint64_t> echo_s, echo_r;
+        Buf<int32_t> ident;
+        Buf<int64_t> bad;
+        BT_CHECK(echo_s.alloc(ctx->pool, 2 * n_mine)); BT_CHECK(echo_r.alloc(ctx->pool, 2 * n_mine));
+        BT_CHECK(ident.alloc(ctx->pool, n_mine)); BT_CHECK(bad.alloc(ctx->pool, 1));
+        iota_kernel<<<(unsigned) div_up(n_mine, 256), 256, 0, stream>>>(n_mine, ident.get());
+        NeedPred all = pr; all.need_bits = nullptr;
+        let_pack_kernel<<<(unsigned) div_up(n_mine, 256), 256, 0, stream>>>(
+            n_mine, all, ident.get(), tree->box_flags, box_ids, echo_s.get());
+        BT_HIP_CHECK(hipMemsetAsync(echo_r.get(), 0xff, (size_t) n_mine * 16, stream));
+        BT_HIP_CHECK(hipMemsetAsync(bad.get(), 0, 8, stream));
+        std::vector<int64_t> z((size_t) nranks, 0), c1((size_t) nranks, 0);
+        c1[rank] = n_mine * 16;
+        BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) echo_s.get(), z.data(), c1.data(),
+                                   (char *) echo_r.get(), z.data(), c1.data(), n_mine * 16, false, nullptr));
+        count_diff_kernel<<<(unsigned) div_up(2 * n_mine, 256), 256, 0, stream>>>(2 * n_mine, echo_s.get(),
+                                                                                 echo_r.get(), bad.get());
+        BT_HIP_CHECK(hipGetLastError());
+        int64_t h_bad = -1;
+        BT_HIP_CHECK(hipMemcpyAsync(&h_bad, bad.get(), 8, hipMemcpyDeviceToHost, stream));
+        BT_HIP_CHECK(hipStreamSynchronize(stream));
+        out->loopback_records = n_mine;
+        out->loopback_mismatches = h_bad;
+    }
     {
         std::vector<int64_t> sob((size_t) nranks), scb((size_t) nranks), rob((size_t) nranks), rcb((size_t) nranks);
         for (int q = 0; q < nranks; ++q) {
@@ -1081,6 +1185,7 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
         let_deep_kernel<<<(unsigned) div_up(nd, 256), 256, 0, stream>>>(
             n_mine, nrecv, b0, paths.get(), tree->box_levels, tree->box_flags, box_ids, halo_rec.get(),
             pathbits, key_a.get(), d_path.get(), d_meta.get(), d_gid.get());
+        BT_HIP_CHECK(hipGetLastError());
         // (level, Morton path) order; equal keys cannot occur (a box is sent by its one owner)
         bool in_b = false;
         BT_CHECK(radix_sort_pairs<uint64_t>(ctx, key_a.get(), ord_a.get(), key_b.get(), ord_b.get(), nd, 0,
@@ -1184,6 +1289,7 @@ int bt_mgpu_let_export(bt_context *ctx, const bt_mgpu_let_arrays *o)
     hipStream_t stream = ctx->stream;
     let_split_meta_kernel<<<(unsigned) div_up(B, 256), 256, 0, stream>>>(B, ms->let_meta.get(), o->box_levels,
                                                                          o->box_flags);
+    BT_HIP_CHECK(hipGetLastError());
     if (o->global_box_ids)
         BT_HIP_CHECK(hipMemcpyAsync(o->global_box_ids, ms->let_gid.get(), (size_t) B * 4, hipMemcpyDeviceToDevice, stream));
     if (o->target_boxes_mask)

@@ -73,7 +73,10 @@ class _RcclComm:
 
     def __init__(self, dist, device_index):
         import torch
-        self.rccl = ct.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self.rccl = ct.CDLL(path)
+        # the library must call into THIS image of RCCL (the one that makes the communicator)
+        _lib.check(_lib.load().bt_mgpu_use_rccl_library(path.encode()))
 
         class UniqueId(ct.Structure):
             _fields_ = [("internal", ct.c_char * 128)]
@@ -100,12 +103,17 @@ class _RcclComm:
             self.comm = None
 
 
-def rccl_comm(actx, dist):
-    """A :class:`NativeComm` over RCCL with the ranks of *dist* (collective)."""
+def rccl_comm(actx, dist, self_loopback=None):
+    """A :class:`NativeComm` over RCCL with the ranks of *dist* (collective).
+    *self_loopback* (default: the environment variable ``BT_MGPU_SELF_LOOPBACK``) sends a
+    rank's messages to itself through ``ncclSend`` / ``ncclRecv`` as well -- the switch that
+    lets a one-GPU box execute the point-to-point branch."""
     rc = _RcclComm(dist, actx.device_index)
     h = ct.c_void_p()
     _lib.check(actx.lib.bt_mgpu_comm_rccl(rc.comm, dist.get_rank(), dist.get_world_size(),
                                           ct.byref(h)))
+    if self_loopback is not None:
+        _lib.check(actx.lib.bt_mgpu_comm_set_self_loopback(h, int(bool(self_loopback))))
     return NativeComm(actx.lib, h, dist.get_rank(), dist.get_world_size(), "rccl", keep=rc)
 
 
@@ -156,6 +164,9 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
     n_owned = int(shard.n_owned)
     if targets is not None:
         return _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev)
+    if shard.sep_targets:
+        raise ValueError("exchange_particles: other ranks passed separate targets; every rank "
+                         "must pass `targets` (an empty chunk is fine)")
     if own_buffer:
         recv = got["buf"][:n_owned * dims * es].view(dtype).view(n_owned, dims)
     else:
@@ -188,6 +199,9 @@ def _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev):
     """Contiguous coordinate arrays of both received sets (``bt_unpack``) + build kwargs."""
     import torch
     out = []
+    if len(bufs) < 2:
+        # no rank of the job had a target: the library exchanged one set
+        bufs = [bufs[0], None]
     for buf, n in ((bufs[0], int(shard.n_owned)), (bufs[1], int(shard.n_owned_targets))):
         arrs = [torch.empty(n, dtype=dtype, device=dev) for _ in range(dims)]
         optrs = (ct.c_void_p * dims)(*[a.data_ptr() for a in arrs])
@@ -287,7 +301,9 @@ def build_local_essential_tree(actx, comm, tree, numbering, well_sep_is_n_away=1
                        for l in range(nlev)], dtype=np.int32)
     info = dict(target_boxes_mask=mask, active_level_ranges=ranges, global_box_ids=gids,
                 halo_boxes_received=int(sizes.halo_boxes_received),
-                halo_boxes_sent=int(sizes.halo_boxes_sent), nboxes=B)
+                halo_boxes_sent=int(sizes.halo_boxes_sent), nboxes=B,
+                loopback_records=int(sizes.loopback_records),
+                loopback_mismatches=int(sizes.loopback_mismatches))
     return let, info
 
 

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BT_ABI_VERSION 4
+#define BT_ABI_VERSION 5
 #define BT_MAX_DIMS 3
 #define BT_MAX_LEVELS 64       /* capacity of per-level arrays in the structs */
 
@@ -559,6 +559,18 @@ int bt_mgpu_local_group_create(int nranks, void **group);
 void bt_mgpu_local_group_destroy(void *group);
 int bt_mgpu_comm_local(void *group, int rank, bt_mgpu_comm **out);
 void bt_mgpu_comm_destroy(bt_mgpu_comm *comm);
+/* The library binds the few RCCL entry points it uses at run time (no link-time dependency).
+ * A communicator must be used through the image of RCCL that made it: name that image here
+ * (before the first bt_mgpu_comm_rccl) when the process could hold more than one, e.g. the
+ * copy inside a torch wheel next to /opt/rocm/lib.  Without the call an image already loaded
+ * is preferred over loading one. */
+int bt_mgpu_use_rccl_library(const char *path);
+/* Test switch for boxes with one GPU (environment: BT_MGPU_SELF_LOOPBACK=1 at communicator
+ * creation): a rank's messages to ITSELF -- its own segment of the particle all-to-all-v, and
+ * an echo of the halo records in bt_mgpu_let_build -- travel through ncclSend / ncclRecv
+ * (512-MiB rounds and all) instead of a device copy, so that the point-to-point branch runs
+ * with a world of one rank.  Results are unchanged. */
+int bt_mgpu_comm_set_self_loopback(bt_mgpu_comm *comm, int on);
 
 typedef struct {
     int32_t dims, coord_kind;
@@ -588,6 +600,8 @@ typedef struct {
                                        /* events on the context's stream)               */
     int64_t n_owned_targets;           /* separate targets: the ones this rank owns, laid */
     void *target_points;               /* out like `points` (second allocation)          */
+    int32_t sep_targets;               /* 1: some rank passed separate targets, so every  */
+                                       /* rank exchanged two sets (n_owned_targets may be 0) */
 } bt_mgpu_shard;
 
 /* the one-sweep partition (bt_partition_pack) keeps one run per owner in LDS: at most this
@@ -653,6 +667,7 @@ typedef struct {
     int32_t level_start_box_nrs[BT_MAX_LEVELS + 2];
     int32_t active_level_ranges[BT_MAX_LEVELS + 1][2];  /* per level: [begin, end) of the rank's boxes */
     int64_t halo_boxes_sent, halo_boxes_received;
+    int64_t loopback_records, loopback_mismatches;      /* self-loopback echo of the halo records */
 } bt_mgpu_let_sizes;
 typedef struct {
     void *box_centers;

@@ -114,16 +114,7 @@ def test_steps_1_to_6_one_rank_rccl(dims, nway):
     actx = HIPArrayContext(0)
     torch.cuda.set_device(0)
 
-    class OneRank:           # the unique id needs no broadcast with one rank
-        @staticmethod
-        def get_rank():
-            return 0
-
-        @staticmethod
-        def get_world_size():
-            return 1
-
-    comm = nat.rccl_comm(actx, OneRank)
+    comm = nat.rccl_comm(actx, _OneRank)
     try:
         rng = np.random.default_rng(3 + dims)
         n, mpb = 150000, 20
@@ -156,6 +147,133 @@ def test_steps_1_to_6_one_rank_rccl(dims, nway):
         assert_same_traversal(actx.to_numpy(t_let), actx.to_numpy(t_plain))
     finally:
         comm.close()
+
+
+class _OneRank:           # the unique id needs no broadcast with one rank
+    @staticmethod
+    def get_rank():
+        return 0
+
+    @staticmethod
+    def get_world_size():
+        return 1
+
+
+@pytest.mark.parametrize("dims,sep", [(3, False), (2, False), (3, True)])
+def test_self_loopback_runs_the_point_to_point_branch(dims, sep):
+    """world = 1 is all a one-GPU box can give RCCL, and there a rank has no peer: with the
+    self-loopback switch its own segment of the particle all-to-all-v and an echo of its halo
+    records go through ncclSend / ncclRecv (grouped, in rounds) instead of device copies.  The
+    shard, the tree, the LET and the lists must be what they are without the switch."""
+    import torch
+    from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
+    from boxtree_amd.distributed import native as nat
+    from compare import assert_same_traversal
+    actx = HIPArrayContext(0)
+    torch.cuda.set_device(0)
+    comm = nat.rccl_comm(actx, _OneRank, self_loopback=True)
+    try:
+        rng = np.random.default_rng(11 + dims)
+        n, nt, mpb = 180000, 70000, 25
+        pts = [torch.from_numpy(rng.standard_normal(n)).cuda() for _ in range(dims)]
+        es = 8
+        if sep:
+            tgts = [torch.from_numpy(rng.standard_normal(nt)).cuda() for _ in range(dims)]
+            p2, t2, kw, stats = nat.exchange_particles(actx, comm, pts, mpb, targets=tgts)
+            assert stats["bytes_sent"] == (n + nt) * dims * es
+            for ax in range(dims):
+                assert torch.equal(p2[ax], pts[ax]) and torch.equal(t2[ax], tgts[ax])
+            tree, _ = TreeBuilder(actx)(actx, p2, targets=t2, max_particles_in_box=mpb, **kw)
+            plain, _ = TreeBuilder(actx)(actx, pts, targets=tgts, max_particles_in_box=mpb)
+        else:
+            p2, kw, stats = nat.exchange_particles(actx, comm, pts, mpb)
+            assert stats["bytes_sent"] == n * dims * es and stats["rounds"] == 1
+            for ax in range(dims):
+                assert torch.equal(p2[ax], pts[ax])
+            tree, _ = TreeBuilder(actx)(actx, p2, max_particles_in_box=mpb, **kw)
+            plain, _ = TreeBuilder(actx)(actx, pts, max_particles_in_box=mpb)
+        assert_same_tree(actx.to_numpy(tree), actx.to_numpy(plain))
+        num = nat.number_sharded_tree(actx, comm, tree)
+        let, info = nat.build_local_essential_tree(actx, comm, tree, num)
+        lsb = actx.to_numpy(tree.level_start_box_nrs)
+        k = stats["top_level"]
+        deep = int(tree.nboxes) - int(lsb[min(k + 1, len(lsb) - 1)])
+        assert deep > 0 and info["loopback_records"] == deep and info["loopback_mismatches"] == 0
+        assert info["halo_boxes_received"] == 0 and info["nboxes"] == int(tree.nboxes)
+        tb = FMMTraversalBuilder(actx)
+        t_let, _ = tb(actx, let, _target_boxes_mask=info["target_boxes_mask"],
+                      _active_level_ranges=info["active_level_ranges"])
+        t_plain, _ = tb(actx, tree)
+        assert_same_traversal(actx.to_numpy(t_let), actx.to_numpy(t_plain))
+    finally:
+        comm.close()
+
+
+def test_self_loopback_messages_above_the_round_limit():
+    """A 1.7 GB message to oneself: four grouped ncclSend / ncclRecv rounds of at most 512 MiB
+    (an unchunked message above 1 GB once arrived corrupted); every byte must arrive."""
+    import torch
+    from boxtree_amd import HIPArrayContext
+    from boxtree_amd.distributed import native as nat
+    actx = HIPArrayContext(0)
+    torch.cuda.set_device(0)
+    comm = nat.rccl_comm(actx, _OneRank, self_loopback=True)
+    try:
+        n = 72_000_000
+        g = torch.Generator(device="cuda").manual_seed(5)
+        pts = [torch.rand(n, dtype=torch.float64, device="cuda", generator=g) for _ in range(3)]
+        p2, kw, stats = nat.exchange_particles(actx, comm, pts, 64)
+        assert stats["bytes_sent"] == n * 24 and stats["rounds"] == 4, stats
+        for ax in range(3):
+            assert torch.equal(p2[ax], pts[ax])
+        assert stats["a2a_ms"] > 0
+    finally:
+        comm.close()
+
+
+def test_rank_without_targets_keeps_the_collectives_in_step():
+    """Target presence is a property of the job, not of a rank's chunk: a rank whose chunk has
+    no target takes part in the two-set exchange (same all-reduce lengths, same flags of the
+    shared top boxes) and may end up owning targets of the others."""
+    import threading
+
+    import torch
+    from boxtree_amd import HIPArrayContext, TreeBuilder
+    from boxtree_amd.distributed import native as nat
+    world, n, mpb = 3, 30000, 20
+    rng = np.random.default_rng(77)
+    chunks = [[rng.random(n) for _ in range(3)] for _ in range(world)]
+    tchunks = [[rng.random(m) for _ in range(3)] for m in (25000, 0, 4000)]
+    group = nat.LocalGroup(world)
+    res, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            actx = HIPArrayContext(0)
+            comm = group.comm(rank)
+            out = nat.sharded_tree_and_lists(
+                actx, comm, [torch.from_numpy(a).cuda() for a in chunks[rank]], mpb,
+                targets=[torch.from_numpy(a).cuda() for a in tchunks[rank]])
+            res[rank] = (out["numbering"]["nboxes"], int(out["tree"].nsources), int(out["tree"].ntargets),
+                         out["numbering"]["ntargets"])
+            comm.close()
+        except BaseException as e:      # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert all(not t.is_alive() for t in threads), "a rank hangs"
+    group.close()
+    assert not errors, errors
+    actx = HIPArrayContext(0)
+    pts = [torch.from_numpy(np.concatenate([c[ax] for c in chunks])).cuda() for ax in range(3)]
+    tg = [torch.from_numpy(np.concatenate([c[ax] for c in tchunks])).cuda() for ax in range(3)]
+    g, _ = TreeBuilder(actx)(actx, pts, targets=tg, max_particles_in_box=mpb)
+    assert all(r[0] == int(g.nboxes) and r[3] == 29000 for r in res)
+    assert sum(r[1] for r in res) == world * n and sum(r[2] for r in res) == 29000
 
 
 def test_sharded_tree_and_lists_one_call():

@@ -1,0 +1,116 @@
+"""The tree assertions of the reference's test-suite (test/test_tree.py:88-220,
+run_build_test; restated for numpy in tests/invariants.py) as torch operations on the
+device, for trees too large to bring to the host: 10^9 particles, 5*10^7 boxes.
+Point particles, sources = targets, kind="adaptive".  Returns a dict of what was checked.
+"""
+
+from __future__ import annotations
+
+
+def check_tree_on_device(torch, tree, particles, max_particles_in_box, chunk=1 << 27):
+    nb = int(tree.nboxes)
+    n = int(tree.nsources)
+    dims = int(tree.dimensions)
+    dev = tree.box_centers.device
+    i64 = torch.int64
+    out = {"nboxes": nb, "nsources": n}
+
+    ids = tree.user_source_ids
+    # a permutation of 0..n-1: every id in range and hit exactly once
+    assert int(ids.min()) == 0 and int(ids.max()) == n - 1
+    hits = torch.zeros(n, dtype=torch.int8, device=dev)
+    hits.index_fill_(0, ids.to(i64), 1)
+    assert bool(hits.all()), "user_source_ids is not a permutation"
+    del hits
+    # sorted_target_ids is its inverse (tree_build.py:1467)
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        assert torch.equal(ids[tree.sorted_target_ids[lo:hi].to(i64)].to(i64),
+                           torch.arange(lo, hi, device=dev, dtype=i64))
+    # sorted coordinates are the inputs in tree order (test_tree.py:110-114)
+    for ax in range(dims):
+        for lo in range(0, n, chunk):
+            hi = min(n, lo + chunk)
+            assert torch.equal(tree.sources[ax][lo:hi], particles[ax][ids[lo:hi].to(i64)])
+    out["permutation"] = "ok"
+
+    levels = tree.box_levels.to(i64)
+    lsb = torch.as_tensor(tree.level_start_box_nrs).to(dev).to(i64)
+    nlev = int(tree.nlevels)
+    # level-major numbering
+    assert int(lsb[0]) == 0 and int(lsb[nlev]) == nb
+    assert bool((levels[1:] >= levels[:-1]).all())
+    cnt_per_level = torch.bincount(levels, minlength=nlev)
+    assert torch.equal(cnt_per_level, lsb[1:nlev + 1] - lsb[:nlev])
+
+    child = tree.box_child_ids[:, :nb].to(i64)              # [C, nb]
+    parent = tree.box_parent_ids.to(i64)
+    has = child != 0
+    box = torch.arange(nb, device=dev, dtype=i64)
+    # children point back, one level down, numbered after their parent
+    for m in range(child.shape[0]):
+        sel = has[m]
+        c = child[m][sel]
+        assert torch.equal(parent[c], box[sel])
+        assert torch.equal(levels[c], levels[sel] + 1)
+    nchildren = has.sum(0)
+    assert int(nchildren.sum()) == nb - 1, "every box but the root is some box's child"
+    assert int(parent[0]) == 0
+
+    cumul = tree.box_source_counts_cumul.to(i64)
+    nonchild = tree.box_source_counts_nonchild.to(i64)
+    starts = tree.box_source_starts.to(i64)
+    # nonchild + sum(children cumul) == cumul  (test_tree.py:182-184)
+    kid_sum = torch.zeros(nb, dtype=i64, device=dev)
+    for m in range(child.shape[0]):
+        kid_sum += torch.where(has[m], cumul[child[m]], torch.zeros((), dtype=i64, device=dev))
+    assert torch.equal(nonchild + kid_sum, cumul)
+    assert int(cumul[0]) == n
+    assert bool((cumul > 0).all()), "pruned tree: no empty box"
+    leaf = nchildren == 0
+    # leaf occupancy and the split rule (test_tree.py:203-218; tree_build_kernels.py:577-591)
+    assert bool((cumul[leaf] <= max_particles_in_box).all())
+    assert bool((cumul[~leaf] > max_particles_in_box).all())
+    assert torch.equal(nonchild[leaf], cumul[leaf]) and int(nonchild[~leaf].sum()) == 0
+    # a box's children tile its particle range in child order
+    run = starts.clone()
+    for m in range(child.shape[0]):
+        sel = has[m]
+        c = child[m][sel]
+        assert torch.equal(starts[c], run[sel])
+        run[sel] += cumul[c]
+    assert torch.equal(run[~leaf], (starts + cumul)[~leaf])
+    # the leaves tile 0..n in box order within ... (each particle in exactly one leaf)
+    assert int(cumul[leaf].sum()) == n
+    out["structure"] = "ok"
+    out["nleaves"] = int(leaf.sum())
+
+    # every particle of a leaf lies in the leaf's box (test_tree.py:186-190), and box centres
+    # are where the level and the root box put them
+    root_extent = float(tree.root_extent)
+    half = 0.5 * root_extent / torch.pow(torch.tensor(2.0, dtype=torch.float64, device=dev),
+                                         levels.to(torch.float64))
+    tol = 1e-12 * root_extent
+    leaf_ids = box[leaf]
+    order = torch.argsort(starts[leaf_ids])
+    leaf_ids = leaf_ids[order]
+    lstart = starts[leaf_ids]
+    lcnt = cumul[leaf_ids]
+    assert int(lstart[0]) == 0 and torch.equal(lstart[1:], (lstart + lcnt)[:-1])
+    bounds = torch.cat([lstart, torch.tensor([n], device=dev, dtype=i64)])
+    for lo in range(0, n, chunk):
+        hi = min(n, lo + chunk)
+        pos = torch.arange(lo, hi, device=dev, dtype=i64)
+        owner = leaf_ids[torch.searchsorted(bounds, pos, right=True) - 1]
+        h = half[owner]
+        for ax in range(dims):
+            p = tree.sources[ax][lo:hi]
+            c = tree.box_centers[ax][owner]
+            assert bool((p < c + h + tol).all()) and bool((c - h - tol <= p).all())
+    bb_lo, bb_hi = tree.bounding_box
+    for ax in range(dims):
+        c = tree.box_centers[ax][:nb]
+        assert bool((c - half >= float(bb_lo[ax]) - tol).all())
+        assert bool((c + half <= float(bb_hi[ax]) + tol).all())
+    out["containment"] = "ok"
+    return out
