@@ -373,6 +373,22 @@ def main():
     info = {}
     last_exchange = {}
 
+    golden_c5 = None
+    if args.workload == "c5" and n_local == WORKLOAD_N["c5"] and args.mpb == 64 and args.rng == "numpy":
+        try:
+            golden_c5 = json.load(open(os.path.join(ROOT, "tests", "golden", "c5_global_counts.json")))
+            golden_c5 = golden_c5["worlds"].get(str(world))
+        except (OSError, KeyError, ValueError):
+            golden_c5 = None
+    c5_local = {}
+
+    def c5_record(global_box_ids, counts_cumul, nboxes, nlevels, level_starts):
+        """This rank's share of the tree checksum (linear in the counts: the ranks' shares add
+        up to the single-GPU tree's, boxtree_amd/distributed/checksum.py)."""
+        from boxtree_amd.distributed.checksum import tree_checksum
+        c5_local.update(checksum=tree_checksum(torch, global_box_ids, counts_cumul), nboxes=int(nboxes),
+                        nlevels=int(nlevels), level_start_box_nrs=[int(v) for v in level_starts])
+
     def step(instrumented=False):
         """One pass of the path.  The timed steps read only the sort's event times (the
         sort of a step has long completed when its build returns); the per-stage times
@@ -400,6 +416,9 @@ def main():
                          sharded_traversal="bt_mgpu_* entries: local essential tree (halo of "
                                            "neighbouring cells); lists for own boxes + shared top levels")
             nboxes, nlevels = int(num["nboxes"]), int(gtree.nlevels)
+            if instrumented and golden_c5 is not None:
+                c5_record(num["box_ids"], tree.box_source_counts_cumul, nboxes, num["nlevels"],
+                          num["global_level_start_box_nrs"])
             return finish_step(st, trav, nboxes, nlevels, instrumented)
         if distributed:
             # the exchange is part of the path (and of the timed step) for N > 1
@@ -436,6 +455,9 @@ def main():
         else:
             trav, _ = tg(actx, tree)
             nboxes, nlevels = int(tree.nboxes), int(tree.nlevels)
+            if instrumented and golden_c5 is not None and not distributed:
+                c5_record(torch.arange(nboxes, device=device), tree.box_source_counts_cumul, nboxes,
+                          nlevels, actx.to_numpy(tree.level_start_box_nrs))
         return finish_step(st, trav, nboxes, nlevels, instrumented)
 
     def finish_step(st, trav, nboxes, nlevels, instrumented):
@@ -479,6 +501,28 @@ def main():
         for k, v in times.items():
             stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
+    if golden_c5 is not None and c5_local:
+        # the global numbering this run arrived at against the tree ONE GPU builds from the
+        # chunks of all ranks (tests/golden/c5_global_counts.json, tools/c5_full.py)
+        from boxtree_amd.distributed.checksum import wrap_int64
+        total = c5_local["checksum"]
+        if distributed and world > 1:
+            shares = [None] * world
+            dist.all_gather_object(shares, c5_local["checksum"])
+            total = wrap_int64(sum(shares))
+        same = (total == golden_c5["counts_cumul_checksum"] and c5_local["nboxes"] == golden_c5["nboxes"]
+                and c5_local["nlevels"] == golden_c5["nlevels"]
+                and c5_local["level_start_box_nrs"] == golden_c5["level_start_box_nrs"])
+        xinfo["c5_check"] = {
+            "matches_single_gpu_tree": bool(same), "nboxes": c5_local["nboxes"],
+            "nlevels": c5_local["nlevels"], "counts_cumul_checksum": total,
+            "expected": {k: golden_c5[k] for k in ("nboxes", "nlevels", "counts_cumul_checksum")},
+            "source": f"tests/golden/c5_global_counts.json, worlds[{world}]: the tree one GPU builds from "
+                      f"the {world} chunk(s) default_rng(15..{14 + world}), checked there with the "
+                      "reference's tree assertions",
+        }
+        if not same and rank == 0:
+            print("bench.py: c5_check FAILED: " + json.dumps(xinfo["c5_check"]), file=sys.stderr)
     if distributed:
         xinfo.update(exchange_report(torch, dist, device, world, elapsed, n_local, last_exchange,
                                      backend, shared_gpu))

@@ -2,7 +2,7 @@
 """BASELINE configs[4] at FULL size on ONE GPU: the tree of the first W chunks of the c5
 recipe (chunk g = 3 x default_rng(15 + g).random(1.25e8), W in {1, 2, 4, 8}; W = 8 is the
 10^9-point tree) -- tree only, its List 2 exceeds the reference's int32 CSR --, checked on
-the device with the reference's tree assertions (tools/device_invariants.py), and recorded
+the device with the reference's tree assertions (tests/device_invariants.py), and recorded
 as tests/golden/c5_global_counts.json: box and level counts and a checksum of
 box_source_counts_cumul that is linear in the counts (boxtree_amd/distributed/checksum.py),
 so that `bench.py --gpus W --workload c5` -- W ranks, each holding one chunk -- can compare
@@ -24,7 +24,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden", "c5_global_counts.json")
 
@@ -93,7 +93,7 @@ def main():
             inv = check_tree_on_device(torch, tree, part, args.mpb)
             entry["invariants"] = {**inv, "seconds": time.perf_counter() - t2,
                                    "what": "reference test_tree.py:88-220 restated on the device "
-                                           "(tools/device_invariants.py)"}
+                                           "(tests/device_invariants.py)"}
         print(f"[c5_full] world {world}: {json.dumps(entry)}", file=sys.stderr, flush=True)
         report[str(world)] = entry
         del tree, cumul, gids
