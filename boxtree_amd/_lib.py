@@ -30,7 +30,7 @@ P3 = vp * BT_MAX_DIMS
 PL = vp * BT_MAX_LEVELS
 
 
-ABI_VERSION = 5      # BT_ABI_VERSION of include/boxtree_hip.h
+ABI_VERSION = 6      # BT_ABI_VERSION of include/boxtree_hip.h
 
 
 class SortStats(ct.Structure):
@@ -253,7 +253,7 @@ EXPORTED_SYMBOLS = [
     "bt_fmm_box_particle_sums", "bt_fmm_csr_sum", "bt_fmm_box_to_particles", "bt_fmm_tree_sweep",
     "bt_translation_classes",
     "bt_filter_targets_user_order", "bt_filter_targets_tree_order", "bt_link_point_sources",
-    "bt_box_morton_paths", "bt_let_build", "bt_mgpu_exchange", "bt_mgpu_plan",
+    "bt_box_morton_paths", "bt_let_build", "bt_mgpu_exchange", "bt_mgpu_exchange_time", "bt_mgpu_plan",
     "bt_mgpu_comm_rccl", "bt_mgpu_local_group_create", "bt_mgpu_local_group_destroy",
     "bt_mgpu_comm_local", "bt_mgpu_comm_destroy", "bt_mgpu_use_rccl_library",
     "bt_mgpu_comm_set_self_loopback", "bt_mgpu_number", "bt_mgpu_let_build",
@@ -314,6 +314,7 @@ def load():
     lib.bt_traversal_build.argtypes = [vp, ct.POINTER(TravParams), ct.POINTER(TravSizes)]
     lib.bt_traversal_export.argtypes = [vp, ct.POINTER(TravArrays)]
     lib.bt_mgpu_exchange.argtypes = [vp, vp, ct.POINTER(MgpuParams), ct.POINTER(MgpuShard)]
+    lib.bt_mgpu_exchange_time.argtypes = [vp, ct.POINTER(ct.c_float)]
     lib.bt_mgpu_comm_rccl.argtypes = [vp, ct.c_int, ct.c_int, ct.POINTER(vp)]
     lib.bt_mgpu_local_group_create.argtypes = [ct.c_int, ct.POINTER(vp)]
     lib.bt_mgpu_local_group_destroy.argtypes = [vp]

@@ -227,4 +227,29 @@ void *zero_alloc(bt_context *ctx, size_t bytes);
 int zero_begin(bt_context *ctx);
 int finish_call(bt_context *ctx);    // end of an API call: check_status, or (stream-ordered
                                      // contexts) queue the status read and return
+// Copy device memory into PINNED host memory as a queued command (a kernel that stores into
+// the pinned block where the platform allows it, hipMemcpyAsync otherwise).
+int copy_to_pinned(bt_context *ctx, void *pinned_dst, const void *dev_src, size_t bytes);
+
+// ---- pieces of the multi-GPU exchange that live beside the single-GPU kernels they share
+// code with (bt_tree.hip, bt_shard.hip); callers: bt_mgpu.hip
+int bbox_minmax_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords, int64_t n,
+                       double *d_mm);
+// bt_morton_cells with the root box read from device memory ({min[3], max[3], extent, 0} in the
+// coordinate type, the layout of the tree build's own root box); no wait
+int morton_cells_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords, int64_t n,
+                        const void *d_rootbox, int level, uint32_t *cells_out, int32_t *hist_inout);
+// bt_box_morton_paths / bt_let_build without their waits (errors raise the device status)
+int box_paths_device(bt_context *ctx, int dims, int coord_kind, int64_t nboxes, int64_t aligned_nboxes,
+                     const void *box_centers, const uint8_t *box_levels, const double *bbox_min,
+                     double root_extent, uint64_t *paths);
+int let_link_device(bt_context *ctx, int dims, int coord_kind, int nlevels, const int32_t *level_start_box_nrs,
+                    const uint64_t *paths, int64_t aligned_nboxes, const double *bbox_min,
+                    const double *bbox_max, double root_extent, int32_t *box_parent_ids,
+                    int32_t *box_child_ids, void *box_centers);
+// bt_partition_pack whose own-segment offsets are read from device memory when the kernel runs
+// (d_self_offsets = {send offset, receive offset} in records); no wait
+int partition_pack_device(bt_context *ctx, int dims, int elem_size, const void *const *in,
+                          const uint32_t *cells, int64_t n, const int32_t *owner_of_cell, int nranks,
+                          int self_rank, const int64_t *d_self_offsets, void *send, void *recv);
 }  // namespace bt

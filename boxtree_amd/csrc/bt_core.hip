@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void copy_bytes_kernel(const unsigned char *sr
         dst[i] = src[i];
 }
 
-static int copy_to_pinned(bt_context *ctx, void *pinned_dst, const void *dev_src, size_t bytes)
+int copy_to_pinned(bt_context *ctx, void *pinned_dst, const void *dev_src, size_t bytes)
 {
     if (!ctx->pinned_stores_ok) {
         BT_HIP_CHECK(hipMemcpyAsync(pinned_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -203,6 +203,11 @@ static int status_verdict(const DeviceStatus *st)
     if (st->lookback_timeout) {
         set_error("radix sort: decoupled look-back spin bound exceeded");
         return BT_ERR_INTERNAL;
+    }
+    if (st->internal == 70) {
+        set_error("bt_let_build: a box has no parent among the boxes of the level above, or a "
+                  "level is not in ascending Morton order");
+        return BT_ERR_INVALID;
     }
     if (st->internal) {
         set_error("device-side consistency check failed (code %d)", st->internal);

@@ -281,6 +281,47 @@ __global__ __launch_bounds__(256) void widen_hist_kernel(int64_t n, const int32_
     if (i < n) out[i] = in[i];
 }
 
+// mm = {min[D], -max[D], -1 if the rank has separate targets}: the identity of MIN first
+__global__ void mm_init_kernel(double *mm, int D, double flag)
+{
+    for (int i = 0; i < 2 * D; ++i) mm[i] = 1.7976931348623158e+308;
+    mm[2 * D] = flag;
+}
+
+// Root box from the all-reduced (min, -max), tree_build.py:462-476 in the coordinate type;
+// out = {min[3], max[3], extent, 0}, the layout the key kernel reads (bt_tree.hip).
+template <class T>
+__global__ void root_box_from_mm_kernel(const double *mm, int D, T *out)
+{
+    T ext = 0;
+    for (int ax = 0; ax < D; ++ax) {
+        const T w = (T) (-mm[D + ax]) - (T) mm[ax];
+        ext = w > ext ? w : ext;
+    }
+    const T re = ext * (T) (1 + 1e-4);
+    for (int ax = 0; ax < 3; ++ax) {
+        out[ax] = ax < D ? (T) mm[ax] : (T) 0;
+        out[3 + ax] = ax < D ? (T) ((T) mm[ax] + re) : (T) 0;
+    }
+    out[6] = re;
+    out[7] = (T) 0;
+}
+
+// where a rank's own segment goes, per particle set: {send offset, receive offset} in records;
+// the receive offset is what the ranks below send to this one (column of the gathered matrix)
+__global__ void self_offsets_kernel(const int64_t *matrix, int nranks, int rank, int64_t s_off0,
+                                    int64_t s_off1, int loop_self, int64_t *out)
+{
+    const int64_t row = 2 * (int64_t) nranks;
+    for (int s = 0; s < 2; ++s) {
+        const int64_t so = s == 0 ? s_off0 : s_off1;
+        int64_t r = 0;
+        for (int q = 0; q < rank; ++q) r += matrix[q * row + (int64_t) s * nranks + rank];
+        out[2 * s] = so;
+        out[2 * s + 1] = loop_self ? so : r;
+    }
+}
+
 // The top of the GLOBAL tree (levels 0..k), a pure function of the all-reduced level-k cell
 // histogram (kind "adaptive", point particles, unit weights: a box splits iff it holds more
 // than max_particles_in_box particles, tree_build_kernels.py:577-591; empty boxes pruned).
@@ -297,6 +338,7 @@ struct TopPlan {
     bool sep_targets = false;                     // the build has separate targets
     std::vector<std::vector<int64_t>> src_counts; // [k+1][C^lev]: the sources among `counts`
     std::vector<int32_t> owner;                   // [C^k]
+    std::vector<int64_t> unit_start;              // [C^k] scratch of compute_plan
     std::vector<int64_t> prefix;                  // [C^k + 1]
     double bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0}, root_extent = 0;
 };
@@ -306,72 +348,141 @@ void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, To
     const int C = 1 << D;
     const int64_t ncells = (int64_t) 1 << (D * k);
     pl.D = D; pl.k = k; pl.mpb = mpb; pl.nranks = nranks;
-    pl.counts.assign((size_t) k + 1, {});
+    pl.counts.resize((size_t) k + 1);
     pl.counts[k].assign(hist, hist + ncells);
     for (int lev = k - 1; lev >= 0; --lev) {
         const int64_t n = (int64_t) 1 << (D * lev);
-        pl.counts[lev].assign((size_t) n, 0);
-        for (int64_t i = 0; i < n; ++i)
-            for (int m = 0; m < C; ++m) pl.counts[lev][i] += pl.counts[lev + 1][i * C + m];
+        pl.counts[lev].resize((size_t) n);
+        const int64_t *below = pl.counts[lev + 1].data();
+        int64_t *here = pl.counts[lev].data();
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t sum = 0;
+            for (int m = 0; m < C; ++m) sum += below[i * C + m];
+            here[i] = sum;
+        }
     }
-    std::vector<int64_t> unit_start((size_t) ncells);
+    // unit[c]: the first cell of the top-tree leaf a cell lies in (cells under a leaf above
+    // level k travel together), found top-down: -1 while the boxes above still split
+    std::vector<int64_t> &unit_start = pl.unit_start;
+    unit_start.resize((size_t) ncells);
     pl.valid = mpb > 0;
     if (mpb > 0) {
-        pl.exists.assign((size_t) k + 1, {});
-        pl.split.assign((size_t) k + 1, {});
-        pl.index.assign((size_t) k + 1, {});
+        pl.exists.resize((size_t) k + 1);
+        pl.split.resize((size_t) k + 1);
+        pl.index.resize((size_t) k + 1);
         pl.nboxes.assign((size_t) k + 1, 0);
         pl.exists[0].assign(1, 1);
+        std::vector<int64_t> unit_here(1, -1), unit_next;
         for (int lev = 0; lev <= k; ++lev) {
             const int64_t n = (int64_t) 1 << (D * lev);
-            pl.split[lev].assign((size_t) n, 0);
-            pl.index[lev].assign((size_t) n, 0);
+            pl.split[lev].resize((size_t) n);
+            pl.index[lev].resize((size_t) n);
+            const char *ex = pl.exists[lev].data();
+            const int64_t *cnt = pl.counts[lev].data();
+            char *sp = pl.split[lev].data();
+            int32_t *ix = pl.index[lev].data();
             int32_t run = 0;
             for (int64_t i = 0; i < n; ++i) {
-                pl.split[lev][i] = pl.exists[lev][i] && pl.counts[lev][i] > mpb;
-                run += pl.exists[lev][i] ? 1 : 0;
-                pl.index[lev][i] = run - 1;
+                sp[i] = ex[i] && cnt[i] > mpb;
+                run += ex[i] ? 1 : 0;
+                ix[i] = run - 1;
             }
             pl.nboxes[lev] = run;
             if (lev < k) {
-                pl.exists[lev + 1].assign((size_t) n * C, 0);
-                for (int64_t i = 0; i < n * C; ++i)
-                    pl.exists[lev + 1][i] = pl.split[lev][i / C] && pl.counts[lev + 1][i] > 0;
+                pl.exists[lev + 1].resize((size_t) n * C);
+                char *exn = pl.exists[lev + 1].data();
+                const int64_t *cntn = pl.counts[lev + 1].data();
+                unit_next.resize((size_t) n * C);
+                const int sh = D * (k - lev);
+                for (int64_t i = 0; i < n; ++i) {
+                    // a box above the ownership level that does not split is a leaf (or absent):
+                    // everything below it is one unit
+                    const int64_t u = unit_here[(size_t) i] >= 0 ? unit_here[(size_t) i] : (sp[i] ? -1 : (i << sh));
+                    for (int m = 0; m < C; ++m) {
+                        exn[i * C + m] = sp[i] && cntn[i * C + m] > 0;
+                        unit_next[(size_t) (i * C + m)] = u;
+                    }
+                }
+                unit_here.swap(unit_next);
             }
         }
-        // frontier: the first cell of the top-tree leaf a cell lies in
-        for (int64_t c = 0; c < ncells; ++c) {
-            int leaf_level = k;
-            for (int lev = k - 1; lev >= 0; --lev)
-                if (!pl.split[lev][c >> (D * (k - lev))]) leaf_level = lev;
-            const int sh = D * (k - leaf_level);
-            unit_start[c] = (c >> sh) << sh;
-        }
+        for (int64_t c = 0; c < ncells; ++c) unit_start[(size_t) c] = unit_here[(size_t) c] >= 0 ? unit_here[(size_t) c] : c;
     } else {
-        for (int64_t c = 0; c < ncells; ++c) unit_start[c] = c;
+        for (int64_t c = 0; c < ncells; ++c) unit_start[(size_t) c] = c;
     }
     // contiguous Morton ranges balanced by particle count: a cell goes to the rank whose
-    // ideal range contains its first particle
-    const int64_t total = pl.counts[0][0];
-    pl.prefix.assign((size_t) ncells + 1, 0);
-    for (int64_t c = 0; c < ncells; ++c) pl.prefix[c + 1] = pl.prefix[c] + hist[c];
-    pl.owner.assign((size_t) ncells, 0);
+    // ideal range contains the first particle of its unit, floor(prefix * nranks / total).
+    // Units ascend with the cells, so the rank only ever grows: no division per cell.
+    const int64_t total = std::max<int64_t>(pl.counts[0][0], 1);
+    pl.prefix.resize((size_t) ncells + 1);
+    pl.prefix[0] = 0;
+    for (int64_t c = 0; c < ncells; ++c) pl.prefix[(size_t) c + 1] = pl.prefix[(size_t) c] + hist[c];
+    pl.owner.resize((size_t) ncells);
+    int32_t r = 0;
     for (int64_t c = 0; c < ncells; ++c) {
-        const int64_t u = unit_start[c];
-        const int64_t o = (int64_t) (((__int128) pl.prefix[u] * nranks) / std::max<int64_t>(total, 1));
-        pl.owner[c] = (int32_t) std::min<int64_t>(o, nranks - 1);
+        if (unit_start[(size_t) c] == c) {
+            const __int128 lhs = (__int128) pl.prefix[(size_t) c] * nranks;
+            while (r < nranks - 1 && (__int128) (r + 1) * total <= lhs) ++r;
+        }
+        pl.owner[(size_t) c] = r;
     }
 }
 
 }  // namespace
 
+// Pinned host memory for what the device reads from, or writes to, the host during the calls of
+// one sharded build: bump-allocated, handed back wholesale when the next exchange begins (or
+// when it has grown large), after the stream has passed the last call that used it.
+struct PinArena {
+    struct Block { char *p; size_t cap; };
+    std::vector<Block> blocks;
+    size_t used = 0, total = 0;
+    void *get(size_t bytes)
+    {
+        bytes = (bytes + 255) & ~(size_t) 255;
+        if (blocks.empty() || blocks.back().cap - used < bytes) {
+            const size_t cap = std::max<size_t>(bytes, (size_t) 4 << 20);
+            char *p = nullptr;
+            if (hipHostMalloc((void **) &p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
+            blocks.push_back({p, cap});
+            used = 0;
+        }
+        void *r = blocks.back().p + used;
+        used += bytes; total += bytes;
+        return r;
+    }
+    void reset()
+    {
+        // keep the newest (largest-so-far) block
+        while (blocks.size() > 1) { (void) hipHostFree(blocks.front().p); blocks.erase(blocks.begin()); }
+        used = 0; total = 0;
+    }
+    ~PinArena() { for (auto &b : blocks) (void) hipHostFree(b.p); }
+};
+
 struct MgpuState {
+    PinArena arena;
     Buf<unsigned char> points;       // received particles, interleaved [n_owned][dims]
     Buf<unsigned char> tpoints;      // ... separate targets
     Buf<int64_t> cell_prefix;        // [C^top_level + 1]
     TopPlan plan;                    // of the last exchange on this context
+    std::vector<int64_t> ghist;      // combined global cell histogram of that exchange
     hipEvent_t ev[2] = {nullptr, nullptr};   // around the payload all-to-all-v
-    ~MgpuState() { for (auto &e : ev) if (e) (void) hipEventDestroy(e); }
+    hipEvent_t ev_counts = nullptr;          // the counts matrix has reached the host
+    hipEvent_t ev_done = nullptr;            // the last exchange's use of the pinned block is over
+    bool done_pending = false, a2a_pending = false;
+    float a2a_ms = 0.f;
+    // pinned host block of the exchange: what the host reads (root box, histograms, counts
+    // matrix) and what the device reads from the host (owner table, send counts, cell prefix)
+    char *pin = nullptr;
+    size_t pin_cap = 0;
+    ~MgpuState()
+    {
+        for (auto &e : ev) if (e) (void) hipEventDestroy(e);
+        if (ev_counts) (void) hipEventDestroy(ev_counts);
+        if (ev_done) (void) hipEventDestroy(ev_done);
+        if (pin) (void) hipHostFree(pin);
+    }
     // local essential tree between bt_mgpu_let_build and bt_mgpu_let_export
     Buf<uint64_t> let_paths;         // [B] level-major, Morton order within a level
     Buf<int32_t> let_meta, let_gid;  // level | flags << 8; global box number
@@ -394,6 +505,30 @@ MgpuState *mgpu_state(bt_context *ctx)
     if (!ctx->mgpu) ctx->mgpu = new MgpuState();
     return ctx->mgpu;
 }
+
+// calls that read or write the pinned arena end with arena_mark (the stream has passed the call
+// once ev_done has); the first call of a build, and any call that finds the arena large, waits
+// for the mark and takes the arena back
+int arena_mark(bt_context *ctx, MgpuState *ms)
+{
+    if (!ms->ev_done) BT_HIP_CHECK(hipEventCreateWithFlags(&ms->ev_done, hipEventDisableTiming));
+    BT_HIP_CHECK(hipEventRecord(ms->ev_done, ctx->stream));
+    ms->done_pending = true;
+    return BT_OK;
+}
+
+int arena_reclaim(MgpuState *ms, bool always)
+{
+    if (!always && ms->arena.total < ((size_t) 64 << 20)) return BT_OK;
+    if (ms->done_pending) { BT_HIP_CHECK(hipEventSynchronize(ms->ev_done)); ms->done_pending = false; }
+    ms->arena.reset();
+    return BT_OK;
+}
+
+#define BT_ARENA(ptr, T, ms, count)                                                              \
+    T *ptr = (T *) (ms)->arena.get(sizeof(T) * (size_t) std::max<int64_t>((int64_t) (count), 1));   \
+    if (!ptr) { set_error("pinned host memory: allocation of %lld bytes failed",                   \
+                          (long long) (sizeof(T) * (size_t) (count))); return BT_ERR_ALLOC; }
 
 constexpr int TOPMAX = 16;            // top levels a numbering kernel looks up by path
 
@@ -476,69 +611,57 @@ __global__ __launch_bounds__(256) void count_diff_kernel(int64_t n, const uint64
         atomicAdd((unsigned long long *) bad, (unsigned long long) __popcll(m));
 }
 
-// deep boxes of the LET before the sort: this rank's own (contiguous in the local tree), then
-// the halo records; key = level << pathbits | path
-__global__ __launch_bounds__(256) void let_deep_kernel(int64_t n_mine, int64_t n_halo, int64_t b0,
-        const uint64_t *paths, const uint8_t *levels, const uint8_t *flags, const int32_t *gids,
-        const uint64_t *halo_rec, int pathbits, uint64_t *key, uint64_t *d_path, int32_t *d_meta,
-        int32_t *d_gid)
-{
-    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_mine + n_halo) return;
-    uint64_t path;
-    int32_t meta, gid;
-    if (i < n_mine) {
-        const int64_t b = b0 + i;
-        path = paths[b];
-        meta = (int32_t) levels[b] | ((int32_t) flags[b] << 8);
-        gid = gids[b];
-    } else {
-        const int64_t j = i - n_mine;
-        path = halo_rec[2 * j];
-        const uint64_t w = halo_rec[2 * j + 1];
-        meta = (int32_t) (w & 0xffffffffu);
-        gid = (int32_t) (w >> 32);
-    }
-    d_path[i] = path; d_meta[i] = meta; d_gid[i] = gid;
-    key[i] = ((uint64_t) (meta & 0xff) << pathbits) | path;
-}
-
-// sorted deep boxes into the LET arrays behind the top boxes; per level: count, and the first
-// and last position of this rank's own boxes (they are one contiguous run: its cells are one
-// Morton range)
-// (boundaries of the sorted order, one writer each: atomics on a dozen addresses from
-// millions of threads serialise in L2 -- 60 ms at 5*10^6 boxes)
-struct LetLevelInfo {
-    int32_t level_first[BT_MAX_LEVELS + 1];   // first sorted position of a level, or -1
-    int32_t mine_runs[BT_MAX_LEVELS + 1];     // runs of this rank's boxes in the level (must be <= 1)
-    int32_t mine_first[BT_MAX_LEVELS + 1];
-    int32_t mine_last[BT_MAX_LEVELS + 1];
+// Where the deep boxes (levels > k) of one sender go in the LET.  Ranks own ascending Morton
+// ranges of cells, a rank's boxes of a level are in Morton order and a peer sends its halo boxes
+// in that order: the boxes of a level are, in Morton order, the blocks of the ranks in rank order
+// -- positions follow from the per-(sender, level) counts, no sort.
+struct LetBlocks {
+    int32_t src_start[BT_MAX_LEVELS + 1];   // index of the sender's first box of a level in its sequence
+    int32_t dst_start[BT_MAX_LEVELS + 1];   // LET position of that box
 };
 
-__global__ __launch_bounds__(256) void let_place_kernel(int64_t nd, int64_t n_mine, int64_t ntop,
-        const uint32_t *order, const uint64_t *d_path, const int32_t *d_meta, const int32_t *d_gid,
-        uint64_t *all_paths, int32_t *all_meta, int32_t *all_gid, int8_t *mask, LetLevelInfo *info)
+// this rank's own deep boxes: the tail [b0, nb) of its level-major local tree
+__global__ __launch_bounds__(256) void let_scatter_own_kernel(int64_t n_mine, int64_t b0, LetBlocks blk,
+        const uint64_t *paths, const uint8_t *levels, const uint8_t *flags, const int32_t *gids,
+        uint64_t *all_paths, int32_t *all_meta, int32_t *all_gid, int8_t *mask)
 {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
-    if (i >= nd) return;
-    const uint32_t o = order[i];
-    const int32_t meta = d_meta[o];
-    const bool mine = (int64_t) o < n_mine;
-    all_paths[ntop + i] = d_path[o];
-    all_meta[ntop + i] = meta;
-    all_gid[ntop + i] = d_gid[o];
-    mask[ntop + i] = mine ? 1 : 0;
+    if (i >= n_mine) return;
+    const int64_t b = b0 + i;
+    const int lev = levels[b];
+    const int64_t dst = (int64_t) blk.dst_start[lev] + (b - blk.src_start[lev]);
+    all_paths[dst] = paths[b];
+    all_meta[dst] = (int32_t) lev | ((int32_t) flags[b] << 8);
+    all_gid[dst] = gids[b];
+    mask[dst] = 1;
+}
+
+// the halo records of one peer: (path, level | flags << 8 | global id << 32), level-major
+__global__ __launch_bounds__(256) void let_scatter_halo_kernel(int64_t n, LetBlocks blk, const uint64_t *rec,
+        uint64_t *all_paths, int32_t *all_meta, int32_t *all_gid, int8_t *mask, DeviceStatus *status)
+{
+    const int64_t j = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const uint64_t w = rec[2 * j + 1];
+    const int32_t meta = (int32_t) (w & 0xffffffffu);
     const int lev = meta & 0xff;
-    int prev_lev = -1, next_lev = -1;
-    bool prev_mine = false, next_mine = false;
-    if (i > 0) { const uint32_t po = order[i - 1]; prev_lev = d_meta[po] & 0xff; prev_mine = (int64_t) po < n_mine; }
-    if (i + 1 < nd) { const uint32_t no = order[i + 1]; next_lev = d_meta[no] & 0xff; next_mine = (int64_t) no < n_mine; }
-    if (prev_lev != lev) info->level_first[lev] = (int32_t) i;
-    if (mine && !(prev_mine && prev_lev == lev)) {
-        info->mine_first[lev] = (int32_t) i;
-        atomicAdd(&info->mine_runs[lev], 1);
-    }
-    if (mine && !(next_mine && next_lev == lev)) info->mine_last[lev] = (int32_t) i;
+    // (a record outside the block its level was announced with: the counts and the records disagree)
+    if (lev > BT_MAX_LEVELS || j < blk.src_start[lev]) { atomicExch(&status->internal, 71); return; }
+    const int64_t dst = (int64_t) blk.dst_start[lev] + (j - blk.src_start[lev]);
+    all_paths[dst] = rec[2 * j];
+    all_meta[dst] = meta;
+    all_gid[dst] = (int32_t) (w >> 32);
+    mask[dst] = 0;
+}
+
+// row[q][l] = number of my level-l boxes peer q needs: differences of the scanned predicate at
+// the level boundaries of the local tree
+struct LocalLevels { int32_t nlevels; int32_t start[BT_MAX_LEVELS + 2]; };
+__global__ void let_level_counts_kernel(const int32_t *pos, int64_t b0, int k, LocalLevels ls, int32_t *row_q)
+{
+    const int l = k + 1 + (int) threadIdx.x;
+    if (l >= ls.nlevels) return;
+    row_q[l] = pos[ls.start[l + 1] - b0] - pos[ls.start[l] - b0];
 }
 
 __global__ __launch_bounds__(256) void let_split_meta_kernel(int64_t n, const int32_t *meta,
@@ -712,46 +835,54 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     const void *const *cset[2] = {p->coords, p->targets};
     hipStream_t stream = ctx->stream;
 
-    // ---- 1. global bounding box -> root box --------------------------------------------
-    double h_mm[7];
-    for (int ax = 0; ax < D; ++ax) { h_mm[ax] = 1.7976931348623158e+308; h_mm[D + ax] = 1.7976931348623158e+308; }
-    for (int s = 0; s < 2; ++s) {
-        if (nset[s] == 0) continue;
-        double lmin[3], lmax[3];
-        BT_CHECK(bt_bbox(ctx, D, p->coord_kind, cset[s], nullptr, nset[s], lmin, lmax));
-        for (int ax = 0; ax < D; ++ax) { h_mm[ax] = std::min(h_mm[ax], lmin[ax]); h_mm[D + ax] = std::min(h_mm[D + ax], -lmax[ax]); }
-    }
-    h_mm[2 * D] = p->ntargets > 0 ? -1.0 : 0.0;      // MIN: -1 if some rank has targets
-    Buf<double> mm;
-    BT_CHECK(mm.alloc(ctx->pool, 2 * D + 1));
-    BT_HIP_CHECK(hipMemcpyAsync(mm.get(), h_mm, sizeof(double) * (2 * D + 1), hipMemcpyHostToDevice, stream));
-    BT_CHECK(comm_all_reduce(comm, stream, mm.get(), 2 * D + 1, RED_MIN_F64));
-    BT_HIP_CHECK(hipMemcpyAsync(h_mm, mm.get(), sizeof(double) * (2 * D + 1), hipMemcpyDeviceToHost, stream));
-    BT_HIP_CHECK(hipStreamSynchronize(stream));
-    const bool sep = h_mm[2 * D] < 0;
-    const int nsets = sep ? 2 : 1;
-    if (h_mm[0] > -h_mm[D]) {
-        set_error("bt_mgpu_exchange: no rank has any particle");
-        return BT_ERR_INVALID;
-    }
-    double bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0}, root_extent = 0;
-    if (f64) {
-        // tree_build.py:462-476 in the coordinate type
-        double ext = 0;
-        for (int ax = 0; ax < D; ++ax) ext = std::max(ext, (-h_mm[D + ax]) - h_mm[ax]);
-        root_extent = ext * (1 + 1e-4);
-        for (int ax = 0; ax < D; ++ax) { bmin[ax] = h_mm[ax]; bmax[ax] = bmin[ax] + root_extent; }
-    } else {
-        float ext = 0;
-        for (int ax = 0; ax < D; ++ax) ext = std::max(ext, (float) (-h_mm[D + ax]) - (float) h_mm[ax]);
-        const float re = ext * (float) (1 + 1e-4);
-        root_extent = re;
-        for (int ax = 0; ax < D; ++ax) { bmin[ax] = (float) h_mm[ax]; bmax[ax] = (float) ((float) h_mm[ax] + re); }
-    }
-
-    // ---- 2. cell histograms (sources, targets), all-reduced ------------------------------------
+    MgpuState *ms = mgpu_state(ctx);
     const int k = p->top_level > 0 ? p->top_level : (D == 3 ? 5 : D == 2 ? 7 : 12);
     const int64_t ncells = (int64_t) 1 << (D * k);
+    const int64_t row = 2 * (int64_t) nranks;
+    if (!ms->ev[0]) {
+        BT_HIP_CHECK(hipEventCreate(&ms->ev[0]));
+        BT_HIP_CHECK(hipEventCreate(&ms->ev[1]));
+        BT_HIP_CHECK(hipEventCreateWithFlags(&ms->ev_counts, hipEventDisableTiming));
+        BT_HIP_CHECK(hipEventCreateWithFlags(&ms->ev_done, hipEventDisableTiming));
+    }
+    // the previous build on this context may still be reading the pinned blocks
+    BT_CHECK(arena_reclaim(ms, true));
+    // pinned block: [box: 16 doubles][local hist: 2 ncells i32][global hist: 2 ncells i64]
+    // [owner: ncells i32][send counts: row i64][matrix: row * nranks i64][prefix: ncells + 1 i64]
+    const size_t o_box = 0, o_local = 128, o_ghist = o_local + (size_t) ncells * 8,
+        o_owner = o_ghist + (size_t) ncells * 16, o_send = o_owner + (size_t) ncells * 4,
+        o_matrix = o_send + (size_t) row * 8, o_prefix = o_matrix + (size_t) row * nranks * 8,
+        pin_need = o_prefix + (size_t) (ncells + 1) * 8;
+    if (ms->pin_cap < pin_need) {
+        if (ms->pin) { BT_HIP_CHECK(hipStreamSynchronize(stream)); (void) hipHostFree(ms->pin); ms->pin = nullptr; ms->pin_cap = 0; }
+        BT_HIP_CHECK(hipHostMalloc((void **) &ms->pin, pin_need, hipHostMallocDefault));
+        ms->pin_cap = pin_need;
+    }
+    double *h_box = (double *) (ms->pin + o_box);             // mm[2 D + 1], then the root box (T[8]) at +8 doubles
+    int32_t *h_local = (int32_t *) (ms->pin + o_local);
+    int64_t *h_ghist2 = (int64_t *) (ms->pin + o_ghist);
+    int32_t *h_owner = (int32_t *) (ms->pin + o_owner);
+    int64_t *h_send = (int64_t *) (ms->pin + o_send);
+    int64_t *h_matrix = (int64_t *) (ms->pin + o_matrix);
+    int64_t *h_prefix = (int64_t *) (ms->pin + o_prefix);
+
+    // ---- 1. global bounding box -> root box, all on the device -----------------------------
+    Buf<double> mm;
+    Buf<unsigned char> rootbox_d;
+    BT_CHECK(mm.alloc(ctx->pool, 2 * D + 1));
+    BT_CHECK(rootbox_d.alloc(ctx->pool, 64));
+    mm_init_kernel<<<1, 1, 0, stream>>>(mm.get(), D, p->ntargets > 0 ? -1.0 : 0.0);   // MIN: -1 if some rank has targets
+    for (int s = 0; s < 2; ++s)
+        BT_CHECK(bt::bbox_minmax_device(ctx, D, p->coord_kind, cset[s], nset[s], mm.get()));
+    BT_CHECK(comm_all_reduce(comm, stream, mm.get(), 2 * D + 1, RED_MIN_F64));
+    if (f64) root_box_from_mm_kernel<double><<<1, 1, 0, stream>>>(mm.get(), D, (double *) rootbox_d.get());
+    else root_box_from_mm_kernel<float><<<1, 1, 0, stream>>>(mm.get(), D, (float *) rootbox_d.get());
+    BT_HIP_CHECK(hipGetLastError());
+    BT_CHECK(bt::copy_to_pinned(ctx, h_box, mm.get(), sizeof(double) * (2 * D + 1)));
+    BT_CHECK(bt::copy_to_pinned(ctx, h_box + 8, rootbox_d.get(), 8 * (size_t) es));
+
+    // ---- 2. cell histograms (sources, targets), all-reduced -------------------------------
+    // (always both: whether the job has separate targets is only known with the bounding box)
     Buf<uint32_t> cells[2];
     Buf<int32_t> hist32, owner_d;
     Buf<int64_t> hist64;
@@ -759,117 +890,147 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     BT_CHECK(hist64.alloc(ctx->pool, 2 * ncells));
     BT_CHECK(owner_d.alloc(ctx->pool, ncells));
     BT_HIP_CHECK(hipMemsetAsync(hist32.get(), 0, (size_t) ncells * 8, stream));
-    for (int s = 0; s < nsets; ++s) {
+    for (int s = 0; s < 2; ++s) {
         if (nset[s] == 0) continue;
         BT_CHECK(cells[s].alloc(ctx->pool, nset[s]));
-        BT_CHECK(bt_morton_cells(ctx, D, p->coord_kind, cset[s], nset[s], bmin, bmax, k, cells[s].get(),
-                                 hist32.get() + s * ncells));
+        BT_CHECK(bt::morton_cells_device(ctx, D, p->coord_kind, cset[s], nset[s], rootbox_d.get(), k,
+                                         cells[s].get(), hist32.get() + s * ncells));
     }
     widen_hist_kernel<<<(unsigned) div_up(2 * ncells, 256), 256, 0, stream>>>(2 * ncells, hist32.get(), hist64.get());
     BT_HIP_CHECK(hipGetLastError());
-    std::vector<int32_t> h_local((size_t) 2 * ncells);
-    BT_HIP_CHECK(hipMemcpyAsync(h_local.data(), hist32.get(), (size_t) ncells * 8, hipMemcpyDeviceToHost, stream));
-    BT_CHECK(comm_all_reduce(comm, stream, hist64.get(), (size_t) (nsets * ncells), RED_SUM_I64));
-    std::vector<int64_t> ghist2((size_t) 2 * ncells, 0), ghist((size_t) ncells);
-    BT_HIP_CHECK(hipMemcpyAsync(ghist2.data(), hist64.get(), (size_t) (nsets * ncells) * 8, hipMemcpyDeviceToHost, stream));
-    BT_HIP_CHECK(hipStreamSynchronize(stream));
-    for (int64_t c = 0; c < ncells; ++c) ghist[c] = ghist2[c] + ghist2[ncells + c];
+    BT_CHECK(bt::copy_to_pinned(ctx, h_local, hist32.get(), (size_t) ncells * 8));
+    BT_CHECK(comm_all_reduce(comm, stream, hist64.get(), (size_t) (2 * ncells), RED_SUM_I64));
+    BT_CHECK(bt::copy_to_pinned(ctx, h_ghist2, hist64.get(), (size_t) ncells * 16));
+    BT_CHECK(bt::sync_stream(ctx));                       // the one wait the GPU idles through
+
+    const bool sep = h_box[2 * D] < 0;
+    const int nsets = sep ? 2 : 1;
+    if (h_box[0] > -h_box[D]) {
+        set_error("bt_mgpu_exchange: no rank has any particle");
+        return BT_ERR_INVALID;
+    }
+    double bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0}, root_extent = 0;
+    for (int ax = 0; ax < D; ++ax) {
+        bmin[ax] = f64 ? h_box[8 + ax] : (double) ((const float *) (h_box + 8))[ax];
+        bmax[ax] = f64 ? h_box[8 + 3 + ax] : (double) ((const float *) (h_box + 8))[3 + ax];
+    }
+    root_extent = f64 ? h_box[8 + 6] : (double) ((const float *) (h_box + 8))[6];
 
     // ---- 3. plan (host, identical on all ranks), counts --------------------------------------
-    MgpuState *ms = mgpu_state(ctx);
+    std::vector<int64_t> &ghist = ms->ghist;
+    ghist.resize((size_t) ncells);
+    for (int64_t c = 0; c < ncells; ++c) ghist[(size_t) c] = h_ghist2[c] + h_ghist2[ncells + c];
     TopPlan &pl = ms->plan;
     compute_plan(D, k, p->max_particles_in_box, nranks, ghist.data(), pl);
     // which top boxes hold sources / targets (flags of the shared top levels)
     pl.sep_targets = sep;
-    pl.src_counts.assign((size_t) k + 1, {});
-    pl.src_counts[k].assign(ghist2.begin(), ghist2.begin() + ncells);
+    pl.src_counts.resize((size_t) k + 1);
+    pl.src_counts[k].assign(h_ghist2, h_ghist2 + ncells);
     for (int lev = k - 1; lev >= 0; --lev) {
         const int64_t n = (int64_t) 1 << (D * lev);
-        pl.src_counts[lev].assign((size_t) n, 0);
-        for (int64_t i = 0; i < n; ++i)
-            for (int m = 0; m < (1 << D); ++m) pl.src_counts[lev][i] += pl.src_counts[lev + 1][i * (1 << D) + m];
+        pl.src_counts[lev].resize((size_t) n);
+        const int64_t *below = pl.src_counts[lev + 1].data();
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t sum = 0;
+            for (int m = 0; m < (1 << D); ++m) sum += below[i * (1 << D) + m];
+            pl.src_counts[lev][(size_t) i] = sum;
+        }
     }
     for (int ax = 0; ax < 3; ++ax) { pl.bbox_min[ax] = bmin[ax]; pl.bbox_max[ax] = bmax[ax]; }
     pl.root_extent = root_extent;
-    BT_HIP_CHECK(hipMemcpyAsync(owner_d.get(), pl.owner.data(), (size_t) ncells * 4, hipMemcpyHostToDevice, stream));
-    std::vector<int64_t> send_counts((size_t) 2 * nranks, 0);       // [set][owner]
+    memcpy(h_owner, pl.owner.data(), (size_t) ncells * 4);
+    BT_HIP_CHECK(hipMemcpyAsync(owner_d.get(), h_owner, (size_t) ncells * 4, hipMemcpyHostToDevice, stream));
+    int64_t send_counts[2 * BT_MGPU_MAX_RANKS], nrecv_of[2] = {0, 0};       // [set][owner]
+    for (int64_t i = 0; i < row; ++i) send_counts[i] = 0;
     for (int s = 0; s < nsets; ++s)
-        for (int64_t c = 0; c < ncells; ++c) send_counts[(size_t) s * nranks + pl.owner[c]] += h_local[(size_t) s * ncells + c];
-    Buf<int64_t> counts_d;
-    const int64_t row = 2 * nranks;
+        for (int64_t c = 0; c < ncells; ++c) {
+            send_counts[(size_t) s * nranks + pl.owner[(size_t) c]] += h_local[(size_t) s * ncells + c];
+            if (pl.owner[(size_t) c] == rank) nrecv_of[s] += h_ghist2[(size_t) s * ncells + c];
+        }
+    memcpy(h_send, send_counts, (size_t) row * 8);
+    Buf<int64_t> counts_d, self_d;
     BT_CHECK(counts_d.alloc(ctx->pool, row * (nranks + 1)));
-    BT_HIP_CHECK(hipMemcpyAsync(counts_d.get(), send_counts.data(), (size_t) row * 8, hipMemcpyHostToDevice, stream));
+    BT_CHECK(self_d.alloc(ctx->pool, 4));
+    BT_HIP_CHECK(hipMemcpyAsync(counts_d.get(), h_send, (size_t) row * 8, hipMemcpyHostToDevice, stream));
     BT_CHECK(comm_all_gather(comm, stream, counts_d.get(), counts_d.get() + row, (size_t) row * 8));
-    std::vector<int64_t> matrix((size_t) row * nranks);      // [sender][set][receiver]
-    BT_HIP_CHECK(hipMemcpyAsync(matrix.data(), counts_d.get() + row, matrix.size() * 8, hipMemcpyDeviceToHost, stream));
-    BT_HIP_CHECK(hipStreamSynchronize(stream));
+    const bool loop_self = comm->kind == 0 && comm->self_loopback;
+    int64_t s_off_self[2] = {0, 0};
+    for (int s = 0; s < 2; ++s)
+        for (int r = 0; r < rank; ++r) s_off_self[s] += send_counts[(size_t) s * nranks + r];
+    self_offsets_kernel<<<1, 1, 0, stream>>>(counts_d.get() + row, nranks, rank, s_off_self[0], s_off_self[1],
+                                             loop_self ? 1 : 0, self_d.get());
+    BT_HIP_CHECK(hipGetLastError());
+    // [sender][set][receiver]: on its way to the host while the partition sweeps run
+    BT_CHECK(bt::copy_to_pinned(ctx, h_matrix, counts_d.get() + row, (size_t) row * nranks * 8));
+    BT_HIP_CHECK(hipEventRecord(ms->ev_counts, stream));
     const int64_t rec = (int64_t) D * es;                       // bytes per particle
 
     // ---- 4. payload: interleaved coordinates, one exchange per particle set -------------------
-    if (!ms->ev[0]) { BT_HIP_CHECK(hipEventCreate(&ms->ev[0])); BT_HIP_CHECK(hipEventCreate(&ms->ev[1])); }
-    BT_HIP_CHECK(hipEventRecord(ms->ev[0], stream));
-    int32_t rounds_total = 0;
-    int64_t bytes_sent = 0;
+    // One sweep over the coordinates per set: stable partition by owner into the send buffer, the
+    // segment this rank keeps straight into the receive buffer (bt_shard.hip) -- or, with the test
+    // switch bt_mgpu_comm_set_self_loopback, into the send buffer like any other, to make the
+    // trip through ncclSend / ncclRecv.
+    Buf<unsigned char> send[2];
     unsigned char *points_of[2] = {nullptr, nullptr};
-    int64_t nrecv_of[2] = {0, 0};
     for (int s = 0; s < nsets; ++s) {
         const int64_t n = nset[s];
-        std::vector<int64_t> s_off((size_t) nranks + 1, 0), r_off((size_t) nranks + 1, 0);
-        std::vector<int64_t> s_cnt_b((size_t) nranks), r_cnt_b((size_t) nranks), s_off_b((size_t) nranks),
-            r_off_b((size_t) nranks);
-        int64_t biggest = 0;
-        for (int r = 0; r < nranks; ++r) {
-            const int64_t sc = send_counts[(size_t) s * nranks + r];
-            const int64_t rc = matrix[(size_t) r * row + (size_t) s * nranks + rank];
-            s_off[r + 1] = s_off[r] + sc;
-            r_off[r + 1] = r_off[r] + rc;
-            s_cnt_b[r] = sc * rec; r_cnt_b[r] = rc * rec;
-            s_off_b[r] = s_off[r] * rec; r_off_b[r] = r_off[r] * rec;
-            for (int q = 0; q < nranks; ++q)
-                if (q != r) biggest = std::max(biggest, matrix[(size_t) r * row + (size_t) s * nranks + q] * rec);
-        }
-        const int64_t nrecv = r_off[nranks];
-        Buf<unsigned char> send;
-        BT_CHECK(send.alloc(ctx->pool, n * D * es));
-        unsigned char *points = nullptr;
-        const int64_t points_bytes = std::max<int64_t>(nrecv, 1) * D * es;
+        BT_CHECK(send[s].alloc(ctx->pool, n * D * es));
+        const int64_t points_bytes = std::max<int64_t>(nrecv_of[s], 1) * D * es;
         Buf<unsigned char> &own = s == 0 ? ms->points : ms->tpoints;
         if (p->alloc) {
-            points = (unsigned char *) p->alloc(p->alloc_user, points_bytes);
-            if (!points) { set_error("bt_mgpu_exchange: the caller's allocator returned NULL"); return BT_ERR_ALLOC; }
+            points_of[s] = (unsigned char *) p->alloc(p->alloc_user, points_bytes);
+            if (!points_of[s]) { set_error("bt_mgpu_exchange: the caller's allocator returned NULL"); return BT_ERR_ALLOC; }
             own.reset();
         } else {
             BT_CHECK(own.alloc(ctx->pool, points_bytes));
-            points = own.get();
+            points_of[s] = own.get();
         }
-        // one sweep over the coordinates: stable partition by owner into the send buffer, the
-        // segment this rank keeps straight into the receive buffer (bt_shard.hip)
-        const bool loop_self = comm->kind == 0 && comm->self_loopback;
+        BT_CHECK(bt::partition_pack_device(ctx, D, es, cset[s], cells[s].get(), n, owner_d.get(), nranks, rank,
+                                           self_d.get() + 2 * s, send[s].get(),
+                                           loop_self ? send[s].get() : points_of[s]));
+    }
+    BT_HIP_CHECK(hipEventSynchronize(ms->ev_counts));     // (the GPU is busy with the sweeps)
+    int32_t rounds_total = 0;
+    int64_t bytes_sent = 0;
+    BT_HIP_CHECK(hipEventRecord(ms->ev[0], stream));
+    for (int s = 0; s < nsets; ++s) {
+        std::vector<int64_t> s_cnt_b((size_t) nranks), r_cnt_b((size_t) nranks), s_off_b((size_t) nranks),
+            r_off_b((size_t) nranks);
+        int64_t biggest = 0, s_off = 0, r_off = 0;
+        for (int r = 0; r < nranks; ++r) {
+            const int64_t sc = send_counts[(size_t) s * nranks + r];
+            const int64_t rc = h_matrix[(size_t) r * row + (size_t) s * nranks + rank];
+            if (h_matrix[(size_t) rank * row + (size_t) s * nranks + r] != sc) {
+                set_error("bt_mgpu_exchange: the gathered counts disagree with this rank's own");
+                return BT_ERR_INTERNAL;
+            }
+            s_cnt_b[r] = sc * rec; r_cnt_b[r] = rc * rec;
+            s_off_b[r] = s_off * rec; r_off_b[r] = r_off * rec;
+            s_off += sc; r_off += rc;
+            for (int q = 0; q < nranks; ++q)
+                if (q != r) biggest = std::max(biggest, h_matrix[(size_t) r * row + (size_t) s * nranks + q] * rec);
+        }
+        if (r_off != nrecv_of[s]) {
+            set_error("bt_mgpu_exchange: rank %d receives %lld particles, its cells hold %lld", rank,
+                      (long long) r_off, (long long) nrecv_of[s]);
+            return BT_ERR_INTERNAL;
+        }
         int32_t rounds = 1;
-        if (!loop_self) {
-            BT_CHECK(bt_partition_pack(ctx, D, es, cset[s], cells[s].get(), n, owner_d.get(), nranks, rank,
-                                       s_off[rank], r_off[rank], send.get(), points));
-            s_cnt_b[rank] = 0; r_cnt_b[rank] = 0;       // (own segment: packed in place)
-        } else {
-            // test switch (bt_mgpu_comm_set_self_loopback): the own segment is packed into the
-            // send buffer like any other and makes the trip through ncclSend / ncclRecv
-            BT_CHECK(bt_partition_pack(ctx, D, es, cset[s], cells[s].get(), n, owner_d.get(), nranks, rank,
-                                       s_off[rank], s_off[rank], send.get(), send.get()));
-            biggest = std::max(biggest, s_cnt_b[rank]);
-        }
-        BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send.get(), s_off_b.data(), s_cnt_b.data(),
-                                   (char *) points, r_off_b.data(), r_cnt_b.data(), biggest, !loop_self, &rounds));
-        BT_HIP_CHECK(hipStreamSynchronize(stream));     // the send buffer and the host vectors go out of scope
+        if (!loop_self) { s_cnt_b[rank] = 0; r_cnt_b[rank] = 0; }       // (own segment: packed in place)
+        else biggest = std::max(biggest, s_cnt_b[rank]);
+        BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send[s].get(), s_off_b.data(), s_cnt_b.data(),
+                                   (char *) points_of[s], r_off_b.data(), r_cnt_b.data(), biggest, !loop_self, &rounds));
         rounds_total += rounds;
-        bytes_sent += (n - (loop_self ? 0 : send_counts[(size_t) s * nranks + rank])) * rec;
-        points_of[s] = points;
-        nrecv_of[s] = nrecv;
+        bytes_sent += (nset[s] - (loop_self ? 0 : send_counts[(size_t) s * nranks + rank])) * rec;
     }
     BT_HIP_CHECK(hipEventRecord(ms->ev[1], stream));
+    ms->a2a_pending = true;
     BT_CHECK(ms->cell_prefix.alloc(ctx->pool, ncells + 1));
-    BT_HIP_CHECK(hipMemcpyAsync(ms->cell_prefix.get(), pl.prefix.data(), (size_t) (ncells + 1) * 8,
+    memcpy(h_prefix, pl.prefix.data(), (size_t) (ncells + 1) * 8);
+    BT_HIP_CHECK(hipMemcpyAsync(ms->cell_prefix.get(), h_prefix, (size_t) (ncells + 1) * 8,
                                 hipMemcpyHostToDevice, stream));
-    BT_HIP_CHECK(hipStreamSynchronize(stream));     // host vectors above go out of scope
+    BT_HIP_CHECK(hipEventRecord(ms->ev_done, stream));
+    ms->done_pending = true;
 
     out->n_owned = nrecv_of[0];
     out->points = points_of[0];
@@ -882,7 +1043,15 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     out->bytes_sent = bytes_sent;
     out->rounds = rounds_total;
     out->sep_targets = sep ? 1 : 0;
-    (void) hipEventElapsedTime(&out->a2a_ms, ms->ev[0], ms->ev[1]);
+    out->a2a_ms = -1.f;
+    // a stream-ordered context returns with the payload exchange queued (bt_mgpu_exchange_time
+    // waits for it); any other waits here
+    BT_CHECK(bt::finish_call(ctx));
+    if (!ctx->stream_ordered) {
+        (void) hipEventElapsedTime(&ms->a2a_ms, ms->ev[0], ms->ev[1]);
+        ms->a2a_pending = false;
+        out->a2a_ms = ms->a2a_ms;
+    }
     return BT_OK;
 }
 
@@ -906,20 +1075,24 @@ static int bt_mgpu_number_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgp
     const TopPlan &pl = ms->plan;
     if (pl.D != tree->dims || pl.k >= TOPMAX) { set_error("bt_mgpu_number: plan / tree mismatch"); return BT_ERR_INVALID; }
     BT_HIP_CHECK(hipSetDevice(ctx->device));
+    BT_CHECK(reset_status(ctx));
     memset(out, 0, sizeof(*out));
     hipStream_t stream = ctx->stream;
     const int rank = comm->rank, nranks = comm->nranks, k = pl.k, nlev = tree->nlevels;
     constexpr int W = BT_MAX_LEVELS + 2;
-    std::vector<int64_t> mine((size_t) W, 0), all((size_t) W * nranks);
+    BT_CHECK(arena_reclaim(ms, false));
+    BT_ARENA(mine, int64_t, ms, W);
+    BT_ARENA(all, int64_t, ms, (int64_t) W * nranks);
+    for (int l = 0; l < W; ++l) mine[l] = 0;
     for (int l = 0; l < nlev; ++l) mine[l] = tree->level_start_box_nrs[l + 1] - tree->level_start_box_nrs[l];
     mine[BT_MAX_LEVELS] = tree->nsources;
     mine[BT_MAX_LEVELS + 1] = tree->ntargets;
     Buf<int64_t> gath;
     BT_CHECK(gath.alloc(ctx->pool, (int64_t) W * (nranks + 1)));
-    BT_HIP_CHECK(hipMemcpyAsync(gath.get(), mine.data(), (size_t) W * 8, hipMemcpyHostToDevice, stream));
+    BT_HIP_CHECK(hipMemcpyAsync(gath.get(), mine, (size_t) W * 8, hipMemcpyHostToDevice, stream));
     BT_CHECK(comm_all_gather(comm, stream, gath.get(), gath.get() + W, (size_t) W * 8));
-    BT_HIP_CHECK(hipMemcpyAsync(all.data(), gath.get() + W, all.size() * 8, hipMemcpyDeviceToHost, stream));
-    BT_HIP_CHECK(hipStreamSynchronize(stream));
+    BT_CHECK(bt::copy_to_pinned(ctx, all, gath.get() + W, (size_t) W * nranks * 8));
+    BT_CHECK(bt::sync_stream(ctx));
     // the deepest local tree; boxes of levels <= k are shared and numbered by Morton path
     // from the plan, deeper levels are the concatenation of the ranks' level slices
     int gl = 0;
@@ -961,16 +1134,20 @@ static int bt_mgpu_number_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgp
     }
     if (tree->nboxes == 0) return BT_OK;
     // index tables of the shared top levels
-    std::vector<int32_t> index;
     const int ntop_levels = std::min(k + 1, nlev);
+    int64_t nindex = 0;
+    for (int l = 0; l < ntop_levels; ++l) nindex += (int64_t) pl.index[l].size();
+    BT_ARENA(index, int32_t, ms, nindex);
+    nindex = 0;
     for (int l = 0; l < ntop_levels; ++l) {
-        na.toff[l] = (int32_t) index.size();
+        na.toff[l] = (int32_t) nindex;
         na.gstart[l] = out->level_start_box_nrs[l];
-        index.insert(index.end(), pl.index[l].begin(), pl.index[l].end());
+        memcpy(index + nindex, pl.index[l].data(), pl.index[l].size() * 4);
+        nindex += (int64_t) pl.index[l].size();
     }
     Buf<int32_t> index_d;
-    BT_CHECK(index_d.alloc(ctx->pool, (int64_t) index.size()));
-    BT_HIP_CHECK(hipMemcpyAsync(index_d.get(), index.data(), index.size() * 4, hipMemcpyHostToDevice, stream));
+    BT_CHECK(index_d.alloc(ctx->pool, nindex));
+    BT_HIP_CHECK(hipMemcpyAsync(index_d.get(), index, (size_t) nindex * 4, hipMemcpyHostToDevice, stream));
     na.index = index_d.get();
     for (int ax = 0; ax < 3; ++ax) na.bmin[ax] = pl.bbox_min[ax];
     na.root_extent = pl.root_extent;
@@ -981,8 +1158,8 @@ static int bt_mgpu_number_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgp
     else { if (pl.D == 1) NB(float, 1); else if (pl.D == 2) NB(float, 2); else NB(float, 3); }
 #undef NB
     BT_HIP_CHECK(hipGetLastError());
-    BT_HIP_CHECK(hipStreamSynchronize(stream));     // `index` goes out of scope
-    return BT_OK;
+    BT_CHECK(arena_mark(ctx, ms));
+    return bt::finish_call(ctx);
 }
 
 // ---- step 6: local essential tree ----------------------------------------------------------------
@@ -1027,12 +1204,13 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
         return BT_ERR_UNSUPPORTED;
     }
 
+    BT_CHECK(reset_status(ctx));
+    BT_CHECK(arena_reclaim(ms, false));
     // -- Morton paths of my boxes ----------------------------------------------------------------
     Buf<uint64_t> paths;
     BT_CHECK(paths.alloc(ctx->pool, nb));
-    if (nb > 0)
-        BT_CHECK(bt_box_morton_paths(ctx, D, tree->coord_kind, nb, tree->aligned_nboxes, tree->box_centers,
-                                     tree->box_levels, pl.bbox_min, pl.root_extent, paths.get()));
+    BT_CHECK(bt::box_paths_device(ctx, D, tree->coord_kind, nb, tree->aligned_nboxes, tree->box_centers,
+                                  tree->box_levels, pl.bbox_min, pl.root_extent, paths.get()));
     // my deep boxes (levels > k) are the tail of the level-major local tree
     const int64_t b0 = nlev_local > k + 1 ? tree->level_start_box_nrs[k + 1] : nb;
     const int64_t n_mine = nb - b0;
@@ -1042,56 +1220,64 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
     std::vector<uint64_t> need_bits;
     std::vector<char> any_for_peer;
     cells_needed_by(pl, rank, well_sep_is_n_away, nwords, need_bits, any_for_peer);
+    BT_ARENA(h_need, uint64_t, ms, need_bits.size());
+    memcpy(h_need, need_bits.data(), need_bits.size() * 8);
     Buf<uint64_t> need_d;
     BT_CHECK(need_d.alloc(ctx->pool, (int64_t) need_bits.size()));
-    BT_HIP_CHECK(hipMemcpyAsync(need_d.get(), need_bits.data(), need_bits.size() * 8, hipMemcpyHostToDevice, stream));
+    BT_HIP_CHECK(hipMemcpyAsync(need_d.get(), h_need, need_bits.size() * 8, hipMemcpyHostToDevice, stream));
     std::vector<int> peers;
     for (int q = 0; q < nranks; ++q)
         if (q != rank && any_for_peer[q] && n_mine > 0) peers.push_back(q);
     Buf<int32_t> pos;                 // [peers][n_mine + 1]
     BT_CHECK(pos.alloc(ctx->pool, (int64_t) peers.size() * (n_mine + 1)));
-    std::vector<int32_t> h_tot(peers.size(), 0);
+    // row[q][l]: how many of my level-l boxes rank q gets; every rank learns every row -- the
+    // whole (sender, receiver, level) table: message sizes, the largest message of the job, and
+    // where every box of the LET goes (LetBlocks)
+    const int LW = nlev;
+    const int64_t rowlen = (int64_t) nranks * LW;
+    Buf<int32_t> rows;
+    BT_CHECK(rows.alloc(ctx->pool, rowlen * (nranks + 1)));
+    BT_HIP_CHECK(hipMemsetAsync(rows.get(), 0, (size_t) rowlen * 4, stream));
+    LocalLevels lls{};
+    lls.nlevels = nlev_local;
+    for (int l = 0; l <= nlev_local; ++l) lls.start[l] = tree->level_start_box_nrs[l];
     NeedPred pr{paths.get(), tree->box_levels, need_d.get(), b0, k, D, nwords, 0};
     for (size_t i = 0; i < peers.size(); ++i) {
         pr.q = peers[i];
         int32_t *pp = pos.get() + (int64_t) i * (n_mine + 1);
         BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, pr, n_mine, pp, (int32_t *) nullptr, true)));
-        BT_CHECK(bt::d2h(ctx, &h_tot[i], pp + n_mine, 4));
+        let_level_counts_kernel<<<1, BT_MAX_LEVELS, 0, stream>>>(pp, b0, k, lls, rows.get() + (int64_t) peers[i] * LW);
     }
-    BT_CHECK(bt::sync_stream(ctx));
-    std::vector<int64_t> s_cnt((size_t) nranks, 0), s_off((size_t) nranks, 0);
-    for (size_t i = 0; i < peers.size(); ++i) s_cnt[peers[i]] = h_tot[i];
-    int64_t nsend = 0;
-    for (int q = 0; q < nranks; ++q) { s_off[q] = nsend; nsend += s_cnt[q]; }
-    Buf<uint64_t> send_rec;
+    BT_HIP_CHECK(hipGetLastError());
+    BT_CHECK(comm_all_gather(comm, stream, rows.get(), rows.get() + rowlen, (size_t) rowlen * 4));
+    BT_ARENA(table, int32_t, ms, rowlen * nranks);          // [sender][receiver][level]
+    BT_CHECK(bt::copy_to_pinned(ctx, table, rows.get() + rowlen, (size_t) rowlen * nranks * 4));
+    BT_CHECK(bt::sync_stream(ctx));                         // the one wait of this call
+    auto sent = [&](int from, int to) {
+        int64_t c = 0;
+        for (int l = 0; l < LW; ++l) c += table[((int64_t) from * nranks + to) * LW + l];
+        return c;
+    };
+    std::vector<int64_t> s_cnt((size_t) nranks, 0), s_off((size_t) nranks, 0), r_cnt((size_t) nranks, 0),
+        r_off((size_t) nranks, 0);
+    int64_t nsend = 0, nrecv = 0, biggest = 0;
+    for (int q = 0; q < nranks; ++q) {
+        s_cnt[q] = sent(rank, q); s_off[q] = nsend; nsend += s_cnt[q];
+        r_cnt[q] = sent(q, rank); r_off[q] = nrecv; nrecv += r_cnt[q];
+        for (int t = 0; t < nranks; ++t)
+            if (t != q) biggest = std::max(biggest, sent(q, t) * 16);
+    }
+    Buf<uint64_t> send_rec, halo_rec;
     BT_CHECK(send_rec.alloc(ctx->pool, 2 * std::max<int64_t>(nsend, 1)));
+    BT_CHECK(halo_rec.alloc(ctx->pool, 2 * std::max<int64_t>(nrecv, 1)));
     for (size_t i = 0; i < peers.size(); ++i) {
-        if (h_tot[i] == 0) continue;
+        if (s_cnt[peers[i]] == 0) continue;
         pr.q = peers[i];
         let_pack_kernel<<<(unsigned) div_up(n_mine, 256), 256, 0, stream>>>(
             n_mine, pr, pos.get() + (int64_t) i * (n_mine + 1), tree->box_flags, box_ids,
             send_rec.get() + 2 * s_off[peers[i]]);
     }
     BT_HIP_CHECK(hipGetLastError());
-    // counts: every rank learns the whole matrix (and with it the largest message)
-    Buf<int64_t> cm;
-    BT_CHECK(cm.alloc(ctx->pool, (int64_t) nranks * (nranks + 1)));
-    BT_HIP_CHECK(hipMemcpyAsync(cm.get(), s_cnt.data(), (size_t) nranks * 8, hipMemcpyHostToDevice, stream));
-    BT_CHECK(comm_all_gather(comm, stream, cm.get(), cm.get() + nranks, (size_t) nranks * 8));
-    std::vector<int64_t> matrix((size_t) nranks * nranks);
-    BT_HIP_CHECK(hipMemcpyAsync(matrix.data(), cm.get() + nranks, matrix.size() * 8, hipMemcpyDeviceToHost, stream));
-    BT_HIP_CHECK(hipStreamSynchronize(stream));
-    std::vector<int64_t> r_cnt((size_t) nranks), r_off((size_t) nranks);
-    int64_t nrecv = 0, biggest = 0;
-    for (int q = 0; q < nranks; ++q) {
-        r_cnt[q] = matrix[(size_t) q * nranks + rank];
-        r_off[q] = nrecv;
-        nrecv += r_cnt[q];
-        for (int t = 0; t < nranks; ++t)
-            if (t != q) biggest = std::max(biggest, matrix[(size_t) q * nranks + t] * 16);
-    }
-    Buf<uint64_t> halo_rec;
-    BT_CHECK(halo_rec.alloc(ctx->pool, 2 * std::max<int64_t>(nrecv, 1)));
     if (comm->kind == 0 && comm->self_loopback && n_mine > 0) {
         // test switch: no peer of a one-rank world gets halo records, so the records of ALL my
         // deep boxes make the trip to myself through ncclSend / ncclRecv and are compared with
@@ -1125,16 +1311,24 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
         for (int q = 0; q < nranks; ++q) {
             sob[q] = s_off[q] * 16; scb[q] = s_cnt[q] * 16; rob[q] = r_off[q] * 16; rcb[q] = r_cnt[q] * 16;
         }
+        // (the host arrays are read while the call queues its sends and receives; ranks that are
+        // threads wait inside)
         BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send_rec.get(), sob.data(), scb.data(),
                                    (char *) halo_rec.get(), rob.data(), rcb.data(), biggest, false, nullptr));
-        BT_HIP_CHECK(hipStreamSynchronize(stream));       // (host vectors)
     }
 
     // -- the box set: top levels from the plan, my deep boxes, the halo ----------------------------
-    std::vector<uint64_t> t_paths;
-    std::vector<int32_t> t_meta, t_gid;
-    std::vector<int8_t> t_mine;
+    int64_t ntop = 0;
+    for (int lev = 0; lev < ntop_levels; ++lev) ntop += pl.nboxes[lev];
+    const int64_t nd = n_mine + nrecv;
+    const int64_t B = ntop + nd;
+    if (B > 0x7fffffff) { set_error("bt_mgpu_let_build: more than 2^31-1 boxes"); return BT_ERR_UNSUPPORTED; }
+    BT_ARENA(t_paths, uint64_t, ms, ntop);
+    BT_ARENA(t_meta, int32_t, ms, ntop);
+    BT_ARENA(t_gid, int32_t, ms, ntop);
+    BT_ARENA(t_mine, int8_t, ms, ntop);
     std::vector<int32_t> level_starts(1, 0);
+    int64_t nt = 0;
     for (int lev = 0; lev < ntop_levels; ++lev) {
         const int64_t n = (int64_t) 1 << (D * lev);
         for (int64_t pth = 0; pth < n; ++pth) {
@@ -1145,95 +1339,73 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
                                      : (BT_BOX_IS_SOURCE_BOX | BT_BOX_IS_TARGET_BOX);
             if (!internal && pl.sep_targets) {
                 // a leaf is a source box iff it holds sources, a target box iff targets (tbk:1258-1262)
-                const int64_t ns = pl.src_counts[lev][pth], nt = pl.counts[lev][pth] - ns;
-                flags = (ns > 0 ? BT_BOX_IS_SOURCE_BOX : 0) | (nt > 0 ? BT_BOX_IS_TARGET_BOX : 0);
+                const int64_t ns = pl.src_counts[lev][pth], ntg = pl.counts[lev][pth] - ns;
+                flags = (ns > 0 ? BT_BOX_IS_SOURCE_BOX : 0) | (ntg > 0 ? BT_BOX_IS_TARGET_BOX : 0);
             }
             // lists of the shared internal boxes are built by every rank, those of a top LEAF
             // only by the rank that owns its cells
             const int64_t first_cell = pth << (D * (k - lev));
-            t_paths.push_back((uint64_t) pth);
-            t_meta.push_back(lev | (flags << 8));
-            t_gid.push_back(num->level_start_box_nrs[lev] + pl.index[lev][pth]);
-            t_mine.push_back((internal || pl.owner[first_cell] == rank) ? 1 : 0);
+            t_paths[nt] = (uint64_t) pth;
+            t_meta[nt] = lev | (flags << 8);
+            t_gid[nt] = num->level_start_box_nrs[lev] + pl.index[lev][pth];
+            t_mine[nt] = (internal || pl.owner[first_cell] == rank) ? 1 : 0;
+            ++nt;
         }
-        level_starts.push_back((int32_t) t_paths.size());
+        level_starts.push_back((int32_t) nt);
     }
-    const int64_t ntop = (int64_t) t_paths.size();
-    const int64_t nd = n_mine + nrecv;
-    const int64_t B = ntop + nd;
-    if (B > 0x7fffffff) { set_error("bt_mgpu_let_build: more than 2^31-1 boxes"); return BT_ERR_UNSUPPORTED; }
+    if (nt != ntop) { set_error("bt_mgpu_let_build: the plan's box counts are inconsistent"); return BT_ERR_INTERNAL; }
     BT_CHECK(ms->let_paths.alloc(ctx->pool, B));
     BT_CHECK(ms->let_meta.alloc(ctx->pool, B));
     BT_CHECK(ms->let_gid.alloc(ctx->pool, B));
     BT_CHECK(ms->let_mask.alloc(ctx->pool, B));
-    BT_HIP_CHECK(hipMemcpyAsync(ms->let_paths.get(), t_paths.data(), (size_t) ntop * 8, hipMemcpyHostToDevice, stream));
-    BT_HIP_CHECK(hipMemcpyAsync(ms->let_meta.get(), t_meta.data(), (size_t) ntop * 4, hipMemcpyHostToDevice, stream));
-    BT_HIP_CHECK(hipMemcpyAsync(ms->let_gid.get(), t_gid.data(), (size_t) ntop * 4, hipMemcpyHostToDevice, stream));
-    BT_HIP_CHECK(hipMemcpyAsync(ms->let_mask.get(), t_mine.data(), (size_t) ntop, hipMemcpyHostToDevice, stream));
+    BT_HIP_CHECK(hipMemcpyAsync(ms->let_paths.get(), t_paths, (size_t) ntop * 8, hipMemcpyHostToDevice, stream));
+    BT_HIP_CHECK(hipMemcpyAsync(ms->let_meta.get(), t_meta, (size_t) ntop * 4, hipMemcpyHostToDevice, stream));
+    BT_HIP_CHECK(hipMemcpyAsync(ms->let_gid.get(), t_gid, (size_t) ntop * 4, hipMemcpyHostToDevice, stream));
+    BT_HIP_CHECK(hipMemcpyAsync(ms->let_mask.get(), t_mine, (size_t) ntop, hipMemcpyHostToDevice, stream));
 
-    LetLevelInfo h_info{};
-    for (int l = 0; l <= BT_MAX_LEVELS; ++l) { h_info.level_first[l] = -1; h_info.mine_last[l] = -1; }
-    if (nd > 0) {
-        Buf<uint64_t> key_a, key_b, d_path;
-        Buf<uint32_t> ord_a, ord_b;
-        Buf<int32_t> d_meta, d_gid;
-        Buf<LetLevelInfo> info;
-        BT_CHECK(key_a.alloc(ctx->pool, nd)); BT_CHECK(key_b.alloc(ctx->pool, nd));
-        BT_CHECK(ord_a.alloc(ctx->pool, nd)); BT_CHECK(ord_b.alloc(ctx->pool, nd));
-        BT_CHECK(d_path.alloc(ctx->pool, nd)); BT_CHECK(d_meta.alloc(ctx->pool, nd)); BT_CHECK(d_gid.alloc(ctx->pool, nd));
-        BT_CHECK(info.alloc(ctx->pool, 1));
-        let_deep_kernel<<<(unsigned) div_up(nd, 256), 256, 0, stream>>>(
-            n_mine, nrecv, b0, paths.get(), tree->box_levels, tree->box_flags, box_ids, halo_rec.get(),
-            pathbits, key_a.get(), d_path.get(), d_meta.get(), d_gid.get());
-        BT_HIP_CHECK(hipGetLastError());
-        // (level, Morton path) order; equal keys cannot occur (a box is sent by its one owner)
-        bool in_b = false;
-        BT_CHECK(radix_sort_pairs<uint64_t>(ctx, key_a.get(), ord_a.get(), key_b.get(), ord_b.get(), nd, 0,
-                                            pathbits + levbits, true, &in_b));
-        LetLevelInfo init{};
-        for (int l = 0; l <= BT_MAX_LEVELS; ++l) { init.level_first[l] = -1; init.mine_first[l] = 0; init.mine_last[l] = -1; }
-        BT_HIP_CHECK(hipMemcpyAsync(info.get(), &init, sizeof(init), hipMemcpyHostToDevice, stream));
-        let_place_kernel<<<(unsigned) div_up(nd, 256), 256, 0, stream>>>(
-            nd, n_mine, ntop, in_b ? ord_b.get() : ord_a.get(), d_path.get(), d_meta.get(), d_gid.get(),
-            ms->let_paths.get(), ms->let_meta.get(), ms->let_gid.get(), ms->let_mask.get(), info.get());
-        BT_HIP_CHECK(hipGetLastError());
-        BT_HIP_CHECK(hipMemcpyAsync(&h_info, info.get(), sizeof(h_info), hipMemcpyDeviceToHost, stream));
-    }
-    BT_CHECK(bt::check_status(ctx));           // waits; the sort and the scans report here
-
-    // -- level starts; the range of a level that holds this rank's boxes ---------------------------
+    // -- deep levels: per level the blocks of the ranks in rank order (LetBlocks) ------------------
+    std::vector<LetBlocks> blk((size_t) nranks);
+    std::vector<int64_t> seq((size_t) nranks, 0);           // position within a sender's sequence
+    int64_t cursor = ntop;
     for (int lev = 0; lev < nlev; ++lev) {
-        const int32_t s = level_starts[(size_t) lev];
         if (lev < ntop_levels) {
-            out->active_level_ranges[lev][0] = s;
+            out->active_level_ranges[lev][0] = level_starts[(size_t) lev];
             out->active_level_ranges[lev][1] = level_starts[(size_t) lev + 1];
             continue;
         }
-        // the sorted deep boxes of this level: from its first position to the next level's
-        int32_t cnt = 0;
-        if (h_info.level_first[lev] >= 0) {
-            int32_t end = (int32_t) nd;
-            for (int l2 = lev + 1; l2 <= BT_MAX_LEVELS; ++l2)
-                if (h_info.level_first[l2] >= 0) { end = h_info.level_first[l2]; break; }
-            cnt = end - h_info.level_first[lev];
-        }
-        if (h_info.mine_runs[lev] > 0) {
-            if (h_info.mine_runs[lev] != 1) {
-                set_error("bt_mgpu_let_build: the rank's boxes of level %d are not one run", lev);
-                return BT_ERR_INTERNAL;
+        for (int q = 0; q < nranks; ++q) {
+            const int64_t c = q == rank
+                ? (lev < nlev_local ? (int64_t) tree->level_start_box_nrs[lev + 1] - tree->level_start_box_nrs[lev] : 0)
+                : (int64_t) table[((int64_t) q * nranks + rank) * LW + lev];
+            blk[(size_t) q].src_start[lev] = q == rank ? (lev < nlev_local ? tree->level_start_box_nrs[lev] : (int32_t) nb)
+                                                       : (int32_t) seq[(size_t) q];
+            blk[(size_t) q].dst_start[lev] = (int32_t) cursor;
+            if (q == rank) {
+                out->active_level_ranges[lev][0] = (int32_t) cursor;
+                out->active_level_ranges[lev][1] = (int32_t) (cursor + c);
             }
-            out->active_level_ranges[lev][0] = (int32_t) (ntop + h_info.mine_first[lev]);
-            out->active_level_ranges[lev][1] = (int32_t) (ntop + h_info.mine_last[lev] + 1);
-        } else {
-            out->active_level_ranges[lev][0] = out->active_level_ranges[lev][1] = s;
+            seq[(size_t) q] += c;
+            cursor += c;
         }
-        level_starts.push_back(s + cnt);
+        level_starts.push_back((int32_t) cursor);
     }
-    if (level_starts.back() != (int32_t) B) {
-        set_error("bt_mgpu_let_build: level counts (%d) do not add up to the box count (%lld)",
-                  level_starts.back(), (long long) B);
+    if (cursor != B) {
+        set_error("bt_mgpu_let_build: level counts (%lld) do not add up to the box count (%lld)",
+                  (long long) cursor, (long long) B);
         return BT_ERR_INTERNAL;
     }
+    if (n_mine > 0)
+        let_scatter_own_kernel<<<(unsigned) div_up(n_mine, 256), 256, 0, stream>>>(
+            n_mine, b0, blk[(size_t) rank], paths.get(), tree->box_levels, tree->box_flags, box_ids,
+            ms->let_paths.get(), ms->let_meta.get(), ms->let_gid.get(), ms->let_mask.get());
+    for (int q = 0; q < nranks; ++q) {
+        if (q == rank || r_cnt[q] == 0) continue;
+        let_scatter_halo_kernel<<<(unsigned) div_up(r_cnt[q], 256), 256, 0, stream>>>(
+            r_cnt[q], blk[(size_t) q], halo_rec.get() + 2 * r_off[q], ms->let_paths.get(), ms->let_meta.get(),
+            ms->let_gid.get(), ms->let_mask.get(), ctx->d_status);
+    }
+    BT_HIP_CHECK(hipGetLastError());
+
     ms->let_level_starts = level_starts;
     ms->let_nlevels = nlev;
     ms->let_dims = D;
@@ -1244,7 +1416,8 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
     for (int l = 0; l <= nlev; ++l) out->level_start_box_nrs[l] = level_starts[(size_t) l];
     out->halo_boxes_sent = nsend;
     out->halo_boxes_received = nrecv;
-    return BT_OK;
+    BT_CHECK(arena_mark(ctx, ms));
+    return bt::finish_call(ctx);
 }
 
 // A rank that leaves a collective entry with an error tells the local group, so that its peers
@@ -1258,6 +1431,21 @@ static int peer_result(bt_mgpu_comm *comm, int status)
 int bt_mgpu_exchange(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *p, bt_mgpu_shard *out)
 {
     return peer_result(comm, bt_mgpu_exchange_body(ctx, comm, p, out));
+}
+
+int bt_mgpu_exchange_time(bt_context *ctx, float *a2a_ms)
+{
+    bt::CallScope bt_call_scope_(ctx);
+    if (!ctx || !a2a_ms) { set_error("bt_mgpu_exchange_time: invalid argument"); return BT_ERR_INVALID; }
+    MgpuState *ms = ctx->mgpu;
+    if (!ms || !ms->ev[1]) { set_error("bt_mgpu_exchange_time: no exchange on this context"); return BT_ERR_INVALID; }
+    if (ms->a2a_pending) {
+        BT_HIP_CHECK(hipEventSynchronize(ms->ev[1]));
+        BT_HIP_CHECK(hipEventElapsedTime(&ms->a2a_ms, ms->ev[0], ms->ev[1]));
+        ms->a2a_pending = false;
+    }
+    *a2a_ms = ms->a2a_ms;
+    return BT_OK;
 }
 
 int bt_mgpu_number(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
@@ -1283,6 +1471,7 @@ int bt_mgpu_let_export(bt_context *ctx, const bt_mgpu_let_arrays *o)
         return BT_ERR_INVALID;
     }
     BT_HIP_CHECK(hipSetDevice(ctx->device));
+    BT_CHECK(reset_status(ctx));
     const TopPlan &pl = ms->plan;
     const int64_t B = ms->let_level_starts.back();
     const int64_t aligned = div_up(B, 32) * 32;
@@ -1294,15 +1483,19 @@ int bt_mgpu_let_export(bt_context *ctx, const bt_mgpu_let_arrays *o)
         BT_HIP_CHECK(hipMemcpyAsync(o->global_box_ids, ms->let_gid.get(), (size_t) B * 4, hipMemcpyDeviceToDevice, stream));
     if (o->target_boxes_mask)
         BT_HIP_CHECK(hipMemcpyAsync(o->target_boxes_mask, ms->let_mask.get(), (size_t) B, hipMemcpyDeviceToDevice, stream));
-    BT_HIP_CHECK(hipMemsetAsync(o->box_parent_ids, 0, (size_t) B * 4, stream));
+    // (every box gets its parent and its centre from the link kernel; only the padding of the
+    // centre rows is cleared)
     const size_t cs = ms->let_kind == BT_F64 ? 8 : 4;
-    BT_HIP_CHECK(hipMemsetAsync(o->box_centers, 0, (size_t) ms->let_dims * (size_t) aligned * cs, stream));
-    BT_CHECK(bt_let_build(ctx, ms->let_dims, ms->let_kind, ms->let_nlevels, ms->let_level_starts.data(),
-                          ms->let_paths.get(), aligned, pl.bbox_min, pl.bbox_max, pl.root_extent,
-                          o->box_parent_ids, o->box_child_ids, o->box_centers));
+    if (aligned > B)
+        for (int ax = 0; ax < ms->let_dims; ++ax)
+            BT_HIP_CHECK(hipMemsetAsync((char *) o->box_centers + ((size_t) ax * (size_t) aligned + (size_t) B) * cs, 0,
+                                        (size_t) (aligned - B) * cs, stream));
+    BT_CHECK(bt::let_link_device(ctx, ms->let_dims, ms->let_kind, ms->let_nlevels, ms->let_level_starts.data(),
+                                 ms->let_paths.get(), aligned, pl.bbox_min, pl.bbox_max, pl.root_extent,
+                                 o->box_parent_ids, o->box_child_ids, o->box_centers));
     ms->let_paths.reset(); ms->let_meta.reset(); ms->let_gid.reset(); ms->let_mask.reset();
     ms->let_nlevels = 0;
-    return BT_OK;
+    return bt::finish_call(ctx);
 }
 
 }  // extern "C"

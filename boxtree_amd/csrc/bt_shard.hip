@@ -17,35 +17,51 @@ template <class T, int D>
 struct CellArgs {
     const T *x[D];
     T bmin[D], bmax[D];
+    const T *rootbox;       // device {min[3], max[3], ...}: takes the place of bmin / bmax
     int64_t n;
     int level;
 };
 
 // same float expression as the key kernel (tbk:374-376) at level `level`
 template <class T, int D>
+__device__ __forceinline__ uint32_t morton_cell_of(const T (&x)[D], const T (&gmin)[D], const T (&gext)[D], int level)
+{
+    uint32_t cell = 0;
+    const uint32_t top = (1u << level) - 1u;
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) {
+        uint32_t v = (uint32_t) (((x[ax] - gmin[ax]) / gext[ax]) * (T) (1u << level));
+        v = v > top ? top : v;
+        for (int b = 0; b < level; ++b)
+            cell |= ((v >> b) & 1u) << (D * b + (D - 1 - ax));       // x most significant
+    }
+    return cell;
+}
+
+template <class T, int D>
 __global__ __launch_bounds__(256) void morton_cells_kernel(CellArgs<T, D> a, uint32_t *cells,
                                                            int32_t *hist)
 {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= a.n) return;
-    uint32_t cell = 0;
-    const uint32_t top = (1u << a.level) - 1u;
+    T gmin[D], gext[D], x[D];
 #pragma unroll
     for (int ax = 0; ax < D; ++ax) {
-        const T gmin = a.bmin[ax];
-        const T gext = a.bmax[ax] - gmin;
-        uint32_t v = (uint32_t) (((a.x[ax][i] - gmin) / gext) * (T) (1u << a.level));
-        v = v > top ? top : v;
-        for (int b = 0; b < a.level; ++b)
-            cell |= ((v >> b) & 1u) << (D * b + (D - 1 - ax));       // x most significant
+        gmin[ax] = a.rootbox ? a.rootbox[ax] : a.bmin[ax];
+        gext[ax] = (a.rootbox ? a.rootbox[3 + ax] : a.bmax[ax]) - gmin[ax];
+        x[ax] = a.x[ax][i];
     }
+    const uint32_t cell = morton_cell_of<T, D>(x, gmin, gext, a.level);
     cells[i] = cell;
     atomicAdd(&hist[cell], 1);
 }
 
 // same, with the histogram privatised in LDS (up to 2^15 cells = 128 KiB, one
-// workgroup per CU): 1e8 global atomics on 32 K addresses cost ~5 ms otherwise
+// workgroup per CU): 1e8 global atomics on 32 K addresses cost ~5 ms otherwise.  One
+// workgroup per CU is 16 waves: four particles per lane and trip keep enough loads in flight
+// (one per trip: 0.86 ms at 10^8 points, 3.2 TB/s).
 constexpr int CELLS_LDS_MAX = 1 << 15;
+constexpr int CELLS_UNROLL = 4;
 
 template <class T, int D>
 __global__ __launch_bounds__(1024) void morton_cells_lds_kernel(CellArgs<T, D> a, uint32_t *cells,
@@ -53,22 +69,31 @@ __global__ __launch_bounds__(1024) void morton_cells_lds_kernel(CellArgs<T, D> a
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist[];
     for (int c = threadIdx.x; c < ncells; c += 1024) s_hist[c] = 0;
-    __syncthreads();
-    const uint32_t top = (1u << a.level) - 1u;
-    const int64_t stride = (int64_t) gridDim.x * 1024;
-    for (int64_t i = (int64_t) blockIdx.x * 1024 + threadIdx.x; i < a.n; i += stride) {
-        uint32_t cell = 0;
+    T gmin[D], gext[D];
 #pragma unroll
-        for (int ax = 0; ax < D; ++ax) {
-            const T gmin = a.bmin[ax];
-            const T gext = a.bmax[ax] - gmin;
-            uint32_t v = (uint32_t) (((a.x[ax][i] - gmin) / gext) * (T) (1u << a.level));
-            v = v > top ? top : v;
-            for (int b = 0; b < a.level; ++b)
-                cell |= ((v >> b) & 1u) << (D * b + (D - 1 - ax));
+    for (int ax = 0; ax < D; ++ax) {
+        gmin[ax] = a.rootbox ? a.rootbox[ax] : a.bmin[ax];
+        gext[ax] = (a.rootbox ? a.rootbox[3 + ax] : a.bmax[ax]) - gmin[ax];
+    }
+    __syncthreads();
+    const int64_t stride = (int64_t) gridDim.x * 1024 * CELLS_UNROLL;
+    for (int64_t i0 = (int64_t) blockIdx.x * 1024 * CELLS_UNROLL + threadIdx.x; i0 < a.n; i0 += stride) {
+        T x[CELLS_UNROLL][D];
+#pragma unroll
+        for (int u = 0; u < CELLS_UNROLL; ++u) {
+            const int64_t i = i0 + (int64_t) u * 1024;
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) x[u][ax] = i < a.n ? a.x[ax][i] : gmin[ax];
         }
-        cells[i] = cell;
-        atomicAdd(&s_hist[cell], 1u);
+#pragma unroll
+        for (int u = 0; u < CELLS_UNROLL; ++u) {
+            const int64_t i = i0 + (int64_t) u * 1024;
+            if (i < a.n) {
+                const uint32_t cell = morton_cell_of<T, D>(x[u], gmin, gext, a.level);
+                cells[i] = cell;
+                atomicAdd(&s_hist[cell], 1u);
+            }
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < ncells; c += 1024) {
@@ -140,41 +165,60 @@ int unpack_impl(bt_context *ctx, const void *in, int64_t n, void *const *out)
 
 template <class T, int D>
 int cells_impl(bt_context *ctx, const void *const *coords, int64_t n, const double *bmin,
-               const double *bmax, int level, uint32_t *cells, int32_t *hist)
+               const double *bmax, const void *d_rootbox, int level, uint32_t *cells, int32_t *hist,
+               bool wait)
 {
-    CellArgs<T, D> a;
+    CellArgs<T, D> a{};
     for (int ax = 0; ax < D; ++ax) {
         a.x[ax] = (const T *) coords[ax];
-        a.bmin[ax] = (T) bmin[ax];
-        a.bmax[ax] = (T) bmax[ax];
+        a.bmin[ax] = bmin ? (T) bmin[ax] : (T) 0;
+        a.bmax[ax] = bmax ? (T) bmax[ax] : (T) 0;
     }
+    a.rootbox = (const T *) d_rootbox;
     a.n = n;
     a.level = level;
     const int ncells = 1 << (D * level);
     if (n > 0 && ncells <= CELLS_LDS_MAX) {
-        const unsigned blocks = (unsigned) std::min<int64_t>(div_up(n, 1024), ctx->num_cus);
+        const unsigned blocks = (unsigned) std::min<int64_t>(div_up(n, 1024 * CELLS_UNROLL), ctx->num_cus);
         morton_cells_lds_kernel<T, D><<<blocks, 1024, (size_t) ncells * 4, ctx->stream>>>(
             a, cells, hist, ncells);
     } else if (n > 0) {
         morton_cells_kernel<T, D><<<(unsigned) div_up(n, 256), 256, 0, ctx->stream>>>(a, cells, hist);
     }
     BT_HIP_CHECK(hipGetLastError());
-    BT_CHECK(bt::sync_stream(ctx));
+    if (wait) BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
+}
+
+template <class T>
+int cells_dims(bt_context *ctx, int dims, const void *const *coords, int64_t n, const double *bmin,
+               const double *bmax, const void *d_rootbox, int level, uint32_t *cells, int32_t *hist, bool wait)
+{
+    switch (dims) {
+    case 1: return cells_impl<T, 1>(ctx, coords, n, bmin, bmax, d_rootbox, level, cells, hist, wait);
+    case 2: return cells_impl<T, 2>(ctx, coords, n, bmin, bmax, d_rootbox, level, cells, hist, wait);
+    default: return cells_impl<T, 3>(ctx, coords, n, bmin, bmax, d_rootbox, level, cells, hist, wait);
+    }
 }
 
 // ---- stable partition of the particles by owner rank, payload carried along -------------
 //
-// The send buffer of the exchange, made in one sweep over the coordinates: a wave owns 1024
-// consecutive particles, counts them per owner (pp_count_kernel), a scan over (owner, wave)
-// turns the counts into record offsets, and pp_scatter_kernel writes every particle's
-// coordinates, interleaved, at its place -- the segment a rank keeps straight into the
-// receive buffer.  Reads are sequential, writes go to `nranks` advancing runs.  (A
-// permutation by owner followed by a gather reads the coordinate arrays in `nranks`
-// interleaved strided passes: with 8 ranks every 64-byte line is fetched 8 times.)
+// The send buffer of the exchange, made in one sweep over the coordinates: a wave owns
+// PP_WAVE_ITEMS consecutive particles and counts them per owner (pp_count_kernel), a scan
+// over (owner, wave) turns the counts into record offsets, and pp_scatter_kernel moves every
+// particle's coordinates, interleaved, to its place -- the segment a rank keeps straight into
+// the receive buffer.  The scatter issues all of a wave's loads first (cells, owners,
+// coordinates: PP_ROWS x D values per lane in flight), ranks the rows in order into a staging
+// area in LDS where the wave's particles of one owner are contiguous, and copies each owner's
+// run out with 16-byte stores: the records of a wave leave as a few contiguous pieces
+// instead of D strided 8-byte stores per particle (2.1 -> ~1 ms at 10^8 points, one to eight
+// owners).  Reads are sequential, writes go to `nranks` advancing runs.  (A permutation by
+// owner followed by a gather reads the coordinate arrays in `nranks` interleaved strided
+// passes: with 8 ranks every 64-byte line is fetched 8 times.)
 constexpr int PP_MAX_RANKS = BT_MGPU_MAX_RANKS;
-constexpr int PP_ITEMS = 16;                    // particles per lane
-constexpr int PP_WAVE_ITEMS = 64 * PP_ITEMS;
+constexpr int PP_ROWS = 8;                      // particles per lane
+constexpr int PP_WAVE_ITEMS = 64 * PP_ROWS;
+constexpr int PP_WAVES = 4;                     // waves per workgroup, each on its own
 
 // lanes of the wave whose value equals this lane's (match-any by ballots over `bits` bits)
 __device__ __forceinline__ uint64_t pp_match(uint32_t d, int bits)
@@ -189,24 +233,34 @@ __device__ __forceinline__ uint64_t pp_match(uint32_t d, int bits)
 }
 
 // counts[owner * nwaves + wave]
-__global__ __launch_bounds__(256) void pp_count_kernel(const uint32_t *cells, int64_t n,
+__global__ __launch_bounds__(64 * PP_WAVES) void pp_count_kernel(const uint32_t *cells, int64_t n,
         const int32_t *owner_of_cell, int nranks, int bits, int64_t nwaves, int32_t *counts)
 {
-    __shared__ int32_t s_cnt[4][PP_MAX_RANKS];
+    __shared__ int32_t s_cnt[PP_WAVES][PP_MAX_RANKS];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t) blockIdx.x * 4 + w;
+    const int64_t wave = (int64_t) blockIdx.x * PP_WAVES + w;
     for (int r = lane; r < nranks; r += 64) s_cnt[w][r] = 0;
     __builtin_amdgcn_wave_barrier();
     if (wave >= nwaves) return;
     const int64_t base = wave * PP_WAVE_ITEMS + lane;
-    for (int j = 0; j < PP_ITEMS; ++j) {
+    uint32_t d[PP_ROWS];
+#pragma unroll
+    for (int j = 0; j < PP_ROWS; ++j) {
         const int64_t i = base + (int64_t) j * 64;
-        const bool in = i < n;
+        d[j] = i < n ? cells[i] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < PP_ROWS; ++j) {
+        const int64_t i = base + (int64_t) j * 64;
         // (lanes past the end form a group of their own)
-        const uint32_t d = in ? (uint32_t) owner_of_cell[cells[i]] : (uint32_t) nranks;
-        const uint64_t mask = pp_match(d, bits + 1);
+        d[j] = i < n ? (uint32_t) owner_of_cell[d[j]] : (uint32_t) nranks;
+    }
+#pragma unroll
+    for (int j = 0; j < PP_ROWS; ++j) {
+        const bool in = d[j] < (uint32_t) nranks;
+        const uint64_t mask = pp_match(d[j], bits + 1);
         const bool leader = (mask & ((1ull << lane) - 1ull)) == 0ull;
-        if (in && leader) s_cnt[w][d] += (int32_t) __popcll(mask);
+        if (in && leader) s_cnt[w][d[j]] += (int32_t) __popcll(mask);
         __builtin_amdgcn_wave_barrier();
     }
     for (int r = lane; r < nranks; r += 64) counts[(int64_t) r * nwaves + wave] = s_cnt[w][r];
@@ -222,42 +276,123 @@ struct PpArgs {
     const U *in[D];
     const uint32_t *cells;
     const int32_t *owner_of_cell;
-    const int32_t *offsets;         // [nranks * nwaves] exclusive scan of the counts
+    const int32_t *offsets;         // [nranks * nwaves + 1] exclusive scan of the counts
     int64_t n, nwaves;
     int nranks, bits, self_rank;
     int64_t self_delta;             // receive offset of the own segment minus its send offset
+    const int64_t *self_offsets;    // or, on the device: {send offset, receive offset}
     U *send, *recv;
 };
 
+struct __attribute__((packed, aligned(4))) PpWords4 { uint32_t x, y, z, w; };
+
+// dynamic LDS: per wave PP_WAVE_ITEMS records, then per wave three tables of `nr_pad` words
+// (first record of an owner's run in the staging area, records ranked so far, global offset)
 template <class U, int D>
-__global__ __launch_bounds__(256) void pp_scatter_kernel(PpArgs<U, D> a)
+__global__ __launch_bounds__(64 * PP_WAVES) void pp_scatter_kernel(PpArgs<U, D> a, int nr_pad)
 {
-    __shared__ int32_t s_run[4][PP_MAX_RANKS];
+    constexpr int RW = D * (int) sizeof(U) / 4;             // 32-bit words per record
+    extern __shared__ __attribute__((aligned(16))) uint32_t pp_lds[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t) blockIdx.x * 4 + w;
+    const int64_t wave = (int64_t) blockIdx.x * PP_WAVES + w;
     if (wave >= a.nwaves) return;
-    for (int r = lane; r < a.nranks; r += 64) s_run[w][r] = a.offsets[(int64_t) r * a.nwaves + wave];
-    __builtin_amdgcn_wave_barrier();
+    uint32_t *stage = pp_lds + (size_t) w * (PP_WAVE_ITEMS * RW);
+    int32_t *s_base = reinterpret_cast<int32_t *>(pp_lds + (size_t) PP_WAVES * (PP_WAVE_ITEMS * RW)) + (size_t) w * 3 * nr_pad;
+    int32_t *s_run = s_base + nr_pad;
+    int32_t *s_goff = s_run + nr_pad;
+
+    // every load of the wave first
     const int64_t base = wave * PP_WAVE_ITEMS + lane;
-    for (int j = 0; j < PP_ITEMS; ++j) {
+    uint32_t d[PP_ROWS];
+    U v[PP_ROWS][D];
+#pragma unroll
+    for (int j = 0; j < PP_ROWS; ++j) {
         const int64_t i = base + (int64_t) j * 64;
-        const bool in = i < a.n;
-        const uint32_t d = in ? (uint32_t) a.owner_of_cell[a.cells[i]] : (uint32_t) a.nranks;
-        U v[D];
+        d[j] = i < a.n ? a.cells[i] : 0u;
+    }
 #pragma unroll
-        for (int ax = 0; ax < D; ++ax) v[ax] = in ? a.in[ax][i] : (U) 0;
-        const uint64_t mask = pp_match(d, a.bits + 1);
+    for (int j = 0; j < PP_ROWS; ++j) {
+        const int64_t i = base + (int64_t) j * 64;
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) v[j][ax] = i < a.n ? a.in[ax][i] : (U) 0;
+    }
+#pragma unroll
+    for (int j = 0; j < PP_ROWS; ++j) {
+        const int64_t i = base + (int64_t) j * 64;
+        d[j] = i < a.n ? (uint32_t) a.owner_of_cell[d[j]] : (uint32_t) a.nranks;
+    }
+
+    // the wave's counts per owner (from the scanned table) -> where an owner's run starts in
+    // the staging area
+    int32_t carry = 0;
+    for (int r0 = 0; r0 < a.nranks; r0 += 64) {
+        const int r = r0 + lane;
+        int32_t g = 0, c = 0;
+        if (r < a.nranks) {
+            const int64_t at = (int64_t) r * a.nwaves + wave;
+            g = a.offsets[at];
+            c = a.offsets[at + 1] - g;
+        }
+        int32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (r < a.nranks) { s_base[r] = carry + incl - c; s_run[r] = 0; s_goff[r] = g; }
+        carry += __shfl(incl, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // rows in order: rank within the owner's run, record into the staging area
+#pragma unroll
+    for (int j = 0; j < PP_ROWS; ++j) {
+        const bool in = d[j] < (uint32_t) a.nranks;
+        const uint64_t mask = pp_match(d[j], a.bits + 1);
         const uint64_t below = mask & ((1ull << lane) - 1ull);
-        int32_t old = 0;
-        if (in) old = s_run[w][d];
+        int32_t old = 0, sb = 0;
+        if (in) { old = s_run[d[j]]; sb = s_base[d[j]]; }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (in && below == 0ull) s_run[w][d] = old + (int32_t) __popcll(mask);
+        if (in && below == 0ull) s_run[d[j]] = old + (int32_t) __popcll(mask);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (in) {
-            const int64_t pos = (int64_t) old + __popcll(below);      // record index, owner-major
-            U *dst = ((int) d == a.self_rank) ? a.recv + (pos + a.self_delta) * D : a.send + pos * D;
+            uint32_t *dst = stage + (size_t) (sb + old + (int32_t) __popcll(below)) * RW;
 #pragma unroll
-            for (int ax = 0; ax < D; ++ax) dst[ax] = v[ax];
+            for (int ax = 0; ax < D; ++ax) {
+                if constexpr (sizeof(U) == 8) {
+                    dst[2 * ax] = (uint32_t) v[j][ax];
+                    dst[2 * ax + 1] = (uint32_t) ((uint64_t) v[j][ax] >> 32);
+                } else {
+                    dst[ax] = (uint32_t) v[j][ax];
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // an owner's run leaves in one piece
+    const int64_t self_delta = a.self_offsets ? a.self_offsets[1] - a.self_offsets[0] : a.self_delta;
+    for (int r = 0; r < a.nranks; ++r) {
+        const int32_t cnt = s_run[r];
+        if (cnt == 0) continue;
+        const uint32_t *src = stage + (size_t) s_base[r] * RW;
+        const int64_t rec = (int64_t) s_goff[r];
+        uint32_t *dst = r == a.self_rank ? reinterpret_cast<uint32_t *>(a.recv) + (rec + self_delta) * RW
+                                         : reinterpret_cast<uint32_t *>(a.send) + rec * RW;
+        const int len = cnt * RW;
+        for (int k = lane * 4; k < len; k += 256) {
+            if (k + 4 <= len) {
+                *reinterpret_cast<PpWords4 *>(dst + k) = PpWords4{src[k], src[k + 1], src[k + 2], src[k + 3]};
+            } else {
+                for (int q = k; q < len; ++q) dst[q] = src[q];
+            }
         }
     }
 }
@@ -265,7 +400,8 @@ __global__ __launch_bounds__(256) void pp_scatter_kernel(PpArgs<U, D> a)
 template <class U, int D>
 int partition_pack_impl(bt_context *ctx, const void *const *in, const uint32_t *cells, int64_t n,
                         const int32_t *owner_of_cell, int nranks, int self_rank,
-                        int64_t self_send_offset, int64_t self_recv_offset, void *send, void *recv)
+                        int64_t self_send_offset, int64_t self_recv_offset, const int64_t *d_self_offsets,
+                        void *send, void *recv, bool wait)
 {
     const int64_t nwaves = div_up(n, PP_WAVE_ITEMS);
     int bits = 0;
@@ -273,7 +409,7 @@ int partition_pack_impl(bt_context *ctx, const void *const *in, const uint32_t *
     Buf<int32_t> counts, offsets;
     BT_CHECK(counts.alloc(ctx->pool, (int64_t) nranks * nwaves));
     BT_CHECK(offsets.alloc(ctx->pool, (int64_t) nranks * nwaves + 1));
-    pp_count_kernel<<<(unsigned) div_up(nwaves, 4), 256, 0, ctx->stream>>>(
+    pp_count_kernel<<<(unsigned) div_up(nwaves, PP_WAVES), 64 * PP_WAVES, 0, ctx->stream>>>(
         cells, n, owner_of_cell, nranks, bits, nwaves, counts.get());
     BT_CHECK((device_exclusive_scan<int64_t, int32_t>(ctx, PpScan{counts.get()}, (int64_t) nranks * nwaves,
                                                       offsets.get(), (int64_t *) nullptr, true)));
@@ -282,13 +418,41 @@ int partition_pack_impl(bt_context *ctx, const void *const *in, const uint32_t *
     a.cells = cells; a.owner_of_cell = owner_of_cell; a.offsets = offsets.get();
     a.n = n; a.nwaves = nwaves; a.nranks = nranks; a.bits = bits; a.self_rank = self_rank;
     a.self_delta = self_recv_offset - self_send_offset;
+    a.self_offsets = d_self_offsets;
     a.send = (U *) send; a.recv = (U *) recv;
-    pp_scatter_kernel<U, D><<<(unsigned) div_up(nwaves, 4), 256, 0, ctx->stream>>>(a);
+    constexpr int RW = D * (int) sizeof(U) / 4;
+    const int nr_pad = (nranks + 3) & ~3;
+    const size_t lds = (size_t) PP_WAVES * ((size_t) PP_WAVE_ITEMS * RW + (size_t) 3 * nr_pad) * 4;
+    pp_scatter_kernel<U, D><<<(unsigned) div_up(nwaves, PP_WAVES), 64 * PP_WAVES, lds, ctx->stream>>>(a, nr_pad);
     BT_HIP_CHECK(hipGetLastError());
-    return bt::finish_call(ctx);
+    return wait ? bt::finish_call(ctx) : BT_OK;
 }
 
 }  // namespace
+
+namespace bt {
+
+int morton_cells_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords, int64_t n,
+                        const void *d_rootbox, int level, uint32_t *cells_out, int32_t *hist_inout)
+{
+    return coord_kind == BT_F64
+        ? cells_dims<double>(ctx, dims, coords, n, nullptr, nullptr, d_rootbox, level, cells_out, hist_inout, false)
+        : cells_dims<float>(ctx, dims, coords, n, nullptr, nullptr, d_rootbox, level, cells_out, hist_inout, false);
+}
+
+int partition_pack_device(bt_context *ctx, int dims, int elem_size, const void *const *in,
+                          const uint32_t *cells, int64_t n, const int32_t *owner_of_cell, int nranks,
+                          int self_rank, const int64_t *d_self_offsets, void *send, void *recv)
+{
+    if (n == 0) return BT_OK;
+#define BT_PP(U, D) partition_pack_impl<U, D>(ctx, in, cells, n, owner_of_cell, nranks, self_rank, 0, 0, \
+                                              d_self_offsets, send, recv, false)
+    if (elem_size == 8) return dims == 1 ? BT_PP(uint64_t, 1) : dims == 2 ? BT_PP(uint64_t, 2) : BT_PP(uint64_t, 3);
+    return dims == 1 ? BT_PP(uint32_t, 1) : dims == 2 ? BT_PP(uint32_t, 2) : BT_PP(uint32_t, 3);
+#undef BT_PP
+}
+
+}  // namespace bt
 
 extern "C" {
 
@@ -303,15 +467,9 @@ int bt_morton_cells(bt_context *ctx, int dims, int coord_kind, const void *const
         return BT_ERR_INVALID;
     }
     BT_HIP_CHECK(hipSetDevice(ctx->device));
-    const bool f64 = coord_kind == BT_F64;
-    switch (dims) {
-    case 1: return f64 ? cells_impl<double, 1>(ctx, coords, n, bbox_min, bbox_max, level, cells_out, hist_inout)
-                       : cells_impl<float, 1>(ctx, coords, n, bbox_min, bbox_max, level, cells_out, hist_inout);
-    case 2: return f64 ? cells_impl<double, 2>(ctx, coords, n, bbox_min, bbox_max, level, cells_out, hist_inout)
-                       : cells_impl<float, 2>(ctx, coords, n, bbox_min, bbox_max, level, cells_out, hist_inout);
-    default: return f64 ? cells_impl<double, 3>(ctx, coords, n, bbox_min, bbox_max, level, cells_out, hist_inout)
-                        : cells_impl<float, 3>(ctx, coords, n, bbox_min, bbox_max, level, cells_out, hist_inout);
-    }
+    return coord_kind == BT_F64
+        ? cells_dims<double>(ctx, dims, coords, n, bbox_min, bbox_max, nullptr, level, cells_out, hist_inout, true)
+        : cells_dims<float>(ctx, dims, coords, n, bbox_min, bbox_max, nullptr, level, cells_out, hist_inout, true);
 }
 
 int bt_bucket_permutation(bt_context *ctx, const uint32_t *cells, int64_t n,
@@ -362,7 +520,7 @@ int bt_partition_pack(bt_context *ctx, int dims, int elem_size, const void *cons
         return BT_ERR_INVALID;
     }
 #define BT_PP(U, D) partition_pack_impl<U, D>(ctx, in, cells, n, owner_of_cell, nranks, self_rank, \
-                                              self_send_offset, self_recv_offset, send, recv)
+                                              self_send_offset, self_recv_offset, nullptr, send, recv, true)
     if (elem_size == 8) return dims == 1 ? BT_PP(uint64_t, 1) : dims == 2 ? BT_PP(uint64_t, 2) : BT_PP(uint64_t, 3);
     return dims == 1 ? BT_PP(uint32_t, 1) : dims == 2 ? BT_PP(uint32_t, 2) : BT_PP(uint32_t, 3);
 #undef BT_PP
@@ -487,43 +645,72 @@ __device__ __forceinline__ int64_t find_path(const uint64_t *a, int64_t lo, int6
     return (l < hi && a[l] == key) ? l : -1;
 }
 
-// one thread per box: the parent by path lookup in the level above; the box then
-// enters itself into its parent's child row (rows are cleared beforehand, a slot
-// nobody claims stays 0)
-template <int D>
-__global__ __launch_bounds__(256) void let_link_kernel(int32_t b0, int32_t b1, int32_t prev0,
-        int64_t aligned, const uint64_t *paths, int32_t *parent_ids, int32_t *child_ids,
-        int32_t *missing_parent)
+// level starts of a level-major box set, for kernels that handle every level in one launch
+struct LevelStarts {
+    int32_t nlevels;
+    int32_t start[BT_MAX_LEVELS + 2];
+};
+
+__device__ __forceinline__ int level_of_box(const LevelStarts &ls, int32_t b)
 {
-    constexpr int C = 1 << D;
-    const int32_t b = b0 + (int32_t) (blockIdx.x * 256 + threadIdx.x);
-    if (b >= b1) return;
-    if (b == 0) { parent_ids[0] = 0; return; }
-    const uint64_t p = paths[b];
-    const int64_t par = find_path(paths, prev0, b0, p >> D);
-    parent_ids[b] = par < 0 ? 0 : (int32_t) par;
-    if (par < 0) { atomicExch(missing_parent, 1); return; }
-    child_ids[(int64_t) (p & (uint64_t) (C - 1)) * aligned + par] = b;
+    int lo = 0, hi = ls.nlevels - 1;          // largest l with start[l] <= b
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ls.start[mid] <= b) lo = mid; else hi = mid - 1;
+    }
+    return lo;
 }
 
-// child centre = parent centre +/- root_extent / 2^(1+level): the builder's own
-// chain of roundings (tree_build_kernels.py:698-705), level by level
+// One thread per box, all levels in one launch: the parent by path lookup in the level above
+// (the box then enters itself into its parent's child row: rows are cleared beforehand, a slot
+// nobody claims stays 0), and the centre by the builder's own chain of roundings from the root
+// (child centre = parent centre +/- root_extent / 2^(1+level), tree_build_kernels.py:698-705),
+// walked down the digits of the path -- the values a level-by-level sweep produces.  A box
+// without parent, or a level that is not ascending by path, raises the device status (code 70).
 template <class T, int D>
-__global__ __launch_bounds__(256) void let_centers_kernel(int32_t b0, int32_t b1, int level,
-        int64_t aligned, const uint64_t *paths, const int32_t *parent_ids, T root_extent,
-        T *centers)
+struct LetLinkArgs {
+    LevelStarts ls;
+    int64_t aligned;
+    const uint64_t *paths;
+    int32_t *parent_ids, *child_ids;
+    T *centers;
+    T root_center[D];
+    T root_extent;
+    DeviceStatus *status;
+};
+
+template <class T, int D>
+__global__ __launch_bounds__(256) void let_link_kernel(LetLinkArgs<T, D> a)
 {
-    const int32_t b = b0 + blockIdx.x * 256 + threadIdx.x;
-    if (b >= b1) return;
-    const int32_t par = parent_ids[b];
-    const int m = (int) (paths[b] & ((1u << D) - 1));
-    const T radius = (root_extent * 1 / (T) (1ull << (1 + level)));
-#pragma unroll
-    for (int ax = 0; ax < D; ++ax) {
-        const bool has_bit = (m >> (D - 1 - ax)) & 1;
-        const T pc = centers[(int64_t) ax * aligned + par];
-        centers[(int64_t) ax * aligned + b] = has_bit ? pc + radius : pc - radius;
+    constexpr int C = 1 << D;
+    const int32_t nboxes = a.ls.start[a.ls.nlevels];
+    const int32_t b = (int32_t) (blockIdx.x * 256 + threadIdx.x);
+    if (b >= nboxes) return;
+    const int lev = level_of_box(a.ls, b);
+    const uint64_t p = a.paths[b];
+    if (lev == 0) {
+        a.parent_ids[b] = 0;
+    } else {
+        const int64_t par = find_path(a.paths, a.ls.start[lev - 1], a.ls.start[lev], p >> D);
+        a.parent_ids[b] = par < 0 ? 0 : (int32_t) par;
+        if (par < 0) atomicExch(&a.status->internal, 70);
+        else a.child_ids[(int64_t) (p & (uint64_t) (C - 1)) * a.aligned + par] = b;
+        if (b > a.ls.start[lev] && !(a.paths[b - 1] < p)) atomicExch(&a.status->internal, 70);
     }
+    T c[D];
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) c[ax] = a.root_center[ax];
+    for (int l = 1; l <= lev; ++l) {
+        const int m = (int) ((p >> (D * (lev - l))) & (uint64_t) (C - 1));
+        const T radius = (a.root_extent * 1 / (T) (1ull << (1 + l)));
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) {
+            const bool has_bit = (m >> (D - 1 - ax)) & 1;
+            c[ax] = has_bit ? c[ax] + radius : c[ax] - radius;
+        }
+    }
+#pragma unroll
+    for (int ax = 0; ax < D; ++ax) a.centers[(int64_t) ax * a.aligned + b] = c[ax];
 }
 
 template <class T, int D>
@@ -533,45 +720,65 @@ int let_build_impl(bt_context *ctx, int nlevels, const int32_t *level_starts, co
 {
     constexpr int C = 1 << D;
     const int32_t nboxes = level_starts[nlevels];
-    Buf<int32_t> d_missing;
-    BT_CHECK(d_missing.alloc(ctx->pool, 1));
-    BT_HIP_CHECK(hipMemsetAsync(d_missing.get(), 0, 4, ctx->stream));
     BT_HIP_CHECK(hipMemsetAsync(child_ids, 0, (size_t) C * (size_t) aligned * 4, ctx->stream));
-    for (int lev = 0; lev < nlevels; ++lev) {
-        const int32_t b0 = level_starts[lev], b1 = level_starts[lev + 1];
-        if (b1 <= b0) continue;
-        const int32_t prev0 = lev > 0 ? level_starts[lev - 1] : 0;
-        let_link_kernel<D><<<(unsigned) div_up(b1 - b0, 256), 256, 0, ctx->stream>>>(
-            b0, b1, prev0, aligned, paths, parent_ids, child_ids, d_missing.get());
-    }
+    if (nboxes <= 0) return BT_OK;
+    LetLinkArgs<T, D> a{};
+    a.ls.nlevels = nlevels;
+    for (int l = 0; l <= nlevels; ++l) a.ls.start[l] = level_starts[l];
+    a.aligned = aligned; a.paths = paths; a.parent_ids = parent_ids; a.child_ids = child_ids;
+    a.centers = centers;
     // root centre: tree_build.py:585-590
-    T root[D];
     for (int ax = 0; ax < D; ++ax) {
         const T mn = (T) bbox_min[ax], mx = (T) bbox_max[ax];
-        root[ax] = mn + (mx - mn) / 2;
-        BT_HIP_CHECK(hipMemcpyAsync(centers + (int64_t) ax * aligned, &root[ax], sizeof(T),
-                                    hipMemcpyHostToDevice, ctx->stream));
+        a.root_center[ax] = mn + (mx - mn) / 2;
     }
-    BT_CHECK(bt::sync_stream(ctx));        // `root` goes out of scope
-    for (int lev = 1; lev < nlevels; ++lev) {
-        const int32_t b0 = level_starts[lev], b1 = level_starts[lev + 1];
-        if (b1 <= b0) continue;
-        let_centers_kernel<T, D><<<(unsigned) div_up(b1 - b0, 256), 256, 0, ctx->stream>>>(
-            b0, b1, lev, aligned, paths, parent_ids, (T) root_extent, centers);
-    }
+    a.root_extent = (T) root_extent;
+    a.status = ctx->d_status;
+    let_link_kernel<T, D><<<(unsigned) div_up(nboxes, 256), 256, 0, ctx->stream>>>(a);
     BT_HIP_CHECK(hipGetLastError());
-    int32_t missing = 0;
-    BT_CHECK(bt::d2h(ctx, &missing, d_missing.get(), 4));
-    BT_CHECK(bt::sync_stream(ctx));
-    if (missing) {
-        set_error("bt_let_build: a box has no parent among the boxes of the level above "
-                  "(%d boxes)", nboxes);
-        return BT_ERR_INVALID;
-    }
+    return BT_OK;
+}
+
+template <class T, int D>
+int box_paths_impl(bt_context *ctx, int64_t nboxes, int64_t aligned_nboxes, const void *box_centers,
+                   const uint8_t *box_levels, const double *bbox_min, double root_extent, uint64_t *paths)
+{
+    const double m0 = bbox_min[0], m1 = D > 1 ? bbox_min[1] : 0, m2 = D > 2 ? bbox_min[2] : 0;
+    box_paths_kernel<T, D><<<(unsigned) div_up(nboxes, 256), 256, 0, ctx->stream>>>(
+        nboxes, aligned_nboxes, (const T *) box_centers, box_levels, m0, m1, m2, root_extent, paths);
+    BT_HIP_CHECK(hipGetLastError());
     return BT_OK;
 }
 
 }  // namespace
+
+namespace bt {
+
+int box_paths_device(bt_context *ctx, int dims, int coord_kind, int64_t nboxes, int64_t aligned_nboxes,
+                     const void *box_centers, const uint8_t *box_levels, const double *bbox_min,
+                     double root_extent, uint64_t *paths)
+{
+    if (nboxes == 0) return BT_OK;
+#define BP(T, D) return box_paths_impl<T, D>(ctx, nboxes, aligned_nboxes, box_centers, box_levels, bbox_min, root_extent, paths)
+    if (coord_kind == BT_F64) { if (dims == 1) BP(double, 1); else if (dims == 2) BP(double, 2); else BP(double, 3); }
+    else { if (dims == 1) BP(float, 1); else if (dims == 2) BP(float, 2); else BP(float, 3); }
+#undef BP
+}
+
+int let_link_device(bt_context *ctx, int dims, int coord_kind, int nlevels, const int32_t *level_start_box_nrs,
+                    const uint64_t *paths, int64_t aligned_nboxes, const double *bbox_min,
+                    const double *bbox_max, double root_extent, int32_t *box_parent_ids,
+                    int32_t *box_child_ids, void *box_centers)
+{
+#define LB(T, D) return let_build_impl<T, D>(ctx, nlevels, level_start_box_nrs, paths,            \
+        aligned_nboxes, bbox_min, bbox_max, root_extent, box_parent_ids, box_child_ids,           \
+        (T *) box_centers)
+    if (coord_kind == BT_F64) { if (dims == 1) LB(double, 1); else if (dims == 2) LB(double, 2); else LB(double, 3); }
+    else { if (dims == 1) LB(float, 1); else if (dims == 2) LB(float, 2); else LB(float, 3); }
+#undef LB
+}
+
+}  // namespace bt
 
 extern "C" {
 
@@ -587,14 +794,8 @@ int bt_box_morton_paths(bt_context *ctx, int dims, int coord_kind, int64_t nboxe
     }
     BT_HIP_CHECK(hipSetDevice(ctx->device));
     if (nboxes == 0) return BT_OK;
-    const unsigned blocks = (unsigned) div_up(nboxes, 256);
-    const double m0 = bbox_min[0], m1 = dims > 1 ? bbox_min[1] : 0, m2 = dims > 2 ? bbox_min[2] : 0;
-#define BP(T, D) box_paths_kernel<T, D><<<blocks, 256, 0, ctx->stream>>>(                    \
-        nboxes, aligned_nboxes, (const T *) box_centers, box_levels, m0, m1, m2, root_extent, paths)
-    if (coord_kind == BT_F64) { if (dims == 1) BP(double, 1); else if (dims == 2) BP(double, 2); else BP(double, 3); }
-    else { if (dims == 1) BP(float, 1); else if (dims == 2) BP(float, 2); else BP(float, 3); }
-#undef BP
-    BT_HIP_CHECK(hipGetLastError());
+    BT_CHECK(bt::box_paths_device(ctx, dims, coord_kind, nboxes, aligned_nboxes, box_centers, box_levels,
+                                  bbox_min, root_extent, paths));
     BT_CHECK(bt::sync_stream(ctx));
     return BT_OK;
 }
@@ -612,12 +813,11 @@ int bt_let_build(bt_context *ctx, int dims, int coord_kind, int nlevels,
         return BT_ERR_INVALID;
     }
     BT_HIP_CHECK(hipSetDevice(ctx->device));
-#define LB(T, D) return let_build_impl<T, D>(ctx, nlevels, level_start_box_nrs, paths,            \
-        aligned_nboxes, bbox_min, bbox_max, root_extent, box_parent_ids, box_child_ids,           \
-        (T *) box_centers)
-    if (coord_kind == BT_F64) { if (dims == 1) LB(double, 1); else if (dims == 2) LB(double, 2); else LB(double, 3); }
-    else { if (dims == 1) LB(float, 1); else if (dims == 2) LB(float, 2); else LB(float, 3); }
-#undef LB
+    BT_CHECK(reset_status(ctx));
+    BT_CHECK(bt::let_link_device(ctx, dims, coord_kind, nlevels, level_start_box_nrs, paths, aligned_nboxes,
+                                 bbox_min, bbox_max, root_extent, box_parent_ids, box_child_ids, box_centers));
+    // a box without parent among the boxes of the level above: device status code 70
+    return bt::finish_call(ctx);
 }
 
 }  // extern "C"

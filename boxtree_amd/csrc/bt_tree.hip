@@ -173,6 +173,53 @@ int bbox_impl(bt_context *ctx, int dims, const void *const *coords, const void *
     return BT_OK;
 }
 
+// (min, -max) per axis of the per-workgroup pairs, folded into mm[0..D) / mm[D..2D) with MIN:
+// the form an all-reduce(MIN) over ranks takes (bt_mgpu.hip)
+template <class T>
+__global__ __launch_bounds__(256) void bbox_fold_kernel(const T *partial, int nblk, int D, double *mm)
+{
+    __shared__ T s_mn[256], s_mx[256];
+    for (int ax = 0; ax < D; ++ax) {
+        T mn = CoordTraits<T>::maxval, mx = -CoordTraits<T>::maxval;
+        const T *ps = partial + (int64_t) 2 * nblk * ax;
+        for (int b = threadIdx.x; b < nblk; b += 256) {
+            mn = (ps[2 * b] < mn) ? ps[2 * b] : mn;
+            mx = (ps[2 * b + 1] > mx) ? ps[2 * b + 1] : mx;
+        }
+        s_mn[threadIdx.x] = mn; s_mx[threadIdx.x] = mx;
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if ((int) threadIdx.x < off) {
+                const T a = s_mn[threadIdx.x + off], c = s_mx[threadIdx.x + off];
+                if (a < s_mn[threadIdx.x]) s_mn[threadIdx.x] = a;
+                if (c > s_mx[threadIdx.x]) s_mx[threadIdx.x] = c;
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const double lo = (double) s_mn[0], nhi = -(double) s_mx[0];
+            if (lo < mm[ax]) mm[ax] = lo;
+            if (nhi < mm[D + ax]) mm[D + ax] = nhi;
+        }
+        __syncthreads();
+    }
+}
+
+template <class T>
+int bbox_fold_impl(bt_context *ctx, int dims, const void *const *coords, int64_t n, double *d_mm)
+{
+    if (n == 0) return BT_OK;
+    const int64_t blocks = std::min<int64_t>(div_up(n, BBOX_THREADS * 8), (int64_t) ctx->num_cus * 8);
+    Buf<T> partial;
+    BT_CHECK(partial.alloc(ctx->pool, 2 * blocks * dims));
+    BboxAxes<T> axs{};
+    for (int ax = 0; ax < dims; ++ax) axs.x[ax] = (const T *) coords[ax];
+    bbox_axes_kernel<T><<<dim3((unsigned) blocks, dims), BBOX_THREADS, 0, ctx->stream>>>(axs, n, partial.get());
+    bbox_fold_kernel<T><<<1, 256, 0, ctx->stream>>>(partial.get(), (int) blocks, dims, d_mm);
+    BT_HIP_CHECK(hipGetLastError());
+    return BT_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Morton keys (tbk:308-470)
 // ---------------------------------------------------------------------------
@@ -3604,6 +3651,19 @@ int dispatch_dims_export(bt_context *ctx, TreeState *st, const bt_tree_arrays *o
 }  // namespace
 
 int bt_trav_stage_times(bt_context *ctx, bt_stage_times *out, int n);   // bt_trav.hip
+
+namespace bt {
+
+// Bounding box of dense coordinate arrays, left on the device: d_mm[0..dims) = min(d_mm, min),
+// d_mm[dims..2 dims) = min(d_mm, -max) -- no host wait (the multi-GPU exchange all-reduces it).
+int bbox_minmax_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords, int64_t n,
+                       double *d_mm)
+{
+    return coord_kind == BT_F64 ? bbox_fold_impl<double>(ctx, dims, coords, n, d_mm)
+                                : bbox_fold_impl<float>(ctx, dims, coords, n, d_mm);
+}
+
+}  // namespace bt
 
 extern "C" {
 

@@ -117,6 +117,29 @@ def rccl_comm(actx, dist, self_loopback=None):
     return NativeComm(actx.lib, h, dist.get_rank(), dist.get_world_size(), "rccl", keep=rc)
 
 
+def exchange_time_ms(actx):
+    """Device time of the payload all-to-all-v of the last exchange on *actx* (waits for it)."""
+    ms = ct.c_float()
+    _lib.check(actx.lib.bt_mgpu_exchange_time(actx.handle, ct.byref(ms)))
+    return float(ms.value)
+
+
+class _LazyA2aTime:
+    """``float(stats["a2a_ms"])``: resolved when asked for -- on a stream-ordered context the
+    exchange returns with the all-to-all-v still queued."""
+
+    def __init__(self, actx, value):
+        self.actx, self.value = actx, value
+
+    def __float__(self):
+        if self.value < 0:
+            self.value = exchange_time_ms(self.actx)
+        return float(self.value)
+
+    def __gt__(self, other):
+        return float(self) > other
+
+
 def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=None,
                        own_buffer=False, targets=None):
     """Steps 1-3 (``bt_mgpu_exchange``).  Returns ``(particles, build_kw, stats)`` for the
@@ -189,7 +212,7 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
             _DevicePointer(shard.top_cell_prefix, ((1 << (dims * k)) + 1,), "<i8"), device=dev)
         build_kw["_top_tree"] = (k, prefix)
     stats = dict(bytes_sent=int(shard.bytes_sent), rounds=int(shard.rounds), top_level=k,
-                 a2a_ms=float(shard.a2a_ms),
+                 a2a_ms=_LazyA2aTime(actx, float(shard.a2a_ms)),
                  bbox_min=bbox_min, bbox_max=bbox_max, root_extent=root_extent,
                  planned=bool(shard.top_cell_prefix), recv_buffer=got.get("buf"))
     return new_particles, build_kw, stats
@@ -219,7 +242,7 @@ def _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev):
             _DevicePointer(shard.top_cell_prefix, ((1 << (dims * k)) + 1,), "<i8"), device=dev)
         build_kw["_top_tree"] = (k, prefix)
     stats = dict(bytes_sent=int(shard.bytes_sent), rounds=int(shard.rounds), top_level=k,
-                 a2a_ms=float(shard.a2a_ms), bbox_min=bbox_min, bbox_max=bbox_max,
+                 a2a_ms=_LazyA2aTime(actx, float(shard.a2a_ms)), bbox_min=bbox_min, bbox_max=bbox_max,
                  root_extent=root_extent, planned=bool(shard.top_cell_prefix))
     return out[0], out[1], build_kw, stats
 
@@ -297,6 +320,9 @@ def build_local_essential_tree(actx, comm, tree, numbering, well_sep_is_n_away=1
         box_id_dtype=np.dtype(np.int32), box_level_dtype=np.dtype(np.uint8),
         coord_dtype=coord_dtype, sources_have_extent=False, targets_have_extent=False,
         extent_norm=None, stick_out_factor=tree.stick_out_factor, _is_pruned=True)
+    # made by the library on this device: contiguous arrays of its own types -- the traversal
+    # builder takes them as they are (no conversions, no look at the root's parent entry)
+    object.__setattr__(let, "_host_level_starts", lsb)
     ranges = np.array([[sizes.active_level_ranges[l][0], sizes.active_level_ranges[l][1]]
                        for l in range(nlev)], dtype=np.int32)
     info = dict(target_boxes_mask=mask, active_level_ranges=ranges, global_box_ids=gids,

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BT_ABI_VERSION 5
+#define BT_ABI_VERSION 6
 #define BT_MAX_DIMS 3
 #define BT_MAX_LEVELS 64       /* capacity of per-level arrays in the structs */
 
@@ -597,7 +597,8 @@ typedef struct {
     int64_t bytes_sent;                /* payload bytes that left this GPU              */
     int32_t rounds;                    /* point-to-point rounds of the all-to-all       */
     float a2a_ms;                      /* device time of the payload all-to-all-v (HIP   */
-                                       /* events on the context's stream)               */
+                                       /* events on the context's stream); -1 on a       */
+                                       /* stream-ordered context: bt_mgpu_exchange_time  */
     int64_t n_owned_targets;           /* separate targets: the ones this rank owns, laid */
     void *target_points;               /* out like `points` (second allocation)          */
     int32_t sep_targets;               /* 1: some rank passed separate targets, so every  */
@@ -609,12 +610,19 @@ typedef struct {
 #define BT_MGPU_MAX_RANKS 256
 
 /* Steps 1-3: global root box, ownership cells, the particles this rank owns.  The call
- * returns when the shard is complete.  Feed the shard to bt_tree_build with sources[ax] =
+ * returns when the shard is complete -- on a stream-ordered context (bt_set_stream_ordered)
+ * when the payload exchange is QUEUED on the context's stream: sizes, root box and pointers
+ * are final, the received particles are there for whatever is queued on that stream next
+ * (the host waits once, for the all-reduced cell histogram).  Feed the shard to bt_tree_build with sources[ax] =
  * (char *) points + ax * sizeof(coord), source_stride = dims, the root box, top_level and
  * top_cell_prefix.  The context remembers the plan (the top of the global tree, the owner
  * of every cell) for bt_mgpu_number and bt_mgpu_let_build. */
 int bt_mgpu_exchange(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *params,
                      bt_mgpu_shard *out);
+
+/* Device time of the last exchange's payload all-to-all-v on this context, in milliseconds
+ * (waits for it if it is still running). */
+int bt_mgpu_exchange_time(bt_context *ctx, float *a2a_ms);
 
 /* The host part of the exchange, a pure function of the all-reduced level-top_level
  * cell histogram: owner rank of every cell (contiguous Morton ranges balanced by
