@@ -248,8 +248,9 @@ int let_link_device(bt_context *ctx, int dims, int coord_kind, int nlevels, cons
                     const double *bbox_max, double root_extent, int32_t *box_parent_ids,
                     int32_t *box_child_ids, void *box_centers);
 // bt_partition_pack whose own-segment offsets are read from device memory when the kernel runs
-// (d_self_offsets = {send offset, receive offset} in records); no wait
+// (d_self_offsets = {send offset, receive offset} in records); ncells: length of owner_of_cell
+// (the table goes to LDS if it fits), 0 if unknown; no wait
 int partition_pack_device(bt_context *ctx, int dims, int elem_size, const void *const *in,
-                          const uint32_t *cells, int64_t n, const int32_t *owner_of_cell, int nranks,
+                          const uint32_t *cells, int64_t n, const int32_t *owner_of_cell, int ncells, int nranks,
                           int self_rank, const int64_t *d_self_offsets, void *send, void *recv);
 }  // namespace bt

@@ -985,7 +985,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
             BT_CHECK(own.alloc(ctx->pool, points_bytes));
             points_of[s] = own.get();
         }
-        BT_CHECK(bt::partition_pack_device(ctx, D, es, cset[s], cells[s].get(), n, owner_d.get(), nranks, rank,
+        BT_CHECK(bt::partition_pack_device(ctx, D, es, cset[s], cells[s].get(), n, owner_d.get(), (int) ncells, nranks, rank,
                                            self_d.get() + 2 * s, send[s].get(),
                                            loop_self ? send[s].get() : points_of[s]));
     }

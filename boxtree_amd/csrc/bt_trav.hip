@@ -1656,8 +1656,9 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         const int32_t *tls = st->h_lev_starts.data() + (nlevels + 1);    // target boxes per level
         int first_tgt = 0;
         while (first_tgt < nlevels && tls[first_tgt + 1] == tls[first_tgt]) ++first_tgt;
+        // (with a target_boxes_mask the counts are those of the masked target boxes, the only
+        // ones the walk makes items for)
         st->l3_lo = std::max(0, std::min(nlevels - 1, first_tgt + 1));
-        if (p.target_boxes_mask) st->l3_lo = 0;
     }
     const int64_t nflat_box = (int64_t) (nlevels - st->l3_lo) * ntb;
     BT_CHECK(st->l3_starts.alloc(ctx->pool, nflat_box + 1));
