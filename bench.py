@@ -353,11 +353,11 @@ def main():
     torch.cuda.synchronize()
     xinfo = {}
 
-    # N > 1 over RCCL, point particles: the library's own multi-GPU entries.  Other process
-    # groups (gloo: ranks that share a GPU) and workloads with separate targets / extents
-    # go through the torch implementation of the same steps.
+    # N > 1 over RCCL, point particles (sources, and separate point targets): the library's
+    # own multi-GPU entries.  Other process groups (gloo: ranks that share a GPU) and workloads
+    # with extents or refine weights go through the torch implementation of the same steps.
     native_comm = None
-    if (distributed and backend == "nccl" and targets is None and not build_kw
+    if (distributed and backend == "nccl" and not build_kw
             and os.environ.get("BOXTREE_HIP_NATIVE_MGPU", "1") != "0"):
         from boxtree_amd.distributed import native as nat
         try:
@@ -400,10 +400,16 @@ def main():
             # steps 1-6 behind the C ABI (bt_mgpu_*): exchange, build, numbering, local
             # essential tree, lists of the rank's own boxes
             from boxtree_amd.distributed import native as nat
-            p_, kw_, xs = nat.exchange_particles(actx, native_comm, particles, args.mpb)
+            if targets is None:
+                p_, kw_, xs = nat.exchange_particles(actx, native_comm, particles, args.mpb)
+                t_ = None
+            else:
+                # separate point targets travel to the owners of their cells like the sources
+                p_, t_, kw_, xs = nat.exchange_particles(actx, native_comm, particles, args.mpb,
+                                                         targets=targets)
             last_exchange.update(bytes_sent=int(xs["bytes_sent"]), owned=int(len(p_[0])),
                                  a2a_ms=xs["a2a_ms"])
-            tree, _ = tb(actx, p_, max_particles_in_box=args.mpb, **kw_)
+            tree, _ = tb(actx, p_, targets=t_, max_particles_in_box=args.mpb, **kw_)
             st = _lib.SortStats()
             actx.lib.bt_get_sort_stats(actx.handle, st)
             num = nat.number_sharded_tree(actx, native_comm, tree)

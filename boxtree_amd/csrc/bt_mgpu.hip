@@ -798,7 +798,7 @@ int bt_mgpu_plan(int dims, int top_level, int64_t max_particles_in_box, int nran
         set_error("bt_mgpu_plan: invalid argument");
         return BT_ERR_INVALID;
     }
-    TopPlan pl;
+    static thread_local TopPlan pl;      // (its tables are reused from call to call)
     compute_plan(dims, top_level, max_particles_in_box, nranks, global_hist, pl);
     std::copy(pl.owner.begin(), pl.owner.end(), owner_of_cell);
     if (cell_prefix) std::copy(pl.prefix.begin(), pl.prefix.end(), cell_prefix);
