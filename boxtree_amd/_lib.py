@@ -30,7 +30,7 @@ P3 = vp * BT_MAX_DIMS
 PL = vp * BT_MAX_LEVELS
 
 
-ABI_VERSION = 6      # BT_ABI_VERSION of include/boxtree_hip.h
+ABI_VERSION = 7      # BT_ABI_VERSION of include/boxtree_hip.h
 
 
 class SortStats(ct.Structure):
@@ -56,6 +56,7 @@ class TreeParams(ct.Structure):
         ("top_level", ct.c_int32), ("top_cell_prefix", vp),
         ("source_stride", ct.c_int64), ("target_stride", ct.c_int64),
         ("compute_root_box", ct.c_int32), ("root_extent_stretch", ct.c_double),
+        ("top_box_arrive", vp), ("top_box_stay", vp),
     ]
 
 
@@ -168,7 +169,8 @@ class MgpuParams(ct.Structure):
     _fields_ = [("dims", ct.c_int32), ("coord_kind", ct.c_int32), ("n", ct.c_int64),
                 ("coords", P3), ("top_level", ct.c_int32),
                 ("max_particles_in_box", ct.c_int64), ("alloc", vp), ("alloc_user", vp),
-                ("ntargets", ct.c_int64), ("targets", P3)]
+                ("ntargets", ct.c_int64), ("targets", P3),
+                ("target_radii", vp), ("stick_out_factor", ct.c_double), ("extent_norm", ct.c_int32)]
 
 
 class MgpuShard(ct.Structure):
@@ -177,7 +179,8 @@ class MgpuShard(ct.Structure):
                 ("root_extent", ct.c_double), ("top_level", ct.c_int32),
                 ("top_cell_prefix", vp), ("bytes_sent", ct.c_int64), ("rounds", ct.c_int32),
                 ("a2a_ms", ct.c_float), ("n_owned_targets", ct.c_int64), ("target_points", vp),
-                ("sep_targets", ct.c_int32)]
+                ("sep_targets", ct.c_int32), ("target_record_len", ct.c_int32),
+                ("top_box_arrive", vp), ("top_box_stay", vp)]
 
 
 class MgpuLocalTree(ct.Structure):

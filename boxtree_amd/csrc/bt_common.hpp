@@ -233,8 +233,15 @@ int copy_to_pinned(bt_context *ctx, void *pinned_dst, const void *dev_src, size_
 
 // ---- pieces of the multi-GPU exchange that live beside the single-GPU kernels they share
 // code with (bt_tree.hip, bt_shard.hip); callers: bt_mgpu.hip
-int bbox_minmax_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords, int64_t n,
-                       double *d_mm);
+int bbox_minmax_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords,
+                       const void *radii, int64_t n, double *d_mm);
+// ... for particles with extents: the cell of a particle that sticks out of the boxes of the top
+// levels is the first cell under the box it stays in; hist_stay counts those per top box
+// (levels 0..level, index (C^l - 1) / (C - 1) + path)
+int morton_cells_ext_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords,
+                            const void *radii, int64_t n, const void *d_rootbox, int level,
+                            double stick_out_factor, int extent_norm, uint32_t *cells_out,
+                            int32_t *hist_cells, int32_t *hist_stay);
 // bt_morton_cells with the root box read from device memory ({min[3], max[3], extent, 0} in the
 // coordinate type, the layout of the tree build's own root box); no wait
 int morton_cells_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords, int64_t n,

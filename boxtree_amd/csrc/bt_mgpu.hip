@@ -331,6 +331,8 @@ struct TopPlan {
     bool valid = false;
     int D = 0, k = 0, nranks = 0;
     int64_t mpb = 0;
+    bool has_stay = false;                        // particles with extents: `stay` is filled
+    std::vector<std::vector<int64_t>> stay;       // [k+1][C^lev]: particles that stay in the box
     std::vector<std::vector<int64_t>> counts;     // [k+1][C^lev]
     std::vector<std::vector<char>> exists, split;
     std::vector<std::vector<int32_t>> index;      // number of a box among the existing boxes of its level
@@ -343,20 +345,46 @@ struct TopPlan {
     double bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0}, root_extent = 0;
 };
 
-void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, TopPlan &pl)
+// index of box (level, path) in a table over the boxes of levels 0..k
+inline int64_t top_table_offset(int D, int level)
+{
+    int64_t off = 0, pw = 1;
+    for (int l = 0; l < level; ++l) { off += pw; pw <<= D; }
+    return off;
+}
+
+// hist: particles per level-k cell (a particle with an extent that stays in a box above level k
+// counts for the first cell under that box); stay (or NULL: point particles): per box of levels
+// 0..k the particles that stay in it, top_table_offset(level) + path.
+void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, const int64_t *stay, TopPlan &pl)
 {
     const int C = 1 << D;
     const int64_t ncells = (int64_t) 1 << (D * k);
     pl.D = D; pl.k = k; pl.mpb = mpb; pl.nranks = nranks;
+    pl.has_stay = stay != nullptr;
+    // counts[lev][i]: the particles that arrive in box (lev, i) -- its cumulative count
     pl.counts.resize((size_t) k + 1);
+    pl.stay.resize(stay ? (size_t) k + 1 : 0);
     pl.counts[k].assign(hist, hist + ncells);
+    if (stay) {
+        for (int lev = 0; lev <= k; ++lev) {
+            const int64_t n = (int64_t) 1 << (D * lev);
+            pl.stay[lev].assign(stay + top_table_offset(D, lev), stay + top_table_offset(D, lev) + n);
+        }
+        // the stayers of the boxes above level k were counted at their first cell
+        for (int lev = 0; lev < k; ++lev) {
+            const int64_t n = (int64_t) 1 << (D * lev);
+            const int sh = D * (k - lev);
+            for (int64_t i = 0; i < n; ++i) pl.counts[k][(size_t) (i << sh)] -= pl.stay[lev][(size_t) i];
+        }
+    }
     for (int lev = k - 1; lev >= 0; --lev) {
         const int64_t n = (int64_t) 1 << (D * lev);
         pl.counts[lev].resize((size_t) n);
         const int64_t *below = pl.counts[lev + 1].data();
         int64_t *here = pl.counts[lev].data();
         for (int64_t i = 0; i < n; ++i) {
-            int64_t sum = 0;
+            int64_t sum = stay ? pl.stay[lev][(size_t) i] : 0;
             for (int m = 0; m < C; ++m) sum += below[i * C + m];
             here[i] = sum;
         }
@@ -379,11 +407,13 @@ void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, To
             pl.index[lev].resize((size_t) n);
             const char *ex = pl.exists[lev].data();
             const int64_t *cnt = pl.counts[lev].data();
+            const int64_t *st = stay ? pl.stay[lev].data() : nullptr;
             char *sp = pl.split[lev].data();
             int32_t *ix = pl.index[lev].data();
             int32_t run = 0;
             for (int64_t i = 0; i < n; ++i) {
-                sp[i] = ex[i] && cnt[i] > mpb;
+                // tbk:569-591: what is bound for the children decides
+                sp[i] = ex[i] && cnt[i] - (st ? st[i] : 0) > mpb;
                 run += ex[i] ? 1 : 0;
                 ix[i] = run - 1;
             }
@@ -413,6 +443,9 @@ void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, To
     // contiguous Morton ranges balanced by particle count: a cell goes to the rank whose
     // ideal range contains the first particle of its unit, floor(prefix * nranks / total).
     // Units ascend with the cells, so the rank only ever grows: no division per cell.
+    // (The particles that stay in an internal box above level k sit at its first cell: they
+    // precede everything below the box in the tree's particle order, and the rank that owns
+    // that cell owns them -- a rank's particles stay one contiguous range of the global order.)
     const int64_t total = std::max<int64_t>(pl.counts[0][0], 1);
     pl.prefix.resize((size_t) ncells + 1);
     pl.prefix[0] = 0;
@@ -465,6 +498,7 @@ struct MgpuState {
     Buf<unsigned char> points;       // received particles, interleaved [n_owned][dims]
     Buf<unsigned char> tpoints;      // ... separate targets
     Buf<int64_t> cell_prefix;        // [C^top_level + 1]
+    Buf<int64_t> top_tables;         // extents: arrivals, stayers per box of levels 0..top_level
     TopPlan plan;                    // of the last exchange on this context
     std::vector<int64_t> ghist;      // combined global cell histogram of that exchange
     hipEvent_t ev[2] = {nullptr, nullptr};   // around the payload all-to-all-v
@@ -799,7 +833,7 @@ int bt_mgpu_plan(int dims, int top_level, int64_t max_particles_in_box, int nran
         return BT_ERR_INVALID;
     }
     static thread_local TopPlan pl;      // (its tables are reused from call to call)
-    compute_plan(dims, top_level, max_particles_in_box, nranks, global_hist, pl);
+    compute_plan(dims, top_level, max_particles_in_box, nranks, global_hist, nullptr, pl);
     std::copy(pl.owner.begin(), pl.owner.end(), owner_of_cell);
     if (cell_prefix) std::copy(pl.prefix.begin(), pl.prefix.end(), cell_prefix);
     return BT_OK;
@@ -833,12 +867,25 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     // of the shared top boxes, so it cannot be a rank's own view of its chunk)
     const int64_t nset[2] = {p->n, p->ntargets};
     const void *const *cset[2] = {p->coords, p->targets};
+    // targets with extents (the same on every rank: extent_norm is a parameter of the job)
+    const bool ext = p->extent_norm != BT_NORM_NONE;
+    if (ext && ((p->extent_norm != BT_NORM_LINF && p->extent_norm != BT_NORM_L2)
+                || (p->ntargets > 0 && !p->target_radii) || p->max_particles_in_box <= 0)) {
+        set_error("bt_mgpu_exchange: extents need extent_norm linf or l2, target_radii on every rank "
+                  "that has targets, and max_particles_in_box > 0");
+        return BT_ERR_INVALID;
+    }
+    const void *rset[2] = {nullptr, ext ? p->target_radii : nullptr};
     hipStream_t stream = ctx->stream;
 
     MgpuState *ms = mgpu_state(ctx);
     const int k = p->top_level > 0 ? p->top_level : (D == 3 ? 5 : D == 2 ? 7 : 12);
     const int64_t ncells = (int64_t) 1 << (D * k);
     const int64_t row = 2 * (int64_t) nranks;
+    // histogram words: source cells, target cells, and with extents the targets that stay in
+    // a box of levels 0..k
+    const int64_t ntop1 = top_table_offset(D, k + 1);
+    const int64_t nh = 2 * ncells + (ext ? ntop1 : 0);
     if (!ms->ev[0]) {
         BT_HIP_CHECK(hipEventCreate(&ms->ev[0]));
         BT_HIP_CHECK(hipEventCreate(&ms->ev[1]));
@@ -849,10 +896,11 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     BT_CHECK(arena_reclaim(ms, true));
     // pinned block: [box: 16 doubles][local hist: 2 ncells i32][global hist: 2 ncells i64]
     // [owner: ncells i32][send counts: row i64][matrix: row * nranks i64][prefix: ncells + 1 i64]
-    const size_t o_box = 0, o_local = 128, o_ghist = o_local + (size_t) ncells * 8,
-        o_owner = o_ghist + (size_t) ncells * 16, o_send = o_owner + (size_t) ncells * 4,
+    const size_t o_box = 0, o_local = 128, o_ghist = o_local + (((size_t) nh * 4 + 7) & ~(size_t) 7),
+        o_owner = o_ghist + (size_t) nh * 8, o_send = o_owner + (size_t) ncells * 4,
         o_matrix = o_send + (size_t) row * 8, o_prefix = o_matrix + (size_t) row * nranks * 8,
-        pin_need = o_prefix + (size_t) (ncells + 1) * 8;
+        o_tables = o_prefix + (size_t) (ncells + 1) * 8,
+        pin_need = o_tables + (ext ? (size_t) ntop1 * 16 : 0);
     if (ms->pin_cap < pin_need) {
         if (ms->pin) { BT_HIP_CHECK(hipStreamSynchronize(stream)); (void) hipHostFree(ms->pin); ms->pin = nullptr; ms->pin_cap = 0; }
         BT_HIP_CHECK(hipHostMalloc((void **) &ms->pin, pin_need, hipHostMallocDefault));
@@ -865,6 +913,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     int64_t *h_send = (int64_t *) (ms->pin + o_send);
     int64_t *h_matrix = (int64_t *) (ms->pin + o_matrix);
     int64_t *h_prefix = (int64_t *) (ms->pin + o_prefix);
+    int64_t *h_tables = (int64_t *) (ms->pin + o_tables);       // arrive [ntop1], stay [ntop1]
 
     // ---- 1. global bounding box -> root box, all on the device -----------------------------
     Buf<double> mm;
@@ -873,7 +922,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     BT_CHECK(rootbox_d.alloc(ctx->pool, 64));
     mm_init_kernel<<<1, 1, 0, stream>>>(mm.get(), D, p->ntargets > 0 ? -1.0 : 0.0);   // MIN: -1 if some rank has targets
     for (int s = 0; s < 2; ++s)
-        BT_CHECK(bt::bbox_minmax_device(ctx, D, p->coord_kind, cset[s], nset[s], mm.get()));
+        BT_CHECK(bt::bbox_minmax_device(ctx, D, p->coord_kind, cset[s], rset[s], nset[s], mm.get()));
     BT_CHECK(comm_all_reduce(comm, stream, mm.get(), 2 * D + 1, RED_MIN_F64));
     if (f64) root_box_from_mm_kernel<double><<<1, 1, 0, stream>>>(mm.get(), D, (double *) rootbox_d.get());
     else root_box_from_mm_kernel<float><<<1, 1, 0, stream>>>(mm.get(), D, (float *) rootbox_d.get());
@@ -886,21 +935,26 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     Buf<uint32_t> cells[2];
     Buf<int32_t> hist32, owner_d;
     Buf<int64_t> hist64;
-    BT_CHECK(hist32.alloc(ctx->pool, 2 * ncells));
-    BT_CHECK(hist64.alloc(ctx->pool, 2 * ncells));
+    BT_CHECK(hist32.alloc(ctx->pool, nh));
+    BT_CHECK(hist64.alloc(ctx->pool, nh));
     BT_CHECK(owner_d.alloc(ctx->pool, ncells));
-    BT_HIP_CHECK(hipMemsetAsync(hist32.get(), 0, (size_t) ncells * 8, stream));
+    BT_HIP_CHECK(hipMemsetAsync(hist32.get(), 0, (size_t) nh * 4, stream));
     for (int s = 0; s < 2; ++s) {
         if (nset[s] == 0) continue;
         BT_CHECK(cells[s].alloc(ctx->pool, nset[s]));
-        BT_CHECK(bt::morton_cells_device(ctx, D, p->coord_kind, cset[s], nset[s], rootbox_d.get(), k,
-                                         cells[s].get(), hist32.get() + s * ncells));
+        if (rset[s])
+            BT_CHECK(bt::morton_cells_ext_device(ctx, D, p->coord_kind, cset[s], rset[s], nset[s], rootbox_d.get(),
+                                                 k, p->stick_out_factor, p->extent_norm, cells[s].get(),
+                                                 hist32.get() + s * ncells, hist32.get() + 2 * ncells));
+        else
+            BT_CHECK(bt::morton_cells_device(ctx, D, p->coord_kind, cset[s], nset[s], rootbox_d.get(), k,
+                                             cells[s].get(), hist32.get() + s * ncells));
     }
-    widen_hist_kernel<<<(unsigned) div_up(2 * ncells, 256), 256, 0, stream>>>(2 * ncells, hist32.get(), hist64.get());
+    widen_hist_kernel<<<(unsigned) div_up(nh, 256), 256, 0, stream>>>(nh, hist32.get(), hist64.get());
     BT_HIP_CHECK(hipGetLastError());
-    BT_CHECK(bt::copy_to_pinned(ctx, h_local, hist32.get(), (size_t) ncells * 8));
-    BT_CHECK(comm_all_reduce(comm, stream, hist64.get(), (size_t) (2 * ncells), RED_SUM_I64));
-    BT_CHECK(bt::copy_to_pinned(ctx, h_ghist2, hist64.get(), (size_t) ncells * 16));
+    BT_CHECK(bt::copy_to_pinned(ctx, h_local, hist32.get(), (size_t) nh * 4));
+    BT_CHECK(comm_all_reduce(comm, stream, hist64.get(), (size_t) nh, RED_SUM_I64));
+    BT_CHECK(bt::copy_to_pinned(ctx, h_ghist2, hist64.get(), (size_t) nh * 8));
     BT_CHECK(bt::sync_stream(ctx));                       // the one wait the GPU idles through
 
     const bool sep = h_box[2 * D] < 0;
@@ -921,7 +975,11 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     ghist.resize((size_t) ncells);
     for (int64_t c = 0; c < ncells; ++c) ghist[(size_t) c] = h_ghist2[c] + h_ghist2[ncells + c];
     TopPlan &pl = ms->plan;
-    compute_plan(D, k, p->max_particles_in_box, nranks, ghist.data(), pl);
+    compute_plan(D, k, p->max_particles_in_box, nranks, ghist.data(), ext ? h_ghist2 + 2 * ncells : nullptr, pl);
+    if (ext && !sep) {
+        set_error("bt_mgpu_exchange: extent_norm is set but no rank has targets");
+        return BT_ERR_INVALID;
+    }
     // which top boxes hold sources / targets (flags of the shared top levels)
     pl.sep_targets = sep;
     pl.src_counts.resize((size_t) k + 1);
@@ -963,7 +1021,9 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     // [sender][set][receiver]: on its way to the host while the partition sweeps run
     BT_CHECK(bt::copy_to_pinned(ctx, h_matrix, counts_d.get() + row, (size_t) row * nranks * 8));
     BT_HIP_CHECK(hipEventRecord(ms->ev_counts, stream));
-    const int64_t rec = (int64_t) D * es;                       // bytes per particle
+    // values and bytes per particle record of a set (targets with extents carry their radius)
+    const int vals_of[2] = {D, D + (ext ? 1 : 0)};
+    const int64_t rec_of[2] = {(int64_t) vals_of[0] * es, (int64_t) vals_of[1] * es};
 
     // ---- 4. payload: interleaved coordinates, one exchange per particle set -------------------
     // One sweep over the coordinates per set: stable partition by owner into the send buffer, the
@@ -974,8 +1034,8 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     unsigned char *points_of[2] = {nullptr, nullptr};
     for (int s = 0; s < nsets; ++s) {
         const int64_t n = nset[s];
-        BT_CHECK(send[s].alloc(ctx->pool, n * D * es));
-        const int64_t points_bytes = std::max<int64_t>(nrecv_of[s], 1) * D * es;
+        BT_CHECK(send[s].alloc(ctx->pool, n * rec_of[s]));
+        const int64_t points_bytes = std::max<int64_t>(nrecv_of[s], 1) * rec_of[s];
         Buf<unsigned char> &own = s == 0 ? ms->points : ms->tpoints;
         if (p->alloc) {
             points_of[s] = (unsigned char *) p->alloc(p->alloc_user, points_bytes);
@@ -985,8 +1045,11 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
             BT_CHECK(own.alloc(ctx->pool, points_bytes));
             points_of[s] = own.get();
         }
-        BT_CHECK(bt::partition_pack_device(ctx, D, es, cset[s], cells[s].get(), n, owner_d.get(), (int) ncells, nranks, rank,
-                                           self_d.get() + 2 * s, send[s].get(),
+        const void *arrays[BT_MAX_DIMS + 1];
+        for (int ax = 0; ax < D; ++ax) arrays[ax] = cset[s][ax];
+        arrays[D] = rset[s];
+        BT_CHECK(bt::partition_pack_device(ctx, vals_of[s], es, arrays, cells[s].get(), n, owner_d.get(), (int) ncells,
+                                           nranks, rank, self_d.get() + 2 * s, send[s].get(),
                                            loop_self ? send[s].get() : points_of[s]));
     }
     BT_HIP_CHECK(hipEventSynchronize(ms->ev_counts));     // (the GPU is busy with the sweeps)
@@ -994,6 +1057,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     int64_t bytes_sent = 0;
     BT_HIP_CHECK(hipEventRecord(ms->ev[0], stream));
     for (int s = 0; s < nsets; ++s) {
+        const int64_t rec = rec_of[s];
         std::vector<int64_t> s_cnt_b((size_t) nranks), r_cnt_b((size_t) nranks), s_off_b((size_t) nranks),
             r_off_b((size_t) nranks);
         int64_t biggest = 0, s_off = 0, r_off = 0;
@@ -1029,9 +1093,22 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     memcpy(h_prefix, pl.prefix.data(), (size_t) (ncells + 1) * 8);
     BT_HIP_CHECK(hipMemcpyAsync(ms->cell_prefix.get(), h_prefix, (size_t) (ncells + 1) * 8,
                                 hipMemcpyHostToDevice, stream));
+    if (ext) {
+        // the top of the global tree for bt_tree_build: arrivals and stayers per top box
+        BT_CHECK(ms->top_tables.alloc(ctx->pool, 2 * ntop1));
+        for (int lev = 0; lev <= k; ++lev) {
+            const int64_t n = (int64_t) 1 << (D * lev), off = top_table_offset(D, lev);
+            memcpy(h_tables + off, pl.counts[lev].data(), (size_t) n * 8);
+            memcpy(h_tables + ntop1 + off, pl.stay[lev].data(), (size_t) n * 8);
+        }
+        BT_HIP_CHECK(hipMemcpyAsync(ms->top_tables.get(), h_tables, (size_t) ntop1 * 16, hipMemcpyHostToDevice, stream));
+        out->top_box_arrive = ms->top_tables.get();
+        out->top_box_stay = ms->top_tables.get() + ntop1;
+    }
     BT_HIP_CHECK(hipEventRecord(ms->ev_done, stream));
     ms->done_pending = true;
 
+    out->target_record_len = vals_of[1];
     out->n_owned = nrecv_of[0];
     out->points = points_of[0];
     out->n_owned_targets = nrecv_of[1];

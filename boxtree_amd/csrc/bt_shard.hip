@@ -505,10 +505,12 @@ int partition_pack_device(bt_context *ctx, int dims, int elem_size, const void *
                           int self_rank, const int64_t *d_self_offsets, void *send, void *recv)
 {
     if (n == 0) return BT_OK;
+    // (dims counts the values of a record: coordinates, and a radius that travels with them)
 #define BT_PP(U, D) partition_pack_impl<U, D>(ctx, in, cells, n, owner_of_cell, ncells, nranks, self_rank, 0, 0, \
                                               d_self_offsets, send, recv, false)
-    if (elem_size == 8) return dims == 1 ? BT_PP(uint64_t, 1) : dims == 2 ? BT_PP(uint64_t, 2) : BT_PP(uint64_t, 3);
-    return dims == 1 ? BT_PP(uint32_t, 1) : dims == 2 ? BT_PP(uint32_t, 2) : BT_PP(uint32_t, 3);
+    if (elem_size == 8)
+        return dims == 1 ? BT_PP(uint64_t, 1) : dims == 2 ? BT_PP(uint64_t, 2) : dims == 3 ? BT_PP(uint64_t, 3) : BT_PP(uint64_t, 4);
+    return dims == 1 ? BT_PP(uint32_t, 1) : dims == 2 ? BT_PP(uint32_t, 2) : dims == 3 ? BT_PP(uint32_t, 3) : BT_PP(uint32_t, 4);
 #undef BT_PP
 }
 
@@ -637,7 +639,8 @@ int bt_gather_pack(bt_context *ctx, int dims, int elem_size, const void *const *
 int bt_unpack(bt_context *ctx, int dims, int elem_size, const void *in, int64_t n, void *const *out)
 {
     bt::CallScope bt_call_scope_(ctx);
-    if (!ctx || n < 0 || dims < 1 || dims > BT_MAX_DIMS || (elem_size != 4 && elem_size != 8)
+    // (dims counts the values of a record: up to BT_MAX_DIMS coordinates and a radius)
+    if (!ctx || n < 0 || dims < 1 || dims > BT_MAX_DIMS + 1 || (elem_size != 4 && elem_size != 8)
             || (n > 0 && (!in || !out))) {
         set_error("bt_unpack: invalid argument");
         return BT_ERR_INVALID;
@@ -648,11 +651,13 @@ int bt_unpack(bt_context *ctx, int dims, int elem_size, const void *in, int64_t 
     if (elem_size == 8) {
         s = dims == 1 ? unpack_impl<uint64_t, 1>(ctx, in, n, out)
           : dims == 2 ? unpack_impl<uint64_t, 2>(ctx, in, n, out)
-                      : unpack_impl<uint64_t, 3>(ctx, in, n, out);
+          : dims == 3 ? unpack_impl<uint64_t, 3>(ctx, in, n, out)
+                      : unpack_impl<uint64_t, 4>(ctx, in, n, out);
     } else {
         s = dims == 1 ? unpack_impl<uint32_t, 1>(ctx, in, n, out)
           : dims == 2 ? unpack_impl<uint32_t, 2>(ctx, in, n, out)
-                      : unpack_impl<uint32_t, 3>(ctx, in, n, out);
+          : dims == 3 ? unpack_impl<uint32_t, 3>(ctx, in, n, out)
+                      : unpack_impl<uint32_t, 4>(ctx, in, n, out);
     }
     BT_CHECK(s);
     BT_HIP_CHECK(hipGetLastError());

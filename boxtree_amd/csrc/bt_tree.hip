@@ -206,15 +206,23 @@ __global__ __launch_bounds__(256) void bbox_fold_kernel(const T *partial, int nb
 }
 
 template <class T>
-int bbox_fold_impl(bt_context *ctx, int dims, const void *const *coords, int64_t n, double *d_mm)
+int bbox_fold_impl(bt_context *ctx, int dims, const void *const *coords, const void *radii, int64_t n,
+                   double *d_mm)
 {
     if (n == 0) return BT_OK;
     const int64_t blocks = std::min<int64_t>(div_up(n, BBOX_THREADS * 8), (int64_t) ctx->num_cus * 8);
     Buf<T> partial;
     BT_CHECK(partial.alloc(ctx->pool, 2 * blocks * dims));
-    BboxAxes<T> axs{};
-    for (int ax = 0; ax < dims; ++ax) axs.x[ax] = (const T *) coords[ax];
-    bbox_axes_kernel<T><<<dim3((unsigned) blocks, dims), BBOX_THREADS, 0, ctx->stream>>>(axs, n, partial.get());
+    if (radii) {
+        // bounding_box.py:54-122 with radii: min(x - r), max(x + r)
+        for (int ax = 0; ax < dims; ++ax)
+            bbox_kernel<T><<<(unsigned) blocks, BBOX_THREADS, 0, ctx->stream>>>(
+                (const T *) coords[ax], (const T *) radii, n, partial.get() + 2 * blocks * ax);
+    } else {
+        BboxAxes<T> axs{};
+        for (int ax = 0; ax < dims; ++ax) axs.x[ax] = (const T *) coords[ax];
+        bbox_axes_kernel<T><<<dim3((unsigned) blocks, dims), BBOX_THREADS, 0, ctx->stream>>>(axs, n, partial.get());
+    }
     bbox_fold_kernel<T><<<1, 256, 0, ctx->stream>>>(partial.get(), (int) blocks, dims, d_mm);
     BT_HIP_CHECK(hipGetLastError());
     return BT_OK;
@@ -703,17 +711,46 @@ struct BuildArgs {
     const int64_t *top_prefix;  // [C^top_level + 1] or null
     int top_local;              // top_prefix holds THIS key array's cell starts (cell_starts_kernel):
                                 // child ranges down to top_level are looked up, not searched
+    const int64_t *top_arrive;  // particles with extents: per top box (levels 0..top_level, index
+    const int64_t *top_stay;    // (C^level - 1) / (C - 1) + path) the global arrivals / stuck ones
     int loff;                   // the key addresses levels loff+1 .. loff+L (continuation keys)
     int can_continue;           // a continuation key exists below level loff+L
     const uint8_t *cand;        // continuation: which boxes of level loff were re-keyed
 };
 
-// global particle count of the box with Morton path `path` at `level` <= top_level
+// index of the top box with Morton path `path` at `level` in the tables over levels 0..top_level
+template <int D>
+__device__ __forceinline__ int64_t top_box_index(uint64_t path, int level)
+{
+    constexpr uint64_t C = 1u << D;
+    uint64_t off = 0, pw = 1;
+    for (int l = 0; l < level; ++l) { off += pw; pw *= C; }
+    return (int64_t) (off + path);
+}
+
+// global particle count of the box with Morton path `path` at `level` <= top_level: everything
+// that arrives in it
 template <int D>
 __device__ __forceinline__ int32_t top_weight(const BuildArgs &a, uint64_t path, int level)
 {
-    const int sh = D * (a.top_level - level);
-    const int64_t w = a.top_prefix[(path + 1) << sh] - a.top_prefix[path << sh];
+    int64_t w;
+    if (a.top_arrive) {
+        w = a.top_arrive[top_box_index<D>(path, level)];
+    } else {
+        const int sh = D * (a.top_level - level);
+        w = a.top_prefix[(path + 1) << sh] - a.top_prefix[path << sh];
+    }
+    return (w > (int64_t) INT_MAX) ? INT_MAX : (int32_t) w;
+}
+
+// ... and the part of it bound for the box's children (tbk:569-573): with extents, what does not
+// stick out of them
+template <int D>
+__device__ __forceinline__ int32_t top_descend_weight(const BuildArgs &a, uint64_t path, int level)
+{
+    if (!a.top_arrive) return top_weight<D>(a, path, level);
+    const int64_t i = top_box_index<D>(path, level);
+    const int64_t w = a.top_arrive[i] - a.top_stay[i];
     return (w > (int64_t) INT_MAX) ? INT_MAX : (int32_t) w;
 }
 
@@ -787,7 +824,7 @@ __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
 
     int32_t W = range_weight(a, first, e);                       // tbk:569-573
     const bool top = a.top_prefix && a.loff == 0 && l - 1 < a.top_level && e > s;
-    if (top) W = top_weight<D>(a, prefix, l - 1);
+    if (top) W = top_descend_weight<D>(a, prefix, l - 1);
     bool split;
     if (forced) split = true;                                    // tbk:593-595
     else if (a.adaptive) split = W > a.max_weight;               // tbk:577-591
@@ -1042,7 +1079,7 @@ __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState
             if (active) {
                 int32_t W = range_weight(a, first, e);                       // tbk:569-573
                 const bool top = a.top_prefix && a.loff == 0 && level - 1 < a.top_level && e > s;
-                if (top) W = top_weight<D>(a, prefix, level - 1);
+                if (top) W = top_descend_weight<D>(a, prefix, level - 1);
                 split = a.adaptive ? W > a.max_weight : true;                // tbk:577-597
                 if (skipped) split = false;
                 if (lr - 1 >= a.L) {
@@ -3098,6 +3135,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         a.adaptive = p.kind != BT_KIND_NON_ADAPTIVE;
         a.top_level = p.top_level;
         a.top_prefix = p.top_cell_prefix;
+        a.top_arrive = p.top_box_arrive;
+        a.top_stay = p.top_box_stay;
         a.top_local = 0;
         if (local_cells.get()) {
             a.top_level = local_top_level;
@@ -3656,11 +3695,80 @@ namespace bt {
 
 // Bounding box of dense coordinate arrays, left on the device: d_mm[0..dims) = min(d_mm, min),
 // d_mm[dims..2 dims) = min(d_mm, -max) -- no host wait (the multi-GPU exchange all-reduces it).
-int bbox_minmax_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords, int64_t n,
-                       double *d_mm)
+int bbox_minmax_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords,
+                       const void *radii, int64_t n, double *d_mm)
 {
-    return coord_kind == BT_F64 ? bbox_fold_impl<double>(ctx, dims, coords, n, d_mm)
-                                : bbox_fold_impl<float>(ctx, dims, coords, n, d_mm);
+    return coord_kind == BT_F64 ? bbox_fold_impl<double>(ctx, dims, coords, radii, n, d_mm)
+                                : bbox_fold_impl<float>(ctx, dims, coords, radii, n, d_mm);
+}
+
+// The ownership cell of particles with extents (bt_mgpu_exchange): the key kernel's own stop
+// test (particle_key) over the levels 1..k+1.  A particle that sticks out of the boxes of level
+// cap + 1 stays in its box of level cap <= k: it counts as STAYING there (hist_stay, index
+// (C^cap - 1) / (C - 1) + path) and its cell is the first level-k cell under that box -- the
+// rank that owns that cell gets the particle.  hist_cells counts the cells so assigned.
+template <class T, int D>
+__global__ __launch_bounds__(1024) void ext_cells_kernel(KeygenArgs<T, D> a, int k, uint32_t *cells,
+        int32_t *hist_cells, int32_t *hist_stay, int ncells)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_hist_ext[];
+    const bool lds = ncells <= (1 << 15);
+    if (lds) for (int c = threadIdx.x; c < ncells; c += 1024) s_hist_ext[c] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t) gridDim.x * 1024;
+    for (int64_t i = (int64_t) blockIdx.x * 1024 + threadIdx.x; i < a.n; i += stride) {
+        T x[D];
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) x[ax] = a.tgt[ax][i];
+        const T radius = a.tgt_radii ? a.tgt_radii[i] : (T) 0;
+        const uint64_t key = particle_key<T, D, true>(a, x, radius);      // L = k + 1
+        const int cap = (int) (key & (((uint64_t) 1 << CAPBITS_EXT) - 1));
+        const uint32_t cell = (uint32_t) ((key >> CAPBITS_EXT) >> D);     // path of level k, zeros below cap
+        cells[i] = cell;
+        if (lds) atomicAdd(&s_hist_ext[cell], 1u); else atomicAdd(&hist_cells[cell], 1);
+        if (cap <= k) atomicAdd(&hist_stay[top_box_index<D>((uint64_t) (cell >> (D * (k - cap))), cap)], 1);
+    }
+    __syncthreads();
+    if (lds)
+        for (int c = threadIdx.x; c < ncells; c += 1024) {
+            const uint32_t v = s_hist_ext[c];
+            if (v) atomicAdd(&hist_cells[c], (int32_t) v);
+        }
+}
+
+template <class T, int D>
+int ext_cells_impl(bt_context *ctx, const void *const *coords, const void *radii, int64_t n,
+                   const void *d_rootbox, int k, double stick_out_factor, int norm, uint32_t *cells,
+                   int32_t *hist_cells, int32_t *hist_stay)
+{
+    if (n == 0) return BT_OK;
+    KeygenArgs<T, D> a{};
+    for (int ax = 0; ax < D; ++ax) a.tgt[ax] = (const T *) coords[ax];
+    a.tgt_radii = (const T *) radii;
+    a.nsources = 0; a.n = n; a.src_stride = 1; a.tgt_stride = 1;
+    a.rootbox = (const T *) d_rootbox;
+    a.stick_out_factor = (T) stick_out_factor;
+    a.L = k + 1;
+    a.norm = norm;
+    a.point_skip_levels = 0;
+    const int ncells = 1 << (D * k);
+    const unsigned blocks = (unsigned) std::min<int64_t>(div_up(n, 1024), ctx->num_cus);
+    ext_cells_kernel<T, D><<<blocks, 1024, ncells <= (1 << 15) ? (size_t) ncells * 4 : 0, ctx->stream>>>(
+        a, k, cells, hist_cells, hist_stay, ncells);
+    BT_HIP_CHECK(hipGetLastError());
+    return BT_OK;
+}
+
+int morton_cells_ext_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords,
+                            const void *radii, int64_t n, const void *d_rootbox, int level,
+                            double stick_out_factor, int extent_norm, uint32_t *cells_out,
+                            int32_t *hist_cells, int32_t *hist_stay)
+{
+#define EC(T, D) return ext_cells_impl<T, D>(ctx, coords, radii, n, d_rootbox, level, stick_out_factor, \
+                                             extent_norm, cells_out, hist_cells, hist_stay)
+    if (coord_kind == BT_F64) { if (dims == 1) EC(double, 1); else if (dims == 2) EC(double, 2); else EC(double, 3); }
+    else { if (dims == 1) EC(float, 1); else if (dims == 2) EC(float, 2); else EC(float, 3); }
+#undef EC
 }
 
 }  // namespace bt
@@ -3713,9 +3821,14 @@ int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
             set_error("bt_tree_build: top_level %d out of range", p->top_level);
             return BT_ERR_INVALID;
         }
-        if (have_extent || p->refine_weights || p->kind != BT_KIND_ADAPTIVE) {
-            set_error("sharded builds (top_cell_prefix) support kind='adaptive' with point "
-                      "particles and unit refine weights only");
+        if (p->refine_weights || p->kind != BT_KIND_ADAPTIVE) {
+            set_error("sharded builds (top_cell_prefix) support kind='adaptive' with unit refine "
+                      "weights only");
+            return BT_ERR_UNSUPPORTED;
+        }
+        if (have_extent && (!p->top_box_arrive || !p->top_box_stay)) {
+            set_error("sharded builds of particles with extents need the tables top_box_arrive / "
+                      "top_box_stay (bt_mgpu_exchange makes them)");
             return BT_ERR_UNSUPPORTED;
         }
     }

@@ -141,7 +141,8 @@ class _LazyA2aTime:
 
 
 def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=None,
-                       own_buffer=False, targets=None):
+                       own_buffer=False, targets=None, target_radii=None, stick_out_factor=None,
+                       extent_norm="linf"):
     """Steps 1-3 (``bt_mgpu_exchange``).  Returns ``(particles, build_kw, stats)`` for the
     local ``TreeBuilder`` call: views of the interleaved receive buffer, and ``_root_box`` /
     ``_top_tree`` / ``_point_stride``.  The receive buffer belongs to the context and is
@@ -149,7 +150,12 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
     *own_buffer* it is a torch allocation the returned views keep alive.  With separate
     point *targets* the return value is ``(particles, targets, build_kw, stats)``: both sets
     travel to the owners of their cells (cells are counted over sources and targets), and
-    come back as contiguous arrays."""
+    come back as contiguous arrays.  With *target_radii* (every rank passes them, an empty
+    chunk included) the return value is ``(particles, targets, target_radii, build_kw,
+    stats)``: a target that sticks out of the boxes of the shared top levels stays in one of
+    them and travels to the owner of that box's first cell; ``build_kw`` then carries
+    ``stick_out_factor`` / ``extent_norm`` and the top of the global tree as arrival / stay
+    counts per top box."""
     import torch
     dims = len(particles)
     dev = particles[0].device
@@ -170,6 +176,15 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
         for ax in range(dims):
             par.targets[ax] = keep_t[ax].data_ptr()
         own_buffer = True
+        if target_radii is not None:
+            if stick_out_factor is None:
+                raise ValueError("stick_out_factor must be given with target_radii")
+            keep_r = target_radii.contiguous()
+            par.target_radii = keep_r.data_ptr()
+            par.stick_out_factor = float(stick_out_factor)
+            par.extent_norm = _lib.NORMS[extent_norm]
+    elif target_radii is not None:
+        raise ValueError("target_radii without targets")
     got = {}
     bufs = []
 
@@ -186,7 +201,13 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
     _lib.check(actx.lib.bt_mgpu_exchange(actx.handle, comm.handle, ct.byref(par), ct.byref(shard)))
     n_owned = int(shard.n_owned)
     if targets is not None:
-        return _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev)
+        res = _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev)
+        if target_radii is None:
+            return res
+        p2, t2, kw, stats = res
+        kw["stick_out_factor"] = stick_out_factor
+        kw["extent_norm"] = extent_norm
+        return p2, t2[:dims], t2[dims], kw, stats
     if shard.sep_targets:
         raise ValueError("exchange_particles: other ranks passed separate targets; every rank "
                          "must pass `targets` (an empty chunk is fine)")
@@ -225,11 +246,12 @@ def _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev):
     if len(bufs) < 2:
         # no rank of the job had a target: the library exchanged one set
         bufs = [bufs[0], None]
-    for buf, n in ((bufs[0], int(shard.n_owned)), (bufs[1], int(shard.n_owned_targets))):
-        arrs = [torch.empty(n, dtype=dtype, device=dev) for _ in range(dims)]
-        optrs = (ct.c_void_p * dims)(*[a.data_ptr() for a in arrs])
+    for buf, n, nv in ((bufs[0], int(shard.n_owned), dims),
+                       (bufs[1], int(shard.n_owned_targets), int(shard.target_record_len) or dims)):
+        arrs = [torch.empty(n, dtype=dtype, device=dev) for _ in range(nv)]
+        optrs = (ct.c_void_p * nv)(*[a.data_ptr() for a in arrs])
         if n:
-            _lib.check(actx.lib.bt_unpack(actx.handle, dims, es, ct.c_void_p(buf.data_ptr()), n, optrs))
+            _lib.check(actx.lib.bt_unpack(actx.handle, nv, es, ct.c_void_p(buf.data_ptr()), n, optrs))
         out.append(arrs)
     coord = np.dtype(np.float64 if dtype == torch.float64 else np.float32)
     bbox_min = np.array(shard.bbox_min[:dims], dtype=coord)
@@ -241,6 +263,12 @@ def _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev):
         prefix = torch.as_tensor(
             _DevicePointer(shard.top_cell_prefix, ((1 << (dims * k)) + 1,), "<i8"), device=dev)
         build_kw["_top_tree"] = (k, prefix)
+        if shard.top_box_arrive:
+            C = 1 << dims
+            ntop = (C ** (k + 1) - 1) // (C - 1)
+            build_kw["_top_tree"] = (k, prefix) + tuple(
+                torch.as_tensor(_DevicePointer(ptr_, (ntop,), "<i8"), device=dev)
+                for ptr_ in (shard.top_box_arrive, shard.top_box_stay))
     stats = dict(bytes_sent=int(shard.bytes_sent), rounds=int(shard.rounds), top_level=k,
                  a2a_ms=_LazyA2aTime(actx, float(shard.a2a_ms)), bbox_min=bbox_min, bbox_max=bbox_max,
                  root_extent=root_extent, planned=bool(shard.top_cell_prefix))

@@ -358,6 +358,11 @@ class TreeBuilder:
             top_prefix = top_tree[1].contiguous()
             assert top_prefix.shape[0] == (1 << (dimensions * tp.top_level)) + 1
             tp.top_cell_prefix = ptr(top_prefix)
+            if len(top_tree) > 2:
+                # particles with extents: arrivals / stayers per box of levels 0..top_level
+                # (int64 device tensors, bt_tree_params.top_box_arrive / top_box_stay)
+                tp.top_box_arrive = ptr(top_tree[2])
+                tp.top_box_stay = ptr(top_tree[3])
 
         sizes = _lib.TreeSizes()
         actx.sync_in()

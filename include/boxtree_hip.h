@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BT_ABI_VERSION 6
+#define BT_ABI_VERSION 7
 #define BT_MAX_DIMS 3
 #define BT_MAX_LEVELS 64       /* capacity of per-level arrays in the structs */
 
@@ -191,6 +191,14 @@ typedef struct {
      * arrays, no top_cell_prefix; BT_ERR_UNSUPPORTED otherwise. */
     int32_t compute_root_box;
     double root_extent_stretch;            /* tree_build.py:101: 1e-4 */
+    /* Sharded builds of particles with extents (radii): where a particle stops is not a
+     * function of the cell counts, so the top of the global tree comes as two tables over the
+     * boxes of levels 0..top_level, box (level, Morton path) at index (C^level - 1) / (C - 1) +
+     * path with C = 2^dims (device, int64): the particles that ARRIVE in the box (its cumulative
+     * count in the global tree) and those that STAY in it (stick out of its children,
+     * tree_build_kernels.py:388-428).  A box splits iff arrive - stay exceeds
+     * max_leaf_refine_weight.  Both NULL: point particles, top_cell_prefix alone. */
+    const int64_t *top_box_arrive, *top_box_stay;
 } bt_tree_params;
 
 typedef struct {
@@ -584,6 +592,13 @@ typedef struct {
     int64_t ntargets;                  /* separate point targets of this rank's chunk, or 0 */
     const void *targets[BT_MAX_DIMS];  /* (sources are the targets); exchanged by the same  */
                                        /* owners, cells counted over sources AND targets     */
+    /* targets with extents (boxtree's target_radii; every rank passes them or none does):
+     * a target that sticks out of the boxes of the shared top levels stays in one of them
+     * (tree_build_kernels.py:388-428) and travels to the owner of that box's first cell; the
+     * received records are [x.. , radius] (target_record_len = dims + 1) */
+    const void *target_radii;          /* device [ntargets] or NULL                          */
+    double stick_out_factor;
+    int32_t extent_norm;               /* BT_NORM_LINF / BT_NORM_L2 with target_radii        */
 } bt_mgpu_params;
 
 typedef struct {
@@ -603,6 +618,10 @@ typedef struct {
     void *target_points;               /* out like `points` (second allocation)          */
     int32_t sep_targets;               /* 1: some rank passed separate targets, so every  */
                                        /* rank exchanged two sets (n_owned_targets may be 0) */
+    int32_t target_record_len;         /* values per received target: dims, or dims + 1 with */
+                                       /* radii (the radius last)                            */
+    const int64_t *top_box_arrive, *top_box_stay;   /* device tables for bt_tree_params with   */
+                                       /* extents (levels 0..top_level), else NULL           */
 } bt_mgpu_shard;
 
 /* the one-sweep partition (bt_partition_pack) keeps one run per owner in LDS: at most this
