@@ -188,7 +188,8 @@ class MgpuLocalTree(ct.Structure):
                 ("aligned_nboxes", ct.c_int64), ("nlevels", ct.c_int32),
                 ("level_start_box_nrs", ct.POINTER(ct.c_int32)), ("box_centers", vp),
                 ("box_levels", vp), ("box_flags", vp), ("nsources", ct.c_int64),
-                ("ntargets", ct.c_int64)]
+                ("ntargets", ct.c_int64), ("box_target_bounding_box_min", vp),
+                ("box_target_bounding_box_max", vp), ("box_source_counts_cumul", vp)]
 
 
 class MgpuNumbering(ct.Structure):
@@ -209,7 +210,8 @@ class MgpuLetSizes(ct.Structure):
 class MgpuLetArrays(ct.Structure):
     _fields_ = [("box_centers", vp), ("box_parent_ids", vp), ("box_child_ids", vp),
                 ("box_levels", vp), ("box_flags", vp), ("global_box_ids", vp),
-                ("target_boxes_mask", vp)]
+                ("target_boxes_mask", vp), ("box_target_bounding_box_min", vp),
+                ("box_target_bounding_box_max", vp), ("box_source_counts_cumul", vp)]
 
 
 class Span(ct.Structure):

@@ -332,6 +332,7 @@ struct TopPlan {
     int D = 0, k = 0, nranks = 0;
     int64_t mpb = 0;
     bool has_stay = false;                        // particles with extents: `stay` is filled
+    double stick_out_factor = 0;                  // ... and this is how far a target may leave its box
     std::vector<std::vector<int64_t>> stay;       // [k+1][C^lev]: particles that stay in the box
     std::vector<std::vector<int64_t>> counts;     // [k+1][C^lev]
     std::vector<std::vector<char>> exists, split;
@@ -521,6 +522,11 @@ struct MgpuState {
     Buf<uint64_t> let_paths;         // [B] level-major, Morton order within a level
     Buf<int32_t> let_meta, let_gid;  // level | flags << 8; global box number
     Buf<int8_t> let_mask;            // 1: lists are built for this box on this rank
+    // targets with extents: target bounding boxes [2][D][B] (min, then max) in the coordinate
+    // type, and cumulative source counts [B]
+    Buf<unsigned char> let_tbb;
+    Buf<int32_t> let_srccum;
+    bool let_ext = false;
     int let_nlevels = 0, let_dims = 0, let_kind = 0;
     std::vector<int32_t> let_level_starts;
 };
@@ -688,6 +694,112 @@ __global__ __launch_bounds__(256) void let_scatter_halo_kernel(int64_t n, LetBlo
     mask[dst] = 0;
 }
 
+// extras of a box whose targets have extents: bounding box of its targets, cumulative source count
+template <class T>
+struct LetExtras {
+    const T *bmin, *bmax;          // [D][aligned] of the local tree
+    const int32_t *srccum;
+    int64_t aligned;
+    int D;
+};
+
+// extras of the boxes peer q needs: [n][2 D] coordinates (min.., max..), then [n] counts
+template <class T>
+__global__ __launch_bounds__(256) void let_pack_extras_kernel(int64_t n, NeedPred pr, const int32_t *pos,
+        LetExtras<T> ex, int64_t nsel, T *out_box, int32_t *out_cnt)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !pr(i)) return;
+    const int64_t b = pr.b0 + i, at = pos[i];
+    for (int ax = 0; ax < ex.D; ++ax) {
+        out_box[at * 2 * ex.D + ax] = ex.bmin[(int64_t) ax * ex.aligned + b];
+        out_box[at * 2 * ex.D + ex.D + ax] = ex.bmax[(int64_t) ax * ex.aligned + b];
+    }
+    out_cnt[at] = ex.srccum[b];
+    (void) nsel;
+}
+
+// own deep boxes' extras into the LET ([2][D][B] boxes, [B] counts)
+template <class T>
+__global__ __launch_bounds__(256) void let_scatter_own_extras_kernel(int64_t n_mine, int64_t b0, LetBlocks blk,
+        const uint8_t *levels, LetExtras<T> ex, int64_t B, T *tbb, int32_t *srccum)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_mine) return;
+    const int64_t b = b0 + i;
+    const int lev = levels[b];
+    const int64_t dst = (int64_t) blk.dst_start[lev] + (b - blk.src_start[lev]);
+    for (int ax = 0; ax < ex.D; ++ax) {
+        tbb[(int64_t) ax * B + dst] = ex.bmin[(int64_t) ax * ex.aligned + b];
+        tbb[((int64_t) ex.D + ax) * B + dst] = ex.bmax[(int64_t) ax * ex.aligned + b];
+    }
+    srccum[dst] = ex.srccum[b];
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void let_scatter_halo_extras_kernel(int64_t n, LetBlocks blk, const uint64_t *rec,
+        const T *in_box, const int32_t *in_cnt, int D, int64_t B, T *tbb, int32_t *srccum)
+{
+    const int64_t j = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int lev = (int) (rec[2 * j + 1] & 0xffu);
+    if (lev > BT_MAX_LEVELS || j < blk.src_start[lev]) return;
+    const int64_t dst = (int64_t) blk.dst_start[lev] + (j - blk.src_start[lev]);
+    for (int ax = 0; ax < D; ++ax) {
+        tbb[(int64_t) ax * B + dst] = in_box[j * 2 * D + ax];
+        tbb[((int64_t) D + ax) * B + dst] = in_box[j * 2 * D + D + ax];
+    }
+    srccum[dst] = in_cnt[j];
+}
+
+// shared top boxes: (min, -max) of the local tree's boxes of levels <= k into mm[gid][2 D]
+// (doubles, +inf where this rank has no such box) for the all-reduce(MIN) over the ranks
+template <class T>
+__global__ __launch_bounds__(256) void let_top_tbb_gather_kernel(int64_t ntop_local, const int32_t *gids,
+        LetExtras<T> ex, double *mm)
+{
+    const int64_t b = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (b >= ntop_local) return;
+    const int64_t g = gids[b];
+    for (int ax = 0; ax < ex.D; ++ax) {
+        mm[g * 2 * ex.D + ax] = (double) ex.bmin[(int64_t) ax * ex.aligned + b];
+        mm[g * 2 * ex.D + ex.D + ax] = -(double) ex.bmax[(int64_t) ax * ex.aligned + b];
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_f64_kernel(int64_t n, double v, double *out)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+
+// ... and back, into the first ntop boxes of the LET
+template <class T>
+__global__ __launch_bounds__(256) void let_top_tbb_place_kernel(int64_t ntop, int D, const double *mm,
+        const int32_t *top_srccum, int64_t B, T *tbb, int32_t *srccum)
+{
+    const int64_t g = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (g >= ntop) return;
+    for (int ax = 0; ax < D; ++ax) {
+        tbb[(int64_t) ax * B + g] = (T) mm[g * 2 * D + ax];
+        tbb[((int64_t) D + ax) * B + g] = (T) (-mm[g * 2 * D + D + ax]);
+    }
+    srccum[g] = top_srccum[g];
+}
+
+// [2][D][B] -> the caller's [D][aligned] arrays
+template <class T>
+__global__ __launch_bounds__(256) void let_tbb_export_kernel(int64_t B, int64_t aligned, int D, const T *tbb,
+        T *bmin, T *bmax)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= aligned) return;
+    for (int ax = 0; ax < D; ++ax) {
+        bmin[(int64_t) ax * aligned + i] = i < B ? tbb[(int64_t) ax * B + i] : (T) 0;
+        bmax[(int64_t) ax * aligned + i] = i < B ? tbb[((int64_t) D + ax) * B + i] : (T) 0;
+    }
+}
+
 // row[q][l] = number of my level-l boxes peer q needs: differences of the scanned predicate at
 // the level boundaries of the local tree
 struct LocalLevels { int32_t nlevels; int32_t start[BT_MAX_LEVELS + 2]; };
@@ -752,6 +864,53 @@ void cells_needed_by(const TopPlan &pl, int rank, int ring, int nwords, std::vec
                     bits[(size_t) c * nwords + (q >> 6)] |= 1ull << (q & 63);
                     any_for_peer[q] = 1;
                 }
+    }
+    // Targets with extents.  (i) The targets that stay in an internal box B above level k are held
+    // by the owner q of B's first cell, and their List 1 takes every leaf under B and beside it
+    // (traversal.py:470-550).  (ii) The List-3 walk of a target box with extents does not stop
+    // at the first box that is not adjacent: where the stick-out regions may still meet it files
+    // the box under "close" and goes on down (traversal.py:830-868), anywhere inside the
+    // colleagues of the target box -- for a target box above level k, leaf or not, that is more
+    // than `ring` cells around its cells.  q needs my non-empty cells under B and within ring_B
+    // cells of it: the colleagues' width (ring * side), cut down to the shell in which a
+    // separation criterion can fail -- a target's extent leaves its box by at most
+    // stick_out_factor box radii, and a source box of a cell or less that fails the criterion is
+    // within one cell of that (linf criteria), or within 3 source radii of the round region of
+    // radius sqrt(d) (1 + stick_out_factor) box radii (static_l2).
+    if (pl.has_stay) {
+        for (int lev = 0; lev < k; ++lev) {
+            const int64_t nb = (int64_t) 1 << (D * lev);
+            const int side = 1 << (k - lev);
+            const double sof = pl.stick_out_factor;
+            const int shell_linf = (int) std::ceil(sof * side / 2) + 1;
+            const int shell_l2 = (int) std::ceil(side / 2.0 * (std::sqrt((double) D) * (1 + sof) - 1) + 2);
+            const int ring_b = std::min(ring * side, std::max(std::max(shell_linf, shell_l2), ring));
+            for (int64_t pth = 0; pth < nb; ++pth) {
+                if (!pl.exists[lev][pth]) continue;
+                const bool internal = pl.split[lev][pth];
+                const int64_t ntg = internal ? pl.stay[lev][pth] : pl.counts[lev][pth] - pl.src_counts[lev][pth];
+                if (ntg <= 0) continue;
+                const int64_t first = pth << (D * (k - lev));
+                const int q = pl.owner[(size_t) first];
+                if (q == rank) continue;
+                int lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+                for (int ax = 0; ax < D; ++ax) {
+                    const int v = xyz_of_cell[(size_t) first * 3 + ax];      // the block's low corner
+                    lo[ax] = std::max(0, v - ring_b); hi[ax] = std::min(n - 1, v + side - 1 + ring_b);
+                }
+                int p[3];
+                for (p[0] = lo[0]; p[0] <= hi[0]; ++p[0])
+                    for (p[1] = lo[1]; p[1] <= hi[1]; ++p[1])
+                        for (p[2] = lo[2]; p[2] <= hi[2]; ++p[2]) {
+                            int64_t gi = 0;
+                            for (int ax = 0; ax < D; ++ax) gi = gi * n + p[ax];
+                            const int64_t c = cell_of_grid[(size_t) gi];
+                            if (pl.owner[(size_t) c] != rank || pl.counts[k][(size_t) c] <= 0) continue;
+                            bits[(size_t) c * nwords + (q >> 6)] |= 1ull << (q & 63);
+                            any_for_peer[q] = 1;
+                        }
+            }
+        }
     }
 }
 
@@ -982,6 +1141,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     }
     // which top boxes hold sources / targets (flags of the shared top levels)
     pl.sep_targets = sep;
+    pl.stick_out_factor = ext ? p->stick_out_factor : 0;
     pl.src_counts.resize((size_t) k + 1);
     pl.src_counts[k].assign(h_ghist2, h_ghist2 + ncells);
     for (int lev = k - 1; lev >= 0; --lev) {
@@ -1283,6 +1443,16 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
 
     BT_CHECK(reset_status(ctx));
     BT_CHECK(arena_reclaim(ms, false));
+    // targets with extents: the traversal also reads the target bounding box and the cumulative
+    // source count of every box of the LET
+    const bool ext = pl.has_stay;
+    if (ext && nb > 0 && (!tree->box_target_bounding_box_min || !tree->box_target_bounding_box_max
+                          || !tree->box_source_counts_cumul)) {
+        set_error("bt_mgpu_let_build: the exchange had targets with extents; the local tree must come "
+                  "with box_target_bounding_box_min / _max and box_source_counts_cumul");
+        return BT_ERR_INVALID;
+    }
+    const size_t es = tree->coord_kind == BT_F64 ? 8 : 4;
     // -- Morton paths of my boxes ----------------------------------------------------------------
     Buf<uint64_t> paths;
     BT_CHECK(paths.alloc(ctx->pool, nb));
@@ -1393,6 +1563,41 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
         BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send_rec.get(), sob.data(), scb.data(),
                                    (char *) halo_rec.get(), rob.data(), rcb.data(), biggest, false, nullptr));
     }
+    // the extras of the same boxes in the same order: per peer [count][2 D] coordinates, then
+    // [count] source counts
+    Buf<unsigned char> send_ex, halo_ex;
+    const int64_t exrec = ext ? (int64_t) (2 * D * es + 4) : 0;
+    if (ext) {
+        BT_CHECK(send_ex.alloc(ctx->pool, std::max<int64_t>(nsend, 1) * exrec));
+        BT_CHECK(halo_ex.alloc(ctx->pool, std::max<int64_t>(nrecv, 1) * exrec));
+        for (size_t i = 0; i < peers.size(); ++i) {
+            const int q = peers[i];
+            if (s_cnt[q] == 0) continue;
+            pr.q = q;
+            unsigned char *blk0 = send_ex.get() + s_off[q] * exrec;
+            const int32_t *pp = pos.get() + (int64_t) i * (n_mine + 1);
+            if (es == 8) {
+                LetExtras<double> ex{(const double *) tree->box_target_bounding_box_min,
+                                     (const double *) tree->box_target_bounding_box_max,
+                                     tree->box_source_counts_cumul, tree->aligned_nboxes, D};
+                let_pack_extras_kernel<double><<<(unsigned) div_up(n_mine, 256), 256, 0, stream>>>(
+                    n_mine, pr, pp, ex, s_cnt[q], (double *) blk0, (int32_t *) (blk0 + s_cnt[q] * 2 * D * es));
+            } else {
+                LetExtras<float> ex{(const float *) tree->box_target_bounding_box_min,
+                                    (const float *) tree->box_target_bounding_box_max,
+                                    tree->box_source_counts_cumul, tree->aligned_nboxes, D};
+                let_pack_extras_kernel<float><<<(unsigned) div_up(n_mine, 256), 256, 0, stream>>>(
+                    n_mine, pr, pp, ex, s_cnt[q], (float *) blk0, (int32_t *) (blk0 + s_cnt[q] * 2 * D * es));
+            }
+        }
+        BT_HIP_CHECK(hipGetLastError());
+        std::vector<int64_t> sob((size_t) nranks), scb((size_t) nranks), rob((size_t) nranks), rcb((size_t) nranks);
+        for (int q = 0; q < nranks; ++q) {
+            sob[q] = s_off[q] * exrec; scb[q] = s_cnt[q] * exrec; rob[q] = r_off[q] * exrec; rcb[q] = r_cnt[q] * exrec;
+        }
+        BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send_ex.get(), sob.data(), scb.data(),
+                                   (char *) halo_ex.get(), rob.data(), rcb.data(), biggest / 16 * exrec, false, nullptr));
+    }
 
     // -- the box set: top levels from the plan, my deep boxes, the halo ----------------------------
     int64_t ntop = 0;
@@ -1404,6 +1609,7 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
     BT_ARENA(t_meta, int32_t, ms, ntop);
     BT_ARENA(t_gid, int32_t, ms, ntop);
     BT_ARENA(t_mine, int8_t, ms, ntop);
+    BT_ARENA(t_srccum, int32_t, ms, ext ? ntop : 1);
     std::vector<int32_t> level_starts(1, 0);
     int64_t nt = 0;
     for (int lev = 0; lev < ntop_levels; ++lev) {
@@ -1419,13 +1625,19 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
                 const int64_t ns = pl.src_counts[lev][pth], ntg = pl.counts[lev][pth] - ns;
                 flags = (ns > 0 ? BT_BOX_IS_SOURCE_BOX : 0) | (ntg > 0 ? BT_BOX_IS_TARGET_BOX : 0);
             }
+            // a box with children whose own (staying) particles are targets is a target box too
+            const bool own_targets = internal && ext && pl.stay[lev][pth] > 0;
+            if (own_targets) flags |= BT_BOX_IS_TARGET_BOX;
             // lists of the shared internal boxes are built by every rank, those of a top LEAF
-            // only by the rank that owns its cells
+            // only by the rank that owns its cells -- and the lists an internal box has as a
+            // target box (its own targets', extents only) by the rank that holds those targets
             const int64_t first_cell = pth << (D * (k - lev));
             t_paths[nt] = (uint64_t) pth;
             t_meta[nt] = lev | (flags << 8);
             t_gid[nt] = num->level_start_box_nrs[lev] + pl.index[lev][pth];
-            t_mine[nt] = (internal || pl.owner[first_cell] == rank) ? 1 : 0;
+            t_mine[nt] = internal ? ((own_targets && pl.owner[first_cell] != rank) ? 2 : 1)
+                                  : (pl.owner[first_cell] == rank ? 1 : 0);
+            if (ext) t_srccum[nt] = (int32_t) std::min<int64_t>(pl.src_counts[lev][pth], 0x7fffffff);
             ++nt;
         }
         level_starts.push_back((int32_t) nt);
@@ -1482,6 +1694,47 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
             ms->let_gid.get(), ms->let_mask.get(), ctx->d_status);
     }
     BT_HIP_CHECK(hipGetLastError());
+    ms->let_ext = ext;
+    if (ext) {
+        BT_CHECK(ms->let_tbb.alloc(ctx->pool, 2 * (int64_t) D * B * (int64_t) es));
+        BT_CHECK(ms->let_srccum.alloc(ctx->pool, B));
+        // the shared top boxes: union of the ranks' versions
+        Buf<double> top_mm;
+        Buf<int32_t> top_srccum_d;
+        BT_CHECK(top_mm.alloc(ctx->pool, ntop * 2 * D));
+        BT_CHECK(top_srccum_d.alloc(ctx->pool, ntop));
+        fill_f64_kernel<<<(unsigned) div_up(ntop * 2 * D, 256), 256, 0, stream>>>(ntop * 2 * D, 1.7976931348623158e+308,
+                                                                               top_mm.get());
+        BT_HIP_CHECK(hipMemcpyAsync(top_srccum_d.get(), t_srccum, (size_t) ntop * 4, hipMemcpyHostToDevice, stream));
+        const int64_t ntop_local = b0;          // the local tree's boxes of levels <= k come first
+#define BT_LET_EXT(T)                                                                                         \
+        {                                                                                                     \
+            LetExtras<T> ex{(const T *) tree->box_target_bounding_box_min,                                    \
+                            (const T *) tree->box_target_bounding_box_max, tree->box_source_counts_cumul,     \
+                            tree->aligned_nboxes, D};                                                         \
+            if (ntop_local > 0)                                                                               \
+                let_top_tbb_gather_kernel<T><<<(unsigned) div_up(ntop_local, 256), 256, 0, stream>>>(        \
+                    ntop_local, box_ids, ex, top_mm.get());                                                   \
+            BT_CHECK(comm_all_reduce(comm, stream, top_mm.get(), (size_t) (ntop * 2 * D), RED_MIN_F64));       \
+            let_top_tbb_place_kernel<T><<<(unsigned) div_up(ntop, 256), 256, 0, stream>>>(                    \
+                ntop, D, top_mm.get(), top_srccum_d.get(), B, (T *) ms->let_tbb.get(), ms->let_srccum.get()); \
+            if (n_mine > 0)                                                                                   \
+                let_scatter_own_extras_kernel<T><<<(unsigned) div_up(n_mine, 256), 256, 0, stream>>>(         \
+                    n_mine, b0, blk[(size_t) rank], tree->box_levels, ex, B, (T *) ms->let_tbb.get(),         \
+                    ms->let_srccum.get());                                                                    \
+            for (int q = 0; q < nranks; ++q) {                                                                \
+                if (q == rank || r_cnt[q] == 0) continue;                                                     \
+                const unsigned char *blk0 = halo_ex.get() + r_off[q] * exrec;                                 \
+                let_scatter_halo_extras_kernel<T><<<(unsigned) div_up(r_cnt[q], 256), 256, 0, stream>>>(      \
+                    r_cnt[q], blk[(size_t) q], halo_rec.get() + 2 * r_off[q], (const T *) blk0,              \
+                    (const int32_t *) (blk0 + r_cnt[q] * 2 * D * es), D, B, (T *) ms->let_tbb.get(),          \
+                    ms->let_srccum.get());                                                                    \
+            }                                                                                                 \
+        }
+        if (es == 8) BT_LET_EXT(double) else BT_LET_EXT(float)
+#undef BT_LET_EXT
+        BT_HIP_CHECK(hipGetLastError());
+    }
 
     ms->let_level_starts = level_starts;
     ms->let_nlevels = nlev;
@@ -1570,6 +1823,25 @@ int bt_mgpu_let_export(bt_context *ctx, const bt_mgpu_let_arrays *o)
     BT_CHECK(bt::let_link_device(ctx, ms->let_dims, ms->let_kind, ms->let_nlevels, ms->let_level_starts.data(),
                                  ms->let_paths.get(), aligned, pl.bbox_min, pl.bbox_max, pl.root_extent,
                                  o->box_parent_ids, o->box_child_ids, o->box_centers));
+    if (ms->let_ext) {
+        if (!o->box_target_bounding_box_min || !o->box_target_bounding_box_max || !o->box_source_counts_cumul) {
+            set_error("bt_mgpu_let_export: the LET has targets with extents; box_target_bounding_box_min / "
+                      "_max and box_source_counts_cumul are required");
+            return BT_ERR_INVALID;
+        }
+        if (cs == 8)
+            let_tbb_export_kernel<double><<<(unsigned) div_up(aligned, 256), 256, 0, stream>>>(
+                B, aligned, ms->let_dims, (const double *) ms->let_tbb.get(), (double *) o->box_target_bounding_box_min,
+                (double *) o->box_target_bounding_box_max);
+        else
+            let_tbb_export_kernel<float><<<(unsigned) div_up(aligned, 256), 256, 0, stream>>>(
+                B, aligned, ms->let_dims, (const float *) ms->let_tbb.get(), (float *) o->box_target_bounding_box_min,
+                (float *) o->box_target_bounding_box_max);
+        BT_HIP_CHECK(hipGetLastError());
+        BT_HIP_CHECK(hipMemcpyAsync(o->box_source_counts_cumul, ms->let_srccum.get(), (size_t) B * 4,
+                                    hipMemcpyDeviceToDevice, stream));
+        ms->let_tbb.reset(); ms->let_srccum.reset();
+    }
     ms->let_paths.reset(); ms->let_meta.reset(); ms->let_gid.reset(); ms->let_mask.reset();
     ms->let_nlevels = 0;
     return bt::finish_call(ctx);

@@ -478,9 +478,12 @@ struct FlagPred {
     const uint8_t *flags;
     const int8_t *mask;     // optional
     uint8_t bits;
+    uint8_t exact;          // the mask value must be 1 (a sharded traversal marks with 2 the shared
+                            // boxes whose own targets another rank holds: parents of target boxes
+                            // here, target boxes there)
     __device__ int32_t operator()(int64_t i) const
     {
-        return ((flags[i] & bits) && (!mask || mask[i])) ? 1 : 0;
+        return ((flags[i] & bits) && (!mask || (exact ? mask[i] == 1 : mask[i] != 0))) ? 1 : 0;
     }
 };
 
@@ -1273,7 +1276,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             BT_CHECK(bt::sync_stream(ctx));    // `list` is freed on scope exit
         }
         if (st->has_blocks)
-            copy_rank_blocks_kernel<<<(unsigned) std::min<int64_t>(ctx->num_cus * 8, div_up(ntb, 4)), 256, 0,
+            copy_rank_blocks_kernel<<<(unsigned) std::min<int64_t>(ctx->num_cus * 8, std::max<int64_t>(1, div_up(ntb, 4))), 256, 0,
                                       ctx->stream>>>(
                 (int32_t) ntb, jobs.dst, jobs.src, jobs.len, st->src_by_rank.get(), c1.lists.get());
     }
@@ -1908,7 +1911,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
                     a, ft, list[1].get(), pos[1].get() + ntb, c1.starts.get(), c1.lists.get(), jobs, 1);
         }
         if (with_blocks)
-            copy_rank_blocks_kernel<<<(unsigned) std::min<int64_t>(ctx->num_cus * 8, div_up(ntb, 4)), 256, 0,
+            copy_rank_blocks_kernel<<<(unsigned) std::min<int64_t>(ctx->num_cus * 8, std::max<int64_t>(1, div_up(ntb, 4))), 256, 0,
                                       ctx->stream>>>(
                 (int32_t) ntb, jobs.dst, jobs.src, jobs.len, st->src_by_rank.get(), c1.lists.get());
         if (l1_stats) {
@@ -1965,7 +1968,7 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
     const bool shared_tb = sat && !p.target_boxes_mask;     // target_boxes is source_boxes
     FlagPred preds[NL] = {
         {p.box_flags, p.source_boxes_mask, BT_BOX_IS_SOURCE_BOX},
-        {p.box_flags, p.target_boxes_mask, BT_BOX_IS_TARGET_BOX},
+        {p.box_flags, p.target_boxes_mask, BT_BOX_IS_TARGET_BOX, 1},
         {p.box_flags, p.source_parent_boxes_mask, BT_BOX_HAS_SOURCE_CHILD_BOXES},
         {p.box_flags, p.target_boxes_mask, BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX},
         {p.box_flags, nullptr, BT_BOX_HAS_SOURCE_CHILD_BOXES | BT_BOX_HAS_TARGET_CHILD_BOXES}};

@@ -292,6 +292,10 @@ def _local_tree_view(actx, tree):
     v.box_flags = tree.box_flags.data_ptr()
     v.nsources = int(tree.nsources)
     v.ntargets = int(tree.ntargets)
+    if getattr(tree, "targets_have_extent", False):
+        v.box_target_bounding_box_min = tree.box_target_bounding_box_min.data_ptr()
+        v.box_target_bounding_box_max = tree.box_target_bounding_box_max.data_ptr()
+        v.box_source_counts_cumul = tree.box_source_counts_cumul.data_ptr()
     return v, lsb
 
 
@@ -333,6 +337,13 @@ def build_local_essential_tree(actx, comm, tree, numbering, well_sep_is_n_away=1
         ((dims, aligned), coord_dtype), (B, np.int32), ((C, aligned), np.int32), (B, np.uint8),
         (B, np.uint8), (B, np.int32), (B, np.int8)])
     arrs = _lib.MgpuLetArrays()
+    ext = bool(getattr(tree, "targets_have_extent", False))
+    if ext:
+        tbb_min, tbb_max, srccum = actx.empty_block([
+            ((dims, aligned), coord_dtype), ((dims, aligned), coord_dtype), (B, np.int32)])
+        arrs.box_target_bounding_box_min = tbb_min.data_ptr()
+        arrs.box_target_bounding_box_max = tbb_max.data_ptr()
+        arrs.box_source_counts_cumul = srccum.data_ptr()
     arrs.box_centers = centers.data_ptr()
     arrs.box_parent_ids = parents.data_ptr()
     arrs.box_child_ids = children.data_ptr()
@@ -346,8 +357,15 @@ def build_local_essential_tree(actx, comm, tree, numbering, well_sep_is_n_away=1
         root_extent=tree.root_extent, box_centers=centers, box_parent_ids=parents,
         box_child_ids=children, box_levels=levels, box_flags=flags, level_start_box_nrs=lsb,
         box_id_dtype=np.dtype(np.int32), box_level_dtype=np.dtype(np.uint8),
-        coord_dtype=coord_dtype, sources_have_extent=False, targets_have_extent=False,
-        extent_norm=None, stick_out_factor=tree.stick_out_factor, _is_pruned=True)
+        coord_dtype=coord_dtype, sources_have_extent=False, targets_have_extent=ext,
+        extent_norm=tree.extent_norm if ext else None, stick_out_factor=tree.stick_out_factor,
+        _is_pruned=True)
+    if ext:
+        # what the traversal reads of a tree whose targets have extents
+        object.__setattr__(let, "box_target_bounding_box_min", tbb_min)
+        object.__setattr__(let, "box_target_bounding_box_max", tbb_max)
+        object.__setattr__(let, "box_source_counts_cumul", srccum)
+        object.__setattr__(let, "sources_are_targets", False)
     # made by the library on this device: contiguous arrays of its own types -- the traversal
     # builder takes them as they are (no conversions, no look at the root's parent entry)
     object.__setattr__(let, "_host_level_starts", lsb)
@@ -358,6 +376,9 @@ def build_local_essential_tree(actx, comm, tree, numbering, well_sep_is_n_away=1
                 halo_boxes_sent=int(sizes.halo_boxes_sent), nboxes=B,
                 loopback_records=int(sizes.loopback_records),
                 loopback_mismatches=int(sizes.loopback_mismatches))
+    if ext:
+        info.update(box_target_bounding_box_min=tbb_min, box_target_bounding_box_max=tbb_max,
+                    box_source_counts_cumul=srccum)
     return let, info
 
 

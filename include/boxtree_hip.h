@@ -660,6 +660,10 @@ typedef struct {
     const uint8_t *box_levels;            /* device [nboxes]                        */
     const uint8_t *box_flags;             /* device [nboxes] (bt_mgpu_let_build)    */
     int64_t nsources, ntargets;
+    /* targets with extents (bt_mgpu_let_build; NULL otherwise): what the traversal reads
+     * of a tree whose targets have extents, laid out as in the tree export */
+    const void *box_target_bounding_box_min, *box_target_bounding_box_max;  /* [dims][aligned_nboxes] */
+    const int32_t *box_source_counts_cumul;                                  /* [nboxes] */
 } bt_mgpu_local_tree;
 
 /* Step 5: where the rank's tree sits in the global one -- the tree a single GPU builds
@@ -701,7 +705,15 @@ typedef struct {
     int32_t *box_parent_ids, *box_child_ids;
     uint8_t *box_levels, *box_flags;
     int32_t *global_box_ids;
-    int8_t *target_boxes_mask;
+    int8_t *target_boxes_mask;            /* 1: this rank builds the lists of the box; 2 (targets  */
+                                          /* with extents): a shared internal box whose own        */
+                                          /* targets another rank holds -- the lists it has as a   */
+                                          /* parent of target boxes, not those of its own targets  */
+    /* targets with extents (the local tree had the three arrays): of every box of the LET --
+     * the owners send them with the halo boxes, the shared top boxes get the union over the
+     * ranks (an all-reduce) and their source counts from the plan */
+    void *box_target_bounding_box_min, *box_target_bounding_box_max;   /* [dims][aligned_nboxes] */
+    int32_t *box_source_counts_cumul;                                   /* [nboxes] */
 } bt_mgpu_let_arrays;
 int bt_mgpu_let_build(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
                       const int32_t *box_ids, const bt_mgpu_numbering *numbering,

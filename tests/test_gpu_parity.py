@@ -1158,6 +1158,37 @@ def test_multi_rank_native_entries_separate_targets(dims, world, dist_kind, nway
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims,world,dist_kind,nway,norm", [(3, 2, "uniform", 1, "linf"), (3, 3, "sphere", 1, "linf"),
+                                                            (2, 4, "uniform", 2, "l2"), (3, 5, "clustered", 1, "linf"),
+                                                            (2, 2, "normal", 1, "l2")])
+def test_multi_rank_native_entries_extents(dims, world, dist_kind, nway, norm):
+    """Targets with extents (BASELINE configs[3] on N ranks): the exchange counts where the
+    targets stop over the shared top levels, a target that stays in a top box travels to the
+    owner of the box's first cell, the LET carries target bounding boxes and source counts
+    (halo boxes from their owners, shared top boxes by an all-reduce), and the lists -- the
+    close lists included -- are those of the single-GPU build with target_radii."""
+    scale = {"uniform": 0.05, "sphere": 0.1, "clustered": 0.3, "normal": 0.4}[dist_kind]
+    check_multi_rank_let(dims, world, dist_kind, nway, native=True, expect_partial=False,
+                         sep_targets=True, target_extents=(scale, 0.25, norm))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(8))
+def test_multi_rank_native_entries_extents_random(seed):
+    rng = np.random.default_rng(12000 + seed)
+    dims = int(rng.choice([2, 3]))
+    dist_kind = str(rng.choice(["sphere", "uniform", "normal", "clustered"]))
+    scale = {"uniform": 0.05, "sphere": 0.1, "clustered": 0.3, "normal": 0.4}[dist_kind]
+    check_multi_rank_let(
+        dims, world=int(rng.integers(2, 7)), dist_kind=dist_kind, nway=int(rng.choice([1, 1, 2])),
+        n_per=int(rng.choice([3000, 20000])), mpb=int(rng.choice([8, 30, 64])),
+        top_level=int(rng.integers(2, 5) if dims == 3 else rng.integers(3, 6)),
+        seed=int(rng.integers(0, 10**6)), expect_partial=False, native=True, sep_targets=True,
+        target_extents=(scale * float(rng.choice([0.3, 1.0, 3.0])), float(rng.choice([0.0, 0.25, 0.5])),
+                        str(rng.choice(["linf", "l2"]))))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(10))
 def test_multi_rank_native_entries_random(seed):
     rng = np.random.default_rng(9000 + seed)
@@ -1188,7 +1219,8 @@ def test_multi_rank_local_essential_tree_random(seed):
 
 
 def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_level=None,
-                         seed=200, expect_partial=True, native=False, sep_targets=False):
+                         seed=200, expect_partial=True, native=False, sep_targets=False,
+                         target_extents=None):
     """native: steps 1-6 through the library's bt_mgpu_* entries, the ranks being threads
     that share a LocalGroup; otherwise the torch implementation over tests/fake_dist.py."""
     import threading
@@ -1223,6 +1255,13 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
         n_per = max(n_per // 3, 1)
         tchunks = [chunk(1000 + r) for r in range(world)]
         n_per = full_n
+    # ... with extents: target_extents = (radius scale, stick_out_factor, extent_norm); radii over
+    # four decades, so that most targets go deep and some stay in boxes of the shared top levels
+    rchunks = None
+    if target_extents is not None:
+        assert sep_targets
+        rchunks = [target_extents[0] * 10.0 ** np.random.default_rng(seed + 5000 + r).uniform(
+            -4, 0, len(tchunks[r][0])) for r in range(world)]
     fw = FakeWorld(world)
     group = None
     if native:
@@ -1237,7 +1276,15 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
             pts = [torch.from_numpy(a).cuda() for a in chunks[rank]]
             if native:
                 comm = group.comm(rank)
-                if sep_targets:
+                if rchunks is not None:
+                    tg = [torch.from_numpy(a).cuda() for a in tchunks[rank]]
+                    p2, t2, r2, kw, stats = nat.exchange_particles(
+                        actx, comm, pts, mpb, top_level=top_level, targets=tg,
+                        target_radii=torch.from_numpy(rchunks[rank]).cuda(),
+                        stick_out_factor=target_extents[1], extent_norm=target_extents[2])
+                    tree, _ = TreeBuilder(actx)(actx, p2, targets=t2, target_radii=r2,
+                                                max_particles_in_box=mpb, **kw)
+                elif sep_targets:
                     tg = [torch.from_numpy(a).cuda() for a in tchunks[rank]]
                     p2, t2, kw, stats = nat.exchange_particles(actx, comm, pts, mpb, top_level=top_level,
                                                                targets=tg)
@@ -1262,9 +1309,12 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
                 _active_level_ranges=info["active_level_ranges"])
             results[rank] = dict(let=actx.to_numpy(let), trav=actx.to_numpy(trav),
                                  gid=info["global_box_ids"].cpu().numpy().astype(np.int64),
-                                 mask=info["target_boxes_mask"].cpu().numpy().astype(bool),
+                                 mask=info["target_boxes_mask"].cpu().numpy().astype(np.int8),
                                  nhalo=info["halo_boxes_received"], nboxes=info["nboxes"],
-                                 nglobal=num["nboxes"])
+                                 nglobal=num["nboxes"],
+                                 ext={k: info[k].cpu().numpy() for k in (
+                                     "box_target_bounding_box_min", "box_target_bounding_box_max",
+                                     "box_source_counts_cumul") if k in info})
         except BaseException as e:      # noqa: BLE001
             import traceback
             errors.append((rank, repr(e), traceback.format_exc()[-1500:]))
@@ -1290,7 +1340,11 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
     if sep_targets:
         alltgts = [torch.from_numpy(np.concatenate([c[ax] for c in tchunks])).cuda()
                    for ax in range(dims)]
-    gt, _ = TreeBuilder(actx)(actx, allpts, targets=alltgts, max_particles_in_box=mpb)
+    ext_kw = {}
+    if rchunks is not None:
+        ext_kw = dict(target_radii=torch.from_numpy(np.concatenate(rchunks)).cuda(),
+                      stick_out_factor=target_extents[1], extent_norm=target_extents[2])
+    gt, _ = TreeBuilder(actx)(actx, allpts, targets=alltgts, max_particles_in_box=mpb, **ext_kw)
     full = actx.to_numpy(FMMTraversalBuilder(actx, well_sep_is_n_away=nway)(actx, gt)[0])
     g = actx.to_numpy(gt)
 
@@ -1304,8 +1358,12 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
     pos_t = {int(b): i for i, b in enumerate(full.target_boxes)}
     pos_p = {int(b): i for i, b in enumerate(full.target_or_target_parent_boxes)}
     deep_cover = np.zeros(g.nboxes, np.int64)
+    tgt_cover = np.zeros(g.nboxes, np.int64)
     for r in results:
-        t, tr, gid, hm = r["let"], r["trav"], r["gid"], r["mask"]
+        t, tr, gid = r["let"], r["trav"], r["gid"]
+        # mask 1: all lists of the box; 2 (extents): the lists it has as a parent of target boxes,
+        # its own targets are another rank's
+        hm, hm1 = r["mask"] != 0, r["mask"] == 1
         nb = t.nboxes
         assert r["nglobal"] == g.nboxes and nb <= g.nboxes
         if world > 2 and expect_partial:
@@ -1324,7 +1382,8 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
         deep_cover[gid[mine_deep]] += 1
         # lists, mapped to global numbers
         gt_boxes = gid[tr.target_boxes]
-        assert np.all(hm[tr.target_boxes])
+        assert np.all(hm1[tr.target_boxes])
+        tgt_cover[gt_boxes] += 1
         sel_t = [pos_t[int(b)] for b in gt_boxes]
         gp_boxes = gid[tr.target_or_target_parent_boxes]
         sel_p = [pos_p[int(b)] for b in gp_boxes]
@@ -1340,8 +1399,21 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
         assert rows(tr.same_level_non_well_sep_boxes_starts, tr.same_level_non_well_sep_boxes_lists,
                     act, gid) == rows(full.same_level_non_well_sep_boxes_starts,
                                       full.same_level_non_well_sep_boxes_lists, gid[act])
+        if rchunks is not None:
+            for name in ("from_sep_close_smaller", "from_sep_close_bigger"):
+                got = rows(getattr(tr, name + "_starts"), getattr(tr, name + "_lists"),
+                           range(len(sel_t)), gid)
+                want = rows(getattr(full, name + "_starts"), getattr(full, name + "_lists"), sel_t)
+                assert got == want, name
+            # what the traversal read of the LET's boxes: the global tree's values, every box
+            ex = r["ext"]
+            assert np.array_equal(ex["box_target_bounding_box_min"][:, :nb],
+                                  g.box_target_bounding_box_min[:, gid])
+            assert np.array_equal(ex["box_target_bounding_box_max"][:, :nb],
+                                  g.box_target_bounding_box_max[:, gid])
+            assert np.array_equal(ex["box_source_counts_cumul"], g.box_source_counts_cumul[gid])
         hm_global = np.zeros(g.nboxes, bool)
-        hm_global[gid[hm]] = True
+        hm_global[gid[hm1]] = True
         for lev in range(g.nlevels):
             a, b = tr.from_sep_smaller_by_level[lev], full.from_sep_smaller_by_level[lev]
             got = {int(gid[tb]): gid[a.lists[a.starts[i]:a.starts[i + 1]]].tolist()
@@ -1349,9 +1421,21 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
             want = {int(tb): b.lists[b.starts[i]:b.starts[i + 1]].tolist()
                     for i, tb in enumerate(full.target_boxes_sep_smaller_by_source_level[lev])
                     if hm_global[tb]}
+            if got != want:         # what differs, for the first few boxes
+                for tb in sorted(set(got) | set(want))[:400]:
+                    gl, wl = got.get(tb), want.get(tb)
+                    if gl != wl:
+                        gs, ws = set(gl or []), set(wl or [])
+                        print("list 3, source level", lev, "target box", tb, "level", g.box_levels[tb],
+                              "got", None if gl is None else len(gl), "want", None if wl is None else len(wl),
+                              "missing", [(int(x), int(g.box_levels[x])) for x in sorted(ws - gs)][:8],
+                              "extra", [(int(x), int(g.box_levels[x])) for x in sorted(gs - ws)][:8],
+                              "in LET", [bool(np.isin(x, gid)) for x in sorted(ws - gs)][:8])
             assert got == want
     # every box below the top levels is some rank's own, exactly once
     assert np.all(deep_cover[g.box_levels > top_level] == 1)
+    # the lists of every target box are built by exactly one rank
+    assert np.all(tgt_cover[full.target_boxes] == 1) and tgt_cover.sum() == len(full.target_boxes)
 
 
 @pytest.mark.gpu
