@@ -354,10 +354,12 @@ def main():
     xinfo = {}
 
     # N > 1 over RCCL, point particles (sources, and separate point targets): the library's
-    # own multi-GPU entries.  Other process groups (gloo: ranks that share a GPU) and workloads
-    # with extents or refine weights go through the torch implementation of the same steps.
+    # own multi-GPU entries, targets with extents included.  Other process groups (gloo: ranks
+    # that share a GPU) and refine weights go through the torch implementation of the same steps.
     native_comm = None
-    if (distributed and backend == "nccl" and not build_kw
+    # (build keywords the entries know: targets with extents)
+    native_kw_ok = set(build_kw) <= {"target_radii", "stick_out_factor", "extent_norm"}
+    if (distributed and backend == "nccl" and native_kw_ok
             and os.environ.get("BOXTREE_HIP_NATIVE_MGPU", "1") != "0"):
         from boxtree_amd.distributed import native as nat
         try:
@@ -403,6 +405,15 @@ def main():
             if targets is None:
                 p_, kw_, xs = nat.exchange_particles(actx, native_comm, particles, args.mpb)
                 t_ = None
+            elif "target_radii" in build_kw:
+                # targets with extents: a target that sticks out of the shared top boxes stays in
+                # one of them and travels to the owner of its first cell; radii ride along
+                p_, t_, r_, kw_, xs = nat.exchange_particles(
+                    actx, native_comm, particles, args.mpb, targets=targets,
+                    target_radii=build_kw["target_radii"],
+                    stick_out_factor=build_kw.get("stick_out_factor"),
+                    extent_norm=build_kw.get("extent_norm", "linf"))
+                kw_ = dict(kw_, target_radii=r_)
             else:
                 # separate point targets travel to the owners of their cells like the sources
                 p_, t_, kw_, xs = nat.exchange_particles(actx, native_comm, particles, args.mpb,

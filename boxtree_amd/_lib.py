@@ -180,7 +180,7 @@ class MgpuShard(ct.Structure):
                 ("top_cell_prefix", vp), ("bytes_sent", ct.c_int64), ("rounds", ct.c_int32),
                 ("a2a_ms", ct.c_float), ("n_owned_targets", ct.c_int64), ("target_points", vp),
                 ("sep_targets", ct.c_int32), ("target_record_len", ct.c_int32),
-                ("top_box_arrive", vp), ("top_box_stay", vp)]
+                ("target_radii", vp), ("top_box_arrive", vp), ("top_box_stay", vp)]
 
 
 class MgpuLocalTree(ct.Structure):

@@ -281,6 +281,14 @@ __global__ __launch_bounds__(256) void widen_hist_kernel(int64_t n, const int32_
     if (i < n) out[i] = in[i];
 }
 
+// column `col` of [n][len] records as a dense array
+template <class U>
+__global__ __launch_bounds__(256) void record_column_kernel(int64_t n, int len, int col, const U *rec, U *out)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = rec[i * len + col];
+}
+
 // mm = {min[D], -max[D], -1 if the rank has separate targets}: the identity of MIN first
 __global__ void mm_init_kernel(double *mm, int D, double flag)
 {
@@ -497,7 +505,8 @@ struct PinArena {
 struct MgpuState {
     PinArena arena;
     Buf<unsigned char> points;       // received particles, interleaved [n_owned][dims]
-    Buf<unsigned char> tpoints;      // ... separate targets
+    Buf<unsigned char> tpoints;      // ... separate targets ([n][dims + 1] with radii)
+    Buf<unsigned char> tradii;       // ... their radii, dense (the tree build reads them so)
     Buf<int64_t> cell_prefix;        // [C^top_level + 1]
     Buf<int64_t> top_tables;         // extents: arrivals, stayers per box of levels 0..top_level
     TopPlan plan;                    // of the last exchange on this context
@@ -1249,6 +1258,25 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     }
     BT_HIP_CHECK(hipEventRecord(ms->ev[1], stream));
     ms->a2a_pending = true;
+    void *radii_out = nullptr;
+    if (ext && nsets == 2) {
+        // the received targets' radii as an array of their own (bt_tree_params.target_radii is dense)
+        const int64_t nt = nrecv_of[1];
+        if (p->alloc) {
+            radii_out = p->alloc(p->alloc_user, std::max<int64_t>(nt, 1) * es);
+            if (!radii_out) { set_error("bt_mgpu_exchange: the caller's allocator returned NULL"); return BT_ERR_ALLOC; }
+        } else {
+            BT_CHECK(ms->tradii.alloc(ctx->pool, std::max<int64_t>(nt, 1) * es));
+            radii_out = ms->tradii.get();
+        }
+        if (nt > 0) {
+            if (f64) record_column_kernel<uint64_t><<<(unsigned) div_up(nt, 256), 256, 0, stream>>>(
+                nt, D + 1, D, (const uint64_t *) points_of[1], (uint64_t *) radii_out);
+            else record_column_kernel<uint32_t><<<(unsigned) div_up(nt, 256), 256, 0, stream>>>(
+                nt, D + 1, D, (const uint32_t *) points_of[1], (uint32_t *) radii_out);
+            BT_HIP_CHECK(hipGetLastError());
+        }
+    }
     BT_CHECK(ms->cell_prefix.alloc(ctx->pool, ncells + 1));
     memcpy(h_prefix, pl.prefix.data(), (size_t) (ncells + 1) * 8);
     BT_HIP_CHECK(hipMemcpyAsync(ms->cell_prefix.get(), h_prefix, (size_t) (ncells + 1) * 8,
@@ -1269,6 +1297,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     ms->done_pending = true;
 
     out->target_record_len = vals_of[1];
+    out->target_radii = radii_out;
     out->n_owned = nrecv_of[0];
     out->points = points_of[0];
     out->n_owned_targets = nrecv_of[1];

@@ -175,7 +175,6 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
         par.ntargets = len(keep_t[0])
         for ax in range(dims):
             par.targets[ax] = keep_t[ax].data_ptr()
-        own_buffer = True
         if target_radii is not None:
             if stick_out_factor is None:
                 raise ValueError("stick_out_factor must be given with target_radii")
@@ -201,7 +200,7 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
     _lib.check(actx.lib.bt_mgpu_exchange(actx.handle, comm.handle, ct.byref(par), ct.byref(shard)))
     n_owned = int(shard.n_owned)
     if targets is not None:
-        res = _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev)
+        res = _exchanged_with_targets(actx, shard, bufs if own_buffer else [], dims, dtype, es, dev)
         if target_radii is None:
             return res
         p2, t2, kw, stats = res
@@ -240,24 +239,46 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
 
 
 def _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev):
-    """Contiguous coordinate arrays of both received sets (``bt_unpack``) + build kwargs."""
+    """Views of both received sets (interleaved records, read in place by the tree build:
+    ``_point_stride`` / ``_target_stride``; radii as a dense array) + build kwargs.  The buffers
+    are the context's (valid until its next exchange) or, with *own_buffer*, torch allocations
+    in the order the library asked for them: sources, targets, radii."""
     import torch
-    out = []
-    if len(bufs) < 2:
-        # no rank of the job had a target: the library exchanged one set
-        bufs = [bufs[0], None]
-    for buf, n, nv in ((bufs[0], int(shard.n_owned), dims),
-                       (bufs[1], int(shard.n_owned_targets), int(shard.target_record_len) or dims)):
-        arrs = [torch.empty(n, dtype=dtype, device=dev) for _ in range(nv)]
-        optrs = (ct.c_void_p * nv)(*[a.data_ptr() for a in arrs])
-        if n:
-            _lib.check(actx.lib.bt_unpack(actx.handle, nv, es, ct.c_void_p(buf.data_ptr()), n, optrs))
-        out.append(arrs)
+    ts = "<f8" if es == 8 else "<f4"
+    ns, nt = int(shard.n_owned), int(shard.n_owned_targets)
+    nv = int(shard.target_record_len) or dims
+
+    def view(ptr_, buf, n, width):
+        if buf is not None:
+            flat = buf[:n * width * es].view(dtype)
+        else:
+            flat = torch.as_tensor(_DevicePointer(ptr_, (max(n, 1) * width,), ts), device=dev)[:n * width]
+        return flat.view(n, width)
+
+    own = len(bufs) > 0
+    src = view(shard.points, bufs[0] if own else None, ns, dims)
+    tbuf = bufs[1] if own and len(bufs) > 1 else None
+    if shard.target_points:
+        tgt = view(shard.target_points, tbuf, nt, nv)
+    else:       # no rank of the job had a target: the library exchanged one set
+        tgt = torch.empty((0, nv), dtype=dtype, device=dev)
+    out = [[src[:, ax] for ax in range(dims)], [tgt[:, ax] for ax in range(dims)]]
+    if shard.target_radii:
+        rbuf = bufs[2] if own and len(bufs) > 2 else None
+        out[1].append(view(shard.target_radii, rbuf, nt, 1)[:, 0])
     coord = np.dtype(np.float64 if dtype == torch.float64 else np.float32)
     bbox_min = np.array(shard.bbox_min[:dims], dtype=coord)
     bbox_max = np.array(shard.bbox_max[:dims], dtype=coord)
     root_extent = coord.type(shard.root_extent)
     build_kw = {"_root_box": (bbox_min, bbox_max, root_extent)}
+    if dims > 1:
+        build_kw["_point_stride"] = dims
+    else:
+        out[0] = [p.contiguous() for p in out[0]]
+    if nv > 1:
+        build_kw["_target_stride"] = nv
+    else:
+        out[1] = [t.contiguous() for t in out[1]]
     k = int(shard.top_level)
     if shard.top_cell_prefix:
         prefix = torch.as_tensor(

@@ -110,7 +110,7 @@ def _check_radii(name, radii, count, coord_dtype):
 
 
 def _normalise_inputs(actx, kind, particles, targets, source_radii, target_radii,
-                      extent_norm, stick_out_factor, point_stride) -> _Inputs:
+                      extent_norm, stick_out_factor, point_stride, target_stride=0) -> _Inputs:
     if kind not in ("adaptive", "adaptive-level-restricted", "non-adaptive"):
         raise ValueError(f"unknown tree kind: '{kind}'")
     if extent_norm is None:
@@ -127,7 +127,7 @@ def _normalise_inputs(actx, kind, particles, targets, source_radii, target_radii
         # place (bt_tree_params.source_stride)
         particles = list(particles)
         assert all(p.stride(0) == point_stride for p in particles)
-        assert source_radii is None and targets is None
+        assert source_radii is None and (targets is None or target_stride > 1)
     else:
         particles = [_on_device(actx, p) for p in particles]
     dtypes = {np_dtype_of(p) for p in particles}
@@ -138,7 +138,11 @@ def _normalise_inputs(actx, kind, particles, targets, source_radii, target_radii
         raise TypeError(f"unsupported coordinate dtype {coord_dtype}")
     _equal_lengths(particles, "coordinate arrays must have equal length")
 
-    if targets is not None:
+    if targets is not None and target_stride > 1:
+        # ... and so are the targets (bt_tree_params.target_stride)
+        targets = list(targets)
+        assert all(t.stride(0) == target_stride for t in targets)
+    elif targets is not None:
         targets = [_on_device(actx, t) for t in targets]
         _equal_lengths(targets, "target coordinate arrays must have equal length")
     inp = _Inputs(particles=particles, targets=targets,
@@ -286,8 +290,9 @@ class TreeBuilder:
         # host side of the call: argument contract, weights, root box (helpers below)
         point_stride = int(kwargs.get("_point_stride") or 0)
         _lib.host_trace("tb:enter")
+        target_stride = int(kwargs.get("_target_stride") or 0)
         inp = _normalise_inputs(actx, kind, particles, targets, source_radii, target_radii,
-                                extent_norm, stick_out_factor, point_stride)
+                                extent_norm, stick_out_factor, point_stride, target_stride)
         refine_weights, max_leaf_refine_weight = _refine_weight_spec(
             actx, inp, max_particles_in_box, refine_weights, max_leaf_refine_weight)
         _lib.host_trace("tb:inputs")
@@ -329,11 +334,13 @@ class TreeBuilder:
         tp.nsources = nsources
         tp.ntargets = -1 if sources_are_targets else ntargets
         tp.source_stride = point_stride if point_stride > 1 else 0
+        tp.target_stride = target_stride if target_stride > 1 else 0
         for i in range(dimensions):
             tp.sources[i] = (particles[i].data_ptr() if point_stride > 1
                              else ptr(particles[i]).value)
             if targets is not None:
-                tp.targets[i] = ptr(targets[i]).value
+                tp.targets[i] = (targets[i].data_ptr() if target_stride > 1
+                                 else ptr(targets[i]).value)
         tp.source_radii = ptr(source_radii)
         tp.target_radii = ptr(target_radii)
         tp.refine_weights = ptr(refine_weights)

@@ -619,7 +619,9 @@ typedef struct {
     int32_t sep_targets;               /* 1: some rank passed separate targets, so every  */
                                        /* rank exchanged two sets (n_owned_targets may be 0) */
     int32_t target_record_len;         /* values per received target: dims, or dims + 1 with */
-                                       /* radii (the radius last)                            */
+                                       /* radii (the radius last): bt_tree_params.target_stride */
+    void *target_radii;                /* ... and the radii once more as a dense array        */
+                                       /* [n_owned_targets] (third allocation), else NULL     */
     const int64_t *top_box_arrive, *top_box_stay;   /* device tables for bt_tree_params with   */
                                        /* extents (levels 0..top_level), else NULL           */
 } bt_mgpu_shard;
