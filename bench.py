@@ -555,7 +555,7 @@ def main():
         n_sorted = sort_ms[-1][2]
         # bytes a digit pass reads + writes per particle: 24 for (u64 key, u32 id) pairs, 16
         # when the build packs the id under the path bits of one 64-bit word (point
-        # particles; DESIGN.md "packed keys")
+        # particles; DESIGN.md section 3, LAB_NOTES.md "Packed keys")
         pass_bytes = float(sort_ms[-1][6] or 24)
         keys_only = pass_bytes == 16.0
         achieved = pass_bytes * n_sorted / (pass_ms * 1e-3) / 1e9 if pass_ms > 0 else 0.0

@@ -115,7 +115,7 @@ Nccl &nccl()
         }                                                                         \
     } while (0)
 
-constexpr int64_t MESSAGE_LIMIT_BYTES = (int64_t) 512 << 20;   // see DESIGN.md (RCCL, > 1 GB)
+constexpr int64_t MESSAGE_LIMIT_BYTES = (int64_t) 512 << 20;   // see LAB_NOTES.md section 6 (RCCL, > 1 GB)
 
 // ranks as threads of one process: a table of pointers and a generation barrier
 struct LocalGroup {

@@ -179,7 +179,7 @@ struct V2Rows {
 // An earlier form (a group of 2^d lanes per BOX, a lane per child slot, one 4-byte load per
 // candidate and lane, two ballots per candidate) took 10-14 % longer at 10^8 sphere points;
 // both forms are bound by vector-ALU issue (SQ_INSTS_VALU x 4 cycles per wave64
-// instruction / 1024 SIMDs accounts for the whole duration), not by memory: see DESIGN.md
+// instruction / 1024 SIMDs accounts for the whole duration), not by memory: see LAB_NOTES.md
 // section 4.
 // four list entries stored at once at any 4-byte boundary (global_store_dwordx4)
 struct __attribute__((packed, aligned(4))) PackedI4 { int32_t x, y, z, w; };
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             // handled in straight-line code -- the child words and the Morton bits are
             // compile-time selections, no stack, one update of the level counter -- instead
             // of one trip of the general loop each (a volume-filling cloud at 1.25*10^8
-            // points: walk 3.0 -> see DESIGN.md).
+            // points: walk 3.0 -> see LAB_NOTES.md section 5).
             if (!kd.has_src_children()) {
                 int n3_here = 0;
 #pragma unroll

@@ -524,7 +524,7 @@ class TreeBuilder:
             # Upstream never tests this combination, and its algorithm -- followed line
             # by line by the oracle, and mirrored here -- can leave a box without
             # children whose particles are not all its own: particles no leaf owns
-            # (tools/fuzz_parity.py seed 100310 with lr_extents=True; DESIGN.md section
+            # (tools/fuzz_parity.py seed 100310 with lr_extents=True; LAB_NOTES.md section
             # 2).  Such a tree is not handed out.
             nb = int(tree.nboxes)
             childless = (tree.box_child_ids[:, :nb] == 0).all(dim=0)

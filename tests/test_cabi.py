@@ -36,7 +36,7 @@ def test_struct_sizes_match_header():
     # guards against ctypes/C layout drift: sizes computed from the header's
     # field lists with natural alignment
     import ctypes as ct
-    assert ct.sizeof(_lib.TreeParams) == 8 + 16 + 24 + 24 + 8 * 3 + 16 + 8 + 48 + 8 + 16 + 16 + 16
+    assert ct.sizeof(_lib.TreeParams) == 8 + 16 + 24 + 24 + 8 * 3 + 16 + 8 + 48 + 8 + 16 + 16 + 16 + 16
     assert ct.sizeof(_lib.TreeSizes) == 16 + 8 + 4 * 65 + 4 + 7 * 8
     assert ct.sizeof(_lib.TravSizes) == 8 * 10 + 8 * 64 * 2
 

@@ -211,7 +211,7 @@ def test_self_loopback_runs_the_point_to_point_branch(dims, sep):
 
 def test_self_loopback_messages_above_the_round_limit():
     """A 1.7 GB message to oneself: four grouped ncclSend / ncclRecv rounds of at most 512 MiB
-    (an unchunked message above 1 GB once arrived corrupted); every byte must arrive."""
+    (an unchunked message above 1 GB once arrived corrupted, LAB_NOTES.md section 6); every byte must arrive."""
     import torch
     from boxtree_amd import HIPArrayContext
     from boxtree_amd.distributed import native as nat

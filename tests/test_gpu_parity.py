@@ -305,7 +305,7 @@ def test_deep_tree_below_the_key(actx, oracle, log2_scale, n_cl):
     keeps splitting, tree_build.py:622, 705-709)."""
     p = clustered_points(3, 20000, n_cl, 2.0 ** log2_scale, seed=7 - log2_scale)
     htree, otree, htrav, _ = build_both(actx, oracle, p, max_particles_in_box=8, trav_kw={})
-    assert 23 <= htree.nlevels <= 30          # (level 30 and below: DESIGN.md, int-shift deviation)
+    assert 23 <= htree.nlevels <= 30          # (level 30 and below: LAB_NOTES.md section 2, int-shift deviation)
     check_tree(htree, p, max_particles_in_box=8)
     check_traversal(htree, htrav)
 
@@ -365,7 +365,7 @@ def test_argument_errors(actx):
 
 
 def test_level_restriction_with_extents_refuses_orphaned_particles(actx):
-    """upstream's algorithm can leave particles that no leaf owns
+    """LAB_NOTES.md section 2: upstream's algorithm can leave particles that no leaf owns
     when level restriction meets extents; such a tree is not handed out."""
     import os
     import sys

@@ -60,7 +60,7 @@ def make_case(seed, lr_extents=False):
         targets = points(int(rng.choice([1, 50, 2000, 15000])), shift=float(rng.random()))
     trav_kw = {"well_sep_is_n_away": int(rng.choice([1, 1, 2]))}
     # (level-restricted trees with extents are left out: upstream's own result there
-    # has boxes flagged as split whose children never materialise)
+    # has boxes flagged as split whose children never materialise, LAB_NOTES.md section 2)
     if (targets is not None and (lr_extents or kind != "adaptive-level-restricted")
             and rng.random() < 0.5):
         nt = len(targets[0])
@@ -256,7 +256,7 @@ def run(ncases, first_seed, verbose=True, aux=True):
             # ``1 << (1 + new_level)`` on a 32-bit int (tree_build_kernels.py:698),
             # which is -2^31 at level 30 -- the oracle restates that literally and
             # mirrors the two children of a level-29 box; the device keeps the
-            # geometrically correct centres (deviations).
+            # geometrically correct centres (LAB_NOTES.md section 2, deviations).
             stats["beyond_int_shift"] = stats.get("beyond_int_shift", 0) + 1
             continue
         try:
