@@ -258,7 +258,7 @@ EXPORTED_SYMBOLS = [
     "bt_fmm_box_particle_sums", "bt_fmm_csr_sum", "bt_fmm_box_to_particles", "bt_fmm_tree_sweep",
     "bt_translation_classes",
     "bt_filter_targets_user_order", "bt_filter_targets_tree_order", "bt_link_point_sources",
-    "bt_box_morton_paths", "bt_let_build", "bt_mgpu_exchange", "bt_mgpu_exchange_time", "bt_mgpu_plan",
+    "bt_box_morton_paths", "bt_let_build", "bt_mgpu_exchange", "bt_mgpu_exchange_time", "bt_mgpu_plan", "bt_mgpu_plan_ext",
     "bt_mgpu_comm_rccl", "bt_mgpu_local_group_create", "bt_mgpu_local_group_destroy",
     "bt_mgpu_comm_local", "bt_mgpu_comm_destroy", "bt_mgpu_use_rccl_library",
     "bt_mgpu_comm_set_self_loopback", "bt_mgpu_number", "bt_mgpu_let_build",
@@ -334,6 +334,7 @@ def load():
                                       ct.POINTER(MgpuNumbering), ct.c_int, ct.POINTER(MgpuLetSizes)]
     lib.bt_mgpu_let_export.argtypes = [vp, ct.POINTER(MgpuLetArrays)]
     lib.bt_mgpu_plan.argtypes = [ct.c_int, ct.c_int, ct.c_int64, ct.c_int, vp, vp, vp]
+    lib.bt_mgpu_plan_ext.argtypes = [ct.c_int, ct.c_int, ct.c_int64, ct.c_int, vp, vp, vp, vp, vp, vp]
     lib.bt_traversal_build_packed.argtypes = [vp, ct.POINTER(TravParams), ALLOC_FN, vp,
                                               ct.POINTER(TravPacked)]
     lib.bt_merge_csr_lists.argtypes = [vp, ct.c_int, ct.POINTER(vp), ct.POINTER(vp),

@@ -1007,6 +1007,33 @@ int bt_mgpu_plan(int dims, int top_level, int64_t max_particles_in_box, int nran
     return BT_OK;
 }
 
+// bt_mgpu_plan for particles with extents: stay_table (levels 0..top_level, box (level, path) at
+// (C^level - 1) / (C - 1) + path) counts the particles that stay in a box; cell_hist counts such
+// a particle at the first cell under its box.  box_arrive / box_split (same indexing, may be
+// NULL): the particles that arrive in every box, and whether it exists and splits.
+int bt_mgpu_plan_ext(int dims, int top_level, int64_t max_particles_in_box, int nranks,
+                     const int64_t *cell_hist, const int64_t *stay_table, int32_t *owner_of_cell,
+                     int64_t *cell_prefix, int64_t *box_arrive, uint8_t *box_split)
+{
+    if (dims < 1 || dims > 3 || top_level < 1 || dims * top_level > 30 || nranks < 1
+            || !cell_hist || !owner_of_cell) {
+        set_error("bt_mgpu_plan_ext: invalid argument");
+        return BT_ERR_INVALID;
+    }
+    static thread_local TopPlan pl;
+    compute_plan(dims, top_level, max_particles_in_box, nranks, cell_hist, stay_table, pl);
+    std::copy(pl.owner.begin(), pl.owner.end(), owner_of_cell);
+    if (cell_prefix) std::copy(pl.prefix.begin(), pl.prefix.end(), cell_prefix);
+    for (int lev = 0; lev <= top_level; ++lev) {
+        const int64_t off = top_table_offset(dims, lev), n = (int64_t) 1 << (dims * lev);
+        if (box_arrive) std::copy(pl.counts[lev].begin(), pl.counts[lev].begin() + n, box_arrive + off);
+        if (box_split)
+            for (int64_t i = 0; i < n; ++i)
+                box_split[off + i] = pl.valid ? (uint8_t) ((pl.exists[lev][(size_t) i] ? 1 : 0) | (pl.split[lev][(size_t) i] ? 2 : 0)) : 0;
+    }
+    return BT_OK;
+}
+
 static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *p, bt_mgpu_shard *out)
 {
     bt::CallScope bt_call_scope_(ctx);

@@ -652,6 +652,15 @@ int bt_mgpu_exchange_time(bt_context *ctx, float *a2a_ms);
 int bt_mgpu_plan(int dims, int top_level, int64_t max_particles_in_box, int nranks,
                  const int64_t *global_hist, int32_t *owner_of_cell, int64_t *cell_prefix);
 
+/* The same for particles with extents: stay_table counts, per box of levels 0..top_level (box
+ * (level, Morton path) at index (C^level - 1) / (C - 1) + path, C = 2^dims), the particles that
+ * stay in it; global_hist counts such a particle at the first cell under its box.  A box splits
+ * iff arrivals - stayers > max_particles_in_box (tree_build_kernels.py:569-591).  box_arrive
+ * (same indexing) and box_split (bit 0: the box exists, bit 1: it splits) may be NULL. */
+int bt_mgpu_plan_ext(int dims, int top_level, int64_t max_particles_in_box, int nranks,
+                     const int64_t *global_hist, const int64_t *stay_table, int32_t *owner_of_cell,
+                     int64_t *cell_prefix, int64_t *box_arrive, uint8_t *box_split);
+
 /* the tree a rank built from its shard (bt_tree_sizes / bt_tree_arrays of that build) */
 typedef struct {
     int32_t dims, coord_kind;

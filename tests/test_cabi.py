@@ -113,3 +113,71 @@ def test_mgpu_plan_matches_the_python_plan():
                     else:
                         want = partition_cells(hist, world, None)
                     assert np.array_equal(owner, want), (dims, k, world, mpb)
+
+
+def test_mgpu_plan_with_extents_from_particles():
+    """bt_mgpu_plan_ext (the plan of a sharded build whose targets have extents) against a
+    particle-level statement: particles are (level-k cell, stop level); a box's arrivals are the
+    particles under it that did not stop above it, it splits iff those that do not stop IN it
+    exceed the limit (tree_build_kernels.py:569-591), a child exists iff its parent splits and
+    something arrives; leaves above level k go to one rank; a particle that stays in a box counts
+    for the box's first cell when the owners are balanced.  Pure host code."""
+    import ctypes as ct
+
+    import numpy as np
+
+    from boxtree_amd.distributed import partition_cells
+    lib = _lib.load()
+    rng = np.random.default_rng(17)
+    for dims, k in ((3, 3), (2, 4), (1, 6), (3, 2)):
+        C = 1 << dims
+        ncells = C ** k
+        off = [(C ** lev - 1) // (C - 1) for lev in range(k + 2)]
+        for trial in range(4):
+            n = int(rng.integers(2000, 20000))
+            # clustered cells; most particles go below level k, some stop at a level <= k
+            cell = np.where(rng.random(n) < 0.5, rng.integers(0, ncells, n),
+                            rng.integers(0, max(ncells // 16, 1), n)).astype(np.int64)
+            cap = np.where(rng.random(n) < 0.15, rng.integers(0, k + 1, n), k + 1)
+            for mpb in (5, 60):
+                # the tables the exchange makes: stayers per box, particles per (effective) cell
+                stay = np.zeros(off[k + 1], np.int64)
+                eff = cell.copy()
+                for lev in range(k + 1):
+                    m = cap == lev
+                    sh = dims * (k - lev)
+                    np.add.at(stay, off[lev] + (cell[m] >> sh), 1)
+                    eff[m] = (cell[m] >> sh) << sh
+                hist = np.bincount(eff, minlength=ncells).astype(np.int64)
+                # particle-level statement
+                arrive, split, exists = {}, {}, {0: np.ones(1, bool)}
+                for lev in range(k + 1):
+                    sh = dims * (k - lev)
+                    m = cap >= lev
+                    arrive[lev] = np.bincount(cell[m] >> sh, minlength=C ** lev)
+                    desc = np.bincount(cell[cap > lev] >> sh, minlength=C ** lev)
+                    split[lev] = exists[lev] & (desc > mpb)
+                    if lev < k:
+                        a_next = np.bincount(cell[cap >= lev + 1] >> (dims * (k - lev - 1)), minlength=C ** (lev + 1))
+                        exists[lev + 1] = np.repeat(split[lev], C) & (a_next > 0)
+                unit = np.arange(ncells)
+                for lev in range(k - 1, -1, -1):          # the topmost box that does not split wins
+                    sh = dims * (k - lev)
+                    leafy = ~split[lev][np.arange(ncells) >> sh]
+                    unit = np.where(leafy, (np.arange(ncells) >> sh) << sh, unit)
+                for world in (1, 3, 8):
+                    owner = np.empty(ncells, np.int32)
+                    prefix = np.empty(ncells + 1, np.int64)
+                    box_arrive = np.empty(off[k + 1], np.int64)
+                    box_split = np.empty(off[k + 1], np.uint8)
+                    vp = lambda a: a.ctypes.data_as(ct.c_void_p)      # noqa: E731
+                    code = lib.bt_mgpu_plan_ext(dims, k, mpb, world, vp(hist), vp(stay), vp(owner),
+                                                vp(prefix), vp(box_arrive), vp(box_split))
+                    assert code == 0
+                    for lev in range(k + 1):
+                        sl = slice(off[lev], off[lev + 1])
+                        assert np.array_equal(box_arrive[sl], arrive[lev]), (dims, k, lev)
+                        assert np.array_equal((box_split[sl] & 1) != 0, exists[lev]), (dims, k, lev)
+                        assert np.array_equal((box_split[sl] & 2) != 0, split[lev]), (dims, k, lev)
+                    assert np.array_equal(prefix, np.concatenate([[0], np.cumsum(hist)]))
+                    assert np.array_equal(owner, partition_cells(hist, world, unit)), (dims, k, world)
