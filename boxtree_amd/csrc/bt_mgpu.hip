@@ -342,6 +342,7 @@ struct TopPlan {
     bool has_stay = false;                        // particles with extents: `stay` is filled
     double stick_out_factor = 0;                  // ... and this is how far a target may leave its box
     std::vector<std::vector<int64_t>> stay;       // [k+1][C^lev]: particles that stay in the box
+    std::vector<std::vector<int64_t>> stay_src;   // ... the sources among them
     std::vector<std::vector<int64_t>> counts;     // [k+1][C^lev]
     std::vector<std::vector<char>> exists, split;
     std::vector<std::vector<int32_t>> index;      // number of a box among the existing boxes of its level
@@ -511,6 +512,7 @@ struct MgpuState {
     Buf<int64_t> top_tables;         // extents: arrivals, stayers per box of levels 0..top_level
     TopPlan plan;                    // of the last exchange on this context
     std::vector<int64_t> ghist;      // combined global cell histogram of that exchange
+    std::vector<int64_t> stay_all;   // ... and stayers (sources + targets) per top box
     hipEvent_t ev[2] = {nullptr, nullptr};   // around the payload all-to-all-v
     hipEvent_t ev_counts = nullptr;          // the counts matrix has reached the host
     hipEvent_t ev_done = nullptr;            // the last exchange's use of the pinned block is over
@@ -897,7 +899,8 @@ void cells_needed_by(const TopPlan &pl, int rank, int ring, int nwords, std::vec
             for (int64_t pth = 0; pth < nb; ++pth) {
                 if (!pl.exists[lev][pth]) continue;
                 const bool internal = pl.split[lev][pth];
-                const int64_t ntg = internal ? pl.stay[lev][pth] : pl.counts[lev][pth] - pl.src_counts[lev][pth];
+                const int64_t ntg = internal ? pl.stay[lev][pth] - pl.stay_src[lev][pth]
+                                             : pl.counts[lev][pth] - pl.src_counts[lev][pth];
                 if (ntg <= 0) continue;
                 const int64_t first = pth << (D * (k - lev));
                 const int q = pl.owner[(size_t) first];
@@ -1080,7 +1083,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     // histogram words: source cells, target cells, and with extents the targets that stay in
     // a box of levels 0..k
     const int64_t ntop1 = top_table_offset(D, k + 1);
-    const int64_t nh = 2 * ncells + (ext ? ntop1 : 0);
+    const int64_t nh = 2 * ncells + (ext ? 2 * ntop1 : 0);       // + stayers: sources, targets
     if (!ms->ev[0]) {
         BT_HIP_CHECK(hipEventCreate(&ms->ev[0]));
         BT_HIP_CHECK(hipEventCreate(&ms->ev[1]));
@@ -1137,10 +1140,12 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     for (int s = 0; s < 2; ++s) {
         if (nset[s] == 0) continue;
         BT_CHECK(cells[s].alloc(ctx->pool, nset[s]));
-        if (rset[s])
+        if (ext)
+            // (the sources too: points, but with a stick-out factor near zero the rounding of the
+            // test lets points stay in boxes, in the build and therefore here)
             BT_CHECK(bt::morton_cells_ext_device(ctx, D, p->coord_kind, cset[s], rset[s], nset[s], rootbox_d.get(),
                                                  k, p->stick_out_factor, p->extent_norm, cells[s].get(),
-                                                 hist32.get() + s * ncells, hist32.get() + 2 * ncells));
+                                                 hist32.get() + s * ncells, hist32.get() + 2 * ncells + s * ntop1));
         else
             BT_CHECK(bt::morton_cells_device(ctx, D, p->coord_kind, cset[s], nset[s], rootbox_d.get(), k,
                                              cells[s].get(), hist32.get() + s * ncells));
@@ -1170,7 +1175,12 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     ghist.resize((size_t) ncells);
     for (int64_t c = 0; c < ncells; ++c) ghist[(size_t) c] = h_ghist2[c] + h_ghist2[ncells + c];
     TopPlan &pl = ms->plan;
-    compute_plan(D, k, p->max_particles_in_box, nranks, ghist.data(), ext ? h_ghist2 + 2 * ncells : nullptr, pl);
+    std::vector<int64_t> &stay_all = ms->stay_all;
+    if (ext) {
+        stay_all.resize((size_t) ntop1);
+        for (int64_t i = 0; i < ntop1; ++i) stay_all[(size_t) i] = h_ghist2[2 * ncells + i] + h_ghist2[2 * ncells + ntop1 + i];
+    }
+    compute_plan(D, k, p->max_particles_in_box, nranks, ghist.data(), ext ? stay_all.data() : nullptr, pl);
     if (ext && !sep) {
         set_error("bt_mgpu_exchange: extent_norm is set but no rank has targets");
         return BT_ERR_INVALID;
@@ -1180,12 +1190,26 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     pl.stick_out_factor = ext ? p->stick_out_factor : 0;
     pl.src_counts.resize((size_t) k + 1);
     pl.src_counts[k].assign(h_ghist2, h_ghist2 + ncells);
+    pl.stay_src.resize(ext ? (size_t) k + 1 : 0);
+    if (ext) {
+        const int64_t *ss = h_ghist2 + 2 * ncells;
+        for (int lev = 0; lev <= k; ++lev) {
+            const int64_t n = (int64_t) 1 << (D * lev), off = top_table_offset(D, lev);
+            pl.stay_src[lev].assign(ss + off, ss + off + n);
+        }
+        // (sources that stay above level k were counted at their box's first cell)
+        for (int lev = 0; lev < k; ++lev) {
+            const int64_t n = (int64_t) 1 << (D * lev);
+            const int sh = D * (k - lev);
+            for (int64_t i = 0; i < n; ++i) pl.src_counts[k][(size_t) (i << sh)] -= pl.stay_src[lev][(size_t) i];
+        }
+    }
     for (int lev = k - 1; lev >= 0; --lev) {
         const int64_t n = (int64_t) 1 << (D * lev);
         pl.src_counts[lev].resize((size_t) n);
         const int64_t *below = pl.src_counts[lev + 1].data();
         for (int64_t i = 0; i < n; ++i) {
-            int64_t sum = 0;
+            int64_t sum = ext ? pl.stay_src[lev][(size_t) i] : 0;
             for (int m = 0; m < (1 << D); ++m) sum += below[i * (1 << D) + m];
             pl.src_counts[lev][(size_t) i] = sum;
         }
@@ -1682,8 +1706,11 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
                 flags = (ns > 0 ? BT_BOX_IS_SOURCE_BOX : 0) | (ntg > 0 ? BT_BOX_IS_TARGET_BOX : 0);
             }
             // a box with children whose own (staying) particles are targets is a target box too
-            const bool own_targets = internal && ext && pl.stay[lev][pth] > 0;
+            // (tbk:1252-1256; likewise sources, which only stay when the stick-out factor is ~0)
+            const int64_t stay_s = (internal && ext) ? pl.stay_src[lev][pth] : 0;
+            const bool own_targets = internal && ext && pl.stay[lev][pth] - stay_s > 0;
             if (own_targets) flags |= BT_BOX_IS_TARGET_BOX;
+            if (stay_s > 0) flags |= BT_BOX_IS_SOURCE_BOX;
             // lists of the shared internal boxes are built by every rank, those of a top LEAF
             // only by the rank that owns its cells -- and the lists an internal box has as a
             // target box (its own targets', extents only) by the rank that holds those targets

@@ -3714,19 +3714,44 @@ __global__ __launch_bounds__(1024) void ext_cells_kernel(KeygenArgs<T, D> a, int
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist_ext[];
     const bool lds = ncells <= (1 << 15);
     if (lds) for (int c = threadIdx.x; c < ncells; c += 1024) s_hist_ext[c] = 0;
+    // Down to which level can a point (radius 0) not stop?  The build's own bound
+    // (tree_build_impl: the margin stick_out_factor / 2 box sizes against 128 spacings of T at
+    // the magnitude of the coordinates), from the root box on the device: with an ordinary
+    // stick-out factor it exceeds k + 1 and points skip the test; with a factor near zero they
+    // do stay in boxes, here as in the build.
+    {
+        const T *rb = a.rootbox;
+        double scale = fabs((double) rb[6]);
+        for (int ax = 0; ax < D; ++ax) scale = fmax(scale, fmax(fabs((double) rb[ax]), fabs((double) rb[3 + ax])));
+        const double eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
+        const double ratio = (double) a.stick_out_factor * (double) rb[6] / (256.0 * eps * scale);
+        int skip = 0;
+        if (ratio > 1.0) skip = (int) floor(log2(ratio)) - 1;      // (one level of slack: log2 here vs. the host's)
+        a.point_skip_levels = skip < 0 ? 0 : (skip > a.L ? a.L : skip);
+    }
     __syncthreads();
-    const int64_t stride = (int64_t) gridDim.x * 1024;
-    for (int64_t i = (int64_t) blockIdx.x * 1024 + threadIdx.x; i < a.n; i += stride) {
-        T x[D];
+    constexpr int UNR = 4;
+    const int64_t stride = (int64_t) gridDim.x * 1024 * UNR;
+    for (int64_t i0 = (int64_t) blockIdx.x * 1024 * UNR + threadIdx.x; i0 < a.n; i0 += stride) {
+        T x[UNR][D], radius[UNR];
 #pragma unroll
-        for (int ax = 0; ax < D; ++ax) x[ax] = a.tgt[ax][i];
-        const T radius = a.tgt_radii ? a.tgt_radii[i] : (T) 0;
-        const uint64_t key = particle_key<T, D, true>(a, x, radius);      // L = k + 1
-        const int cap = (int) (key & (((uint64_t) 1 << CAPBITS_EXT) - 1));
-        const uint32_t cell = (uint32_t) ((key >> CAPBITS_EXT) >> D);     // path of level k, zeros below cap
-        cells[i] = cell;
-        if (lds) atomicAdd(&s_hist_ext[cell], 1u); else atomicAdd(&hist_cells[cell], 1);
-        if (cap <= k) atomicAdd(&hist_stay[top_box_index<D>((uint64_t) (cell >> (D * (k - cap))), cap)], 1);
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + (int64_t) u * 1024;
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) x[u][ax] = i < a.n ? a.tgt[ax][i] : a.rootbox[ax];
+            radius[u] = (i < a.n && a.tgt_radii) ? a.tgt_radii[i] : (T) 0;
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t i = i0 + (int64_t) u * 1024;
+            if (i >= a.n) continue;
+            const uint64_t key = particle_key<T, D, true>(a, x[u], radius[u]);      // L = k + 1
+            const int cap = (int) (key & (((uint64_t) 1 << CAPBITS_EXT) - 1));
+            const uint32_t cell = (uint32_t) ((key >> CAPBITS_EXT) >> D);     // path of level k, zeros below cap
+            cells[i] = cell;
+            if (lds) atomicAdd(&s_hist_ext[cell], 1u); else atomicAdd(&hist_cells[cell], 1);
+            if (cap <= k) atomicAdd(&hist_stay[top_box_index<D>((uint64_t) (cell >> (D * (k - cap))), cap)], 1);
+        }
     }
     __syncthreads();
     if (lds)
@@ -3752,7 +3777,7 @@ int ext_cells_impl(bt_context *ctx, const void *const *coords, const void *radii
     a.norm = norm;
     a.point_skip_levels = 0;
     const int ncells = 1 << (D * k);
-    const unsigned blocks = (unsigned) std::min<int64_t>(div_up(n, 1024), ctx->num_cus);
+    const unsigned blocks = (unsigned) std::min<int64_t>(div_up(n, 4096), ctx->num_cus);
     ext_cells_kernel<T, D><<<blocks, 1024, ncells <= (1 << 15) ? (size_t) ncells * 4 : 0, ctx->stream>>>(
         a, k, cells, hist_cells, hist_stay, ncells);
     BT_HIP_CHECK(hipGetLastError());

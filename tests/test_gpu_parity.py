@@ -1371,6 +1371,13 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
         assert len(set(gid.tolist())) == nb
         # the LET is the global tree restricted to its boxes
         assert np.array_equal(t.box_levels, g.box_levels[gid])
+        if not np.array_equal(t.box_flags, g.box_flags[gid]):
+            bad = np.nonzero(t.box_flags != g.box_flags[gid])[0]
+            print("flags differ at LET boxes", bad[:10], "levels", t.box_levels[bad][:10], "got",
+                  t.box_flags[bad][:10], "want", g.box_flags[gid][bad][:10], "global ids", gid[bad][:10],
+                  "tgt nonchild/cumul", g.box_target_counts_nonchild[gid[bad]][:10],
+                  g.box_target_counts_cumul[gid[bad]][:10], "src cumul", g.box_source_counts_cumul[gid[bad]][:10],
+                  "children", g.box_child_ids[:, gid[bad[0]]])
         assert np.array_equal(t.box_flags, g.box_flags[gid])
         assert np.array_equal(t.box_centers[:, :nb], g.box_centers[:, gid])
         assert np.array_equal(gid[t.box_parent_ids], g.box_parent_ids[gid])
