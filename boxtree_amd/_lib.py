@@ -30,7 +30,7 @@ P3 = vp * BT_MAX_DIMS
 PL = vp * BT_MAX_LEVELS
 
 
-ABI_VERSION = 7      # BT_ABI_VERSION of include/boxtree_hip.h
+ABI_VERSION = 8      # BT_ABI_VERSION of include/boxtree_hip.h
 
 
 class SortStats(ct.Structure):
@@ -170,7 +170,9 @@ class MgpuParams(ct.Structure):
                 ("coords", P3), ("top_level", ct.c_int32),
                 ("max_particles_in_box", ct.c_int64), ("alloc", vp), ("alloc_user", vp),
                 ("ntargets", ct.c_int64), ("targets", P3),
-                ("target_radii", vp), ("stick_out_factor", ct.c_double), ("extent_norm", ct.c_int32)]
+                ("target_radii", vp), ("stick_out_factor", ct.c_double), ("extent_norm", ct.c_int32),
+                ("max_leaf_refine_weight", ct.c_int32), ("source_refine_weights", vp),
+                ("target_refine_weights", vp)]
 
 
 class MgpuShard(ct.Structure):
@@ -180,7 +182,8 @@ class MgpuShard(ct.Structure):
                 ("top_cell_prefix", vp), ("bytes_sent", ct.c_int64), ("rounds", ct.c_int32),
                 ("a2a_ms", ct.c_float), ("n_owned_targets", ct.c_int64), ("target_points", vp),
                 ("sep_targets", ct.c_int32), ("target_record_len", ct.c_int32),
-                ("target_radii", vp), ("top_box_arrive", vp), ("top_box_stay", vp)]
+                ("target_radii", vp), ("source_record_len", ct.c_int32), ("refine_weights", vp),
+                ("top_box_arrive", vp), ("top_box_stay", vp)]
 
 
 class MgpuLocalTree(ct.Structure):

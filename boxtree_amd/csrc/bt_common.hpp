@@ -241,7 +241,8 @@ int bbox_minmax_device(bt_context *ctx, int dims, int coord_kind, const void *co
 int morton_cells_ext_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords,
                             const void *radii, int64_t n, const void *d_rootbox, int level,
                             double stick_out_factor, int extent_norm, uint32_t *cells_out,
-                            int32_t *hist_cells, int32_t *hist_stay);
+                            int32_t *hist_cells, int32_t *hist_stay, const int32_t *weights,
+                            int64_t *hist_stay_weight);
 // bt_morton_cells with the root box read from device memory ({min[3], max[3], extent, 0} in the
 // coordinate type, the layout of the tree build's own root box); no wait
 int morton_cells_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords, int64_t n,
@@ -254,6 +255,11 @@ int let_link_device(bt_context *ctx, int dims, int coord_kind, int nlevels, cons
                     const uint64_t *paths, int64_t aligned_nboxes, const double *bbox_min,
                     const double *bbox_max, double root_extent, int32_t *box_parent_ids,
                     int32_t *box_child_ids, void *box_centers);
+// whist[cell] += refine weight of every particle (NULL: 1); 32-bit weights as values of the
+// coordinates' width for the partition
+int weight_hist_device(bt_context *ctx, const uint32_t *cells, const int32_t *weights, int64_t n,
+                       int ncells, int64_t *whist);
+int widen_weights_device(bt_context *ctx, const int32_t *weights, int64_t n, int elem_size, void *out);
 // bt_partition_pack whose own-segment offsets are read from device memory when the kernel runs
 // (d_self_offsets = {send offset, receive offset} in records); ncells: length of owner_of_cell
 // (the table goes to LDS if it fits), 0 if unknown; no wait

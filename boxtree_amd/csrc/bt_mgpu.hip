@@ -281,6 +281,14 @@ __global__ __launch_bounds__(256) void widen_hist_kernel(int64_t n, const int32_
     if (i < n) out[i] = in[i];
 }
 
+// column `col` of [n][len] records: its low 32 bits as a dense int32 array (refine weights)
+template <class U>
+__global__ __launch_bounds__(256) void record_column_i32_kernel(int64_t n, int len, int col, const U *rec, int32_t *out)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (int32_t) (uint32_t) rec[i * len + col];
+}
+
 // column `col` of [n][len] records as a dense array
 template <class U>
 __global__ __launch_bounds__(256) void record_column_kernel(int64_t n, int len, int col, const U *rec, U *out)
@@ -343,6 +351,8 @@ struct TopPlan {
     double stick_out_factor = 0;                  // ... and this is how far a target may leave its box
     std::vector<std::vector<int64_t>> stay;       // [k+1][C^lev]: particles that stay in the box
     std::vector<std::vector<int64_t>> stay_src;   // ... the sources among them
+    bool weighted = false;                        // refine weights: the same two tables for weights
+    std::vector<std::vector<int64_t>> wcounts, wstay;
     std::vector<std::vector<int64_t>> counts;     // [k+1][C^lev]
     std::vector<std::vector<char>> exists, split;
     std::vector<std::vector<int32_t>> index;      // number of a box among the existing boxes of its level
@@ -366,7 +376,11 @@ inline int64_t top_table_offset(int D, int level)
 // hist: particles per level-k cell (a particle with an extent that stays in a box above level k
 // counts for the first cell under that box); stay (or NULL: point particles): per box of levels
 // 0..k the particles that stay in it, top_table_offset(level) + path.
-void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, const int64_t *stay, TopPlan &pl)
+// wcell / wstay (or NULL: unit weights): the same two tables for the particles' refine weights; the
+// split rule then compares weights with mpb (= max_leaf_refine_weight), existence stays a matter
+// of counts.
+void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, const int64_t *stay, TopPlan &pl,
+                  const int64_t *wcell = nullptr, const int64_t *wstay = nullptr)
 {
     const int C = 1 << D;
     const int64_t ncells = (int64_t) 1 << (D * k);
@@ -399,6 +413,32 @@ void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, co
             here[i] = sum;
         }
     }
+    // the same pyramid for refine weights
+    pl.weighted = wcell != nullptr;
+    pl.wcounts.resize(wcell ? (size_t) k + 1 : 0);
+    pl.wstay.resize(wcell ? (size_t) k + 1 : 0);
+    if (wcell) {
+        pl.wcounts[k].assign(wcell, wcell + ncells);
+        for (int lev = 0; lev <= k; ++lev) {
+            const int64_t n = (int64_t) 1 << (D * lev);
+            if (wstay) pl.wstay[lev].assign(wstay + top_table_offset(D, lev), wstay + top_table_offset(D, lev) + n);
+            else pl.wstay[lev].assign((size_t) n, 0);
+        }
+        for (int lev = 0; lev < k; ++lev) {
+            const int64_t n = (int64_t) 1 << (D * lev);
+            const int sh = D * (k - lev);
+            for (int64_t i = 0; i < n; ++i) pl.wcounts[k][(size_t) (i << sh)] -= pl.wstay[lev][(size_t) i];
+        }
+        for (int lev = k - 1; lev >= 0; --lev) {
+            const int64_t n = (int64_t) 1 << (D * lev);
+            pl.wcounts[lev].resize((size_t) n);
+            for (int64_t i = 0; i < n; ++i) {
+                int64_t sum = pl.wstay[lev][(size_t) i];
+                for (int m = 0; m < C; ++m) sum += pl.wcounts[lev + 1][(size_t) (i * C + m)];
+                pl.wcounts[lev][(size_t) i] = sum;
+            }
+        }
+    }
     // unit[c]: the first cell of the top-tree leaf a cell lies in (cells under a leaf above
     // level k travel together), found top-down: -1 while the boxes above still split
     std::vector<int64_t> &unit_start = pl.unit_start;
@@ -421,9 +461,11 @@ void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, co
             char *sp = pl.split[lev].data();
             int32_t *ix = pl.index[lev].data();
             int32_t run = 0;
+            const int64_t *wc = wcell ? pl.wcounts[lev].data() : nullptr;
+            const int64_t *ws = wcell ? pl.wstay[lev].data() : nullptr;
             for (int64_t i = 0; i < n; ++i) {
-                // tbk:569-591: what is bound for the children decides
-                sp[i] = ex[i] && cnt[i] - (st ? st[i] : 0) > mpb;
+                // tbk:569-591: what is bound for the children decides (its weight, if weighted)
+                sp[i] = ex[i] && (wc ? wc[i] - ws[i] : cnt[i] - (st ? st[i] : 0)) > mpb;
                 run += ex[i] ? 1 : 0;
                 ix[i] = run - 1;
             }
@@ -513,6 +555,8 @@ struct MgpuState {
     TopPlan plan;                    // of the last exchange on this context
     std::vector<int64_t> ghist;      // combined global cell histogram of that exchange
     std::vector<int64_t> stay_all;   // ... and stayers (sources + targets) per top box
+    std::vector<int64_t> wcell;      // ... and refine weights per cell
+    Buf<int32_t> weights;            // received particles' refine weights: sources, then targets
     hipEvent_t ev[2] = {nullptr, nullptr};   // around the payload all-to-all-v
     hipEvent_t ev_counts = nullptr;          // the counts matrix has reached the host
     hipEvent_t ev_done = nullptr;            // the last exchange's use of the pinned block is over
@@ -1065,10 +1109,15 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     // of the shared top boxes, so it cannot be a rank's own view of its chunk)
     const int64_t nset[2] = {p->n, p->ntargets};
     const void *const *cset[2] = {p->coords, p->targets};
+    // refine weights (the limit is a parameter of the job; a NULL array means unit weights)
+    const bool weighted = p->max_leaf_refine_weight > 0;
+    const int32_t *wset[2] = {weighted ? p->source_refine_weights : nullptr,
+                              weighted ? p->target_refine_weights : nullptr};
+    const int64_t split_limit = weighted ? (int64_t) p->max_leaf_refine_weight : p->max_particles_in_box;
     // targets with extents (the same on every rank: extent_norm is a parameter of the job)
     const bool ext = p->extent_norm != BT_NORM_NONE;
     if (ext && ((p->extent_norm != BT_NORM_LINF && p->extent_norm != BT_NORM_L2)
-                || (p->ntargets > 0 && !p->target_radii) || p->max_particles_in_box <= 0)) {
+                || (p->ntargets > 0 && !p->target_radii) || split_limit <= 0)) {
         set_error("bt_mgpu_exchange: extents need extent_norm linf or l2, target_radii on every rank "
                   "that has targets, and max_particles_in_box > 0");
         return BT_ERR_INVALID;
@@ -1084,6 +1133,9 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     // a box of levels 0..k
     const int64_t ntop1 = top_table_offset(D, k + 1);
     const int64_t nh = 2 * ncells + (ext ? 2 * ntop1 : 0);       // + stayers: sources, targets
+    // ... and 64-bit words for refine weights: per source cell, per target cell, per box of the
+    // stayers (both kinds together)
+    const int64_t nw = weighted ? 2 * ncells + (ext ? ntop1 : 0) : 0;
     if (!ms->ev[0]) {
         BT_HIP_CHECK(hipEventCreate(&ms->ev[0]));
         BT_HIP_CHECK(hipEventCreate(&ms->ev[1]));
@@ -1095,10 +1147,10 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     // pinned block: [box: 16 doubles][local hist: 2 ncells i32][global hist: 2 ncells i64]
     // [owner: ncells i32][send counts: row i64][matrix: row * nranks i64][prefix: ncells + 1 i64]
     const size_t o_box = 0, o_local = 128, o_ghist = o_local + (((size_t) nh * 4 + 7) & ~(size_t) 7),
-        o_owner = o_ghist + (size_t) nh * 8, o_send = o_owner + (size_t) ncells * 4,
+        o_owner = o_ghist + (size_t) (nh + nw) * 8, o_send = o_owner + (size_t) ncells * 4,
         o_matrix = o_send + (size_t) row * 8, o_prefix = o_matrix + (size_t) row * nranks * 8,
         o_tables = o_prefix + (size_t) (ncells + 1) * 8,
-        pin_need = o_tables + (ext ? (size_t) ntop1 * 16 : 0);
+        pin_need = o_tables + ((ext || weighted) ? (size_t) ntop1 * 16 : 0);
     if (ms->pin_cap < pin_need) {
         if (ms->pin) { BT_HIP_CHECK(hipStreamSynchronize(stream)); (void) hipHostFree(ms->pin); ms->pin = nullptr; ms->pin_cap = 0; }
         BT_HIP_CHECK(hipHostMalloc((void **) &ms->pin, pin_need, hipHostMallocDefault));
@@ -1134,7 +1186,8 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     Buf<int32_t> hist32, owner_d;
     Buf<int64_t> hist64;
     BT_CHECK(hist32.alloc(ctx->pool, nh));
-    BT_CHECK(hist64.alloc(ctx->pool, nh));
+    BT_CHECK(hist64.alloc(ctx->pool, nh + nw));
+    if (nw > 0) BT_HIP_CHECK(hipMemsetAsync(hist64.get() + nh, 0, (size_t) nw * 8, stream));
     BT_CHECK(owner_d.alloc(ctx->pool, ncells));
     BT_HIP_CHECK(hipMemsetAsync(hist32.get(), 0, (size_t) nh * 4, stream));
     for (int s = 0; s < 2; ++s) {
@@ -1145,16 +1198,21 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
             // test lets points stay in boxes, in the build and therefore here)
             BT_CHECK(bt::morton_cells_ext_device(ctx, D, p->coord_kind, cset[s], rset[s], nset[s], rootbox_d.get(),
                                                  k, p->stick_out_factor, p->extent_norm, cells[s].get(),
-                                                 hist32.get() + s * ncells, hist32.get() + 2 * ncells + s * ntop1));
+                                                 hist32.get() + s * ncells, hist32.get() + 2 * ncells + s * ntop1,
+                                                 wset[s], weighted ? hist64.get() + nh + 2 * ncells : nullptr));
         else
             BT_CHECK(bt::morton_cells_device(ctx, D, p->coord_kind, cset[s], nset[s], rootbox_d.get(), k,
                                              cells[s].get(), hist32.get() + s * ncells));
     }
+    if (weighted)
+        for (int s = 0; s < 2; ++s)
+            BT_CHECK(bt::weight_hist_device(ctx, cells[s].get(), wset[s], nset[s], (int) ncells,
+                                            hist64.get() + nh + s * ncells));
     widen_hist_kernel<<<(unsigned) div_up(nh, 256), 256, 0, stream>>>(nh, hist32.get(), hist64.get());
     BT_HIP_CHECK(hipGetLastError());
     BT_CHECK(bt::copy_to_pinned(ctx, h_local, hist32.get(), (size_t) nh * 4));
-    BT_CHECK(comm_all_reduce(comm, stream, hist64.get(), (size_t) nh, RED_SUM_I64));
-    BT_CHECK(bt::copy_to_pinned(ctx, h_ghist2, hist64.get(), (size_t) nh * 8));
+    BT_CHECK(comm_all_reduce(comm, stream, hist64.get(), (size_t) (nh + nw), RED_SUM_I64));
+    BT_CHECK(bt::copy_to_pinned(ctx, h_ghist2, hist64.get(), (size_t) (nh + nw) * 8));
     BT_CHECK(bt::sync_stream(ctx));                       // the one wait the GPU idles through
 
     const bool sep = h_box[2 * D] < 0;
@@ -1180,7 +1238,13 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
         stay_all.resize((size_t) ntop1);
         for (int64_t i = 0; i < ntop1; ++i) stay_all[(size_t) i] = h_ghist2[2 * ncells + i] + h_ghist2[2 * ncells + ntop1 + i];
     }
-    compute_plan(D, k, p->max_particles_in_box, nranks, ghist.data(), ext ? stay_all.data() : nullptr, pl);
+    std::vector<int64_t> &wcell = ms->wcell;
+    if (weighted) {
+        wcell.resize((size_t) ncells);
+        for (int64_t c = 0; c < ncells; ++c) wcell[(size_t) c] = h_ghist2[nh + c] + h_ghist2[nh + ncells + c];
+    }
+    compute_plan(D, k, split_limit, nranks, ghist.data(), ext ? stay_all.data() : nullptr, pl,
+                 weighted ? wcell.data() : nullptr, (weighted && ext) ? h_ghist2 + nh + 2 * ncells : nullptr);
     if (ext && !sep) {
         set_error("bt_mgpu_exchange: extent_norm is set but no rank has targets");
         return BT_ERR_INVALID;
@@ -1242,7 +1306,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     BT_CHECK(bt::copy_to_pinned(ctx, h_matrix, counts_d.get() + row, (size_t) row * nranks * 8));
     BT_HIP_CHECK(hipEventRecord(ms->ev_counts, stream));
     // values and bytes per particle record of a set (targets with extents carry their radius)
-    const int vals_of[2] = {D, D + (ext ? 1 : 0)};
+    const int vals_of[2] = {D + (weighted ? 1 : 0), D + (ext ? 1 : 0) + (weighted ? 1 : 0)};
     const int64_t rec_of[2] = {(int64_t) vals_of[0] * es, (int64_t) vals_of[1] * es};
 
     // ---- 4. payload: interleaved coordinates, one exchange per particle set -------------------
@@ -1250,7 +1314,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     // segment this rank keeps straight into the receive buffer (bt_shard.hip) -- or, with the test
     // switch bt_mgpu_comm_set_self_loopback, into the send buffer like any other, to make the
     // trip through ncclSend / ncclRecv.
-    Buf<unsigned char> send[2];
+    Buf<unsigned char> send[2], wide_w[2];
     unsigned char *points_of[2] = {nullptr, nullptr};
     for (int s = 0; s < nsets; ++s) {
         const int64_t n = nset[s];
@@ -1265,9 +1329,15 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
             BT_CHECK(own.alloc(ctx->pool, points_bytes));
             points_of[s] = own.get();
         }
-        const void *arrays[BT_MAX_DIMS + 1];
-        for (int ax = 0; ax < D; ++ax) arrays[ax] = cset[s][ax];
-        arrays[D] = rset[s];
+        const void *arrays[BT_MAX_DIMS + 2];
+        int nv = 0;
+        for (int ax = 0; ax < D; ++ax) arrays[nv++] = cset[s][ax];
+        if (s == 1 && ext) arrays[nv++] = rset[s];
+        if (weighted) {
+            BT_CHECK(wide_w[s].alloc(ctx->pool, std::max<int64_t>(n, 1) * es));
+            BT_CHECK(bt::widen_weights_device(ctx, wset[s], n, es, wide_w[s].get()));
+            arrays[nv++] = wide_w[s].get();
+        }
         BT_CHECK(bt::partition_pack_device(ctx, vals_of[s], es, arrays, cells[s].get(), n, owner_d.get(), (int) ncells,
                                            nranks, rank, self_d.get() + 2 * s, send[s].get(),
                                            loop_self ? send[s].get() : points_of[s]));
@@ -1322,9 +1392,9 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
         }
         if (nt > 0) {
             if (f64) record_column_kernel<uint64_t><<<(unsigned) div_up(nt, 256), 256, 0, stream>>>(
-                nt, D + 1, D, (const uint64_t *) points_of[1], (uint64_t *) radii_out);
+                nt, vals_of[1], D, (const uint64_t *) points_of[1], (uint64_t *) radii_out);
             else record_column_kernel<uint32_t><<<(unsigned) div_up(nt, 256), 256, 0, stream>>>(
-                nt, D + 1, D, (const uint32_t *) points_of[1], (uint32_t *) radii_out);
+                nt, vals_of[1], D, (const uint32_t *) points_of[1], (uint32_t *) radii_out);
             BT_HIP_CHECK(hipGetLastError());
         }
     }
@@ -1332,13 +1402,35 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     memcpy(h_prefix, pl.prefix.data(), (size_t) (ncells + 1) * 8);
     BT_HIP_CHECK(hipMemcpyAsync(ms->cell_prefix.get(), h_prefix, (size_t) (ncells + 1) * 8,
                                 hipMemcpyHostToDevice, stream));
-    if (ext) {
-        // the top of the global tree for bt_tree_build: arrivals and stayers per top box
+    if (weighted) {
+        // the received particles' weights as the dense int32 array bt_tree_params.refine_weights is
+        const int64_t n0 = nrecv_of[0], n1 = nsets == 2 ? nrecv_of[1] : 0;
+        BT_CHECK(ms->weights.alloc(ctx->pool, std::max<int64_t>(n0 + n1, 1)));
+        for (int s = 0; s < nsets; ++s) {
+            const int64_t n = s == 0 ? n0 : n1;
+            if (n == 0) continue;
+            int32_t *dst = ms->weights.get() + (s == 0 ? 0 : n0);
+            if (f64) record_column_i32_kernel<uint64_t><<<(unsigned) div_up(n, 256), 256, 0, stream>>>(
+                n, vals_of[s], vals_of[s] - 1, (const uint64_t *) points_of[s], dst);
+            else record_column_i32_kernel<uint32_t><<<(unsigned) div_up(n, 256), 256, 0, stream>>>(
+                n, vals_of[s], vals_of[s] - 1, (const uint32_t *) points_of[s], dst);
+        }
+        BT_HIP_CHECK(hipGetLastError());
+        out->refine_weights = ms->weights.get();
+    }
+    if (ext || weighted) {
+        // the top of the global tree for bt_tree_build: arrivals and stayers per top box (their
+        // refine weights in a weighted job)
         BT_CHECK(ms->top_tables.alloc(ctx->pool, 2 * ntop1));
         for (int lev = 0; lev <= k; ++lev) {
             const int64_t n = (int64_t) 1 << (D * lev), off = top_table_offset(D, lev);
-            memcpy(h_tables + off, pl.counts[lev].data(), (size_t) n * 8);
-            memcpy(h_tables + ntop1 + off, pl.stay[lev].data(), (size_t) n * 8);
+            if (weighted) {
+                memcpy(h_tables + off, pl.wcounts[lev].data(), (size_t) n * 8);
+                memcpy(h_tables + ntop1 + off, pl.wstay[lev].data(), (size_t) n * 8);
+            } else {
+                memcpy(h_tables + off, pl.counts[lev].data(), (size_t) n * 8);
+                memcpy(h_tables + ntop1 + off, pl.stay[lev].data(), (size_t) n * 8);
+            }
         }
         BT_HIP_CHECK(hipMemcpyAsync(ms->top_tables.get(), h_tables, (size_t) ntop1 * 16, hipMemcpyHostToDevice, stream));
         out->top_box_arrive = ms->top_tables.get();
@@ -1348,6 +1440,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     ms->done_pending = true;
 
     out->target_record_len = vals_of[1];
+    out->source_record_len = vals_of[0];
     out->target_radii = radii_out;
     out->n_owned = nrecv_of[0];
     out->points = points_of[0];
@@ -1356,7 +1449,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     for (int ax = 0; ax < D; ++ax) { out->bbox_min[ax] = bmin[ax]; out->bbox_max[ax] = bmax[ax]; }
     out->root_extent = root_extent;
     out->top_level = k;
-    out->top_cell_prefix = p->max_particles_in_box > 0 ? ms->cell_prefix.get() : nullptr;
+    out->top_cell_prefix = split_limit > 0 ? ms->cell_prefix.get() : nullptr;
     out->bytes_sent = bytes_sent;
     out->rounds = rounds_total;
     out->sep_targets = sep ? 1 : 0;

@@ -102,6 +102,40 @@ __global__ __launch_bounds__(1024) void morton_cells_lds_kernel(CellArgs<T, D> a
     }
 }
 
+// Refine weights per cell (int64: a cell's weight is the sum the reference saturates at
+// INT_MAX, tbk:270-274 -- exact here, compared against the limit as a 64-bit number): 64-bit
+// counters privatised in LDS, the cells in slices of 2^14 so that a slice's counters fit
+// (blockIdx.y = slice; every slice reads all cells and weights: 8 bytes per particle each).
+constexpr int WH_SLICE = 1 << 14;
+
+__global__ __launch_bounds__(1024) void weight_hist_kernel(const uint32_t *cells, const int32_t *weights,
+        int64_t n, int ncells, unsigned long long *whist)
+{
+    __shared__ unsigned long long s_w[WH_SLICE];
+    const uint32_t lo = blockIdx.y * (uint32_t) WH_SLICE;
+    const uint32_t cnt = min((uint32_t) WH_SLICE, (uint32_t) ncells - lo);
+    for (uint32_t c = threadIdx.x; c < cnt; c += 1024) s_w[c] = 0ull;
+    __syncthreads();
+    const int64_t stride = (int64_t) gridDim.x * 1024;
+    for (int64_t i = (int64_t) blockIdx.x * 1024 + threadIdx.x; i < n; i += stride) {
+        const uint32_t c = cells[i] - lo;
+        if (c < cnt) atomicAdd(&s_w[c], (unsigned long long) (weights ? weights[i] : 1));
+    }
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < cnt; c += 1024) {
+        const unsigned long long v = s_w[c];
+        if (v) atomicAdd(&whist[lo + c], v);
+    }
+}
+
+// a 32-bit weight in the low bits of a record value (the partition moves values of one width)
+template <class U>
+__global__ __launch_bounds__(256) void widen_weights_kernel(int64_t n, const int32_t *w, U *out)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (U) (uint32_t) (w ? w[i] : 1);
+}
+
 __global__ __launch_bounds__(256) void owner_keys_kernel(int64_t n, const uint32_t *cells,
         const int32_t *owner_of_cell, uint32_t *keys)
 {
@@ -500,17 +534,41 @@ int morton_cells_device(bt_context *ctx, int dims, int coord_kind, const void *c
         : cells_dims<float>(ctx, dims, coords, n, nullptr, nullptr, d_rootbox, level, cells_out, hist_inout, false);
 }
 
+int weight_hist_device(bt_context *ctx, const uint32_t *cells, const int32_t *weights, int64_t n,
+                       int ncells, int64_t *whist)
+{
+    if (n == 0) return BT_OK;
+    const unsigned slices = (unsigned) div_up(ncells, WH_SLICE);
+    const unsigned blocks = (unsigned) std::min<int64_t>(div_up(n, 1024 * 8), ctx->num_cus);
+    weight_hist_kernel<<<dim3(blocks, slices), 1024, 0, ctx->stream>>>(cells, weights, n, ncells,
+                                                                     (unsigned long long *) whist);
+    BT_HIP_CHECK(hipGetLastError());
+    return BT_OK;
+}
+
+int widen_weights_device(bt_context *ctx, const int32_t *weights, int64_t n, int elem_size, void *out)
+{
+    if (n == 0) return BT_OK;
+    if (elem_size == 8) widen_weights_kernel<uint64_t><<<(unsigned) div_up(n, 256), 256, 0, ctx->stream>>>(n, weights, (uint64_t *) out);
+    else widen_weights_kernel<uint32_t><<<(unsigned) div_up(n, 256), 256, 0, ctx->stream>>>(n, weights, (uint32_t *) out);
+    BT_HIP_CHECK(hipGetLastError());
+    return BT_OK;
+}
+
 int partition_pack_device(bt_context *ctx, int dims, int elem_size, const void *const *in,
                           const uint32_t *cells, int64_t n, const int32_t *owner_of_cell, int ncells, int nranks,
                           int self_rank, const int64_t *d_self_offsets, void *send, void *recv)
 {
     if (n == 0) return BT_OK;
-    // (dims counts the values of a record: coordinates, and a radius that travels with them)
+    // (dims counts the values of a record: coordinates, and a radius and a refine weight that
+    // travel with them)
 #define BT_PP(U, D) partition_pack_impl<U, D>(ctx, in, cells, n, owner_of_cell, ncells, nranks, self_rank, 0, 0, \
                                               d_self_offsets, send, recv, false)
     if (elem_size == 8)
-        return dims == 1 ? BT_PP(uint64_t, 1) : dims == 2 ? BT_PP(uint64_t, 2) : dims == 3 ? BT_PP(uint64_t, 3) : BT_PP(uint64_t, 4);
-    return dims == 1 ? BT_PP(uint32_t, 1) : dims == 2 ? BT_PP(uint32_t, 2) : dims == 3 ? BT_PP(uint32_t, 3) : BT_PP(uint32_t, 4);
+        return dims == 1 ? BT_PP(uint64_t, 1) : dims == 2 ? BT_PP(uint64_t, 2) : dims == 3 ? BT_PP(uint64_t, 3)
+             : dims == 4 ? BT_PP(uint64_t, 4) : BT_PP(uint64_t, 5);
+    return dims == 1 ? BT_PP(uint32_t, 1) : dims == 2 ? BT_PP(uint32_t, 2) : dims == 3 ? BT_PP(uint32_t, 3)
+         : dims == 4 ? BT_PP(uint32_t, 4) : BT_PP(uint32_t, 5);
 #undef BT_PP
 }
 

@@ -3709,7 +3709,8 @@ int bbox_minmax_device(bt_context *ctx, int dims, int coord_kind, const void *co
 // rank that owns that cell gets the particle.  hist_cells counts the cells so assigned.
 template <class T, int D>
 __global__ __launch_bounds__(1024) void ext_cells_kernel(KeygenArgs<T, D> a, int k, uint32_t *cells,
-        int32_t *hist_cells, int32_t *hist_stay, int ncells)
+        int32_t *hist_cells, int32_t *hist_stay, int ncells, const int32_t *weights,
+        unsigned long long *hist_stay_weight /* or null: stayers are counted only */)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_hist_ext[];
     const bool lds = ncells <= (1 << 15);
@@ -3750,7 +3751,11 @@ __global__ __launch_bounds__(1024) void ext_cells_kernel(KeygenArgs<T, D> a, int
             const uint32_t cell = (uint32_t) ((key >> CAPBITS_EXT) >> D);     // path of level k, zeros below cap
             cells[i] = cell;
             if (lds) atomicAdd(&s_hist_ext[cell], 1u); else atomicAdd(&hist_cells[cell], 1);
-            if (cap <= k) atomicAdd(&hist_stay[top_box_index<D>((uint64_t) (cell >> (D * (k - cap))), cap)], 1);
+            if (cap <= k) {
+                const int64_t at = top_box_index<D>((uint64_t) (cell >> (D * (k - cap))), cap);
+                atomicAdd(&hist_stay[at], 1);
+                if (hist_stay_weight) atomicAdd(&hist_stay_weight[at], (unsigned long long) (weights ? weights[i] : 1));
+            }
         }
     }
     __syncthreads();
@@ -3764,7 +3769,7 @@ __global__ __launch_bounds__(1024) void ext_cells_kernel(KeygenArgs<T, D> a, int
 template <class T, int D>
 int ext_cells_impl(bt_context *ctx, const void *const *coords, const void *radii, int64_t n,
                    const void *d_rootbox, int k, double stick_out_factor, int norm, uint32_t *cells,
-                   int32_t *hist_cells, int32_t *hist_stay)
+                   int32_t *hist_cells, int32_t *hist_stay, const int32_t *weights, int64_t *hist_stay_weight)
 {
     if (n == 0) return BT_OK;
     KeygenArgs<T, D> a{};
@@ -3779,7 +3784,7 @@ int ext_cells_impl(bt_context *ctx, const void *const *coords, const void *radii
     const int ncells = 1 << (D * k);
     const unsigned blocks = (unsigned) std::min<int64_t>(div_up(n, 4096), ctx->num_cus);
     ext_cells_kernel<T, D><<<blocks, 1024, ncells <= (1 << 15) ? (size_t) ncells * 4 : 0, ctx->stream>>>(
-        a, k, cells, hist_cells, hist_stay, ncells);
+        a, k, cells, hist_cells, hist_stay, ncells, weights, (unsigned long long *) hist_stay_weight);
     BT_HIP_CHECK(hipGetLastError());
     return BT_OK;
 }
@@ -3787,10 +3792,11 @@ int ext_cells_impl(bt_context *ctx, const void *const *coords, const void *radii
 int morton_cells_ext_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords,
                             const void *radii, int64_t n, const void *d_rootbox, int level,
                             double stick_out_factor, int extent_norm, uint32_t *cells_out,
-                            int32_t *hist_cells, int32_t *hist_stay)
+                            int32_t *hist_cells, int32_t *hist_stay, const int32_t *weights,
+                            int64_t *hist_stay_weight)
 {
 #define EC(T, D) return ext_cells_impl<T, D>(ctx, coords, radii, n, d_rootbox, level, stick_out_factor, \
-                                             extent_norm, cells_out, hist_cells, hist_stay)
+                                             extent_norm, cells_out, hist_cells, hist_stay, weights, hist_stay_weight)
     if (coord_kind == BT_F64) { if (dims == 1) EC(double, 1); else if (dims == 2) EC(double, 2); else EC(double, 3); }
     else { if (dims == 1) EC(float, 1); else if (dims == 2) EC(float, 2); else EC(float, 3); }
 #undef EC
@@ -3846,14 +3852,13 @@ int bt_tree_build(bt_context *ctx, const bt_tree_params *p, bt_tree_sizes *out)
             set_error("bt_tree_build: top_level %d out of range", p->top_level);
             return BT_ERR_INVALID;
         }
-        if (p->refine_weights || p->kind != BT_KIND_ADAPTIVE) {
-            set_error("sharded builds (top_cell_prefix) support kind='adaptive' with unit refine "
-                      "weights only");
+        if (p->kind != BT_KIND_ADAPTIVE) {
+            set_error("sharded builds (top_cell_prefix) support kind='adaptive' only");
             return BT_ERR_UNSUPPORTED;
         }
-        if (have_extent && (!p->top_box_arrive || !p->top_box_stay)) {
-            set_error("sharded builds of particles with extents need the tables top_box_arrive / "
-                      "top_box_stay (bt_mgpu_exchange makes them)");
+        if ((have_extent || p->refine_weights) && (!p->top_box_arrive || !p->top_box_stay)) {
+            set_error("sharded builds of particles with extents or refine weights need the tables "
+                      "top_box_arrive / top_box_stay (bt_mgpu_exchange makes them)");
             return BT_ERR_UNSUPPORTED;
         }
     }

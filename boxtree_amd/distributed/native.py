@@ -142,7 +142,8 @@ class _LazyA2aTime:
 
 def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=None,
                        own_buffer=False, targets=None, target_radii=None, stick_out_factor=None,
-                       extent_norm="linf"):
+                       extent_norm="linf", refine_weights=None, target_refine_weights=None,
+                       max_leaf_refine_weight=None):
     """Steps 1-3 (``bt_mgpu_exchange``).  Returns ``(particles, build_kw, stats)`` for the
     local ``TreeBuilder`` call: views of the interleaved receive buffer, and ``_root_box`` /
     ``_top_tree`` / ``_point_stride``.  The receive buffer belongs to the context and is
@@ -155,7 +156,10 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
     stats)``: a target that sticks out of the boxes of the shared top levels stays in one of
     them and travels to the owner of that box's first cell; ``build_kw`` then carries
     ``stick_out_factor`` / ``extent_norm`` and the top of the global tree as arrival / stay
-    counts per top box."""
+    counts per top box.  With *max_leaf_refine_weight* (the same on every rank; then
+    *max_particles_in_box* is ignored) boxes split by refine weight: *refine_weights* /
+    *target_refine_weights* (int32, None = ones) travel with the particles and come back in
+    ``build_kw`` (``refine_weights``: sources then targets, ``max_leaf_refine_weight``)."""
     import torch
     dims = len(particles)
     dev = particles[0].device
@@ -170,6 +174,16 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
         par.coords[ax] = keep[ax].data_ptr()
     par.top_level = int(top_level or 0)
     par.max_particles_in_box = int(max_particles_in_box or 0)
+    keep_w = []
+    if max_leaf_refine_weight is not None:
+        par.max_leaf_refine_weight = int(max_leaf_refine_weight)
+        for name, w in (("source_refine_weights", refine_weights), ("target_refine_weights", target_refine_weights)):
+            if w is not None:
+                assert w.dtype == torch.int32
+                keep_w.append(w.contiguous())
+                setattr(par, name, keep_w[-1].data_ptr())
+    elif refine_weights is not None or target_refine_weights is not None:
+        raise ValueError("refine weights need max_leaf_refine_weight")
     if targets is not None:
         keep_t = [t.contiguous() for t in targets]
         par.ntargets = len(keep_t[0])
@@ -200,7 +214,8 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
     _lib.check(actx.lib.bt_mgpu_exchange(actx.handle, comm.handle, ct.byref(par), ct.byref(shard)))
     n_owned = int(shard.n_owned)
     if targets is not None:
-        res = _exchanged_with_targets(actx, shard, bufs if own_buffer else [], dims, dtype, es, dev)
+        res = _exchanged_with_targets(actx, shard, bufs if own_buffer else [], dims, dtype, es, dev,
+                                      max_leaf_refine_weight)
         if target_radii is None:
             return res
         p2, t2, kw, stats = res
@@ -210,27 +225,29 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
     if shard.sep_targets:
         raise ValueError("exchange_particles: other ranks passed separate targets; every rank "
                          "must pass `targets` (an empty chunk is fine)")
+    slen = int(shard.source_record_len) or dims
     if own_buffer:
-        recv = got["buf"][:n_owned * dims * es].view(dtype).view(n_owned, dims)
+        recv = got["buf"][:n_owned * slen * es].view(dtype).view(n_owned, slen)
     else:
         recv = torch.as_tensor(
-            _DevicePointer(shard.points, (max(n_owned, 1) * dims,), "<f8" if es == 8 else "<f4"),
-            device=dev)[:n_owned * dims].view(n_owned, dims)
+            _DevicePointer(shard.points, (max(n_owned, 1) * slen,), "<f8" if es == 8 else "<f4"),
+            device=dev)[:n_owned * slen].view(n_owned, slen)
     new_particles = [recv[:, ax] for ax in range(dims)]
     coord = np.dtype(np.float64 if dtype == torch.float64 else np.float32)
     bbox_min = np.array(shard.bbox_min[:dims], dtype=coord)
     bbox_max = np.array(shard.bbox_max[:dims], dtype=coord)
     root_extent = coord.type(shard.root_extent)
     build_kw = {"_root_box": (bbox_min, bbox_max, root_extent)}
-    if dims > 1:
-        build_kw["_point_stride"] = dims
+    if slen > 1:
+        build_kw["_point_stride"] = slen
     else:
         new_particles = [p.contiguous() for p in new_particles]
     k = int(shard.top_level)
     if shard.top_cell_prefix:
         prefix = torch.as_tensor(
             _DevicePointer(shard.top_cell_prefix, ((1 << (dims * k)) + 1,), "<i8"), device=dev)
-        build_kw["_top_tree"] = (k, prefix)
+        build_kw["_top_tree"] = (k, prefix) + _top_tables(shard, dims, k, dev)
+    _weights_kw(build_kw, shard, n_owned, 0, max_leaf_refine_weight, dev)
     stats = dict(bytes_sent=int(shard.bytes_sent), rounds=int(shard.rounds), top_level=k,
                  a2a_ms=_LazyA2aTime(actx, float(shard.a2a_ms)),
                  bbox_min=bbox_min, bbox_max=bbox_max, root_extent=root_extent,
@@ -238,7 +255,28 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
     return new_particles, build_kw, stats
 
 
-def _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev):
+def _top_tables(shard, dims, k, dev):
+    """(arrive, stay) per box of levels 0..k as device tensors, or () for point particles with
+    unit weights (``bt_tree_params.top_box_arrive`` / ``top_box_stay``)."""
+    import torch
+    if not shard.top_box_arrive:
+        return ()
+    C = 1 << dims
+    ntop = (C ** (k + 1) - 1) // (C - 1)
+    return tuple(torch.as_tensor(_DevicePointer(ptr_, (ntop,), "<i8"), device=dev)
+                 for ptr_ in (shard.top_box_arrive, shard.top_box_stay))
+
+
+def _weights_kw(build_kw, shard, nsources, ntargets, max_leaf_refine_weight, dev):
+    import torch
+    if shard.refine_weights:
+        n = nsources + ntargets
+        build_kw["refine_weights"] = torch.as_tensor(
+            _DevicePointer(shard.refine_weights, (max(n, 1),), "<i4"), device=dev)[:n]
+        build_kw["max_leaf_refine_weight"] = int(max_leaf_refine_weight)
+
+
+def _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev, max_leaf_refine_weight=None):
     """Views of both received sets (interleaved records, read in place by the tree build:
     ``_point_stride`` / ``_target_stride``; radii as a dense array) + build kwargs.  The buffers
     are the context's (valid until its next exchange) or, with *own_buffer*, torch allocations
@@ -256,13 +294,14 @@ def _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev):
         return flat.view(n, width)
 
     own = len(bufs) > 0
-    src = view(shard.points, bufs[0] if own else None, ns, dims)
+    slen = int(shard.source_record_len) or dims
+    src = view(shard.points, bufs[0] if own else None, ns, slen)
     tbuf = bufs[1] if own and len(bufs) > 1 else None
     if shard.target_points:
         tgt = view(shard.target_points, tbuf, nt, nv)
     else:       # no rank of the job had a target: the library exchanged one set
         tgt = torch.empty((0, nv), dtype=dtype, device=dev)
-    out = [[src[:, ax] for ax in range(dims)], [tgt[:, ax] for ax in range(dims)]]
+    out = [[src[:, ax] for ax in range(dims)], [tgt[:, ax] for ax in range(dims)]]     # (radius / weight columns: below)
     if shard.target_radii:
         rbuf = bufs[2] if own and len(bufs) > 2 else None
         out[1].append(view(shard.target_radii, rbuf, nt, 1)[:, 0])
@@ -271,8 +310,8 @@ def _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev):
     bbox_max = np.array(shard.bbox_max[:dims], dtype=coord)
     root_extent = coord.type(shard.root_extent)
     build_kw = {"_root_box": (bbox_min, bbox_max, root_extent)}
-    if dims > 1:
-        build_kw["_point_stride"] = dims
+    if slen > 1:
+        build_kw["_point_stride"] = slen
     else:
         out[0] = [p.contiguous() for p in out[0]]
     if nv > 1:
@@ -283,13 +322,8 @@ def _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev):
     if shard.top_cell_prefix:
         prefix = torch.as_tensor(
             _DevicePointer(shard.top_cell_prefix, ((1 << (dims * k)) + 1,), "<i8"), device=dev)
-        build_kw["_top_tree"] = (k, prefix)
-        if shard.top_box_arrive:
-            C = 1 << dims
-            ntop = (C ** (k + 1) - 1) // (C - 1)
-            build_kw["_top_tree"] = (k, prefix) + tuple(
-                torch.as_tensor(_DevicePointer(ptr_, (ntop,), "<i8"), device=dev)
-                for ptr_ in (shard.top_box_arrive, shard.top_box_stay))
+        build_kw["_top_tree"] = (k, prefix) + _top_tables(shard, dims, k, dev)
+    _weights_kw(build_kw, shard, ns, nt, max_leaf_refine_weight, dev)
     stats = dict(bytes_sent=int(shard.bytes_sent), rounds=int(shard.rounds), top_level=k,
                  a2a_ms=_LazyA2aTime(actx, float(shard.a2a_ms)), bbox_min=bbox_min, bbox_max=bbox_max,
                  root_extent=root_extent, planned=bool(shard.top_cell_prefix))

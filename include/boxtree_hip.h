@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BT_ABI_VERSION 7
+#define BT_ABI_VERSION 8
 #define BT_MAX_DIMS 3
 #define BT_MAX_LEVELS 64       /* capacity of per-level arrays in the structs */
 
@@ -197,7 +197,8 @@ typedef struct {
      * path with C = 2^dims (device, int64): the particles that ARRIVE in the box (its cumulative
      * count in the global tree) and those that STAY in it (stick out of its children,
      * tree_build_kernels.py:388-428).  A box splits iff arrive - stay exceeds
-     * max_leaf_refine_weight.  Both NULL: point particles, top_cell_prefix alone. */
+     * max_leaf_refine_weight.  With refine weights both tables hold weights instead of counts.
+     * Both NULL: point particles with unit weights, top_cell_prefix alone. */
     const int64_t *top_box_arrive, *top_box_stay;
 } bt_tree_params;
 
@@ -599,6 +600,14 @@ typedef struct {
     const void *target_radii;          /* device [ntargets] or NULL                          */
     double stick_out_factor;
     int32_t extent_norm;               /* BT_NORM_LINF / BT_NORM_L2 with target_radii        */
+    /* refine weights (boxtree's refine_weights / max_leaf_refine_weight; the limit is a parameter
+     * of the job, > 0 on every rank or on none): a box splits iff the weight bound for its
+     * children exceeds the limit (tree_build_kernels.py:569-591), so the exchange sums weights
+     * per cell next to the counts; the weights travel with the particles.  A NULL array on a
+     * rank of a weighted job means unit weights. */
+    int32_t max_leaf_refine_weight;
+    const int32_t *source_refine_weights;   /* device [n] or NULL           */
+    const int32_t *target_refine_weights;   /* device [ntargets] or NULL    */
 } bt_mgpu_params;
 
 typedef struct {
@@ -622,6 +631,11 @@ typedef struct {
                                        /* radii (the radius last): bt_tree_params.target_stride */
     void *target_radii;                /* ... and the radii once more as a dense array        */
                                        /* [n_owned_targets] (third allocation), else NULL     */
+    int32_t source_record_len;         /* values per received source: dims (+ 1: its refine   */
+                                       /* weight, in the low 32 bits of the last value)      */
+    const int32_t *refine_weights;     /* weighted jobs: [n_owned + n_owned_targets] weights  */
+                                       /* of the received sources, then targets (the order of */
+                                       /* bt_tree_params.refine_weights); owned by the context */
     const int64_t *top_box_arrive, *top_box_stay;   /* device tables for bt_tree_params with   */
                                        /* extents (levels 0..top_level), else NULL           */
 } bt_mgpu_shard;

@@ -140,3 +140,102 @@ def test_sharded_tree_with_target_extents(dims, world, dist_kind, norm):
     assert np.array_equal(tnon[top & (g.box_target_counts_nonchild < g.box_target_counts_cumul)],
                           g.box_target_counts_nonchild[top & (g.box_target_counts_nonchild
                                                               < g.box_target_counts_cumul)])
+
+
+@pytest.mark.parametrize("dims,world,dist_kind,mode", [(3, 3, "uniform", "sources"), (2, 4, "blob", "sources"),
+                                                       (3, 2, "blob", "targets"), (2, 5, "normal", "targets"),
+                                                       (3, 4, "uniform", "extents"), (2, 3, "blob", "extents")])
+def test_sharded_tree_with_refine_weights(dims, world, dist_kind, mode):
+    """Refine weights (tree_build.py:395-446, tree_build_kernels.py:569-591: a box splits iff the
+    weight bound for its children exceeds max_leaf_refine_weight): the exchange sums weights per
+    cell next to the counts, the weights travel with the particles, and the per-rank trees are
+    slices of the single-GPU tree built with the same weights -- sources only, with separate
+    targets, and with targets that have extents."""
+    import torch
+    from boxtree_amd import HIPArrayContext, TreeBuilder
+    from boxtree_amd.distributed import native as nat
+    n_src, n_tgt, max_w, top_level, sof = 30000, 6000, 40, 3 if dims == 3 else 4, 0.25
+    src, tgt, rad = make_chunks(world, dims, n_src, n_tgt, 900, dist_kind,
+                                0.4 if dist_kind == "normal" else 0.05)
+    wsrc = [np.random.default_rng(70 + r).integers(0, 6, n_src).astype(np.int32) for r in range(world)]
+    wtgt = [np.random.default_rng(170 + r).integers(0, 4, n_tgt).astype(np.int32) for r in range(world)]
+    group = nat.LocalGroup(world)
+
+    def rank_fn(rank):
+        actx = HIPArrayContext(0)
+        comm = group.comm(rank)
+        p = [torch.from_numpy(a).cuda() for a in src[rank]]
+        kw_x = dict(top_level=top_level, refine_weights=torch.from_numpy(wsrc[rank]).cuda(),
+                    max_leaf_refine_weight=max_w)
+        if mode == "sources":
+            p2, kw, stats = nat.exchange_particles(actx, comm, p, None, **kw_x)
+            tree, _ = TreeBuilder(actx)(actx, p2, **kw)
+        else:
+            t = [torch.from_numpy(a).cuda() for a in tgt[rank]]
+            kw_x["targets"] = t
+            # (one rank passes no target weights: ones)
+            kw_x["target_refine_weights"] = None if rank == 1 else torch.from_numpy(wtgt[rank]).cuda()
+            if mode == "extents":
+                p2, t2, r2, kw, stats = nat.exchange_particles(
+                    actx, comm, p, None, target_radii=torch.from_numpy(rad[rank]).cuda(),
+                    stick_out_factor=sof, extent_norm="linf", **kw_x)
+                tree, _ = TreeBuilder(actx)(actx, p2, targets=t2, target_radii=r2, **kw)
+            else:
+                p2, t2, kw, stats = nat.exchange_particles(actx, comm, p, None, **kw_x)
+                tree, _ = TreeBuilder(actx)(actx, p2, targets=t2, **kw)
+        num = nat.number_sharded_tree(actx, comm, tree)
+        comm.close()
+        return dict(tree=actx.to_numpy(tree), gid=num["box_ids"].cpu().numpy().astype(np.int64),
+                    num={k: num[k] for k in ("nboxes", "nlevels", "source_offset", "target_offset")})
+
+    results = run_ranks(world, rank_fn)
+    group.close()
+
+    actx = HIPArrayContext(0)
+    cat = lambda chunks, ax: torch.from_numpy(np.concatenate([c[ax] for c in chunks])).cuda()  # noqa: E731
+    allsrc = [cat(src, ax) for ax in range(dims)]
+    weights = np.concatenate(wsrc)
+    gkw = {}
+    if mode != "sources":
+        gkw["targets"] = [cat(tgt, ax) for ax in range(dims)]
+        wt = [np.ones(n_tgt, np.int32) if r == 1 else wtgt[r] for r in range(world)]
+        weights = np.concatenate([weights] + wt)
+        if mode == "extents":
+            gkw.update(target_radii=torch.from_numpy(np.concatenate(rad)).cuda(), stick_out_factor=sof,
+                       extent_norm="linf")
+    gt, _ = TreeBuilder(actx)(actx, allsrc, refine_weights=torch.from_numpy(weights).cuda(),
+                              max_leaf_refine_weight=max_w, **gkw)
+    g = actx.to_numpy(gt)
+    # the weights matter: the same particles with unit weights make another tree
+    gu = TreeBuilder(actx)(actx, allsrc, max_particles_in_box=max_w, **gkw)[0]
+    assert int(gu.nboxes) != g.nboxes
+    hits = np.zeros(g.nboxes, np.int64)
+    scum = np.zeros(g.nboxes, np.int64)
+    for res in results:
+        h, m, num = res["tree"], res["gid"], res["num"]
+        nb = h.nboxes
+        assert num["nboxes"] == g.nboxes and num["nlevels"] == g.nlevels
+        assert len(set(m.tolist())) == nb
+        hits[m] += 1
+        assert np.array_equal(g.box_levels[m], h.box_levels)
+        assert np.array_equal(g.box_centers[:, m], h.box_centers[:, :nb])
+        assert np.array_equal(g.box_parent_ids[m], m[h.box_parent_ids])
+        ch = h.box_child_ids[:, :nb]
+        mapped = np.where(ch != 0, m[ch], 0)
+        gch = g.box_child_ids[:, m]
+        deep = h.box_levels > top_level
+        assert np.array_equal(mapped[:, deep], gch[:, deep])
+        assert np.all((mapped == 0) | (mapped == gch))
+        for name in ("box_source_counts_cumul", "box_source_counts_nonchild", "box_flags"):
+            assert np.array_equal(getattr(g, name)[m][deep], getattr(h, name)[deep]), name
+        so = num["source_offset"]
+        assert np.array_equal(g.box_source_starts[m][deep], h.box_source_starts[deep] + so)
+        scum[m] += h.box_source_counts_cumul
+        for ax in range(dims):
+            assert np.array_equal(g.sources[ax][so:so + h.nsources], h.sources[ax])
+        if mode != "sources":
+            to = num["target_offset"]
+            for ax in range(dims):
+                assert np.array_equal(g.targets[ax][to:to + h.ntargets], h.targets[ax])
+    assert np.all(hits >= 1) and np.all(hits[g.box_levels > top_level] == 1)
+    assert np.array_equal(scum, g.box_source_counts_cumul)
