@@ -154,6 +154,10 @@ struct bt_mgpu_comm {
     nccl_comm_t nccl = nullptr;
     LocalGroup *group = nullptr;
     bool self_loopback = false;   // RCCL: a rank's message to itself travels as ncclSend/ncclRecv too
+    // ranks as threads: what this rank publishes for its peers to read lives as long as the
+    // communicator (a rank that leaves a collective on a failed barrier must not take the
+    // vector its peers are still reading with it)
+    std::vector<int64_t> published;
 };
 
 namespace {
@@ -170,7 +174,9 @@ int comm_all_reduce(bt_mgpu_comm *c, hipStream_t stream, void *dev, size_t count
         return BT_OK;
     }
     LocalGroup *g = c->group;
-    std::vector<int64_t> mine(count), res(count);
+    std::vector<int64_t> &mine = c->published;
+    std::vector<int64_t> res(count);
+    mine.resize(count);
     BT_HIP_CHECK(hipMemcpyAsync(mine.data(), dev, count * 8, hipMemcpyDeviceToHost, stream));
     BT_HIP_CHECK(hipStreamSynchronize(stream));
     g->ptr[c->rank] = mine.data();
@@ -1213,7 +1219,9 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     BT_CHECK(bt::copy_to_pinned(ctx, h_local, hist32.get(), (size_t) nh * 4));
     BT_CHECK(comm_all_reduce(comm, stream, hist64.get(), (size_t) (nh + nw), RED_SUM_I64));
     BT_CHECK(bt::copy_to_pinned(ctx, h_ghist2, hist64.get(), (size_t) (nh + nw) * 8));
+    bt::host_trace("x:queued");
     BT_CHECK(bt::sync_stream(ctx));                       // the one wait the GPU idles through
+    bt::host_trace("x:hist here");
 
     const bool sep = h_box[2 * D] < 0;
     const int nsets = sep ? 2 : 1;
@@ -1280,6 +1288,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     }
     for (int ax = 0; ax < 3; ++ax) { pl.bbox_min[ax] = bmin[ax]; pl.bbox_max[ax] = bmax[ax]; }
     pl.root_extent = root_extent;
+    bt::host_trace("x:planned");
     memcpy(h_owner, pl.owner.data(), (size_t) ncells * 4);
     BT_HIP_CHECK(hipMemcpyAsync(owner_d.get(), h_owner, (size_t) ncells * 4, hipMemcpyHostToDevice, stream));
     int64_t send_counts[2 * BT_MGPU_MAX_RANKS], nrecv_of[2] = {0, 0};       // [set][owner]
@@ -1342,7 +1351,9 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
                                            nranks, rank, self_d.get() + 2 * s, send[s].get(),
                                            loop_self ? send[s].get() : points_of[s]));
     }
+    bt::host_trace("x:sweeps queued");
     BT_HIP_CHECK(hipEventSynchronize(ms->ev_counts));     // (the GPU is busy with the sweeps)
+    bt::host_trace("x:counts here");
     int32_t rounds_total = 0;
     int64_t bytes_sent = 0;
     BT_HIP_CHECK(hipEventRecord(ms->ev[0], stream));

@@ -48,6 +48,13 @@ SPECS = {
         ("level_tables_kernel", None, "4 bytes per row entry written"),
     ],
 }
+# the N > 1 code path on one rank (bench.py --force-dist): the exchange's own kernels
+SPECS["c3dist"] = SPECS["c3"] + [
+    ("morton_cells_lds_kernel", 28, "24 (coordinates) + 4 (cell out); the histogram stays in LDS"),
+    ("pp_count_kernel", 5, "4 (cell) + 1 (owner byte out)"),
+    ("pp_scatter_kernel", 49, "1 (owner) + 24 (coordinates) + 24 (record out)"),
+    ("let_link_kernel", None, "per box: path lookups in the level above, parent / child / centre out"),
+]
 SPECS["c4"] = SPECS["c3"]
 SPECS["c2"] = SPECS["c3"]
 SPECS["c5"] = SPECS["c3"] + [
