@@ -22,6 +22,7 @@
 #include "bt_geom.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <climits>
 #include <cstdlib>
 #include <cmath>
@@ -627,11 +628,16 @@ struct RekeyPred {
     const int32_t *box_start;
     int32_t b0, max_weight;
     int adaptive;
+    // level-restricted builds (boxes in creation order, any leaf may be split later): every
+    // non-empty box of level `want_level`
+    const uint8_t *levels;
+    int want_level;
     __device__ bool cand(int64_t i) const
     {
         const int32_t b = b0 + (int32_t) i;
         const int32_t n = box_count[b];
         if (n <= 0) return false;
+        if (levels) return (int) levels[b] == want_level;
         if (!adaptive) return true;
         int64_t w = n;
         if (wprefix) { const int32_t s = box_start[b]; w = wprefix[s + n] - wprefix[s]; }
@@ -711,6 +717,8 @@ struct BuildArgs {
     const int64_t *top_prefix;  // [C^top_level + 1] or null
     int top_local;              // top_prefix holds THIS key array's cell starts (cell_starts_kernel):
                                 // child ranges down to top_level are looked up, not searched
+    const uint64_t *keys2;      // count_children_kernel (level-restricted builds): the key of the
+    int L1k, L2k;               // levels L1k+1 .. L1k+L2k, for parents of level >= L1k
     const int64_t *top_arrive;  // particles with extents: per top box (levels 0..top_level, index
     const int64_t *top_stay;    // (C^level - 1) / (C - 1) + path) the global arrivals / stuck ones
     int loff;                   // the key addresses levels loff+1 .. loff+L (continuation keys)
@@ -790,27 +798,31 @@ __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
 
     int lo = 0, e = 0, s = 0;
     uint64_t prefix = 0;
-    const int lr = l - a.loff;          // level relative to the key
+    // a parent below the reach of the first key is searched in the continuation key
+    const bool deep = a.keys2 != nullptr && l - 1 >= a.L1k;
+    const uint64_t *keys = deep ? a.keys2 : a.keys;
+    const int KL = deep ? a.L2k : a.L;
+    const int lr = l - (deep ? a.L1k : a.loff);          // level relative to the key
     // continuation: boxes of level loff that were not re-keyed have nothing to split
     const bool skipped = a.cand != nullptr && !forced && active && !a.cand[bl];
     if (active) {
         s = a.box_start[b];
         e = s + a.box_count[b];
-        if (lr - 1 < a.L && e > s && !skipped) {
-            const int pshift = a.capbits + D * (a.L - (lr - 1));
-            prefix = (pshift >= 64) ? 0 : (a.keys[s] >> pshift);
-            const int cshift = a.capbits + D * (a.L - lr);
+        if (lr - 1 < KL && e > s && !skipped) {
+            const int pshift = a.capbits + D * (KL - (lr - 1));
+            prefix = (pshift >= 64) ? 0 : (keys[s] >> pshift);
+            const int cshift = a.capbits + D * (KL - lr);
             if (m == 0) {
                 if (EXT) {
                     // own (stuck) particles: Kt == prefix000.., cap == lr-1
                     const uint64_t stuck = ((prefix << D) << cshift) | (uint64_t) (lr - 1);
-                    lo = upper_bound_key(a.keys, s, e, stuck);
+                    lo = upper_bound_key(keys, s, e, stuck);
                 } else {
                     lo = s;
                 }
             } else {
                 const uint64_t ck = ((prefix << D) | (uint64_t) m) << cshift;
-                lo = lower_bound_key(a.keys, s, e, ck);
+                lo = lower_bound_key(keys, s, e, ck);
             }
         } else {
             lo = (m == 0) ? s : e;
@@ -830,12 +842,12 @@ __global__ __launch_bounds__(256) void count_children_kernel(BuildArgs a)
     else if (a.adaptive) split = W > a.max_weight;               // tbk:577-591
     else split = true;
     if (skipped) split = false;
-    if (lr - 1 >= a.L) {
+    if (lr - 1 >= KL) {
         if (split && e > s && (a.adaptive || W > a.max_weight)) {
             // deeper than this key reaches: re-key the box's particles for the levels
             // below (tree_build_impl), or give up where the coordinate bits end
             if (m == 0) {
-                if (a.can_continue)
+                if (a.can_continue && !deep)
                     __hip_atomic_store(&a.flags->need_more, 1, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
                 else
@@ -2433,7 +2445,8 @@ __global__ __launch_bounds__(256) void lr_renumber_kernel(int32_t n, LrKeep keep
 }
 
 template <class T, int D>
-int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
+int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys, const uint64_t *keys2, int L2,
+                   const std::function<int(int64_t, int64_t)> &rekey_level)
 {
     constexpr int C = 1 << D;
     const bt_tree_params &p = st->p;
@@ -2442,6 +2455,7 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
     BT_CHECK(d_flags.alloc(ctx->pool, 1));
     Buf<int32_t> d_have;
     BT_CHECK(d_have.alloc(ctx->pool, 1));
+    bool keys2_ready = false;
 
     auto make_args = [&](BuildArgs &a) {
         a = BuildArgs{};
@@ -2456,6 +2470,10 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
         a.L = st->L; a.capbits = st->capbits;
         a.adaptive = 1;
         a.keep_empty = 1;
+        // below level L: the continuation key, once it has been made (rekey_level)
+        a.keys2 = keys2_ready ? keys2 : nullptr;
+        a.L1k = st->L; a.L2k = L2;
+        a.can_continue = (L2 > 0 && !keys2_ready) ? 1 : 0;
     };
 
     // splits the boxes [b0, b0+n) of one level, or the listed boxes (forced)
@@ -2480,6 +2498,23 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
         LevelFlags hf;
         BT_CHECK(bt::d2h(ctx, &hf, d_flags.get(), sizeof(hf)));
         BT_CHECK(bt::sync_stream(ctx));
+        if (hf.need_more && !keys2_ready) {
+            // a box at the deepest level of the key has to split: continuation keys for the
+            // boxes of that level, then the same boxes once more
+            BT_CHECK(rekey_level(0, st->nboxes));
+            keys2_ready = true;
+            BT_HIP_CHECK(hipMemsetAsync(d_flags.get(), 0, sizeof(LevelFlags), ctx->stream));
+            make_args(a);
+            a.bounds = bounds.get(); a.nnew = nnew.get(); a.offsets = offsets.get();
+            a.level = level; a.b0 = (int) b0; a.nprev = (int) n;
+            a.parent_list = (const int32_t *) list;
+            if (EXT) count_children_kernel<D, true><<<blocks, 256, 0, ctx->stream>>>(a);
+            else count_children_kernel<D, false><<<blocks, 256, 0, ctx->stream>>>(a);
+            BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, sn, n, offsets.get(),
+                                                              &d_flags.get()->total_new)));
+            BT_CHECK(bt::d2h(ctx, &hf, d_flags.get(), sizeof(hf)));
+            BT_CHECK(bt::sync_stream(ctx));
+        }
         *total_new = hf.total_new;
         *oversize = hf.have_oversize;
         if (hf.total_new == 0) return BT_OK;
@@ -2492,7 +2527,12 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
         write_children_kernel<T, D><<<blocks, 256, 0, ctx->stream>>>(a, (T *) st->centers.get(),
                                                                      (T) p.root_extent);
         BT_HIP_CHECK(hipGetLastError());
+        const int64_t first_new = st->nboxes;
         st->nboxes += hf.total_new;
+        // boxes of the key's deepest level that appear after the continuation keys were made
+        // (children of leaves the restriction splits late) get theirs now
+        if (keys2_ready && (list != nullptr || level == st->L))
+            BT_CHECK(rekey_level(first_new, hf.total_new));
         return BT_OK;
     };
 
@@ -2569,7 +2609,9 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
         const size_t lds = (size_t) (level + 2) * WALK_THREADS * 4;
         for (int upper_level = level - 2; upper_level >= 1; --upper_level) {
             BT_HIP_CHECK(hipMemsetAsync(d_have.get(), 0, 4, ctx->stream));
-            if (walk_pass) {
+            // (the look-up form descends along 64-bit Morton paths: trees that deep -- below
+            // the first key -- take the reference's walk)
+            if (walk_pass || D * level > 63) {
                 lr_pass_kernel<T, D><<<(unsigned) div_up(nb, WALK_THREADS), WALK_THREADS, lds, ctx->stream>>>(
                     nb, upper_level, (T) p.root_extent, st->box_level.get(), st->box_haschild.get(),
                     st->box_child.get(), (const T *) st->centers.get(), force.get(), d_have.get());
@@ -2617,7 +2659,7 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys)
         }
         if (!oversize) break;                   // :1228-1230
         level += 1;
-        if (level > st->L + 1) break;           // defensive; max_levels flag is set on device
+        if (level > st->L + L2 + 1) break;      // defensive; max_levels flag is set on device
     }
     BT_CHECK(check_status(ctx));
 
@@ -3157,8 +3199,102 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     st->nboxes = 1;
     st->level_start = {0, 1};
 
+    // ---- continuation keys: the particles of the boxes `pr` selects among [pr.b0, pr.b0 + nb)
+    // (boxes of level L1 = st->L that have to split, or may have to) are re-keyed for the levels
+    // L1+1..31 (keygen2_kernel), sorted -- the key prefixed by the box's rank, so that ONE global
+    // stable sort keeps the boxes apart -- and put back into their ranges: keys_oth becomes the key
+    // array of the deeper levels, ids follows.  cand[i] = 1 for the boxes that were re-keyed.
+    const int L2_cont = KEY_AXIS_BITS - st->L;
+    auto rekey_boxes = [&](RekeyPred pr, int nb, Buf<uint8_t> &cand) -> int {
+        const int L1 = st->L, L2 = L2_cont;
+        const int keybits2 = D * L2 + st->capbits;
+        Buf<int32_t> seg_rank, seg_off, seg_box, seg_start;
+        BT_CHECK(seg_rank.alloc(ctx->pool, nb + 1));
+        BT_CHECK(seg_off.alloc(ctx->pool, nb + 1));
+        BT_CHECK(cand.alloc(ctx->pool, nb));
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, RekeyFlag{pr}, nb, seg_rank.get(),
+                                                          (int32_t *) nullptr, true)));
+        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, RekeyCount{pr}, nb, seg_off.get(),
+                                                          (int32_t *) nullptr, true)));
+        int32_t h_tot[2] = {0, 0};
+        BT_CHECK(bt::d2h(ctx, &h_tot[0], seg_rank.get() + nb, 4));
+        BT_CHECK(bt::d2h(ctx, &h_tot[1], seg_off.get() + nb, 4));
+        BT_CHECK(bt::sync_stream(ctx));
+        ctx->n_host_syncs++;
+        const int32_t nseg = h_tot[0];
+        const int64_t M = h_tot[1];
+        int segbits = 1;
+        while (((int64_t) 1 << segbits) < nseg) ++segbits;
+        if (keybits2 + segbits > 64) {
+            set_error("%d boxes of level %d have to be refined below the reach of the 64-bit "
+                      "Morton key: more than its continuation can tell apart", nseg, L1);
+            return BT_ERR_UNSUPPORTED;
+        }
+        BT_CHECK(seg_box.alloc(ctx->pool, nseg));
+        BT_CHECK(seg_start.alloc(ctx->pool, nseg + 1));
+        rekey_segments_kernel<<<(unsigned) div_up(nb + 1, 256), 256, 0, ctx->stream>>>(
+            nb, pr, seg_rank.get(), seg_off.get(), cand.get(), seg_box.get(), seg_start.get());
+        Buf<uint64_t> k2a, k2b;
+        Buf<uint32_t> i2a, i2b;
+        Buf<int32_t> positions;
+        BT_CHECK(k2a.alloc(ctx->pool, M));
+        BT_CHECK(k2b.alloc(ctx->pool, M));
+        BT_CHECK(i2a.alloc(ctx->pool, M));
+        BT_CHECK(i2b.alloc(ctx->pool, M));
+        BT_CHECK(positions.alloc(ctx->pool, M));
+        Keygen2Args<T, D> ka2{};
+        ka2.packed = (const T *) st->packed.get();
+        ka2.src_radii = (const T *) p.source_radii;
+        ka2.tgt_radii = (const T *) p.target_radii;
+        ka2.nsources = st->nsources;
+        for (int ax = 0; ax < D; ++ax) {
+            ka2.bbox_min[ax] = (T) p.bbox_min[ax];
+            ka2.bbox_max[ax] = (T) p.bbox_max[ax];
+        }
+        ka2.stick_out_factor = (T) p.stick_out_factor;
+        ka2.L1 = L1; ka2.L2 = L2; ka2.capbits = st->capbits; ka2.norm = p.extent_norm;
+        ka2.point_skip_levels = std::min(point_skip_raw, KEY_AXIS_BITS);
+        ka2.ids = ids;
+        ka2.box_start = st->box_start.get();
+        ka2.seg_box = seg_box.get(); ka2.seg_start = seg_start.get();
+        ka2.nseg = nseg; ka2.m = M;
+        const unsigned kblocks = (unsigned) div_up(M, 256);
+        if (M > 0) {
+            if (EXT) keygen2_kernel<T, D, true><<<kblocks, 256, 0, ctx->stream>>>(ka2, k2a.get(), i2a.get(), positions.get());
+            else keygen2_kernel<T, D, false><<<kblocks, 256, 0, ctx->stream>>>(ka2, k2a.get(), i2a.get(), positions.get());
+            bool in_b = false;
+            BT_CHECK(radix_sort_pairs<uint64_t>(ctx, k2a.get(), i2a.get(), k2b.get(), i2b.get(), M, 0,
+                                                keybits2 + segbits, false, &in_b));
+            // the re-keyed boxes keep their ranges: compact index j <-> position positions[j]
+            // (ascending), so the sorted pairs go back in order; keys_oth is free after the
+            // full sort and becomes the key array of the deeper levels
+            scatter_rekeyed_kernel<<<kblocks, 256, 0, ctx->stream>>>(
+                M, positions.get(), in_b ? k2b.get() : k2a.get(), in_b ? i2b.get() : i2a.get(),
+                keys_oth, ids);
+        }
+        if (p.refine_weights) {
+            // positions inside the re-keyed boxes changed: weight prefix sums again
+            GatherWeight gw{p.refine_weights, ids};
+            BT_CHECK((device_exclusive_scan<int64_t, int64_t>(ctx, gw, N, st->wprefix.get(),
+                                                              (int64_t *) nullptr, true)));
+        }
+        BT_HIP_CHECK(hipGetLastError());
+        return BT_OK;
+    };
+
     const bool level_restricted = p.kind == BT_KIND_ADAPTIVE_LEVEL_RESTRICTED;
-    if (level_restricted && N > 0) BT_CHECK((lr_build_boxes<T, D>(ctx, st, keys)));
+    if (level_restricted && N > 0) {
+        // a level-restricted tree may split any leaf later: when the level loop first needs a
+        // box below the reach of the key, ALL non-empty boxes of that level are re-keyed
+        // (boxes [b0, b0 + nb) in creation order: all of them at first, later the new ones)
+        std::function<int(int64_t, int64_t)> rekey_level = [&](int64_t b0, int64_t nb) -> int {
+            RekeyPred pr{st->box_count.get(), st->wprefix.get(), st->box_start.get(), (int32_t) b0,
+                         p.max_leaf_refine_weight, 1, st->box_level.get(), st->L};
+            Buf<uint8_t> cand;
+            return rekey_boxes(pr, (int) nb, cand);
+        };
+        BT_CHECK((lr_build_boxes<T, D>(ctx, st, keys, keys_oth, L2_cont, rekey_level)));
+    }
     // tree_build.py:676: the level loop is not entered at all when the root is not
     // overfull -- this also keeps a non-adaptive tree, which otherwise splits every
     // box of a level, at a single box
@@ -3304,7 +3440,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     };
 
     // levels addressable below the first key (the per-axis cell index has 31 bits)
-    const int L2 = KEY_AXIS_BITS - st->L;
+    const int L2 = L2_cont;
     bool need_more = false;
     bool status_read = false;      // the level loop's last wait brought the status word
     if (enter_loop) {
@@ -3325,81 +3461,12 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         // ---- continuation below level L1 = st->L (keygen2_kernel) ---------------------
         if (packed) BT_CHECK(unpack_keys(false));
         const int L1 = st->L;
-        const int keybits2 = D * L2 + st->capbits;
         const int b0 = st->level_start[L1];
         const int nb = st->level_start[L1 + 1] - b0;
         RekeyPred pr{st->box_count.get(), st->wprefix.get(), st->box_start.get(), b0,
-                     p.max_leaf_refine_weight, p.kind != BT_KIND_NON_ADAPTIVE};
-        Buf<int32_t> seg_rank, seg_off, seg_box, seg_start;
+                     p.max_leaf_refine_weight, p.kind != BT_KIND_NON_ADAPTIVE, nullptr, 0};
         Buf<uint8_t> cand;
-        BT_CHECK(seg_rank.alloc(ctx->pool, nb + 1));
-        BT_CHECK(seg_off.alloc(ctx->pool, nb + 1));
-        BT_CHECK(cand.alloc(ctx->pool, nb));
-        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, RekeyFlag{pr}, nb, seg_rank.get(),
-                                                          (int32_t *) nullptr, true)));
-        BT_CHECK((device_exclusive_scan<int32_t, int32_t>(ctx, RekeyCount{pr}, nb, seg_off.get(),
-                                                          (int32_t *) nullptr, true)));
-        int32_t h_tot[2] = {0, 0};
-        BT_CHECK(bt::d2h(ctx, &h_tot[0], seg_rank.get() + nb, 4));
-        BT_CHECK(bt::d2h(ctx, &h_tot[1], seg_off.get() + nb, 4));
-        BT_CHECK(bt::sync_stream(ctx));
-        ctx->n_host_syncs++;
-        const int32_t nseg = h_tot[0];
-        const int64_t M = h_tot[1];
-        int segbits = 1;
-        while (((int64_t) 1 << segbits) < nseg) ++segbits;
-        if (keybits2 + segbits > 64) {
-            set_error("%d boxes of level %d have to be refined below the reach of the 64-bit "
-                      "Morton key: more than its continuation can tell apart", nseg, L1);
-            return BT_ERR_UNSUPPORTED;
-        }
-        BT_CHECK(seg_box.alloc(ctx->pool, nseg));
-        BT_CHECK(seg_start.alloc(ctx->pool, nseg + 1));
-        rekey_segments_kernel<<<(unsigned) div_up(nb + 1, 256), 256, 0, ctx->stream>>>(
-            nb, pr, seg_rank.get(), seg_off.get(), cand.get(), seg_box.get(), seg_start.get());
-        Buf<uint64_t> k2a, k2b;
-        Buf<uint32_t> i2a, i2b;
-        Buf<int32_t> positions;
-        BT_CHECK(k2a.alloc(ctx->pool, M));
-        BT_CHECK(k2b.alloc(ctx->pool, M));
-        BT_CHECK(i2a.alloc(ctx->pool, M));
-        BT_CHECK(i2b.alloc(ctx->pool, M));
-        BT_CHECK(positions.alloc(ctx->pool, M));
-        Keygen2Args<T, D> ka{};
-        ka.packed = (const T *) st->packed.get();
-        ka.src_radii = (const T *) p.source_radii;
-        ka.tgt_radii = (const T *) p.target_radii;
-        ka.nsources = st->nsources;
-        for (int ax = 0; ax < D; ++ax) {
-            ka.bbox_min[ax] = (T) p.bbox_min[ax];
-            ka.bbox_max[ax] = (T) p.bbox_max[ax];
-        }
-        ka.stick_out_factor = (T) p.stick_out_factor;
-        ka.L1 = L1; ka.L2 = L2; ka.capbits = st->capbits; ka.norm = p.extent_norm;
-        ka.point_skip_levels = std::min(point_skip_raw, KEY_AXIS_BITS);
-        ka.ids = ids;
-        ka.box_start = st->box_start.get();
-        ka.seg_box = seg_box.get(); ka.seg_start = seg_start.get();
-        ka.nseg = nseg; ka.m = M;
-        const unsigned kblocks = (unsigned) div_up(M, 256);
-        if (EXT) keygen2_kernel<T, D, true><<<kblocks, 256, 0, ctx->stream>>>(ka, k2a.get(), i2a.get(), positions.get());
-        else keygen2_kernel<T, D, false><<<kblocks, 256, 0, ctx->stream>>>(ka, k2a.get(), i2a.get(), positions.get());
-        bool in_b = false;
-        BT_CHECK(radix_sort_pairs<uint64_t>(ctx, k2a.get(), i2a.get(), k2b.get(), i2b.get(), M, 0,
-                                            keybits2 + segbits, false, &in_b));
-        // the re-keyed boxes keep their ranges: compact index j <-> position positions[j]
-        // (ascending), so the sorted pairs go back in order; keys_oth is free after the
-        // full sort and becomes the key array of the deeper levels
-        scatter_rekeyed_kernel<<<kblocks, 256, 0, ctx->stream>>>(
-            M, positions.get(), in_b ? k2b.get() : k2a.get(), in_b ? i2b.get() : i2a.get(),
-            keys_oth, ids);
-        if (p.refine_weights) {
-            // positions inside the re-keyed boxes changed: weight prefix sums again
-            GatherWeight gw{p.refine_weights, ids};
-            BT_CHECK((device_exclusive_scan<int64_t, int64_t>(ctx, gw, N, st->wprefix.get(),
-                                                              (int64_t *) nullptr, true)));
-        }
-        BT_HIP_CHECK(hipGetLastError());
+        BT_CHECK(rekey_boxes(pr, nb, cand));
         const uint64_t *keys2 = keys_oth;
         bool dummy = false;
         // the launch of level L1+1 on the first key took that level's tickets

@@ -338,6 +338,37 @@ def test_deep_tree_below_the_key_with_extents(actx, oracle):
     check_traversal(htree, htrav)
 
 
+@pytest.mark.parametrize("log2_scale,n_cl,mpb", [(-20, 300, 8), (-22, 1500, 8), (-23, 600, 30)])
+def test_deep_level_restricted_tree_below_the_key(actx, oracle, log2_scale, n_cl, mpb):
+    """kind="adaptive-level-restricted" deeper than the 21 levels of the 64-bit key
+    (tree_build.py:622 allows it: nlevels_max = 2 (nmant + 1) for every kind): when the level
+    loop first needs a box below the key's reach, every non-empty box of level 21 is re-keyed --
+    any leaf may be split later by the restriction -- and parents of level >= 21 are searched in
+    the continuation key."""
+    p = clustered_points(3, 6000, n_cl, 2.0 ** log2_scale, seed=11 - log2_scale)
+    htree, otree, htrav, _ = build_both(actx, oracle, p, kind="adaptive-level-restricted",
+                                        max_particles_in_box=mpb, trav_kw={})
+    assert 23 <= htree.nlevels <= 30
+    check_tree(htree, p, max_particles_in_box=mpb)
+    check_traversal(htree, htrav)
+
+
+def test_deep_level_restricted_tree_two_clusters_unpruned(actx, oracle):
+    """Several re-keyed boxes, refine weights, and skip_prune (empty boxes are kept and may be
+    force-split below the key as well)."""
+    rng = np.random.default_rng(6)
+    a = clustered_points(3, 3000, 400, 2.0 ** -22, seed=4)
+    b = clustered_points(3, 3000, 500, 2.0 ** -23, seed=5)
+    p = [np.concatenate([a[d], b[d]]) for d in range(3)]
+    rw = rng.integers(1, 5, len(p[0]), dtype=np.int32)
+    htree, _, _, _ = build_both(actx, oracle, p, kind="adaptive-level-restricted", refine_weights=rw,
+                                max_leaf_refine_weight=20)
+    assert htree.nlevels >= 24
+    htree2, _, _, _ = build_both(actx, oracle, p, kind="adaptive-level-restricted",
+                                 max_particles_in_box=10, skip_prune=True)
+    assert htree2.nlevels >= 24
+
+
 def test_max_levels_exceeded(actx):
     from boxtree_amd import MaxLevelsExceeded, TreeBuilder
     p = [np.zeros(100), np.zeros(100)]
