@@ -682,8 +682,9 @@ def main():
         # over the kernel trace of this command), not in this process -- the committed
         # timeline of the same workload, named
         try:
-            tls = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles"))
-                         if f.endswith(f"_{args.workload}_timeline.txt"))
+            # (the N > 1 code path has a timeline of its own)
+            suffix = f"_{args.workload}_forcedist_timeline.txt" if distributed else f"_{args.workload}_timeline.txt"
+            tls = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(suffix))
             first = open(os.path.join(ROOT, "profiles", tls[-1])).readline().split()
             # "launches 104  span 17.530 ms  busy 17.131 ms  idle 0.399 ms"
             out["launches_per_step"] = {"value": int(first[1]), "gpu_idle_ms": float(first[9]),
