@@ -6,9 +6,12 @@
  *   bt_mgpu_exchange -> bt_tree_build / bt_tree_export -> bt_mgpu_number
  *   -> bt_mgpu_let_build / bt_mgpu_let_export
  *
- *   cabi_mgpu <nranks> <dims> <n_per_rank> <max_particles_in_box> <seed>
+ *   cabi_mgpu <nranks> <dims> <n_per_rank> <max_particles_in_box> <seed> [n_targets_per_rank]
  *
- * Rank r draws its chunk from the stream seeded with seed + r (splitmix64, uniform).  One
+ * Rank r draws its chunk from the stream seeded with seed + r (splitmix64, uniform).  With
+ * n_targets_per_rank > 0 every rank also has separate targets with extents -- coordinates from
+ * the stream seeded with seed + 1000 + r, radii 2^-4 * 2^(-12 u) from the same stream after them,
+ * stick-out factor 0.25, l^inf --: the sharded build of particles with extents from plain C.  One
  * line per rank: what it owns and where its boxes sit in the global tree;
  * tests/test_gpu_cabi.py compares the global figures with the tree the Python layer
  * builds on one GPU from all chunks. */
@@ -37,12 +40,13 @@ static uint64_t splitmix64(uint64_t *s)
 
 typedef struct {
     int rank, nranks, dims, mpb;
-    int64_t n;
+    int64_t n, nt;
     uint64_t seed;
     void *group;
     int status;
     /* results */
     int64_t n_owned, nboxes_local, nboxes_global, let_nboxes, halo_in, source_offset, nsources_global;
+    int64_t nt_owned, target_offset, ntargets_global;
     int32_t nlevels_global;
     uint64_t digest_ids;           /* sum of the global numbers of the rank's deep boxes */
 } rank_args;
@@ -62,6 +66,29 @@ static int run_rank(rank_args *a)
         CHECK_HIP(hipMemcpy(dev[ax], host, (size_t) n * sizeof(double), hipMemcpyHostToDevice));
         free(host);
     }
+    const int64_t nt = a->nt;
+    void *tdev[3] = {0, 0, 0}, *rdev = NULL;
+    if (nt > 0) {
+        uint64_t tseed = a->seed + 1000u + (uint64_t) a->rank;
+        double *host = (double *) malloc((size_t) nt * sizeof(double));
+        for (int ax = 0; ax < dims; ++ax) {
+            for (int64_t i = 0; i < nt; ++i)
+                host[i] = (double) (splitmix64(&tseed) >> 11) * (1.0 / 9007199254740992.0);
+            CHECK_HIP(hipMalloc(&tdev[ax], (size_t) nt * sizeof(double)));
+            CHECK_HIP(hipMemcpy(tdev[ax], host, (size_t) nt * sizeof(double), hipMemcpyHostToDevice));
+        }
+        for (int64_t i = 0; i < nt; ++i) {
+            const double u = (double) (splitmix64(&tseed) >> 11) * (1.0 / 9007199254740992.0);
+            /* 2^-4 * 2^(-12 u) without libm: 2^-(4 + k) * (1 - f/2), k = floor(12 u), f its fraction
+             * (a fixed, reproducible function of u; the Python side evaluates the same expression) */
+            const int k = (int) (12.0 * u);
+            const double f = 12.0 * u - (double) k;
+            host[i] = (1.0 / (double) (1u << (4 + k))) * (1.0 - 0.5 * f);
+        }
+        CHECK_HIP(hipMalloc(&rdev, (size_t) nt * sizeof(double)));
+        CHECK_HIP(hipMemcpy(rdev, host, (size_t) nt * sizeof(double), hipMemcpyHostToDevice));
+        free(host);
+    }
     bt_context *ctx = NULL;
     CHECK_BT(bt_create(0, NULL, &ctx));
     bt_mgpu_comm *comm = NULL;
@@ -72,6 +99,11 @@ static int run_rank(rank_args *a)
     memset(&mp, 0, sizeof(mp));
     mp.dims = dims; mp.coord_kind = BT_F64; mp.n = n; mp.max_particles_in_box = a->mpb;
     for (int ax = 0; ax < dims; ++ax) mp.coords[ax] = dev[ax];
+    if (nt > 0) {
+        mp.ntargets = nt;
+        for (int ax = 0; ax < dims; ++ax) mp.targets[ax] = tdev[ax];
+        mp.target_radii = rdev; mp.stick_out_factor = 0.25; mp.extent_norm = BT_NORM_LINF;
+    }
     bt_mgpu_shard sh;
     CHECK_BT(bt_mgpu_exchange(ctx, comm, &mp, &sh));
 
@@ -85,6 +117,16 @@ static int run_rank(rank_args *a)
     for (int ax = 0; ax < dims; ++ax) {
         tp.sources[ax] = (const double *) sh.points + ax;
         tp.bbox_min[ax] = sh.bbox_min[ax]; tp.bbox_max[ax] = sh.bbox_max[ax];
+    }
+    if (nt > 0) {
+        /* the received targets: records of dims + 1 values, radii once more as a dense array;
+         * the top of the global tree as arrivals / stayers per top box */
+        tp.ntargets = sh.n_owned_targets;
+        tp.target_stride = sh.target_record_len;
+        for (int ax = 0; ax < dims; ++ax) tp.targets[ax] = (const double *) sh.target_points + ax;
+        tp.target_radii = sh.target_radii;
+        tp.stick_out_factor = 0.25; tp.extent_norm = BT_NORM_LINF;
+        tp.top_box_arrive = sh.top_box_arrive; tp.top_box_stay = sh.top_box_stay;
     }
     bt_tree_sizes sz;
     CHECK_BT(bt_tree_build(ctx, &tp, &sz));
@@ -105,6 +147,16 @@ static int run_rank(rank_args *a)
     CHECK_HIP(hipMalloc((void **) &o.box_flags, nb));
     CHECK_HIP(hipMalloc(&o.box_source_bounding_box_min, (size_t) dims * al * 8));
     CHECK_HIP(hipMalloc(&o.box_source_bounding_box_max, (size_t) dims * al * 8));
+    if (nt > 0) {
+        const size_t nto = (size_t) (sh.n_owned_targets > 0 ? sh.n_owned_targets : 1);
+        for (int ax = 0; ax < dims; ++ax) CHECK_HIP(hipMalloc(&o.targets[ax], nto * 8));
+        CHECK_HIP(hipMalloc(&o.target_radii, nto * 8));
+        CHECK_HIP(hipMalloc((void **) &o.box_target_starts, nb * 4));
+        CHECK_HIP(hipMalloc((void **) &o.box_target_counts_nonchild, nb * 4));
+        CHECK_HIP(hipMalloc((void **) &o.box_target_counts_cumul, nb * 4));
+        CHECK_HIP(hipMalloc(&o.box_target_bounding_box_min, (size_t) dims * al * 8));
+        CHECK_HIP(hipMalloc(&o.box_target_bounding_box_max, (size_t) dims * al * 8));
+    }
     CHECK_BT(bt_tree_export(ctx, &o));
     CHECK_BT(bt_synchronize(ctx));
 
@@ -114,7 +166,12 @@ static int run_rank(rank_args *a)
     lt.dims = dims; lt.coord_kind = BT_F64; lt.nboxes = sz.nboxes; lt.aligned_nboxes = sz.aligned_nboxes;
     lt.nlevels = sz.nlevels; lt.level_start_box_nrs = sz.level_start_box_nrs;
     lt.box_centers = o.box_centers; lt.box_levels = o.box_levels; lt.box_flags = o.box_flags;
-    lt.nsources = sh.n_owned; lt.ntargets = sh.n_owned;
+    lt.nsources = sh.n_owned; lt.ntargets = nt > 0 ? sh.n_owned_targets : sh.n_owned;
+    if (nt > 0) {
+        lt.box_target_bounding_box_min = o.box_target_bounding_box_min;
+        lt.box_target_bounding_box_max = o.box_target_bounding_box_max;
+        lt.box_source_counts_cumul = o.box_source_counts_cumul;
+    }
     int32_t *d_box_ids = NULL;
     CHECK_HIP(hipMalloc((void **) &d_box_ids, nb * 4));
     bt_mgpu_numbering num;
@@ -133,6 +190,11 @@ static int run_rank(rank_args *a)
     CHECK_HIP(hipMalloc((void **) &la.box_flags, lb));
     CHECK_HIP(hipMalloc((void **) &la.global_box_ids, lb * 4));
     CHECK_HIP(hipMalloc((void **) &la.target_boxes_mask, lb));
+    if (nt > 0) {
+        CHECK_HIP(hipMalloc(&la.box_target_bounding_box_min, (size_t) dims * lal * 8));
+        CHECK_HIP(hipMalloc(&la.box_target_bounding_box_max, (size_t) dims * lal * 8));
+        CHECK_HIP(hipMalloc((void **) &la.box_source_counts_cumul, lb * 4));
+    }
     CHECK_BT(bt_mgpu_let_export(ctx, &la));
     CHECK_BT(bt_synchronize(ctx));
 
@@ -147,6 +209,7 @@ static int run_rank(rank_args *a)
     a->n_owned = sh.n_owned; a->nboxes_local = sz.nboxes; a->nboxes_global = num.nboxes;
     a->nlevels_global = num.nlevels; a->let_nboxes = ls.nboxes; a->halo_in = ls.halo_boxes_received;
     a->source_offset = num.source_offset; a->nsources_global = num.nsources; a->digest_ids = dg;
+    a->nt_owned = sh.n_owned_targets; a->target_offset = num.target_offset; a->ntargets_global = num.ntargets;
     bt_mgpu_comm_destroy(comm);
     bt_destroy(ctx);
     return 0;
@@ -165,7 +228,8 @@ static void *thread_main(void *p)
 
 int main(int argc, char **argv)
 {
-    if (argc != 6) { fprintf(stderr, "usage: %s nranks dims n_per_rank mpb seed\n", argv[0]); return 1; }
+    if (argc != 6 && argc != 7) { fprintf(stderr, "usage: %s nranks dims n_per_rank mpb seed [n_targets_per_rank]\n", argv[0]); return 1; }
+    const int64_t nt = argc == 7 ? atoll(argv[6]) : 0;
     const int nranks = atoi(argv[1]), dims = atoi(argv[2]), mpb = atoi(argv[4]);
     const int64_t n = atoll(argv[3]);
     const uint64_t seed = (uint64_t) atoll(argv[5]);
@@ -177,18 +241,20 @@ int main(int argc, char **argv)
     pthread_t *th = (pthread_t *) calloc((size_t) nranks, sizeof(pthread_t));
     for (int r = 0; r < nranks; ++r) {
         args[r].rank = r; args[r].nranks = nranks; args[r].dims = dims; args[r].mpb = mpb;
-        args[r].n = n; args[r].seed = seed; args[r].group = group;
+        args[r].n = n; args[r].nt = nt; args[r].seed = seed; args[r].group = group;
         pthread_create(&th[r], NULL, thread_main, &args[r]);
     }
     for (int r = 0; r < nranks; ++r) pthread_join(th[r], NULL);
     for (int r = 0; r < nranks; ++r)
         printf("rank %d owned %lld source_offset %lld nboxes_local %lld nboxes_global %lld "
-               "nlevels_global %d nsources_global %lld let_nboxes %lld halo_in %lld deep_ids %llu\n",
+               "nlevels_global %d nsources_global %lld let_nboxes %lld halo_in %lld deep_ids %llu "
+               "targets_owned %lld target_offset %lld ntargets_global %lld\n",
                r, (long long) args[r].n_owned, (long long) args[r].source_offset,
                (long long) args[r].nboxes_local, (long long) args[r].nboxes_global,
                args[r].nlevels_global, (long long) args[r].nsources_global,
                (long long) args[r].let_nboxes, (long long) args[r].halo_in,
-               (unsigned long long) args[r].digest_ids);
+               (unsigned long long) args[r].digest_ids, (long long) args[r].nt_owned,
+               (long long) args[r].target_offset, (long long) args[r].ntargets_global);
     bt_mgpu_local_group_destroy(group);
     return 0;
 }

@@ -95,3 +95,58 @@ def test_plain_c_program_runs_the_sharded_build(nranks, dims, n, mpb, seed):
         assert rows[0]["let_nboxes"] == h.nboxes and rows[0]["halo_in"] == 0
     deep = np.nonzero(h.box_levels > top_level)[0].astype(np.uint64)
     assert sum(r["deep_ids"] for r in rows) == int(deep.sum())
+
+
+@pytest.mark.parametrize("nranks,dims,n,nt,mpb,seed", [(2, 3, 60000, 12000, 30, 4), (5, 2, 30000, 8000, 10, 8),
+                                                      (3, 3, 40000, 9000, 16, 12)])
+def test_plain_c_program_runs_the_sharded_build_with_target_extents(nranks, dims, n, nt, mpb, seed):
+    """The same program with separate targets that have extents (bt_mgpu_params.target_radii,
+    the shard's record length and radii column, bt_tree_params.top_box_arrive / _stay, the three
+    extra arrays of the local tree view and of the LET export): global box, level and particle
+    counts, particle offsets and the global numbers of all owned deep boxes are those of the tree
+    one GPU builds from all chunks with target_radii."""
+    exe = os.path.join(HERE, "cabi", "cabi_mgpu")
+    if not os.path.exists(exe):
+        pytest.fail("tests/cabi/cabi_mgpu missing: __graft_entry__.build() compiles it")
+    out = subprocess.run([exe, str(nranks), str(dims), str(n), str(mpb), str(seed), str(nt)],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-1500:]
+    rows = []
+    for line in out.stdout.splitlines():
+        tok = line.split()
+        if tok and tok[0] == "rank":
+            rows.append({tok[i]: int(tok[i + 1]) for i in range(0, len(tok), 2)})
+    assert [r["rank"] for r in rows] == list(range(nranks))
+
+    from boxtree_amd import HIPArrayContext, TreeBuilder
+    actx = HIPArrayContext(0)
+    src = [[splitmix64_uniform(seed + r, n * dims)[ax * n:(ax + 1) * n] for ax in range(dims)]
+           for r in range(nranks)]
+    tgt, rad = [], []
+    for r in range(nranks):
+        draws = splitmix64_uniform(seed + 1000 + r, nt * (dims + 1))
+        tgt.append([draws[ax * nt:(ax + 1) * nt] for ax in range(dims)])
+        u = draws[dims * nt:]
+        k = np.floor(12.0 * u)
+        rad.append((1.0 / 2.0 ** (4 + k)) * (1.0 - 0.5 * (12.0 * u - k)))
+    cat = lambda chunks: [np.concatenate([c[ax] for c in chunks]) for ax in range(dims)]  # noqa: E731
+    tree, _ = TreeBuilder(actx)(actx, [actx.from_numpy(p) for p in cat(src)],
+                                targets=[actx.from_numpy(p) for p in cat(tgt)],
+                                target_radii=actx.from_numpy(np.concatenate(rad)), stick_out_factor=0.25,
+                                max_particles_in_box=mpb)
+    h = actx.to_numpy(tree)
+    top_level = 5 if dims == 3 else 7
+    # the case must have targets that stay in boxes of the shared top levels
+    assert np.any((h.box_levels <= top_level) & (h.box_target_counts_nonchild > 0)
+                  & (h.box_target_counts_nonchild < h.box_target_counts_cumul))
+    assert sum(r["owned"] for r in rows) == nranks * n
+    assert sum(r["targets_owned"] for r in rows) == nranks * nt
+    soff = np.cumsum([0] + [r["owned"] for r in rows[:-1]])
+    toff = np.cumsum([0] + [r["targets_owned"] for r in rows[:-1]])
+    for r, so, to in zip(rows, soff, toff):
+        assert r["nboxes_global"] == h.nboxes and r["nlevels_global"] == h.nlevels
+        assert r["nsources_global"] == nranks * n and r["ntargets_global"] == nranks * nt
+        assert r["source_offset"] == int(so) and r["target_offset"] == int(to)
+        assert r["let_nboxes"] <= h.nboxes
+    deep = np.nonzero(h.box_levels > top_level)[0].astype(np.uint64)
+    assert sum(r["deep_ids"] for r in rows) == int(deep.sum())
