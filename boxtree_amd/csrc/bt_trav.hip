@@ -1413,7 +1413,6 @@ __global__ __launch_bounds__(256) void gather_starts_dev_kernel(int32_t n, const
 template <class T, int D>
 int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
 {
-    constexpr int C = 1 << D;
     constexpr int P = V2Dims<D>::P;
     const bt_trav_params &p = st->p;
     const int64_t B = p.nboxes;
