@@ -767,7 +767,7 @@ struct LetExtras {
 // extras of the boxes peer q needs: [n][2 D] coordinates (min.., max..), then [n] counts
 template <class T>
 __global__ __launch_bounds__(256) void let_pack_extras_kernel(int64_t n, NeedPred pr, const int32_t *pos,
-        LetExtras<T> ex, int64_t nsel, T *out_box, int32_t *out_cnt)
+        LetExtras<T> ex, T *out_box, int32_t *out_cnt)
 {
     const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= n || !pr(i)) return;
@@ -777,7 +777,6 @@ __global__ __launch_bounds__(256) void let_pack_extras_kernel(int64_t n, NeedPre
         out_box[at * 2 * ex.D + ex.D + ax] = ex.bmax[(int64_t) ax * ex.aligned + b];
     }
     out_cnt[at] = ex.srccum[b];
-    (void) nsel;
 }
 
 // own deep boxes' extras into the LET ([2][D][B] boxes, [B] counts)
@@ -1765,13 +1764,13 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
                                      (const double *) tree->box_target_bounding_box_max,
                                      tree->box_source_counts_cumul, tree->aligned_nboxes, D};
                 let_pack_extras_kernel<double><<<(unsigned) div_up(n_mine, 256), 256, 0, stream>>>(
-                    n_mine, pr, pp, ex, s_cnt[q], (double *) blk0, (int32_t *) (blk0 + s_cnt[q] * 2 * D * es));
+                    n_mine, pr, pp, ex, (double *) blk0, (int32_t *) (blk0 + s_cnt[q] * 2 * D * es));
             } else {
                 LetExtras<float> ex{(const float *) tree->box_target_bounding_box_min,
                                     (const float *) tree->box_target_bounding_box_max,
                                     tree->box_source_counts_cumul, tree->aligned_nboxes, D};
                 let_pack_extras_kernel<float><<<(unsigned) div_up(n_mine, 256), 256, 0, stream>>>(
-                    n_mine, pr, pp, ex, s_cnt[q], (float *) blk0, (int32_t *) (blk0 + s_cnt[q] * 2 * D * es));
+                    n_mine, pr, pp, ex, (float *) blk0, (int32_t *) (blk0 + s_cnt[q] * 2 * D * es));
             }
         }
         BT_HIP_CHECK(hipGetLastError());
