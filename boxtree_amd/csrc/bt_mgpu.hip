@@ -1749,7 +1749,9 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
     // the extras of the same boxes in the same order: per peer [count][2 D] coordinates, then
     // [count] source counts
     Buf<unsigned char> send_ex, halo_ex;
-    const int64_t exrec = ext ? (int64_t) (2 * D * es + 4) : 0;
+    // (a multiple of the coordinate width, so that every peer's block starts aligned: the counts
+    // are int32 at the head of a region of one coordinate width per box)
+    const int64_t exrec = ext ? (int64_t) (2 * D * es + es) : 0;
     if (ext) {
         BT_CHECK(send_ex.alloc(ctx->pool, std::max<int64_t>(nsend, 1) * exrec));
         BT_CHECK(halo_ex.alloc(ctx->pool, std::max<int64_t>(nrecv, 1) * exrec));
