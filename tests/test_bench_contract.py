@@ -58,6 +58,19 @@ def test_bench_forced_distributed_path_matches_single():
     assert b["config"]["global_nboxes"] == a["config"]["nboxes"]
 
 
+@pytest.mark.gpu
+def test_bench_forced_distributed_path_with_target_extents():
+    """BASELINE configs[3] (targets with radii) through the N > 1 code path on one rank: the
+    library's multi-GPU entries carry the radii, and the tree and lists are the single-GPU ones."""
+    a = run_bench("--workload", "c4", "--n", "2000000", "--steps", "1", "--cpu-sample", "0")
+    b = run_bench("--workload", "c4", "--n", "2000000", "--steps", "1", "--cpu-sample", "0",
+                  "--force-dist")
+    for key in ("nboxes", "nlevels", "list1_entries", "list2_entries"):
+        assert a["config"][key] == b["config"][key], key
+    assert b["config"]["global_nboxes"] == a["config"]["nboxes"]
+    assert "bt_mgpu" in b["config"]["sharded_traversal"]
+
+
 def _free_port():
     import socket
     s = socket.socket()
