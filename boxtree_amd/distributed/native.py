@@ -437,11 +437,18 @@ def build_local_essential_tree(actx, comm, tree, numbering, well_sep_is_n_away=1
     return let, info
 
 
-def sharded_tree_and_lists(actx, comm, particles, max_particles_in_box, targets=None,
-                           well_sep_is_n_away=1, tree_builder=None, traversal_builder=None):
+def sharded_tree_and_lists(actx, comm, particles, max_particles_in_box=None, targets=None,
+                           well_sep_is_n_away=1, tree_builder=None, traversal_builder=None,
+                           target_radii=None, stick_out_factor=None, extent_norm="linf",
+                           refine_weights=None, target_refine_weights=None,
+                           max_leaf_refine_weight=None):
     """Steps 1-6 in one call (collective over *comm*, a :class:`NativeComm`): exchange the
     particles, build the subtrees this rank owns, number them globally, assemble the local
-    essential tree and build the interaction lists of the rank's own boxes.
+    essential tree and build the interaction lists of the rank's own boxes.  The keyword
+    arguments are ``TreeBuilder.__call__``'s (tree_build.py:145-260), per rank: separate
+    *targets*, *target_radii* with *stick_out_factor* / *extent_norm*, *refine_weights* (sources;
+    *target_refine_weights* for separate targets) with *max_leaf_refine_weight* instead of
+    *max_particles_in_box*.
 
     Returns a dict: ``tree`` (the rank's :class:`~boxtree_amd.tree.Tree`, local box
     numbers), ``numbering`` (:func:`number_sharded_tree`: ``box_ids`` maps them to the
@@ -452,12 +459,20 @@ def sharded_tree_and_lists(actx, comm, particles, max_particles_in_box, targets=
     from boxtree_amd import FMMTraversalBuilder, TreeBuilder
     tb = tree_builder or TreeBuilder(actx)
     tg = traversal_builder or FMMTraversalBuilder(actx, well_sep_is_n_away=well_sep_is_n_away)
+    xkw = dict(refine_weights=refine_weights, target_refine_weights=target_refine_weights,
+               max_leaf_refine_weight=max_leaf_refine_weight)
+    bkw = {} if max_leaf_refine_weight is not None else dict(max_particles_in_box=max_particles_in_box)
     if targets is None:
-        p2, kw, xs = exchange_particles(actx, comm, particles, max_particles_in_box)
-        tree, _ = tb(actx, p2, max_particles_in_box=max_particles_in_box, **kw)
+        p2, kw, xs = exchange_particles(actx, comm, particles, max_particles_in_box, **xkw)
+        tree, _ = tb(actx, p2, **bkw, **kw)
+    elif target_radii is None:
+        p2, t2, kw, xs = exchange_particles(actx, comm, particles, max_particles_in_box, targets=targets, **xkw)
+        tree, _ = tb(actx, p2, targets=t2, **bkw, **kw)
     else:
-        p2, t2, kw, xs = exchange_particles(actx, comm, particles, max_particles_in_box, targets=targets)
-        tree, _ = tb(actx, p2, targets=t2, max_particles_in_box=max_particles_in_box, **kw)
+        p2, t2, r2, kw, xs = exchange_particles(
+            actx, comm, particles, max_particles_in_box, targets=targets, target_radii=target_radii,
+            stick_out_factor=stick_out_factor, extent_norm=extent_norm, **xkw)
+        tree, _ = tb(actx, p2, targets=t2, target_radii=r2, **bkw, **kw)
     num = number_sharded_tree(actx, comm, tree)
     let, info = build_local_essential_tree(actx, comm, tree, num, well_sep_is_n_away=well_sep_is_n_away)
     trav, _ = tg(actx, let, _target_boxes_mask=info["target_boxes_mask"],

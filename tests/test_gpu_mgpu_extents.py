@@ -239,3 +239,39 @@ def test_sharded_tree_with_refine_weights(dims, world, dist_kind, mode):
                 assert np.array_equal(g.targets[ax][to:to + h.ntargets], h.targets[ax])
     assert np.all(hits >= 1) and np.all(hits[g.box_levels > top_level] == 1)
     assert np.array_equal(scum, g.box_source_counts_cumul)
+
+
+def test_one_call_entry_with_extents_and_weights():
+    """boxtree_amd.distributed.native.sharded_tree_and_lists with TreeBuilder's keyword arguments:
+    targets with radii, and refine weights on both sets, three thread ranks."""
+    import torch
+    from boxtree_amd import HIPArrayContext, TreeBuilder
+    from boxtree_amd.distributed import native as nat
+    world, dims, n_src, n_tgt, max_w, sof = 3, 3, 20000, 4000, 30, 0.25
+    src, tgt, rad = make_chunks(world, dims, n_src, n_tgt, 1500, "uniform", 0.05)
+    wsrc = [np.random.default_rng(7 + r).integers(1, 4, n_src).astype(np.int32) for r in range(world)]
+    wtgt = [np.random.default_rng(17 + r).integers(1, 3, n_tgt).astype(np.int32) for r in range(world)]
+    group = nat.LocalGroup(world)
+
+    def rank_fn(rank):
+        actx = HIPArrayContext(0)
+        comm = group.comm(rank)
+        dev = lambda a: torch.from_numpy(a).cuda()      # noqa: E731
+        out = nat.sharded_tree_and_lists(
+            actx, comm, [dev(a) for a in src[rank]], targets=[dev(a) for a in tgt[rank]],
+            target_radii=dev(rad[rank]), stick_out_factor=sof, refine_weights=dev(wsrc[rank]),
+            target_refine_weights=dev(wtgt[rank]), max_leaf_refine_weight=max_w)
+        comm.close()
+        return dict(nboxes=int(out["numbering"]["nboxes"]), nlevels=int(out["numbering"]["nlevels"]),
+                    nl1=int(out["traversal"].neighbor_source_boxes_lists.shape[0]))
+
+    results = run_ranks(world, rank_fn)
+    group.close()
+    actx = HIPArrayContext(0)
+    cat = lambda chunks, ax: torch.from_numpy(np.concatenate([c[ax] for c in chunks])).cuda()  # noqa: E731
+    g, _ = TreeBuilder(actx)(
+        actx, [cat(src, ax) for ax in range(dims)], targets=[cat(tgt, ax) for ax in range(dims)],
+        target_radii=torch.from_numpy(np.concatenate(rad)).cuda(), stick_out_factor=sof,
+        refine_weights=torch.from_numpy(np.concatenate(wsrc + wtgt)).cuda(), max_leaf_refine_weight=max_w)
+    for r in results:
+        assert r["nboxes"] == int(g.nboxes) and r["nlevels"] == int(g.nlevels) and r["nl1"] > 0
