@@ -51,6 +51,7 @@ struct TravArgs {
     const int32_t *srccoll_rows, *srccoll_cnt;
     int srccoll_stride;
     uint32_t srccoll_id_mask;       // row entries carry lattice codes above these bits
+    uint32_t srccoll_src_bit;       // the rows hold all colleagues, source boxes carry this bit (or 0)
     const int8_t *target_mask;      // sharded traversals: boxes whose lists are wanted
     const int32_t *dfs_rank;        // preorder rank (parent-colleague kernels)
 };
@@ -340,9 +341,14 @@ __device__ __forceinline__ void gen_list4(const TravArgs<T, D> &a, int32_t it, E
     for (; wl != 0; --wl, cur = a.parent[cur]) {
         const bool rows = a.srccoll_stride != 0;
         const int64_t s0 = rows ? (int64_t) cur * a.srccoll_stride : a.coll_starts[cur];
-        const int64_t s1 = rows ? s0 + a.srccoll_cnt[cur] : a.coll_starts[cur + 1];
+        // (one row family: srccoll_cnt holds the mask of the row's source entries)
+        const bool masked = rows && a.srccoll_src_bit;
+        uint32_t smask = masked ? (uint32_t) a.srccoll_cnt[cur] : 0u;
+        const int64_t s1 = masked ? s0 + __popc(smask) : rows ? s0 + a.srccoll_cnt[cur] : a.coll_starts[cur + 1];
         const int32_t *src = rows ? a.srccoll_rows : a.coll_lists;
-        for (int64_t i = s0; i < s1; ++i) {
+        for (int64_t ii = s0; ii < s1; ++ii) {
+            const int64_t i = masked ? s0 + __builtin_ctz(smask) : ii;
+            smask &= smask - 1u;
             const int32_t sb = rows ? (int32_t) ((uint32_t) src[i] & a.srccoll_id_mask) : src[i];
             if (!rows && !(box_flags(a, sb) & BT_BOX_IS_SOURCE_BOX)) continue;
             T sc[D];
@@ -1153,6 +1159,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         a.srccoll_cnt = srccoll_cnt.get();
         a.srccoll_stride = COLL_STRIDE;
         a.srccoll_id_mask = ~0u;
+        a.srccoll_src_bit = 0;
     } else {
         BT_CHECK(lcoll_starts_buf.alloc(ctx->pool, B + 1));
         filter_source_colleagues_kernel<T, D, false><<<nblk(B), 256, 0, ctx->stream>>>(
@@ -1438,10 +1445,21 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
                 st->subtree_size.get());
         sizes = st->subtree_size.get();
     }
-    Buf<int32_t> coll_rows, coll_cnt, coll_ins, l2_cnt;
+    // One family of colleague rows with the source flag in the entry, and a mask per box of the
+    // entries that carry it, where box numbers leave a bit for the flag (3D: every BASELINE
+    // configuration; BT_ROW_FAMILIES=2 forces the other form), else all colleagues in one
+    // family and the source boxes among them in a second one.
+    // (read per call: a test builds the same lists in both forms)
+    const bool two_env = [] { const char *e = getenv("BT_ROW_FAMILIES"); return e && atoi(e) == 2; }();
+    const bool one_family = D == 3 && B < V2_ONE_FAMILY_MAX_BOXES && !two_env;
+    const uint32_t row_id_mask = one_family ? (V2_SRC_BIT - 1u) : V2_ID_MASK;
+    const uint32_t row_src_bit = one_family ? V2_SRC_BIT : 0u;
+    Buf<int32_t> coll_rows_two, coll_cnt, coll_ins, l2_cnt;
     Buf<int32_t> &srccoll_rows = st->srccoll_rows, &srccoll_cnt = st->srccoll_cnt;
-    BT_CHECK(coll_rows.alloc(ctx->pool, B * P));
+    if (!one_family) BT_CHECK(coll_rows_two.alloc(ctx->pool, B * P));
     BT_CHECK(srccoll_rows.alloc(ctx->pool, B * P));
+    // (one family: it lives where the source rows of two families do -- list 4 reads it last)
+    Buf<int32_t> &coll_rows = one_family ? srccoll_rows : coll_rows_two;
     // coll_cnt | coll_ins | l2_cnt | srccoll_cnt are one array, zeroed together (the last
     // quarter outlives this function: list 4 reads it)
     BT_CHECK(srccoll_cnt.alloc(ctx->pool, 4 * B));
@@ -1454,8 +1472,14 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     rows.flags = p.box_flags;
     rows.target_mask = p.target_boxes_mask;
     rows.coll_rows = coll_rows.get(); rows.coll_cnt = d_coll_cnt; rows.coll_ins = d_coll_ins;
-    rows.srccoll_rows = srccoll_rows.get(); rows.srccoll_cnt = srccoll_cnt.get();
+    rows.srccoll_rows = one_family ? nullptr : srccoll_rows.get();
+    rows.srccoll_cnt = srccoll_cnt.get();
+    rows.id_mask = row_id_mask;
     rows.l2_cnt = d_l2_cnt;
+    // what list 4 and the coarse part of list 1 read: the source colleagues of a box
+    const int32_t *src_rows = coll_rows.get();
+    const int32_t *src_cnt = srccoll_cnt.get();
+    if (!one_family) src_rows = srccoll_rows.get();
     // Level lev: its boxes hand depth-first ranks and cells to their children, and the rows
     // of level lev + 1 are built from those of level lev -- one launch for both
     // (level_tables_kernel).  The last level has no children: nothing to do there.
@@ -1475,8 +1499,11 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             // a group of lanes per box of this level that has children
             np = pls[lev + 1] - pls[lev];
         }
-        if (nb > 0 && np > 0)
-            level_tables_kernel<D><<<dfs_blocks + nblk((int64_t) np * V3Lanes<D>::N), 256, 0, ctx->stream>>>(
+        if (nb > 0 && np > 0 && one_family)
+            level_tables_kernel<D, true><<<dfs_blocks + nblk((int64_t) np * V3Lanes<D>::N), 256, 0, ctx->stream>>>(
+                dl, dfs_blocks, rows, st->parent_boxes.get() + pls[lev], np, b0, b0 + nb);
+        else if (nb > 0 && np > 0)
+            level_tables_kernel<D, false><<<dfs_blocks + nblk((int64_t) np * V3Lanes<D>::N), 256, 0, ctx->stream>>>(
                 dl, dfs_blocks, rows, st->parent_boxes.get() + pls[lev], np, b0, b0 + nb);
         else
             dfs_rank_cells_kernel<D><<<dfs_blocks, 256, 0, ctx->stream>>>(dl);
@@ -1494,10 +1521,11 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     a.dfs_rank = st->dfs_rank.get();
     FastTree ft{st->dfs_rank.get(), st->box_of_rank.get(), sizes,
                 st->src_rank_prefix.get(), st->src_by_rank.get()};
-    a.srccoll_rows = srccoll_rows.get();       // list 4 walks the same rows
-    a.srccoll_cnt = srccoll_cnt.get();
+    a.srccoll_rows = src_rows;                 // list 4 walks the same rows
+    a.srccoll_cnt = src_cnt;
     a.srccoll_stride = P;
-    a.srccoll_id_mask = V2_ID_MASK;
+    a.srccoll_id_mask = row_id_mask;
+    a.srccoll_src_bit = row_src_bit;
     BT_CHECK(tmark(ctx, st, "trav:colleague rows"));
 
     // ---- work items -----------------------------------------------------------------------
@@ -1600,7 +1628,8 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     w.flags = p.box_flags;
     w.child8 = st->child8.get();
     w.coll_rows = coll_rows.get(); w.coll_cnt = d_coll_cnt;
-    w.srccoll_rows = srccoll_rows.get(); w.srccoll_cnt = srccoll_cnt.get();
+    w.srccoll_rows = src_rows; w.srccoll_cnt = src_cnt;
+    w.id_mask = row_id_mask; w.src_bit = row_src_bit;
     w.item_tbn = item_tbn.get(); w.item_slot = item_slot.get();
     w.d_nitems = d_nitems;
     w.items_cap = (int32_t) items_cap;
@@ -1686,8 +1715,8 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     const bool l4_lattice = !st->with_extent && a.nway == 1 && !l4_float;
     if (l4_lattice)
         list4_lattice_kernel<D, false><<<nblk(c4.n), 256, 0, ctx->stream>>>(
-            (int32_t) c4.n, st->ttp_boxes.get(), cells, p.box_parent_ids, srccoll_rows.get(),
-            srccoll_cnt.get(), P, l4_cnt.get(), nullptr);
+            (int32_t) c4.n, st->ttp_boxes.get(), cells, p.box_parent_ids, src_rows,
+            src_cnt, P, row_id_mask, row_src_bit, l4_cnt.get(), nullptr);
     else
         list4_kernel<T, D, false><<<nblk(c4.n), 256, 0, ctx->stream>>>(
             a, (int32_t) c4.n, l4_cnt.get(), nullptr, st->with_extent ? raw4_cnt.get() : nullptr, nullptr);
@@ -1759,7 +1788,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     }
     BT_CHECK(place_list(ctx, st, coll.lists, coll.total, pk ? &pk->same_level_non_well_sep_boxes_lists : nullptr));
     compact_coll_rows_v2_kernel<8><<<nblk(B * 8), 256, 0, ctx->stream>>>(
-        B, P, coll_rows.get(), coll.starts.get(), coll.lists.get());
+        B, P, row_id_mask, coll_rows.get(), coll.starts.get(), coll.lists.get());
     a.coll_starts = coll.starts.get();
     a.coll_lists = coll.lists.get();
     {
@@ -1841,8 +1870,8 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     if (st->with_extent) BT_CHECK(raw4.lists.alloc(ctx->pool, raw4.total));
     if (l4_lattice)
         list4_lattice_kernel<D, true><<<nblk(c4.n), 256, 0, ctx->stream>>>(
-            (int32_t) c4.n, st->ttp_boxes.get(), cells, p.box_parent_ids, srccoll_rows.get(),
-            srccoll_cnt.get(), P, c4.starts.get(), c4.lists.get());
+            (int32_t) c4.n, st->ttp_boxes.get(), cells, p.box_parent_ids, src_rows,
+            src_cnt, P, row_id_mask, row_src_bit, c4.starts.get(), c4.lists.get());
     else
         list4_kernel<T, D, true><<<nblk(c4.n), 256, 0, ctx->stream>>>(
             a, (int32_t) c4.n, c4.starts.get(), c4.lists.get(),

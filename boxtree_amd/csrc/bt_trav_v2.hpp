@@ -19,7 +19,11 @@
 //
 // Layout of the lattice information:
 //  * colleague rows [nboxes][3^d - 1] hold "box | code << 26", code = 2 bits per
-//    axis: (offset of the colleague's cell from the box's cell) + 1;
+//    axis: (offset of the colleague's cell from the box's cell) + 1.  Lists 1 and 4 want the
+//    colleagues of a box's ancestors that are source boxes -- few of them: most colleagues
+//    of a box above the leaves have children.  3D trees of fewer than 2^25 boxes mark them
+//    with bit 25 of the entry (V2_SRC_BIT) and keep one 32-bit mask per box of the row's
+//    entries that carry it; other trees keep a second family of rows with the source boxes;
 //  * child_t[box][2^d] holds "child | flags": bit 28 = the child is a source box,
 //    bit 29 = it has source child boxes (tree walks read nothing else per step);
 //  * ICell{c[3], lf}: integer cell coordinates at the box's own level.
@@ -29,6 +33,8 @@
 constexpr int V2_CODE_SHIFT = 26;
 constexpr uint32_t V2_ID_MASK = (1u << V2_CODE_SHIFT) - 1u;
 constexpr uint32_t V2_CODE_SELF = 0x15u;            // offsets (0,0,0): 01 01 01
+constexpr uint32_t V2_SRC_BIT = 1u << (V2_CODE_SHIFT - 1);    // one row family: the entry is a source box
+constexpr int64_t V2_ONE_FAMILY_MAX_BOXES = (int64_t) 1 << (V2_CODE_SHIFT - 1);
 
 struct alignas(16) ICell {
     uint32_t c[3];
@@ -157,7 +163,9 @@ struct V2Rows {
     const uint8_t *flags;
     const int8_t *target_mask;
     int32_t *coll_rows, *coll_cnt, *coll_ins;
-    int32_t *srccoll_rows, *srccoll_cnt;
+    int32_t *srccoll_rows, *srccoll_cnt;   // second family (one family: no rows, and
+                                           // srccoll_cnt holds the masks of the source entries)
+    uint32_t id_mask;              // the box number of a row entry
     int32_t *l2_cnt;               // [nboxes]
     const int32_t *l2_starts;      // fill pass: [nboxes + 1]
     int32_t *l2_lists;
@@ -236,7 +244,7 @@ __device__ __forceinline__ constexpr uint32_t v3_set_mask(int ax)
 
 // parents[0 .. np): boxes that have children; rows / lists are made for their children in
 // [b_lo, b_hi)
-template <int D, bool FILL>
+template <int D, bool FILL, bool ONE /* one row family: V2_SRC_BIT in the entries */>
 __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int32_t *parents, int32_t np,
         int32_t b_lo, int32_t b_hi, int32_t blk)
 {
@@ -285,7 +293,7 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
     uint32_t e = 0;
     if (valid)
         e = self ? ((uint32_t) p | (V2_CODE_SELF << V2_CODE_SHIFT)) : (j < ins ? e_at : e_before);
-    const uint32_t q = e & V2_ID_MASK;
+    const uint32_t q = e & t.id_mask;
 
     // the candidate's children (the parent's own for the parent itself)
     Kids ck{0u, 0u};
@@ -312,7 +320,10 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
     // (numbers of absent children are never used: every use is under `present`)
     uint32_t chid[C], plain[C];
 #pragma unroll
-    for (int m = 0; m < C; ++m) { plain[m] = (uint32_t) ck.id(m); chid[m] = plain[m] + off; }
+    for (int m = 0; m < C; ++m) {
+        plain[m] = (uint32_t) ck.id(m);
+        chid[m] = plain[m] + off + (ONE ? ((source >> m) & 1u) * V2_SRC_BIT : 0u);
+    }
 
 #pragma unroll
     for (int sb = 0; sb < C; ++sb) {
@@ -327,7 +338,7 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
         uint32_t cm = present & adjacent;                       // traversal.py:429-442
         if (self) cm &= ~(1u << sb);                            // the box itself
         const uint32_t lm = ttp ? (present & ~adjacent & FULL) : 0u;   // traversal.py:588-597
-        const uint32_t sm = cm & source;
+        const uint32_t sm = ONE ? 0u : (cm & source);
 
         // positions: an inclusive scan of (colleagues | source colleagues << 10 | list 2 << 20)
         const uint32_t packed = FILL ? (uint32_t) __popc(lm)
@@ -342,7 +353,7 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
         // masks, scan, addresses --, and stores are not part of it.
         if (!FILL) {
             int32_t *crow = t.coll_rows + (int64_t) b * P;
-            int32_t *srow = t.srccoll_rows + (int64_t) b * P;
+            int32_t *srow = ONE ? nullptr : t.srccoll_rows + (int64_t) b * P;
             int pc = (int) (excl & 0x3ffu), ps = (int) ((excl >> 10) & 0x3ffu);
             if (self) t.coll_ins[b] = pc + __popc(cm & ((1u << sb) - 1u));
             if constexpr (LANES == 32) {
@@ -358,7 +369,7 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
                     if ((cm >> m) & 1u) {
                         const int32_t entry = (int32_t) (chid[m] + v3_code_delta<D>(m, sb));
                         lc[pc++] = entry;
-                        if ((sm >> m) & 1u) ls[ps++] = entry;
+                        if (!ONE && ((sm >> m) & 1u)) ls[ps++] = entry;
                     }
                 }
                 if (j == LANES - 1) lc[31] = (int32_t) incl;       // (P = 27: slot 31 is free)
@@ -366,9 +377,15 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
                 __builtin_amdgcn_wave_barrier();
                 const uint32_t tot = (uint32_t) lc[31];
                 const int nc = (int) (tot & 0x3ffu), ns = (int) ((tot >> 10) & 0x3ffu);
-                const int32_t vc = lc[j], vs = ls[j];
+                const int32_t vc = lc[j], vs = ONE ? 0 : ls[j];
                 if (j < nc) crow[j] = vc;
-                if (j < ns) srow[j] = vs;
+                if (!ONE && j < ns) srow[j] = vs;
+                if (ONE) {
+                    // which entries of the row are source boxes: the group's half of a ballot
+                    const uint64_t bal = __ballot(j < nc && ((uint32_t) vc & V2_SRC_BIT));
+                    if (j == LANES - 1)
+                        t.srccoll_cnt[b] = (int32_t) (uint32_t) (bal >> (32 * ((threadIdx.x >> 5) & 1)));
+                }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
             } else {
@@ -377,13 +394,13 @@ __device__ __forceinline__ void coll_rows_v3_block(const V2Rows<D> &t, const int
                     if ((cm >> m) & 1u) {
                         const int32_t entry = (int32_t) (chid[m] + v3_code_delta<D>(m, sb));
                         crow[pc++] = entry;
-                        if ((sm >> m) & 1u) srow[ps++] = entry;
+                        if (!ONE && ((sm >> m) & 1u)) srow[ps++] = entry;
                     }
                 }
             }
             if (j == LANES - 1) {               // the last lane's inclusive sums are the totals
                 t.coll_cnt[b] = (int32_t) (incl & 0x3ffu);
-                t.srccoll_cnt[b] = (int32_t) ((incl >> 10) & 0x3ffu);
+                if (!ONE) t.srccoll_cnt[b] = (int32_t) ((incl >> 10) & 0x3ffu);
                 t.l2_cnt[b] = (int32_t) (incl >> 20);
             }
         } else if (LANES == 32 && t.l2_stage) {
@@ -435,18 +452,19 @@ template <int D, bool FILL>
 __global__ __launch_bounds__(256) void coll_rows_v3_kernel(V2Rows<D> t, const int32_t *parents, int32_t np,
         int32_t b_lo, int32_t b_hi)
 {
-    coll_rows_v3_block<D, FILL>(t, parents, np, b_lo, b_hi, (int32_t) blockIdx.x);
+    static_assert(FILL, "the rows are built by level_tables_kernel");
+    coll_rows_v3_block<D, FILL, false>(t, parents, np, b_lo, b_hi, (int32_t) blockIdx.x);
 }
 
 // One launch per level for the two top-down tables: the first dfs_blocks workgroups give the
 // children of level `lev` their depth-first ranks and cells, the others build the colleague
 // rows of level `lev + 1` from those of level `lev`.  Neither reads what the other writes.
-template <int D>
+template <int D, bool ONE>
 __global__ __launch_bounds__(256) void level_tables_kernel(DfsLevel d, int32_t dfs_blocks, V2Rows<D> t,
         const int32_t *parents, int32_t np, int32_t b_lo, int32_t b_hi)
 {
     if ((int32_t) blockIdx.x < dfs_blocks) dfs_rank_cells_block<D>(d, (int32_t) blockIdx.x);
-    else coll_rows_v3_block<D, false>(t, parents, np, b_lo, b_hi, (int32_t) blockIdx.x - dfs_blocks);
+    else coll_rows_v3_block<D, false, ONE>(t, parents, np, b_lo, b_hi, (int32_t) blockIdx.x - dfs_blocks);
 }
 
 // List 4 without extents (traversal.py:931-1146, no close lists), thread per target (or
@@ -459,7 +477,9 @@ __global__ __launch_bounds__(256) void level_tables_kernel(DfsLevel d, int32_t d
 template <int D, bool FILL>
 __global__ __launch_bounds__(256) void list4_lattice_kernel(int32_t n, const int32_t *ttp_boxes,
         const ICell *cells, const int32_t *parent, const int32_t *srccoll_rows,
-        const int32_t *srccoll_cnt, int stride, int32_t *counts_or_starts, int32_t *lists)
+        const int32_t *srccoll_cnt, int stride, uint32_t id_mask,
+        uint32_t src_bit /* one row family: entries without it are skipped; else 0 */,
+        int32_t *counts_or_starts, int32_t *lists)
 {
     const int32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -479,8 +499,12 @@ __global__ __launch_bounds__(256) void list4_lattice_kernel(int32_t n, const int
             lp[ax] = (int64_t) ((tc.c[ax] >> 1) & ((1u << (k - 1)) - 1u));
         }
         const int32_t *row = srccoll_rows + (int64_t) cur * stride;
-        const int nrow = srccoll_cnt[cur];
-        for (int j = 0; j < nrow; ++j) {
+        // (one family: srccoll_cnt is the mask of the row's source entries)
+        uint32_t smask = src_bit ? (uint32_t) srccoll_cnt[cur] : 0u;
+        const int nrow = src_bit ? __popc(smask) : srccoll_cnt[cur];
+        for (int jj = 0; jj < nrow; ++jj) {
+            const int j = src_bit ? __builtin_ctz(smask) : jj;
+            smask &= smask - 1u;
             const uint32_t e = (uint32_t) row[j];
             bool adj_box = true, adj_parent = true;
 #pragma unroll
@@ -495,7 +519,7 @@ __global__ __launch_bounds__(256) void list4_lattice_kernel(int32_t n, const int
                 if (FILL) {
                     // entries leave four at a time (one 16-byte store per lane instead of four
                     // lane-strided 4-byte ones)
-                    const int32_t id = (int32_t) (e & V2_ID_MASK);
+                    const int32_t id = (int32_t) (e & id_mask);
                     const int q = cnt & 3;
                     if (q == 0) buf.x = id; else if (q == 1) buf.y = id; else if (q == 2) buf.z = id;
                     else { buf.w = id; *reinterpret_cast<PackedI4 *>(out + cnt - 3) = buf; }
@@ -516,7 +540,7 @@ __global__ __launch_bounds__(256) void list4_lattice_kernel(int32_t n, const int
 // colleague CSR from the rows (codes stripped); LANES lanes per row
 template <int LANES>
 __global__ __launch_bounds__(256) void compact_coll_rows_v2_kernel(int64_t nrows, int stride,
-        const int32_t *rows, const int32_t *starts, int32_t *lists)
+        uint32_t id_mask, const int32_t *rows, const int32_t *starts, int32_t *lists)
 {
     const int64_t gid = (int64_t) blockIdx.x * 256 + threadIdx.x;
     const int64_t r = gid / LANES;
@@ -525,7 +549,7 @@ __global__ __launch_bounds__(256) void compact_coll_rows_v2_kernel(int64_t nrows
     const int32_t s = starts[r], e = starts[r + 1];
     const int32_t *row = rows + r * stride;
     for (int32_t k = lane; k < e - s; k += LANES)
-        lists[(int64_t) s + k] = (int32_t) ((uint32_t) row[k] & V2_ID_MASK);
+        lists[(int64_t) s + k] = (int32_t) ((uint32_t) row[k] & id_mask);
 }
 
 // ---- work items (see make_items_kernel) -------------------------------------------------
@@ -576,6 +600,7 @@ struct V2Walk {
     const uint8_t *flags;
     const uint64_t *child8;            // Kids
     const int32_t *coll_rows, *coll_cnt, *srccoll_rows, *srccoll_cnt;
+    uint32_t id_mask, src_bit;         // of the row entries (src_bit: one row family, else 0)
     const int32_t *item_tbn, *item_slot;
     const int32_t *d_nitems;           // actual item count (device)
     int32_t items_cap;                 // columns of the item arrays (>= the item count)
@@ -764,8 +789,11 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                 if (w.flags[anc] & BT_BOX_IS_SOURCE_BOX) emit1(anc);
                 const uint32_t mask = (1u << (tl - k)) - 1u;
                 const int32_t *srow = w.srccoll_rows + (int64_t) anc * P;
-                const int ns = w.srccoll_cnt[anc];
-                for (int i = 0; i < ns; ++i) {
+                uint32_t smask = w.src_bit ? (uint32_t) w.srccoll_cnt[anc] : 0u;
+                const int ns = w.src_bit ? __popc(smask) : w.srccoll_cnt[anc];
+                for (int ii = 0; ii < ns; ++ii) {
+                    const int i = w.src_bit ? __builtin_ctz(smask) : ii;
+                    smask &= smask - 1u;
                     const uint32_t e = (uint32_t) srow[i];
                     bool adjacent = true;
 #pragma unroll
@@ -774,7 +802,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
                         const uint32_t r = cell.c[ax] & mask;
                         adjacent = adjacent && (o == 0 || (o < 0 ? r == 0u : r == mask));
                     }
-                    if (adjacent) emit1(e & V2_ID_MASK);
+                    if (adjacent) emit1(e & w.id_mask);
                 }
             }
         }
@@ -824,7 +852,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
     int32_t *stk = s_walk_lds + threadIdx.x;
     for (int ci = c0; ci < c1; ++ci) {
         const uint32_t ce = (uint32_t) crow[ci];
-        const int32_t nws = (int32_t) (ce & V2_ID_MASK);
+        const int32_t nws = (int32_t) (ce & w.id_mask);
         const uint8_t cfl = w.flags[nws];
         // a colleague is adjacent (well_sep_is_n_away == 1)
         if (cfl & BT_BOX_IS_SOURCE_BOX) emit1(nws);

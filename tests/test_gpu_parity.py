@@ -160,6 +160,31 @@ def test_walk_rows_overflow(actx, k1, k3, spill, dims, n, mpb, monkeypatch):
                stick_out_factor=0.25, trav_kw={})
 
 
+@pytest.mark.parametrize("families", [1, 2])
+@pytest.mark.parametrize("case", ["points", "separate_targets", "extents"])
+def test_colleague_row_families(actx, families, case, monkeypatch):
+    """3D trees of fewer than 2^25 boxes keep one family of colleague rows (the source flag in
+    the entry, a mask per box of the entries that carry it), other trees a second family with the
+    source colleagues; Lists 1 and 4 read either.  Same lists in both forms, where source boxes
+    are few among the colleagues (separate targets, extents) and where they are all of them."""
+    from oracle import oracle
+    monkeypatch.setenv("BT_ROW_FAMILIES", str(families))
+    rng = np.random.default_rng(77)
+    n = 60000
+    pts = [np.concatenate([rng.random(n // 2), 0.6 + 0.03 * rng.standard_normal(n - n // 2)])
+           for _ in range(3)]
+    if case == "points":
+        build_both(actx, oracle, pts, max_particles_in_box=24, trav_kw={})
+    elif case == "separate_targets":
+        tg = [0.5 + 0.2 * rng.standard_normal(n // 3) for _ in range(3)]
+        build_both(actx, oracle, pts, targets=tg, max_particles_in_box=24, trav_kw={})
+    else:
+        tg = [rng.random(n // 4) for _ in range(3)]
+        radii = 2.0 ** rng.uniform(-10, 0, n // 4) * 0.04
+        build_both(actx, oracle, pts, targets=tg, max_particles_in_box=24, target_radii=radii,
+                   stick_out_factor=0.25, trav_kw={})
+
+
 @pytest.mark.parametrize("kind", ["uniform", "surface", "blob"])
 def test_depth_probe_large_build(actx, kind):
     """Builds of 2^20 particles and more look at a sample of the particles before they choose
