@@ -68,6 +68,14 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T *s_tmp, T *total)
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
+// Scans of more than this many 4096-element tiles use 16384-element tiles (1024 threads): the
+// look-back chain crosses XCDs, a tile of either size costs it about the same, so larger tiles
+// pay as soon as they still fill the CUs (LAB_NOTES.md section 8; BT_SCAN_BIG_TILES: tuning aid)
+inline int64_t scan_big_threshold()
+{
+    static const int64_t v = [] { const char *e = getenv("BT_SCAN_BIG_TILES"); return e ? (int64_t) atoll(e) : (int64_t) 256; }();
+    return v;
+}
 
 template <class AccT, class F>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(F f, int64_t n, AccT *tile_sums)
@@ -344,7 +352,7 @@ int device_exclusive_scan(bt_context *ctx, F f, int64_t n, OutT *out, AccT *d_to
     const int64_t ntiles = div_up(n, SCAN_TILE);
     if constexpr (std::is_integral<AccT>::value && sizeof(OutT) == 4) {
         uint32_t gen = 0, base = 0;
-        if (ntiles > 2048) {
+        if (ntiles > scan_big_threshold()) {
             const int64_t nbig = div_up(n, (int64_t) 1024 * SCAN_ITEMS);
             BT_CHECK(scan_prepare(ctx, nbig, &gen, &base));
             scan_single_pass_kernel<AccT, OutT, F, 1024><<<(unsigned) nbig, 1024, 0, ctx->stream>>>(
@@ -394,7 +402,7 @@ int device_exclusive_scan_batch(bt_context *ctx, int count, const F *f, const in
         const int c = b.count++;
         b.f[c] = f[k]; b.n[c] = n[k]; b.out[c] = out[k];
         b.total[c] = d_total ? d_total[k] : nullptr;
-        big = big || div_up(n[k], SCAN_TILE) > 2048;
+        big = big || div_up(n[k], SCAN_TILE) > scan_big_threshold();
     }
     if (b.count == 0) return BT_OK;
     const int64_t tile = big ? (int64_t) 1024 * SCAN_ITEMS : SCAN_TILE;
