@@ -354,3 +354,70 @@ def test_failing_rank_does_not_hang_its_peers():
     group.close()
     assert "no top-tree plan" in outcome[0]
     assert "peer rank" in outcome[1]
+
+
+@pytest.mark.parametrize("case", ["empty_chunk", "own_nothing", "empty_sources_with_targets"])
+def test_ranks_with_nothing_to_give_or_to_own(case):
+    """A rank whose chunk is empty still takes part in every collective, and so does a rank
+    that ends up owning no particle (more ranks than occupied top cells: its tree is the root
+    box alone): all ranks arrive at the global tree's box count, no particle is lost."""
+    import threading
+
+    import torch
+    from boxtree_amd import HIPArrayContext, TreeBuilder
+    from boxtree_amd.distributed import native as nat
+    n, mpb = 20000, 20
+    full = lambda r: [np.random.default_rng(50 + r).standard_normal(n) for _ in range(3)]    # noqa: E731
+    empty = [np.zeros(0) for _ in range(3)]
+    tchunks = None
+    if case == "empty_chunk":
+        chunks = [full(0), empty, full(2)]
+    elif case == "own_nothing":
+        def tiny(r):
+            g = np.random.default_rng(70 + r)
+            c = [0.3 + 1e-4 * g.random(3000) for _ in range(3)]
+            if r == 0:
+                for ax in range(3):
+                    c[ax][0] = 0.0
+                    c[ax][1] = 1.0
+            return c
+        chunks = [tiny(r) for r in range(6)]
+    else:
+        chunks = [empty, full(1)]
+        tchunks = [full(5), full(6)]
+    world = len(chunks)
+    group = nat.LocalGroup(world)
+    res, errors = [None] * world, []
+
+    def run(rank):
+        try:
+            actx = HIPArrayContext(0)
+            comm = group.comm(rank)
+            kw = {}
+            if tchunks is not None:
+                kw["targets"] = [torch.from_numpy(a).cuda() for a in tchunks[rank]]
+            out = nat.sharded_tree_and_lists(
+                actx, comm, [torch.from_numpy(a).cuda() for a in chunks[rank]], mpb, **kw)
+            res[rank] = (out["numbering"]["nboxes"], int(out["tree"].nsources), int(out["tree"].ntargets))
+            comm.close()
+        except BaseException as e:      # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    group.close()
+    assert not errors, errors
+    assert all(r is not None for r in res)
+    actx = HIPArrayContext(0)
+    cat = lambda cs: [torch.from_numpy(np.concatenate([c[ax] for c in cs])).cuda() for ax in range(3)]   # noqa: E731
+    g, _ = TreeBuilder(actx)(actx, cat(chunks), targets=None if tchunks is None else cat(tchunks),
+                             max_particles_in_box=mpb)
+    assert all(r[0] == int(g.nboxes) for r in res), (res, int(g.nboxes))
+    assert sum(r[1] for r in res) == sum(len(c[0]) for c in chunks)
+    if tchunks is not None:
+        assert sum(r[2] for r in res) == sum(len(c[0]) for c in tchunks)
+    if case == "own_nothing":
+        assert sum(1 for r in res if r[1] == 0) >= 3
