@@ -1256,37 +1256,6 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
         set_error("bt_mgpu_exchange: extent_norm is set but no rank has targets");
         return BT_ERR_INVALID;
     }
-    // which top boxes hold sources / targets (flags of the shared top levels)
-    pl.sep_targets = sep;
-    pl.stick_out_factor = ext ? p->stick_out_factor : 0;
-    pl.src_counts.resize((size_t) k + 1);
-    pl.src_counts[k].assign(h_ghist2, h_ghist2 + ncells);
-    pl.stay_src.resize(ext ? (size_t) k + 1 : 0);
-    if (ext) {
-        const int64_t *ss = h_ghist2 + 2 * ncells;
-        for (int lev = 0; lev <= k; ++lev) {
-            const int64_t n = (int64_t) 1 << (D * lev), off = top_table_offset(D, lev);
-            pl.stay_src[lev].assign(ss + off, ss + off + n);
-        }
-        // (sources that stay above level k were counted at their box's first cell)
-        for (int lev = 0; lev < k; ++lev) {
-            const int64_t n = (int64_t) 1 << (D * lev);
-            const int sh = D * (k - lev);
-            for (int64_t i = 0; i < n; ++i) pl.src_counts[k][(size_t) (i << sh)] -= pl.stay_src[lev][(size_t) i];
-        }
-    }
-    for (int lev = k - 1; lev >= 0; --lev) {
-        const int64_t n = (int64_t) 1 << (D * lev);
-        pl.src_counts[lev].resize((size_t) n);
-        const int64_t *below = pl.src_counts[lev + 1].data();
-        for (int64_t i = 0; i < n; ++i) {
-            int64_t sum = ext ? pl.stay_src[lev][(size_t) i] : 0;
-            for (int m = 0; m < (1 << D); ++m) sum += below[i * (1 << D) + m];
-            pl.src_counts[lev][(size_t) i] = sum;
-        }
-    }
-    for (int ax = 0; ax < 3; ++ax) { pl.bbox_min[ax] = bmin[ax]; pl.bbox_max[ax] = bmax[ax]; }
-    pl.root_extent = root_extent;
     bt::host_trace("x:planned");
     memcpy(h_owner, pl.owner.data(), (size_t) ncells * 4);
     BT_HIP_CHECK(hipMemcpyAsync(owner_d.get(), h_owner, (size_t) ncells * 4, hipMemcpyHostToDevice, stream));
@@ -1351,6 +1320,38 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
                                            loop_self ? send[s].get() : points_of[s]));
     }
     bt::host_trace("x:sweeps queued");
+    // (host work the sweeps do not wait for: the GPU is busy meanwhile)
+    // which top boxes hold sources / targets (flags of the shared top levels)
+    pl.sep_targets = sep;
+    pl.stick_out_factor = ext ? p->stick_out_factor : 0;
+    pl.src_counts.resize((size_t) k + 1);
+    pl.src_counts[k].assign(h_ghist2, h_ghist2 + ncells);
+    pl.stay_src.resize(ext ? (size_t) k + 1 : 0);
+    if (ext) {
+        const int64_t *ss = h_ghist2 + 2 * ncells;
+        for (int lev = 0; lev <= k; ++lev) {
+            const int64_t n = (int64_t) 1 << (D * lev), off = top_table_offset(D, lev);
+            pl.stay_src[lev].assign(ss + off, ss + off + n);
+        }
+        // (sources that stay above level k were counted at their box's first cell)
+        for (int lev = 0; lev < k; ++lev) {
+            const int64_t n = (int64_t) 1 << (D * lev);
+            const int sh = D * (k - lev);
+            for (int64_t i = 0; i < n; ++i) pl.src_counts[k][(size_t) (i << sh)] -= pl.stay_src[lev][(size_t) i];
+        }
+    }
+    for (int lev = k - 1; lev >= 0; --lev) {
+        const int64_t n = (int64_t) 1 << (D * lev);
+        pl.src_counts[lev].resize((size_t) n);
+        const int64_t *below = pl.src_counts[lev + 1].data();
+        for (int64_t i = 0; i < n; ++i) {
+            int64_t sum = ext ? pl.stay_src[lev][(size_t) i] : 0;
+            for (int m = 0; m < (1 << D); ++m) sum += below[i * (1 << D) + m];
+            pl.src_counts[lev][(size_t) i] = sum;
+        }
+    }
+    for (int ax = 0; ax < 3; ++ax) { pl.bbox_min[ax] = bmin[ax]; pl.bbox_max[ax] = bmax[ax]; }
+    pl.root_extent = root_extent;
     BT_HIP_CHECK(hipEventSynchronize(ms->ev_counts));     // (the GPU is busy with the sweeps)
     bt::host_trace("x:counts here");
     int32_t rounds_total = 0;
