@@ -493,6 +493,30 @@ def main():
         return st, times
 
     actx.set_stage_timing(False)      # ~30 event records per step; see step()
+    if native_comm is not None and world > 1:
+        # One untimed step through the library's own RCCL entries before anything is measured,
+        # and an agreement over torch's process group that it worked on every rank: a failure
+        # the ranks share (an RCCL this build cannot talk to) moves the job to the
+        # torch.distributed implementation of the same steps instead of ending it.  (A rank
+        # that fails alone inside a collective leaves its peers waiting, here as anywhere.)
+        ok = 1
+        try:
+            step()
+            actx.synchronize()
+        except (RuntimeError, OSError, ValueError) as e:
+            ok = 0
+            print(f"bench.py: rank {rank}: the bt_mgpu_* path failed ({e})", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if rank == 0:
+                print("bench.py: the torch.distributed implementation of the sharded build runs instead",
+                      file=sys.stderr)
+            try:
+                native_comm.close()
+            except (RuntimeError, OSError):
+                pass
+            native_comm = None
     for _ in range(args.warmup):
         step()
 
