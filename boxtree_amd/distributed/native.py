@@ -82,6 +82,9 @@ class _RcclComm:
             _fields_ = [("internal", ct.c_char * 128)]
 
         rank, world = dist.get_rank(), dist.get_world_size()
+        # (before the broadcast: an NCCL process group moves the pickled id through the
+        # current device)
+        torch.cuda.set_device(device_index)
         uid = UniqueId()
         if rank == 0:
             if self.rccl.ncclGetUniqueId(ct.byref(uid)) != 0:
@@ -90,7 +93,6 @@ class _RcclComm:
         if world > 1:
             dist.broadcast_object_list(box, src=0)
             ct.memmove(ct.byref(uid), box[0], ct.sizeof(uid))
-        torch.cuda.set_device(device_index)
         self.comm = ct.c_void_p()
         self.rccl.ncclCommInitRank.argtypes = [ct.POINTER(ct.c_void_p), ct.c_int, UniqueId, ct.c_int]
         code = self.rccl.ncclCommInitRank(ct.byref(self.comm), world, uid, rank)
