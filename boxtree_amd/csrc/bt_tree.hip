@@ -715,8 +715,8 @@ struct BuildArgs {
     const int32_t *parent_list; // level restriction: force-split these boxes (any level)
     int top_level;              // sharded builds: levels above it use global counts
     const int64_t *top_prefix;  // [C^top_level + 1] or null
-    int top_local;              // top_prefix holds THIS key array's cell starts (cell_starts_kernel):
-                                // child ranges down to top_level are looked up, not searched
+    const int64_t *cell_starts; // THIS key array's cell starts at level cell_level (cell_starts_kernel),
+    int cell_level;             // or null: child ranges down to that level are looked up, not searched
     const uint64_t *keys2;      // count_children_kernel (level-restricted builds): the key of the
     int L1k, L2k;               // levels L1k+1 .. L1k+L2k, for parents of level >= L1k
     const int64_t *top_arrive;  // particles with extents: per top box (levels 0..top_level, index
@@ -1045,11 +1045,11 @@ __global__ __launch_bounds__(256) void split_level_kernel(BuildArgs a, LoopState
                             } else {
                                 lo = hi = s;
                             }
-                        } else if (!EXT && a.top_local && a.loff == 0 && level <= a.top_level) {
+                        } else if (!EXT && a.cell_starts && a.loff == 0 && level <= a.cell_level) {
                             // the child's first particle = the first particle of its first
-                            // level-top_level cell
-                            const int sh = D * (a.top_level - level);
-                            lo = hi = (int) a.top_prefix[((prefix << D) | (uint64_t) m) << sh];
+                            // level-cell_level cell
+                            const int sh = D * (a.cell_level - level);
+                            lo = hi = (int) a.cell_starts[((prefix << D) | (uint64_t) m) << sh];
                         } else {
                             const uint64_t ck = ((prefix << D) | (uint64_t) m) << cshift;
                             if (ck == 0) { lo = hi = s; }
@@ -3137,15 +3137,17 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         const int64_t guess = (int64_t) std::min(2.0 * C * per_leaf + 4096.0, 2.0e9);
         BT_CHECK(ensure_box_capacity(ctx, st, std::max<int64_t>(guess, 1024), sizeof(T)));
     }
-    // ---- cell starts of the top levels (point particles, unit weights, a self-contained
-    // build): see cell_starts_kernel ---------------------------------------------------------
+    // ---- cell starts of the top levels (point particles, unit weights): see cell_starts_kernel.
+    // A self-contained build also takes the counts of its top boxes from them; a sharded one has
+    // the global tables for that (top_cell_prefix) and only looks child ranges up here -- searched,
+    // its five shared levels took 0.3 ms of few threads' dependent loads at 10^8 points. ------
     Buf<int64_t> local_cells;
     int local_top_level = 0;
     {
         static const bool off = [] { const char *e = getenv("BT_NO_CELL_STARTS"); return e && atoi(e); }();
         int k = D == 3 ? 5 : D == 2 ? 7 : 15;
         k = std::min(k, packed ? pk_sorted : st->L);
-        if (!off && !EXT && !p.refine_weights && !p.top_cell_prefix && N >= 4096 && k >= 2
+        if (!off && !EXT && !p.refine_weights && N >= 4096 && k >= 2
                 && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED) {
             const int64_t ncells = (int64_t) 1 << (D * k);
             BT_CHECK(local_cells.alloc(ctx->pool, ncells + 1));
@@ -3179,11 +3181,13 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         a.top_prefix = p.top_cell_prefix;
         a.top_arrive = p.top_box_arrive;
         a.top_stay = p.top_box_stay;
-        a.top_local = 0;
         if (local_cells.get()) {
-            a.top_level = local_top_level;
-            a.top_prefix = local_cells.get();
-            a.top_local = 1;
+            a.cell_starts = local_cells.get();
+            a.cell_level = local_top_level;
+            if (!p.top_cell_prefix) {           // the build's own counts are the global ones
+                a.top_level = local_top_level;
+                a.top_prefix = local_cells.get();
+            }
         }
         a.keep_empty = p.skip_prune ? 1 : 0;
     };
