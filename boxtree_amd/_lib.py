@@ -30,7 +30,7 @@ P3 = vp * BT_MAX_DIMS
 PL = vp * BT_MAX_LEVELS
 
 
-ABI_VERSION = 8      # BT_ABI_VERSION of include/boxtree_hip.h
+ABI_VERSION = 9      # BT_ABI_VERSION of include/boxtree_hip.h
 
 
 class SortStats(ct.Structure):
@@ -192,7 +192,8 @@ class MgpuLocalTree(ct.Structure):
                 ("level_start_box_nrs", ct.POINTER(ct.c_int32)), ("box_centers", vp),
                 ("box_levels", vp), ("box_flags", vp), ("nsources", ct.c_int64),
                 ("ntargets", ct.c_int64), ("box_target_bounding_box_min", vp),
-                ("box_target_bounding_box_max", vp), ("box_source_counts_cumul", vp)]
+                ("box_target_bounding_box_max", vp), ("box_source_counts_cumul", vp),
+                ("box_subtree_sizes", vp)]
 
 
 class MgpuNumbering(ct.Structure):
@@ -207,14 +208,16 @@ class MgpuLetSizes(ct.Structure):
                 ("level_start_box_nrs", ct.c_int32 * (BT_MAX_LEVELS + 2)),
                 ("active_level_ranges", (ct.c_int32 * 2) * (BT_MAX_LEVELS + 1)),
                 ("halo_boxes_sent", ct.c_int64), ("halo_boxes_received", ct.c_int64),
-                ("loopback_records", ct.c_int64), ("loopback_mismatches", ct.c_int64)]
+                ("loopback_records", ct.c_int64), ("loopback_mismatches", ct.c_int64),
+                ("has_subtree_sizes", ct.c_int32)]
 
 
 class MgpuLetArrays(ct.Structure):
     _fields_ = [("box_centers", vp), ("box_parent_ids", vp), ("box_child_ids", vp),
                 ("box_levels", vp), ("box_flags", vp), ("global_box_ids", vp),
                 ("target_boxes_mask", vp), ("box_target_bounding_box_min", vp),
-                ("box_target_bounding_box_max", vp), ("box_source_counts_cumul", vp)]
+                ("box_target_bounding_box_max", vp), ("box_source_counts_cumul", vp),
+                ("box_subtree_sizes", vp)]
 
 
 class Span(ct.Structure):

@@ -588,6 +588,8 @@ struct MgpuState {
     Buf<unsigned char> let_tbb;
     Buf<int32_t> let_srccum;
     bool let_ext = false;
+    Buf<int32_t> let_sizes;          // subtree sizes of the deep boxes (every rank passed its own)
+    bool let_has_sizes = false;
     int let_nlevels = 0, let_dims = 0, let_kind = 0;
     std::vector<int32_t> let_level_starts;
 };
@@ -753,6 +755,52 @@ __global__ __launch_bounds__(256) void let_scatter_halo_kernel(int64_t n, LetBlo
     all_meta[dst] = meta;
     all_gid[dst] = (int32_t) (w >> 32);
     mask[dst] = 0;
+}
+
+__global__ void let_flag_kernel(int32_t *p) { *p = 1; }
+
+// subtree sizes: of the boxes peer q needs, of this rank's own deep boxes, of a peer's halo boxes
+__global__ __launch_bounds__(256) void let_pack_sizes_kernel(int64_t n, NeedPred pr, const int32_t *pos,
+        const int32_t *sizes, int32_t *out)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || !pr(i)) return;
+    out[pos[i]] = sizes[pr.b0 + i];
+}
+
+__global__ __launch_bounds__(256) void let_scatter_own_sizes_kernel(int64_t n_mine, int64_t b0, LetBlocks blk,
+        const uint8_t *levels, const int32_t *sizes, int32_t *all_sizes)
+{
+    const int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_mine) return;
+    const int64_t b = b0 + i;
+    const int lev = levels[b];
+    all_sizes[(int64_t) blk.dst_start[lev] + (b - blk.src_start[lev])] = sizes[b];
+}
+
+__global__ __launch_bounds__(256) void let_scatter_halo_sizes_kernel(int64_t n, LetBlocks blk, const uint64_t *rec,
+        const int32_t *in, int32_t *all_sizes)
+{
+    const int64_t j = (int64_t) blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    const int lev = (int) (rec[2 * j + 1] & 0xffu);
+    if (lev > BT_MAX_LEVELS || j < blk.src_start[lev]) return;      // (let_scatter_halo_kernel reports it)
+    all_sizes[(int64_t) blk.dst_start[lev] + (j - blk.src_start[lev])] = in[j];
+}
+
+// the shared top boxes, one level per launch, bottom-up over the LET's child table
+__global__ __launch_bounds__(256) void let_top_sizes_kernel(int32_t b0, int32_t nb, int C, int64_t aligned,
+        const int32_t *child, int32_t *sizes)
+{
+    const int32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nb) return;
+    const int32_t b = b0 + i;
+    int32_t s = 1;
+    for (int m = 0; m < C; ++m) {
+        const int32_t c = child[(int64_t) m * aligned + b];
+        if (c) s += sizes[c];
+    }
+    sizes[b] = s;
 }
 
 // extras of a box whose targets have extents: bounding box of its targets, cumulative source count
@@ -1672,6 +1720,10 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
     LocalLevels lls{};
     lls.nlevels = nlev_local;
     for (int l = 0; l <= nlev_local; ++l) lls.start[l] = tree->level_start_box_nrs[l];
+    // (slot [receiver = this rank][level 0] of a rank's row counts nothing -- no rank sends to
+    // itself, level 0 is shared --: it says whether the rank came with subtree sizes)
+    if (tree->box_subtree_sizes || nb == 0)
+        let_flag_kernel<<<1, 1, 0, stream>>>(rows.get() + (int64_t) rank * LW);
     NeedPred pr{paths.get(), tree->box_levels, need_d.get(), b0, k, D, nwords, 0};
     for (size_t i = 0; i < peers.size(); ++i) {
         pr.q = peers[i];
@@ -1686,9 +1738,11 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
     BT_CHECK(bt::sync_stream(ctx));                         // the one wait of this call
     auto sent = [&](int from, int to) {
         int64_t c = 0;
-        for (int l = 0; l < LW; ++l) c += table[((int64_t) from * nranks + to) * LW + l];
+        for (int l = ntop_levels; l < LW; ++l) c += table[((int64_t) from * nranks + to) * LW + l];
         return c;
     };
+    bool with_sizes = true;
+    for (int q = 0; q < nranks; ++q) with_sizes = with_sizes && table[((int64_t) q * nranks + q) * LW] != 0;
     std::vector<int64_t> s_cnt((size_t) nranks, 0), s_off((size_t) nranks, 0), r_cnt((size_t) nranks, 0),
         r_off((size_t) nranks, 0);
     int64_t nsend = 0, nrecv = 0, biggest = 0;
@@ -1783,6 +1837,27 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
         }
         BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send_ex.get(), sob.data(), scb.data(),
                                    (char *) halo_ex.get(), rob.data(), rcb.data(), biggest / 16 * exrec, false, nullptr));
+    }
+
+    // subtree sizes of the halo boxes, from their owners
+    Buf<int32_t> send_sz, halo_sz;
+    if (with_sizes) {
+        BT_CHECK(send_sz.alloc(ctx->pool, std::max<int64_t>(nsend, 1)));
+        BT_CHECK(halo_sz.alloc(ctx->pool, std::max<int64_t>(nrecv, 1)));
+        for (size_t i = 0; i < peers.size(); ++i) {
+            const int q = peers[i];
+            if (s_cnt[q] == 0) continue;
+            pr.q = q;
+            let_pack_sizes_kernel<<<(unsigned) div_up(n_mine, 256), 256, 0, stream>>>(
+                n_mine, pr, pos.get() + (int64_t) i * (n_mine + 1), tree->box_subtree_sizes, send_sz.get() + s_off[q]);
+        }
+        BT_HIP_CHECK(hipGetLastError());
+        std::vector<int64_t> sob((size_t) nranks), scb((size_t) nranks), rob((size_t) nranks), rcb((size_t) nranks);
+        for (int q = 0; q < nranks; ++q) {
+            sob[q] = s_off[q] * 4; scb[q] = s_cnt[q] * 4; rob[q] = r_off[q] * 4; rcb[q] = r_cnt[q] * 4;
+        }
+        BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send_sz.get(), sob.data(), scb.data(),
+                                   (char *) halo_sz.get(), rob.data(), rcb.data(), biggest / 4, false, nullptr));
     }
 
     // -- the box set: top levels from the plan, my deep boxes, the halo ----------------------------
@@ -1883,6 +1958,20 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
             ms->let_gid.get(), ms->let_mask.get(), ctx->d_status);
     }
     BT_HIP_CHECK(hipGetLastError());
+    ms->let_has_sizes = with_sizes;
+    out->has_subtree_sizes = with_sizes ? 1 : 0;
+    if (with_sizes) {
+        BT_CHECK(ms->let_sizes.alloc(ctx->pool, std::max<int64_t>(B, 1)));
+        if (n_mine > 0)
+            let_scatter_own_sizes_kernel<<<(unsigned) div_up(n_mine, 256), 256, 0, stream>>>(
+                n_mine, b0, blk[(size_t) rank], tree->box_levels, tree->box_subtree_sizes, ms->let_sizes.get());
+        for (int q = 0; q < nranks; ++q) {
+            if (q == rank || r_cnt[q] == 0) continue;
+            let_scatter_halo_sizes_kernel<<<(unsigned) div_up(r_cnt[q], 256), 256, 0, stream>>>(
+                r_cnt[q], blk[(size_t) q], halo_rec.get() + 2 * r_off[q], halo_sz.get() + r_off[q], ms->let_sizes.get());
+        }
+        BT_HIP_CHECK(hipGetLastError());
+    }
     ms->let_ext = ext;
     if (ext) {
         BT_CHECK(ms->let_tbb.alloc(ctx->pool, 2 * (int64_t) D * B * (int64_t) es));
@@ -2031,6 +2120,20 @@ int bt_mgpu_let_export(bt_context *ctx, const bt_mgpu_let_arrays *o)
                                     hipMemcpyDeviceToDevice, stream));
         ms->let_tbb.reset(); ms->let_srccum.reset();
     }
+    if (ms->let_has_sizes && o->box_subtree_sizes) {
+        // the shared top levels: a box and what the LET holds below it
+        const int ntop_levels = std::min(pl.k + 1, ms->let_nlevels);
+        for (int lev = ntop_levels - 1; lev >= 0; --lev) {
+            const int32_t b0 = ms->let_level_starts[(size_t) lev], nbl = ms->let_level_starts[(size_t) lev + 1] - b0;
+            if (nbl > 0)
+                let_top_sizes_kernel<<<(unsigned) div_up(nbl, 256), 256, 0, stream>>>(
+                    b0, nbl, 1 << ms->let_dims, aligned, o->box_child_ids, ms->let_sizes.get());
+        }
+        BT_HIP_CHECK(hipGetLastError());
+        BT_HIP_CHECK(hipMemcpyAsync(o->box_subtree_sizes, ms->let_sizes.get(), (size_t) B * 4,
+                                    hipMemcpyDeviceToDevice, stream));
+    }
+    ms->let_sizes.reset();
     ms->let_paths.reset(); ms->let_meta.reset(); ms->let_gid.reset(); ms->let_mask.reset();
     ms->let_nlevels = 0;
     return bt::finish_call(ctx);

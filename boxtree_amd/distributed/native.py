@@ -353,6 +353,11 @@ def _local_tree_view(actx, tree):
         v.box_target_bounding_box_min = tree.box_target_bounding_box_min.data_ptr()
         v.box_target_bounding_box_max = tree.box_target_bounding_box_max.data_ptr()
         v.box_source_counts_cumul = tree.box_source_counts_cumul.data_ptr()
+    # (what TreeBuilder kept of its export: the LET then comes with subtree sizes, if every rank's
+    # tree has them)
+    sizes = getattr(tree, "_subtree_sizes", None)
+    if sizes is not None and os.environ.get("BOXTREE_HIP_SUBTREE_SIZES", "1") != "0":
+        v.box_subtree_sizes = sizes.data_ptr()
     return v, lsb
 
 
@@ -408,6 +413,10 @@ def build_local_essential_tree(actx, comm, tree, numbering, well_sep_is_n_away=1
     arrs.box_flags = flags.data_ptr()
     arrs.global_box_ids = gids.data_ptr()
     arrs.target_boxes_mask = mask.data_ptr()
+    let_sizes = None
+    if int(sizes.has_subtree_sizes):
+        let_sizes = torch.empty(B, dtype=torch.int32, device=tree.box_centers.device)
+        arrs.box_subtree_sizes = let_sizes.data_ptr()
     _lib.check(actx.lib.bt_mgpu_let_export(actx.handle, ct.byref(arrs)))
     lsb = np.array(sizes.level_start_box_nrs[:nlev + 1], dtype=np.int32)
     let = TreeOfBoxes(
@@ -426,6 +435,9 @@ def build_local_essential_tree(actx, comm, tree, numbering, well_sep_is_n_away=1
     # made by the library on this device: contiguous arrays of its own types -- the traversal
     # builder takes them as they are (no conversions, no look at the root's parent entry)
     object.__setattr__(let, "_host_level_starts", lsb)
+    if let_sizes is not None:
+        # (bt_trav_params.box_subtree_sizes: the traversal's depth-first ranks start from them)
+        object.__setattr__(let, "_subtree_sizes", let_sizes)
     ranges = np.array([[sizes.active_level_ranges[l][0], sizes.active_level_ranges[l][1]]
                        for l in range(nlev)], dtype=np.int32)
     info = dict(target_boxes_mask=mask, active_level_ranges=ranges, global_box_ids=gids,

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BT_ABI_VERSION 8
+#define BT_ABI_VERSION 9
 #define BT_MAX_DIMS 3
 #define BT_MAX_LEVELS 64       /* capacity of per-level arrays in the structs */
 
@@ -689,6 +689,11 @@ typedef struct {
      * of a tree whose targets have extents, laid out as in the tree export */
     const void *box_target_bounding_box_min, *box_target_bounding_box_max;  /* [dims][aligned_nboxes] */
     const int32_t *box_source_counts_cumul;                                  /* [nboxes] */
+    /* Optional: bt_tree_arrays.box_subtree_sizes of the local tree ([nboxes]).  If EVERY rank
+     * passes it, the LET comes with the subtree sizes bt_trav_params.box_subtree_sizes takes
+     * (own boxes keep theirs, the owners send those of the halo boxes, the shared top boxes are
+     * summed) and the traversal saves its sweep over the levels. */
+    const int32_t *box_subtree_sizes;
 } bt_mgpu_local_tree;
 
 /* Step 5: where the rank's tree sits in the global one -- the tree a single GPU builds
@@ -724,6 +729,7 @@ typedef struct {
     int32_t active_level_ranges[BT_MAX_LEVELS + 1][2];  /* per level: [begin, end) of the rank's boxes */
     int64_t halo_boxes_sent, halo_boxes_received;
     int64_t loopback_records, loopback_mismatches;      /* self-loopback echo of the halo records */
+    int32_t has_subtree_sizes;            /* every rank passed box_subtree_sizes: _export has them */
 } bt_mgpu_let_sizes;
 typedef struct {
     void *box_centers;
@@ -739,6 +745,7 @@ typedef struct {
      * ranks (an all-reduce) and their source counts from the plan */
     void *box_target_bounding_box_min, *box_target_bounding_box_max;   /* [dims][aligned_nboxes] */
     int32_t *box_source_counts_cumul;                                   /* [nboxes] */
+    int32_t *box_subtree_sizes;           /* [nboxes] or NULL; filled if has_subtree_sizes */
 } bt_mgpu_let_arrays;
 int bt_mgpu_let_build(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,
                       const int32_t *box_ids, const bt_mgpu_numbering *numbering,

@@ -1363,6 +1363,20 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
             trav, _ = FMMTraversalBuilder(actx, well_sep_is_n_away=nway)(
                 actx, let, _target_boxes_mask=info["target_boxes_mask"],
                 _active_level_ranges=info["active_level_ranges"])
+            if native:
+                # the LET comes with subtree sizes (own boxes' from the local tree, halo boxes'
+                # from their owners, shared top boxes summed): the sizes of its own child table
+                sz = getattr(let, "_subtree_sizes", None)
+                assert sz is not None
+                ch = let.box_child_ids.cpu().numpy()[:, :int(let.nboxes)]
+                lv = let.box_levels.cpu().numpy().astype(np.int64)
+                want = np.ones(int(let.nboxes), np.int64)
+                for l in range(int(lv.max()), 0, -1):
+                    idx = np.nonzero(lv == l)[0]
+                    par = let.box_parent_ids.cpu().numpy()[idx]
+                    np.add.at(want, par, want[idx])
+                assert np.array_equal(sz.cpu().numpy().astype(np.int64), want), "LET subtree sizes"
+                del ch
             results[rank] = dict(let=actx.to_numpy(let), trav=actx.to_numpy(trav),
                                  gid=info["global_box_ids"].cpu().numpy().astype(np.int64),
                                  mask=info["target_boxes_mask"].cpu().numpy().astype(np.int8),
