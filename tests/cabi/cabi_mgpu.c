@@ -145,6 +145,7 @@ static int run_rank(rank_args *a)
     CHECK_HIP(hipMalloc(&o.box_centers, (size_t) dims * al * 8));
     CHECK_HIP(hipMalloc((void **) &o.box_levels, nb));
     CHECK_HIP(hipMalloc((void **) &o.box_flags, nb));
+    CHECK_HIP(hipMalloc((void **) &o.box_subtree_sizes, nb * 4));
     CHECK_HIP(hipMalloc(&o.box_source_bounding_box_min, (size_t) dims * al * 8));
     CHECK_HIP(hipMalloc(&o.box_source_bounding_box_max, (size_t) dims * al * 8));
     if (nt > 0) {
@@ -167,6 +168,7 @@ static int run_rank(rank_args *a)
     lt.nlevels = sz.nlevels; lt.level_start_box_nrs = sz.level_start_box_nrs;
     lt.box_centers = o.box_centers; lt.box_levels = o.box_levels; lt.box_flags = o.box_flags;
     lt.nsources = sh.n_owned; lt.ntargets = nt > 0 ? sh.n_owned_targets : sh.n_owned;
+    lt.box_subtree_sizes = o.box_subtree_sizes;     /* every rank: the LET then comes with sizes */
     if (nt > 0) {
         lt.box_target_bounding_box_min = o.box_target_bounding_box_min;
         lt.box_target_bounding_box_max = o.box_target_bounding_box_max;
@@ -195,8 +197,18 @@ static int run_rank(rank_args *a)
         CHECK_HIP(hipMalloc(&la.box_target_bounding_box_max, (size_t) dims * lal * 8));
         CHECK_HIP(hipMalloc((void **) &la.box_source_counts_cumul, lb * 4));
     }
+    if (!ls.has_subtree_sizes) { fprintf(stderr, "rank %d: the LET has no subtree sizes\n", a->rank); return 90; }
+    CHECK_HIP(hipMalloc((void **) &la.box_subtree_sizes, lb * 4));
     CHECK_BT(bt_mgpu_let_export(ctx, &la));
     CHECK_BT(bt_synchronize(ctx));
+    {
+        int32_t root_size = 0;      /* the root's subtree is the whole LET */
+        CHECK_HIP(hipMemcpy(&root_size, la.box_subtree_sizes, 4, hipMemcpyDeviceToHost));
+        if ((int64_t) root_size != ls.nboxes) {
+            fprintf(stderr, "rank %d: root subtree size %d, LET boxes %lld\n", a->rank, root_size, (long long) ls.nboxes);
+            return 91;
+        }
+    }
 
     /* digest: global numbers of the boxes this rank owns below the shared top levels */
     int32_t *h_ids = (int32_t *) malloc(nb * 4);
