@@ -30,7 +30,7 @@ P3 = vp * BT_MAX_DIMS
 PL = vp * BT_MAX_LEVELS
 
 
-ABI_VERSION = 9      # BT_ABI_VERSION of include/boxtree_hip.h
+ABI_VERSION = 10     # BT_ABI_VERSION of include/boxtree_hip.h
 
 
 class SortStats(ct.Structure):
@@ -152,6 +152,8 @@ class TravArrays(ct.Structure):
         ("target_boxes_sep_smaller", PL),
     ]
 
+BT_ROUTE_TO_OWNERS, BT_ROUTE_TO_CALLERS = 0, 1
+
 
 # every symbol include/boxtree_hip.h declares
 class AqTree(ct.Structure):
@@ -183,7 +185,9 @@ class MgpuShard(ct.Structure):
                 ("a2a_ms", ct.c_float), ("n_owned_targets", ct.c_int64), ("target_points", vp),
                 ("sep_targets", ct.c_int32), ("target_record_len", ct.c_int32),
                 ("target_radii", vp), ("source_record_len", ct.c_int32), ("refine_weights", vp),
-                ("top_box_arrive", vp), ("top_box_stay", vp)]
+                ("top_box_arrive", vp), ("top_box_stay", vp),
+                ("source_chunk_offset", ct.c_int64), ("target_chunk_offset", ct.c_int64),
+                ("n_global_sources", ct.c_int64), ("n_global_targets", ct.c_int64)]
 
 
 class MgpuLocalTree(ct.Structure):
@@ -268,7 +272,7 @@ EXPORTED_SYMBOLS = [
     "bt_mgpu_comm_rccl", "bt_mgpu_local_group_create", "bt_mgpu_local_group_destroy",
     "bt_mgpu_comm_local", "bt_mgpu_comm_destroy", "bt_mgpu_use_rccl_library",
     "bt_mgpu_comm_set_self_loopback", "bt_mgpu_number", "bt_mgpu_let_build",
-    "bt_mgpu_let_export",
+    "bt_mgpu_let_export", "bt_mgpu_route", "bt_mgpu_global_ids",
     "bt_dfs_order", "bt_partition_work", "bt_ancestor_mask", "bt_mark_list_boxes",
     "bt_local_particles", "bt_modify_target_flags", "bt_box_to_user_ranks",
     "bt_boxes_used_by_ranks",
@@ -339,6 +343,8 @@ def load():
     lib.bt_mgpu_let_build.argtypes = [vp, vp, ct.POINTER(MgpuLocalTree), vp,
                                       ct.POINTER(MgpuNumbering), ct.c_int, ct.POINTER(MgpuLetSizes)]
     lib.bt_mgpu_let_export.argtypes = [vp, ct.POINTER(MgpuLetArrays)]
+    lib.bt_mgpu_route.argtypes = [vp, vp, ct.c_int, ct.c_int, ct.c_int, vp, vp]
+    lib.bt_mgpu_global_ids.argtypes = [vp, vp, ct.c_int, ct.c_int, vp]
     lib.bt_mgpu_plan.argtypes = [ct.c_int, ct.c_int, ct.c_int64, ct.c_int, vp, vp, vp]
     lib.bt_mgpu_plan_ext.argtypes = [ct.c_int, ct.c_int, ct.c_int64, ct.c_int, vp, vp, vp, vp, vp, vp]
     lib.bt_traversal_build_packed.argtypes = [vp, ct.POINTER(TravParams), ALLOC_FN, vp,

@@ -265,5 +265,13 @@ int widen_weights_device(bt_context *ctx, const int32_t *weights, int64_t n, int
 // (the table goes to LDS if it fits), 0 if unknown; no wait
 int partition_pack_device(bt_context *ctx, int dims, int elem_size, const void *const *in,
                           const uint32_t *cells, int64_t n, const int32_t *owner_of_cell, int ncells, int nranks,
-                          int self_rank, const int64_t *d_self_offsets, void *send, void *recv);
+                          int self_rank, const int64_t *d_self_offsets, void *send, void *recv,
+                          Buf<uint8_t> *keep_owners = nullptr, Buf<int32_t> *keep_offsets = nullptr);
+// Any per-particle array (4- or 8-byte elements) over the send plan a partition_pack_device call
+// kept (owners, offsets): forward, `lay` [n] gets the elements in the send layout (in == nullptr:
+// the values iota_base + i) and `self` (owner order, or nullptr) the own segment at self_delta;
+// reverse, out[i] = the element at particle i's place.  No wait.
+int route_device(bt_context *ctx, int elem_size, bool reverse, const void *in, int64_t iota_base, void *lay,
+                 void *self, void *out, const uint8_t *owners, const int32_t *offsets, int64_t n, int nranks,
+                 int self_rank, int64_t self_delta);
 }  // namespace bt

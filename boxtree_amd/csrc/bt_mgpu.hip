@@ -551,8 +551,23 @@ struct PinArena {
     ~PinArena() { for (auto &b : blocks) (void) hipHostFree(b.p); }
 };
 
+// The stable send plan of one particle set of the last exchange: what bt_mgpu_route needs to move
+// any per-particle array between the caller's order and the owners' (receive-buffer) order.
+struct RoutePlan {
+    bool valid = false;
+    int rank = 0, nranks = 0;
+    bool loop_self = false;
+    int64_t n = 0, nrecv = 0;                // particles of the chunk / owned after the exchange
+    Buf<uint8_t> owners;                     // [n] owner of every chunk particle
+    Buf<int32_t> offsets;                    // [nranks * nwaves + 1] scanned per-(owner, tile) counts
+    std::vector<int64_t> s_cnt, r_cnt;       // records to / from every rank
+    int64_t biggest = 0;                     // largest rank-to-rank message of the job, records
+    int64_t chunk_offset = 0, total = 0;     // global id of the chunk's first particle; all chunks
+};
+
 struct MgpuState {
     PinArena arena;
+    RoutePlan route[2];              // sources, separate targets
     Buf<unsigned char> points;       // received particles, interleaved [n_owned][dims]
     Buf<unsigned char> tpoints;      // ... separate targets ([n][dims + 1] with radii)
     Buf<unsigned char> tradii;       // ... their radii, dense (the tree build reads them so)
@@ -1042,7 +1057,7 @@ int bt_mgpu_comm_rccl(void *nccl_comm, int rank, int nranks, bt_mgpu_comm **out)
     bt_mgpu_comm *c = new bt_mgpu_comm();
     c->kind = 0; c->rank = rank; c->nranks = nranks; c->nccl = (nccl_comm_t) nccl_comm;
     const char *lb = getenv("BT_MGPU_SELF_LOOPBACK");
-    c->self_loopback = lb && atoi(lb) != 0;
+    c->self_loopback = lb && atoi(lb) != 0 && nranks == 1;    // (a switch for worlds of one rank)
     *out = c;
     return BT_OK;
 }
@@ -1082,6 +1097,14 @@ int bt_mgpu_use_rccl_library(const char *path)
 
 int bt_mgpu_comm_set_self_loopback(bt_mgpu_comm *c, int on)
 {
+    // (the number of point-to-point rounds follows from the largest message of any rank; with the
+    // own segments in play that maximum would have to include every rank's diagonal -- the switch
+    // exists for worlds of one rank, where nothing else travels)
+    if (c && on && c->nranks > 1) {
+        set_error("bt_mgpu_comm_set_self_loopback: a test switch for communicators of one rank (this one has %d)",
+                  c->nranks);
+        return BT_ERR_INVALID;
+    }
     if (!c) { set_error("bt_mgpu_comm_set_self_loopback: invalid argument"); return BT_ERR_INVALID; }
     c->self_loopback = on != 0;
     return BT_OK;
@@ -1162,6 +1185,7 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     // of the shared top boxes, so it cannot be a rank's own view of its chunk)
     const int64_t nset[2] = {p->n, p->ntargets};
     const void *const *cset[2] = {p->coords, p->targets};
+    if (ctx->mgpu) { ctx->mgpu->route[0].valid = false; ctx->mgpu->route[1].valid = false; }
     // refine weights (the limit is a parameter of the job; a NULL array means unit weights)
     const bool weighted = p->max_leaf_refine_weight > 0;
     const int32_t *wset[2] = {weighted ? p->source_refine_weights : nullptr,
@@ -1365,7 +1389,8 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
         }
         BT_CHECK(bt::partition_pack_device(ctx, vals_of[s], es, arrays, cells[s].get(), n, owner_d.get(), (int) ncells,
                                            nranks, rank, self_d.get() + 2 * s, send[s].get(),
-                                           loop_self ? send[s].get() : points_of[s]));
+                                           loop_self ? send[s].get() : points_of[s], &ms->route[s].owners,
+                                           &ms->route[s].offsets));
     }
     bt::host_trace("x:sweeps queued");
     // (host work the sweeps do not wait for: the GPU is busy meanwhile)
@@ -1428,7 +1453,27 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
                       (long long) r_off, (long long) nrecv_of[s]);
             return BT_ERR_INTERNAL;
         }
+        // (self-loopback is refused on communicators of more than one rank: `biggest`, which fixes
+        // the number of rounds, must be the same on every rank)
         int32_t rounds = 1;
+        {
+            // the plan bt_mgpu_route and bt_mgpu_global_ids work from
+            RoutePlan &rp = ms->route[s];
+            rp.rank = rank; rp.nranks = nranks; rp.loop_self = loop_self;
+            rp.n = nset[s]; rp.nrecv = nrecv_of[s];
+            rp.s_cnt.assign((size_t) nranks, 0); rp.r_cnt.assign((size_t) nranks, 0);
+            rp.chunk_offset = 0; rp.total = 0;
+            for (int q = 0; q < nranks; ++q) {
+                rp.s_cnt[(size_t) q] = send_counts[(size_t) s * nranks + q];
+                rp.r_cnt[(size_t) q] = h_matrix[(size_t) q * row + (size_t) s * nranks + rank];
+                int64_t nq = 0;
+                for (int r = 0; r < nranks; ++r) nq += h_matrix[(size_t) q * row + (size_t) s * nranks + r];
+                if (q < rank) rp.chunk_offset += nq;
+                rp.total += nq;
+            }
+            rp.biggest = (loop_self ? std::max(biggest, s_cnt_b[rank]) : biggest) / rec;
+            rp.valid = true;
+        }
         if (!loop_self) { s_cnt_b[rank] = 0; r_cnt_b[rank] = 0; }       // (own segment: packed in place)
         else biggest = std::max(biggest, s_cnt_b[rank]);
         BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) send[s].get(), s_off_b.data(), s_cnt_b.data(),
@@ -1512,6 +1557,12 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     out->bytes_sent = bytes_sent;
     out->rounds = rounds_total;
     out->sep_targets = sep ? 1 : 0;
+    out->source_chunk_offset = ms->route[0].chunk_offset;
+    out->n_global_sources = ms->route[0].total;
+    if (nsets == 2) {
+        out->target_chunk_offset = ms->route[1].chunk_offset;
+        out->n_global_targets = ms->route[1].total;
+    }
     out->a2a_ms = -1.f;
     // a stream-ordered context returns with the payload exchange queued (bt_mgpu_exchange_time
     // waits for it); any other waits here
@@ -1522,6 +1573,73 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
         out->a2a_ms = ms->a2a_ms;
     }
     return BT_OK;
+}
+
+
+// ---- particle identity: per-particle arrays over the plan of the last exchange ------------------
+
+static int bt_mgpu_route_body(bt_context *ctx, bt_mgpu_comm *comm, int set, int direction, int elem_size,
+                              const void *in, void *out, bool ids)
+{
+    bt::CallScope bt_call_scope_(ctx);
+    const char *who = ids ? "bt_mgpu_global_ids" : "bt_mgpu_route";
+    if (!ctx || !comm || set < 0 || set > 1 || (elem_size != 4 && elem_size != 8)
+            || (direction != BT_ROUTE_TO_OWNERS && direction != BT_ROUTE_TO_CALLERS)) {
+        set_error("%s: invalid argument", who);
+        return BT_ERR_INVALID;
+    }
+    MgpuState *ms = ctx->mgpu;
+    if (!ms || !ms->route[set].valid) {
+        set_error("%s: no exchange of %s on this context", who, set == 0 ? "sources" : "separate targets");
+        return BT_ERR_INVALID;
+    }
+    RoutePlan &rp = ms->route[set];
+    if (rp.rank != comm->rank || rp.nranks != comm->nranks) {
+        set_error("%s: the communicator (rank %d of %d) is not the exchange's (rank %d of %d)", who, comm->rank,
+                  comm->nranks, rp.rank, rp.nranks);
+        return BT_ERR_INVALID;
+    }
+    const bool reverse = direction == BT_ROUTE_TO_CALLERS;
+    const int64_t n_in = reverse ? rp.nrecv : rp.n, n_out = reverse ? rp.n : rp.nrecv;
+    if ((n_in > 0 && !in && !ids) || (n_out > 0 && !out)) {
+        set_error("%s: NULL array", who);
+        return BT_ERR_INVALID;
+    }
+    if (ids && elem_size == 4 && rp.total > (int64_t) INT32_MAX) {
+        set_error("bt_mgpu_global_ids: %lld particles do not fit 32-bit ids; ask for 8-byte ids", (long long) rp.total);
+        return BT_ERR_UNSUPPORTED;
+    }
+    BT_HIP_CHECK(hipSetDevice(ctx->device));
+    BT_CHECK(reset_status(ctx));
+    hipStream_t stream = ctx->stream;
+    const int rank = rp.rank, nranks = rp.nranks;
+    const int64_t es = elem_size;
+    // byte offsets and counts of the two layouts: the chunk's send layout (owner-major) and the
+    // owner order (senders in rank order)
+    std::vector<int64_t> lay_off((size_t) nranks), lay_cnt((size_t) nranks), own_off((size_t) nranks), own_cnt((size_t) nranks);
+    int64_t a = 0, b = 0;
+    for (int r = 0; r < nranks; ++r) {
+        lay_off[(size_t) r] = a * es; lay_cnt[(size_t) r] = rp.s_cnt[(size_t) r] * es; a += rp.s_cnt[(size_t) r];
+        own_off[(size_t) r] = b * es; own_cnt[(size_t) r] = rp.r_cnt[(size_t) r] * es; b += rp.r_cnt[(size_t) r];
+    }
+    const int64_t self_delta = (own_off[(size_t) rank] - lay_off[(size_t) rank]) / es;
+    if (!rp.loop_self) { lay_cnt[(size_t) rank] = 0; own_cnt[(size_t) rank] = 0; }     // (own segment: moved by the kernel)
+    Buf<unsigned char> lay;
+    BT_CHECK(lay.alloc(ctx->pool, std::max<int64_t>(rp.n, 1) * es));
+    int32_t rounds = 1;
+    if (!reverse) {
+        BT_CHECK(bt::route_device(ctx, elem_size, false, ids ? nullptr : in, rp.chunk_offset, lay.get(),
+                                  rp.loop_self ? nullptr : out, nullptr, rp.owners.get(), rp.offsets.get(), rp.n,
+                                  nranks, rank, self_delta));
+        BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) lay.get(), lay_off.data(), lay_cnt.data(), (char *) out,
+                                   own_off.data(), own_cnt.data(), rp.biggest * es, !rp.loop_self, &rounds));
+    } else {
+        BT_CHECK(comm_all_to_all_v(comm, stream, (const char *) in, own_off.data(), own_cnt.data(), (char *) lay.get(),
+                                   lay_off.data(), lay_cnt.data(), rp.biggest * es, !rp.loop_self, &rounds));
+        BT_CHECK(bt::route_device(ctx, elem_size, true, nullptr, 0, lay.get(), rp.loop_self ? nullptr : (void *) in,
+                                  out, rp.owners.get(), rp.offsets.get(), rp.n, nranks, rank, self_delta));
+    }
+    return bt::finish_call(ctx);
 }
 
 // ---- step 5: global numbering ------------------------------------------------------------------
@@ -2054,6 +2172,17 @@ int bt_mgpu_exchange_time(bt_context *ctx, float *a2a_ms)
     }
     *a2a_ms = ms->a2a_ms;
     return BT_OK;
+}
+
+int bt_mgpu_route(bt_context *ctx, bt_mgpu_comm *comm, int particle_set, int direction, int elem_size,
+                  const void *in, void *out)
+{
+    return peer_result(comm, bt_mgpu_route_body(ctx, comm, particle_set, direction, elem_size, in, out, false));
+}
+
+int bt_mgpu_global_ids(bt_context *ctx, bt_mgpu_comm *comm, int particle_set, int id_size, void *ids)
+{
+    return peer_result(comm, bt_mgpu_route_body(ctx, comm, particle_set, BT_ROUTE_TO_OWNERS, id_size, nullptr, ids, true));
 }
 
 int bt_mgpu_number(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_local_tree *tree,

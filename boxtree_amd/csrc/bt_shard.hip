@@ -346,6 +346,78 @@ struct PpArgs {
     U *send, *recv;
 };
 
+// The tables of one tile (a wave's PP_WAVE_ITEMS particles), from the scanned counts: s_base[r] =
+// first slot of owner r's run in the wave's owner-major order, s_run[r] = its length, s_goff[r]
+// = the run's first record in the send layout.  Returns the number of particles of the tile.
+__device__ __forceinline__ int32_t pp_tile_tables(const int32_t *offsets, int64_t nwaves, int64_t wave, int nranks,
+                                                  int lane, int32_t *s_base, int32_t *s_run, int32_t *s_goff)
+{
+    int32_t carry = 0;
+    for (int r0 = 0; r0 < nranks; r0 += 64) {
+        const int r = r0 + lane;
+        int32_t g = 0, c = 0;
+        if (r < nranks) {
+            const int64_t at = (int64_t) r * nwaves + wave;
+            g = offsets[at];
+            c = offsets[at + 1] - g;
+        }
+        int32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (r < nranks) { s_base[r] = carry + incl - c; s_run[r] = c; s_goff[r] = g; }
+        carry += __shfl(incl, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    return carry;
+}
+
+// slot[j] = place of row j's particle in the wave's owner-major, stable order (-1 past the end
+// of the input).  SMALL (at most PP_SMALL owners): a row is ranked by one ballot per owner, no
+// LDS traffic and no barriers; otherwise s_run (an owner's count) is counted down, rows last to
+// first.  The SAME function ranks the payload sweep of the exchange and every later
+// bt_mgpu_route over its plan: the send order is a pure function of (owners, offsets).
+template <bool SMALL>
+__device__ __forceinline__ void pp_rank_rows(const uint32_t (&d)[PP_ROWS], int nranks, int bits, int lane,
+                                             const int32_t *s_base, int32_t *s_run, int32_t (&slot)[PP_ROWS])
+{
+    const uint64_t lt = (1ull << lane) - 1ull;
+    if constexpr (SMALL) {
+#pragma unroll
+        for (int j = 0; j < PP_ROWS; ++j) slot[j] = -1;
+        for (int r = 0; r < nranks; ++r) {
+            int32_t at = s_base[r];                     // (uniform)
+#pragma unroll
+            for (int j = 0; j < PP_ROWS; ++j) {
+                const bool is = d[j] == (uint32_t) r;
+                const uint64_t m = __ballot(is);
+                if (is) slot[j] = at + (int32_t) __popcll(m & lt);
+                at += (int32_t) __popcll(m);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = PP_ROWS - 1; j >= 0; --j) {
+            const bool in = d[j] < (uint32_t) nranks;
+            const uint64_t mask = pp_match(d[j], bits + 1);
+            const uint64_t above = mask & ~(lt | (1ull << lane));
+            int32_t left = 0, sb = 0;
+            if (in) { left = s_run[d[j]]; sb = s_base[d[j]]; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (in && above == 0ull) s_run[d[j]] = left - (int32_t) __popcll(mask);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            slot[j] = in ? sb + left - 1 - (int32_t) __popcll(above) : -1;
+        }
+    }
+}
+
 struct __attribute__((packed, aligned(4))) PpWords4 { uint32_t x, y, z, w; };
 
 // dynamic LDS: per wave PP_WAVE_ITEMS records, then per wave three tables of `nr_pad` words
@@ -364,7 +436,6 @@ __global__ __launch_bounds__(64 * PP_WAVES) void pp_scatter_kernel(PpArgs<U, D> 
     int32_t *s_run = s_base + nr_pad;
     int32_t *s_goff = s_run + nr_pad;
     const int64_t self_delta = a.self_offsets ? a.self_offsets[1] - a.self_offsets[0] : a.self_delta;
-    const uint64_t lt = (1ull << lane) - 1ull;
     const int64_t wave = (int64_t) blockIdx.x * PP_WAVES + w;
     if (wave < a.nwaves) {
         // every load of the tile first
@@ -383,63 +454,11 @@ __global__ __launch_bounds__(64 * PP_WAVES) void pp_scatter_kernel(PpArgs<U, D> 
             for (int ax = 0; ax < D; ++ax) v[j][ax] = i < a.n ? a.in[ax][i] : (U) 0;
         }
 
-        // the tile's counts per owner (from the scanned table) -> where an owner's run starts
-        // in the staging area
-        int32_t carry = 0;
-        for (int r0 = 0; r0 < a.nranks; r0 += 64) {
-            const int r = r0 + lane;
-            int32_t g = 0, c = 0;
-            if (r < a.nranks) {
-                const int64_t at = (int64_t) r * a.nwaves + wave;
-                g = a.offsets[at];
-                c = a.offsets[at + 1] - g;
-            }
-            int32_t incl = c;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int32_t t = __shfl_up(incl, off);
-                if (lane >= off) incl += t;
-            }
-            if (r < a.nranks) { s_base[r] = carry + incl - c; s_run[r] = c; s_goff[r] = g; }
-            carry += __shfl(incl, 63);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // rows in order: rank within the owner's run, record into the staging area
+        // the tile's counts per owner -> where an owner's run starts in the staging area; rows
+        // in order: rank within the owner's run
+        const int32_t carry = pp_tile_tables(a.offsets, a.nwaves, wave, a.nranks, lane, s_base, s_run, s_goff);
         int32_t slot[PP_ROWS];
-        if constexpr (SMALL) {
-#pragma unroll
-            for (int j = 0; j < PP_ROWS; ++j) slot[j] = -1;
-            for (int r = 0; r < a.nranks; ++r) {
-                int32_t at = s_base[r];                     // (uniform)
-#pragma unroll
-                for (int j = 0; j < PP_ROWS; ++j) {
-                    const bool is = d[j] == (uint32_t) r;
-                    const uint64_t m = __ballot(is);
-                    if (is) slot[j] = at + (int32_t) __popcll(m & lt);
-                    at += (int32_t) __popcll(m);
-                }
-            }
-        } else {
-            // (s_run holds an owner's count: rows are visited last to first and count it down)
-#pragma unroll
-            for (int j = PP_ROWS - 1; j >= 0; --j) {
-                const bool in = d[j] < (uint32_t) a.nranks;
-                const uint64_t mask = pp_match(d[j], a.bits + 1);
-                const uint64_t above = mask & ~(lt | (1ull << lane));
-                int32_t left = 0, sb = 0;
-                if (in) { left = s_run[d[j]]; sb = s_base[d[j]]; }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (in && above == 0ull) s_run[d[j]] = left - (int32_t) __popcll(mask);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                slot[j] = in ? sb + left - 1 - (int32_t) __popcll(above) : -1;
-            }
-        }
+        pp_rank_rows<SMALL>(d, a.nranks, a.bits, lane, s_base, s_run, slot);
 #pragma unroll
         for (int j = 0; j < PP_ROWS; ++j) {
             if (slot[j] >= 0) {
@@ -484,7 +503,8 @@ template <class U, int D>
 int partition_pack_impl(bt_context *ctx, const void *const *in, const uint32_t *cells, int64_t n,
                         const int32_t *owner_of_cell, int ncells, int nranks, int self_rank,
                         int64_t self_send_offset, int64_t self_recv_offset, const int64_t *d_self_offsets,
-                        void *send, void *recv, bool wait)
+                        void *send, void *recv, bool wait, Buf<uint8_t> *keep_owners = nullptr,
+                        Buf<int32_t> *keep_offsets = nullptr)
 {
     const int64_t nwaves = div_up(n, PP_WAVE_ITEMS);
     int bits = 0;
@@ -519,12 +539,104 @@ int partition_pack_impl(bt_context *ctx, const void *const *in, const uint32_t *
     if (small) pp_scatter_kernel<U, D, true><<<sblocks, 64 * PP_WAVES, lds, ctx->stream>>>(a, nr_pad);
     else pp_scatter_kernel<U, D, false><<<sblocks, 64 * PP_WAVES, lds, ctx->stream>>>(a, nr_pad);
     BT_HIP_CHECK(hipGetLastError());
+    // the send plan (one byte per particle + the scanned tile counts): bt_mgpu_route re-ranks
+    // any per-particle array with it
+    if (keep_owners) *keep_owners = std::move(owners);
+    if (keep_offsets) *keep_offsets = std::move(offsets);
     return wait ? bt::finish_call(ctx) : BT_OK;
+}
+
+// ---- any per-particle array over the plan of an exchange ------------------------------------
+//
+// FORWARD: lay[position of particle i in the send layout] = in[i] (in == nullptr: iota_base + i)
+// -- the own segment straight to its place in the owner-order output (self != nullptr).
+// REVERSE: out[i] = lay[position of particle i] (own segment read from the owner-order input).
+// The position is recomputed from (owners, offsets) by the ranking the payload sweep used; 4-
+// or 8-byte elements go directly (an owner's run of a tile is contiguous: lanes of one owner
+// write neighbouring addresses).
+template <class U>
+struct PpRouteArgs {
+    const U *in;
+    U *out;
+    U *lay;                         // send layout [n] (FORWARD: written, REVERSE: read)
+    U *self;                        // owner-order array of this rank, or nullptr (the own segment
+                                    // travels through the send layout like any other)
+    const uint8_t *owners;
+    const int32_t *offsets;
+    int64_t n, nwaves, self_delta, iota_base;
+    int nranks, bits, self_rank;
+};
+
+template <class U, bool SMALL, bool REVERSE>
+__global__ __launch_bounds__(64 * PP_WAVES) void pp_route_kernel(PpRouteArgs<U> a, int nr_pad)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t pp_lds[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int32_t *s_base = reinterpret_cast<int32_t *>(pp_lds) + (size_t) w * 3 * nr_pad;
+    int32_t *s_run = s_base + nr_pad;
+    int32_t *s_goff = s_run + nr_pad;
+    const int64_t wave = (int64_t) blockIdx.x * PP_WAVES + w;
+    if (wave >= a.nwaves) return;
+    const int64_t base = wave * PP_WAVE_ITEMS + lane;
+    uint32_t d[PP_ROWS];
+#pragma unroll
+    for (int j = 0; j < PP_ROWS; ++j) {
+        const int64_t i = base + (int64_t) j * 64;
+        d[j] = i < a.n ? (uint32_t) a.owners[i] : (uint32_t) a.nranks;
+    }
+    (void) pp_tile_tables(a.offsets, a.nwaves, wave, a.nranks, lane, s_base, s_run, s_goff);
+    int32_t slot[PP_ROWS];
+    pp_rank_rows<SMALL>(d, a.nranks, a.bits, lane, s_base, s_run, slot);
+#pragma unroll
+    for (int j = 0; j < PP_ROWS; ++j) {
+        const int64_t i = base + (int64_t) j * 64;
+        if (slot[j] < 0) continue;
+        const int r = (int) d[j];
+        const int64_t pos = (int64_t) s_goff[r] + (slot[j] - s_base[r]);
+        U *where = (r == a.self_rank && a.self) ? a.self + (pos + a.self_delta) : a.lay + pos;
+        if constexpr (REVERSE) a.out[i] = *where;
+        else *where = a.in ? a.in[i] : (U) (a.iota_base + i);
+    }
+}
+
+template <class U>
+int route_impl(bt_context *ctx, bool reverse, const void *in, int64_t iota_base, void *lay, void *self, void *out,
+               const uint8_t *owners, const int32_t *offsets, int64_t n, int nranks, int self_rank,
+               int64_t self_delta)
+{
+    const int64_t nwaves = div_up(n, PP_WAVE_ITEMS);
+    int bits = 0;
+    while ((1 << bits) < nranks) ++bits;
+    PpRouteArgs<U> a{};
+    a.in = (const U *) in; a.out = (U *) out; a.lay = (U *) lay; a.self = (U *) self;
+    a.owners = owners; a.offsets = offsets;
+    a.n = n; a.nwaves = nwaves; a.self_delta = self_delta; a.iota_base = iota_base;
+    a.nranks = nranks; a.bits = bits; a.self_rank = self_rank;
+    const int nr_pad = (nranks + 3) & ~3;
+    const size_t lds = (size_t) PP_WAVES * (size_t) 3 * nr_pad * 4;
+    const unsigned blocks = (unsigned) div_up(nwaves, PP_WAVES);
+    const bool small = nranks <= PP_SMALL;
+    if (small && !reverse) pp_route_kernel<U, true, false><<<blocks, 64 * PP_WAVES, lds, ctx->stream>>>(a, nr_pad);
+    else if (small) pp_route_kernel<U, true, true><<<blocks, 64 * PP_WAVES, lds, ctx->stream>>>(a, nr_pad);
+    else if (!reverse) pp_route_kernel<U, false, false><<<blocks, 64 * PP_WAVES, lds, ctx->stream>>>(a, nr_pad);
+    else pp_route_kernel<U, false, true><<<blocks, 64 * PP_WAVES, lds, ctx->stream>>>(a, nr_pad);
+    BT_HIP_CHECK(hipGetLastError());
+    return BT_OK;
 }
 
 }  // namespace
 
 namespace bt {
+
+int route_device(bt_context *ctx, int elem_size, bool reverse, const void *in, int64_t iota_base, void *lay,
+                 void *self, void *out, const uint8_t *owners, const int32_t *offsets, int64_t n, int nranks,
+                 int self_rank, int64_t self_delta)
+{
+    if (n == 0) return BT_OK;
+    return elem_size == 8
+        ? route_impl<uint64_t>(ctx, reverse, in, iota_base, lay, self, out, owners, offsets, n, nranks, self_rank, self_delta)
+        : route_impl<uint32_t>(ctx, reverse, in, iota_base, lay, self, out, owners, offsets, n, nranks, self_rank, self_delta);
+}
 
 int morton_cells_device(bt_context *ctx, int dims, int coord_kind, const void *const *coords, int64_t n,
                         const void *d_rootbox, int level, uint32_t *cells_out, int32_t *hist_inout)
@@ -557,13 +669,16 @@ int widen_weights_device(bt_context *ctx, const int32_t *weights, int64_t n, int
 
 int partition_pack_device(bt_context *ctx, int dims, int elem_size, const void *const *in,
                           const uint32_t *cells, int64_t n, const int32_t *owner_of_cell, int ncells, int nranks,
-                          int self_rank, const int64_t *d_self_offsets, void *send, void *recv)
+                          int self_rank, const int64_t *d_self_offsets, void *send, void *recv,
+                          Buf<uint8_t> *keep_owners, Buf<int32_t> *keep_offsets)
 {
+    if (keep_owners) keep_owners->reset();
+    if (keep_offsets) keep_offsets->reset();
     if (n == 0) return BT_OK;
     // (dims counts the values of a record: coordinates, and a radius and a refine weight that
     // travel with them)
 #define BT_PP(U, D) partition_pack_impl<U, D>(ctx, in, cells, n, owner_of_cell, ncells, nranks, self_rank, 0, 0, \
-                                              d_self_offsets, send, recv, false)
+                                              d_self_offsets, send, recv, false, keep_owners, keep_offsets)
     if (elem_size == 8)
         return dims == 1 ? BT_PP(uint64_t, 1) : dims == 2 ? BT_PP(uint64_t, 2) : dims == 3 ? BT_PP(uint64_t, 3)
              : dims == 4 ? BT_PP(uint64_t, 4) : BT_PP(uint64_t, 5);

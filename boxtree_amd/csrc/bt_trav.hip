@@ -334,7 +334,11 @@ __device__ __forceinline__ void gen_list4(const TravArgs<T, D> &a, int32_t it, E
     const int pl = tl - 1;
     T pc[D];
     load_center(a, tparent, pc);
-    const uint8_t tflags = box_flags(a, tgt);
+    // (a sharded traversal marks with 2 a shared box whose own targets another rank holds: it has
+    // lists as a parent of target boxes here, but it is not one of this rank's target boxes -- a
+    // close list made for it would be dropped by the re-indexing to target boxes, and counted)
+    const uint8_t tflags = (a.target_mask && a.target_mask[tgt] != 1)
+        ? (uint8_t) (box_flags(a, tgt) & ~BT_BOX_IS_TARGET_BOX) : box_flags(a, tgt);
     int wl; int32_t cur;
     if (a.nway == 1) { wl = tl - 1; cur = tparent; }
     else { wl = tl; cur = tgt; }

@@ -331,6 +331,97 @@ def all_to_all_chunked(dist, recv, send, r_split, s_split, limit_bytes=None,
     return rounds
 
 
+class ParticleRoute:
+    """Particle identity across :func:`exchange_particles` (the torch implementation; the
+    library's own is ``bt_mgpu_route``, :class:`boxtree_amd.distributed.native.ParticleRoute`):
+    the stable send order of every exchanged particle set and the split sizes of its
+    all-to-all-v, with which any per-particle array travels between the order of this rank's
+    chunk and the order of the received particles -- the order ``user_source_ids`` /
+    ``sorted_target_ids`` of the rank's tree refer to.  What the reference keeps for the same
+    purpose: ``src_idx`` / ``tgt_idx`` (boxtree/distributed/__init__.py:238-248,
+    distributed/calculation.py:86-142).  Every method is collective."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self._sets = {}
+        self._offsets = {}
+
+    def _add(self, which, n, nrecv, s_split, r_split, order_fn):
+        self._sets[which] = dict(n=int(n), nrecv=int(nrecv), s_split=list(s_split),
+                                 r_split=list(r_split), order_fn=order_fn, order=None)
+
+    def _get(self, which):
+        if which not in ("sources", "targets"):
+            raise ValueError("which must be 'sources' or 'targets'")
+        if which not in self._sets:
+            raise ValueError("no separate targets were exchanged")
+        st = self._sets[which]
+        if st["order"] is None:
+            st["order"] = st["order_fn"]().long()
+        return st
+
+    def n_owned(self, which="sources"):
+        return self._get(which)["nrecv"]
+
+    def to_owners(self, array, which="sources"):
+        """``[n]`` in the chunk's order -> ``[n_owned]`` in the order of the received particles."""
+        import torch
+        st = self._get(which)
+        if len(array) != st["n"]:
+            raise ValueError(f"ParticleRoute: {len(array)} values for {st['n']} {which}")
+        send = array[st["order"]].contiguous()
+        recv = torch.empty(st["nrecv"], dtype=array.dtype, device=array.device)
+        all_to_all_chunked(self.dist, recv, send, st["r_split"], st["s_split"])
+        return recv
+
+    def to_callers(self, array, which="sources"):
+        """The inverse: ``[n_owned]`` in received order -> ``[n]`` in the chunk's order."""
+        import torch
+        st = self._get(which)
+        if len(array) != st["nrecv"]:
+            raise ValueError(f"ParticleRoute: {len(array)} values for {st['nrecv']} owned {which}")
+        back = torch.empty(st["n"], dtype=array.dtype, device=array.device)
+        all_to_all_chunked(self.dist, back, array.contiguous(), st["s_split"], st["r_split"])
+        out = torch.empty_like(back)
+        out[st["order"]] = back
+        return out
+
+    def chunk_offset(self, which="sources"):
+        """(global id of this chunk's first particle, number of particles of all chunks)"""
+        import torch
+        st = self._get(which)
+        if which not in self._offsets:
+            world, rank = self.dist.get_world_size(), self.dist.get_rank()
+            mine = torch.zeros(world, dtype=torch.int64, device=st["order"].device)
+            mine[rank] = st["n"]
+            self.dist.all_reduce(mine)
+            counts = mine.cpu().tolist()
+            self._offsets[which] = (int(sum(counts[:rank])), int(sum(counts)))
+        return self._offsets[which]
+
+    def global_ids(self, which="sources", dtype=None):
+        """Global user id of every received particle: the sender's chunk offset + the index in
+        its chunk (int32 like the reference's ``particle_id_t`` unless *dtype* says otherwise)."""
+        import torch
+        st = self._get(which)
+        off, total = self.chunk_offset(which)
+        dtype = dtype or torch.int32
+        if dtype == torch.int32 and total > np.iinfo(np.int32).max:
+            raise NotImplementedError(f"{total} particles do not fit int32 ids; pass dtype=torch.int64")
+        ids = torch.arange(off, off + st["n"], dtype=dtype, device=st["order"].device)
+        return self.to_owners(ids, which)
+
+    def global_user_source_ids(self, tree):
+        """This rank's share of the global tree's ``user_source_ids`` (tree.py:426-431)."""
+        return self.global_ids("sources")[tree.user_source_ids.long()]
+
+    def global_sorted_target_ids(self, tree, target_offset):
+        """The global tree's ``sorted_target_ids`` (tree.py:433-438) for the targets of this rank's
+        chunk, in the chunk's order."""
+        which = "targets" if "targets" in self._sets else "sources"
+        return self.to_callers(tree.sorted_target_ids + int(target_offset), which)
+
+
 def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
                        top_level=None, return_plan=False, max_particles_in_box=None):
     """Steps 1-4.  Returns ``(particles, targets, build_kw, stats)`` for the local
@@ -417,6 +508,8 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
     tick("plan (host)")
 
     stats = {"bytes_sent": 0, "top_level": top_level}
+    plan_route = ParticleRoute(dist)
+    stats["route"] = plan_route
 
     def send_order(cells, local_hist):
         """(order, send_counts): original indices grouped by owner, stable."""
@@ -462,7 +555,7 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         e1.record()
         stats.setdefault("a2a_events", []).append((e0, e1))
 
-    def route(arrs, cells, local_hist, extra, keep_interleaved=False):
+    def route(arrs, cells, local_hist, extra, keep_interleaved=False, which="sources"):
         """all-to-all-v of the coordinate arrays (+ extras) by owner of `cells`."""
         # coordinates alone are partitioned by owner in one sweep that writes the send buffer
         # (bt_partition_pack); arrays that travel with them need the permutation
@@ -484,6 +577,11 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
         nrecv = int(sum(r_split))
         outs = []
         d_ = len(arrs)
+        # particle identity: the send order (made on demand where the one-sweep partition never
+        # materialises it) + the splits, for ParticleRoute
+        kept = order
+        plan_route._add(which, len(arrs[0]), nrecv, s_split, r_split,
+                        (lambda: kept) if kept is not None else (lambda: send_order(cells, local_hist)[0]))
         if native:
             # coordinates travel interleaved: one message per peer instead of d
             import ctypes as ct
@@ -552,7 +650,8 @@ def exchange_particles(actx, dist, particles, targets=None, build_kw=None,
     new_targets = None
     if targets is not None:
         new_targets, extra = route(
-            targets, tgt_cells, tgt_hist, [target_radii] if target_radii is not None else [])
+            targets, tgt_cells, tgt_hist, [target_radii] if target_radii is not None else [],
+            which="targets")
         if target_radii is not None:
             build_kw["target_radii"] = extra[0]
 

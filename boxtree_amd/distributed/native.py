@@ -127,19 +127,169 @@ def exchange_time_ms(actx):
 
 
 class _LazyA2aTime:
-    """``float(stats["a2a_ms"])``: resolved when asked for -- on a stream-ordered context the
-    exchange returns with the all-to-all-v still queued."""
+    """``stats["a2a_ms"]`` of an exchange on a stream-ordered context, which returns with the
+    all-to-all-v still queued: a number that is resolved when first used (``float()``,
+    formatting, arithmetic, comparisons).  The library keeps ONE event pair per context, so
+    the value must be read before the next exchange on the same context: a later one
+    invalidates it (``float()`` then raises instead of reporting another exchange's time)."""
 
-    def __init__(self, actx, value):
-        self.actx, self.value = actx, value
+    def __init__(self, actx, serial):
+        self.actx, self.serial, self.value = actx, serial, None
 
     def __float__(self):
-        if self.value < 0:
+        if self.value is None:
+            if getattr(self.actx, "_mgpu_exchange_serial", None) != self.serial:
+                raise RuntimeError("a2a_ms was not read before the next exchange on this context")
             self.value = exchange_time_ms(self.actx)
-        return float(self.value)
+        return self.value
+
+    def __format__(self, spec):
+        return format(float(self), spec)
+
+    def __repr__(self):
+        return repr(float(self))
+
+    def __bool__(self):
+        return float(self) != 0.0
+
+    def __round__(self, ndigits=None):
+        return round(float(self), ndigits)
+
+    def __eq__(self, other):
+        return float(self) == other
+
+    def __lt__(self, other):
+        return float(self) < other
+
+    def __le__(self, other):
+        return float(self) <= other
 
     def __gt__(self, other):
         return float(self) > other
+
+    def __ge__(self, other):
+        return float(self) >= other
+
+    def __hash__(self):
+        return hash(float(self))
+
+    def __add__(self, other):
+        return float(self) + other
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return float(self) - other
+
+    def __rsub__(self, other):
+        return other - float(self)
+
+    def __mul__(self, other):
+        return float(self) * other
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, other):
+        return float(self) / other
+
+    def __rtruediv__(self, other):
+        return other / float(self)
+
+    def __neg__(self):
+        return -float(self)
+
+
+def _a2a_time(actx, shard):
+    """Device time of the payload all-to-all-v: a float where the exchange waited for it, a
+    number resolved on first use on a stream-ordered context."""
+    serial = getattr(actx, "_mgpu_exchange_serial", 0) + 1
+    actx._mgpu_exchange_serial = serial
+    if float(shard.a2a_ms) >= 0:
+        return float(shard.a2a_ms)
+    return _LazyA2aTime(actx, serial)
+
+
+class ParticleRoute:
+    """Particle identity across the exchange (``bt_mgpu_route`` / ``bt_mgpu_global_ids``): moves
+    any per-particle array between the order of this rank's chunk -- the *particles* /
+    *targets* handed to :func:`exchange_particles` -- and the order of what the rank received,
+    which is what ``user_source_ids`` / ``sorted_target_ids`` of the rank's tree index.  The
+    reference keeps the same map as index arrays on the root rank
+    (boxtree/distributed/__init__.py:238-248 ``src_idx`` / ``tgt_idx``) and uses it to hand out
+    source weights and to collect potentials (distributed/calculation.py:86-142).  Valid until
+    the next exchange on the context; every method is collective over the ranks."""
+
+    def __init__(self, actx, comm, shard, n_sources, n_targets):
+        self.actx, self.comm = actx, comm
+        have_targets = n_targets is not None
+        self.n = {"sources": int(n_sources), "targets": int(n_targets) if have_targets else None}
+        self.n_owned = {"sources": int(shard.n_owned),
+                        "targets": int(shard.n_owned_targets) if have_targets else None}
+        self.chunk_offset = {"sources": int(shard.source_chunk_offset),
+                             "targets": int(shard.target_chunk_offset) if have_targets else None}
+        self.n_global = {"sources": int(shard.n_global_sources),
+                         "targets": int(shard.n_global_targets) if have_targets else None}
+
+    def _set(self, which):
+        if which not in ("sources", "targets"):
+            raise ValueError("which must be 'sources' or 'targets'")
+        if self.n_owned[which] is None:
+            raise ValueError("no separate targets were exchanged")
+        return 0 if which == "sources" else 1
+
+    def _route(self, array, which, direction, n_in, n_out):
+        import torch
+        if array.dim() != 1 or array.element_size() not in (4, 8):
+            raise TypeError("ParticleRoute: 1-D arrays of 4- or 8-byte elements")
+        if len(array) != n_in:
+            raise ValueError(f"ParticleRoute: {len(array)} values for {n_in} {which}")
+        a = array.contiguous()
+        out = torch.empty(n_out, dtype=a.dtype, device=a.device)
+        self.actx.sync_in()
+        _lib.check(self.actx.lib.bt_mgpu_route(
+            self.actx.handle, self.comm.handle, self._set(which), direction, a.element_size(),
+            ct.c_void_p(a.data_ptr()), ct.c_void_p(out.data_ptr())))
+        return out
+
+    def to_owners(self, array, which="sources"):
+        """*array* ``[n]`` in the order of this rank's chunk -> ``[n_owned]`` in the order of the
+        received particles."""
+        self._set(which)
+        return self._route(array, which, _lib.BT_ROUTE_TO_OWNERS, self.n[which], self.n_owned[which])
+
+    def to_callers(self, array, which="sources"):
+        """The inverse: ``[n_owned]`` in received order -> ``[n]`` in the chunk's order."""
+        self._set(which)
+        return self._route(array, which, _lib.BT_ROUTE_TO_CALLERS, self.n_owned[which], self.n[which])
+
+    def global_ids(self, which="sources", dtype=None):
+        """Global user id of every received particle (int32 like the reference's
+        ``particle_id_t``; ``torch.int64`` on request): ``chunk_offset`` of the sending rank +
+        index in its chunk, i.e. the index in the concatenation of the ranks' chunks."""
+        import torch
+        dtype = dtype or torch.int32
+        iset = self._set(which)
+        out = torch.empty(self.n_owned[which], dtype=dtype, device=f"cuda:{self.actx.device_index}")
+        self.actx.sync_in()
+        _lib.check(self.actx.lib.bt_mgpu_global_ids(
+            self.actx.handle, self.comm.handle, iset, out.element_size(),
+            ct.c_void_p(out.data_ptr())))
+        return out
+
+    # the two index arrays of the single-GPU Tree (tree.py:426-438), this rank's share
+
+    def global_user_source_ids(self, tree):
+        """``user_source_ids`` of the global tree for this rank's sources: entry ``j`` is entry
+        ``numbering["source_offset"] + j`` of the array one GPU builds from the concatenated
+        chunks."""
+        return self.global_ids("sources")[tree.user_source_ids.long()]
+
+    def global_sorted_target_ids(self, tree, target_offset):
+        """``sorted_target_ids`` of the global tree for the targets of this rank's CHUNK, in the
+        chunk's order: where each of them sits in the global tree's target order
+        (*target_offset*: ``numbering["target_offset"]``)."""
+        which = "targets" if self.n_owned["targets"] is not None else "sources"
+        return self.to_callers(tree.sorted_target_ids + int(target_offset), which)
 
 
 def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=None,
@@ -218,6 +368,7 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
     if targets is not None:
         res = _exchanged_with_targets(actx, shard, bufs if own_buffer else [], dims, dtype, es, dev,
                                       max_leaf_refine_weight)
+        res[-1]["route"] = ParticleRoute(actx, comm, shard, par.n, par.ntargets)
         if target_radii is None:
             return res
         p2, t2, kw, stats = res
@@ -251,9 +402,10 @@ def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=No
         build_kw["_top_tree"] = (k, prefix) + _top_tables(shard, dims, k, dev)
     _weights_kw(build_kw, shard, n_owned, 0, max_leaf_refine_weight, dev)
     stats = dict(bytes_sent=int(shard.bytes_sent), rounds=int(shard.rounds), top_level=k,
-                 a2a_ms=_LazyA2aTime(actx, float(shard.a2a_ms)),
+                 a2a_ms=_a2a_time(actx, shard),
                  bbox_min=bbox_min, bbox_max=bbox_max, root_extent=root_extent,
-                 planned=bool(shard.top_cell_prefix), recv_buffer=got.get("buf"))
+                 planned=bool(shard.top_cell_prefix), recv_buffer=got.get("buf"),
+                 route=ParticleRoute(actx, comm, shard, par.n, None))
     return new_particles, build_kw, stats
 
 
@@ -327,7 +479,7 @@ def _exchanged_with_targets(actx, shard, bufs, dims, dtype, es, dev, max_leaf_re
         build_kw["_top_tree"] = (k, prefix) + _top_tables(shard, dims, k, dev)
     _weights_kw(build_kw, shard, ns, nt, max_leaf_refine_weight, dev)
     stats = dict(bytes_sent=int(shard.bytes_sent), rounds=int(shard.rounds), top_level=k,
-                 a2a_ms=_LazyA2aTime(actx, float(shard.a2a_ms)), bbox_min=bbox_min, bbox_max=bbox_max,
+                 a2a_ms=_a2a_time(actx, shard), bbox_min=bbox_min, bbox_max=bbox_max,
                  root_extent=root_extent, planned=bool(shard.top_cell_prefix))
     return out[0], out[1], build_kw, stats
 
@@ -468,8 +620,9 @@ def sharded_tree_and_lists(actx, comm, particles, max_particles_in_box=None, tar
     numbers), ``numbering`` (:func:`number_sharded_tree`: ``box_ids`` maps them to the
     global tree's), ``let`` / ``let_info`` (:func:`build_local_essential_tree`:
     ``let_info["global_box_ids"]`` maps LET boxes to global numbers), ``traversal`` (lists
-    on the LET for the boxes with ``let_info["target_boxes_mask"]``) and ``exchange`` (bytes
-    sent, device time of the all-to-all-v, root box)."""
+    on the LET for the boxes with ``let_info["target_boxes_mask"]``), ``exchange`` (bytes
+    sent, device time of the all-to-all-v, root box) and ``route`` (:class:`ParticleRoute`:
+    per-particle data between the caller's order and the tree's, global user ids)."""
     from boxtree_amd import FMMTraversalBuilder, TreeBuilder
     tb = tree_builder or TreeBuilder(actx)
     tg = traversal_builder or FMMTraversalBuilder(actx, well_sep_is_n_away=well_sep_is_n_away)
@@ -491,4 +644,5 @@ def sharded_tree_and_lists(actx, comm, particles, max_particles_in_box=None, tar
     let, info = build_local_essential_tree(actx, comm, tree, num, well_sep_is_n_away=well_sep_is_n_away)
     trav, _ = tg(actx, let, _target_boxes_mask=info["target_boxes_mask"],
                  _active_level_ranges=info["active_level_ranges"])
-    return dict(tree=tree, numbering=num, let=let, let_info=info, traversal=trav, exchange=xs)
+    return dict(tree=tree, numbering=num, let=let, let_info=info, traversal=trav, exchange=xs,
+                route=xs["route"])

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BT_ABI_VERSION 9
+#define BT_ABI_VERSION 10
 #define BT_MAX_DIMS 3
 #define BT_MAX_LEVELS 64       /* capacity of per-level arrays in the structs */
 
@@ -638,6 +638,11 @@ typedef struct {
                                        /* bt_tree_params.refine_weights); owned by the context */
     const int64_t *top_box_arrive, *top_box_stay;   /* device tables for bt_tree_params with   */
                                        /* extents (levels 0..top_level), else NULL           */
+    /* particle identity: global user ids number the ranks' chunks in rank order (the input */
+    /* a single GPU would be given is their concatenation); particle i of this rank's chunk  */
+    /* is global particle source_chunk_offset + i (targets likewise)                         */
+    int64_t source_chunk_offset, target_chunk_offset;
+    int64_t n_global_sources, n_global_targets;
 } bt_mgpu_shard;
 
 /* the one-sweep partition (bt_partition_pack) keeps one run per owner in LDS: at most this
@@ -654,6 +659,35 @@ typedef struct {
  * of every cell) for bt_mgpu_number and bt_mgpu_let_build. */
 int bt_mgpu_exchange(bt_context *ctx, bt_mgpu_comm *comm, const bt_mgpu_params *params,
                      bt_mgpu_shard *out);
+
+/* Particle identity across the exchange (what the reference keeps as
+ * src_idx / tgt_idx, boxtree/distributed/__init__.py:238-248, and uses to hand out source
+ * weights and collect potentials, distributed/calculation.py:86-142).  The received records carry
+ * no ids: the exchange keeps its stable send plan instead -- the owner of every chunk particle
+ * (one byte) and the scanned per-tile counts, from which the partition kernel's own ranking
+ * reproduces every particle's place -- and bt_mgpu_route moves ANY per-particle array of 4- or
+ * 8-byte elements over that plan (one all-to-all-v of elem_size bytes per particle that changes
+ * rank; nothing rides on the coordinate exchange):
+ *   BT_ROUTE_TO_OWNERS   in: [n] in the order of this rank's chunk (bt_mgpu_params.coords /
+ *                        .targets)  ->  out: [n_owned] in the order of the receive buffer, the
+ *                        order bt_tree_arrays.user_source_ids / sorted_target_ids of the
+ *                        rank's tree refer to;
+ *   BT_ROUTE_TO_CALLERS  the inverse: [n_owned] -> [n].
+ * particle_set: 0 sources, 1 separate targets.  Collective: every rank of the exchange calls it
+ * with the same particle_set, direction and elem_size, after bt_mgpu_exchange and before the
+ * next one on this context.  Source weights given in the caller's order reach tree order by
+ * TO_OWNERS and a gather through user_source_ids; potentials in tree order go back by a gather
+ * through sorted_target_ids and TO_CALLERS. */
+#define BT_ROUTE_TO_OWNERS 0
+#define BT_ROUTE_TO_CALLERS 1
+int bt_mgpu_route(bt_context *ctx, bt_mgpu_comm *comm, int particle_set, int direction, int elem_size,
+                  const void *in, void *out);
+/* The global user id (bt_mgpu_shard.source_chunk_offset + index in its chunk) of every OWNED
+ * particle, in receive-buffer order: ids [n_owned] of id_size 4 (int32, the reference's
+ * particle_id_t; BT_ERR_UNSUPPORTED past 2^31 - 1 particles) or 8 bytes.  ids[user_source_ids[j]]
+ * of the rank's tree is entry source_offset + j of the single-GPU tree's user_source_ids
+ * (bt_mgpu_numbering).  Same collective rules as bt_mgpu_route (it is one). */
+int bt_mgpu_global_ids(bt_context *ctx, bt_mgpu_comm *comm, int particle_set, int id_size, void *ids);
 
 /* Device time of the last exchange's payload all-to-all-v on this context, in milliseconds
  * (waits for it if it is still running). */

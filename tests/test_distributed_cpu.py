@@ -39,8 +39,19 @@ def _worker(rank, world, port, dims, with_targets, q):
                   "stick_out_factor": 0.25}
         newp, newt, nkw, st = exchange_particles(None, dist, pts, tgts, kw, return_plan=True)
         cells = morton_cells(newp, st["bbox_min"], st["bbox_max"], st["top_level"]).numpy()
+        # particle identity: global ids of what arrived, per-particle arrays to
+        # the owners and back over the exchange's own plan -- several rounds with the 20-kB limit
+        route = st["route"]
+        gids = route.global_ids("sources").numpy()
+        back = route.to_callers(route.to_owners(pts[0], "sources"), "sources")
+        ident = dict(gids=gids, x_owned=route.to_owners(pts[0], "sources").numpy(),
+                     round_trip=bool(torch.equal(back, pts[0])), offset=route.chunk_offset("sources"))
+        if with_targets:
+            ident["tgids"] = route.global_ids("targets", dtype=torch.int64).numpy()
+            ident["t_round_trip"] = bool(torch.equal(
+                route.to_callers(route.to_owners(tgts[1], "targets"), "targets"), tgts[1]))
         res = dict(
-            rank=rank,
+            rank=rank, ident=ident,
             sent=np.stack([p.numpy() for p in pts]),
             got=np.stack([p.numpy() for p in newp]),
             owner=st["owner"],
@@ -94,6 +105,21 @@ def test_exchange_world2(dims, with_targets):
     # every rank received exactly the particles of the cells it owns
     for r in results:
         assert np.all(owner[r["cells"]] == r["rank"])
+    # particle identity: received particle j is particle gids[j] of the concatenated chunks;
+    # ids ascend within what one sender sent (stable exchange), arrays come home unchanged
+    off = 0
+    for r in results:
+        idn = r["ident"]
+        assert idn["gids"].dtype == np.int32 and idn["round_trip"]
+        assert idn["offset"] == (off, sent.shape[1])
+        off += r["sent"].shape[1]
+        assert np.array_equal(sent[:, idn["gids"]], r["got"])
+        assert np.array_equal(sent[0, idn["gids"]], idn["x_owned"])
+        if with_targets:
+            assert idn["tgids"].dtype == np.int64 and idn["t_round_trip"]
+            assert np.array_equal(tsent[:, idn["tgids"]], r["tgot"])
+    assert np.array_equal(np.sort(np.concatenate([r["ident"]["gids"] for r in results])),
+                          np.arange(sent.shape[1]))
     # root box covers everything and is square
     bbox = results[0]["bbox"]
     assert np.all(bbox[:, 0] <= sent.min(axis=1)) and np.all(bbox[:, 1] > sent.max(axis=1))

@@ -1457,6 +1457,12 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
         mine_deep = hm & (t.box_levels > top_level)
         assert np.array_equal(mapped[:, mine_deep], g.box_child_ids[:, gid[mine_deep]])
         deep_cover[gid[mine_deep]] += 1
+        # every list array ends where its starts say (no slack behind the last row)
+        for name in ("same_level_non_well_sep_boxes", "neighbor_source_boxes", "from_sep_siblings",
+                     "from_sep_bigger", "from_sep_close_smaller", "from_sep_close_bigger"):
+            st_, li_ = getattr(tr, name + "_starts", None), getattr(tr, name + "_lists", None)
+            if st_ is not None:
+                assert len(li_) == st_[-1], name
         # lists, mapped to global numbers
         gt_boxes = gid[tr.target_boxes]
         assert np.all(hm1[tr.target_boxes])
