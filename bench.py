@@ -149,6 +149,9 @@ def make_workload_numpy(workload, n, seed):
     raise ValueError(workload)
 
 
+# N > 1 steps produce the global user ids of the received particles (BOXTREE_HIP_BENCH_IDS=0: a
+# step without them, for comparison with round 4's lines)
+WITH_IDS = os.environ.get("BOXTREE_HIP_BENCH_IDS", "1") != "0"
 WORKLOAD_MPB = {"c1": 30}      # max_particles_in_box of a workload (64 unless listed)
 
 # }}}
@@ -361,14 +364,14 @@ def main():
     native_kw_ok = set(build_kw) <= {"target_radii", "stick_out_factor", "extent_norm"}
     if (distributed and backend == "nccl" and native_kw_ok
             and os.environ.get("BOXTREE_HIP_NATIVE_MGPU", "1") != "0"):
+        # (no fallback: a job on RCCL that cannot make its communicator ends here, so that a
+        # timing can never silently be of the other implementation)
         from boxtree_amd.distributed import native as nat
-        try:
-            native_comm = nat.rccl_comm(actx, dist)
-        except (RuntimeError, OSError) as e:
-            # (every rank fails or succeeds alike: the same library, the same call)
-            print(f"bench.py: no RCCL communicator of our own ({e}); the torch.distributed "
-                  "implementation of the sharded build runs instead", file=sys.stderr)
-            native_comm = None
+        native_comm = nat.rccl_comm(actx, dist)
+    # which implementation of the sharded build this job times (config.sharded_impl)
+    sharded_impl = None
+    if distributed:
+        sharded_impl = "bt_mgpu" if native_comm is not None else "torch"
 
     stage_acc: dict[str, float] = {}
     sort_ms = []
@@ -418,11 +421,24 @@ def main():
                 # separate point targets travel to the owners of their cells like the sources
                 p_, t_, kw_, xs = nat.exchange_particles(actx, native_comm, particles, args.mpb,
                                                          targets=targets)
-            last_exchange.update(bytes_sent=int(xs["bytes_sent"]), owned=int(len(p_[0])),
-                                 a2a_ms=xs["a2a_ms"])
             tree, _ = tb(actx, p_, targets=t_, max_particles_in_box=args.mpb, **kw_)
             st = _lib.SortStats()
             actx.lib.bt_get_sort_stats(actx.handle, st)
+            # particle identity (part of the step: a Tree comes with user_source_ids that name the
+            # caller's particles): global user ids of what this rank received, over the exchange's
+            # kept plan -- 4 more bytes per particle that changed rank, in messages of their own
+            route = xs["route"]
+            id_bytes = 0
+            if WITH_IDS:
+                gids = route.global_ids("sources")
+                id_bytes = 4 * route.n_sent["sources"]
+                if t_ is not None:
+                    tgids = route.global_ids("targets")
+                    id_bytes += 4 * route.n_sent["targets"]
+                    del tgids
+                del gids
+            last_exchange.update(bytes_sent=int(xs["bytes_sent"]), owned=int(len(p_[0])),
+                                 a2a_ms=xs["a2a_ms"], id_bytes=id_bytes)
             num = nat.number_sharded_tree(actx, native_comm, tree)
             gtree, let = nat.build_local_essential_tree(actx, native_comm, tree, num)
             trav, _ = tg(actx, gtree, _target_boxes_mask=let["target_boxes_mask"],
@@ -442,8 +458,16 @@ def main():
             from boxtree_amd.distributed import exchange_particles
             p_, t_, kw_, xs = exchange_particles(
                 actx, dist, particles, targets, build_kw, max_particles_in_box=args.mpb)
+            id_bytes = 0
+            if WITH_IDS:
+                # (as on the bt_mgpu_* path: global user ids of the received particles)
+                for which, arrs in (("sources", particles), ("targets", targets)):
+                    if arrs is not None:
+                        g_ = xs["route"].global_ids(which)
+                        id_bytes += 4 * (len(arrs[0]) - xs["route"]._get(which)["s_split"][rank])
+                        del g_
             last_exchange.update(bytes_sent=int(xs["bytes_sent"]), owned=int(len(p_[0])),
-                                 events=xs.get("a2a_events", []))
+                                 events=xs.get("a2a_events", []), id_bytes=id_bytes)
         tree, _ = tb(actx, p_, targets=t_, max_particles_in_box=args.mpb, **kw_)
         st = _lib.SortStats()
         actx.lib.bt_get_sort_stats(actx.handle, st)
@@ -495,28 +519,21 @@ def main():
     actx.set_stage_timing(False)      # ~30 event records per step; see step()
     if native_comm is not None and world > 1:
         # One untimed step through the library's own RCCL entries before anything is measured,
-        # and an agreement over torch's process group that it worked on every rank: a failure
-        # the ranks share (an RCCL this build cannot talk to) moves the job to the
-        # torch.distributed implementation of the same steps instead of ending it.  (A rank
-        # that fails alone inside a collective leaves its peers waiting, here as anywhere.)
-        ok = 1
+        # and an agreement over torch's process group that it worked on every rank: if it did
+        # not, every rank ends the job (bench.py does not move a job to the torch implementation:
+        # BOXTREE_HIP_NATIVE_MGPU=0 selects that one, and the line then says so).
+        ok, why = 1, ""
         try:
             step()
             actx.synchronize()
         except (RuntimeError, OSError, ValueError) as e:
-            ok = 0
+            ok, why = 0, str(e)
             print(f"bench.py: rank {rank}: the bt_mgpu_* path failed ({e})", file=sys.stderr)
         flag = torch.tensor([ok], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            if rank == 0:
-                print("bench.py: the torch.distributed implementation of the sharded build runs instead",
-                      file=sys.stderr)
-            try:
-                native_comm.close()
-            except (RuntimeError, OSError):
-                pass
-            native_comm = None
+            raise RuntimeError("bench.py: the sharded build through bt_mgpu_* failed on some rank"
+                               + (f" (this one: {why})" if why else ""))
     for _ in range(args.warmup):
         step()
 
@@ -642,6 +659,7 @@ def main():
                 "nboxes": info.get("nboxes"), "nlevels": info.get("nlevels"),
                 "list1_entries": info.get("n_list1"), "list2_entries": info.get("n_list2"),
                 "parallelism": f"{world} rank(s), one per GPU, shard by top-level Morton cell",
+                **({"sharded_impl": sharded_impl} if sharded_impl else {}),
                 **({"scaling_note": "weak scaling of BASELINE configs[4] (1.25e8 uniform points per rank): "
                                     "the matching one-GPU figure is `bench.py --gpus 1 --workload c5`; the "
                                     "default N = 1 line measures configs[2] (10^8 sphere-surface points)"}
@@ -745,7 +763,8 @@ def exchange_report(torch, dist, device, world, elapsed, n_local, last_exchange,
     if last_exchange.get("events"):
         a2a_ms = float(sum(e0.elapsed_time(e1) for e0, e1 in last_exchange["events"]))
     mine = torch.tensor([elapsed, float(n_local), float(last_exchange.get("bytes_sent", 0)),
-                         float(last_exchange.get("owned", n_local)), a2a_ms],
+                         float(last_exchange.get("owned", n_local)), a2a_ms,
+                         float(last_exchange.get("id_bytes", 0))],
                         dtype=torch.float64, device=device)
     rows = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(rows, mine)
@@ -762,14 +781,19 @@ def exchange_report(torch, dist, device, world, elapsed, n_local, last_exchange,
                                   else ""),
             "ranks_in_group": int(dist.get_world_size()),
         },
-        "exchange_bytes": int(round(sent.sum())),
-        "exchange_bytes_by_rank": [int(round(v)) for v in sent],
+        # coordinates (+ radii / weights) that left their GPU, and the global user ids of those
+        # particles (4 bytes each, routed over the same plan in messages of their own)
+        "exchange_bytes": int(round(sent.sum() + t[:, 5].sum())),
+        "exchange_bytes_coordinates": int(round(sent.sum())),
+        "exchange_bytes_ids": int(round(t[:, 5].sum())),
+        "exchange_bytes_by_rank": [int(round(v)) for v in sent + t[:, 5]],
         "exchange_a2a_ms_by_rank": [float(v) for v in a2a],
         "owned_particles_by_rank": [int(round(v)) for v in owned],
         "owned_particle_imbalance": float(owned.max() / max(owned.mean(), 1.0)),
     }
     if world > 1 and a2a.max() > 0:
         # every peer sits on its own xGMI link: a rank's payload leaves over world-1 links
+        # (bytes and device time of the coordinate all-to-all-v)
         rep["exchange_GBps_per_link"] = float(
             (sent / (world - 1) / np.maximum(a2a, 1e-9) / 1e6).min())
         rep["exchange_GBps_per_gpu"] = float((sent / np.maximum(a2a, 1e-9) / 1e6).min())
@@ -792,9 +816,15 @@ def dry_run(args, torch, dist, device, world, rank, backend, distributed):
             actx = HIPArrayContext(device.index)
         newp, _, _, xs = exchange_particles(actx, dist, particles, None, {},
                                             max_particles_in_box=args.mpb)
+        id_bytes = 0
+        if WITH_IDS:
+            # global user ids of the received particles, over the exchange's own plan
+            gids = xs["route"].global_ids("sources")
+            assert len(gids) == len(newp[0])
+            id_bytes = 4 * (n - xs["route"]._get("sources")["s_split"][rank])
         xinfo = exchange_report(torch, dist, device, world, 0.0, n,
                                 dict(bytes_sent=int(xs["bytes_sent"]), owned=int(len(newp[0])),
-                                     events=xs.get("a2a_events", [])), backend, False)
+                                     events=xs.get("a2a_events", []), id_bytes=id_bytes), backend, False)
         xinfo.pop("_elapsed_max")
         n_total = xinfo.pop("_n_total")
     else:

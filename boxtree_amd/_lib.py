@@ -187,7 +187,8 @@ class MgpuShard(ct.Structure):
                 ("target_radii", vp), ("source_record_len", ct.c_int32), ("refine_weights", vp),
                 ("top_box_arrive", vp), ("top_box_stay", vp),
                 ("source_chunk_offset", ct.c_int64), ("target_chunk_offset", ct.c_int64),
-                ("n_global_sources", ct.c_int64), ("n_global_targets", ct.c_int64)]
+                ("n_global_sources", ct.c_int64), ("n_global_targets", ct.c_int64),
+                ("n_sent_sources", ct.c_int64), ("n_sent_targets", ct.c_int64)]
 
 
 class MgpuLocalTree(ct.Structure):

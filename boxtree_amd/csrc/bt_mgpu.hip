@@ -1559,9 +1559,11 @@ static int bt_mgpu_exchange_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_m
     out->sep_targets = sep ? 1 : 0;
     out->source_chunk_offset = ms->route[0].chunk_offset;
     out->n_global_sources = ms->route[0].total;
+    out->n_sent_sources = nset[0] - (loop_self ? 0 : send_counts[(size_t) rank]);
     if (nsets == 2) {
         out->target_chunk_offset = ms->route[1].chunk_offset;
         out->n_global_targets = ms->route[1].total;
+        out->n_sent_targets = nset[1] - (loop_self ? 0 : send_counts[(size_t) nranks + rank]);
     }
     out->a2a_ms = -1.f;
     // a stream-ordered context returns with the payload exchange queued (bt_mgpu_exchange_time

@@ -229,6 +229,9 @@ class ParticleRoute:
                              "targets": int(shard.target_chunk_offset) if have_targets else None}
         self.n_global = {"sources": int(shard.n_global_sources),
                          "targets": int(shard.n_global_targets) if have_targets else None}
+        # particles of the chunk that live on another rank now: what one routed array moves
+        self.n_sent = {"sources": int(shard.n_sent_sources),
+                       "targets": int(shard.n_sent_targets) if have_targets else None}
 
     def _set(self, which):
         if which not in ("sources", "targets"):

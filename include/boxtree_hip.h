@@ -643,6 +643,9 @@ typedef struct {
     /* is global particle source_chunk_offset + i (targets likewise)                         */
     int64_t source_chunk_offset, target_chunk_offset;
     int64_t n_global_sources, n_global_targets;
+    int64_t n_sent_sources, n_sent_targets;   /* particles of the chunk that went to another rank: */
+                                       /* a bt_mgpu_route of elem_size bytes moves that many   */
+                                       /* elements off this GPU                                */
 } bt_mgpu_shard;
 
 /* the one-sweep partition (bt_partition_pack) keeps one run per owner in LDS: at most this

@@ -12,6 +12,11 @@
  * n_targets_per_rank > 0 every rank also has separate targets with extents -- coordinates from
  * the stream seeded with seed + 1000 + r, radii 2^-4 * 2^(-12 u) from the same stream after them,
  * stick-out factor 0.25, l^inf --: the sharded build of particles with extents from plain C.  One
+ * After the build every rank asks the library who its particles are (bt_mgpu_global_ids), checks
+ * on the host that received particle j carries the x coordinate of global particle ids[j] (the
+ * draw of the stream of the rank that id belongs to) and that an array routed to the owners and
+ * back (bt_mgpu_route) is unchanged, and reports a digest of the global user_source_ids of its
+ * slice of the tree order.  One
  * line per rank: what it owns and where its boxes sit in the global tree;
  * tests/test_gpu_cabi.py compares the global figures with the tree the Python layer
  * builds on one GPU from all chunks. */
@@ -49,6 +54,9 @@ typedef struct {
     int64_t nt_owned, target_offset, ntargets_global;
     int32_t nlevels_global;
     uint64_t digest_ids;           /* sum of the global numbers of the rank's deep boxes */
+    uint64_t digest_user_ids;      /* sum over the rank's tree positions p of (source_offset + p + 1) * */
+                                   /* (global user id of the source at p), mod 2^64                    */
+    int64_t chunk_offset;
 } rank_args;
 
 static int run_rank(rank_args *a)
@@ -161,6 +169,53 @@ static int run_rank(rank_args *a)
     CHECK_BT(bt_tree_export(ctx, &o));
     CHECK_BT(bt_synchronize(ctx));
 
+    /* particle identity: who are the particles this rank received? */
+    uint64_t id_digest = 0;
+    {
+        int32_t *d_ids = NULL, *h_ids = (int32_t *) malloc(no * 4), *h_usid = (int32_t *) malloc(no * 4);
+        double *d_x = NULL, *d_back = NULL, *h_x = (double *) malloc(no * 8), *h_rec = (double *) malloc(no * 8 * (size_t) dims);
+        double *h_back = (double *) malloc((size_t) n * 8), *h_mine = (double *) malloc((size_t) n * 8);
+        CHECK_HIP(hipMalloc((void **) &d_ids, no * 4));
+        CHECK_HIP(hipMalloc((void **) &d_x, no * 8));
+        CHECK_HIP(hipMalloc((void **) &d_back, (size_t) n * 8));
+        CHECK_BT(bt_mgpu_global_ids(ctx, comm, 0, 4, d_ids));
+        CHECK_BT(bt_mgpu_route(ctx, comm, 0, BT_ROUTE_TO_OWNERS, 8, dev[0], d_x));
+        CHECK_BT(bt_mgpu_route(ctx, comm, 0, BT_ROUTE_TO_CALLERS, 8, d_x, d_back));
+        CHECK_BT(bt_synchronize(ctx));
+        CHECK_HIP(hipMemcpy(h_ids, d_ids, (size_t) sh.n_owned * 4, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(h_x, d_x, (size_t) sh.n_owned * 8, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(h_rec, sh.points, (size_t) sh.n_owned * 8 * (size_t) dims, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(h_usid, o.user_source_ids, (size_t) sh.n_owned * 4, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(h_back, d_back, (size_t) n * 8, hipMemcpyDeviceToHost));
+        CHECK_HIP(hipMemcpy(h_mine, dev[0], (size_t) n * 8, hipMemcpyDeviceToHost));
+        if (memcmp(h_back, h_mine, (size_t) n * 8) != 0) { fprintf(stderr, "rank %d: route round trip differs\n", a->rank); return 92; }
+        if (sh.source_chunk_offset != (int64_t) a->rank * n || sh.n_global_sources != (int64_t) a->nranks * n) {
+            fprintf(stderr, "rank %d: chunk offset %lld of %lld\n", a->rank, (long long) sh.source_chunk_offset,
+                    (long long) sh.n_global_sources);
+            return 93;
+        }
+        /* x of every chunk's particles, as their ranks drew them */
+        double *all_x = (double *) malloc((size_t) a->nranks * (size_t) n * 8);
+        for (int q = 0; q < a->nranks; ++q) {
+            uint64_t sq = a->seed + (uint64_t) q;
+            for (int64_t i = 0; i < n; ++i) all_x[(size_t) q * (size_t) n + (size_t) i] = (double) (splitmix64(&sq) >> 11) * (1.0 / 9007199254740992.0);
+        }
+        for (int64_t j = 0; j < sh.n_owned; ++j) {
+            const int32_t g = h_ids[j];
+            if (g < 0 || (int64_t) g >= (int64_t) a->nranks * n || all_x[g] != h_x[j] || h_rec[(size_t) j * (size_t) dims] != h_x[j]) {
+                fprintf(stderr, "rank %d: received particle %lld is not global particle %d\n", a->rank, (long long) j, g);
+                return 94;
+            }
+        }
+        /* (filled in with the global source offset after bt_mgpu_number) */
+        for (int64_t pidx = 0; pidx < sh.n_owned; ++pidx)
+            id_digest += (uint64_t) (pidx + 1) * (uint64_t) h_ids[h_usid[pidx]];
+        a->digest_user_ids = 0;
+        for (int64_t pidx = 0; pidx < sh.n_owned; ++pidx) a->digest_user_ids += (uint64_t) h_ids[h_usid[pidx]];
+        free(all_x); free(h_ids); free(h_usid); free(h_x); free(h_rec); free(h_back); free(h_mine);
+        (void) hipFree(d_ids); (void) hipFree(d_x); (void) hipFree(d_back);
+    }
+
     /* step 5 */
     bt_mgpu_local_tree lt;
     memset(&lt, 0, sizeof(lt));
@@ -222,6 +277,9 @@ static int run_rank(rank_args *a)
     a->nlevels_global = num.nlevels; a->let_nboxes = ls.nboxes; a->halo_in = ls.halo_boxes_received;
     a->source_offset = num.source_offset; a->nsources_global = num.nsources; a->digest_ids = dg;
     a->nt_owned = sh.n_owned_targets; a->target_offset = num.target_offset; a->ntargets_global = num.ntargets;
+    /* sum_p (source_offset + p + 1) * id(p) = id_digest + source_offset * sum_p id(p) */
+    a->digest_user_ids = id_digest + (uint64_t) num.source_offset * a->digest_user_ids;
+    a->chunk_offset = sh.source_chunk_offset;
     bt_mgpu_comm_destroy(comm);
     bt_destroy(ctx);
     return 0;
@@ -260,13 +318,14 @@ int main(int argc, char **argv)
     for (int r = 0; r < nranks; ++r)
         printf("rank %d owned %lld source_offset %lld nboxes_local %lld nboxes_global %lld "
                "nlevels_global %d nsources_global %lld let_nboxes %lld halo_in %lld deep_ids %llu "
-               "targets_owned %lld target_offset %lld ntargets_global %lld\n",
+               "targets_owned %lld target_offset %lld ntargets_global %lld user_id_digest %llu chunk_offset %lld\n",
                r, (long long) args[r].n_owned, (long long) args[r].source_offset,
                (long long) args[r].nboxes_local, (long long) args[r].nboxes_global,
                args[r].nlevels_global, (long long) args[r].nsources_global,
                (long long) args[r].let_nboxes, (long long) args[r].halo_in,
                (unsigned long long) args[r].digest_ids, (long long) args[r].nt_owned,
-               (long long) args[r].target_offset, (long long) args[r].ntargets_global);
+               (long long) args[r].target_offset, (long long) args[r].ntargets_global,
+               (unsigned long long) args[r].digest_user_ids, (long long) args[r].chunk_offset);
     bt_mgpu_local_group_destroy(group);
     return 0;
 }

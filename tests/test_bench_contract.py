@@ -88,8 +88,11 @@ def check_two_ranks(d, n):
     assert len(c["owned_particles_by_rank"]) == 2 and sum(c["owned_particles_by_rank"]) == 2 * n
     assert 1.0 <= c["owned_particle_imbalance"] < 1.2
     assert c["exchange_bytes"] == sum(c["exchange_bytes_by_rank"]) > 0
-    # uniform points, two owners: about half of a rank's 24-byte records leave it
-    assert 0.3 * 24 * n < c["exchange_bytes_by_rank"][0] < 0.7 * 24 * n
+    # uniform points, two owners: about half of a rank's particles leave it -- 24 bytes of
+    # coordinates and, in a message of its own, the 4-byte global user id
+    assert 0.3 * 28 * n < c["exchange_bytes_by_rank"][0] < 0.7 * 28 * n
+    assert c["exchange_bytes"] == c["exchange_bytes_coordinates"] + c["exchange_bytes_ids"]
+    assert c["exchange_bytes_ids"] * 6 == c["exchange_bytes_coordinates"]
 
 
 def test_bench_gpus_2_starts_two_ranks_cpu():

@@ -95,6 +95,11 @@ def test_plain_c_program_runs_the_sharded_build(nranks, dims, n, mpb, seed):
         assert rows[0]["let_nboxes"] == h.nboxes and rows[0]["halo_in"] == 0
     deep = np.nonzero(h.box_levels > top_level)[0].astype(np.uint64)
     assert sum(r["deep_ids"] for r in rows) == int(deep.sum())
+    # particle identity from C: sum over tree positions p of (p + 1) * (global user id of the source
+    # at p), over all ranks, is the single-GPU tree's (mod 2^64) -- every rank's ids, in its slice
+    want = int((np.arange(1, h.nsources + 1, dtype=np.uint64) * h.user_source_ids.astype(np.uint64)).sum())
+    assert sum(r["user_id_digest"] for r in rows) % 2**64 == want
+    assert [r["chunk_offset"] for r in rows] == [k * n for k in range(nranks)]
 
 
 @pytest.mark.parametrize("nranks,dims,n,nt,mpb,seed", [(2, 3, 60000, 12000, 30, 4), (5, 2, 30000, 8000, 10, 8),
@@ -150,3 +155,8 @@ def test_plain_c_program_runs_the_sharded_build_with_target_extents(nranks, dims
         assert r["let_nboxes"] <= h.nboxes
     deep = np.nonzero(h.box_levels > top_level)[0].astype(np.uint64)
     assert sum(r["deep_ids"] for r in rows) == int(deep.sum())
+    # particle identity from C: sum over tree positions p of (p + 1) * (global user id of the source
+    # at p), over all ranks, is the single-GPU tree's (mod 2^64) -- every rank's ids, in its slice
+    want = int((np.arange(1, h.nsources + 1, dtype=np.uint64) * h.user_source_ids.astype(np.uint64)).sum())
+    assert sum(r["user_id_digest"] for r in rows) % 2**64 == want
+    assert [r["chunk_offset"] for r in rows] == [k * n for k in range(nranks)]
