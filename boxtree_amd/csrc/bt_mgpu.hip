@@ -70,12 +70,17 @@ std::string &nccl_library_path()
     static std::string p;
     return p;
 }
+// the path nccl() bound its entry points through ("" = by search), once it has
+bool &nccl_bound() { static bool b = false; return b; }
+std::string &nccl_bound_path() { static std::string p; return p; }
 
 Nccl &nccl()
 {
     static Nccl n = [] {
         Nccl r;
         void *h = nullptr;
+        nccl_bound() = true;
+        nccl_bound_path() = nccl_library_path();
         if (!nccl_library_path().empty())
             h = dlopen(nccl_library_path().c_str(), RTLD_NOW | RTLD_GLOBAL);
         for (int pass = 0; pass < 2 && !h; ++pass)
@@ -1091,6 +1096,14 @@ void bt_mgpu_comm_destroy(bt_mgpu_comm *c) { delete c; }
 int bt_mgpu_use_rccl_library(const char *path)
 {
     if (!path || !*path) { set_error("bt_mgpu_use_rccl_library: empty path"); return BT_ERR_INVALID; }
+    // the entry points are bound once per process: naming another image afterwards cannot take
+    // effect, and a communicator made by that image must not be driven through this one
+    if (nccl_bound() && nccl_bound_path() != path) {
+        set_error("bt_mgpu_use_rccl_library: the RCCL entry points are already bound (%s); %s cannot be used "
+                  "in this process any more", nccl_bound_path().empty() ? "image found by search"
+                                                                         : nccl_bound_path().c_str(), path);
+        return BT_ERR_INVALID;
+    }
     nccl_library_path() = path;
     return BT_OK;
 }
@@ -1998,7 +2011,11 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
         for (int64_t pth = 0; pth < n; ++pth) {
             if (!pl.exists[lev][pth]) continue;
             const bool internal = pl.split[lev][pth];
-            // tree.py:109-145 with sources = targets: children on both sides, or a leaf that is both
+            // tree.py:109-145 with sources = targets: children on both sides, or a leaf that is both.
+            // With separate targets a box with children STILL carries both child flags, whatever
+            // lies below it: tree_build_kernels.py:1254 sets HAS_SOURCE_OR_TARGET_CHILD_BOXES (=
+            // both bits, tree.py:138-139) before the per-side tests of :1262-1272 -- the single-GPU
+            // build does the same (test_multi_rank_native_entries_disjoint_clouds).
             int32_t flags = internal ? (BT_BOX_HAS_SOURCE_CHILD_BOXES | BT_BOX_HAS_TARGET_CHILD_BOXES)
                                      : (BT_BOX_IS_SOURCE_BOX | BT_BOX_IS_TARGET_BOX);
             if (!internal && pl.sep_targets) {

@@ -106,7 +106,11 @@ __global__ __launch_bounds__(1024) void morton_cells_lds_kernel(CellArgs<T, D> a
 // INT_MAX, tbk:270-274 -- exact here, compared against the limit as a 64-bit number): 64-bit
 // counters privatised in LDS, the cells in slices of 2^14 so that a slice's counters fit
 // (blockIdx.y = slice; every slice reads all cells and weights: 8 bytes per particle each).
+// (128 KiB of static LDS here, up to ~92 KiB of dynamic LDS in pp_scatter_kernel with many owners
+// and 5-value records: sized for the 160 KiB of a gfx950 CU, the only target of this library --
+// csrc/Makefile builds --offload-arch=gfx950 and nothing else)
 constexpr int WH_SLICE = 1 << 14;
+static_assert(WH_SLICE * 8 <= 160 * 1024, "weight_hist_kernel: the slice must fit the 160 KiB of LDS of a gfx950 CU");
 
 __global__ __launch_bounds__(1024) void weight_hist_kernel(const uint32_t *cells, const int32_t *weights,
         int64_t n, int ncells, unsigned long long *whist)
@@ -535,6 +539,11 @@ int partition_pack_impl(bt_context *ctx, const void *const *in, const uint32_t *
     constexpr int RW = D * (int) sizeof(U) / 4;
     const int nr_pad = (nranks + 3) & ~3;
     const size_t lds = (size_t) PP_WAVES * ((size_t) PP_WAVE_ITEMS * RW + (size_t) 3 * nr_pad) * 4;
+    if (lds > (size_t) 160 * 1024) {
+        set_error("partition: %zu bytes of LDS for %d owners and %d-byte records exceed the 160 KiB of a gfx950 CU",
+                  lds, nranks, RW * 4);
+        return BT_ERR_UNSUPPORTED;
+    }
     const unsigned sblocks = (unsigned) div_up(nwaves, PP_WAVES);
     if (small) pp_scatter_kernel<U, D, true><<<sblocks, 64 * PP_WAVES, lds, ctx->stream>>>(a, nr_pad);
     else pp_scatter_kernel<U, D, false><<<sblocks, 64 * PP_WAVES, lds, ctx->stream>>>(a, nr_pad);

@@ -1214,6 +1214,20 @@ def test_multi_rank_native_entries_separate_targets(dims, world, dist_kind, nway
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dims,world,dist_kind,nway,shift,ext", [
+    (3, 3, "uniform", 1, 1.5, False), (2, 4, "uniform", 2, 0.7, False), (3, 4, "sphere", 1, 2.5, False),
+    (3, 3, "uniform", 1, 1.5, True), (2, 5, "uniform", 1, 0.7, True)])
+def test_multi_rank_native_entries_disjoint_clouds(dims, world, dist_kind, nway, shift, ext):
+    """Sources and targets in different places: shared top boxes that hold only sources, or only
+    targets, must carry the flags of the single-GPU tree -- which, like the reference, gives every
+    box with children BOTH child flags (tree_build_kernels.py:1254 sets
+    HAS_SOURCE_OR_TARGET_CHILD_BOXES before the per-side tests of :1262-1272).  The flags decide
+    which top boxes are source parents, target parents and List-2 members."""
+    check_multi_rank_let(dims, world, dist_kind, nway, native=True, expect_partial=False, sep_targets=True,
+                         target_shift=shift, target_extents=(0.05, 0.25, "linf") if ext else None)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dims,world,dist_kind,nway,norm", [(3, 2, "uniform", 1, "linf"), (3, 3, "sphere", 1, "linf"),
                                                             (2, 4, "uniform", 2, "l2"), (3, 5, "clustered", 1, "linf"),
                                                             (2, 2, "normal", 1, "l2")])
@@ -1276,7 +1290,7 @@ def test_multi_rank_local_essential_tree_random(seed):
 
 def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_level=None,
                          seed=200, expect_partial=True, native=False, sep_targets=False,
-                         target_extents=None):
+                         target_extents=None, target_shift=0.0):
     """native: steps 1-6 through the library's bt_mgpu_* entries, the ranks being threads
     that share a LocalGroup; otherwise the torch implementation over tests/fake_dist.py."""
     import threading
@@ -1309,7 +1323,9 @@ def check_multi_rank_let(dims, world, dist_kind, nway, n_per=40000, mpb=30, top_
         assert native
         full_n = n_per
         n_per = max(n_per // 3, 1)
-        tchunks = [chunk(1000 + r) for r in range(world)]
+        # (target_shift: the target cloud beside the source cloud -- top boxes that hold particles
+        # of one kind only)
+        tchunks = [[a + target_shift for a in chunk(1000 + r)] for r in range(world)]
         n_per = full_n
     # ... with extents: target_extents = (radius scale, stick_out_factor, extent_norm); radii over
     # four decades, so that most targets go deep and some stay in boxes of the shared top levels
