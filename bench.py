@@ -387,12 +387,16 @@ def main():
             golden_c5 = None
     c5_local = {}
 
-    def c5_record(global_box_ids, counts_cumul, nboxes, nlevels, level_starts):
+    def c5_record(global_box_ids, counts_cumul, nboxes, nlevels, level_starts, ids_in_tree_order=None,
+                  first_position=0):
         """This rank's share of the tree checksum (linear in the counts: the ranks' shares add
-        up to the single-GPU tree's, boxtree_amd/distributed/checksum.py)."""
-        from boxtree_amd.distributed.checksum import tree_checksum
+        up to the single-GPU tree's, boxtree_amd/distributed/checksum.py) and of the checksum of
+        the particle order (global user id at every tree position of the rank's slice)."""
+        from boxtree_amd.distributed.checksum import particle_order_checksum, tree_checksum
         c5_local.update(checksum=tree_checksum(torch, global_box_ids, counts_cumul), nboxes=int(nboxes),
                         nlevels=int(nlevels), level_start_box_nrs=[int(v) for v in level_starts])
+        if ids_in_tree_order is not None:
+            c5_local["ids_checksum"] = particle_order_checksum(torch, ids_in_tree_order, first_position)
 
     def step(instrumented=False):
         """One pass of the path.  The timed steps read only the sort's event times (the
@@ -429,6 +433,7 @@ def main():
             # kept plan -- 4 more bytes per particle that changed rank, in messages of their own
             route = xs["route"]
             id_bytes = 0
+            gids = None
             if WITH_IDS:
                 gids = route.global_ids("sources")
                 id_bytes = 4 * route.n_sent["sources"]
@@ -436,7 +441,6 @@ def main():
                     tgids = route.global_ids("targets")
                     id_bytes += 4 * route.n_sent["targets"]
                     del tgids
-                del gids
             last_exchange.update(bytes_sent=int(xs["bytes_sent"]), owned=int(len(p_[0])),
                                  a2a_ms=xs["a2a_ms"], id_bytes=id_bytes)
             num = nat.number_sharded_tree(actx, native_comm, tree)
@@ -451,7 +455,8 @@ def main():
             nboxes, nlevels = int(num["nboxes"]), int(gtree.nlevels)
             if instrumented and golden_c5 is not None:
                 c5_record(num["box_ids"], tree.box_source_counts_cumul, nboxes, num["nlevels"],
-                          num["global_level_start_box_nrs"])
+                          num["global_level_start_box_nrs"],
+                          None if gids is None else gids[tree.user_source_ids.long()], num["source_offset"])
             return finish_step(st, trav, nboxes, nlevels, instrumented)
         if distributed:
             # the exchange is part of the path (and of the timed step) for N > 1
@@ -498,7 +503,7 @@ def main():
             nboxes, nlevels = int(tree.nboxes), int(tree.nlevels)
             if instrumented and golden_c5 is not None and not distributed:
                 c5_record(torch.arange(nboxes, device=device), tree.box_source_counts_cumul, nboxes,
-                          nlevels, actx.to_numpy(tree.level_start_box_nrs))
+                          nlevels, actx.to_numpy(tree.level_start_box_nrs), tree.user_source_ids)
         return finish_step(st, trav, nboxes, nlevels, instrumented)
 
     def finish_step(st, trav, nboxes, nlevels, instrumented):
@@ -564,16 +569,25 @@ def main():
         # chunks of all ranks (tests/golden/c5_global_counts.json, tools/c5_full.py)
         from boxtree_amd.distributed.checksum import wrap_int64
         total = c5_local["checksum"]
+        ids_total = c5_local.get("ids_checksum")
         if distributed and world > 1:
             shares = [None] * world
-            dist.all_gather_object(shares, c5_local["checksum"])
-            total = wrap_int64(sum(shares))
+            dist.all_gather_object(shares, (c5_local["checksum"], c5_local.get("ids_checksum")))
+            total = wrap_int64(sum(s_[0] for s_ in shares))
+            ids_total = (wrap_int64(sum(s_[1] for s_ in shares))
+                         if all(s_[1] is not None for s_ in shares) else None)
         same = (total == golden_c5["counts_cumul_checksum"] and c5_local["nboxes"] == golden_c5["nboxes"]
                 and c5_local["nlevels"] == golden_c5["nlevels"]
                 and c5_local["level_start_box_nrs"] == golden_c5["level_start_box_nrs"])
+        ids_same = None
+        if ids_total is not None and "user_source_ids_checksum" in golden_c5:
+            # every particle at its place of the global tree order, named by its global user id
+            ids_same = ids_total == golden_c5["user_source_ids_checksum"]
+            same = same and ids_same
         xinfo["c5_check"] = {
             "matches_single_gpu_tree": bool(same), "nboxes": c5_local["nboxes"],
             "nlevels": c5_local["nlevels"], "counts_cumul_checksum": total,
+            "user_source_ids_checksum": ids_total, "particle_order_matches": ids_same,
             "expected": {k: golden_c5[k] for k in ("nboxes", "nlevels", "counts_cumul_checksum")},
             "source": f"tests/golden/c5_global_counts.json, worlds[{world}]: the tree one GPU builds from "
                       f"the {world} chunk(s) default_rng(15..{14 + world}), checked there with the "

@@ -258,7 +258,7 @@ class TravPacked(ct.Structure):
 
 
 EXPORTED_SYMBOLS = [
-    "bt_abi_version", "bt_create", "bt_destroy", "bt_trim", "bt_last_error_string",
+    "bt_abi_version", "bt_create", "bt_destroy", "bt_trim", "bt_release_cached", "bt_last_error_string",
     "bt_set_stream", "bt_set_stream_ordered", "bt_synchronize", "bt_set_stage_timing",
     "bt_bbox", "bt_radix_sort_u64_u32", "bt_radix_sort_u32_u32", "bt_radix_sort_u64_keys",
     "bt_get_sort_stats",
@@ -314,6 +314,7 @@ def load():
     lib.bt_destroy.argtypes = [vp]
     lib.bt_destroy.restype = None
     lib.bt_trim.argtypes = [vp]
+    lib.bt_release_cached.argtypes = [vp]
     lib.bt_set_stream.argtypes = [vp, vp]
     lib.bt_set_stream_ordered.argtypes = [vp, ct.c_int]
     lib.bt_synchronize.argtypes = [vp]

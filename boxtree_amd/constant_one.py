@@ -10,28 +10,24 @@ import numpy as np
 
 from boxtree_amd import _lib
 from boxtree_amd.array_context import ptr
+from boxtree_amd.fmm import ExpansionWranglerInterface, TreeIndependentDataForWrangler
 
 __all__ = ["ConstantOneExpansionWrangler", "ConstantOneTreeIndependentDataForWrangler"]
 
 
-class ConstantOneTreeIndependentDataForWrangler:
+class ConstantOneTreeIndependentDataForWrangler(TreeIndependentDataForWrangler):
     """Nothing to precompute for a constant kernel (constant_one.py:43-46)."""
 
 
-class ConstantOneExpansionWrangler:
+class ConstantOneExpansionWrangler(ExpansionWranglerInterface):
     """An 'expansion' is one float64 per box; translations are sums.
 
     :arg traversal: a device :class:`~boxtree_amd.traversal.FMMTraversalInfo`.
     """
 
     def __init__(self, tree_indep, traversal):
-        self.tree_indep = tree_indep
-        self.traversal = traversal
+        super().__init__(tree_indep, traversal)
         self._box_weight_cache = None
-
-    @property
-    def tree(self):
-        return self.traversal.tree
 
     # -- helpers ------------------------------------------------------------------
     def _call(self, actx, code):
@@ -94,15 +90,13 @@ class ConstantOneExpansionWrangler:
     def reorder_potentials(self, potentials):
         return potentials[self.tree.sorted_target_ids.long()]          # constant_one.py:77-78
 
-    # -- single-rank no-ops of the interface ------------------------------------------
-    def distribute_source_weights(self, actx, src_weight_vecs, src_idx_all_ranks):
-        return src_weight_vecs
+    # (one float per box: there is nothing to slice per level; upstream leaves the two views
+    # unimplemented as well, constant_one.py:80-86)
+    def multipole_expansions_view(self, mpole_exps, level):
+        raise NotImplementedError
 
-    def communicate_mpoles(self, actx, mpole_exps, return_stats=False):
-        pass
-
-    def gather_potential_results(self, actx, potentials, tgt_idx_all_ranks):
-        return potentials
+    def local_expansions_view(self, local_exps, level):
+        raise NotImplementedError
 
     def finalize_potentials(self, actx, potentials):
         return potentials

@@ -68,6 +68,7 @@ public:
     int alloc(void **out, size_t bytes);
     void free(void *p);
     void release_all();
+    void release_idle();     // blocks that are not in use go back to the device
     size_t bytes_reserved() const { return reserved_; }
 
 private:

@@ -105,6 +105,16 @@ void Pool::free(void *p)
         if (b.ptr == p) { b.used = false; return; }
 }
 
+void Pool::release_idle()
+{
+    size_t k = 0;
+    for (size_t i = 0; i < blocks_.size(); ++i) {
+        if (blocks_[i].used) blocks_[k++] = blocks_[i];
+        else { (void) hipFree(blocks_[i].ptr); reserved_ -= blocks_[i].size; }
+    }
+    blocks_.resize(k);
+}
+
 void Pool::release_all()
 {
     for (auto &b : blocks_) (void) hipFree(b.ptr);
@@ -422,6 +432,15 @@ int bt_synchronize(bt_context *ctx)
     if (!ctx) return BT_ERR_INVALID;
     BT_HIP_CHECK(hipSetDevice(ctx->device));
     return bt::sync_stream(ctx);
+}
+
+int bt_release_cached(bt_context *ctx)
+{
+    bt::CallScope bt_call_scope_(ctx);
+    if (!ctx) return BT_ERR_INVALID;
+    BT_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->pool.release_idle();
+    return BT_OK;
 }
 
 int bt_trim(bt_context *ctx)

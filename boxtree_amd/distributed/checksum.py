@@ -30,3 +30,16 @@ def wrap_int64(v):
     """Python int -> the int64 it wraps to (sums of per-rank checksums)."""
     v &= (1 << 64) - 1
     return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def particle_order_checksum(torch, global_user_ids_in_tree_order, first_position=0):
+    """Checksum of ``user_source_ids`` (tree.py:426-431) of a tree, or of a rank's slice of it:
+    ``sum_p (p + 1) * id(p)`` in wrapping int64 arithmetic, ``p`` the GLOBAL tree position
+    (*first_position* = ``numbering["source_offset"]`` of a sharded build) and ``id(p)`` the
+    global user id of the source there -- for a sharded build the library's own
+    (``ParticleRoute.global_user_source_ids``).  The ranks' values add up (wrapping) to the
+    single-GPU tree's: equal sums mean every particle sits at its position of the global
+    order."""
+    ids = global_user_ids_in_tree_order.to(torch.int64)
+    pos = torch.arange(1, len(ids) + 1, device=ids.device, dtype=torch.int64) + int(first_position)
+    return int((pos * ids).sum().item())

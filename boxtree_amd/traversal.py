@@ -346,6 +346,12 @@ class FMMTraversalBuilder:
         _lib.host_trace("tg:built")
         info = _info_from_packed(tree, self.well_sep_is_n_away, packed, block[0], nlevels,
                                  share_target_boxes=sources_are_targets and tbm is None)
+        if debug:
+            # (the reference waits after every stage and compiles its walks with a stack check,
+            # traversal.py:150-156, 2035-2039; here: wait, then every list must be a well-formed CSR)
+            from boxtree_amd.debug import check_traversal
+            actx.synchronize()
+            check_traversal(actx.torch, info, nboxes)
         return actx.freeze(info), (StreamEvent(actx) if actx.stream_ordered else DoneEvent())
 
 # vim: fdm=marker

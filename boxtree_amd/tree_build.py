@@ -536,6 +536,12 @@ class TreeBuilder:
                     "kind='adaptive-level-restricted' with particle extents left "
                     f"{int(orphaned.sum())} boxes whose particles no leaf owns; this input "
                     "is not supported")
+        if debug:
+            # the reference's host assertions (tree_build.py:1039-1052, 1087-1098, 1545-1559) on
+            # the finished tree, as device operations (boxtree_amd/debug.py); waits for the build
+            from boxtree_amd.debug import check_tree
+            actx.synchronize()
+            check_tree(actx.torch, tree)
         return actx.freeze(tree), (StreamEvent(actx) if actx.stream_ordered else DoneEvent())
 
 # vim: foldmethod=marker

@@ -79,8 +79,13 @@ int bt_abi_version(void);
 /* hip_stream: a hipStream_t to run on, or NULL for a library-owned stream. */
 int bt_create(int device, void *hip_stream, bt_context **out);
 void bt_destroy(bt_context *ctx);
-/* release cached device workspace (kept between calls otherwise) */
+/* release cached device workspace (kept between calls otherwise) -- and what the context keeps
+ * BETWEEN the calls of one job: a tree not yet exported, the plan of a sharded build
+ * (bt_mgpu_number, bt_mgpu_let_build and bt_mgpu_route need the exchange's) */
 int bt_trim(bt_context *ctx);
+/* give back only the workspace that is not in use: safe between the calls of one job (several
+ * contexts taking turns on one device) */
+int bt_release_cached(bt_context *ctx);
 /* Run later calls on another stream (NULL: the legacy default stream); waits for the work
  * queued on the old one first, because the workspace is ordered by the stream. */
 int bt_set_stream(bt_context *ctx, void *hip_stream);

@@ -15,18 +15,11 @@ def check_tree_on_device(torch, tree, particles, max_particles_in_box, chunk=1 <
     i64 = torch.int64
     out = {"nboxes": nb, "nsources": n}
 
+    # the reference's debug assertions (levels, parent/child tables, counts, ids are permutations,
+    # sorted_target_ids inverts user_source_ids): boxtree_amd/debug.py, what debug=True runs
+    from boxtree_amd.debug import check_tree
+    out.update(check_tree(torch, tree, chunk))
     ids = tree.user_source_ids
-    # a permutation of 0..n-1: every id in range and hit exactly once
-    assert int(ids.min()) == 0 and int(ids.max()) == n - 1
-    hits = torch.zeros(n, dtype=torch.int8, device=dev)
-    hits.index_fill_(0, ids.to(i64), 1)
-    assert bool(hits.all()), "user_source_ids is not a permutation"
-    del hits
-    # sorted_target_ids is its inverse (tree_build.py:1467)
-    for lo in range(0, n, chunk):
-        hi = min(n, lo + chunk)
-        assert torch.equal(ids[tree.sorted_target_ids[lo:hi].to(i64)].to(i64),
-                           torch.arange(lo, hi, device=dev, dtype=i64))
     # sorted coordinates are the inputs in tree order (test_tree.py:110-114)
     for ax in range(dims):
         for lo in range(0, n, chunk):
@@ -35,38 +28,13 @@ def check_tree_on_device(torch, tree, particles, max_particles_in_box, chunk=1 <
     out["permutation"] = "ok"
 
     levels = tree.box_levels.to(i64)
-    lsb = torch.as_tensor(tree.level_start_box_nrs).to(dev).to(i64)
-    nlev = int(tree.nlevels)
-    # level-major numbering
-    assert int(lsb[0]) == 0 and int(lsb[nlev]) == nb
-    assert bool((levels[1:] >= levels[:-1]).all())
-    cnt_per_level = torch.bincount(levels, minlength=nlev)
-    assert torch.equal(cnt_per_level, lsb[1:nlev + 1] - lsb[:nlev])
-
     child = tree.box_child_ids[:, :nb].to(i64)              # [C, nb]
-    parent = tree.box_parent_ids.to(i64)
     has = child != 0
     box = torch.arange(nb, device=dev, dtype=i64)
-    # children point back, one level down, numbered after their parent
-    for m in range(child.shape[0]):
-        sel = has[m]
-        c = child[m][sel]
-        assert torch.equal(parent[c], box[sel])
-        assert torch.equal(levels[c], levels[sel] + 1)
     nchildren = has.sum(0)
-    assert int(nchildren.sum()) == nb - 1, "every box but the root is some box's child"
-    assert int(parent[0]) == 0
-
     cumul = tree.box_source_counts_cumul.to(i64)
     nonchild = tree.box_source_counts_nonchild.to(i64)
     starts = tree.box_source_starts.to(i64)
-    # nonchild + sum(children cumul) == cumul  (test_tree.py:182-184)
-    kid_sum = torch.zeros(nb, dtype=i64, device=dev)
-    for m in range(child.shape[0]):
-        kid_sum += torch.where(has[m], cumul[child[m]], torch.zeros((), dtype=i64, device=dev))
-    assert torch.equal(nonchild + kid_sum, cumul)
-    assert int(cumul[0]) == n
-    assert bool((cumul > 0).all()), "pruned tree: no empty box"
     leaf = nchildren == 0
     # leaf occupancy and the split rule (test_tree.py:203-218; tree_build_kernels.py:577-591)
     assert bool((cumul[leaf] <= max_particles_in_box).all())

@@ -41,7 +41,7 @@ def main():
 
     import torch
     from boxtree_amd import HIPArrayContext, TreeBuilder
-    from boxtree_amd.distributed.checksum import tree_checksum
+    from boxtree_amd.distributed.checksum import particle_order_checksum, tree_checksum
     from device_invariants import check_tree_on_device
 
     dev = torch.device("cuda", 0)
@@ -83,6 +83,8 @@ def main():
             "level_start_box_nrs": [int(v) for v in lsb],
             "counts_cumul_checksum": tree_checksum(torch, gids, cumul),
             "counts_cumul_sha256": hashlib.sha256(cumul.cpu().numpy().tobytes()).hexdigest(),
+            # which particle sits where in tree order (sharded builds: the library's global ids)
+            "user_source_ids_checksum": particle_order_checksum(torch, tree.user_source_ids),
             "root_extent": float(tree.root_extent),
             "bbox_min": [float(v) for v in tree.bounding_box[0]],
             "tree_build_ms_one_gpu": build_ms,
@@ -105,6 +107,10 @@ def main():
                 "from the chunks of W ranks, W = 1, 2, 4, 8 (8 = the 10^9-point tree).  Written by "
                 "tools/c5_full.py on an MI355X after the tree passed the reference's assertions on "
                 "the device; bench.py --gpus W --workload c5 compares its global numbering with it.",
+        "user_source_ids_checksum": "sum_p (p + 1) * user_source_ids[p], wrapping int64 "
+                                    "(checksum.particle_order_checksum): the ranks' sums over their "
+                                    "slices of the tree order, with the library's global user ids, add "
+                                    "up to it",
         "checksum": "sum_b box_source_counts_cumul[b] * ((b * 2654435761 mod 2^32) | 1), wrapping "
                     "int64 (boxtree_amd/distributed/checksum.py): linear in the counts, so the "
                     "ranks' checksums over their local trees add up to it",
