@@ -46,10 +46,18 @@ __global__ __launch_bounds__(256) void pack_nodes_kernel(int32_t nboxes, int64_t
     }
 }
 
-template <class T>
-__device__ __forceinline__ T level_to_rad(T root_extent, int level)
+// root_extent * 1 / 2^(level + 1) (traversal.py:234-235).  A division by a power of two is an
+// exact scaling: ldexp returns the same bits (both are the correctly rounded value of the same real
+// number, subnormal results included) in ONE instruction (v_ldexp_f64), where the IEEE f64
+// division the expression compiles to takes about twenty -- and the list walks evaluate it per
+// candidate box, in kernels that are bound by vector-ALU issue (LAB_NOTES.md section 9).
+__device__ __forceinline__ double level_to_rad(double root_extent, int level)
 {
-    return (root_extent * 1 / (T) (1ull << (level + 1)));      // traversal.py:234-235
+    return __builtin_ldexp(root_extent, -(level + 1));
+}
+__device__ __forceinline__ float level_to_rad(float root_extent, int level)
+{
+    return __builtin_ldexpf(root_extent, -(level + 1));
 }
 
 // traversal.py:279-305
