@@ -1652,8 +1652,8 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     static const bool trav_stats = [] { const char *e = getenv("BT_TRAV_STATS"); return e && atoi(e); }();
     Buf<int32_t> dbg_counts;
     if (trav_stats) {
-        BT_CHECK(dbg_counts.alloc(ctx->pool, 4));
-        BT_HIP_CHECK(hipMemsetAsync(dbg_counts.get(), 0, 16, ctx->stream));
+        BT_CHECK(dbg_counts.alloc(ctx->pool, 16));
+        BT_HIP_CHECK(hipMemsetAsync(dbg_counts.get(), 0, 64, ctx->stream));
         w.dbg_counts = dbg_counts.get();
     }
     // (with target extents the centre of the box being scanned has an LDS column as well)
@@ -1747,8 +1747,16 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         }
     const int64_t novf = h_tot[T_OVF] & 0xffffffffll;
     if (trav_stats) {
-        int32_t hc[4];
-        BT_HIP_CHECK(hipMemcpy(hc, dbg_counts.get(), 16, hipMemcpyDeviceToHost));
+        int32_t hc[16];
+        BT_HIP_CHECK(hipMemcpy(hc, dbg_counts.get(), 64, hipMemcpyDeviceToHost));
+        {
+            // lane utilisation of the walk (units of 1024 steps): what the lanes did, what their
+            // waves spent with a DFS per colleague (sum over colleagues of the longest lane), what
+            // they would spend with the colleagues' walks flattened into one loop (longest lane total)
+            const uint32_t *u = (const uint32_t *) hc;
+            fprintf(stderr, "[bt trav] walk steps (x1024): lanes %u | waves x 64 as nested loops %u, flattened %u | "
+                    "colleague visits %u\n", u[4], u[5], u[6], u[7]);
+        }
         fprintf(stderr, "[bt trav] boxes %lld target boxes %lld items %lld (cap %lld) K1 %d K3 %d Kc %d | "
                 "overflow items %lld (list1 %d, list3 %d, close %d; per-colleague items %d) | entries: "
                 "coll %lld l2 %lld l1 %lld l3 %lld close %lld l4 %lld\n", (long long) B, (long long) ntb,
