@@ -181,3 +181,35 @@ def test_mgpu_plan_with_extents_from_particles():
                         assert np.array_equal((box_split[sl] & 2) != 0, split[lev]), (dims, k, lev)
                     assert np.array_equal(prefix, np.concatenate([[0], np.cumsum(hist)]))
                     assert np.array_equal(owner, partition_cells(hist, world, unit)), (dims, k, world)
+
+
+def test_lazy_a2a_time_behaves_like_a_number():
+    import pytest
+    """stats["a2a_ms"] of an exchange on a stream-ordered context resolves on first use and can be
+    formatted, compared and used in arithmetic like the float it stands for; after another exchange
+    on the same context it refuses to report that one's time."""
+    import json
+
+    from boxtree_amd.distributed import native as nat
+
+    class FakeActx:
+        _mgpu_exchange_serial = 3
+
+    actx = FakeActx()
+    calls = []
+    orig = nat.exchange_time_ms
+    nat.exchange_time_ms = lambda a: calls.append(a) or 1.25
+    try:
+        t = nat._LazyA2aTime(actx, 3)
+        assert calls == []
+        assert f"{t:.2f}" == "1.25" and calls == [actx]
+        assert t + 1 == 2.25 and 1 + t == 2.25 and t * 2 == 2.5 and t / 5 == 0.25 and 5 / t == 4.0
+        assert t - 0.25 == 1.0 and 2 - t == 0.75 and -t == -1.25
+        assert t > 1 and t >= 1.25 and t < 2 and t <= 1.25 and t == 1.25 and bool(t)
+        assert round(t, 1) == 1.2 and json.dumps(float(t)) == "1.25" and max(t, 0.5) == 1.25
+        assert len(calls) == 1                      # resolved once
+        stale = nat._LazyA2aTime(actx, 2)           # an exchange before the context's last one
+        with pytest.raises(RuntimeError, match="before the next exchange"):
+            float(stale)
+    finally:
+        nat.exchange_time_ms = orig
