@@ -1650,6 +1650,8 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     w.ovf_count = (int32_t *) (totals.get() + T_OVF);
     w.ovf_list = ovf_list.get();
     static const bool trav_stats = [] { const char *e = getenv("BT_TRAV_STATS"); return e && atoi(e); }();
+    // (an experiment, off by default: see walk13_v2_kernel)
+    static const bool walk_two_pass = [] { const char *e = getenv("BT_WALK_TWO_PASS"); return e && atoi(e); }();
     Buf<int32_t> dbg_counts;
     if (trav_stats) {
         BT_CHECK(dbg_counts.alloc(ctx->pool, 16));
@@ -1658,10 +1660,13 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     }
     // (with target extents the centre of the box being scanned has an LDS column as well)
     const size_t cen_lds = (size_t) D * sizeof(T) * WALK_THREADS;
-    if (a.targets_have_extent)
-        walk13_v2_kernel<T, D, true, true><<<nblk(items_cap), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
-    else
-        walk13_v2_kernel<T, D, true, false><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
+    if (a.targets_have_extent) {
+        if (walk_two_pass) walk13_v2_kernel<T, D, true, true, true><<<nblk(items_cap), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
+        else walk13_v2_kernel<T, D, true, true><<<nblk(items_cap), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
+    } else {
+        if (walk_two_pass) walk13_v2_kernel<T, D, true, false, true><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
+        else walk13_v2_kernel<T, D, true, false><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
+    }
     BT_CHECK(tmark(ctx, st, "trav:walk (rows)"));
 
     // ---- starts of everything, totals in one transfer -------------------------------------------
@@ -1860,10 +1865,13 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         wf.close_cs = st->with_extent ? close_item.get() : nullptr;
         wf.l1_lists = c1.lists.get(); wf.l3_lists = st->l3_lists.get();
         wf.close_lists = st->with_extent ? cs.lists.get() : nullptr;
-        if (a.targets_have_extent)
-            walk13_v2_kernel<T, D, false, true><<<nblk(novf), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, wf);
-        else
-            walk13_v2_kernel<T, D, false, false><<<nblk(novf), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, wf);
+        if (a.targets_have_extent) {
+            if (walk_two_pass) walk13_v2_kernel<T, D, false, true, true><<<nblk(novf), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, wf);
+            else walk13_v2_kernel<T, D, false, true><<<nblk(novf), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, wf);
+        } else {
+            if (walk_two_pass) walk13_v2_kernel<T, D, false, false, true><<<nblk(novf), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, wf);
+            else walk13_v2_kernel<T, D, false, false><<<nblk(novf), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, wf);
+        }
     }
     BT_CHECK(tmark(ctx, st, "trav:lists 1+3 (final)"));
 

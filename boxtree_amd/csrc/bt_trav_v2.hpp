@@ -671,7 +671,15 @@ struct V2Emit {                        // list 1 / close list of one item
 // and the target's bounding box live in registers).  Without them the kernel needs a
 // quarter fewer registers, which is a wave more per SIMD for a kernel bound by the latency
 // of dependent loads.
-template <class T, int D, bool ROWS, bool TEXT>
+// TWO (BT_WALK_TWO_PASS=1, an experiment: LAB_NOTES.md section 10): two passes over the colleagues.
+// The first is the same for every lane of the wave: the colleague itself goes to List 1 if it is a
+// source box, and the colleagues with source boxes below them are marked.  The second walks below
+// the marked ones only, trip t being the lane's t-th such colleague: the lanes' walks start together
+// instead of wherever each lane's row happens to hold a colleague with children, and the trips that
+// find nothing to walk are gone.  Entries of List 3 and of the close list come from the walks alone
+// and keep their order; List 1 is put into depth-first order afterwards whatever order it is
+// written in.
+template <class T, int D, bool ROWS, bool TEXT, bool TWO = false>
 __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTree ft, V2Walk w)
 {
     const bool targets_have_extent = TEXT && a.targets_have_extent;
@@ -861,15 +869,33 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         if (st_here) atomicMax(&s_stat[threadIdx.x >> 6][iter & 31], st_here);
         st_here = 0;
     };
-    for (int ci = c0; ci < c1; ++ci) {
-        st_close(ci - c0 - 1);
+    uint32_t below = 0;
+    if constexpr (TWO) {
+        for (int ci = c0; ci < c1; ++ci) {
+            const uint32_t ce = (uint32_t) crow[ci];
+            const int32_t nws = (int32_t) (ce & w.id_mask);
+            const uint8_t cfl = w.flags[nws];
+            if (cfl & BT_BOX_IS_SOURCE_BOX) emit1(nws);
+            if (cfl & BT_BOX_HAS_SOURCE_CHILD_BOXES) below |= 1u << ci;
+        }
+    }
+    int trip = 0;
+    for (int cnext = c0; TWO ? below != 0u : cnext < c1; ++cnext, ++trip) {
+        st_close(trip - 1);
         if (w.dbg_counts) ++st_visits;
+        int ci = cnext;
+        if constexpr (TWO) {
+            ci = __builtin_ctz(below);
+            below &= below - 1u;
+        }
         const uint32_t ce = (uint32_t) crow[ci];
         const int32_t nws = (int32_t) (ce & w.id_mask);
-        const uint8_t cfl = w.flags[nws];
-        // a colleague is adjacent (well_sep_is_n_away == 1)
-        if (cfl & BT_BOX_IS_SOURCE_BOX) emit1(nws);
-        if (!(cfl & BT_BOX_HAS_SOURCE_CHILD_BOXES)) continue;
+        if constexpr (!TWO) {
+            const uint8_t cfl = w.flags[nws];
+            // a colleague is adjacent (well_sep_is_n_away == 1)
+            if (cfl & BT_BOX_IS_SOURCE_BOX) emit1(nws);
+            if (!(cfl & BT_BOX_HAS_SOURCE_CHILD_BOXES)) continue;
+        }
         int prel[D];
 #pragma unroll
         for (int ax = 0; ax < D; ++ax) prel[ax] = v2_off(ce, ax);
@@ -1031,7 +1057,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         }
     }
 
-    st_close(c1 - c0 - 1);
+    st_close(trip - 1);
     if (w.dbg_counts && ROWS) {
         // (the lanes are together again: per wave the nested-loop cost is the sum of the per-iteration
         // maxima, the flattened cost the longest lane's total)
