@@ -193,6 +193,20 @@ def test_self_loopback_runs_the_point_to_point_branch(dims, sep):
             tree, _ = TreeBuilder(actx)(actx, p2, max_particles_in_box=mpb, **kw)
             plain, _ = TreeBuilder(actx)(actx, pts, max_particles_in_box=mpb)
         assert_same_tree(actx.to_numpy(tree), actx.to_numpy(plain))
+        # particle identity through ncclSend / ncclRecv as well: with one rank the received order
+        # is the chunk's, so the ids are 0..n-1 and a routed array arrives as it left
+        route = stats["route"]
+        assert torch.equal(route.global_ids("sources"), torch.arange(n, dtype=torch.int32, device="cuda"))
+        assert route.chunk_offset["sources"] == 0 and route.n_global["sources"] == n
+        assert route.n_sent["sources"] == n             # (the own segment travels too, here)
+        vals = torch.from_numpy(rng.standard_normal(n)).cuda()
+        owned = route.to_owners(vals, "sources")
+        assert torch.equal(owned, vals) and torch.equal(route.to_callers(owned, "sources"), vals)
+        if sep:
+            i32 = torch.arange(nt, dtype=torch.int32, device="cuda") * 3
+            assert torch.equal(route.global_ids("targets", dtype=torch.int64),
+                               torch.arange(nt, dtype=torch.int64, device="cuda"))
+            assert torch.equal(route.to_callers(route.to_owners(i32, "targets"), "targets"), i32)
         num = nat.number_sharded_tree(actx, comm, tree)
         let, info = nat.build_local_essential_tree(actx, comm, tree, num)
         lsb = actx.to_numpy(tree.level_start_box_nrs)
@@ -227,6 +241,9 @@ def test_self_loopback_messages_above_the_round_limit():
         for ax in range(3):
             assert torch.equal(p2[ax], pts[ax])
         assert stats["a2a_ms"] > 0
+        # a routed 8-byte array to oneself: 576 MB, two rounds
+        owned = stats["route"].to_owners(pts[1], "sources")
+        assert torch.equal(owned, pts[1])
     finally:
         comm.close()
 

@@ -64,6 +64,8 @@ def constant_one_on_boxes(trav, box_levels, box_parent_ids, own_w, cum_w, nlevel
 @pytest.mark.parametrize("dims,world,dist_kind,mode", [
     (3, 2, "uniform", "points"), (3, 3, "blob", "points"), (2, 5, "normal", "points"),
     (3, 8, "uniform", "points"), (2, 8, "blob", "points"),
+    # (more than 8 owners: the partition ranks with LDS counters instead of one ballot per owner)
+    (3, 12, "uniform", "points"), (2, 19, "normal", "targets"),
     (3, 3, "uniform", "targets"), (2, 4, "blob", "targets"), (3, 8, "normal", "targets"),
     (3, 2, "uniform", "extents"), (3, 5, "blob", "extents"), (2, 8, "normal", "extents")])
 def test_identity_ids_and_sharded_fmm(dims, world, dist_kind, mode):
