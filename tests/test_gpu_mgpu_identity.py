@@ -69,6 +69,11 @@ def constant_one_on_boxes(trav, box_levels, box_parent_ids, own_w, cum_w, nlevel
     (3, 3, "uniform", "targets"), (2, 4, "blob", "targets"), (3, 8, "normal", "targets"),
     (3, 2, "uniform", "extents"), (3, 5, "blob", "extents"), (2, 8, "normal", "extents")])
 def test_identity_ids_and_sharded_fmm(dims, world, dist_kind, mode):
+    check_identity(dims, world, dist_kind, mode)
+
+
+def check_identity(dims, world, dist_kind, mode, n_src=24000, n_tgt=5000, mpb=20, seed=900, sof=0.25,
+                   norm="linf"):
     """(1) bt_mgpu_global_ids + the rank's user_source_ids reproduce the single-GPU tree's
     user_source_ids slice; sorted_target_ids likewise through bt_mgpu_route; (2) arrays routed
     to the owners and back are unchanged and land beside their particles; (3) a constant-one FMM
@@ -79,12 +84,11 @@ def test_identity_ids_and_sharded_fmm(dims, world, dist_kind, mode):
     import torch
     from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
     from boxtree_amd.distributed import native as nat
-    n_src, n_tgt, mpb, top_level, sof = 24000, 5000, 20, 3 if dims == 3 else 4, 0.25
-    src, tgt, rad = make_chunks(world, dims, n_src, n_tgt, 900 + world, dist_kind,
+    src, tgt, rad = make_chunks(world, dims, n_src, n_tgt, seed + world, dist_kind,
                                 0.4 if dist_kind == "normal" else 0.05)
     # ragged chunks: rank r gives away a different number of particles, one rank (of > 2) none
     for r in range(world):
-        keep = n_src - 997 * r if not (world > 2 and r == 1) else 0
+        keep = max(n_src - (n_src // 25) * r, 1) if not (world > 2 and r == 1) else 0
         src[r] = [a[:keep] for a in src[r]]
     sep = mode != "points"
     ext = mode == "extents"
@@ -101,7 +105,7 @@ def test_identity_ids_and_sharded_fmm(dims, world, dist_kind, mode):
             kw_x["targets"] = [torch.from_numpy(a).cuda() for a in tgt[rank]]
         if ext:
             kw_x.update(target_radii=torch.from_numpy(rad[rank]).cuda(), stick_out_factor=sof,
-                        extent_norm="linf")
+                        extent_norm=norm)
         res = nat.sharded_tree_and_lists(actx, comm, p, mpb, **kw_x)
         tree, num, let, info, trav, route = (res[k] for k in ("tree", "numbering", "let", "let_info",
                                                               "traversal", "route"))
@@ -147,7 +151,7 @@ def test_identity_ids_and_sharded_fmm(dims, world, dist_kind, mode):
         gkw["targets"] = [cat(tgt, ax) for ax in range(dims)]
     if ext:
         gkw.update(target_radii=torch.from_numpy(np.concatenate(rad)).cuda(), stick_out_factor=sof,
-                   extent_norm="linf")
+                   extent_norm=norm)
     gt, _ = TreeBuilder(actx)(actx, allsrc, max_particles_in_box=mpb, **gkw)
     g = actx.to_numpy(gt)
     gtrav = actx.to_numpy(FMMTraversalBuilder(actx)(actx, gt)[0])
@@ -238,7 +242,8 @@ def test_identity_ids_and_sharded_fmm(dims, world, dist_kind, mode):
     got_near = np.concatenate([p[1] for p in pots])
     assert np.array_equal(got_full, want_full)
     assert np.array_equal(got_near, want_near)
-    assert len(np.unique(want_near)) > 10          # (it does tell the sources apart)
+    if n_all >= 20000 * 2:
+        assert len(np.unique(want_near)) > 10      # (it does tell the sources apart)
 
 
 def test_route_errors():
