@@ -372,6 +372,7 @@ struct TopPlan {
     std::vector<std::vector<int64_t>> src_counts; // [k+1][C^lev]: the sources among `counts`
     std::vector<int32_t> owner;                   // [C^k]
     std::vector<int64_t> unit_start;              // [C^k] scratch of compute_plan
+    std::vector<int64_t> unit_a, unit_b, rank_from;   // ... more of it (kept: no allocation per call)
     std::vector<int64_t> prefix;                  // [C^k + 1]
     double bbox_min[3] = {0, 0, 0}, bbox_max[3] = {0, 0, 0}, root_extent = 0;
 };
@@ -461,7 +462,10 @@ void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, co
         pl.index.resize((size_t) k + 1);
         pl.nboxes.assign((size_t) k + 1, 0);
         pl.exists[0].assign(1, 1);
-        std::vector<int64_t> unit_here(1, -1), unit_next;
+        // (scratch kept in the plan: two 256-KiB vectors allocated and first touched on every
+        // call cost the exchange a third of its one idle wait)
+        std::vector<int64_t> &unit_here = pl.unit_a, &unit_next = pl.unit_b;
+        unit_here.assign(1, -1);
         for (int lev = 0; lev <= k; ++lev) {
             const int64_t n = (int64_t) 1 << (D * lev);
             pl.split[lev].resize((size_t) n);
@@ -514,13 +518,19 @@ void compute_plan(int D, int k, int64_t mpb, int nranks, const int64_t *hist, co
     pl.prefix[0] = 0;
     for (int64_t c = 0; c < ncells; ++c) pl.prefix[(size_t) c + 1] = pl.prefix[(size_t) c] + hist[c];
     pl.owner.resize((size_t) ncells);
+    // rank r + 1 begins at the first unit whose prefix reaches ceil((r + 1) * total / nranks):
+    // (r + 1) * total <= prefix * nranks  <=>  prefix >= that threshold (positive integers)
+    std::vector<int64_t> &from = pl.rank_from;
+    from.resize((size_t) nranks);
+    for (int q = 0; q + 1 < nranks; ++q)
+        from[(size_t) q] = (int64_t) (((__int128) (q + 1) * total + nranks - 1) / nranks);
     int32_t r = 0;
+    const int64_t *us = unit_start.data(), *pf = pl.prefix.data();
+    int32_t *ow = pl.owner.data();
     for (int64_t c = 0; c < ncells; ++c) {
-        if (unit_start[(size_t) c] == c) {
-            const __int128 lhs = (__int128) pl.prefix[(size_t) c] * nranks;
-            while (r < nranks - 1 && (__int128) (r + 1) * total <= lhs) ++r;
-        }
-        pl.owner[(size_t) c] = r;
+        if (us[c] == c)
+            while (r < nranks - 1 && pf[c] >= from[(size_t) r]) ++r;
+        ow[c] = r;
     }
 }
 
