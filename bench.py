@@ -711,27 +711,11 @@ def main():
             },
             "stages_ms": {k: v / n_instrumented for k, v in stage_acc.items()},
         }
-        # The whole step against the HBM roofline (single GPU: what one rank's build + lists
-        # must move at least, DESIGN.md section 4 / SURVEY 8d), so that the step's fraction of
-        # peak is tracked next to the digit pass's.  Per particle of this rank: bounding box 24,
-        # key kernel 24 + 8 + 32, digit histogram 8, digit passes 16 each (24 for (key, id)
-        # pairs), within-leaf order 12, id arrays 16, coordinate gather 60, box extents 24; per
-        # box 190; per list entry 4, per list start 4.
         nb_ = int(info.get("nboxes") or 0) if world == 1 else int(xinfo.get("let_nboxes_rank0") or 0)
         entries = sum(int(info.get(k, 0) or 0) for k in (
             "n_colleagues", "n_list1", "n_list2", "n_list3", "n_list4", "n_close"))
-        per_particle = 24 + 64 + 8 + pass_bytes * int(sort_ms[-1][1]) + 12 + 16 + 60 + 24
-        step_bytes = per_particle * n_sorted + 190.0 * nb_ + 4.0 * entries + 4.0 * 6 * nb_
-        out["roofline"]["step"] = {
-            "algorithmic_bytes": step_bytes,
-            "algorithmic_bytes_per_particle": per_particle,
-            "achieved": step_bytes / (ms_per_step * 1e-3) / 1e9,
-            "unit": "GB/s",
-            "frac": step_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "what": "one rank's build + lists: particles of the rank x per-particle bytes of the "
-                    "build's kernels + 190 B per box + 4 B per list entry and per list start "
-                    "(exchange kernels of an N > 1 step not counted: its fraction is a lower bound)",
-        }
+        out["roofline"]["step"] = step_roofline(n_sorted, nb_, int(sort_ms[-1][1]), pass_bytes, entries,
+                                                ms_per_step)
         # list output rate of the traversal stages (the walks are latency /
         # L2 bound; what they deliver is 4 bytes per list entry)
         st_ms = out["stages_ms"]
@@ -787,6 +771,29 @@ def emit(out):
     ctypes.CDLL(None).fflush(None)
     sys.stdout.flush()
     print(json.dumps(out), flush=True)
+
+
+def step_roofline(n_particles, nboxes, passes, pass_bytes, list_entries, ms_per_step):
+    """The whole step against the HBM roofline (what one rank's build + lists must move at least,
+    DESIGN.md section 4 / SURVEY 8d), so that the step's fraction of peak is tracked next to the
+    digit pass's.  Per particle of the rank: bounding box 24, key kernel 24 + 8 + 32, digit
+    histogram 8, digit passes 16 each (24 for (key, id) pairs), within-leaf order 12, id arrays
+    16, coordinate gather 60, box extents 24; per box 190; per list entry 4, per list
+    start 4 (six lists)."""
+    per_particle = 24 + 64 + 8 + float(pass_bytes) * int(passes) + 12 + 16 + 60 + 24
+    step_bytes = per_particle * int(n_particles) + 190.0 * int(nboxes) + 4.0 * int(list_entries) \
+        + 4.0 * 6 * int(nboxes)
+    achieved = step_bytes / (ms_per_step * 1e-3) / 1e9 if ms_per_step and ms_per_step > 0 else 0.0
+    return {
+        "algorithmic_bytes": step_bytes,
+        "algorithmic_bytes_per_particle": per_particle,
+        "achieved": achieved,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "what": "one rank's build + lists: particles of the rank x per-particle bytes of the build's "
+                "kernels + 190 B per box + 4 B per list entry and per list start (exchange kernels of "
+                "an N > 1 step not counted: its fraction is a lower bound)",
+    }
 
 
 def exchange_report(torch, dist, device, world, elapsed, n_local, last_exchange, backend,

@@ -143,3 +143,14 @@ def test_bench_gpus_2_real_processes_one_gpu():
     tree, _ = TreeBuilder(actx)(actx, [actx.from_numpy(p) for p in pts], max_particles_in_box=64)
     assert d["config"]["global_nboxes"] == int(tree.nboxes)
     assert d["config"]["nlevels"] == int(tree.nlevels)
+
+
+def test_step_roofline_arithmetic():
+    """roofline.step of the bench line: c3's figures give the 31 GB / 0.23 of peak of DESIGN.md."""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.step_roofline(10**8, 5261406, 4, 16.0, 356782353, 16.45)
+    assert r["algorithmic_bytes_per_particle"] == 24 + 64 + 8 + 64 + 12 + 16 + 60 + 24
+    assert abs(r["algorithmic_bytes"] - (272e8 + 214 * 5261406 + 4 * 356782353)) < 1
+    assert 0.22 < r["frac"] < 0.25 and r["unit"] == "GB/s"
+    assert bench.step_roofline(0, 0, 0, 16.0, 0, 0.0)["frac"] == 0.0
