@@ -19,7 +19,8 @@ from boxtree_amd.area_query import (
     AreaQueryBuilder, LeavesToBallsLookupBuilder, PeerListFinder, SpaceInvaderQueryBuilder)
 from boxtree_amd.array_context import HIPArrayContext
 from boxtree_amd.bounding_box import BoundingBoxFinder
-from boxtree_amd.tools import make_normal_particle_array
+from boxtree_amd.tools import (
+    make_normal_particle_array, make_surface_particle_array, make_uniform_particle_array)
 from boxtree_amd.traversal import BuiltList, FMMTraversalBuilder, FMMTraversalInfo
 from boxtree_amd.tree import Tree, TreeOfBoxes, TreeWithLinkedPointSources, box_flags_enum
 from boxtree_amd.tree_build import ExtentNorm, MaxLevelsExceeded, TreeBuilder, TreeKind
@@ -30,6 +31,7 @@ __all__ = [
     "BoundingBoxFinder", "BuiltList", "FMMTraversalBuilder", "FMMTraversalInfo",
     "ExtentNorm", "HIPArrayContext", "MaxLevelsExceeded", "Tree", "TreeBuilder", "TreeKind",
     "TreeOfBoxes", "TreeWithLinkedPointSources", "box_flags_enum", "make_normal_particle_array",
+    "make_surface_particle_array", "make_uniform_particle_array",
 ]
 
 __version__ = "0.1"

@@ -186,3 +186,22 @@ def test_stage_table_is_the_reference_order():
         # traversal arrays + the one state input fill the method's parameters after `actx`
         assert len(fields) + 1 == len(params) - 1 - (1 if method == "communicate_mpoles" else 0), method
         assert reads in ("w", "m", "l") and writes in (None, "m", "l", "+l", "+p")
+
+
+def test_particle_fixtures_on_the_host():
+    """The reference's deterministic particle fixtures (boxtree/tools.py:122-276): sizes, the
+    surfaces they lie on, and that an oracle tree of them passes the tree invariants."""
+    from boxtree_amd.tools import surface_particle_coords, uniform_particle_coords
+    x, y = surface_particle_coords(1000, 2, np.float64)
+    assert x.shape == (1000,) and abs(x[0] - 1.5) < 1e-12 and abs(y[0]) < 1e-12
+    x, y, z = surface_particle_coords(10000, 3, np.float64)
+    assert x.shape == (10000,)
+    rho = np.sqrt(x * x + y * y)
+    assert np.allclose((rho - 15.0) ** 2 + z * z, 25.0)            # a torus of radii 15 and 5
+    x, y = uniform_particle_coords(900, 2, np.float32)
+    assert x.shape == (900,) and x.dtype == np.float32
+    x, y, z = uniform_particle_coords(4096, 3, np.float64)
+    assert x.shape == (15 ** 3,)                                    # int(4096 ** (1/3)) = 15
+    # rotations keep distances: the lattice's nearest-neighbour spacing is 4 / (n - 1)
+    d = np.sqrt((x[1] - x[0]) ** 2 + (y[1] - y[0]) ** 2 + (z[1] - z[0]) ** 2)
+    assert abs(d - 4 / 14) < 1e-12
