@@ -1754,14 +1754,6 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     if (trav_stats) {
         int32_t hc[16];
         BT_HIP_CHECK(hipMemcpy(hc, dbg_counts.get(), 64, hipMemcpyDeviceToHost));
-        {
-            // lane utilisation of the walk (units of 1024 steps): what the lanes did, what their
-            // waves spent with a DFS per colleague (sum over colleagues of the longest lane), what
-            // they would spend with the colleagues' walks flattened into one loop (longest lane total)
-            const uint32_t *u = (const uint32_t *) hc;
-            fprintf(stderr, "[bt trav] walk steps (x1024): lanes %u | waves x 64 as nested loops %u, flattened %u | "
-                    "colleague visits %u\n", u[4], u[5], u[6], u[7]);
-        }
         fprintf(stderr, "[bt trav] boxes %lld target boxes %lld items %lld (cap %lld) K1 %d K3 %d Kc %d | "
                 "overflow items %lld (list1 %d, list3 %d, close %d; per-colleague items %d) | entries: "
                 "coll %lld l2 %lld l1 %lld l3 %lld close %lld l4 %lld\n", (long long) B, (long long) ntb,

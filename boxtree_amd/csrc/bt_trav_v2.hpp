@@ -858,17 +858,6 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
     else if (slot == SLOT_SELF) c1 = 0;
     const int32_t *crow = w.coll_rows + (int64_t) b * P;
     int32_t *stk = s_walk_lds + threadIdx.x;
-    // BT_TRAV_STATS: steps per lane, and per wave the longest lane of every colleague iteration
-    __shared__ uint32_t s_stat[4][32];
-    uint32_t st_lane = 0, st_visits = 0;
-    if (w.dbg_counts && (threadIdx.x & 63) < 32) s_stat[threadIdx.x >> 6][threadIdx.x & 63] = 0;
-    uint32_t st_here = 0;
-    auto st_close = [&](int iter) {        // the colleague iteration `iter` took st_here steps on this lane
-        if (!w.dbg_counts) return;
-        st_lane += st_here;
-        if (st_here) atomicMax(&s_stat[threadIdx.x >> 6][iter & 31], st_here);
-        st_here = 0;
-    };
     uint32_t below = 0;
     if constexpr (TWO) {
         for (int ci = c0; ci < c1; ++ci) {
@@ -879,10 +868,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             if (cfl & BT_BOX_HAS_SOURCE_CHILD_BOXES) below |= 1u << ci;
         }
     }
-    int trip = 0;
-    for (int cnext = c0; TWO ? below != 0u : cnext < c1; ++cnext, ++trip) {
-        st_close(trip - 1);
-        if (w.dbg_counts) ++st_visits;
+    for (int cnext = c0; TWO ? below != 0u : cnext < c1; ++cnext) {
         int ci = cnext;
         if constexpr (TWO) {
             ci = __builtin_ctz(below);
@@ -954,7 +940,6 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
             for (int q = 0; q < D; ++q) pcen[q * WALK_THREADS] = pc0[q];
         }
         while (go) {
-            if (w.dbg_counts) ++st_here;
             const bool wb_src = (kd.source() >> mnr) & 1u, wb_hsc = (kd.has_src_children() >> mnr) & 1u;
             const int32_t wb = kd.id(mnr);              // (used only if the child is there)
             bool descend = false;
@@ -1057,27 +1042,6 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
         }
     }
 
-    st_close(trip - 1);
-    if (w.dbg_counts && ROWS) {
-        // (the lanes are together again: per wave the nested-loop cost is the sum of the per-iteration
-        // maxima, the flattened cost the longest lane's total)
-        const int lane = threadIdx.x & 63;
-        uint32_t nested = lane < 32 ? s_stat[threadIdx.x >> 6][lane] : 0u, flat = st_lane, tot = st_lane,
-                 vis = st_visits;
-        for (int off = 32; off > 0; off >>= 1) {
-            nested += __shfl_xor(nested, off, 64);
-            const uint32_t o = __shfl_xor(flat, off, 64);
-            flat = o > flat ? o : flat;
-            tot += __shfl_xor(tot, off, 64);
-            vis += __shfl_xor(vis, off, 64);
-        }
-        if (lane == 0) {
-            atomicAdd((uint32_t *) w.dbg_counts + 4, (tot + 512) >> 10);
-            atomicAdd((uint32_t *) w.dbg_counts + 5, (nested * 64 + 512) >> 10);
-            atomicAdd((uint32_t *) w.dbg_counts + 6, (flat * 64 + 512) >> 10);
-            atomicAdd((uint32_t *) w.dbg_counts + 7, (vis + 512) >> 10);
-        }
-    }
     if (ROWS) {
         e1.flush();
         ec.flush();
