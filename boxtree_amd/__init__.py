@@ -19,8 +19,6 @@ from boxtree_amd.area_query import (
     AreaQueryBuilder, LeavesToBallsLookupBuilder, PeerListFinder, SpaceInvaderQueryBuilder)
 from boxtree_amd.array_context import HIPArrayContext
 from boxtree_amd.bounding_box import BoundingBoxFinder
-from boxtree_amd.tools import (
-    make_normal_particle_array, make_surface_particle_array, make_uniform_particle_array)
 from boxtree_amd.traversal import BuiltList, FMMTraversalBuilder, FMMTraversalInfo
 from boxtree_amd.tree import Tree, TreeOfBoxes, TreeWithLinkedPointSources, box_flags_enum
 from boxtree_amd.tree_build import ExtentNorm, MaxLevelsExceeded, TreeBuilder, TreeKind
@@ -30,8 +28,9 @@ __all__ = [
     "SpaceInvaderQueryBuilder",
     "BoundingBoxFinder", "BuiltList", "FMMTraversalBuilder", "FMMTraversalInfo",
     "ExtentNorm", "HIPArrayContext", "MaxLevelsExceeded", "Tree", "TreeBuilder", "TreeKind",
-    "TreeOfBoxes", "TreeWithLinkedPointSources", "box_flags_enum", "make_normal_particle_array",
-    "make_surface_particle_array", "make_uniform_particle_array",
+    "TreeOfBoxes", "TreeWithLinkedPointSources", "box_flags_enum",
 ]
+# (the reference's particle fixtures live in boxtree_amd.tools, as upstream's do in boxtree.tools;
+# boxtree/__init__.py:26-52 does not export them either)
 
 __version__ = "0.1"

@@ -232,6 +232,15 @@ class ParticleRoute:
         # particles of the chunk that live on another rank now: what one routed array moves
         self.n_sent = {"sources": int(shard.n_sent_sources),
                        "targets": int(shard.n_sent_targets) if have_targets else None}
+        # the library keeps ONE plan per context (that of its latest exchange) and takes no array
+        # lengths: a route that outlives its exchange would move the new plan's counts through
+        # buffers sized for the old one
+        self.serial = getattr(actx, "_mgpu_exchange_serial", None)
+
+    def _check_current(self):
+        if getattr(self.actx, "_mgpu_exchange_serial", None) != self.serial:
+            raise RuntimeError("ParticleRoute: the context has run another exchange since this route "
+                               "was made; the library keeps the plan of the latest exchange only")
 
     def _set(self, which):
         if which not in ("sources", "targets"):
@@ -246,6 +255,7 @@ class ParticleRoute:
             raise TypeError("ParticleRoute: 1-D arrays of 4- or 8-byte elements")
         if len(array) != n_in:
             raise ValueError(f"ParticleRoute: {len(array)} values for {n_in} {which}")
+        self._check_current()
         a = array.contiguous()
         out = torch.empty(n_out, dtype=a.dtype, device=a.device)
         self.actx.sync_in()
@@ -270,8 +280,10 @@ class ParticleRoute:
         ``particle_id_t``; ``torch.int64`` on request): ``chunk_offset`` of the sending rank +
         index in its chunk, i.e. the index in the concatenation of the ranks' chunks."""
         import torch
-        dtype = dtype or torch.int32
         iset = self._set(which)
+        self._check_current()
+        if dtype is None:       # the reference's particle_id_t while it can name every particle
+            dtype = torch.int32 if self.n_global[which] <= 2**31 - 1 else torch.int64
         out = torch.empty(self.n_owned[which], dtype=dtype, device=f"cuda:{self.actx.device_index}")
         self.actx.sync_in()
         _lib.check(self.actx.lib.bt_mgpu_global_ids(
@@ -281,18 +293,22 @@ class ParticleRoute:
 
     # the two index arrays of the single-GPU Tree (tree.py:426-438), this rank's share
 
-    def global_user_source_ids(self, tree):
+    def global_user_source_ids(self, tree, dtype=None):
         """``user_source_ids`` of the global tree for this rank's sources: entry ``j`` is entry
         ``numbering["source_offset"] + j`` of the array one GPU builds from the concatenated
-        chunks."""
-        return self.global_ids("sources")[tree.user_source_ids.long()]
+        chunks.  *dtype* as in :meth:`global_ids` (int32 while the global count fits, else int64)."""
+        return self.global_ids("sources", dtype)[tree.user_source_ids.long()]
 
     def global_sorted_target_ids(self, tree, target_offset):
         """``sorted_target_ids`` of the global tree for the targets of this rank's CHUNK, in the
         chunk's order: where each of them sits in the global tree's target order
         (*target_offset*: ``numbering["target_offset"]``)."""
+        import torch
         which = "targets" if self.n_owned["targets"] is not None else "sources"
-        return self.to_callers(tree.sorted_target_ids + int(target_offset), which)
+        pos = tree.sorted_target_ids
+        if self.n_global[which] > 2**31 - 1:        # positions beyond particle_id_t: 8-byte ids
+            pos = pos.to(torch.int64)
+        return self.to_callers(pos + int(target_offset), which)
 
 
 def exchange_particles(actx, comm, particles, max_particles_in_box, top_level=None,

@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import dataclasses
 from dataclasses import dataclass
+from functools import cached_property
 from typing import Any
 
 import numpy as np
@@ -83,7 +84,9 @@ class TreeOfBoxes(_Container):
         boxes = np.arange(self.nboxes, dtype=self.box_id_dtype)
         return boxes[self.box_flags & box_flags_enum.IS_LEAF_BOX != 0]
 
-    @property
+    # (a cached_property, not a property, as in the reference: Tree below replaces it by a FIELD, and
+    # a data descriptor on the base class would refuse the frozen dataclass's object.__setattr__)
+    @cached_property
     def bounding_box(self):
         # host values also for device-resident box arrays (local essential trees)
         c0 = self.box_centers[:, 0]
@@ -102,9 +105,10 @@ class TreeOfBoxes(_Container):
 
 
 @dataclass(frozen=True)
-class Tree(_Container):
+class Tree(TreeOfBoxes):
     """Particles sorted into a hierarchy of boxes; field-for-field the
-    reference's :class:`boxtree.Tree` (boxtree/tree.py:298-686)."""
+    reference's :class:`boxtree.Tree` (boxtree/tree.py:298-686), and like it a
+    :class:`TreeOfBoxes` (tree.py:298 ``class Tree(TreeOfBoxes)``)."""
     sources_are_targets: bool
     sources_have_extent: bool
     targets_have_extent: bool
@@ -114,7 +118,9 @@ class Tree(_Container):
     coord_dtype: Any
     box_level_dtype: Any
 
-    bounding_box: Any            # (bbox_min, bbox_max) numpy vectors
+    # (bbox_min, bbox_max) numpy vectors; an explicit field() so that it replaces the base
+    # class's cached property (tree.py:571-574)
+    bounding_box: Any = dataclasses.field(init=True)
     root_extent: Any
     stick_out_factor: Any
     extent_norm: Any

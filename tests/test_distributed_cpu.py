@@ -379,3 +379,55 @@ def test_all_to_all_chunked_world3():
         for limit, (rounds, ok) in res.items():
             assert ok, (rank, limit)
         assert res[8 * 100][0] >= 13 and res[8 * 5000][0] == 1
+
+
+def test_native_particle_route_refuses_to_outlive_its_exchange():
+    """The library keeps the plan of a context's LATEST exchange only and takes no array lengths
+    (bt_mgpu_route): a ParticleRoute kept across a second exchange must raise before it reaches the
+    library, not move the new plan's counts through buffers sized for the old one.  Also: the id
+    width follows the global particle count (int32 = the reference's particle_id_t while it fits)."""
+    import types
+
+    import torch
+    from boxtree_amd.distributed import native as nat
+
+    class Ctx:
+        _mgpu_exchange_serial = 3
+        device_index = 0
+
+        def sync_in(self):
+            raise AssertionError("reached the library")
+
+    def shard(total):
+        return types.SimpleNamespace(n_owned=10, n_owned_targets=0, source_chunk_offset=0, target_chunk_offset=0,
+                                     n_global_sources=total, n_global_targets=0, n_sent_sources=4,
+                                     n_sent_targets=0)
+
+    actx = Ctx()
+    route = nat.ParticleRoute(actx, None, shard(100), 12, None)
+    assert route.serial == 3
+    actx._mgpu_exchange_serial = 4          # another exchange on the same context
+    with pytest.raises(RuntimeError, match="another exchange"):
+        route.to_owners(torch.zeros(12, dtype=torch.float64))
+    with pytest.raises(RuntimeError, match="another exchange"):
+        route.to_callers(torch.zeros(10, dtype=torch.float64))
+    with pytest.raises(RuntimeError, match="another exchange"):
+        route.global_ids("sources")
+    # a current route gets as far as the library (the stub's sync_in) -- with the id width chosen
+    # by the global count
+    for total, want in ((2**31 - 1, torch.int32), (2**31, torch.int64)):
+        route = nat.ParticleRoute(actx, None, shard(total), 12, None)
+        seen = {}
+        real_empty = torch.empty
+
+        def spy(n, dtype=None, device=None):
+            seen["dtype"] = dtype
+            return real_empty(n, dtype=dtype)
+
+        torch.empty = spy
+        try:
+            with pytest.raises(AssertionError, match="reached the library"):
+                route.global_ids("sources")
+        finally:
+            torch.empty = real_empty
+        assert seen["dtype"] == want
