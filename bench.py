@@ -436,10 +436,11 @@ def main():
             gids = None
             if WITH_IDS:
                 gids = route.global_ids("sources")
-                id_bytes = 4 * route.n_sent["sources"]
+                # (int32 = the reference's particle_id_t while the global count fits, else int64)
+                id_bytes = gids.element_size() * route.n_sent["sources"]
                 if t_ is not None:
                     tgids = route.global_ids("targets")
-                    id_bytes += 4 * route.n_sent["targets"]
+                    id_bytes += tgids.element_size() * route.n_sent["targets"]
                     del tgids
             last_exchange.update(bytes_sent=int(xs["bytes_sent"]), owned=int(len(p_[0])),
                                  a2a_ms=xs["a2a_ms"], id_bytes=id_bytes)
@@ -678,6 +679,7 @@ def main():
                                     "the matching one-GPU figure is `bench.py --gpus 1 --workload c5`; the "
                                     "default N = 1 line measures configs[2] (10^8 sphere-surface points)"}
                    if world > 1 and args.workload == "c5" else {}),
+                **({"one_gpu_reference": one_gpu_reference(args.workload)} if world > 1 else {}),
                 **xinfo,
             },
             "roofline": {
@@ -762,6 +764,29 @@ def main():
         native_comm.close()
     if distributed:
         dist.destroy_process_group()
+
+
+def one_gpu_reference(workload):
+    """The committed ONE-GPU line of the same workload (same particles per GPU): what a weak-scaling
+    efficiency of this N > 1 line is computed against -- value_N / (N * value_1) -- without a second
+    run.  `plain`: the single-GPU code path; `sharded_path`: the N > 1 code path on one rank
+    (--force-dist: exchange, numbering, local essential tree with nobody to talk to)."""
+    ref = {}
+    try:
+        files = sorted(os.listdir(os.path.join(ROOT, "profiles")))
+    except OSError:
+        return None
+    for key, suffix in (("plain", f"_bench_{workload}.json"), ("sharded_path", f"_bench_{workload}_forcedist.json")):
+        cand = [f for f in files if f.endswith(suffix)]
+        if not cand:
+            continue
+        try:
+            line = json.loads(open(os.path.join(ROOT, "profiles", cand[-1])).read().strip().splitlines()[-1])
+            ref[key] = {"ms_per_step": line["ms_per_step"], "particles_per_s": line["value"],
+                        "file": f"profiles/{cand[-1]}"}
+        except (OSError, ValueError, KeyError, IndexError):
+            continue
+    return ref or None
 
 
 def emit(out):

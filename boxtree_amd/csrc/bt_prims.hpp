@@ -70,12 +70,8 @@ constexpr int SCAN_ITEMS = 16;
 constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;
 // Scans of more than this many 4096-element tiles use 16384-element tiles (1024 threads): the
 // look-back chain crosses XCDs, a tile of either size costs it about the same, so larger tiles
-// pay as soon as they still fill the CUs (LAB_NOTES.md section 8; BT_SCAN_BIG_TILES: tuning aid)
-inline int64_t scan_big_threshold()
-{
-    static const int64_t v = [] { const char *e = getenv("BT_SCAN_BIG_TILES"); return e ? (int64_t) atoll(e) : (int64_t) 256; }();
-    return v;
-}
+// pay as soon as they still fill the CUs (LAB_NOTES.md section 8)
+inline int64_t scan_big_threshold() { return 256; }
 
 template <class AccT, class F>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_reduce_kernel(F f, int64_t n, AccT *tile_sums)

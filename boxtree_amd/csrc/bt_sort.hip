@@ -26,40 +26,16 @@ constexpr int RADIX = 1 << RADIX_BITS;
 constexpr uint32_t LB_AGG = 1, LB_PREFIX = 2;
 constexpr uint32_t LOOKBACK_SPIN_LIMIT = 1u << 22;
 
-// tile shapes (threads x keys per thread); index chosen by BT_SORT_CFG (tuning aid)
-// MINW = waves per SIMD the register allocator must leave room for
+// Tile shape of the pair sort (threads x keys per thread; MINW = waves per SIMD the register
+// allocator must leave room for).  Twelve other shapes (256 ... 1024 threads, 8 ... 24 keys) were
+// measured in rounds 1-3 (LAB_NOTES.md section 4) and dropped with their switch.
 struct Cfg0 { static constexpr int THREADS = 512, ITEMS = 16, MINW = 4; };
-struct Cfg1 { static constexpr int THREADS = 256, ITEMS = 16, MINW = 4; };
-struct Cfg2 { static constexpr int THREADS = 512, ITEMS = 12, MINW = 4; };
-struct Cfg3 { static constexpr int THREADS = 256, ITEMS = 24, MINW = 2; };
-struct Cfg4 { static constexpr int THREADS = 1024, ITEMS = 8, MINW = 4; };
-struct Cfg5 { static constexpr int THREADS = 512, ITEMS = 8, MINW = 6; };
-struct Cfg6 { static constexpr int THREADS = 512, ITEMS = 14, MINW = 4; };
-struct Cfg7 { static constexpr int THREADS = 512, ITEMS = 10, MINW = 6; };
-struct Cfg8 { static constexpr int THREADS = 768, ITEMS = 8, MINW = 6; };
-struct Cfg9 { static constexpr int THREADS = 384, ITEMS = 16, MINW = 3; };
-struct Cfg10 { static constexpr int THREADS = 512, ITEMS = 12, MINW = 2; };
-struct Cfg11 { static constexpr int THREADS = 256, ITEMS = 20, MINW = 2; };
-// 16384-key tiles: one workgroup per CU (128 KiB reorder buffer), digit runs twice as
-// long (fewer partial lines), half as many look-back rows
-struct Cfg12 { static constexpr int THREADS = 1024, ITEMS = 16, MINW = 4; };
 
 static int sort_dbg()
 {
     static int v = -1;
     if (v < 0) { const char *e = getenv("BT_SORT_DBG"); v = e ? atoi(e) : 0; }
     return v;
-}
-
-static int sort_cfg_index()
-{
-    static int idx = -1;
-    if (idx < 0) {
-        const char *e = getenv("BT_SORT_CFG");
-        idx = e ? atoi(e) : 0;
-        if (idx < 0 || idx > 12) idx = 0;
-    }
-    return idx;
 }
 
 // Look-back words.  64-bit: {generation | flag, count}, one array shared by all passes
@@ -703,19 +679,11 @@ int radix_sort_keys_w(bt_context *ctx, uint64_t *ka, uint64_t *kb, int64_t n, in
     return BT_OK;
 }
 
-// tile shapes of the keys-only pass (BT_SORT_KCFG).  Default: 1024 x 16 keys = 128 KiB of
+// Tile shape of the keys-only pass: 1024 x 16 keys = 128 KiB of
 // LDS, one workgroup per CU -- measured at 10^8 keys, 9-bit digits: 0.468 ms per pass
 // against 0.520 for 512 x 16 (two workgroups per CU), 0.53-0.76 for the smaller tiles:
 // digit runs twice as long (32 keys = 256 bytes at 512 digits) and half the look-back rows
 struct KCfg0 { static constexpr int THREADS = 1024, ITEMS = 16, MINW = 4; };
-struct KCfg1 { static constexpr int THREADS = 512, ITEMS = 12, MINW = 4; };
-struct KCfg2 { static constexpr int THREADS = 512, ITEMS = 16, MINW = 4; };
-struct KCfg3 { static constexpr int THREADS = 512, ITEMS = 18, MINW = 4; };
-struct KCfg4 { static constexpr int THREADS = 1024, ITEMS = 8, MINW = 8; };
-struct KCfg5 { static constexpr int THREADS = 1024, ITEMS = 7, MINW = 8; };
-struct KCfg6 { static constexpr int THREADS = 512, ITEMS = 8, MINW = 6; };
-struct KCfg7 { static constexpr int THREADS = 1024, ITEMS = 12, MINW = 4; };
-struct KCfg8 { static constexpr int THREADS = 512, ITEMS = 14, MINW = 4; };
 
 template <class Tr>
 static int radix_sort_keys_cfg(bt_context *ctx, uint64_t *ka, uint64_t *kb, int64_t n,
@@ -756,18 +724,7 @@ int radix_sort_keys(bt_context *ctx, uint64_t *ka, uint64_t *kb, int64_t n, int 
     if (n == 0 || end_bit == begin_bit) return BT_OK;
     int rb = 8;
     const int npasses = radix_sort_keys_plan(end_bit - begin_bit, &rb);
-    static const int kcfg = [] { const char *e = getenv("BT_SORT_KCFG"); return e ? atoi(e) : 0; }();
-    switch (kcfg) {
-    case 1: return radix_sort_keys_cfg<KCfg1>(ctx, ka, kb, n, begin_bit, npasses, rb, in_b);
-    case 2: return radix_sort_keys_cfg<KCfg2>(ctx, ka, kb, n, begin_bit, npasses, rb, in_b);
-    case 3: return radix_sort_keys_cfg<KCfg3>(ctx, ka, kb, n, begin_bit, npasses, rb, in_b);
-    case 4: return radix_sort_keys_cfg<KCfg4>(ctx, ka, kb, n, begin_bit, npasses, rb, in_b);
-    case 5: return radix_sort_keys_cfg<KCfg5>(ctx, ka, kb, n, begin_bit, npasses, rb, in_b);
-    case 6: return radix_sort_keys_cfg<KCfg6>(ctx, ka, kb, n, begin_bit, npasses, rb, in_b);
-    case 7: return radix_sort_keys_cfg<KCfg7>(ctx, ka, kb, n, begin_bit, npasses, rb, in_b);
-    case 8: return radix_sort_keys_cfg<KCfg8>(ctx, ka, kb, n, begin_bit, npasses, rb, in_b);
-    default: return radix_sort_keys_cfg<KCfg0>(ctx, ka, kb, n, begin_bit, npasses, rb, in_b);
-    }
+    return radix_sort_keys_cfg<KCfg0>(ctx, ka, kb, n, begin_bit, npasses, rb, in_b);
 }
 
 template <class KeyT, class Tr>
@@ -786,21 +743,7 @@ template <class KeyT>
 int radix_sort_pairs(bt_context *ctx, KeyT *ka, uint32_t *va, KeyT *kb, uint32_t *vb,
                      int64_t n, int begin_bit, int end_bit, bool identity_vals, bool *in_b)
 {
-    switch (sort_cfg_index()) {
-    case 1: return radix_sort_pairs_cfg<KeyT, Cfg1>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    case 2: return radix_sort_pairs_cfg<KeyT, Cfg2>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    case 3: return radix_sort_pairs_cfg<KeyT, Cfg3>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    case 4: return radix_sort_pairs_cfg<KeyT, Cfg4>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    case 5: return radix_sort_pairs_cfg<KeyT, Cfg5>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    case 6: return radix_sort_pairs_cfg<KeyT, Cfg6>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    case 7: return radix_sort_pairs_cfg<KeyT, Cfg7>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    case 8: return radix_sort_pairs_cfg<KeyT, Cfg8>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    case 9: return radix_sort_pairs_cfg<KeyT, Cfg9>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    case 10: return radix_sort_pairs_cfg<KeyT, Cfg10>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    case 11: return radix_sort_pairs_cfg<KeyT, Cfg11>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    case 12: return radix_sort_pairs_cfg<KeyT, Cfg12>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    default: return radix_sort_pairs_cfg<KeyT, Cfg0>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
-    }
+    return radix_sort_pairs_cfg<KeyT, Cfg0>(ctx, ka, va, kb, vb, n, begin_bit, end_bit, identity_vals, in_b);
 }
 
 template int radix_sort_pairs<uint64_t>(bt_context *, uint64_t *, uint32_t *, uint64_t *,

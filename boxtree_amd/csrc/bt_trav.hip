@@ -935,24 +935,7 @@ int coll_l2_two_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<int3
         a.coll_starts = coll.starts.get();
         a.coll_lists = coll.lists.get();
         CollL2Out oc{ccnt.get(), lcnt.get(), nullptr, nullptr};
-        // parents of the boxes [b0, b0+nb): the boxes of the level above (or, for a
-        // sharded traversal, its active range)
-        int32_t p0 = ls[lev - 1], np = ls[lev] - ls[lev - 1];
-        if (p.active_level_ranges) {
-            p0 = p.active_level_ranges[2 * (lev - 1)];
-            np = p.active_level_ranges[2 * (lev - 1) + 1] - p0;
-        }
-        static const bool per_box = [] {
-            // tuning aid; measured on c3: per-box (batched loads) 4.9 ms, per-parent
-            // wave 6.0 ms -- both are bound by the latency of dependent loads
-            const char *e = getenv("BT_COLL_PER_BOX");
-            return !e || atoi(e);
-        }();
-        if (per_box)
-            coll_l2_kernel<T, D, false><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(a, b0, nb, oc);
-        else
-            coll_l2_parent_kernel<T, D, false><<<nblk((int64_t) np * 64), 256, 0, ctx->stream>>>(
-                a, p0, np, b0, nb, oc);
+        coll_l2_kernel<T, D, false><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(a, b0, nb, oc);
         int64_t h_tot[2] = {0, 0};
         BT_CHECK(scan_list_counts(ctx, ScanI32{ccnt.get()}, nb, crel.get(), &h_tot[0]));
         BT_CHECK(scan_list_counts(ctx, ScanI32{lcnt.get()}, nb, lrel.get(), &h_tot[1]));
@@ -968,11 +951,7 @@ int coll_l2_two_pass(bt_context *ctx, TravState *st, TravArgs<T, D> &a, Buf<int3
                                                               l2_by_box.get() + b0);
         a.coll_lists = coll.lists.get();
         CollL2Out of{coll.starts.get(), l2_by_box.get(), coll.lists.get(), l2_lists.get()};
-        if (per_box)
-            coll_l2_kernel<T, D, true><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(a, b0, nb, of);
-        else
-            coll_l2_parent_kernel<T, D, true><<<nblk((int64_t) np * 64), 256, 0, ctx->stream>>>(
-                a, p0, np, b0, nb, of);
+        coll_l2_kernel<T, D, true><<<nblk((int64_t) nb * C), 256, 0, ctx->stream>>>(a, b0, nb, of);
         coll_total += h_tot[0];
         l2_total += h_tot[1];
         fill_outside(b0 + nb + 1, ls[lev + 1] + (lev == nlevels - 1 ? 1 : 0), coll_total, l2_total);
@@ -1122,12 +1101,8 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     Buf<int32_t> l2_by_box;
     Buf<int32_t> l2_lists;
     int64_t l2_total = 0;
-    static const bool two_pass_env = [] {
-        const char *e = getenv("BT_COLL_TWO_PASS");     // tuning aid: the count+fill kernels
-        return e && atoi(e);
-    }();
     Buf<int32_t> &srccoll_rows = st->srccoll_rows, &srccoll_cnt = st->srccoll_cnt;
-    const bool single_pass = p.well_sep_is_n_away == 1 && !two_pass_env;
+    const bool single_pass = p.well_sep_is_n_away == 1;      // (else: the count + fill kernels)
     if (single_pass) {
         BT_CHECK((coll_l2_single_pass<T, D>(ctx, st, a, l2_by_box, l2_lists, &l2_total,
                                             srccoll_rows, srccoll_cnt)));
@@ -1182,10 +1157,7 @@ int fast_lists(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         const int64_t ntb = st->ntb;
         // work items: heavy target boxes (far above the leaf level) get one item per
         // colleague, see make_items_kernel
-        static const int heavy_margin = [] {
-            const char *e = getenv("BT_HEAVY_MARGIN");      // tuning aid
-            return e ? atoi(e) : 3;
-        }();
+        constexpr int heavy_margin = 3;
         const int heavy_max_level = nlevels - heavy_margin;
         Buf<int32_t> first_item, item_tbn, item_slot;
         BT_CHECK(first_item.alloc(ctx->pool, ntb + 1));
@@ -1533,10 +1505,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     BT_CHECK(tmark(ctx, st, "trav:colleague rows"));
 
     // ---- work items -----------------------------------------------------------------------
-    static const int heavy_margin = [] {
-        const char *e = getenv("BT_HEAVY_MARGIN");      // tuning aid
-        return e ? atoi(e) : 3;
-    }();
+    constexpr int heavy_margin = 3;
     const int heavy_max_level = nlevels - heavy_margin;
     // columns: the target boxes of level tl make at most cap(tl) items
     L3Layout lay{};
@@ -1720,8 +1689,7 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     Buf<int32_t> l4_cnt, raw4_cnt;
     BT_CHECK(l4_cnt.alloc(ctx->pool, c4.n));
     if (st->with_extent) BT_CHECK(raw4_cnt.alloc(ctx->pool, raw4.n));
-    static const bool l4_float = [] { const char *e = getenv("BT_LIST4_FLOAT"); return e && atoi(e); }();
-    const bool l4_lattice = !st->with_extent && a.nway == 1 && !l4_float;
+    const bool l4_lattice = !st->with_extent && a.nway == 1;
     if (l4_lattice)
         list4_lattice_kernel<D, false><<<nblk(c4.n), 256, 0, ctx->stream>>>(
             (int32_t) c4.n, st->ttp_boxes.get(), cells, p.box_parent_ids, src_rows,
@@ -1808,9 +1776,9 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
             (int32_t) c.n, st->ttp_boxes.get(), l2_by_box.get(), (int32_t) B, c.starts.get());
         rows.l2_starts = l2_by_box.get();
         rows.l2_lists = c.lists.get();
-        // (BT_L2_STAGE=0: every lane stores its own entries -- 0.2 ms slower on 1.25*10^8
-        // uniform points and on the 10^8 + 10^7 extent tree, the same on a sphere surface)
-        rows.l2_stage = [] { const char *e = getenv("BT_L2_STAGE"); return e ? atoi(e) : 1; }();
+        // (0: every lane stores its own entries -- measured 0.2 ms slower on 1.25*10^8 uniform
+        // points and on the 10^8 + 10^7 extent tree, the same on a sphere surface)
+        rows.l2_stage = 1;
         if (B > 1 && c.total > 0 && st->nparents > 0)
             coll_rows_v3_kernel<D, true><<<nblk(st->nparents * V3Lanes<D>::N), 256, 0, ctx->stream>>>(
                 rows, st->parent_boxes.get(), (int32_t) st->nparents, 1, (int32_t) B);
@@ -2119,12 +2087,8 @@ int trav_build_impl(bt_context *ctx, TravState *st, bt_trav_sizes *out)
         const double eps = sizeof(T) == 8 ? 2.220446049250313e-16 : 1.1920928955078125e-07;
         const double rmin = p.root_extent / std::ldexp(1.0, nlevels);     // radius of the deepest level
         const bool levels_ok = rmin > 16.0 * (nlevels + 2) * eps * mag;
-        static const bool v2_off_env = [] {
-            const char *e = getenv("BT_TRAV_V1");            // debugging aid: the float kernels
-            return e && atoi(e);
-        }();
         st->lattice = st->fast && hb[1] == 0 && hb[3] == 0 && levels_ok && p.well_sep_is_n_away == 1
-            && B < ((int64_t) 1 << 26) && nlevels <= 29 && !v2_off_env && p.force_generic != 2;
+            && B < ((int64_t) 1 << 26) && nlevels <= 29 && p.force_generic != 2;
     }
     a.fast = st->fast ? 1 : 0;
 

@@ -428,112 +428,8 @@ __global__ __launch_bounds__(256) void compact_strided_rows_kernel(int64_t nrows
     for (int32_t k = lane; k < e - s; k += LANES) lists[(int64_t) base + s + k] = row[k];
 }
 
-// Same lists, one WAVE per parent box: the candidates (children of the parent's
-// colleagues and of the parent itself, <= 27*8 in 3D) are loaded once and tested
-// against all children of the parent -- an eighth of the node loads of the
-// per-box kernel above -- and the separation threshold, which only depends on the
-// level, is computed once per wave (same expression, traversal.py:279-305).
-template <class T, int D, bool FILL>
-__global__ __launch_bounds__(256) void coll_l2_parent_kernel(TravArgs<T, D> a, int32_t p0,
-        int32_t np, int32_t b0, int32_t nb, CollL2Out o)
-{
-    constexpr int C = 1 << D;
-    const int lane = threadIdx.x & 63;
-    const int32_t wp = (blockIdx.x * 256 + threadIdx.x) >> 6;
-    if (wp >= np) return;
-    const int32_t p = __builtin_amdgcn_readfirstlane(p0 + wp);
-    if (!(box_flags(a, p) & (BT_BOX_HAS_SOURCE_CHILD_BOXES | BT_BOX_HAS_TARGET_CHILD_BOXES))) return;
-
-    int32_t bk[C];
-    T cen[C][D];
-    bool ttp[C];
-    bool any = false;
-#pragma unroll
-    for (int k = 0; k < C; ++k) {
-        int32_t b = child_of<D>(a, p, k);
-        if (b < b0 || b >= b0 + nb) b = 0;          // not ours (sharded traversals)
-        bk[k] = b;
-        any |= b != 0;
-        ttp[k] = false;
-        if (b) {
-            load_center(a, b, cen[k]);
-            ttp[k] = (box_flags(a, b) & (BT_BOX_HAS_TARGET_CHILD_BOXES | BT_BOX_IS_TARGET_BOX))
-                && (!a.target_mask || a.target_mask[b]);
-        }
-    }
-    if (!any) return;
-
-    const int level = box_level(a, p) + 1;
-    // is_adjacent_or_overlapping_with_neighborhood for two boxes of `level`
-    const T target_rad = level_to_rad(a.root_extent, level);
-    const T source_rad = level_to_rad(a.root_extent, level);
-    const T rad_sum = ((2 * ((T) a.nway - 1) + 1) * target_rad + source_rad);
-    const T slack = rad_sum + ((target_rad < source_rad) ? target_rad : source_rad);
-
-    const int32_t ps = a.coll_starts[p];
-    const int32_t n = a.coll_starts[p + 1] - ps;
-    int ins = 0;                         // depth-first position of p among its colleagues
-    for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        ins += __popcll(__ballot(i < n && a.dfs_rank[a.coll_lists[ps + i]] < a.dfs_rank[p]));
-    }
-
-    int32_t ccur[C], lcur[C];
-#pragma unroll
-    for (int k = 0; k < C; ++k) {
-        ccur[k] = (FILL && bk[k]) ? o.coll_cnt_or_starts[bk[k]] : 0;
-        lcur[k] = (FILL && bk[k]) ? o.l2_cnt_or_starts[bk[k]] : 0;
-    }
-    const uint64_t lanes_below = (1ull << lane) - 1ull;
-    const int ncand = (n + 1) * C;
-    for (int base = 0; base < ncand; base += 64) {
-        const int j = base + lane;
-        int32_t ch = 0;
-        bool from_parent = false;
-        T cc[D];
-#pragma unroll
-        for (int ax = 0; ax < D; ++ax) cc[ax] = 0;
-        if (j < ncand) {
-            const int i = j / C, m = j % C;
-            const int32_t c = (i < ins) ? a.coll_lists[ps + i]
-                            : (i == ins ? p : a.coll_lists[ps + i - 1]);
-            from_parent = c == p;
-            ch = child_of<D>(a, c, m);
-            if (ch) load_center(a, ch, cc);
-        }
-#pragma unroll
-        for (int k = 0; k < C; ++k) {
-            if (!bk[k]) continue;                    // wave-uniform
-            T linf = 0;
-#pragma unroll
-            for (int ax = 0; ax < D; ++ax) {
-                T d = cen[k][ax] - cc[ax];
-                d = (d < 0) ? -d : d;
-                linf = (d > linf) ? d : linf;
-            }
-            const bool cand = ch != 0 && ch != bk[k];
-            const bool a_or_o = linf <= slack;
-            const bool is_coll = cand && a_or_o;                            // traversal.py:429-442
-            const bool is_l2 = cand && !a_or_o && !from_parent && ttp[k];   // traversal.py:588-597
-            const uint64_t bc = __ballot(is_coll);
-            const uint64_t bl = __ballot(is_l2);
-            if (FILL) {
-                if (is_coll) o.coll_lists[ccur[k] + __popcll(bc & lanes_below)] = ch;
-                if (is_l2) o.l2_lists[lcur[k] + __popcll(bl & lanes_below)] = ch;
-            }
-            ccur[k] += __popcll(bc);
-            lcur[k] += __popcll(bl);
-        }
-    }
-    if (!FILL) {
-#pragma unroll
-        for (int k = 0; k < C; ++k)
-            if (bk[k] && lane == k) {
-                o.coll_cnt_or_starts[bk[k] - b0] = ccur[k];
-                o.l2_cnt_or_starts[bk[k] - b0] = lcur[k];
-            }
-    }
-}
+// (a variant with one WAVE per parent box -- candidates loaded once for all children -- measured
+// slower on c3, 6.0 against 4.9 ms, and was dropped with its switch in round 6)
 
 __global__ __launch_bounds__(256) void add_base_kernel(int32_t n, const int32_t *rel, int32_t base,
                                                        int32_t *dst)

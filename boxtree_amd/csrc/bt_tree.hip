@@ -1543,183 +1543,11 @@ __global__ __launch_bounds__(256) void segment_sort_block_kernel(const int32_t *
     }
 }
 
-// ---------------------------------------------------------------------------
-// Leaves in one pass (sources == targets, no extents): order the leaf's ids
-// (fix-up), write them out, gather the coordinates of its particles and reduce
-// the leaf's bounding box while they are in registers.  Replaces the in-place id
-// sort, the id copy, the gather's re-read of the ids and the extent kernel's
-// re-read of all gathered coordinates (tbk:776-790, 1170-1186, 1311-1399).
-// ---------------------------------------------------------------------------
-
-template <class T, int D>
-struct LeafOut {
-    int32_t *user_source_ids;
-    T *out[D];
-    T *bmin, *bmax;             // [D][aligned]
-    int64_t aligned;
-};
-
-template <class T, int D>
-__global__ __launch_bounds__(256) void leaf_gather_wave_kernel(int nboxes, const int32_t *box_start,
-        const int32_t *box_count, const uint8_t *box_haschild, const uint32_t *ids,
-        const T *__restrict__ packed, const T *centers /* [box][D] */, LeafOut<T, D> o,
-        int32_t *large_list, SegSortFlags *flags)
-{
-    const int b = (blockIdx.x * 256 + threadIdx.x) >> 5;
-    const int lane = threadIdx.x & 31;
-    if (b >= nboxes) return;
-    if (box_haschild[b]) return;            // no own particles without extents
-    const int n = box_count[b];
-    const int s = box_start[b];
-    if (n > 64) {
-        if (lane == 0) {
-            if (n <= SEG_BLOCK_MAX) large_list[atomicAdd(&flags->n_large, 1)] = b;
-            else atomicExch(&flags->has_huge, 1);
-        }
-        return;
-    }
-    uint32_t v0 = (lane < n) ? ids[s + lane] : 0xFFFFFFFFu;
-    uint32_t v1 = (lane + 32 < n) ? ids[s + lane + 32] : 0xFFFFFFFFu;
-    auto cmpx = [&](uint32_t v, int idx, int k, int j) {
-        const uint32_t other = __shfl_xor(v, j, 32);
-        const bool up = (idx & k) == 0;
-        const bool lower = (idx & j) == 0;
-        const uint32_t mn = v < other ? v : other, mx = v < other ? other : v;
-        return (lower == up) ? mn : mx;
-    };
-    if (n > 1) {
-#pragma unroll
-        for (int k = 2; k <= 32; k <<= 1) {
-#pragma unroll
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                v0 = cmpx(v0, lane, k, j);
-                if (n > 32) v1 = cmpx(v1, lane + 32, k, j);
-            }
-        }
-        if (n > 32) {
-            {
-                const uint32_t mn = v0 < v1 ? v0 : v1, mx = v0 < v1 ? v1 : v0;
-                v0 = mn; v1 = mx;
-            }
-#pragma unroll
-            for (int j = 16; j > 0; j >>= 1) {
-                v0 = cmpx(v0, lane, 64, j);
-                v1 = cmpx(v1, lane + 32, 64, j);
-            }
-        }
-    }
-    constexpr int PS = PackStride<D>::value;
-    T c0[D], c1[D], mn[D], mx[D];
-    const bool h0 = lane < n, h1 = lane + 32 < n;
-#pragma unroll
-    for (int ax = 0; ax < D; ++ax) {
-        c0[ax] = h0 ? packed[(int64_t) v0 * PS + ax] : (T) 0;      // tbk:1170-1186
-        c1[ax] = h1 ? packed[(int64_t) v1 * PS + ax] : (T) 0;
-    }
-    if (h0) o.user_source_ids[s + lane] = (int32_t) v0;
-    if (h1) o.user_source_ids[s + lane + 32] = (int32_t) v1;
-#pragma unroll
-    for (int ax = 0; ax < D; ++ax) {
-        if (h0) __builtin_nontemporal_store(c0[ax], &o.out[ax][s + lane]);
-        if (h1) __builtin_nontemporal_store(c1[ax], &o.out[ax][s + lane + 32]);
-        // tbk:1311-1399: the extent starts from the box centre
-        const T cen = centers[(int64_t) b * D + ax];
-        T lo = cen, hi = cen;
-        if (h0) { lo = c0[ax] < lo ? c0[ax] : lo; hi = c0[ax] > hi ? c0[ax] : hi; }
-        if (h1) { lo = c1[ax] < lo ? c1[ax] : lo; hi = c1[ax] > hi ? c1[ax] : hi; }
-        mn[ax] = lo; mx[ax] = hi;
-    }
-#pragma unroll
-    for (int off = 16; off > 0; off >>= 1) {
-#pragma unroll
-        for (int ax = 0; ax < D; ++ax) {
-            const T omn = __shfl_xor(mn[ax], off, 32), omx = __shfl_xor(mx[ax], off, 32);
-            mn[ax] = (omn < mn[ax]) ? omn : mn[ax];
-            mx[ax] = (omx > mx[ax]) ? omx : mx[ax];
-        }
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int ax = 0; ax < D; ++ax) {
-            o.bmin[(int64_t) ax * o.aligned + b] = mn[ax];
-            o.bmax[(int64_t) ax * o.aligned + b] = mx[ax];
-        }
-    }
-}
-
-// leaves of 65 .. SEG_BLOCK_MAX particles: one workgroup at a time per listed leaf
-template <class T, int D>
-__global__ __launch_bounds__(256) void leaf_gather_block_kernel(const int32_t *large_list,
-        const SegSortFlags *flags, const int32_t *box_start, const int32_t *box_count,
-        const uint32_t *ids, const T *__restrict__ packed, const T *centers, LeafOut<T, D> o)
-{
-    __shared__ uint32_t s_v[SEG_BLOCK_MAX];
-    __shared__ T s_mn[256 / 64][D], s_mx[256 / 64][D];
-    const int nl = flags->n_large;
-    constexpr int PS = PackStride<D>::value;
-    for (int jb = blockIdx.x; jb < nl; jb += gridDim.x) {
-        __syncthreads();
-        const int b = large_list[jb];
-        const int s = box_start[b], n = box_count[b];
-        int m = 128;
-        while (m < n) m <<= 1;
-        for (int i = threadIdx.x; i < m; i += 256) s_v[i] = (i < n) ? ids[s + i] : 0xFFFFFFFFu;
-        __syncthreads();
-        for (int k = 2; k <= m; k <<= 1) {
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = threadIdx.x; i < m; i += 256) {
-                    const int l = i ^ j;
-                    if (l > i) {
-                        const uint32_t a = s_v[i], c = s_v[l];
-                        const bool up = (i & k) == 0;
-                        if ((a > c) == up) { s_v[i] = c; s_v[l] = a; }
-                    }
-                }
-                __syncthreads();
-            }
-        }
-        T mn[D], mx[D];
-#pragma unroll
-        for (int ax = 0; ax < D; ++ax) mn[ax] = mx[ax] = centers[(int64_t) b * D + ax];
-        for (int i = threadIdx.x; i < n; i += 256) {
-            const uint32_t id = s_v[i];
-            o.user_source_ids[s + i] = (int32_t) id;
-#pragma unroll
-            for (int ax = 0; ax < D; ++ax) {
-                const T c = packed[(int64_t) id * PS + ax];
-                o.out[ax][s + i] = c;
-                mn[ax] = c < mn[ax] ? c : mn[ax];
-                mx[ax] = c > mx[ax] ? c : mx[ax];
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-            for (int ax = 0; ax < D; ++ax) {
-                const T omn = __shfl_xor(mn[ax], off, 64), omx = __shfl_xor(mx[ax], off, 64);
-                mn[ax] = (omn < mn[ax]) ? omn : mn[ax];
-                mx[ax] = (omx > mx[ax]) ? omx : mx[ax];
-            }
-        }
-        if ((threadIdx.x & 63) == 0) {
-#pragma unroll
-            for (int ax = 0; ax < D; ++ax) { s_mn[threadIdx.x >> 6][ax] = mn[ax]; s_mx[threadIdx.x >> 6][ax] = mx[ax]; }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int ax = 0; ax < D; ++ax) {
-                T a = s_mn[0][ax], c = s_mx[0][ax];
-                for (int w = 1; w < 256 / 64; ++w) {
-                    a = s_mn[w][ax] < a ? s_mn[w][ax] : a;
-                    c = s_mx[w][ax] > c ? s_mx[w][ax] : c;
-                }
-                o.bmin[(int64_t) ax * o.aligned + b] = a;
-                o.bmax[(int64_t) ax * o.aligned + b] = c;
-            }
-        }
-    }
-}
+// (Leaves in one pass -- ids ordered, written out, coordinates gathered and the leaf's bounding box
+// reduced while they are in registers, a half-wave per leaf -- measured 4.5 ms at 10^8 sphere points
+// against 0.9 + 2.6 + 0.4 ms for the separate id sort, gather and leaf extents: the random 32-byte
+// gathers keep 40 % of a half-wave per ~25-particle leaf busy, a thread per particle all of them.
+// Dropped with its switch in round 6.)
 
 // ---------------------------------------------------------------------------
 // sources / targets (tbk:1013-1164, 1770-1782; tools.py:81-109)
@@ -1797,18 +1625,6 @@ __global__ __launch_bounds__(256) void same_ids_kernel(int64_t n, const uint32_t
     const uint32_t id = ids[p];
     user_source_ids[p] = (int32_t) id;
     if ((int64_t) id < n) sorted_target_ids[id] = (int32_t) p;   // reverse_index_array, tools.py:81-109
-}
-
-// The scatter half of same_ids_kernel restricted to destinations [lo, hi): run
-// over a few destination windows that each fit the 256 MB memory-side cache, the
-// sixteen 4-byte writes of a line merge there instead of each costing a DRAM burst.
-__global__ __launch_bounds__(256) void inverse_ids_window_kernel(int64_t n, const uint32_t *ids,
-        uint32_t lo, uint32_t hi, int32_t *sorted_target_ids)
-{
-    const int64_t p = (int64_t) blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t id = ids[p];
-    if (id >= lo && id < hi && (int64_t) id < n) sorted_target_ids[id] = (int32_t) p;
 }
 
 // inverse permutation from (id, position) pairs that one radix pass has grouped by
@@ -2536,10 +2352,6 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys, const u
         return BT_OK;
     };
 
-    static const bool walk_pass = [] {
-        const char *e = getenv("BT_LR_WALK");           // debugging aid: the literal walk
-        return e && atoi(e);
-    }();
     Buf<uint64_t> box_path;
     int64_t path_cap = 0, paths_done = 1;
     auto update_paths = [&]() -> int {
@@ -2611,7 +2423,7 @@ int lr_build_boxes(bt_context *ctx, TreeState *st, const uint64_t *keys, const u
             BT_HIP_CHECK(hipMemsetAsync(d_have.get(), 0, 4, ctx->stream));
             // (the look-up form descends along 64-bit Morton paths: trees that deep -- below
             // the first key -- take the reference's walk)
-            if (walk_pass || D * level > 63) {
+            if (D * level > 63) {
                 lr_pass_kernel<T, D><<<(unsigned) div_up(nb, WALK_THREADS), WALK_THREADS, lds, ctx->stream>>>(
                     nb, upper_level, (T) p.root_extent, st->box_level.get(), st->box_haschild.get(),
                     st->box_child.get(), (const T *) st->centers.get(), force.get(), d_have.get());
@@ -2954,9 +2766,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     bool can_pack;
     {
         const char *e_off = getenv("BT_NO_PACKED_KEYS");
-        const char *e_fused = getenv("BT_FUSED_LEAVES"), *e_full = getenv("BT_FULL_SORT");
-        can_pack = !(e_off && atoi(e_off)) && !(e_fused && atoi(e_fused)) && !(e_full && atoi(e_full))
-            && !p.refine_weights && p.kind == BT_KIND_ADAPTIVE
+        can_pack = !(e_off && atoi(e_off)) && !p.refine_weights && p.kind == BT_KIND_ADAPTIVE
             && (EXT || p.max_leaf_refine_weight <= SEG_BLOCK_MAX) && N >= 2 && lk_max >= 1;
     }
     // levels the packed word holds for a depth estimate: the passes are whole digits, take
@@ -2996,8 +2806,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
         const int fan = D > 1 ? D - 1 : 1;
         if (!p.top_cell_prefix) est_levels = (int) std::ceil(std::log2(per_leaf) / fan) + 2;
         est_levels = std::max(1, std::min(est_levels, st->L));
-        static const bool probe_off = [] { const char *e = getenv("BT_NO_DEPTH_PROBE"); return e && atoi(e); }();
-        const bool probe = !probe_off && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED
+        const bool probe = p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED
             && (p.top_cell_prefix || N >= ((int64_t) 1 << 20));
         if (probe) {
             int k = p.top_cell_prefix ? p.top_level : (D == 3 ? 4 : D == 2 ? 6 : 12);
@@ -3075,11 +2884,7 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     // to that level.  6 passes instead of 8 at 10^8 + 10^7 particles.
     const int keybits = D * st->L + st->capbits;
     int sorted_high_bits = keybits;
-    static const bool partial_sort_ok = [] {
-        const char *e = getenv("BT_FULL_SORT");      // debugging aid: 1 = always sort all bits
-        return !(e && atoi(e));
-    }();
-    if (partial_sort_ok && !p.refine_weights && keybits > 40 + (EXT ? 8 : 0)
+    if (!p.refine_weights && keybits > 40 + (EXT ? 8 : 0)
             && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED) {
         // (depth estimate above)
         int bits = ((D * est_levels + 7) / 8) * 8;
@@ -3144,10 +2949,9 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     Buf<int64_t> local_cells;
     int local_top_level = 0;
     {
-        static const bool off = [] { const char *e = getenv("BT_NO_CELL_STARTS"); return e && atoi(e); }();
         int k = D == 3 ? 5 : D == 2 ? 7 : 15;
         k = std::min(k, packed ? pk_sorted : st->L);
-        if (!off && !EXT && !p.refine_weights && N >= 4096 && k >= 2
+        if (!EXT && !p.refine_weights && N >= 4096 && k >= 2
                 && p.kind != BT_KIND_ADAPTIVE_LEVEL_RESTRICTED) {
             const int64_t ncells = (int64_t) 1 << (D * k);
             BT_CHECK(local_cells.alloc(ctx->pool, ncells + 1));
@@ -3487,18 +3291,8 @@ int tree_build_impl(bt_context *ctx, TreeState *st, bt_tree_sizes *out)
     st->ids_other = ids_other;
     st->pk = packed ? keys_cur : nullptr;
     st->pk_mask = packed ? ((uint64_t) 1 << pk_idbits) - 1 : 0;
-    // sources == targets without extents: the leaves CAN be ordered, gathered and
-    // measured in one pass at export time (leaf_gather_wave_kernel, BT_FUSED_LEAVES=1).
-    // Measured at 10^8 sphere points: 4.5 ms against 0.9 + 2.6 + 0.4 ms for the separate
-    // id sort, gather and leaf extents -- a half-wave per leaf of ~25 particles keeps
-    // 40 % of the lanes busy during the random 32-byte gathers, the thread-per-particle
-    // gather keeps all of them busy -- so it is off by default (3 % faster at 10^7).
-    static const bool fused_env = [] {
-        const char *e = getenv("BT_FUSED_LEAVES");
-        return e && atoi(e);
-    }();
     st->fixup_done = false;
-    if (!(fused_env && st->sat && !EXT)) BT_CHECK(fixup_launch(ctx, st));
+    BT_CHECK(fixup_launch(ctx, st));
     BT_CHECK(mark(ctx, st, "fixup"));
 
     // keys are no longer needed
@@ -3552,48 +3346,15 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
                                                           st->src_before.get(), (int32_t *) nullptr, true)));
     }
     BT_CHECK(mark(ctx, st, "srcscan"));
-    // ---- leaves in one pass (sources == targets, no extents): ids in their final order,
-    // coordinates, leaf extents -------------------------------------------------------------
-    const bool fused = !st->fixup_done && N > 1;
-    Buf<int32_t> large_list;
-    Buf<SegSortFlags> sflags;
-    if (fused) {
-        T *bmin = (T *) o->box_source_bounding_box_min, *bmax = (T *) o->box_source_bounding_box_max;
-        BT_HIP_CHECK(hipMemsetAsync(bmin, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
-        BT_HIP_CHECK(hipMemsetAsync(bmax, 0, (size_t) (D * aligned) * sizeof(T), ctx->stream));
-        BT_CHECK(large_list.alloc(ctx->pool, N / 64 + 1));
-        BT_CHECK(sflags.alloc(ctx->pool, 1));
-        BT_HIP_CHECK(hipMemsetAsync(sflags.get(), 0, sizeof(SegSortFlags), ctx->stream));
-        LeafOut<T, D> lo{};
-        lo.user_source_ids = o->user_source_ids;
-        for (int ax = 0; ax < D; ++ax) lo.out[ax] = (T *) o->sources[ax];
-        lo.bmin = bmin; lo.bmax = bmax; lo.aligned = aligned;
-        leaf_gather_wave_kernel<T, D><<<blocks(B * 32), 256, 0, ctx->stream>>>(
-            (int) B, st->box_start.get(), st->box_count.get(), st->box_haschild.get(), st->ids,
-            (const T *) st->packed.get(), (const T *) st->centers.get(), lo, large_list.get(),
-            sflags.get());
-        leaf_gather_block_kernel<T, D><<<(unsigned) std::min<int64_t>(ctx->num_cus * 2, N / 64 + 1), 256, 0,
-                                         ctx->stream>>>(
-            large_list.get(), sflags.get(), st->box_start.get(), st->box_count.get(), st->ids,
-            (const T *) st->packed.get(), (const T *) st->centers.get(), lo);
-        BT_HIP_CHECK(hipGetLastError());
-    }
     BT_CHECK(mark(ctx, st, "leaves"));
-    const uint32_t *final_ids = fused ? (const uint32_t *) o->user_source_ids : st->ids;
+    const uint32_t *final_ids = st->ids;
     // ---- ids -------------------------------------------------------------------
     if (N > 0) {
-        static const int id_windows_env = [] {
-            const char *e = getenv("BT_ID_WINDOWS");     // tuning aid
-            return e ? atoi(e) : 0;
-        }();
-        // destination windows of ~100 MB; measured at 10^8 ids: 1 window 2.26 ms,
-        // 2: 2.11, 4: 1.86, 8: 2.47 (every window re-reads the ids)
-        const int id_windows = id_windows_env > 0 ? id_windows_env
-            : (int) std::min<int64_t>(4, std::max<int64_t>(1, N / (20 << 20)));
-        if (sat && id_windows_env == 0 && N >= ((int64_t) 1 << 22)) {
+        if (sat && N >= ((int64_t) 1 << 22)) {
             // sorted_target_ids = inverse of the sort permutation.  A direct scatter
-            // costs a DRAM burst per 4-byte write (2.26 ms at 10^8), four destination
-            // windows 1.86 ms; grouping the (id, position) pairs by the id's top byte
+            // costs a DRAM burst per 4-byte write (2.26 ms at 10^8), scattering into four
+            // destination windows of ~100 MB one after the other 1.86 ms (8 windows: 2.47, every
+            // window re-reads the ids; dropped); grouping the (id, position) pairs by the id's top byte
             // first (one 32-bit onesweep pass that synthesises the positions) makes
             // the scatter local.
             int bits = 0;
@@ -3603,7 +3364,7 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
             BT_CHECK(positions.alloc(ctx->pool, N));
             bool in_b = false;
             // (user_source_ids is a copy of the ids: the sort's histogram pass writes it)
-            if (!fused) ctx->sort_copy_keys = o->user_source_ids;
+            ctx->sort_copy_keys = o->user_source_ids;
             BT_CHECK(radix_sort_pairs<uint32_t>(ctx, const_cast<uint32_t *>(final_ids), nullptr,
                                                 grouped_ids.get(), positions.get(), N, bits - 8, bits,
                                                 true, &in_b));
@@ -3613,14 +3374,6 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
             const unsigned nb = (unsigned) ((blocks(N) + 7) / 8 * 8);
             scatter_inverse_kernel<<<nb, 256, 0, ctx->stream>>>(
                 N, grouped_ids.get(), positions.get(), o->sorted_target_ids);
-        } else if (sat && id_windows > 1) {
-            if (!fused) copy_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(N, st->ids, o->user_source_ids);
-            for (int w = 0; w < id_windows; ++w) {
-                const uint32_t lo = (uint32_t) (N * w / id_windows);
-                const uint32_t hi = (uint32_t) (N * (w + 1) / id_windows);
-                inverse_ids_window_kernel<<<blocks(N), 256, 0, ctx->stream>>>(
-                    N, final_ids, lo, hi, o->sorted_target_ids);
-            }
         } else if (sat) {
             same_ids_kernel<<<blocks(N), 256, 0, ctx->stream>>>(N, final_ids, o->user_source_ids,
                                                               o->sorted_target_ids);
@@ -3641,7 +3394,7 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
             gs.out[ax] = (T *) o->sources[ax];
             gt.out[ax] = sat ? nullptr : (T *) o->targets[ax];
         }
-        if (st->nsources > 0 && !fused)
+        if (st->nsources > 0)
             gather_packed_kernel<T, D><<<blocks(st->nsources), 256, 0, ctx->stream>>>(
                 st->nsources, o->user_source_ids, packed, gs);
         if (!sat && st->ntargets > 0)
@@ -3675,10 +3428,10 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
         a.o_levels = o->box_levels; a.o_flags = o->box_flags;
         a.centers = st->centers.get(); a.o_centers = o->box_centers; a.csize = (int) sizeof(T);
         // (box_extent_kernel writes every box of every level: only the padding needs zeros)
-        a.o_extents[0] = fused ? nullptr : o->box_source_bounding_box_min;
-        a.o_extents[1] = fused ? nullptr : o->box_source_bounding_box_max;
-        a.o_extents[2] = (fused || sat) ? nullptr : o->box_target_bounding_box_min;
-        a.o_extents[3] = (fused || sat) ? nullptr : o->box_target_bounding_box_max;
+        a.o_extents[0] = o->box_source_bounding_box_min;
+        a.o_extents[1] = o->box_source_bounding_box_max;
+        a.o_extents[2] = sat ? nullptr : o->box_target_bounding_box_min;
+        a.o_extents[3] = sat ? nullptr : o->box_target_bounding_box_max;
         a.o_level_starts = o->level_start_box_nrs;
         a.o_sizes = o->box_subtree_sizes;
         a.n_level_starts = (int) std::min<size_t>(st->level_start.size(), BT_MAX_LEVELS + 1);
@@ -3695,9 +3448,9 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
         T *bmax = (T *) (round == 0 ? o->box_source_bounding_box_max : o->box_target_bounding_box_max);
 
         // (with the leaves done the deepest level has nothing left)
-        for (int lev = nlevels - 1 - (fused ? 1 : 0); lev >= 0; --lev) {
+        for (int lev = nlevels - 1; lev >= 0; --lev) {
             ExtentArgs<T, D> a;
-            a.leaves_done = fused ? 1 : 0;
+            a.leaves_done = 0;
             a.b0 = st->level_start[lev];
             a.nb = st->level_start[lev + 1] - a.b0;
             a.aligned = aligned;
@@ -3717,19 +3470,6 @@ int tree_export_impl(bt_context *ctx, TreeState *st, const bt_tree_arrays *o)
     }
     BT_HIP_CHECK(hipGetLastError());
     BT_CHECK(mark(ctx, st, "extents"));
-    if (fused) {
-        SegSortFlags hf;
-        BT_CHECK(bt::d2h(ctx, &hf, sflags.get(), sizeof(hf)));
-        BT_CHECK(bt::check_status(ctx));       // waits; the sort and the scans above report here
-        ctx->n_host_syncs++;
-        if (hf.has_huge) {
-            // a leaf beyond the workgroup sort (zero refine weights): order the ids with
-            // the global fix-up and take the general path
-            BT_CHECK(run_fixup(ctx, st));
-            return tree_export_impl<T, D>(ctx, st, o);
-        }
-        return BT_OK;
-    }
     // (a stream-ordered context does not wait here: the caller's arrays are ordered by
     // the stream, boxtree_hip.h bt_set_stream_ordered)
     if (!ctx->stream_ordered) ctx->n_host_syncs++;
