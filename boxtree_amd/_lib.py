@@ -30,7 +30,7 @@ P3 = vp * BT_MAX_DIMS
 PL = vp * BT_MAX_LEVELS
 
 
-ABI_VERSION = 10     # BT_ABI_VERSION of include/boxtree_hip.h
+ABI_VERSION = 11     # BT_ABI_VERSION of include/boxtree_hip.h
 
 
 class SortStats(ct.Structure):
@@ -271,7 +271,7 @@ EXPORTED_SYMBOLS = [
     "bt_filter_targets_user_order", "bt_filter_targets_tree_order", "bt_link_point_sources",
     "bt_box_morton_paths", "bt_let_build", "bt_mgpu_exchange", "bt_mgpu_exchange_time", "bt_mgpu_plan", "bt_mgpu_plan_ext",
     "bt_mgpu_comm_rccl", "bt_mgpu_local_group_create", "bt_mgpu_local_group_destroy",
-    "bt_mgpu_comm_local", "bt_mgpu_comm_destroy", "bt_mgpu_use_rccl_library",
+    "bt_mgpu_comm_local", "bt_mgpu_comm_shm", "bt_mgpu_comm_destroy", "bt_mgpu_use_rccl_library",
     "bt_mgpu_comm_set_self_loopback", "bt_mgpu_number", "bt_mgpu_let_build",
     "bt_mgpu_let_export", "bt_mgpu_route", "bt_mgpu_global_ids",
     "bt_dfs_order", "bt_partition_work", "bt_ancestor_mask", "bt_mark_list_boxes",
@@ -337,6 +337,7 @@ def load():
     lib.bt_mgpu_local_group_destroy.argtypes = [vp]
     lib.bt_mgpu_local_group_destroy.restype = None
     lib.bt_mgpu_comm_local.argtypes = [vp, ct.c_int, ct.POINTER(vp)]
+    lib.bt_mgpu_comm_shm.argtypes = [ct.c_char_p, ct.c_int, ct.c_int, ct.c_int64, ct.c_double, ct.POINTER(vp)]
     lib.bt_mgpu_comm_destroy.argtypes = [vp]
     lib.bt_mgpu_comm_destroy.restype = None
     lib.bt_mgpu_use_rccl_library.argtypes = [ct.c_char_p]

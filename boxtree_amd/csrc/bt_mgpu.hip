@@ -30,6 +30,7 @@
 #include "bt_common.hpp"
 #include "bt_prims.hpp"
 #include "bt_sort.hpp"
+#include "bt_shm_group.hpp"
 
 #include <dlfcn.h>
 
@@ -154,10 +155,12 @@ struct LocalGroup {
 }  // namespace
 
 struct bt_mgpu_comm {
-    int kind = 0;                 // 0: RCCL, 1: threads of one process
+    int kind = 0;                 // 0: RCCL, 1: threads of one process, 2: processes over shared memory
     int rank = 0, nranks = 1;
     nccl_comm_t nccl = nullptr;
     LocalGroup *group = nullptr;
+    bt::ShmGroup *shm = nullptr;  // kind 2 (owned)
+    ~bt_mgpu_comm() { delete shm; }
     bool self_loopback = false;   // RCCL: a rank's message to itself travels as ncclSend/ncclRecv too
     // ranks as threads: what this rank publishes for its peers to read lives as long as the
     // communicator (a rank that leaves a collective on a failed barrier must not take the
@@ -169,6 +172,27 @@ namespace {
 
 enum { RED_SUM_I64 = 0, RED_MIN_F64 = 1 };
 
+// kind 2: device bytes to and from the shared segment, on the context's stream, complete at return
+int shm_to_host(void *user, void *host, const void *dev, size_t bytes)
+{
+    hipStream_t stream = *(hipStream_t *) user;
+    if (hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return 1;
+    return hipStreamSynchronize(stream) == hipSuccess ? 0 : 1;
+}
+int shm_to_dev(void *user, void *dev, const void *host, size_t bytes)
+{
+    hipStream_t stream = *(hipStream_t *) user;
+    if (hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return 1;
+    return hipStreamSynchronize(stream) == hipSuccess ? 0 : 1;
+}
+#define BT_SHM_CHECK(c, expr)                                                     \
+    do {                                                                          \
+        if (!(expr)) {                                                            \
+            ::bt::set_error("shared-memory group, rank %d: %s", (c)->rank, (c)->shm->last_error()); \
+            return BT_ERR_INTERNAL;                                               \
+        }                                                                         \
+    } while (0)
+
 // in-place all-reduce of a small device array (8-byte elements)
 int comm_all_reduce(bt_mgpu_comm *c, hipStream_t stream, void *dev, size_t count, int what)
 {
@@ -176,6 +200,11 @@ int comm_all_reduce(bt_mgpu_comm *c, hipStream_t stream, void *dev, size_t count
         Nccl &nc = nccl();
         BT_NCCL_CHECK(nc.AllReduce(dev, dev, count, what == RED_SUM_I64 ? NCCL_INT64 : NCCL_FLOAT64,
                                    what == RED_SUM_I64 ? NCCL_SUM : NCCL_MIN, c->nccl, stream));
+        return BT_OK;
+    }
+    if (c->kind == 2) {
+        bt::ShmMover mv{&stream, shm_to_host, shm_to_dev};
+        BT_SHM_CHECK(c, c->shm->all_reduce(mv, dev, count, what == RED_MIN_F64));
         return BT_OK;
     }
     LocalGroup *g = c->group;
@@ -210,6 +239,11 @@ int comm_all_gather(bt_mgpu_comm *c, hipStream_t stream, const void *send, void 
         BT_NCCL_CHECK(nccl().AllGather(send, recv, bytes, NCCL_UINT8, c->nccl, stream));
         return BT_OK;
     }
+    if (c->kind == 2) {
+        bt::ShmMover mv{&stream, shm_to_host, shm_to_dev};
+        BT_SHM_CHECK(c, c->shm->all_gather(mv, send, recv, bytes));
+        return BT_OK;
+    }
     LocalGroup *g = c->group;
     BT_HIP_CHECK(hipStreamSynchronize(stream));
     g->ptr[c->rank] = send;
@@ -235,6 +269,14 @@ int comm_all_to_all_v(bt_mgpu_comm *c, hipStream_t stream, const char *send, con
     if (!self_done && !loop_self && s_cnt[me] > 0)
         BT_HIP_CHECK(hipMemcpyAsync(recv + r_off[me], send + s_off[me], (size_t) s_cnt[me],
                                     hipMemcpyDeviceToDevice, stream));
+    if (c->kind == 2) {
+        // (the rank's own segment went by device copy above, or was written in place)
+        bt::ShmMover mv{&stream, shm_to_host, shm_to_dev};
+        int rounds = 1;
+        BT_SHM_CHECK(c, c->shm->all_to_all_v(mv, send, s_off, s_cnt, recv, r_off, r_cnt, /*skip_self=*/true, &rounds));
+        if (rounds_out) *rounds_out = std::max(1, rounds);
+        return BT_OK;
+    }
     if (c->kind == 1) {
         LocalGroup *g = c->group;
         BT_HIP_CHECK(hipStreamSynchronize(stream));
@@ -1097,6 +1139,19 @@ int bt_mgpu_comm_local(void *group, int rank, bt_mgpu_comm **out)
     if (!g || !out || rank < 0 || rank >= g->n) { set_error("bt_mgpu_comm_local: invalid argument"); return BT_ERR_INVALID; }
     bt_mgpu_comm *c = new bt_mgpu_comm();
     c->kind = 1; c->rank = rank; c->nranks = g->n; c->group = g;
+    *out = c;
+    return BT_OK;
+}
+
+int bt_mgpu_comm_shm(const char *name, int rank, int nranks, int64_t slot_bytes, double timeout_s, bt_mgpu_comm **out)
+{
+    if (!out) { set_error("bt_mgpu_comm_shm: invalid argument"); return BT_ERR_INVALID; }
+    std::string err;
+    bt::ShmGroup *g = bt::ShmGroup::open(name, rank, nranks, slot_bytes > 0 ? slot_bytes : (int64_t) 64 << 20,
+                                         timeout_s > 0 ? timeout_s : 120.0, &err);
+    if (!g) { set_error("bt_mgpu_comm_shm: %s", err.c_str()); return BT_ERR_INVALID; }
+    bt_mgpu_comm *c = new bt_mgpu_comm();
+    c->kind = 2; c->rank = rank; c->nranks = nranks; c->shm = g;
     *out = c;
     return BT_OK;
 }
@@ -2176,10 +2231,12 @@ static int bt_mgpu_let_build_body(bt_context *ctx, bt_mgpu_comm *comm, const bt_
 }
 
 // A rank that leaves a collective entry with an error tells the local group, so that its peers
-// (threads waiting at a barrier of the same collective) return an error instead of waiting.
+// (threads, or processes of a shared-memory group, waiting at a barrier of the same collective)
+// return an error instead of waiting.
 static int peer_result(bt_mgpu_comm *comm, int status)
 {
     if (status != BT_OK && comm && comm->kind == 1 && comm->group) comm->group->fail();
+    if (status != BT_OK && comm && comm->kind == 2 && comm->shm) comm->shm->fail();
     return status;
 }
 

@@ -67,6 +67,18 @@ class LocalGroup:
             self.handle = None
 
 
+def shm_comm(name, rank, nranks, slot_bytes=0, timeout_s=0.0):
+    """A :class:`NativeComm` whose ranks are PROCESSES that share a GPU (``bt_mgpu_comm_shm``): the
+    collectives are staged through the POSIX shared-memory segment *name* (``"/..."``, the same fresh
+    name on every rank of the job).  RCCL refuses two ranks on one device; this is how the N-rank
+    code runs as N real processes on a one-GPU box -- a correctness vehicle, nothing to time."""
+    lib = _lib.load()
+    h = ct.c_void_p()
+    _lib.check(lib.bt_mgpu_comm_shm(name.encode(), int(rank), int(nranks), int(slot_bytes), float(timeout_s),
+                                    ct.byref(h)))
+    return NativeComm(lib, h, int(rank), int(nranks), "processes")
+
+
 class _RcclComm:
     """An RCCL communicator of our own, created through ctypes (torch does not hand out
     the ``ncclComm_t`` of its process groups).  The unique id travels over *dist*."""

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define BT_ABI_VERSION 10
+#define BT_ABI_VERSION 11
 #define BT_MAX_DIMS 3
 #define BT_MAX_LEVELS 64       /* capacity of per-level arrays in the structs */
 
@@ -572,6 +572,15 @@ int bt_mgpu_comm_rccl(void *nccl_comm, int rank, int nranks, bt_mgpu_comm **out)
 int bt_mgpu_local_group_create(int nranks, void **group);
 void bt_mgpu_local_group_destroy(void *group);
 int bt_mgpu_comm_local(void *group, int rank, bt_mgpu_comm **out);
+/* Ranks as PROCESSES that share a GPU (RCCL refuses that; threads share an address space): the
+ * collectives are staged through the POSIX shared-memory segment `name` ("/..."; every rank of
+ * the job opens the same fresh name, the last one to destroy its communicator unlinks it) in
+ * slots of slot_bytes per rank (<= 0: 64 MiB; larger messages go in rounds); a rank that waits
+ * longer than timeout_s (<= 0: 120 s) for a peer fails the group.  Every byte crosses the host:
+ * a vehicle for running the N-rank code as N real processes on a box with one GPU (tests,
+ * `bench.py --gpus 2` there), not a transport to measure. */
+int bt_mgpu_comm_shm(const char *name, int rank, int nranks, int64_t slot_bytes, double timeout_s,
+                     bt_mgpu_comm **out);
 void bt_mgpu_comm_destroy(bt_mgpu_comm *comm);
 /* The library binds the few RCCL entry points it uses at run time (no link-time dependency).
  * A communicator must be used through the image of RCCL that made it: name that image here

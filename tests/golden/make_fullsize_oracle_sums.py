@@ -67,25 +67,19 @@ def sharded_sums(torch, tree, trav):
     """The sums a sharded build can reproduce rank by rank (distributed/checksum.py for the tree;
     fullsize_sums.csr_rows_sum with global box numbers for the lists)."""
     import fullsize_sums as fs
+    import sharded_sums as ss
     nb = int(tree.nboxes)
     gids = torch.arange(nb, dtype=torch.int64)
+    lists = ss.single_tree_sums(torch, tree, trav)
     out = {
         "nboxes": nb, "nlevels": int(tree.nlevels),
         "level_start_box_nrs": [int(v) for v in tree.level_start_box_nrs],
         "counts_cumul_checksum": fs.rows_sum(torch, gids, torch.from_numpy(tree.box_source_counts_cumul).to(torch.int64)),
         "user_source_ids_checksum": fs.array_sum(torch, tree.user_source_ids),
         "ntarget_boxes": len(trav.target_boxes),
-        "colleagues": fs.csr_rows_sum(torch, trav.same_level_non_well_sep_boxes_starts,
-                                      trav.same_level_non_well_sep_boxes_lists),
-        "list1": fs.csr_rows_sum(torch, trav.neighbor_source_boxes_starts, trav.neighbor_source_boxes_lists,
-                                 row_gid=trav.target_boxes),
-        "list2": fs.csr_rows_sum(torch, trav.from_sep_siblings_starts, trav.from_sep_siblings_lists,
-                                 row_gid=trav.target_or_target_parent_boxes),
-        "list4": fs.csr_rows_sum(torch, trav.from_sep_bigger_starts, trav.from_sep_bigger_lists,
-                                 row_gid=trav.target_or_target_parent_boxes),
-        "list3": [fs.csr_rows_sum(torch, bl.starts, bl.lists,
-                                  row_gid=trav.target_boxes_sep_smaller_by_source_level[lev])
-                  for lev, bl in enumerate(trav.from_sep_smaller_by_level)],
+        "colleagues": lists["colleagues"], "list1": lists["list1"], "list2": lists["list2"],
+        "list4": lists["list4"],
+        "list3": [lists[f"list3[{lev}]"] for lev in range(int(tree.nlevels))],
         "entries": {"colleagues": len(trav.same_level_non_well_sep_boxes_lists),
                     "list1": len(trav.neighbor_source_boxes_lists),
                     "list2": len(trav.from_sep_siblings_lists),

@@ -115,19 +115,9 @@ def test_c5_eight_ranks_lists_sum_to_the_oracle_single_tree():
     dev = torch.device("cuda", 0)
     group = nat.LocalGroup(world)
     res, errors = [None] * world, []
-    names = ["colleagues", "list1", "list2", "list4"] + [f"list3[{lev}]" for lev in range(gold["nlevels"])]
-    acc = {k: torch.zeros(nglobal, dtype=torch.int64, device=dev) for k in names}
-    seen = {k: torch.zeros(nglobal, dtype=torch.bool, device=dev) for k in names}
-    disagreements = []
+    import sharded_sums as ss
+    merger = ss.RowMerger(torch, nglobal, gold["nlevels"], dev)
     merge = threading.Lock()
-
-    def put(name, g, vals):
-        g = g.to(torch.int64)
-        old = seen[name][g]
-        if bool((acc[name][g][old] != vals[old]).any()):
-            disagreements.append(name)
-        acc[name][g] = vals
-        seen[name][g] = True
 
     def run(rank):
         try:
@@ -143,24 +133,9 @@ def test_c5_eight_ranks_lists_sum_to_the_oracle_single_tree():
             trav, ev = FMMTraversalBuilder(actx)(actx, let, _target_boxes_mask=info["target_boxes_mask"],
                                                  _active_level_ranges=info["active_level_ranges"])
             ev.wait()
-            gid = info["global_box_ids"].to(torch.int64)
-            mask = info["target_boxes_mask"]
+            rows = ss.rank_rows(torch, trav, info["global_box_ids"], info["target_boxes_mask"])
             with merge:
-                act = torch.nonzero(mask != 0).reshape(-1)
-                v = fs.csr_row_values(torch, trav.same_level_non_well_sep_boxes_starts,
-                                      trav.same_level_non_well_sep_boxes_lists, entry_gid=gid)
-                put("colleagues", gid[act], v[act])
-                put("list1", gid[trav.target_boxes.long()], fs.csr_row_values(
-                    torch, trav.neighbor_source_boxes_starts, trav.neighbor_source_boxes_lists, entry_gid=gid))
-                ttp = gid[trav.target_or_target_parent_boxes.long()]
-                put("list2", ttp, fs.csr_row_values(torch, trav.from_sep_siblings_starts,
-                                                    trav.from_sep_siblings_lists, entry_gid=gid))
-                put("list4", ttp, fs.csr_row_values(torch, trav.from_sep_bigger_starts,
-                                                    trav.from_sep_bigger_lists, entry_gid=gid))
-                for lev, bl in enumerate(trav.from_sep_smaller_by_level):
-                    tb = trav.target_boxes_sep_smaller_by_source_level[lev]
-                    put(f"list3[{lev}]", gid[tb.long()],
-                        fs.csr_row_values(torch, bl.starts, bl.lists, entry_gid=gid))
+                merger.add(rows)
             res[rank] = dict(
                 checksum=tree_checksum(torch, num["box_ids"], tree.box_source_counts_cumul),
                 ids_checksum=particle_order_checksum(torch, ids, num["source_offset"]),
@@ -180,7 +155,7 @@ def test_c5_eight_ranks_lists_sum_to_the_oracle_single_tree():
     assert all(not t.is_alive() for t in threads), "a rank hangs"
     group.close()
     assert not errors, errors
-    assert not disagreements, f"ranks disagree on shared rows of {sorted(set(disagreements))}"
+    assert not merger.disagreements, f"ranks disagree on shared rows of {sorted(set(merger.disagreements))}"
     for r in res:
         assert (r["nboxes"], r["nlevels"]) == (gold["nboxes"], gold["nlevels"])
         assert r["level_starts"] == gold["level_start_box_nrs"]
@@ -188,8 +163,7 @@ def test_c5_eight_ranks_lists_sum_to_the_oracle_single_tree():
     assert wrap_int64(sum(r["checksum"] for r in res)) == gold["counts_cumul_checksum"]
     assert wrap_int64(sum(r["ids_checksum"] for r in res)) == gold["user_source_ids_checksum"]
     assert sum(r["ntb"] for r in res) == gold["ntarget_boxes"]       # every target box: exactly one rank
-    allg = torch.arange(nglobal, device=dev, dtype=torch.int64)
-    got = {k: fs.rows_sum(torch, allg, acc[k]) for k in names}
+    got = merger.sums()
     want = {"colleagues": gold["colleagues"], "list1": gold["list1"], "list2": gold["list2"],
             "list4": gold["list4"], **{f"list3[{lev}]": v for lev, v in enumerate(gold["list3"])}}
     assert got == want, fs.diff(got, want)
