@@ -368,10 +368,22 @@ def main():
         # timing can never silently be of the other implementation)
         from boxtree_amd.distributed import native as nat
         native_comm = nat.rccl_comm(actx, dist)
+    elif (distributed and shared_gpu and backend == "gloo" and native_kw_ok and world > 1
+            and os.environ.get("BOXTREE_HIP_NATIVE_MGPU", "1") != "0"):
+        # ranks that share a GPU (a test setup): the same bt_mgpu_* entries over the library's
+        # shared-memory communicator -- every byte crosses the host, nothing here is a scaling
+        # measurement, but it is the N > 1 code path and not its torch twin
+        from boxtree_amd.distributed import native as nat
+        box = [f"/bt_bench_{os.getpid()}" if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        native_comm = nat.shm_comm(box[0], rank, world)
     # which implementation of the sharded build this job times (config.sharded_impl)
     sharded_impl = None
     if distributed:
-        sharded_impl = "bt_mgpu" if native_comm is not None else "torch"
+        sharded_impl = "torch"
+        if native_comm is not None:
+            sharded_impl = "bt_mgpu" + (" over its shared-memory communicator (ranks share a GPU)"
+                                        if native_comm.kind == "processes" else "")
 
     stage_acc: dict[str, float] = {}
     sort_ms = []

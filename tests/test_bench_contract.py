@@ -125,12 +125,15 @@ def test_bench_without_gpu_fails_loudly():
 def test_bench_gpus_2_real_processes_one_gpu():
     """Two REAL rank processes through the whole N > 1 path -- exchange, per-rank build,
     global numbering, local essential tree, lists -- on however many GPUs the box has (one:
-    the ranks share it and talk over gloo, RCCL refuses two ranks on a device).  The global
-    tree of the two shards must be the tree one rank builds from both chunks."""
+    the ranks share it -- RCCL refuses two ranks on a device -- and drive the library's bt_mgpu_*
+    entries over its shared-memory communicator; torch.distributed / gloo only carries the
+    barrier and the statistics).  The global tree of the two shards must be the tree one rank
+    builds from both chunks, and the job must say that it timed the library's implementation."""
     n = 400000
     d = run_bench("--gpus", "2", "--n", str(n), "--steps", "1", "--warmup", "1")
     check_two_ranks(d, n)
     assert d["value"] > 0 and d["steps"] == 1 and "cpu_baseline" not in d
+    assert d["config"]["sharded_impl"].startswith("bt_mgpu")
     import numpy as np
     from boxtree_amd import HIPArrayContext, TreeBuilder
     actx = HIPArrayContext(0)
