@@ -307,7 +307,12 @@ def load():
     # device pointers).  The other order maps /opt/rocm's runtime as well, and the
     # second runtime finds no device.
     import torch  # noqa: F401
-    lib = ct.CDLL(LIB_PATH)
+    _lib = _bind(ct.CDLL(LIB_PATH))
+    return _lib
+
+
+def _bind(lib):
+    """Declare the argument types of every entry (include/boxtree_hip.h) on a loaded image."""
     lib.bt_abi_version.restype = ct.c_int
     lib.bt_last_error_string.restype = ct.c_char_p
     lib.bt_create.argtypes = [ct.c_int, vp, ct.POINTER(vp)]
@@ -400,7 +405,6 @@ def load():
     lib.bt_unpack.argtypes = [vp, ct.c_int, ct.c_int, vp, ct.c_int64, ct.POINTER(vp)]
     if lib.bt_abi_version() != ABI_VERSION:
         raise RuntimeError("libboxtree_hip.so ABI version mismatch")
-    _lib = lib
     return lib
 
 
