@@ -8,6 +8,16 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# BOXTREE_EMU=1: run the tests -- the `-m gpu` ones included -- against tests/emu's CPU emulation of the
+# kernels instead of a GPU (test infrastructure for boxes without one: the kernels' logic against
+# the oracle, nothing about their speed; tests/emu/README.md)
+EMU = os.environ.get("BOXTREE_EMU", "0") == "1"
+if EMU:
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import emu_actx
+    emu_actx.install_for_tests()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     # marks the reference's test files carry (tests/test_reference_suite.py compiles them)

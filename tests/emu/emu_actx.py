@@ -68,3 +68,111 @@ def _make_class():
 
 def EmuArrayContext():          # noqa: N802  (a factory named like the class it returns an instance of)
     return _make_class()()
+
+
+# ---- running the -m gpu tests under emulation (BOXTREE_EMU=1) ----------------------------------------
+
+def _cpu_device(dev):
+    import torch
+    if dev is None:
+        return None
+    if isinstance(dev, str):
+        return "cpu" if dev.startswith("cuda") else dev
+    if isinstance(dev, torch.device):
+        return torch.device("cpu") if dev.type == "cuda" else dev
+    if isinstance(dev, int):
+        return "cpu"
+    return dev
+
+
+def patch_torch():
+    """Process-wide: every request for a "cuda" tensor yields a CPU tensor, and the torch.cuda calls
+    the tests and the Python layer make become no-ops.  (Plain monkeypatches rather than a
+    TorchFunctionMode: the rank threads of the multi-rank tests must see them too.)"""
+    import ctypes as ct_
+    import numpy as np
+    import torch
+    if getattr(torch, "_boxtree_emu_patched", False):
+        return
+    torch._boxtree_emu_patched = True
+
+    def wrap_factory(fn):
+        def inner(*a, **k):
+            if "device" in k:
+                k["device"] = _cpu_device(k["device"])
+            if "generator" in k and k["generator"] is not None:
+                k["generator"] = getattr(k["generator"], "_gen", k["generator"])
+            return fn(*a, **k)
+        inner.__name__ = getattr(fn, "__name__", "factory")
+        return inner
+
+    for name in ("empty", "zeros", "ones", "full", "arange", "rand", "randn", "randint", "tensor",
+                 "empty_like", "zeros_like", "ones_like", "full_like", "linspace", "randperm", "eye"):
+        setattr(torch, name, wrap_factory(getattr(torch, name)))
+
+    real_as_tensor = torch.as_tensor
+
+    def as_tensor(obj, *a, **k):
+        if "device" in k:
+            k["device"] = _cpu_device(k["device"])
+        cai = getattr(obj, "__cuda_array_interface__", None)
+        if cai is not None and not isinstance(obj, torch.Tensor):
+            # a raw "device" pointer handed over by the library: host memory under emulation
+            shape, typestr, ptr = tuple(cai["shape"]), cai["typestr"], int(cai["data"][0])
+            dt = np.dtype(typestr)
+            count = int(np.prod(shape)) if len(shape) else 1
+            if count == 0:
+                return torch.from_numpy(np.zeros(shape, dt))
+            buf = (ct_.c_char * (count * dt.itemsize)).from_address(ptr)
+            return torch.from_numpy(np.frombuffer(buf, dtype=dt, count=count).reshape(shape))
+        return real_as_tensor(obj, *a, **k)
+    torch.as_tensor = as_tensor
+
+    real_to = torch.Tensor.to
+
+    def to(self, *a, **k):
+        a = tuple(_cpu_device(x) if isinstance(x, (str, torch.device)) else x for x in a)
+        if "device" in k:
+            k["device"] = _cpu_device(k["device"])
+        return real_to(self, *a, **k)
+    torch.Tensor.to = to
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.Tensor.is_cuda = property(lambda self: True)
+
+    class Gen:                      # torch.Generator(device="cuda")
+        def __init__(self, device=None):
+            self._gen = real_generator()
+
+        def manual_seed(self, seed):
+            self._gen.manual_seed(seed)
+            return self
+    real_generator = torch.Generator
+    torch.Generator = Gen
+
+    class _Stream:
+        cuda_stream = 0
+    cu = torch.cuda
+    cu.is_available = lambda: True
+    cu.synchronize = lambda *a, **k: None
+    cu.set_device = lambda *a, **k: None
+    cu.current_device = lambda: 0
+    cu.device_count = lambda: 1
+    cu.empty_cache = lambda: None
+    cu.mem_get_info = lambda *a, **k: (8 << 30, 16 << 30)
+    cu.current_stream = lambda *a, **k: _Stream()
+
+
+def install_for_tests():
+    """conftest.py calls this when BOXTREE_EMU=1: the emulated library, CPU tensors for "cuda", and
+    boxtree_amd.HIPArrayContext constructing the emulator's context."""
+    install()
+    patch_torch()
+    from boxtree_amd import array_context
+    emu_cls = _make_class()
+    base = array_context.HIPArrayContext
+
+    def init(self, device=None):
+        emu_cls.__init__(self)
+    base.__init__ = init
+    base.stream = property(lambda self: None)
+    base.sync_in = lambda self: None
