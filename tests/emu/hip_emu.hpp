@@ -40,8 +40,8 @@ extern thread_local ThreadCtx *g_cur;
 // wave-wide exchange: every lane deposits `v`; returns the record of the lanes that met at this
 // call site (mask + their values)
 struct WaveRec { uint64_t mask; uint64_t val[64]; };
-const WaveRec &wave_meet(uint64_t v, const void *site);
-void block_barrier();
+__attribute__((noduplicate, convergent)) const WaveRec &wave_meet(uint64_t v, const void *site);
+__attribute__((noduplicate, convergent)) void block_barrier();
 void spin_yield();
 
 using KernelThunk = void (*)(void *);
@@ -91,28 +91,43 @@ inline void launch(const char *name, dim3 grid, dim3 block, size_t lds, void * /
 }  // namespace emu
 
 // ---- barriers and wave-wide operations ----------------------------------------------------------
-static inline void __syncthreads() { ::emu::block_barrier(); }
-static inline void __threadfence_block() {}
-static inline void __threadfence() {}
-#define __builtin_amdgcn_fence(...) ((void) 0)
-#define __builtin_amdgcn_s_sleep(n) (::emu::spin_yield())
+// Every meeting point is also a compiler barrier: LDS variables are statics of this translation unit
+// whose addresses never leave it, so without one the optimizer would carry their values in
+// registers across a call it can see does not touch them -- across __syncthreads(), that is.
+#define EMU_MEMORY_BARRIER() __asm__ __volatile__("" ::: "memory")
+static inline void __syncthreads() { EMU_MEMORY_BARRIER(); ::emu::block_barrier(); EMU_MEMORY_BARRIER(); }
+static inline void __threadfence_block() { EMU_MEMORY_BARRIER(); }
+static inline void __threadfence() { EMU_MEMORY_BARRIER(); }
+#define __builtin_amdgcn_fence(...) EMU_MEMORY_BARRIER()
+#define __builtin_amdgcn_s_sleep(n) do { EMU_MEMORY_BARRIER(); ::emu::spin_yield(); EMU_MEMORY_BARRIER(); } while (0)
 #define EMU_SITE __builtin_return_address(0)
+// A wave-wide operation is identified by its call site, so the host compiler must not clone a call
+// (jump threading, unrolling, tail duplication) or move it under a branch: the attributes GPU
+// compilers give such operations.
+#define EMU_WAVE_OP __attribute__((noinline, noduplicate, convergent))
+static inline __attribute__((always_inline)) const ::emu::WaveRec &emu_meet_(uint64_t v, const void *site)
+{
+    __asm__ __volatile__("" ::: "memory");
+    const ::emu::WaveRec &r = ::emu::wave_meet(v, site);
+    __asm__ __volatile__("" ::: "memory");
+    return r;
+}
 
-__attribute__((noinline)) static void emu_wave_barrier_() { (void) ::emu::wave_meet(0, EMU_SITE); }
+EMU_WAVE_OP static void emu_wave_barrier_() { (void) emu_meet_(0, EMU_SITE); }
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier_()
 
-__attribute__((noinline)) static uint64_t __ballot(int pred)
+EMU_WAVE_OP static uint64_t __ballot(int pred)
 {
-    const ::emu::WaveRec &r = ::emu::wave_meet(pred ? 1 : 0, EMU_SITE);
+    const ::emu::WaveRec &r = emu_meet_(pred ? 1 : 0, EMU_SITE);
     uint64_t b = 0;
     for (int i = 0; i < 64; ++i) if (((r.mask >> i) & 1) && r.val[i]) b |= 1ull << i;
     return b;
 }
 // v_cmp into a lane mask: cond 33 = ICMP_NE (the only one used)
-__attribute__((noinline)) static uint64_t emu_uicmp_(uint32_t a, uint32_t b, int cond)
+EMU_WAVE_OP static uint64_t emu_uicmp_(uint32_t a, uint32_t b, int cond)
 {
     if (cond != 33) { fprintf(stderr, "emu: uicmp condition %d not modelled\n", cond); abort(); }
-    const ::emu::WaveRec &r = ::emu::wave_meet(a != b ? 1 : 0, EMU_SITE);
+    const ::emu::WaveRec &r = emu_meet_(a != b ? 1 : 0, EMU_SITE);
     uint64_t m = 0;
     for (int i = 0; i < 64; ++i) if (((r.mask >> i) & 1) && r.val[i]) m |= 1ull << i;
     return m;
@@ -123,33 +138,33 @@ template <class T> static inline uint64_t emu_bits_(T v) { uint64_t u = 0; memcp
 template <class T> static inline T emu_unbits_(uint64_t u) { T v; memcpy(&v, &u, sizeof(T)); return v; }
 
 template <class T>
-__attribute__((noinline)) static T __shfl(T v, int src, int width = 64)
+EMU_WAVE_OP static T __shfl(T v, int src, int width = 64)
 {
-    const ::emu::WaveRec &r = ::emu::wave_meet(emu_bits_(v), EMU_SITE);
+    const ::emu::WaveRec &r = emu_meet_(emu_bits_(v), EMU_SITE);
     const int lane = emu_lane(), base = lane / width * width;
     const int j = base + (((src % width) + width) % width);
     return ((r.mask >> j) & 1) ? emu_unbits_<T>(r.val[j]) : v;
 }
 template <class T>
-__attribute__((noinline)) static T __shfl_xor(T v, int m, int width = 64)
+EMU_WAVE_OP static T __shfl_xor(T v, int m, int width = 64)
 {
-    const ::emu::WaveRec &r = ::emu::wave_meet(emu_bits_(v), EMU_SITE);
+    const ::emu::WaveRec &r = emu_meet_(emu_bits_(v), EMU_SITE);
     const int lane = emu_lane(), base = lane / width * width;
     const int j = base + ((lane - base) ^ m);
     return (j < base + width && ((r.mask >> j) & 1)) ? emu_unbits_<T>(r.val[j]) : v;
 }
 template <class T>
-__attribute__((noinline)) static T __shfl_up(T v, unsigned d, int width = 64)
+EMU_WAVE_OP static T __shfl_up(T v, unsigned d, int width = 64)
 {
-    const ::emu::WaveRec &r = ::emu::wave_meet(emu_bits_(v), EMU_SITE);
+    const ::emu::WaveRec &r = emu_meet_(emu_bits_(v), EMU_SITE);
     const int lane = emu_lane(), base = lane / width * width;
     const int j = lane - (int) d;
     return (j >= base && ((r.mask >> j) & 1)) ? emu_unbits_<T>(r.val[j]) : v;
 }
 template <class T>
-__attribute__((noinline)) static T __shfl_down(T v, unsigned d, int width = 64)
+EMU_WAVE_OP static T __shfl_down(T v, unsigned d, int width = 64)
 {
-    const ::emu::WaveRec &r = ::emu::wave_meet(emu_bits_(v), EMU_SITE);
+    const ::emu::WaveRec &r = emu_meet_(emu_bits_(v), EMU_SITE);
     const int lane = emu_lane(), base = lane / width * width;
     const int j = lane + (int) d;
     return (j < base + width && ((r.mask >> j) & 1)) ? emu_unbits_<T>(r.val[j]) : v;
@@ -158,9 +173,9 @@ __attribute__((noinline)) static T __shfl_down(T v, unsigned d, int width = 64)
 // DPP move (v_mov_b32_dpp): the controls used in csrc -- quad_perm, row_shl / row_shr, row_mirror,
 // row_half_mirror, row_bcast:15 / :31.  A lane whose row or bank is masked off, or whose source is
 // out of range or inactive, keeps `old` (bound_ctrl: 0 instead, for an out-of-range source).
-__attribute__((noinline)) static int emu_update_dpp_(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
+EMU_WAVE_OP static int emu_update_dpp_(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl)
 {
-    const ::emu::WaveRec &r = ::emu::wave_meet((uint32_t) src, EMU_SITE);
+    const ::emu::WaveRec &r = emu_meet_((uint32_t) src, EMU_SITE);
     const int lane = emu_lane(), row = lane >> 4, in_row = lane & 15;
     if (!((row_mask >> row) & 1) || !((bank_mask >> (in_row >> 2)) & 1)) return old;
     int j = -1;

@@ -31,6 +31,10 @@ def _rank_main(rank, world, name, n_per, dims, kind, mpb, slot_bytes, q):
     try:
         sys.path.insert(0, HERE)
         sys.path.insert(0, os.path.dirname(HERE))
+        if os.environ.get("BOXTREE_EMU", "0") == "1":      # (tests/emu: this child is not a pytest process)
+            sys.path.insert(0, os.path.join(HERE, "emu"))
+            import emu_actx
+            emu_actx.install_for_tests()
         import torch
         import sharded_sums as ss
         from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
