@@ -1082,6 +1082,321 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
     }
 }
 
+// ---- the first walk of a tree whose targets have extents, 2^d lanes per work item ----------------
+//
+// (BT_WALK_G8=1, an experiment awaiting its measurement: LAB_NOTES.md sections 10-12.)  The kernel
+// above gives a lane a work item and lets it test ONE child of the box it scans per trip; the 64
+// walks of a wave diverge, and what the walk of the 10^8 + 10^7 extent tree is bound by is the
+// issue of vector instructions at 16 of 64 lanes active.  Here a GROUP of C = 2^d lanes owns an
+// item: lane m of the group tests child slot m of the box being scanned, so a scanned box costs the
+// group one trip -- its Kids word and its centre are loaded once for the group -- and a wave makes
+// 64 / C walks whose control flow is uniform within each group.
+//
+// What has to come out the same (the rows feed rows_to_csr_v2_kernel / l3_scatter_v2_kernel and the
+// second walk of the overflowed items unchanged; row layout of RowGroup<true>, G = 1):
+//  * List 3 is kept per source level, and within a level in the order the entries are emitted.  The
+//    one-lane walk emits the entries of level l + 1 when it tests the children of a box of level l,
+//    boxes being scanned in depth-first preorder and children in slot order.  Testing a box's
+//    children all at once keeps exactly that: boxes are still scanned in preorder, a box's children
+//    are appended in slot order (a ballot prefix over the group), and what the subtree of a child
+//    emits lies at deeper levels.
+//  * The close list is ONE list per item, in emission order: child m's entry, then everything the
+//    subtree below m emits, then child m + 1's.  So the children that go to the close list or are
+//    descended into are handled one after the other, in slot order, after the tests: the masks of
+//    both kinds wait on the group's stack.
+//  * List 1 is put into depth-first order afterwards whatever order it is written in.
+// Per-item state (counts, stack, level counters) is uniform over the group: every lane of the
+// group holds the same values, only the child tests and the row stores differ by lane.
+template <class T, int D>
+__global__ __launch_bounds__(256) void walk13_g8_kernel(TravArgs<T, D> a, FastTree ft, V2Walk w)
+{
+    constexpr int C = 1 << D;
+    constexpr int P = V2Dims<D>::P;
+    constexpr int IPB = WALK_THREADS / C;              // items per workgroup
+    const int sub = threadIdx.x % C;                   // the child slot this lane tests
+    const int git = threadIdx.x / C;                   // the group's number in the workgroup
+    const int lane = threadIdx.x & 63;
+    const int gshift = lane & ~(C - 1);                // the group's first lane in its wave
+    const uint32_t gmask = (C == 64) ? ~0u : ((1u << C) - 1u);
+    const int32_t item = blockIdx.x * IPB + git;
+    const int32_t nitems = *w.d_nitems;
+    if (item >= nitems) {
+        if (item < w.items_cap) {
+            // the count arrays are scanned over all their columns
+            for (int l = sub; l < w.nlevels; l += C)
+                if (item < w.lay.ecap[l]) w.l3_cs[w.lay.base[l] + item] = 0;
+            if (sub == 0) {
+                w.l1_cs[item] = 0;
+                if (w.close_cs) w.close_cs[item] = 0;
+                w.overflow[item] = 0;
+                if (w.spill_idx) { w.spill_idx[item] = -1; w.spill_idx[w.items_cap + item] = -1; }
+            }
+        }
+        return;                                        // whole groups drop out together
+    }
+    const int32_t tbn = w.item_tbn[item];
+    const int slot = w.item_slot[item];
+    const int32_t b = a.target_boxes[tbn];
+    const ICell cell = w.cells[b];
+    const int tl = (int) (cell.lf & 0xffu);
+    const uint8_t bflags = (uint8_t) (cell.lf >> 8);
+
+    // rows (tiles of 64 items, entry j of the 64 items of a tile contiguous: RowGroup<true>)
+    const int64_t tile = (int64_t) (item >> 6) * 64;
+    const int tl64 = item & 63;
+    int32_t *row1 = w.row1 + tile * w.K1 + tl64;
+    int32_t *row3 = w.row3 + tile * w.K3 + tl64;
+    int32_t *rowc = w.rowc ? w.rowc + tile * w.Kc + tl64 : nullptr;
+    int n1 = 0, n3 = 0, nc = 0;                        // group-uniform
+    // LDS: per item a stack of {box | masks} pairs and the per-level List-3 counters
+    int32_t *stk = s_walk_lds + git;                   // entry i: stk[(2 i) * IPB], stk[(2 i + 1) * IPB]
+    int32_t *lvl = s_walk_lds + 2 * w.walk_cap * IPB + git;
+    for (int l = sub; l < w.nlevels; l += C) lvl[l * IPB] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    // appends of the group: the lanes with `take` store their value at the list's end, in lane order
+    auto group_bits = [&](bool take) -> uint32_t {
+        return (uint32_t) (__ballot(take) >> gshift) & gmask;
+    };
+    auto append = [&](int32_t *row, int cap, int &n, bool take, int32_t v) {
+        const uint32_t m = group_bits(take);
+        if (take) {
+            const int j = n + __popc(m & ((1u << sub) - 1u));
+            if (j < cap) row[(int64_t) j * 64] = v;
+        }
+        n += __popc(m);
+    };
+    auto append_one = [&](int32_t *row, int cap, int &n, int32_t v) {       // group-uniform value
+        if (sub == 0 && n < cap) row[(int64_t) n * 64] = v;
+        ++n;
+    };
+
+    if (slot < 0) {
+        if (w.flags[0] & BT_BOX_IS_SOURCE_BOX) append_one(row1, w.K1, n1, 0);      // traversal.py:489-495
+        if (tl >= 1 && (bflags & BT_BOX_IS_SOURCE_BOX)) append_one(row1, w.K1, n1, b);
+        // coarser levels: the ancestors and their source-box colleagues (see walk13_v2_kernel); the
+        // group takes C row entries per trip
+        if (tl >= 2) {
+            int32_t anc = a.parent[b];
+            for (int k = tl - 1; k >= 1; --k, anc = a.parent[anc]) {
+                if (w.flags[anc] & BT_BOX_IS_SOURCE_BOX) append_one(row1, w.K1, n1, anc);
+                const uint32_t mask = (1u << (tl - k)) - 1u;
+                const int32_t *srow = w.srccoll_rows + (int64_t) anc * P;
+                const uint32_t smask0 = w.src_bit ? (uint32_t) w.srccoll_cnt[anc] : 0u;
+                const int ns = w.src_bit ? __popc(smask0) : w.srccoll_cnt[anc];
+                for (int i0 = 0; i0 < ns; i0 += C) {
+                    const int ii = i0 + sub;
+                    bool adjacent = ii < ns;
+                    uint32_t e = 0;
+                    if (adjacent) {
+                        int i = ii;
+                        if (w.src_bit) {               // the ii-th set bit of the mask
+                            uint32_t sm = smask0;
+                            for (int q = 0; q < ii; ++q) sm &= sm - 1u;
+                            i = __builtin_ctz(sm);
+                        }
+                        e = (uint32_t) srow[i];
+#pragma unroll
+                        for (int ax = 0; ax < D; ++ax) {
+                            const int o = v2_off(e, ax);
+                            const uint32_t r = cell.c[ax] & mask;
+                            adjacent = adjacent && (o == 0 || (o < 0 ? r == 0u : r == mask));
+                        }
+                    }
+                    append(row1, w.K1, n1, adjacent, (int32_t) (e & w.id_mask));
+                }
+            }
+        }
+    }
+
+    // the box's LAST item reserves the space of the own-subtree block at the end of the box's
+    // list-1 segment
+    const int32_t ncoll = w.coll_cnt[b];
+    int32_t blk_len = 0;
+    if (w.with_blocks) {
+        const bool last_item = slot == SLOT_ALL || slot == ncoll - 1;
+        if (last_item && (bflags & BT_BOX_HAS_SOURCE_CHILD_BOXES)) {
+            const int32_t my_rank = ft.dfs_rank[b];
+            blk_len = ft.src_prefix[my_rank + ft.subtree_size[b]] - ft.src_prefix[my_rank + 1];
+        }
+    }
+
+    // float data of the separation criteria with target extents (traversal.py:757-820)
+    const bool targets_have_extent = a.targets_have_extent;
+    T cen[D], rad[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) { cen[i] = 0; rad[i] = 0; }
+    if (targets_have_extent) {
+        if (a.crit == BT_CRIT_STATIC_LINF || a.crit == BT_CRIT_STATIC_L2) {
+            load_center(a, b, cen);
+            const T stickout_rad = (1 + a.stick_out_factor) * level_to_rad(a.root_extent, tl);
+#pragma unroll
+            for (int i = 0; i < D; ++i) rad[i] = stickout_rad;
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {          // load_true_box_extent, :177-198
+                const T mn = a.tgt_bbox_min[i * a.aligned + b];
+                const T mx = a.tgt_bbox_max[i * a.aligned + b];
+                cen[i] = ((T) 0.5) * (mn + mx);
+                rad[i] = ((T) 0.5) * (mx - mn);
+            }
+        }
+    }
+
+    // colleagues and everything below them
+    int c0 = 0, c1 = ncoll;
+    if (slot >= 0) { c0 = slot; c1 = (slot + 1 < ncoll) ? slot + 1 : ncoll; }
+    else if (slot == SLOT_SELF) c1 = 0;
+    const int32_t *crow = w.coll_rows + (int64_t) b * P;
+    for (int ci = c0; ci < c1; ++ci) {
+        const uint32_t ce = (uint32_t) crow[ci];
+        const int32_t nws = (int32_t) (ce & w.id_mask);
+        const uint8_t cfl = w.flags[nws];
+        // a colleague is adjacent (well_sep_is_n_away == 1)
+        if (cfl & BT_BOX_IS_SOURCE_BOX) append_one(row1, w.K1, n1, nws);
+        if (!(cfl & BT_BOX_HAS_SOURCE_CHILD_BOXES)) continue;
+        int prel[D];
+#pragma unroll
+        for (int ax = 0; ax < D; ++ax) prel[ax] = v2_off(ce, ax);
+        int size = 0;                              // stack entries below the box being scanned
+        int32_t parent = nws;
+        bool fresh = true;                         // `parent` has not been scanned yet
+        uint32_t closem = 0, descm = 0;            // children of `parent` still to take, slot order
+        Kids kd{0u, 0u};
+        T pcen[D];
+#pragma unroll
+        for (int q = 0; q < D; ++q) pcen[q] = 0;
+        while (true) {
+            if (fresh) {
+                // ---- scan `parent`: lane `sub` tests child slot `sub` --------------------------------
+                kd = v2_load_kids(w.child8, parent);
+                if (targets_have_extent) load_center(a, parent, pcen);
+                const bool wb_src = (kd.source() >> sub) & 1u, wb_hsc = (kd.has_src_children() >> sub) & 1u;
+                const int32_t wb = kd.id(sub);          // (used only if the child is there)
+                const int k = size + 1;                 // level of the children minus tl
+                const int wl = tl + k;
+                bool to1 = false, to3 = false, toc = false, desc = false;
+                if (wb_src || wb_hsc) {                 // (set for present children only)
+                    bool in_list_1 = true;
+#pragma unroll
+                    for (int ax = 0; ax < D; ++ax) {
+                        const int r = 2 * prel[ax] + v2_mbit<D>(sub, ax);
+                        in_list_1 = in_list_1 && r >= -1 && r <= (1 << k);
+                    }
+                    if (in_list_1) {
+                        to1 = wb_src;
+                        desc = wb_hsc;
+                    } else {
+                        bool meets = true;
+                        if (targets_have_extent) {
+                            const T source_rad = level_to_rad(a.root_extent, wl);
+                            const T child_rad = source_rad;
+                            if (a.crit == BT_CRIT_STATIC_LINF || a.crit == BT_CRIT_PRECISE_LINF) {
+                                T l_inf = 0;
+#pragma unroll
+                                for (int q = 0; q < D; ++q) {
+                                    const T wcq = v2_mbit<D>(sub, q) ? pcen[q] + child_rad : pcen[q] - child_rad;
+                                    T d = cen[q] - wcq;
+                                    d = (d < 0) ? -d : d;
+                                    const T v = d - rad[q] - source_rad;
+                                    l_inf = (v > l_inf) ? v : l_inf;
+                                }
+                                meets = l_inf >= (2 - 8 * Eps<T>::v) * source_rad;
+                            } else {
+                                T l2sq = 0;
+#pragma unroll
+                                for (int q = 0; q < D; ++q) {
+                                    const T wcq = v2_mbit<D>(sub, q) ? pcen[q] + child_rad : pcen[q] - child_rad;
+                                    const T d = cen[q] - wcq;
+                                    l2sq = l2sq + d * d;
+                                }
+                                const T rhs = sqrt(l2sq) - sqrt((T) D) * rad[0] - source_rad;
+                                meets = ((2 - 8 * Eps<T>::v) * source_rad <= rhs);
+                            }
+                        }
+                        const bool force_close = a.close_lists_exist && a.min_nsources_cumul > 0
+                            && (a.src_counts_cumul[wb] < a.min_nsources_cumul);
+                        if (meets && !force_close) {
+                            to3 = true;
+                        } else if (a.close_lists_exist) {
+                            toc = wb_src;
+                            desc = wb_hsc;
+                        }
+                    }
+                }
+                append(row1, w.K1, n1, to1, wb);
+                {
+                    const uint32_t m3 = group_bits(to3);
+                    if (to3) {
+                        const int j = n3 + __popc(m3 & ((1u << sub) - 1u));
+                        if (j < w.K3) row3[(int64_t) j * 64] = wb | (wl << V2_CODE_SHIFT);
+                    }
+                    const int c3 = __popc(m3);
+                    n3 += c3;
+                    if (sub == 0 && c3) lvl[wl * IPB] += c3;
+                }
+                closem = group_bits(toc);
+                descm = group_bits(desc);
+                fresh = false;
+            }
+            // ---- the children of `parent` that go to the close list or are walked into, in slot order
+            const uint32_t pend = closem | descm;
+            if (pend) {
+                const int m = __builtin_ctz(pend);
+                const int32_t wb = kd.id(m);
+                if ((closem >> m) & 1u) append_one(rowc, w.Kc, nc, wb);
+                closem &= ~(1u << m);
+                if ((descm >> m) & 1u) {
+                    descm &= ~(1u << m);
+                    if (sub == 0) {
+                        stk[(2 * size) * IPB] = parent;
+                        stk[(2 * size + 1) * IPB] = (int32_t) (closem | (descm << 8));
+                    }
+                    ++size;
+#pragma unroll
+                    for (int ax = 0; ax < D; ++ax) prel[ax] = 2 * prel[ax] + v2_mbit<D>(m, ax);
+                    parent = wb;
+                    fresh = true;
+                }
+                continue;
+            }
+            // ---- `parent` is finished: back to the box it was entered from ------------------------
+            if (size == 0) break;
+            --size;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            parent = stk[(2 * size) * IPB];
+            const uint32_t ms = (uint32_t) stk[(2 * size + 1) * IPB];
+            closem = ms & 0xffu; descm = (ms >> 8) & 0xffu;
+#pragma unroll
+            for (int ax = 0; ax < D; ++ax) prel[ax] >>= 1;
+            if (closem | descm) kd = v2_load_kids(w.child8, parent);
+        }
+    }
+
+    // ---- the item's counts ---------------------------------------------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int l = sub; l < w.nlevels; l += C)
+        if (item < w.lay.ecap[l]) w.l3_cs[w.lay.base[l] + item] = lvl[l * IPB];
+    const bool ovf = n1 > w.K1 || n3 > w.K3 || (w.close_cs && nc > w.Kc);
+    if (sub == 0) {
+        w.l1_cs[item] = n1 + blk_len;
+        if (w.close_cs) w.close_cs[item] = nc;
+        w.overflow[item] = ovf ? 1 : 0;
+        if (w.spill_idx) { w.spill_idx[item] = -1; w.spill_idx[w.items_cap + item] = -1; }
+    }
+    // one append per wave (the lanes are together again here)
+    const uint64_t obal = __ballot(ovf && sub == 0);
+    if (obal) {
+        const int leader = __ffsll((long long) obal) - 1;
+        int32_t base = 0;
+        if (lane == leader) base = atomicAdd(w.ovf_count, (int32_t) __popcll(obal));
+        base = __shfl(base, leader, 64);
+        if (ovf && sub == 0) w.ovf_list[base + __popcll(obal & ((1ull << lane) - 1ull))] = item;
+    }
+}
+
 // rows -> final places, one wave per tile of 64 items: a lane reads entry j of its own
 // item (the wave reads 256 contiguous bytes) and writes it to the item's CSR segment
 template <int G /* entries per group of the rows, see V2Emit */>
