@@ -1632,11 +1632,12 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     // (an experiment, off by default: 2^d lanes per item, see walk13_g8_kernel)
     static const bool walk_g8 = [] { const char *e = getenv("BT_WALK_G8"); return e && atoi(e); }();
     if (a.targets_have_extent) {
-        if (walk_g8) walk13_g8_kernel<T, D><<<(unsigned) div_up(items_cap, WALK_THREADS >> D), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
+        if (walk_g8) walk13_g8_kernel<T, D, true><<<(unsigned) div_up(items_cap, WALK_THREADS >> D), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
         else if (walk_two_pass) walk13_v2_kernel<T, D, true, true, true><<<nblk(items_cap), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
         else walk13_v2_kernel<T, D, true, true><<<nblk(items_cap), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
     } else {
-        if (walk_two_pass) walk13_v2_kernel<T, D, true, false, true><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
+        if (walk_g8) walk13_g8_kernel<T, D, false><<<(unsigned) div_up(items_cap, WALK_THREADS >> D), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
+        else if (walk_two_pass) walk13_v2_kernel<T, D, true, false, true><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
         else walk13_v2_kernel<T, D, true, false><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
     }
     BT_CHECK(tmark(ctx, st, "trav:walk (rows)"));

@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
     }
 }
 
-// ---- the first walk of a tree whose targets have extents, 2^d lanes per work item ----------------
+// ---- the first walk with 2^d lanes per work item -------------------------------------------------
 //
 // (BT_WALK_G8=1, an experiment awaiting its measurement: LAB_NOTES.md sections 10-12.)  The kernel
 // above gives a lane a work item and lets it test ONE child of the box it scans per trip; the 64
@@ -1093,7 +1093,8 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
 // 64 / C walks whose control flow is uniform within each group.
 //
 // What has to come out the same (the rows feed rows_to_csr_v2_kernel / l3_scatter_v2_kernel and the
-// second walk of the overflowed items unchanged; row layout of RowGroup<true>, G = 1):
+// second walk of the overflowed items unchanged; an item whose lists outgrow its rows is walked
+// again -- no spill chunks here):
 //  * List 3 is kept per source level, and within a level in the order the entries are emitted.  The
 //    one-lane walk emits the entries of level l + 1 when it tests the children of a box of level l,
 //    boxes being scanned in depth-first preorder and children in slot order.  Testing a box's
@@ -1107,10 +1108,11 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
 //  * List 1 is put into depth-first order afterwards whatever order it is written in.
 // Per-item state (counts, stack, level counters) is uniform over the group: every lane of the
 // group holds the same values, only the child tests and the row stores differ by lane.
-template <class T, int D>
+template <class T, int D, bool TEXT>
 __global__ __launch_bounds__(256) void walk13_g8_kernel(TravArgs<T, D> a, FastTree ft, V2Walk w)
 {
     constexpr int C = 1 << D;
+    constexpr int G = RowGroup<TEXT>::G;               // entries per group of the rows (V2Emit)
     constexpr int P = V2Dims<D>::P;
     constexpr int IPB = WALK_THREADS / C;              // items per workgroup
     const int sub = threadIdx.x % C;                   // the child slot this lane tests
@@ -1141,12 +1143,13 @@ __global__ __launch_bounds__(256) void walk13_g8_kernel(TravArgs<T, D> a, FastTr
     const int tl = (int) (cell.lf & 0xffu);
     const uint8_t bflags = (uint8_t) (cell.lf >> 8);
 
-    // rows (tiles of 64 items, entry j of the 64 items of a tile contiguous: RowGroup<true>)
+    // rows: tiles of 64 items, entry j of item t of a tile at (j / G) * 64 * G + t * G + j % G (V2Emit)
     const int64_t tile = (int64_t) (item >> 6) * 64;
     const int tl64 = item & 63;
-    int32_t *row1 = w.row1 + tile * w.K1 + tl64;
-    int32_t *row3 = w.row3 + tile * w.K3 + tl64;
-    int32_t *rowc = w.rowc ? w.rowc + tile * w.Kc + tl64 : nullptr;
+    int32_t *row1 = w.row1 + tile * w.K1 + tl64 * G;
+    int32_t *row3 = w.row3 + tile * w.K3 + tl64 * G;
+    int32_t *rowc = w.rowc ? w.rowc + tile * w.Kc + tl64 * G : nullptr;
+    auto slot_of = [](int j) -> int64_t { return (int64_t) (j / G) * (64 * G) + (j % G); };
     int n1 = 0, n3 = 0, nc = 0;                        // group-uniform
     // LDS: per item a stack of {box | masks} pairs and the per-level List-3 counters
     int32_t *stk = s_walk_lds + git;                   // entry i: stk[(2 i) * IPB], stk[(2 i + 1) * IPB]
@@ -1163,12 +1166,12 @@ __global__ __launch_bounds__(256) void walk13_g8_kernel(TravArgs<T, D> a, FastTr
         const uint32_t m = group_bits(take);
         if (take) {
             const int j = n + __popc(m & ((1u << sub) - 1u));
-            if (j < cap) row[(int64_t) j * 64] = v;
+            if (j < cap) row[slot_of(j)] = v;
         }
         n += __popc(m);
     };
     auto append_one = [&](int32_t *row, int cap, int &n, int32_t v) {       // group-uniform value
-        if (sub == 0 && n < cap) row[(int64_t) n * 64] = v;
+        if (sub == 0 && n < cap) row[slot_of(n)] = v;
         ++n;
     };
 
@@ -1223,7 +1226,7 @@ __global__ __launch_bounds__(256) void walk13_g8_kernel(TravArgs<T, D> a, FastTr
     }
 
     // float data of the separation criteria with target extents (traversal.py:757-820)
-    const bool targets_have_extent = a.targets_have_extent;
+    const bool targets_have_extent = TEXT && a.targets_have_extent;
     T cen[D], rad[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) { cen[i] = 0; rad[i] = 0; }
@@ -1330,7 +1333,7 @@ __global__ __launch_bounds__(256) void walk13_g8_kernel(TravArgs<T, D> a, FastTr
                     const uint32_t m3 = group_bits(to3);
                     if (to3) {
                         const int j = n3 + __popc(m3 & ((1u << sub) - 1u));
-                        if (j < w.K3) row3[(int64_t) j * 64] = wb | (wl << V2_CODE_SHIFT);
+                        if (j < w.K3) row3[slot_of(j)] = wb | (wl << V2_CODE_SHIFT);
                     }
                     const int c3 = __popc(m3);
                     n3 += c3;

@@ -9,6 +9,12 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# BOXTREE_EMU=1: against the CPU emulation of the kernels (tests/emu/README.md) instead of a GPU
+if os.environ.get("BOXTREE_EMU", "0") == "1":
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import emu_actx
+    emu_actx.install_for_tests()
 import numpy as np  # noqa: E402
 
 from test_gpu_mgpu_identity import check_identity  # noqa: E402

@@ -14,6 +14,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+# BOXTREE_EMU=1: against the CPU emulation of the kernels (tests/emu/README.md) instead of a GPU
+if os.environ.get("BOXTREE_EMU", "0") == "1":
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import emu_actx
+    emu_actx.install_for_tests()
 from test_gpu_parity import check_multi_rank_let  # noqa: E402
 
 n, first = (int(sys.argv[1]) if len(sys.argv) > 1 else 40), (int(sys.argv[2]) if len(sys.argv) > 2 else 0)
