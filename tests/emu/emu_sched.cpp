@@ -182,6 +182,28 @@ static void on_segv(int sig, siginfo_t *si, void *)
     _exit(139);
 }
 
+static int order_mode()
+{
+    static const int m = [] {
+        const char *e = getenv("EMU_ORDER");
+        if (!e) return 0;
+        if (!strcmp(e, "reverse")) return 1;
+        if (!strncmp(e, "shuffle", 7)) return 2;
+        return 0;
+    }();
+    return m;
+}
+static uint64_t order_next()
+{
+    static thread_local uint64_t x = [] {
+        const char *e = getenv("EMU_ORDER");
+        const char *c = e ? strchr(e, ':') : nullptr;
+        return (uint64_t) (c ? atoll(c + 1) : 1) * 0x9E3779B97F4A7C15ull + 12345u;
+    }();
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    return x;
+}
+
 void trace_launch(const char *name, dim3 grid, dim3 block, size_t lds)
 {
     static const bool on = [] {
@@ -235,10 +257,20 @@ void run_grid(dim3 grid, dim3 block, size_t dyn_lds_bytes, KernelThunk fn, void 
         uint64_t idle_passes = 0;
         while (done < nthreads) {
             bool progress = false;
-            for (unsigned w = 0; w < nwaves; ++w) {
+            for (unsigned wi = 0; wi < nwaves; ++wi) {
+                // EMU_ORDER=reverse | shuffle: the order in which the waves of a workgroup, and the
+                // lanes of a wave, get their turn between two meeting points -- nothing a correct
+                // kernel may depend on
+                unsigned w = wi;
+                if (order_mode() == 1) w = nwaves - 1 - wi;
+                else if (order_mode() == 2) w = (wi + (unsigned) (order_next() % nwaves)) % nwaves;
                 const unsigned lo = w * 64, hi = std::min(nthreads, lo + 64);
                 for (;;) {
-                    for (unsigned t = lo; t < hi; ++t) {
+                    const unsigned rot = order_mode() == 2 ? (unsigned) (order_next() & 63u) : 0u;
+                    for (unsigned ti = 0; ti < hi - lo; ++ti) {
+                        unsigned t = lo + ti;
+                        if (order_mode() == 1) t = hi - 1 - ti;
+                        else if (order_mode() == 2) t = lo + (ti + rot) % (hi - lo);
                         Fiber &f = s.fibers[t];
                         if (f.st != RUN) continue;
                         f.spun = false;
