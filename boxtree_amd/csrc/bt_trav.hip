@@ -1630,13 +1630,16 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
     // (with target extents the centre of the box being scanned has an LDS column as well)
     const size_t cen_lds = (size_t) D * sizeof(T) * WALK_THREADS;
     // (an experiment, off by default: 2^d lanes per item, see walk13_g8_kernel)
-    static const bool walk_g8 = [] { const char *e = getenv("BT_WALK_G8"); return e && atoi(e); }();
+    // (1: rows as the one-lane walk lays them out; 2: item-major rows, which the row readers follow)
+    static const int walk_g8 = [] { const char *e = getenv("BT_WALK_G8"); return e ? atoi(e) : 0; }();
     if (a.targets_have_extent) {
-        if (walk_g8) walk13_g8_kernel<T, D, true><<<(unsigned) div_up(items_cap, WALK_THREADS >> D), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
+        if (walk_g8 == 2) walk13_g8_kernel<T, D, true, true><<<(unsigned) div_up(items_cap, WALK_THREADS >> D), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
+        else if (walk_g8) walk13_g8_kernel<T, D, true, false><<<(unsigned) div_up(items_cap, WALK_THREADS >> D), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
         else if (walk_two_pass) walk13_v2_kernel<T, D, true, true, true><<<nblk(items_cap), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
         else walk13_v2_kernel<T, D, true, true><<<nblk(items_cap), 256, walk_lds + lvl_lds + cen_lds, ctx->stream>>>(a, ft, w);
     } else {
-        if (walk_g8) walk13_g8_kernel<T, D, false><<<(unsigned) div_up(items_cap, WALK_THREADS >> D), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
+        if (walk_g8 == 2) walk13_g8_kernel<T, D, false, true><<<(unsigned) div_up(items_cap, WALK_THREADS >> D), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
+        else if (walk_g8) walk13_g8_kernel<T, D, false, false><<<(unsigned) div_up(items_cap, WALK_THREADS >> D), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
         else if (walk_two_pass) walk13_v2_kernel<T, D, true, false, true><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
         else walk13_v2_kernel<T, D, true, false><<<nblk(items_cap), 256, walk_lds + lvl_lds, ctx->stream>>>(a, ft, w);
     }
@@ -1791,17 +1794,24 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
 
     BT_CHECK(place_list(ctx, st, c1.lists, c1.total, pk ? &pk->neighbor_source_boxes_lists : nullptr));
     BT_CHECK(place_list(ctx, st, st->l3_lists, total3, pk ? &pk->from_sep_smaller_lists[0] : nullptr));
-    // (the rows' layout follows the walk kernel that wrote them: RowGroup)
-    if (a.targets_have_extent)
+    // (the rows' layout follows the walk kernel that wrote them: RowGroup, or item-major)
+    const bool rows_im = walk_g8 == 2;
+    const int32_t *sp1_idx = spill_idx.get() ? spill_idx.get() + items_cap : nullptr;
+    if (rows_im)
+        rows_to_csr_v2_kernel<1, true><<<nblk(items_cap), 256, 0, ctx->stream>>>(
+            d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, 0, c1.lists.get(), sp1_idx, spill3.get());
+    else if (a.targets_have_extent)
         rows_to_csr_v2_kernel<1><<<nblk(items_cap), 256, 0, ctx->stream>>>(
-            d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, 0, c1.lists.get(),
-            spill_idx.get() ? spill_idx.get() + items_cap : nullptr, spill3.get());
+            d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, 0, c1.lists.get(), sp1_idx, spill3.get());
     else
         rows_to_csr_v2_kernel<4><<<nblk(items_cap), 256, 0, ctx->stream>>>(
-            d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, 0, c1.lists.get(),
-            spill_idx.get() ? spill_idx.get() + items_cap : nullptr, spill3.get());
+            d_nitems, overflow.get(), row1.get(), K1, l1_item.get(), nullptr, 0, c1.lists.get(), sp1_idx, spill3.get());
     if (total3 > 0) {
-        if (a.targets_have_extent)
+        if (rows_im)
+            l3_scatter_v2_kernel<1, true><<<nblk(items_cap), 256, lvl_lds, ctx->stream>>>(
+                d_nitems, lay, nlevels, overflow.get(), row3.get(), K3,
+                l3_item.get(), st->l3_lists.get(), spill_idx.get(), spill3.get());
+        else if (a.targets_have_extent)
             l3_scatter_v2_kernel<1><<<nblk(items_cap), 256, lvl_lds, ctx->stream>>>(
                 d_nitems, lay, nlevels, overflow.get(), row3.get(), K3,
                 l3_item.get(), st->l3_lists.get(), spill_idx.get(), spill3.get());
@@ -1814,7 +1824,10 @@ int fast_lists_v2(bt_context *ctx, TravState *st, TravArgs<T, D> &a)
         BT_CHECK(place_list(ctx, st, cs.lists, cs.total, pk ? &pk->from_sep_close_smaller_lists : nullptr));
         if (cs.total > 0)
         {
-            if (a.targets_have_extent)
+            if (rows_im)
+                rows_to_csr_v2_kernel<1, true><<<nblk(items_cap), 256, 0, ctx->stream>>>(
+                    d_nitems, overflow.get(), rowc.get(), Kc, close_item.get(), nullptr, 0, cs.lists.get());
+            else if (a.targets_have_extent)
                 rows_to_csr_v2_kernel<1><<<nblk(items_cap), 256, 0, ctx->stream>>>(
                     d_nitems, overflow.get(), rowc.get(), Kc, close_item.get(), nullptr, 0, cs.lists.get());
             else

@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
 //  * List 1 is put into depth-first order afterwards whatever order it is written in.
 // Per-item state (counts, stack, level counters) is uniform over the group: every lane of the
 // group holds the same values, only the child tests and the row stores differ by lane.
-template <class T, int D, bool TEXT>
+template <class T, int D, bool TEXT, bool IM /* item-major rows: a group's entries are neighbours */>
 __global__ __launch_bounds__(256) void walk13_g8_kernel(TravArgs<T, D> a, FastTree ft, V2Walk w)
 {
     constexpr int C = 1 << D;
@@ -1146,10 +1146,10 @@ __global__ __launch_bounds__(256) void walk13_g8_kernel(TravArgs<T, D> a, FastTr
     // rows: tiles of 64 items, entry j of item t of a tile at (j / G) * 64 * G + t * G + j % G (V2Emit)
     const int64_t tile = (int64_t) (item >> 6) * 64;
     const int tl64 = item & 63;
-    int32_t *row1 = w.row1 + tile * w.K1 + tl64 * G;
-    int32_t *row3 = w.row3 + tile * w.K3 + tl64 * G;
-    int32_t *rowc = w.rowc ? w.rowc + tile * w.Kc + tl64 * G : nullptr;
-    auto slot_of = [](int j) -> int64_t { return (int64_t) (j / G) * (64 * G) + (j % G); };
+    int32_t *row1 = IM ? w.row1 + (int64_t) item * w.K1 : w.row1 + tile * w.K1 + tl64 * G;
+    int32_t *row3 = IM ? w.row3 + (int64_t) item * w.K3 : w.row3 + tile * w.K3 + tl64 * G;
+    int32_t *rowc = !w.rowc ? nullptr : IM ? w.rowc + (int64_t) item * w.Kc : w.rowc + tile * w.Kc + tl64 * G;
+    auto slot_of = [](int j) -> int64_t { return IM ? (int64_t) j : (int64_t) (j / G) * (64 * G) + (j % G); };
     int n1 = 0, n3 = 0, nc = 0;                        // group-uniform
     // LDS: per item a stack of {box | masks} pairs and the per-level List-3 counters
     int32_t *stk = s_walk_lds + git;                   // entry i: stk[(2 i) * IPB], stk[(2 i + 1) * IPB]
@@ -1267,13 +1267,15 @@ __global__ __launch_bounds__(256) void walk13_g8_kernel(TravArgs<T, D> a, FastTr
         bool fresh = true;                         // `parent` has not been scanned yet
         uint32_t closem = 0, descm = 0;            // children of `parent` still to take, slot order
         Kids kd{0u, 0u};
-        T pcen[D];
-#pragma unroll
-        for (int q = 0; q < D; ++q) pcen[q] = 0;
         while (true) {
             if (fresh) {
                 // ---- scan `parent`: lane `sub` tests child slot `sub` --------------------------------
                 kd = v2_load_kids(w.child8, parent);
+                // (the centre of the box being scanned is needed here only: the tree is a lattice on
+                // this path, a child's centre is the parent's +/- the radius of its level, bit for bit)
+                T pcen[D];
+#pragma unroll
+                for (int q = 0; q < D; ++q) pcen[q] = 0;
                 if (targets_have_extent) load_center(a, parent, pcen);
                 const bool wb_src = (kd.source() >> sub) & 1u, wb_hsc = (kd.has_src_children() >> sub) & 1u;
                 const int32_t wb = kd.id(sub);          // (used only if the child is there)
@@ -1402,7 +1404,8 @@ __global__ __launch_bounds__(256) void walk13_g8_kernel(TravArgs<T, D> a, FastTr
 
 // rows -> final places, one wave per tile of 64 items: a lane reads entry j of its own
 // item (the wave reads 256 contiguous bytes) and writes it to the item's CSR segment
-template <int G /* entries per group of the rows, see V2Emit */>
+// IM: the rows are item-major (entry j of item t at t * K + j: what walk13_g8_kernel<..., true> writes)
+template <int G /* entries per group of the rows, see V2Emit */, bool IM = false>
 __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_nitems,
         const uint8_t *overflow, const int32_t *rows, int K, const int32_t *starts,
         const int32_t *translate /* entries are indices into this table, or null */,
@@ -1421,13 +1424,25 @@ __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_ni
         const int o = __shfl_xor(nmax, off, 64);
         nmax = o > nmax ? o : nmax;
     }
-    const int32_t *row = rows + (int64_t) (item >> 6) * 64 * K + (item & 63) * G;
+    const int32_t *row = IM ? rows + (int64_t) item * K : rows + (int64_t) (item >> 6) * 64 * K + (item & 63) * G;
     // eight loads in flight per lane: one load and one store per trip made every trip wait
     // for its load (the stores may alias the rows as far as the compiler knows)
     constexpr int UNR = 8;
     for (int j0 = 0; j0 < nmax; j0 += UNR) {
         int32_t v[UNR];
-        if (G == 1) {
+        if (IM) {
+#pragma unroll
+            for (int u = 0; u < UNR; u += 4) {
+                PackedI4 g{0, 0, 0, 0};
+                if (j0 + u + 4 <= K) { if (j0 + u < n) g = *reinterpret_cast<const PackedI4 *>(row + j0 + u); }
+                else {                                  // (a row that is not a whole number of groups)
+                    if (j0 + u < n) g.x = row[j0 + u];
+                    if (j0 + u + 1 < n) g.y = row[j0 + u + 1];
+                    if (j0 + u + 2 < n) g.z = row[j0 + u + 2];
+                }
+                v[u] = g.x; v[u + 1] = g.y; v[u + 2] = g.z; v[u + 3] = g.w;
+            }
+        } else if (G == 1) {
 #pragma unroll
             for (int u = 0; u < UNR; ++u) v[u] = (j0 + u < n) ? row[(int64_t) (j0 + u) * 64] : 0;
         } else {
@@ -1470,7 +1485,7 @@ __global__ __launch_bounds__(256) void rows_to_csr_v2_kernel(const int32_t *d_ni
 }
 
 // list 3: rows -> per-level lists (cursors start at the item's per-level starts)
-template <int G /* entries per group of the rows, see V2Emit */>
+template <int G /* entries per group of the rows, see V2Emit */, bool IM = false /* item-major rows */>
 __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nitems, L3Layout lay,
         int nlevels, const uint8_t *overflow, const int32_t *row3, int K3,
         const int32_t *l3_item_starts, int32_t *l3_lists, const int32_t *spill_idx,
@@ -1488,7 +1503,7 @@ __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nit
         }
         cur[l * WALK_THREADS] = s;
     }
-    const int32_t *row = row3 + (int64_t) (item >> 6) * 64 * K3 + (item & 63) * G;
+    const int32_t *row = IM ? row3 + (int64_t) item * K3 : row3 + (int64_t) (item >> 6) * 64 * K3 + (item & 63) * G;
     constexpr int UNR = 8;                 // loads in flight per lane (see rows_to_csr_v2_kernel)
     const int n_all = n;
     n = n < K3 ? n : K3;                   // the rest is in the item's spill chunk
@@ -1496,7 +1511,19 @@ __global__ __launch_bounds__(256) void l3_scatter_v2_kernel(const int32_t *d_nit
         int32_t v[UNR];
         int lev[UNR];
         int32_t raw[UNR];
-        if (G == 1) {
+        if (IM) {
+#pragma unroll
+            for (int u = 0; u < UNR; u += 4) {
+                PackedI4 g{0, 0, 0, 0};
+                if (j0 + u + 4 <= K3) { if (j0 + u < n) g = *reinterpret_cast<const PackedI4 *>(row + j0 + u); }
+                else {
+                    if (j0 + u < n) g.x = row[j0 + u];
+                    if (j0 + u + 1 < n) g.y = row[j0 + u + 1];
+                    if (j0 + u + 2 < n) g.z = row[j0 + u + 2];
+                }
+                raw[u] = g.x; raw[u + 1] = g.y; raw[u + 2] = g.z; raw[u + 3] = g.w;
+            }
+        } else if (G == 1) {
 #pragma unroll
             for (int u = 0; u < UNR; ++u) raw[u] = (j0 + u < n) ? row[(int64_t) (j0 + u) * 64] : 0;
         } else {

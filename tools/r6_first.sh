@@ -56,7 +56,7 @@ cat $OUT/ab_level_to_rad.txt | cut -c1-300
 # the walk variants: default, two passes over the colleagues, 2^d lanes per item -- alternating
 {
 for rep in 1 2 3; do
-  for var in "BT_WALK_G8=0" "BT_WALK_TWO_PASS=1" "BT_WALK_G8=1"; do
+  for var in "BT_WALK_G8=0" "BT_WALK_TWO_PASS=1" "BT_WALK_G8=1" "BT_WALK_G8=2"; do
     bash tools/stage_times.sh "c4 c3 c5" $var 2>&1 | cut -c1-420
   done
 done
@@ -64,10 +64,12 @@ done
 cat $OUT/ab_walk_variants.txt | cut -c1-300
 BT_WALK_TWO_PASS=1 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_configs.py -q > $OUT/pytest_two_pass.txt 2>&1
 echo "pytest two-pass rc=$?"; tail -2 $OUT/pytest_two_pass.txt
-BT_WALK_G8=1 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_configs.py tests/test_gpu_mgpu_extents.py -q > $OUT/pytest_walk_g8.txt 2>&1
-echo "pytest walk-g8 rc=$?"; tail -2 $OUT/pytest_walk_g8.txt
+for g8 in 1 2; do
+  BT_WALK_G8=$g8 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_configs.py tests/test_gpu_mgpu_extents.py -q > $OUT/pytest_walk_g8_$g8.txt 2>&1
+  echo "pytest walk-g8=$g8 rc=$?"; tail -2 $OUT/pytest_walk_g8_$g8.txt
+done
 # walk kernels alone under rocprofv3 (c4: the extent-tree walk), default against 2^d lanes per item
-for g8 in 0 1; do
+for g8 in 0 1 2; do
   (cd /tmp && BT_WALK_G8=$g8 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/wg8_$g8 -o p -- python $GRAFT_REPO_ROOT/bench.py --workload c4 --steps 5 --warmup 2 --cpu-sample 0 > /tmp/wg8_$g8.log 2>&1)
   DB=$(find /tmp/wg8_$g8 -name '*.db' | head -1)
   [ -n "$DB" ] && python tools/rocpd_stats.py $DB $OUT/c4_kernel_stats_walk_g8_$g8.csv && grep -i "walk13\|rows_to_csr\|l3_scatter" $OUT/c4_kernel_stats_walk_g8_$g8.csv | cut -c1-200
