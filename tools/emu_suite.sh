@@ -15,7 +15,7 @@ while read -r id _; do
 done < tests/emu/needs_hardware.txt
 {
   echo "# BOXTREE_EMU=1 python -m pytest tests -m gpu -n 7 --timeout ${EMU_TIMEOUT:-900} (minus tests/emu/needs_hardware.txt) $*"
-  echo "# switches in the environment: $(env | grep '^BT_' | tr '\n' ' ')"
+  echo "# switches in the environment: $(env | grep '^BT_\|^EMU_' | tr '\n' ' ')"
   echo "# HEAD $(git rev-parse --short HEAD)  $(date -u +%Y-%m-%dT%H:%MZ)  host: $(nproc) cores, no GPU"
   echo "# not run under emulation (tests/emu/needs_hardware.txt):"
   grep -v "^#" tests/emu/needs_hardware.txt | sed 's/^/#   /'
