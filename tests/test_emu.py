@@ -20,17 +20,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SELECTION = [
     "tests/test_gpu_parity.py::test_radix_sort_u64_keys[bits0-8193]",
     "tests/test_gpu_parity.py::test_radix_sort_u64[bits2-100003]",
-    "tests/test_gpu_parity.py::test_packed_key_build_modes",
-    "tests/test_gpu_parity.py::test_walk_rows_overflow",
+    "tests/test_gpu_parity.py::test_packed_key_build_modes[3-7-2-pairs]",
+    "tests/test_gpu_parity.py::test_walk_rows_overflow[2-30000-6-2-2-1]",
+    "tests/test_gpu_parity.py::test_walk_rows_overflow[2-30000-6-64-3-0]",
     "tests/test_gpu_parity.py::test_colleague_row_families",
     "tests/test_gpu_parity.py::test_extent_tree",
-    "tests/test_gpu_parity.py::test_source_target_tree",
-    "tests/test_gpu_parity.py::test_tree_connectivity",
+    "tests/test_gpu_parity.py::test_tree_connectivity[2-True]",
     "tests/test_gpu_parity.py::test_deep_tree_below_the_key_with_extents",
-    "tests/test_gpu_parity.py::test_multi_rank_native_entries",
-    "tests/test_gpu_parity.py::test_multi_rank_native_entries_extents",
-    "tests/test_gpu_level_restricted.py",
-    "tests/test_gpu_area_query.py",
+    "tests/test_gpu_parity.py::test_multi_rank_native_entries[2-2-normal-1]",
+    "tests/test_gpu_parity.py::test_multi_rank_native_entries[3-3-sphere-1]",
+    "tests/test_gpu_parity.py::test_multi_rank_native_entries_extents[2-2-normal-1-l2]",
+    "tests/test_gpu_level_restricted.py::test_level_restricted_tree",
+    "tests/test_gpu_level_restricted.py::test_level_restricted_targets_extents_weights",
+    "tests/test_gpu_area_query.py::test_peer_lists",
+    "tests/test_gpu_area_query.py::test_area_query_reference_sizes",
     "tests/test_gpu_filters.py",
 ]
 
@@ -52,7 +55,9 @@ def test_emulated_library_builds():
 
 
 def test_parity_cross_section_under_emulation():
-    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-n", "6", "--timeout", "600",
+    """About a minute on 8 cores; the whole suite: tools/emu_suite.sh (16 minutes, 518 tests)."""
+    workers = str(max(1, min(6, len(os.sched_getaffinity(0)) - 1)))
+    cmd = [sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-n", workers, "--timeout", "600",
            "-p", "no:cacheprovider", *SELECTION]
     p = subprocess.run(cmd, cwd=ROOT, env=emu_env(), capture_output=True, text=True, timeout=3000)
     tail = p.stdout[-3000:] + p.stderr[-2000:]
