@@ -110,6 +110,20 @@ def patch_torch():
                  "empty_like", "zeros_like", "ones_like", "full_like", "linspace", "randperm", "eye"):
         setattr(torch, name, wrap_factory(getattr(torch, name)))
 
+    # uninitialised "device" arrays come back poisoned (0xA5 bytes), as the emulator's hipMalloc does:
+    # an output array a kernel does not write completely must not pass because the host allocator
+    # happened to hand out zeros (EMU_POISON=0 switches it off)
+    if os.environ.get("EMU_POISON", "1") != "0":
+        def poisoned(fn):
+            def inner(*a, **k):
+                t = fn(*a, **k)
+                if t.numel() and t.is_contiguous():
+                    t.view(torch.uint8).fill_(0xA5)
+                return t
+            return inner
+        torch.empty = poisoned(torch.empty)
+        torch.empty_like = poisoned(torch.empty_like)
+
     real_as_tensor = torch.as_tensor
 
     def as_tensor(obj, *a, **k):

@@ -361,10 +361,19 @@ static double emu_now_ms()
     using namespace std::chrono;
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
+// Device memory comes back POISONED (0xA5 bytes; EMU_POISON=0: as malloc leaves it): hipMalloc does not
+// clear memory, and fresh pages from the host allocator are zero more often than not -- a kernel
+// that relies on zeros it never wrote would pass here and fail on the hardware.
+static bool emu_poison()
+{
+    static const bool on = [] { const char *e = getenv("EMU_POISON"); return !e || atoi(e); }();
+    return on;
+}
 hipError_t hipMalloc(void **p, size_t n)
 {
     void *q = nullptr;
     if (posix_memalign(&q, 256, n ? n : 1) != 0) return hipErrorOutOfMemory;
+    if (emu_poison()) memset(q, 0xA5, n ? n : 1);
     *p = q;
     return hipSuccess;
 }
