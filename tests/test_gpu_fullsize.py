@@ -95,27 +95,20 @@ def test_full_size_configuration_equals_the_oracle(name):
     release(torch, actx)
 
 
-def test_c5_eight_ranks_lists_sum_to_the_oracle_single_tree():
-    """BASELINE configs[4]'s split over N = 8 at 8 x 15 625 000 points (the largest size whose
-    single-tree lists fit the reference's int32 CSR): eight ranks (threads over the library's local
-    communicator) exchange, build, number globally, assemble their local essential trees and build
-    their lists; per list, the rows every rank built -- box numbers mapped to global ones -- carry
-    the values of the ORACLE's single tree: sum_rows w(box) * sum_k (k + 1) * (entry_k + 1).  Rows
-    that several ranks build (shared top boxes) must agree; a row nobody builds counts as empty."""
+def sharded_lists_against_single_tree(world, n_chunk, mpb, gold):
+    """`world` ranks (threads over the library's local communicator) with the c5 recipe's chunks of
+    n_chunk points: exchange, build, number globally, local essential trees, lists; the ranks' rows,
+    mapped to global box numbers, must add up to *gold* (the single tree's sums, tests/sharded_sums.py;
+    checksums of the tree and of the particle order as in distributed/checksum.py)."""
     import torch
+    import sharded_sums as ss
     from boxtree_amd import FMMTraversalBuilder, HIPArrayContext, TreeBuilder
     from boxtree_amd.distributed import native as nat
     from boxtree_amd.distributed.checksum import particle_order_checksum, tree_checksum, wrap_int64
-    if "c5r8" not in GOLDEN:
-        pytest.skip("no oracle sums for c5r8")
-    gold = GOLDEN["c5r8"]["sharded"]
-    cfg = GOLDEN["c5r8"]["config"]
-    world, n_chunk = cfg["chunks"], cfg["n_chunk"]
     nglobal = gold["nboxes"]
     dev = torch.device("cuda", 0)
     group = nat.LocalGroup(world)
     res, errors = [None] * world, []
-    import sharded_sums as ss
     merger = ss.RowMerger(torch, nglobal, gold["nlevels"], dev)
     merge = threading.Lock()
 
@@ -125,8 +118,8 @@ def test_c5_eight_ranks_lists_sum_to_the_oracle_single_tree():
             comm = group.comm(rank)
             rng = np.random.default_rng(15 + rank)
             mine = [torch.from_numpy(rng.random(n_chunk)).cuda() for _ in range(3)]
-            p2, kw, xs = nat.exchange_particles(actx, comm, mine, cfg["mpb"], own_buffer=True)
-            tree, _ = TreeBuilder(actx)(actx, p2, max_particles_in_box=cfg["mpb"], **kw)
+            p2, kw, xs = nat.exchange_particles(actx, comm, mine, mpb, own_buffer=True)
+            tree, _ = TreeBuilder(actx)(actx, p2, max_particles_in_box=mpb, **kw)
             ids = xs["route"].global_user_source_ids(tree)
             num = nat.number_sharded_tree(actx, comm, tree)
             let, info = nat.build_local_essential_tree(actx, comm, tree, num)
@@ -167,3 +160,37 @@ def test_c5_eight_ranks_lists_sum_to_the_oracle_single_tree():
     want = {"colleagues": gold["colleagues"], "list1": gold["list1"], "list2": gold["list2"],
             "list4": gold["list4"], **{f"list3[{lev}]": v for lev, v in enumerate(gold["list3"])}}
     assert got == want, fs.diff(got, want)
+
+
+def test_c5_eight_ranks_lists_sum_to_the_oracle_single_tree():
+    """BASELINE configs[4]'s split over N = 8 at 8 x 15 625 000 points (the largest size whose
+    single-tree lists fit the reference's int32 CSR): eight ranks (threads over the library's local
+    communicator) exchange, build, number globally, assemble their local essential trees and build
+    their lists; per list, the rows every rank built -- box numbers mapped to global ones -- carry
+    the values of the ORACLE's single tree: sum_rows w(box) * sum_k (k + 1) * (entry_k + 1).  Rows
+    that several ranks build (shared top boxes) must agree; a row nobody builds counts as empty."""
+    if "c5r8" not in GOLDEN:
+        pytest.skip("no oracle sums for c5r8")
+    cfg = GOLDEN["c5r8"]["config"]
+    sharded_lists_against_single_tree(cfg["chunks"], cfg["n_chunk"], cfg["mpb"], GOLDEN["c5r8"]["sharded"])
+
+
+@pytest.mark.parametrize("world,n_chunk", [(8, 60_000), (3, 150_000)])
+def test_sharded_lists_sum_to_the_oracle_single_tree_small(oracle, world, n_chunk):
+    """The same comparison at a size the oracle builds on the spot (and the CPU emulation of the
+    kernels gets through: tests/emu): the sums are made from the oracle's single tree here."""
+    import torch
+    sys_path_golden = os.path.join(HERE, "golden")
+    import sys
+    if sys_path_golden not in sys.path:
+        sys.path.insert(0, sys_path_golden)
+    import make_fullsize_oracle_sums as mk
+    parts = [[], [], []]
+    for g in range(world):
+        rng = np.random.default_rng(15 + g)
+        for ax in range(3):
+            parts[ax].append(rng.random(n_chunk))
+    pts = [np.concatenate(p) for p in parts]
+    otree = oracle.build_tree(pts, max_particles_in_box=64)
+    gold = mk.sharded_sums(torch, otree, oracle.build_traversal(otree))
+    sharded_lists_against_single_tree(world, n_chunk, 64, gold)
