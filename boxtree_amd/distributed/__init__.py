@@ -357,8 +357,19 @@ class ParticleRoute:
             raise ValueError("no separate targets were exchanged")
         st = self._sets[which]
         if st["order"] is None:
+            if st["order_fn"] is None:
+                raise RuntimeError("ParticleRoute.release() was called: the send order is gone")
             st["order"] = st["order_fn"]().long()
+            st["order_fn"] = None          # (the closure holds the cell indices: 4-12 B per particle)
         return st
+
+    def release(self):
+        """Drop what the route keeps of the exchange (the send order, or the cell indices it can be
+        made from on demand: 4-12 bytes per particle of device memory).  For callers that keep the
+        exchange's statistics but never ask who their particles are."""
+        for st in self._sets.values():
+            st["order"] = None
+            st["order_fn"] = None
 
     def n_owned(self, which="sources"):
         return self._get(which)["nrecv"]
