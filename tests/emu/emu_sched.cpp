@@ -50,6 +50,7 @@ emu_switch:
 enum State : uint8_t { RUN, WAIT_WAVE, WAIT_MEM, WAIT_BLOCK, DONE };
 
 constexpr size_t STACK_BYTES = 256 << 10;
+constexpr size_t DYN_LDS_GUARD = 64 << 10;     // behind the dynamic LDS of a launch: accesses there are reported
 
 struct Fiber {
     void *sp = nullptr;
@@ -155,9 +156,19 @@ static inline void lds_access(const void *addr, int kind /* 1 load, 2 store */)
     ThreadCtx *c = g_cur;
     if (!c) return;
     const char *a = (const char *) addr;
-    const bool lds = (a >= __start_emu_lds && a < __stop_emu_lds)
-        || (a >= (const char *) c->dyn_lds && a < (const char *) c->dyn_lds + c->dyn_lds_bytes);
-    if (!lds) return;
+    const char *dyn = (const char *) c->dyn_lds;
+    const bool lds = (a >= __start_emu_lds && a < __stop_emu_lds) || (a >= dyn && a < dyn + c->dyn_lds_bytes);
+    if (!lds) {
+        // an access just behind the dynamic LDS the launch asked for: on the hardware that is another
+        // workgroup's memory or a fault
+        if (a >= dyn + c->dyn_lds_bytes && a < dyn + c->dyn_lds_bytes + DYN_LDS_GUARD) {
+            fprintf(stderr, "emu: thread (%u,%u,%u) of workgroup (%u,%u,%u) touches dynamic LDS at byte %zu, "
+                    "the launch asked for %zu\n", c->tid.x, c->tid.y, c->tid.z, c->bid.x, c->bid.y, c->bid.z,
+                    (size_t) (a - dyn), c->dyn_lds_bytes);
+            abort();
+        }
+        return;
+    }
     if (c->lds_phase != 0 && c->lds_phase != kind) {
         Sched &s = S();
         s.cur->st = WAIT_MEM;
@@ -237,7 +248,7 @@ void run_grid(dim3 grid, dim3 block, size_t dyn_lds_bytes, KernelThunk fn, void 
     if (s.fibers.size() < nthreads) s.fibers.resize(nthreads);
     const unsigned nwaves = (nthreads + 63) / 64;
     if (s.recs.size() < (size_t) nwaves * 64) s.recs.resize((size_t) nwaves * 64);
-    s.dyn.assign(dyn_lds_bytes + 64, 0);
+    s.dyn.assign(dyn_lds_bytes + 64 + DYN_LDS_GUARD, 0);
     void *dyn = (void *) (((uintptr_t) s.dyn.data() + 63) & ~(uintptr_t) 63);
     s.fn = fn; s.arg = arg;
     for (unsigned bz = 0; bz < grid.z; ++bz)
