@@ -54,6 +54,22 @@ def test_emulated_library_builds():
         assert hasattr(emu, name), name
 
 
+def test_emulator_known_answers():
+    """The emulator itself against the documented semantics of what it emulates (shuffles, ballots,
+    DPP controls, mbcnt, bitop3), the lock step of a wave's LDS traffic, a wave-wide operation under
+    a branch the host compiler would like to clone, tickets / spins / dynamic LDS -- in the three
+    orders the scheduler can give waves and lanes their turns in."""
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-j8"], stdout=subprocess.DEVNULL)
+    exe = os.path.join(ROOT, "tests", "emu", "_build", "emu_selftest")
+    for order in (None, "reverse", "shuffle:5"):
+        env = dict(os.environ)
+        env.pop("EMU_ORDER", None)
+        if order:
+            env["EMU_ORDER"] = order
+        p = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+        assert p.returncode == 0 and "emu_selftest: ok" in p.stdout, (order, p.stdout[-2000:], p.stderr[-2000:])
+
+
 def test_parity_cross_section_under_emulation():
     """About a minute on 8 cores; the whole suite: tools/emu_suite.sh (16 minutes, 518 tests)."""
     workers = str(max(1, min(6, len(os.sched_getaffinity(0)) - 1)))
