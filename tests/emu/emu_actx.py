@@ -187,11 +187,34 @@ def patch_torch():
     cu.current_stream = lambda *a, **k: _Stream()
 
 
+RCCL_STUB = os.path.join(HERE, "_build", "librccl.so.1")
+
+
+def patch_rccl(lib):
+    """A one-rank stand-in for RCCL (emu_rccl.cpp, SONAME librccl.so.1): whoever loads torch's
+    librccl.so through ctypes gets it, and so does the library when it is told which image to bind
+    (bt_mgpu_use_rccl_library) or looks for a loaded one by SONAME."""
+    real_cdll = ct.CDLL
+
+    class CDLL(real_cdll):
+        def __init__(self, name, *a, **k):
+            if isinstance(name, str) and os.path.basename(name).startswith(("librccl.so", "libamdhip64.so")):
+                name = RCCL_STUB
+            super().__init__(name, *a, **k)
+    ct.CDLL = CDLL
+    # (torch has the real RCCL in the process already, under the same SONAME: name the stand-in's
+    # image now, before the library binds its entry points, and keep later calls from naming another)
+    use = lib.bt_mgpu_use_rccl_library
+    use(RCCL_STUB.encode())
+    lib.bt_mgpu_use_rccl_library = lambda path: use(RCCL_STUB.encode())
+
+
 def install_for_tests():
     """conftest.py calls this when BOXTREE_EMU=1: the emulated library, CPU tensors for "cuda", and
     boxtree_amd.HIPArrayContext constructing the emulator's context."""
-    install()
+    lib = install()
     patch_torch()
+    patch_rccl(lib)
     from boxtree_amd import array_context
     emu_cls = _make_class()
     base = array_context.HIPArrayContext
