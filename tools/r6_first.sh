@@ -68,9 +68,11 @@ for g8 in 1 2; do
   BT_WALK_G8=$g8 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_configs.py tests/test_gpu_mgpu_extents.py -q > $OUT/pytest_walk_g8_$g8.txt 2>&1
   echo "pytest walk-g8=$g8 rc=$?"; tail -2 $OUT/pytest_walk_g8_$g8.txt
 done
-# walk kernels alone under rocprofv3 (c4: the extent-tree walk), default against 2^d lanes per item
-for g8 in 0 1 2; do
-  (cd /tmp && BT_WALK_G8=$g8 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/wg8_$g8 -o p -- python $GRAFT_REPO_ROOT/bench.py --workload c4 --steps 5 --warmup 2 --cpu-sample 0 > /tmp/wg8_$g8.log 2>&1)
-  DB=$(find /tmp/wg8_$g8 -name '*.db' | head -1)
-  [ -n "$DB" ] && python tools/rocpd_stats.py $DB $OUT/c4_kernel_stats_walk_g8_$g8.csv && grep -i "walk13\|rows_to_csr\|l3_scatter" $OUT/c4_kernel_stats_walk_g8_$g8.csv | cut -c1-200
+# walk kernels alone under rocprofv3: default against 2^d lanes per item in both row layouts
+for WL in c4 c3 c5; do
+  for g8 in 0 1 2; do
+    (cd /tmp && BT_WALK_G8=$g8 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/wg8_${WL}_$g8 -o p -- python $GRAFT_REPO_ROOT/bench.py --workload $WL --steps 5 --warmup 2 --cpu-sample 0 > /tmp/wg8_${WL}_$g8.log 2>&1)
+    DB=$(find /tmp/wg8_${WL}_$g8 -name '*.db' | head -1)
+    [ -n "$DB" ] && python tools/rocpd_stats.py $DB $OUT/${WL}_kernel_stats_walk_g8_$g8.csv && grep -i "walk13\|rows_to_csr\|l3_scatter" $OUT/${WL}_kernel_stats_walk_g8_$g8.csv | cut -c1-200
+  done
 done
