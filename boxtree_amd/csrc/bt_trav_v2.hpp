@@ -1084,7 +1084,8 @@ __global__ __launch_bounds__(256) void walk13_v2_kernel(TravArgs<T, D> a, FastTr
 
 // ---- the first walk with 2^d lanes per work item -------------------------------------------------
 //
-// (BT_WALK_G8=1, an experiment awaiting its measurement: LAB_NOTES.md sections 10-12.)  The kernel
+// (BT_WALK_G8=1 | 2, an experiment awaiting its measurement on a GPU -- its lists equal the oracle's
+// under the CPU emulation of tests/emu, LAB_NOTES.md sections 10-12.)  The kernel
 // above gives a lane a work item and lets it test ONE child of the box it scans per trip; the 64
 // walks of a wave diverge, and what the walk of the 10^8 + 10^7 extent tree is bound by is the
 // issue of vector instructions at 16 of 64 lanes active.  Here a GROUP of C = 2^d lanes owns an
